@@ -1,0 +1,447 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference
+(/root/reference, read-only) in the build container.
+
+This is the only place the reference is executed.  It never travels to the GPU
+box: what is committed is data (captured inputs + the reference's outputs in
+fp32 and, from the same modules switched to .double(), fp64) plus this script.
+
+Import shims: collections.Iterable alias, stub modules
+for gym / Box2D / tensorboardX, sys.dont_write_bytecode.
+
+Usage:  python tools/make_golden.py [--out tests/golden] [--only name]
+"""
+import argparse
+import collections
+import collections.abc
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+collections.Iterable = collections.abc.Iterable
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return type(name, (), {'__init__': lambda self, *a, **k: None})
+
+
+for _m in ['gym', 'gym.spaces', 'gym.utils', 'gym.utils.seeding', 'gym.envs',
+           'gym.envs.classic_control', 'Box2D', 'Box2D.b2', 'tensorboardX']:
+    if _m not in sys.modules:
+        sys.modules[_m] = _Stub(_m)
+sys.path.insert(0, '/root/reference')
+warnings.filterwarnings('ignore')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import prob_mbrl  # noqa: E402,F401
+from prob_mbrl import algorithms, models, utils  # noqa: E402
+from prob_mbrl.envs.cartpole.env import CartpoleReward  # noqa: E402
+from prob_mbrl.envs.double_cartpole.env import DoubleCartpoleReward  # noqa: E402
+from prob_mbrl.envs.pendulum.env import PendulumReward  # noqa: E402
+from prob_mbrl.envs.rendezvous.env import RendezvousReward  # noqa: E402
+
+torch.set_num_threads(1)
+torch.set_flush_denormal(True)
+
+
+# ---------------------------------------------------------------------------
+# reward spec extraction: restate each reference reward module as the generic
+# (angle_dims, C, tip_target, norm, w, Q, R, kind) tuple used by the build.
+# ---------------------------------------------------------------------------
+def expanded_width(D, angle_dims):
+    return D + len(angle_dims)
+
+
+def reward_spec(rew, D):
+    """Return dict of numpy arrays describing `rew` evaluated on D-dim states."""
+    if isinstance(rew, CartpoleReward):
+        adims, l = [2], float(rew.pole_length)
+        De = 5
+        C = np.zeros((2, De))
+        C[0, 0], C[0, 3], C[1, 4] = 1.0, l, -l
+        norm, w, kind = 2 * l, 0.5, 'exp'
+        target = rew.target
+    elif isinstance(rew, PendulumReward):
+        adims, l = [0], float(rew.pole_length)
+        De = 3
+        C = np.zeros((2, De))
+        C[0, 1], C[1, 2] = l, -l
+        norm, w, kind = 2 * l, 0.5, 'exp'
+        target = rew.target
+    elif isinstance(rew, DoubleCartpoleReward):
+        adims = [2, 4]
+        l1, l2 = float(rew.pole1_length), float(rew.pole2_length)
+        De = 8
+        C = np.zeros((2, De))
+        C[0, 0], C[0, 4], C[0, 5] = 1.0, -l1, -l2
+        C[1, 6], C[1, 7] = l1, l2
+        norm, w, kind = 2 * (l1 + l2), 0.5, 'exp'
+        target = rew.target
+    elif isinstance(rew, RendezvousReward):
+        adims = []
+        De = 8
+        C = np.zeros((4, De))
+        for i, (a, b) in enumerate([(0, 2), (1, 3), (4, 6), (5, 7)]):
+            C[i, a], C[i, b] = 1.0, -1.0
+        norm, w, kind = 1.0, 1.0, 'neg'
+        target = torch.zeros(1, 8)
+    else:
+        raise TypeError(rew)
+    targeta = utils.angles.to_complex(target.double(), adims).numpy()
+    tip_target = targeta @ C.T
+    expand = (D != De)
+    assert D == De or D == De - len(adims)
+    return dict(rew_kind=kind, rew_expand=expand,
+                rew_angle_dims=np.array(adims, dtype=np.int64), rew_C=C,
+                rew_tip_target=tip_target.reshape(-1), rew_norm=norm, rew_w=w,
+                rew_Q=rew.Q.detach().double().numpy(),
+                rew_R=rew.R.detach().double().numpy())
+
+
+# ---------------------------------------------------------------------------
+# model construction exactly as examples/deep_pilco_mm.py:117-151
+# ---------------------------------------------------------------------------
+def build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_drop=0.1, dyn_drop=0.1,
+          n_data=300, y_scale=0.01):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dyn_model = models.mlp(
+        D + U, 2 * D, dyn_hid,
+        dropout_layers=[
+            models.modules.CDropout(dyn_drop * np.ones(hid))
+            if dyn_drop > 0 else None for hid in dyn_hid
+        ],
+        nonlin=torch.nn.ReLU)
+    dyn = models.DynamicsModel(dyn_model, reward_func=rew,
+                               output_density=models.DiagGaussianDensity(D)).float()
+    from functools import partial
+    pol_model = models.mlp(
+        D, 2 * U, pol_hid,
+        dropout_layers=[
+            models.modules.BDropout(pol_drop) if pol_drop > 0 else None
+            for hid in pol_hid
+        ],
+        nonlin=torch.nn.ReLU,
+        output_nonlin=partial(models.DiagGaussianDensity, U))
+    maxU_t = np.asarray(maxU, dtype=np.float32).reshape(-1)
+    pol = models.Policy(pol_model, maxU_t, -maxU_t).float()
+    # synthetic dataset -> normalisation buffers (models/core.py:134-152)
+    X = torch.randn(n_data, D + U)
+    Y = y_scale * torch.randn(n_data, D)
+    dyn.set_dataset(X, Y)
+    # random (non-default) dropout logits so the concrete masks are non-trivial
+    return dyn, pol
+
+
+def n_linear(seq):
+    return len([m for m in seq._modules.values()
+                if isinstance(m, torch.nn.Linear)])
+
+
+def capture_inputs(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
+                   z_mm, z_rr, maximize, infer_ns, rew):
+    """Everything the build needs to reproduce the rollout, as float64 numpy
+    (values are exactly representable fp32)."""
+    d = {}
+    f = lambda t: t.detach().double().cpu().numpy()  # noqa: E731
+    D = x0.shape[-1]
+    # policy
+    lin = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    drops = [m for m in pol.model._modules.values()
+             if isinstance(m, models.modules.BDropout)]
+    d['pol_n_layers'] = len(lin)
+    for i, m in enumerate(lin):
+        d['pol_W%d' % i] = f(m.weight)
+        d['pol_b%d' % i] = f(m.bias)
+    scales = []
+    for i in range(len(lin) - 1):
+        if i < len(drops):
+            dr = drops[i]
+            if isinstance(dr, models.modules.CDropout):
+                d['pol_mask%d' % i] = f(dr.concrete_noise)
+                scales.append(1.0)
+            else:
+                d['pol_mask%d' % i] = f(dr.noise)
+                scales.append(float(dr.p))
+        else:
+            d['pol_mask%d' % i] = np.ones((x0.shape[0], lin[i].out_features))
+            scales.append(1.0)
+    d['pol_keep'] = np.array(scales)
+    d['pol_z'] = f(pol.model.fc_nonlin.z)
+    d['pol_scale'] = f(pol.scale).reshape(-1)
+    d['pol_bias'] = f(pol.bias).reshape(-1)
+    d['pol_angle_dims'] = pol.angle_dims.numpy().astype(np.int64)
+    # dynamics
+    lin = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    drops = [m for m in dyn.model._modules.values()
+             if isinstance(m, models.modules.BDropout)]
+    d['dyn_n_layers'] = len(lin)
+    for i, m in enumerate(lin):
+        d['dyn_W%d' % i] = f(m.weight)
+        d['dyn_b%d' % i] = f(m.bias)
+    scales = []
+    for i in range(len(lin) - 1):
+        if i < len(drops):
+            dr = drops[i]
+            if isinstance(dr, models.modules.CDropout):
+                d['dyn_mask%d' % i] = f(dr.concrete_noise)
+                scales.append(1.0)
+            else:
+                d['dyn_mask%d' % i] = f(dr.noise)
+                scales.append(float(dr.p))
+        else:
+            d['dyn_mask%d' % i] = np.ones((x0.shape[0], lin[i].out_features))
+            scales.append(1.0)
+    d['dyn_keep'] = np.array(scales)
+    d['dyn_z'] = f(dyn.output_density.z)
+    for k in ['mx', 'iSx', 'my', 'Sy']:
+        d['dyn_' + k] = f(getattr(dyn, k)).reshape(-1)
+    d['dyn_angle_dims'] = dyn.angle_dims.numpy().astype(np.int64)
+    d.update(reward_spec(rew, D))
+    d['x0'] = f(x0)
+    d['H'] = H
+    d['gamma'] = np.asarray(gamma, dtype=np.float64)
+    d['mm_states'] = bool(mm_states)
+    d['mm_rewards'] = bool(mm_rewards)
+    d['mm_groups'] = int(mm_groups) if mm_groups is not None else 0
+    d['maximize'] = bool(maximize)
+    d['infer_ns'] = bool(infer_ns)
+    if z_mm is not None:
+        d['z_mm'] = f(z_mm)
+        d['z_rr'] = f(z_rr)
+    for k, v in d.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float64:
+            assert np.array_equal(v.astype(np.float32).astype(np.float64), v) \
+                or k.startswith('rew_') or k == 'gamma', k
+    return d
+
+
+def ref_iteration(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
+                  z_mm, z_rr, maximize, infer_ns):
+    """Reference rollout + loss + backward (algorithms/mc_pilco.py:86-197 body)."""
+    pol.zero_grad()
+    dyn.zero_grad()
+    states, actions, rewards = utils.rollout(
+        x0, dyn, pol, H, resample_state_noise=False,
+        resample_action_noise=False, mm_states=mm_states,
+        mm_rewards=mm_rewards, z_mm=z_mm, z_rr=z_rr, mm_groups=mm_groups,
+        infer_noise_variables=infer_ns)
+    disc = torch.stack([r * gamma[i] for i, r in enumerate(rewards)])
+    returns = -disc.sum(0) if maximize else disc.sum(0)
+    loss = returns.mean()
+    loss.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in pol.parameters()])
+    out = dict(states=torch.stack(states).detach().numpy(),
+               actions=torch.stack(actions).detach().numpy(),
+               rewards=torch.stack(rewards).detach().numpy(),
+               loss=float(loss), grad=g.detach().numpy().copy())
+    return out
+
+
+def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
+              mm_groups=None, discount=None, seed=0, infer_ns=False,
+              maximize=True, x0_scale=0.1, P=None):
+    rew = rew_fn()
+    dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
+    dyn.eval()
+    pol.train()
+    torch.manual_seed(seed + 1000)
+    if P is not None:  # particles x samples layout (utils.tile)
+        x0 = utils.tile(x0_scale * torch.randn(P, D), B // P)
+    else:
+        x0 = x0_scale * torch.randn(B, D)
+    x0 = x0 + torch.tensor([0.0] * D)
+    z_mm = torch.randn(H + B, D)
+    z_rr = torch.randn(H + B, 1)
+    gamma = [1.0 / H] * H if discount is None else [discount**i for i in range(H)]
+    kw = dict(mm_states=mm, mm_rewards=mm, mm_groups=mm_groups, z_mm=z_mm,
+              z_rr=z_rr, maximize=maximize, infer_ns=infer_ns)
+    # warm-up: sizes the [B,h] / [B,D] buffers; then redraw at final shape
+    with torch.no_grad():
+        utils.rollout(x0, dyn, pol, 1, resample_state_noise=False,
+                      resample_action_noise=False)
+    seed_t = torch.tensor([seed + 77])
+    dyn.resample(seed=seed_t)
+    pol.resample(seed=seed_t)
+    torch.manual_seed(seed + 5)
+    pol.model.fc_nonlin.z.data = torch.randn_like(pol.model.fc_nonlin.z)
+    d = capture_inputs(dyn, pol, x0, H, gamma, rew=rew, **kw)
+    r32 = ref_iteration(dyn, pol, x0, H, gamma, **kw)
+    r32b = ref_iteration(dyn, pol, x0, H, gamma, **kw)
+    assert np.array_equal(r32['grad'], r32b['grad']), 'reference not deterministic'
+    # fp64 run of the same modules
+    dyn.double()
+    pol.double()
+    rew.double()
+    kw64 = dict(kw, z_mm=z_mm.double(), z_rr=z_rr.double())
+    r64 = ref_iteration(dyn, pol, x0.double(), H, gamma, **kw64)
+    for k, v in r32.items():
+        d['ref32_' + k] = np.asarray(v, dtype=np.float32)
+    for k, v in r64.items():
+        d['ref64_' + k] = np.asarray(v, dtype=np.float64)
+    gerr = np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])
+    print('%-22s B=%d H=%d loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' %
+          (name, B, H, r32['loss'], r64['loss'], gerr))
+    return d
+
+
+def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
+                      mm=False, mm_groups=None, lr=1e-3, clip=1.0, seed=0,
+                      discount=None):
+    """Run the REAL algorithms.mc_pilco for n_iters with a fixed x0 and capture
+    the frozen randomness through a wrapper around utils.rollout."""
+    rew = rew_fn()
+    dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
+    torch.manual_seed(seed + 1000)
+    x0 = 0.1 * torch.randn(B, D)
+    torch.manual_seed(seed + 5)
+    with torch.no_grad():
+        dyn.eval()
+        utils.rollout(x0, dyn, pol, 1, resample_state_noise=False,
+                      resample_action_noise=False)
+    opt = torch.optim.Adam(pol.parameters(), lr)
+    cap = {}
+    init_params = [p.detach().clone() for p in pol.parameters()]
+    orig_rollout = utils.rollout
+    losses = []
+
+    def wrapped(states, dynamics, policy, steps, **kw):
+        out = orig_rollout(states, dynamics, policy, steps, **kw)
+        if 'd' not in cap:
+            gamma = ([1.0 / steps] * steps if discount is None else
+                     [discount**i for i in range(steps)])
+            # parameters at capture time are still the initial ones (iteration 0)
+            cap['d'] = capture_inputs(
+                dynamics, policy, states, steps, gamma, kw['mm_states'],
+                kw['mm_rewards'], kw['mm_groups'], kw['z_mm'], kw['z_rr'], True,
+                False, rew)
+        return out
+
+    def on_iteration(i, loss, states, actions, rewards, disc):
+        losses.append(float(loss))
+
+    utils.rollout = wrapped
+    try:
+        algorithms.mc_pilco(x0, dyn, pol, H, opt, None, n_iters, mm_states=mm,
+                            mm_rewards=mm, mm_groups=mm_groups, maximize=True,
+                            clip_grad=clip, discount=discount,
+                            on_iteration=on_iteration, resampling_period=99)
+    finally:
+        utils.rollout = orig_rollout
+    d = cap['d']
+    for i, p in enumerate(init_params):
+        pass
+    assert len(losses) == n_iters, losses
+    d['mcp_lr'] = lr
+    d['mcp_clip'] = clip
+    d['mcp_n_iters'] = n_iters
+    d['ref32_mcp_losses'] = np.asarray(losses, dtype=np.float32)
+    d['ref32_mcp_final'] = torch.cat(
+        [p.detach().reshape(-1) for p in pol.parameters()]).numpy()
+    d['ref32_mcp_exp_avg'] = torch.cat(
+        [opt.state[p]['exp_avg'].reshape(-1) for p in pol.parameters()]).numpy()
+    d['ref32_mcp_exp_avg_sq'] = torch.cat(
+        [opt.state[p]['exp_avg_sq'].reshape(-1) for p in pol.parameters()]).numpy()
+    print('%-22s mc_pilco %d its, losses %s' % (name, n_iters, losses))
+    return d
+
+
+def _cartpole():
+    return CartpoleReward(pole_length=torch.tensor(0.5))
+
+
+def _dcartpole():
+    return DoubleCartpoleReward(pole1_length=torch.tensor(0.6),
+                                pole2_length=torch.tensor(0.6))
+
+
+def _pendulum():
+    return PendulumReward(pole_length=torch.tensor(1.0))
+
+
+CASES = {
+    # example-faithful shape: 5-D observation (sin/cos already in the state)
+    'nomm_d5': lambda: make_case('nomm_d5', 5, 1, [32, 32], [32, 32],
+                                 _cartpole, 10.0, 24, 12, seed=1),
+    # BASELINE synthetic shape: raw 4-D state, angle expanded inside the reward
+    'nomm_d4': lambda: make_case('nomm_d4', 4, 1, [32, 32], [32, 32],
+                                 _cartpole, 10.0, 40, 12, seed=2, P=8),
+    'nomm_h1': lambda: make_case('nomm_h1', 4, 1, [16, 16], [16, 16],
+                                 _cartpole, 10.0, 7, 1, seed=3),
+    'nomm_h40_disc': lambda: make_case('nomm_h40_disc', 4, 1, [24, 24], [24, 24],
+                                       _cartpole, 10.0, 20, 40, seed=4,
+                                       discount=0.97),
+    'mm1_d5': lambda: make_case('mm1_d5', 5, 1, [32, 32], [32, 32],
+                                _cartpole, 10.0, 24, 12, mm=True, seed=5),
+    'mmg_d4': lambda: make_case('mmg_d4', 4, 1, [32, 32], [32, 32],
+                                _cartpole, 10.0, 40, 12, mm=True,
+                                mm_groups=4, seed=6, P=4),
+    'mmg_infer_ns': lambda: make_case('mmg_infer_ns', 4, 1, [16, 16], [16, 16],
+                                      _cartpole, 10.0, 24, 8, mm=True,
+                                      mm_groups=3, seed=7, infer_ns=True, P=3),
+    'full200_mmg': lambda: make_case('full200_mmg', 4, 1, [200, 200], [200, 200],
+                                     _cartpole, 10.0, 50, 10, mm=True,
+                                     mm_groups=2, seed=8, P=2),
+    'full200_nomm': lambda: make_case('full200_nomm', 5, 1, [200, 200],
+                                      [200, 200], _cartpole, 10.0, 37, 10,
+                                      seed=9),
+    'dcp_d6_mmg': lambda: make_case('dcp_d6_mmg', 6, 1, [40, 40], [24, 24],
+                                    _dcartpole, 20.0, 36, 8, mm=True,
+                                    mm_groups=3, seed=10, P=3),
+    'pend_d2': lambda: make_case('pend_d2', 2, 1, [16, 16], [16, 16],
+                                 _pendulum, 2.0, 19, 10, seed=11),
+    'rdv_d8_u4_3layer': lambda: make_case('rdv_d8_u4_3layer', 8, 4,
+                                          [24, 24, 24], [20, 20, 20],
+                                          RendezvousReward, [1.0, 2.0, 3.0, 4.0],
+                                          21, 6, seed=12, maximize=True),
+    'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
+                                          _cartpole, 10.0, 30, 10, 4,
+                                          seed=13),
+    'mcp_mm1': lambda: make_mcpilco_case('mcp_mm1', 5, 1, [32, 32], [32, 32],
+                                         _cartpole, 10.0, 30, 10, 3,
+                                         mm=True, seed=14, discount=0.95),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__),
+                                                  '..', 'tests', 'golden'))
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name, fn in CASES.items():
+        if args.only and name != args.only:
+            continue
+        d = fn()
+        # fp32-exact inputs are stored as fp32 to keep fixtures small
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, np.ndarray) and v.dtype == np.float64 \
+                    and not k.startswith('ref64_'):
+                v32 = v.astype(np.float32)
+                out[k] = v32 if np.array_equal(v32.astype(np.float64), v) else v
+            else:
+                out[k] = v
+        # masks are {0,1}: store as bit-packed uint8
+        for k in list(out):
+            if '_mask' in k:
+                m = np.asarray(out.pop(k))
+                assert np.all((m == 0) | (m == 1)), k
+                out[k + '_shape'] = np.array(m.shape, dtype=np.int64)
+                out[k + '_bits'] = np.packbits(m.astype(np.uint8), axis=None,
+                                               bitorder='little')
+        path = os.path.join(args.out, name + '.npz')
+        np.savez_compressed(path, **out)
+        print('   -> %s (%.1f kB)' % (path, os.path.getsize(path) / 1e3))
+
+
+if __name__ == '__main__':
+    main()
