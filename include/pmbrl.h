@@ -1,0 +1,201 @@
+/*
+ * pmbrl.h -- C ABI of libpmbrl_hip.so: the MI355X (gfx950) implementation of the
+ * MC-PILCO particle-rollout + back-prop-through-rollout hot path of
+ * mcgillmrl/prob_mbrl.
+ *
+ * The reference has no FFI (it is pure Python on torch); the boundary it offers
+ * is the Python call surface.  Each entry point below names the reference
+ * function(s) whose arithmetic it replaces (paths relative to the reference
+ * repository root).  The Python host layer (prob_mbrl_amd/) keeps the
+ * reference's signatures and calls these through ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no exceptions, no Python/torch types; every pointer named *_d is
+ *    a DEVICE pointer owned by the caller (a torch tensor's data_ptr()) that
+ *    must stay alive until `stream` has drained; all arrays are contiguous,
+ *    row-major, fp32 unless stated.
+ *  - return value: 0 = ok, < 0 = usage / HIP error (message via
+ *    pmbrl_last_error()).  Numerical failures inside a rollout (non-finite
+ *    state, non-positive Cholesky pivot) do not fail the call: they are
+ *    reported through the int32 `status_d` word (see pmbrl_rollout_fwd), which
+ *    the host turns into the RuntimeError the reference's control flow relies
+ *    on (utils/rollout.py:154-157, algorithms/mc_pilco.py:122-131).
+ *  - calls on one plan are stream-ordered and not thread-safe; different plans
+ *    may be used from different host threads.
+ */
+#ifndef PMBRL_H
+#define PMBRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMBRL_MAX_LAYERS 8  /* Linear layers per network (hidden + output) */
+#define PMBRL_MAX_ANGLE 8
+#define PMBRL_MAX_TIP 8
+#define PMBRL_MAX_DIM 64    /* max state / action / expanded-state width */
+
+#define PMBRL_FLAG_MM_STATES 1   /* utils/rollout.py:121-132 */
+#define PMBRL_FLAG_MM_REWARDS 2  /* utils/rollout.py:135-145 */
+#define PMBRL_FLAG_INFER_NS 4    /* utils/rollout.py:6-17 (mm_resample_infer_ns_) */
+
+#define PMBRL_REWARD_EXP 0 /* r = exp(-w (d'Qd + u'Ru)): envs/cartpole/env.py:41-86 */
+#define PMBRL_REWARD_NEG 1 /* r = -w (d'Qd + u'Ru):      envs/rendezvous/env.py:32-45 */
+
+/* One MLP as built by models/core.py:15-99 (mlp): Linear -> ReLU -> dropout ...
+ * -> Linear.  dims[0] = input width, dims[n_layers] = output width.
+ * keep[i] is the keep-probability the masked activation of hidden layer i is
+ * DIVIDED by (BDropout, models/modules.py:61) or 1.0 (eval-mode CDropout,
+ * models/modules.py:158-160, and layers without dropout). */
+typedef struct pmbrl_mlp {
+  int32_t n_layers;
+  int32_t dims[PMBRL_MAX_LAYERS + 1];
+  float keep[PMBRL_MAX_LAYERS];
+} pmbrl_mlp;
+
+/* Analytic reward, the common form of envs/<env>/env.py:*Reward.forward and
+ * losses.py:67-75:  phi = expand ? [others, sin(angles), cos(angles)] : x
+ * (utils/angles.py:7-42);  delta = (C phi - tip_target) / norm;
+ * cost = w (delta' Q delta + u' R u);  r = exp(-cost) | -cost. */
+typedef struct pmbrl_reward {
+  int32_t kind;   /* PMBRL_REWARD_* */
+  int32_t expand; /* 1: expand angle_dims inside the reward */
+  int32_t n_angle;
+  int32_t angle_dims[PMBRL_MAX_ANGLE];
+  int32_t k; /* rows of C (tip coordinates) */
+  float C[PMBRL_MAX_TIP * PMBRL_MAX_DIM]; /* [k, De] row-major, De = D + (expand ? n_angle : 0) */
+  float tip_target[PMBRL_MAX_TIP];
+  float norm;
+  float w;
+  float Q[PMBRL_MAX_TIP * PMBRL_MAX_TIP]; /* [k, k] */
+  float R[PMBRL_MAX_DIM * PMBRL_MAX_DIM]; /* [U, U] */
+} pmbrl_reward;
+
+/* Problem shape.  B is the number of particle rows resident on THIS device;
+ * rows are laid out as utils/core.py:188-190 (tile): row = particle*S + sample.
+ * With moment matching, rows are grouped contiguously: mm_groups groups of
+ * B/mm_groups rows (utils/rollout.py:125-129); mm_groups = 0 with an MM flag
+ * set means one group of all B rows (the examples' default).
+ * For multi-GPU sharding B_global / row_offset locate this shard in the global
+ * batch: the cyclic noise index of utils/rollout.py:53-59 is
+ * (t + row_offset + b) mod B_global. */
+typedef struct pmbrl_config {
+  int32_t B, D, U, H;
+  int32_t B_global, row_offset;
+  int32_t flags;
+  int32_t mm_groups;
+  float max_log_std_pol; /* models/densities.py:75: log(max_noise_std) */
+  float max_log_std_dyn;
+  pmbrl_mlp pol; /* dims[0] = D, dims[n] = 2U */
+  pmbrl_mlp dyn; /* dims[0] = D+U, dims[n] = 2D */
+  pmbrl_reward reward;
+  int32_t rows_per_wg_hint; /* 0 = choose automatically */
+} pmbrl_config;
+
+typedef struct pmbrl_plan pmbrl_plan;
+
+/* plan->info indices for pmbrl_plan_info */
+enum {
+  PMBRL_INFO_ROWS_PER_WG = 0,
+  PMBRL_INFO_N_WG = 1,
+  PMBRL_INFO_ROW_TILES = 2,
+  PMBRL_INFO_LDS_BYTES = 3,
+  PMBRL_INFO_N_POL_PARAMS = 4,
+  PMBRL_INFO_N_DYN_PARAMS = 5,
+  PMBRL_INFO_DW_SPLITS = 6,
+  PMBRL_INFO_COUNT = 16
+};
+
+const char* pmbrl_last_error(void);
+int pmbrl_version(void);
+
+/* Validates the shape, chooses the tiling and sizes the workspace. */
+int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan** out);
+void pmbrl_plan_destroy(pmbrl_plan* plan);
+/* Bytes of scratch the caller must provide (one device allocation, 256-byte
+ * aligned) to every fwd/bwd call on this plan: fragment-packed weights, the
+ * activation / gradient stashes, bit masks, dW partial sums. */
+size_t pmbrl_plan_workspace_bytes(const pmbrl_plan* plan);
+int pmbrl_plan_info(const pmbrl_plan* plan, int32_t* info /* [PMBRL_INFO_COUNT] */);
+
+/* {0,1} float mask [B, h] -> bit rows [B, ceil(h/16)] uint16 (little-endian bit
+ * order).  Replaces the per-step fp32 mask multiply of models/modules.py:61,160
+ * by a one-off packing at resample() time (models/modules.py:40-44,95-118). */
+int pmbrl_pack_mask(void* stream, const float* mask_d, int32_t B, int32_t h,
+                    int32_t src_ld, uint16_t* bits_d);
+
+/* Network + noise inputs shared by forward and backward. */
+typedef struct pmbrl_inputs {
+  const float* x0_d;          /* [B, D] */
+  const float* pol_params_d;  /* flat, torch parameter order: W0[out,in], b0, W1, b1, ... */
+  const float* dyn_params_d;  /* same for the dynamics MLP */
+  const float* mx_d;          /* [D+U]  models/core.py:141-145 */
+  const float* iSx_d;         /* [D+U] */
+  const float* my_d;          /* [D] */
+  const float* Sy_d;          /* [D] */
+  const float* pol_scale_d;   /* [U]  models/core.py:201-206 */
+  const float* pol_bias_d;    /* [U] */
+  const uint16_t* pol_mask_bits_d[PMBRL_MAX_LAYERS]; /* per hidden layer, from pmbrl_pack_mask */
+  const uint16_t* dyn_mask_bits_d[PMBRL_MAX_LAYERS];
+  const float* z_pol_d;       /* [B, U]  models/densities.py:78,111-119 */
+  const float* z_dyn_d;       /* [B, D] */
+  const float* z_mm_d;        /* [>= B_global, D] or NULL  algorithms/mc_pilco.py:57-62 */
+  const float* z_rr_d;        /* [>= B_global, 1] or NULL */
+} pmbrl_inputs;
+
+/* utils/rollout.py:62-163 (rollout) fused over all H steps, including
+ * models/core.py:221-248 (Policy.forward), models/core.py:265-303
+ * (DynamicsModel.forward), models/densities.py:87-121, the reward module and
+ * utils/rollout.py:20-29 (mm_resample_).
+ * Outputs: states [H+1,B,D], actions [H,B,U], rewards [H,B,1].
+ * status_d: device int32, set to 0x7fffffff on entry; on a numerical failure at
+ * step t (non-finite state/reward, non-positive pivot) atomically min'ed with t
+ * (= number of valid steps before the failure). */
+int pmbrl_rollout_fwd(pmbrl_plan* plan, void* stream, void* workspace_d,
+                      const pmbrl_inputs* in, float* states_d, float* actions_d,
+                      float* rewards_d, int32_t* status_d);
+
+/* The adjoint of the above = what loss.backward() computes in
+ * algorithms/mc_pilco.py:190-197 for loss = sum_{t,b} grad_rewards[t,b] *
+ * rewards[t,b] (+ sum grad_states[t,b,:] . states[t,b,:] when grad_states_d is
+ * given -- terminal value bootstrap, algorithms/mc_pilco.py:136-140).
+ * Must follow a pmbrl_rollout_fwd on the same plan/workspace/inputs.
+ * Outputs: grad_pol_flat_d [n_pol_params] (overwritten), optional grad_x0_d
+ * [B,D], optional action_grad_norms_d [H,B] (||dL/da_t|| per row, the
+ * prioritised-replay hook of algorithms/mc_pilco.py:156-188). */
+int pmbrl_rollout_bwd(pmbrl_plan* plan, void* stream, void* workspace_d,
+                      const pmbrl_inputs* in, const float* states_d,
+                      const float* actions_d, const float* rewards_d,
+                      const float* grad_rewards_d, const float* grad_states_d,
+                      float* grad_pol_flat_d, float* grad_x0_d,
+                      float* action_grad_norms_d);
+
+/* out[0] = sum_i a[i] * w[i]  (the discounted-return loss of
+ * algorithms/mc_pilco.py:134-144,190 given w = dL/dr). Deterministic. */
+int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d,
+                       int64_t n, float* out_d);
+
+/* torch.nn.utils.clip_grad_norm_ (algorithms/mc_pilco.py:209-210) fused with
+ * torch.optim.Adam.step (examples/deep_pilco_mm.py:166; no weight decay, no
+ * amsgrad).  max_norm <= 0 disables clipping.  norm_out_d (optional) receives
+ * the pre-clip global L2 norm.  grads are left scaled by the clip coefficient,
+ * like the reference. */
+int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d,
+                    float* exp_avg_d, float* exp_avg_sq_d, int64_t n,
+                    int64_t step, float lr, float beta1, float beta2, float eps,
+                    float max_norm, float* norm_out_d);
+
+/* ---- test hooks (used by tests/ only) ---------------------------------- */
+/* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout
+ * kernels use (R <= 64). */
+int pmbrl_debug_linear(void* stream, const float* x_d, const float* W_d,
+                       const float* b_d, int32_t R, int32_t K, int32_t O,
+                       int32_t transpose_w, float* y_d, float* scratch_d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMBRL_H */

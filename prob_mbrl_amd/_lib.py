@@ -1,0 +1,112 @@
+"""ctypes binding of libpmbrl_hip.so (C ABI declared in include/pmbrl.h).
+
+There is NO fallback: importing this module without the built library, or
+calling into it without a GPU, raises.  Build with `python __graft_entry__.py`
+(or `make -C prob_mbrl_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libpmbrl_hip.so')
+
+MAX_LAYERS = 8
+MAX_ANGLE = 8
+MAX_TIP = 8
+MAX_DIM = 64
+FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS = 1, 2, 4
+REWARD_EXP, REWARD_NEG = 0, 1
+INFO_COUNT = 16
+
+
+class MLP(C.Structure):
+    _fields_ = [('n_layers', C.c_int32),
+                ('dims', C.c_int32 * (MAX_LAYERS + 1)),
+                ('keep', C.c_float * MAX_LAYERS)]
+
+
+class Reward(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('expand', C.c_int32),
+                ('n_angle', C.c_int32), ('angle_dims', C.c_int32 * MAX_ANGLE),
+                ('k', C.c_int32), ('C', C.c_float * (MAX_TIP * MAX_DIM)),
+                ('tip_target', C.c_float * MAX_TIP), ('norm', C.c_float),
+                ('w', C.c_float), ('Q', C.c_float * (MAX_TIP * MAX_TIP)),
+                ('R', C.c_float * (MAX_DIM * MAX_DIM))]
+
+
+class Config(C.Structure):
+    _fields_ = [('B', C.c_int32), ('D', C.c_int32), ('U', C.c_int32),
+                ('H', C.c_int32), ('B_global', C.c_int32),
+                ('row_offset', C.c_int32), ('flags', C.c_int32),
+                ('mm_groups', C.c_int32), ('max_log_std_pol', C.c_float),
+                ('max_log_std_dyn', C.c_float), ('pol', MLP), ('dyn', MLP),
+                ('reward', Reward), ('rows_per_wg_hint', C.c_int32)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [('x0', C.c_void_p), ('pol_params', C.c_void_p),
+                ('dyn_params', C.c_void_p), ('mx', C.c_void_p),
+                ('iSx', C.c_void_p), ('my', C.c_void_p), ('Sy', C.c_void_p),
+                ('pol_scale', C.c_void_p), ('pol_bias', C.c_void_p),
+                ('pol_mask_bits', C.c_void_p * MAX_LAYERS),
+                ('dyn_mask_bits', C.c_void_p * MAX_LAYERS),
+                ('z_pol', C.c_void_p), ('z_dyn', C.c_void_p),
+                ('z_mm', C.c_void_p), ('z_rr', C.c_void_p)]
+
+
+EXPORTS = [
+    'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
+    'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
+    'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
+    'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
+]
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'prob_mbrl_amd: %s is missing -- build the HIP extension first '
+            '(python -c "import __graft_entry__ as g; g.build()"). There is no '
+            'CPU fallback for the rollout hot path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.pmbrl_last_error.restype = C.c_char_p
+    lib.pmbrl_last_error.argtypes = []
+    lib.pmbrl_version.restype = C.c_int
+    lib.pmbrl_plan_create.restype = C.c_int
+    lib.pmbrl_plan_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(vp)]
+    lib.pmbrl_plan_destroy.restype = None
+    lib.pmbrl_plan_destroy.argtypes = [vp]
+    lib.pmbrl_plan_workspace_bytes.restype = C.c_size_t
+    lib.pmbrl_plan_workspace_bytes.argtypes = [vp]
+    lib.pmbrl_plan_info.restype = C.c_int
+    lib.pmbrl_plan_info.argtypes = [vp, C.POINTER(i32)]
+    lib.pmbrl_pack_mask.restype = C.c_int
+    lib.pmbrl_pack_mask.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.pmbrl_rollout_fwd.restype = C.c_int
+    lib.pmbrl_rollout_fwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp, vp]
+    lib.pmbrl_rollout_bwd.restype = C.c_int
+    lib.pmbrl_rollout_bwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp,
+                                      vp, vp, vp, vp, vp]
+    lib.pmbrl_weighted_sum.restype = C.c_int
+    lib.pmbrl_weighted_sum.argtypes = [vp, vp, vp, i64, vp]
+    lib.pmbrl_clip_adam.restype = C.c_int
+    lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32,
+                                    f32, f32, vp]
+    lib.pmbrl_debug_linear.restype = C.c_int
+    lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pmbrl_last_error()
+        raise RuntimeError('%s failed (%d): %s' %
+                           (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,748 @@
+// libpmbrl_hip.so -- C ABI (include/pmbrl.h) over the gfx950 kernels.
+// Host side: shape validation, tiling choice, workspace carve-up, launches.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "pmbrl.h"
+#include "pmbrl_dev.h"
+#include "pmbrl_mm.h"
+#include "pmbrl_rollout.h"
+#include "pmbrl_dw.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                               \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return fail(-100 - (int)_e, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
+extern "C" int pmbrl_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+// fragment packing: dst[((ot*n_kb + kb)*64 + lane)*4 + j] = W[ot*16 + (lane&15)][kb*16 + 4*(lane>>4) + j]
+// (transpose=1: the roles of the two indices of W[O][K] are swapped)
+__global__ void pm_pack_frag(const float* __restrict__ W, int O, int K, int transpose,
+                             float* __restrict__ dst) {
+  const int n_out = transpose ? K : O, n_in = transpose ? O : K;
+  const int n_ot = (n_out + 15) / 16, n_kb = (n_in + 15) / 16;
+  const size_t total = (size_t)n_ot * n_kb * 256;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63;
+    const size_t tb = i >> 8;
+    const int kb = tb % n_kb, ot = tb / n_kb;
+    const int o = ot * 16 + (lane & 15);
+    const int k = kb * 16 + 4 * (lane >> 4) + j;
+    float v = 0.f;
+    if (o < n_out && k < n_in) v = transpose ? W[(size_t)k * K + o] : W[(size_t)o * K + k];
+    dst[i] = v;
+  }
+}
+__global__ void pm_pack_bias(const float* __restrict__ b, int O, int O16, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < O16) dst[i] = i < O ? b[i] : 0.f;
+}
+__global__ void pm_pack_mask_kernel(const float* __restrict__ m, int B, int h, int ld,
+                                    uint16_t* __restrict__ bits) {
+  const int nt = (h + 15) / 16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nt) return;
+  const int r = i / nt, t = i - r * nt;
+  unsigned w = 0;
+  for (int j = 0; j < 16; ++j) {
+    const int f = t * 16 + j;
+    if (f < h && m[(size_t)r * ld + f] != 0.f) w |= 1u << j;
+  }
+  bits[i] = (uint16_t)w;
+}
+__global__ void pm_set_int(int* p, int v) { *p = v; }
+
+__global__ void pm_weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                       long long n, float* __restrict__ out) {
+  __shared__ double sm[1024];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)a[i] * (double)w[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)sm[0];
+}
+
+// clip_grad_norm_ + Adam, one workgroup (policy nets are 1e4..1e6 parameters)
+__global__ __launch_bounds__(1024) void pm_clip_adam_kernel(float* __restrict__ p,
+                                                            float* __restrict__ g,
+                                                            float* __restrict__ m,
+                                                            float* __restrict__ v, long long n,
+                                                            float lr, float b1, float b2,
+                                                            float eps, float bc1, float bc2_sqrt,
+                                                            float max_norm,
+                                                            float* __restrict__ norm_out) {
+  __shared__ double sm[1024];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = g[i];
+    s += x * x;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float norm = (float)sqrt(sm[0]);
+  if (threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  const float step_size = lr / bc1;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    g[i] = gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+// external moment matching (groups larger than a workgroup's rows): one
+// workgroup (one wave active) per group, rows in HBM.
+__global__ void pm_mm_fwd_kernel(RolloutArgs A, int t) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr[];
+  const int gi = blockIdx.x, lane = threadIdx.x;
+  const int r0 = gi * A.M;
+  const int zrow0 = t + A.row_off + r0;
+  if (A.flags & PMBRL_FLAG_MM_STATES) {
+    const bool ok = pm_mm_fwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, A.zmm, A.D, zrow0,
+                              A.Bg, false, A.states + ((size_t)(t + 1) * A.B + r0) * A.D, A.D,
+                              mmscr, lane);
+    if (!ok && lane == 0) atomicMin(A.status, t);
+  }
+  if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+    const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, A.zrr, 1, zrow0, A.Bg, false,
+                              A.rewards + (size_t)t * A.B + r0, 1, mmscr, lane);
+    if (!ok && lane == 0) atomicMin(A.status, t);
+  }
+}
+// adjoint: (gx_carry = dL/dx_{t+1}, grad_rewards[t]) -> (gx_carry = dL/dx~, gr_tilde[t] = dL/dr~)
+__global__ void pm_mm_bwd_kernel(RolloutArgs A, int t, float* gr_tilde) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr[];
+  const int gi = blockIdx.x, lane = threadIdx.x;
+  const int r0 = gi * A.M;
+  const int zrow0 = t + A.row_off + r0;
+  if (A.flags & PMBRL_FLAG_MM_STATES) {
+    float* g = A.gx_carry + (size_t)r0 * A.D;
+    // in-place is NOT safe for d > 1 reads of g after writes: pm_mm_bwd reads g only
+    // before its first wave sync, so aliasing g/gout is fine (see pmbrl_mm.h).
+    pm_mm_bwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, A.zmm, A.D, zrow0, A.Bg, false, g,
+              A.D, g, A.D, mmscr, lane);
+  }
+  const float* gsrc = A.grad_rewards + (size_t)t * A.B + r0;
+  float* gdst = gr_tilde + (size_t)t * A.B + r0;
+  if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+    pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, A.zrr, 1, zrow0, A.Bg, false, gsrc, 1, gdst, 1,
+              mmscr, lane);
+  } else {
+    for (int i = lane; i < A.M; i += 64) gdst[i] = gsrc[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct NetPlan {
+  int nl;
+  int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
+  float keep[PM_MAXL];
+  size_t w_off[PM_MAXL], b_off[PM_MAXL];   // offsets (floats) in the flat parameter vector
+  size_t n_params;
+  // workspace offsets (bytes)
+  size_t wf[PM_MAXL], wb[PM_MAXL], bias[PM_MAXL], abits[PM_MAXL];
+};
+
+struct pmbrl_plan {
+  pmbrl_config cfg;
+  int device;
+  int RT, rows_per_wg, nwg, LD, mm_mode, G, M;
+  size_t lds_bytes;
+  NetPlan pol, dyn;
+  RewardDev* rew_d;
+  DwBlock* dw_blocks_d;
+  int n_dw_blocks, dw_wg_per_split, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  // workspace offsets (bytes)
+  size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
+      off_gxc, off_grt, ws_bytes;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expect,
+                    const char* name) {
+  if (m.n_layers < 1 || m.n_layers > PM_MAXL)
+    return fail(-2, std::string(name) + ": n_layers out of range");
+  n.nl = m.n_layers;
+  size_t off = 0;
+  for (int i = 0; i <= n.nl; ++i) {
+    if (m.dims[i] < 1 || m.dims[i] > 4096) return fail(-2, std::string(name) + ": bad layer width");
+    n.dim[i] = m.dims[i];
+    n.nt[i] = (m.dims[i] + 15) / 16;
+  }
+  if (n.dim[0] != in_expect || n.dim[n.nl] != out_expect)
+    return fail(-2, std::string(name) + ": input/output width does not match D/U");
+  for (int l = 0; l < n.nl; ++l) {
+    n.keep[l] = (l < n.nl - 1) ? m.keep[l] : 1.f;
+    if (l < n.nl - 1 && !(n.keep[l] > 0.f)) return fail(-2, std::string(name) + ": keep must be > 0");
+    n.w_off[l] = off;
+    off += (size_t)n.dim[l + 1] * n.dim[l];
+    n.b_off[l] = off;
+    off += n.dim[l + 1];
+  }
+  n.n_params = off;
+  return 0;
+}
+
+template <int RT>
+static int set_attr(size_t lds) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<RT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<RT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return 0;
+}
+
+extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan** out) {
+  if (!cfg || !out) return fail(-1, "null argument");
+  const pmbrl_config& c = *cfg;
+  if (c.B < 1 || c.D < 1 || c.U < 1 || c.H < 1) return fail(-2, "B, D, U, H must be >= 1");
+  if (c.D > 32 || c.U > 16) return fail(-2, "supported widths: D <= 32, U <= 16");
+  if (c.reward.k < 1 || c.reward.k > PMBRL_MAX_TIP) return fail(-2, "reward.k out of range");
+  if (c.flags & PMBRL_FLAG_INFER_NS)
+    return fail(-3, "infer_noise_variables is not offered on the device path");
+  pmbrl_plan* p = new pmbrl_plan();
+  memset(p, 0, sizeof(*p));
+  p->cfg = c;
+  if (p->cfg.B_global <= 0) p->cfg.B_global = c.B;
+  p->device = device;
+  int rc = net_plan(c.pol, p->pol, c.D, 2 * c.U, "policy");
+  if (rc == 0) rc = net_plan(c.dyn, p->dyn, c.D + c.U, 2 * c.D, "dynamics");
+  if (rc) { delete p; return rc; }
+
+  // LDS leading dimension: widest activation (any layer of either net), +8 so that
+  // LD % 16 == 8 (conflict-free ds_read_b128 for the MFMA B operand)
+  int maxnt = 1;
+  for (int i = 0; i <= p->pol.nl; ++i) maxnt = std::max(maxnt, p->pol.nt[i]);
+  for (int i = 0; i <= p->dyn.nl; ++i) maxnt = std::max(maxnt, p->dyn.nt[i]);
+  p->LD = maxnt * 16 + 8;
+
+  const bool mm = (c.flags & (PMBRL_FLAG_MM_STATES | PMBRL_FLAG_MM_REWARDS)) != 0;
+  const size_t lds_cap = 160 * 1024;
+  auto lds_need = [&](int RT, int mmd) {
+    return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
+  };
+  p->G = 1;
+  p->M = c.B;
+  p->mm_mode = 0;
+  if (mm) {
+    p->G = c.mm_groups > 0 ? c.mm_groups : 1;
+    if (c.B % p->G) { delete p; return fail(-2, "B must be divisible by mm_groups"); }
+    p->M = c.B / p->G;
+    if (p->M < 2) { delete p; return fail(-2, "moment matching needs >= 2 rows per group"); }
+    // in-kernel if a whole number of groups fits a workgroup's row tiles and LDS
+    p->mm_mode = 2;
+    for (int RT : {1, 2, 4}) {
+      const int R = 16 * RT;
+      if (p->M <= R && lds_need(RT, c.D) <= lds_cap) {
+        p->mm_mode = 1;
+        p->RT = RT;
+        p->rows_per_wg = (R / p->M) * p->M;
+        break;
+      }
+    }
+  }
+  if (p->mm_mode != 1) {
+    int RT = 1;
+    if (c.rows_per_wg_hint >= 64) RT = 4;
+    else if (c.rows_per_wg_hint >= 32) RT = 2;
+    else if (c.rows_per_wg_hint == 0) {
+      // fill the chip first: >= 2 waves of workgroups over 256 CUs before growing tiles
+      if ((c.B + 15) / 16 > 1024) RT = 2;
+      if ((c.B + 31) / 32 > 1024) RT = 4;
+    }
+    while (RT > 1 && lds_need(RT, 0) > lds_cap) RT /= 2;
+    p->RT = RT;
+    p->rows_per_wg = 16 * RT;
+  } else if (c.rows_per_wg_hint > 0) {
+    // allow the caller to force fewer groups per workgroup
+    const int want = std::max(p->M, (c.rows_per_wg_hint / p->M) * p->M);
+    if (want <= 16 * p->RT) p->rows_per_wg = want;
+  }
+  p->lds_bytes = lds_need(p->RT, p->mm_mode == 1 ? c.D : 0);
+  if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
+  p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
+
+  HIPCHK(hipSetDevice(device));
+  // reward constants
+  {
+    RewardDev r;
+    memset(&r, 0, sizeof(r));
+    const pmbrl_reward& s = c.reward;
+    r.kind = s.kind;
+    r.expand = s.expand;
+    r.k = s.k;
+    r.n_angle = s.expand ? s.n_angle : 0;
+    if (r.n_angle > PMBRL_MAX_ANGLE) { delete p; return fail(-2, "too many angle dims"); }
+    int no = 0;
+    for (int i = 0; i < c.D; ++i) {
+      bool isang = false;
+      for (int j = 0; j < r.n_angle; ++j) isang |= (s.angle_dims[j] == i);
+      if (!isang) r.other_dims[no++] = i;
+    }
+    for (int j = 0; j < r.n_angle; ++j) {
+      if (s.angle_dims[j] < 0 || s.angle_dims[j] >= c.D) { delete p; return fail(-2, "angle dim out of range"); }
+      r.angle_dims[j] = s.angle_dims[j];
+    }
+    r.n_other = s.expand ? no : c.D;
+    r.De = s.expand ? no + 2 * r.n_angle : c.D;
+    if (r.De > PMBRL_MAX_DIM) { delete p; return fail(-2, "expanded state too wide"); }
+    for (int i = 0; i < s.k; ++i) {
+      for (int j = 0; j < r.De; ++j) r.C[i * r.De + j] = s.C[i * r.De + j] / s.norm;
+      r.tt[i] = s.tip_target[i] / s.norm;
+    }
+    r.w = s.w;
+    for (int i = 0; i < s.k; ++i)
+      for (int j = 0; j < s.k; ++j) {
+        r.Q[i * s.k + j] = s.Q[i * s.k + j];
+        r.QQ[i * s.k + j] = s.Q[i * s.k + j] + s.Q[j * s.k + i];
+      }
+    for (int i = 0; i < c.U; ++i)
+      for (int j = 0; j < c.U; ++j) {
+        r.R[i * c.U + j] = s.R[i * c.U + j];
+        r.RR[i * c.U + j] = s.R[i * c.U + j] + s.R[j * c.U + i];
+      }
+    HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
+    HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
+  }
+  // dW wave blocks
+  {
+    std::vector<DwBlock> blocks;
+    for (int l = 0; l < p->pol.nl; ++l) {
+      const int OT = p->pol.nt[l + 1], IT = p->pol.nt[l];
+      for (int o = 0; o < OT; o += PM_DW_TM)
+        for (int i = 0; i < IT; i += PM_DW_TN) {
+          DwBlock b;
+          b.layer = (int16_t)l;
+          b.ot0 = (int16_t)o;
+          b.it0 = (int16_t)i;
+          b.n_ot = (int16_t)std::min(PM_DW_TM, OT - o);
+          b.n_it = (int16_t)std::min(PM_DW_TN, IT - i);
+          b.pad = 0;
+          blocks.push_back(b);
+        }
+    }
+    // heaviest blocks first within a workgroup quartet does not matter; keep layer order
+    p->n_dw_blocks = (int)blocks.size();
+    p->dw_wg_per_split = (p->n_dw_blocks + PM_NW - 1) / PM_NW;
+    p->dw_n_chunks = c.H * p->nwg * p->RT;
+    int nsplit = std::max(1, 1024 / p->dw_wg_per_split);
+    nsplit = std::min(nsplit, p->dw_n_chunks);
+    p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
+    p->dw_nsplit = (p->dw_n_chunks + p->dw_chunks_per_split - 1) / p->dw_chunks_per_split;
+    HIPCHK(hipMalloc(&p->dw_blocks_d, blocks.size() * sizeof(DwBlock)));
+    HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock),
+                     hipMemcpyHostToDevice));
+  }
+  // workspace carve-up
+  {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      const size_t o = off;
+      off = align_up(off + bytes, 256);
+      return o;
+    };
+    NetPlan* nets[2] = {&p->pol, &p->dyn};
+    for (NetPlan* n : nets) {
+      for (int l = 0; l < n->nl; ++l) {
+        const size_t fr = (size_t)n->nt[l + 1] * n->nt[l] * 256 * sizeof(float);
+        n->wf[l] = take(fr);
+        n->wb[l] = take(fr);
+        n->bias[l] = take((size_t)n->nt[l + 1] * 16 * sizeof(float));
+        if (l < n->nl - 1)
+          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * sizeof(uint16_t));
+      }
+    }
+    const size_t Rw = 16 * p->RT;
+    for (int l = 0; l < p->pol.nl; ++l) {
+      p->off_actT[l] = take((size_t)c.H * p->nwg * p->pol.nt[l] * 16 * Rw * sizeof(float));
+      p->off_gT[l] = take((size_t)c.H * p->nwg * p->pol.nt[l + 1] * 16 * Rw * sizeof(float));
+    }
+    p->off_Tp = take((size_t)c.H * c.B * c.U * sizeof(float));
+    p->off_Td = take((size_t)c.H * c.B * c.D * sizeof(float));
+    p->off_xt = take((size_t)c.H * c.B * c.D * sizeof(float));
+    p->off_rt = take((size_t)c.H * c.B * sizeof(float));
+    p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
+    p->off_grt = take((size_t)c.H * c.B * sizeof(float));
+    p->off_part = take((size_t)p->dw_nsplit * p->pol.n_params * sizeof(float));
+    p->ws_bytes = off;
+  }
+  int rc2 = 0;
+  switch (p->RT) {
+    case 1: rc2 = set_attr<1>(p->lds_bytes); break;
+    case 2: rc2 = set_attr<2>(p->lds_bytes); break;
+    default: rc2 = set_attr<4>(p->lds_bytes); break;
+  }
+  if (p->mm_mode == 2) {
+    const int smem = (int)(pm_mm_scratch_doubles(c.D) * sizeof(double));
+    if (smem > 64 * 1024) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_fwd_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_bwd_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+  }
+  if (rc2) { pmbrl_plan_destroy(p); return rc2; }
+  *out = p;
+  return 0;
+}
+
+extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
+  if (!p) return;
+  if (p->rew_d) (void)hipFree(p->rew_d);
+  if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
+  delete p;
+}
+
+extern "C" size_t pmbrl_plan_workspace_bytes(const pmbrl_plan* p) { return p ? p->ws_bytes : 0; }
+
+extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
+  if (!p || !info) return fail(-1, "null argument");
+  memset(info, 0, sizeof(int32_t) * PMBRL_INFO_COUNT);
+  info[PMBRL_INFO_ROWS_PER_WG] = p->rows_per_wg;
+  info[PMBRL_INFO_N_WG] = p->nwg;
+  info[PMBRL_INFO_ROW_TILES] = p->RT;
+  info[PMBRL_INFO_LDS_BYTES] = (int32_t)p->lds_bytes;
+  info[PMBRL_INFO_N_POL_PARAMS] = (int32_t)p->pol.n_params;
+  info[PMBRL_INFO_N_DYN_PARAMS] = (int32_t)p->dyn.n_params;
+  info[PMBRL_INFO_DW_SPLITS] = p->dw_nsplit;
+  info[7] = p->mm_mode;
+  info[8] = p->LD;
+  info[9] = p->n_dw_blocks;
+  return 0;
+}
+
+extern "C" int pmbrl_pack_mask(void* stream, const float* mask_d, int32_t B, int32_t h,
+                               int32_t src_ld, uint16_t* bits_d) {
+  if (!mask_d || !bits_d || B < 1 || h < 1 || src_ld < h) return fail(-1, "bad argument");
+  const int nt = (h + 15) / 16;
+  const int n = B * nt;
+  hipLaunchKernelGGL(pm_pack_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     mask_d, B, h, src_ld, bits_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// argument assembly
+// ---------------------------------------------------------------------------
+static void fill_net(const NetPlan& n, char* ws, const uint16_t* const* masks, NetDev& d) {
+  d.nl = n.nl;
+  for (int i = 0; i <= n.nl; ++i) {
+    d.dim[i] = n.dim[i];
+    d.nt[i] = n.nt[i];
+  }
+  for (int l = 0; l < n.nl; ++l) {
+    d.keep[l] = n.keep[l];
+    d.wf[l] = reinterpret_cast<const float*>(ws + n.wf[l]);
+    d.wb[l] = reinterpret_cast<const float*>(ws + n.wb[l]);
+    d.bias[l] = reinterpret_cast<const float*>(ws + n.bias[l]);
+    d.mask[l] = (l < n.nl - 1) ? masks[l] : nullptr;
+    d.abits[l] = (l < n.nl - 1) ? reinterpret_cast<uint16_t*>(ws + n.abits[l]) : nullptr;
+  }
+}
+
+static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* in, RolloutArgs& A) {
+  const pmbrl_config& c = p->cfg;
+  char* ws = static_cast<char*>(workspace);
+  memset(&A, 0, sizeof(A));
+  A.B = c.B; A.D = c.D; A.U = c.U; A.H = c.H;
+  A.Bg = c.B_global; A.row_off = c.row_offset; A.flags = c.flags;
+  A.G = p->G; A.M = p->M; A.mm_mode = p->mm_mode;
+  A.t0 = 0; A.t1 = c.H;
+  A.rows_per_wg = p->rows_per_wg; A.nwg = p->nwg; A.Rw = 16 * p->RT; A.LD = p->LD;
+  A.mls_pol = c.max_log_std_pol; A.mls_dyn = c.max_log_std_dyn;
+  for (int l = 0; l < p->pol.nl - 1; ++l)
+    if (!in->pol_mask_bits_d[l]) return fail(-1, "missing policy mask bits");
+  for (int l = 0; l < p->dyn.nl - 1; ++l)
+    if (!in->dyn_mask_bits_d[l]) return fail(-1, "missing dynamics mask bits");
+  fill_net(p->pol, ws, in->pol_mask_bits_d, A.pol);
+  fill_net(p->dyn, ws, in->dyn_mask_bits_d, A.dyn);
+  A.rew = p->rew_d;
+  A.x0 = in->x0_d; A.mx = in->mx_d; A.iSx = in->iSx_d; A.my = in->my_d; A.Sy = in->Sy_d;
+  A.pscale = in->pol_scale_d; A.pbias = in->pol_bias_d;
+  A.zpol = in->z_pol_d; A.zdyn = in->z_dyn_d; A.zmm = in->z_mm_d; A.zrr = in->z_rr_d;
+  if (!A.x0 || !A.mx || !A.iSx || !A.my || !A.Sy || !A.pscale || !A.pbias || !A.zpol || !A.zdyn)
+    return fail(-1, "null input pointer");
+  if ((c.flags & PMBRL_FLAG_MM_STATES) && !A.zmm) return fail(-1, "mm_states needs z_mm");
+  if ((c.flags & PMBRL_FLAG_MM_REWARDS) && !A.zrr) return fail(-1, "mm_rewards needs z_rr");
+  for (int l = 0; l < p->pol.nl; ++l) {
+    A.actT[l] = reinterpret_cast<float*>(ws + p->off_actT[l]);
+    A.gT[l] = reinterpret_cast<float*>(ws + p->off_gT[l]);
+  }
+  A.Tp = reinterpret_cast<float*>(ws + p->off_Tp);
+  A.Td = reinterpret_cast<float*>(ws + p->off_Td);
+  A.xt = reinterpret_cast<float*>(ws + p->off_xt);
+  A.rt = reinterpret_cast<float*>(ws + p->off_rt);
+  A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
+  return 0;
+}
+
+static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t s) {
+  for (int l = 0; l < n.nl; ++l) {
+    const int O = n.dim[l + 1], K = n.dim[l];
+    const size_t tot = (size_t)n.nt[l + 1] * n.nt[l] * 256;
+    const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 0,
+                       reinterpret_cast<float*>(ws + n.wf[l]));
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 1,
+                       reinterpret_cast<float*>(ws + n.wb[l]));
+    const int O16 = n.nt[l + 1] * 16;
+    hipLaunchKernelGGL(pm_pack_bias, dim3((O16 + 255) / 256), dim3(256), 0, s,
+                       params + n.b_off[l], O, O16, reinterpret_cast<float*>(ws + n.bias[l]));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int RT>
+static void launch_fwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  hipLaunchKernelGGL(pm_rollout_fwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+}
+template <int RT>
+static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+}
+static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  switch (p->RT) {
+    case 1: launch_fwd<1>(p, A, s); break;
+    case 2: launch_fwd<2>(p, A, s); break;
+    default: launch_fwd<4>(p, A, s); break;
+  }
+}
+static void launch_bwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  switch (p->RT) {
+    case 1: launch_bwd<1>(p, A, s); break;
+    case 2: launch_bwd<2>(p, A, s); break;
+    default: launch_bwd<4>(p, A, s); break;
+  }
+}
+
+extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
+                                 float* states_d, float* actions_d, float* rewards_d,
+                                 int32_t* status_d) {
+  if (!p || !workspace || !in || !states_d || !actions_d || !rewards_d || !status_d)
+    return fail(-1, "null argument");
+  if (!in->pol_params_d || !in->dyn_params_d) return fail(-1, "null parameter pointer");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(p->device));
+  RolloutArgs A;
+  int rc = fill_args(p, workspace, in, A);
+  if (rc) return rc;
+  A.states = states_d; A.actions = actions_d; A.rewards = rewards_d; A.status = status_d;
+  char* ws = static_cast<char*>(workspace);
+  rc = pack_net(p->pol, ws, in->pol_params_d, s);
+  if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
+  if (p->mm_mode != 2) {
+    launch_fwd_rt(p, A, s);
+  } else {
+    const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+    for (int t = 0; t < p->cfg.H; ++t) {
+      A.t0 = t; A.t1 = t + 1;
+      launch_fwd_rt(p, A, s);
+      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(64), smem, s, A, t);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
+                                 const float* states_d, const float* actions_d,
+                                 const float* rewards_d, const float* grad_rewards_d,
+                                 const float* grad_states_d, float* grad_pol_flat_d,
+                                 float* grad_x0_d, float* action_grad_norms_d) {
+  if (!p || !workspace || !in || !states_d || !actions_d || !rewards_d || !grad_rewards_d ||
+      !grad_pol_flat_d)
+    return fail(-1, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(p->device));
+  RolloutArgs A;
+  int rc = fill_args(p, workspace, in, A);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(workspace);
+  A.states = const_cast<float*>(states_d);
+  A.actions = const_cast<float*>(actions_d);
+  A.rewards = const_cast<float*>(rewards_d);
+  A.grad_rewards = grad_rewards_d;
+  A.grad_states = grad_states_d;
+  A.grad_x0 = grad_x0_d;
+  A.agn = action_grad_norms_d;
+  if (p->mm_mode != 2) {
+    A.gx_from_carry = 0;
+    launch_bwd_rt(p, A, s);
+  } else {
+    if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
+    float* grt = reinterpret_cast<float*>(ws + p->off_grt);
+    const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+    HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
+    RolloutArgs Am = A;
+    A.grad_rewards = grt;
+    A.gx_from_carry = 1;
+    for (int t = p->cfg.H - 1; t >= 0; --t) {
+      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t, grt);
+      A.t0 = t; A.t1 = t + 1;
+      launch_bwd_rt(p, A, s);
+    }
+  }
+  // dW GEMM over the stashes + deterministic reduction
+  DwArgs W;
+  memset(&W, 0, sizeof(W));
+  W.nl = p->pol.nl;
+  W.n_blocks = p->n_dw_blocks;
+  W.n_wg_per_split = p->dw_wg_per_split;
+  W.nsplit = p->dw_nsplit;
+  W.n_chunks = p->dw_n_chunks;
+  W.chunks_per_split = p->dw_chunks_per_split;
+  W.nwg_rollout = p->nwg;
+  W.RT = p->RT;
+  W.Rw = 16 * p->RT;
+  W.n_params = (int)p->pol.n_params;
+  for (int i = 0; i <= p->pol.nl; ++i) {
+    W.dim[i] = p->pol.dim[i];
+    W.nt[i] = p->pol.nt[i];
+  }
+  for (int l = 0; l < p->pol.nl; ++l) {
+    W.w_off[l] = (int)p->pol.w_off[l];
+    W.b_off[l] = (int)p->pol.b_off[l];
+    W.actT[l] = A.actT[l];
+    W.gT[l] = A.gT[l];
+  }
+  W.blocks = p->dw_blocks_d;
+  W.part = reinterpret_cast<float*>(ws + p->off_part);
+  hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_wg_per_split * p->dw_nsplit), dim3(PM_NT), 0, s, W);
+  const int n = (int)p->pol.n_params;
+  hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(256), 0, s, W.part, p->dw_nsplit, n,
+                     grad_pol_flat_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d, int64_t n,
+                                  float* out_d) {
+  if (!a_d || !w_d || !out_d || n < 0) return fail(-1, "bad argument");
+  hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a_d, w_d,
+                     (long long)n, out_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, float* exp_avg_d,
+                               float* exp_avg_sq_d, int64_t n, int64_t step, float lr, float beta1,
+                               float beta2, float eps, float max_norm, float* norm_out_d) {
+  if (!params_d || !grads_d || !exp_avg_d || !exp_avg_sq_d || n < 1 || step < 1)
+    return fail(-1, "bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params_d,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, lr, beta1, beta2, eps,
+                     (float)bc1, (float)sqrt(bc2), max_norm, norm_out_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// test hook: y = x W^T + b through gemm_tiles / gemm_narrow
+// ---------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(PM_NT, 1) void pm_debug_linear_kernel(const float* x, const float* wf,
+                                                                  const float* bias, int R, int K,
+                                                                  int O, int LD, int narrow,
+                                                                  float* y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int RR = 16 * RT;
+  float* X = smem;
+  float* Y = X + RR * LD;
+  float* part = Y + RR * LD;
+  const int n_kb = (K + 15) / 16, n_ot = (O + 15) / 16;
+  for (int i = tid; i < RR * LD; i += PM_NT) {
+    const int r = i / LD, k = i - r * LD;
+    X[i] = (r < R && k < K) ? x[(size_t)r * K + k] : 0.f;
+  }
+  __syncthreads();
+  if (narrow) {
+    gemm_narrow<RT>(wf, n_ot, n_kb, bias, X, Y, LD, part, wid, lane, tid);
+  } else {
+    EpiPlain e{bias, Y, LD, lane};
+    gemm_tiles<RT>(wf, n_ot, n_kb, X, LD, wid, lane, e);
+    __syncthreads();
+  }
+  for (int i = tid; i < R * O; i += PM_NT) {
+    const int r = i / O, o = i - r * O;
+    y[i] = Y[r * LD + o];
+  }
+}
+
+extern "C" int pmbrl_debug_linear(void* stream, const float* x_d, const float* W_d, const float* b_d,
+                                  int32_t R, int32_t K, int32_t O, int32_t transpose_w, float* y_d,
+                                  float* scratch_d) {
+  // transpose_w: treat W as [K_out... ] i.e. compute y = x W (W is [K][O] row-major = stored [in][out])
+  if (R < 1 || R > 64 || K < 1 || O < 1) return fail(-1, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_kb = (K + 15) / 16, n_ot = (O + 15) / 16;
+  const int LD = std::max(n_kb, n_ot) * 16 + 8;
+  float* wf = scratch_d;
+  float* bias = scratch_d + (size_t)n_ot * n_kb * 256;
+  const size_t tot = (size_t)n_ot * n_kb * 256;
+  const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
+  if (!transpose_w)
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, O, K, 0, wf);
+  else  // W_d is [K][O]: out feature index is the second one
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, K, O, 1, wf);
+  hipLaunchKernelGGL(pm_pack_bias, dim3((n_ot * 16 + 255) / 256), dim3(256), 0, s, b_d, O, n_ot * 16,
+                     bias);
+  const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
+  const size_t lds = ((size_t)2 * 16 * RT * LD + (size_t)PM_NW * PM_KS_NT * RT * 256) * sizeof(float);
+  const int narrow = n_ot <= PM_KS_NT ? 1 : 0;
+#define DBG_LAUNCH(RTV)                                                                         \
+  do {                                                                                          \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_debug_linear_kernel<RTV>),     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL(pm_debug_linear_kernel<RTV>, dim3(1), dim3(PM_NT), lds, s, x_d, wf, bias, R, \
+                       K, O, LD, narrow, y_d);                                                  \
+  } while (0)
+  if (RT == 1) DBG_LAUNCH(1);
+  else if (RT == 2) DBG_LAUNCH(2);
+  else DBG_LAUNCH(4);
+#undef DBG_LAUNCH
+  HIPCHK(hipGetLastError());
+  return 0;
+}

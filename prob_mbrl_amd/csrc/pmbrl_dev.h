@@ -1,0 +1,292 @@
+// Device-side building blocks shared by the rollout kernels (gfx950 only).
+//
+// The one matmul shape on this path is  out[R rows, O] = act[R, K] . W[O, K]^T
+// with R = 16..64 particle rows owned by one workgroup and W streamed from L2.
+// It is mapped on v_mfma_f32_16x16x4_f32 (exact fp32, 1e-4 parity bar) with the
+// WEIGHTS as the A operand and the ACTIVATIONS (transposed) as the B operand:
+//   A[i = out feature (lane&15)][k = lane>>4]   one f32 per lane
+//   B[k = lane>>4][j = particle row (lane&15)]  one f32 per lane
+//   D[i = 4*(lane>>4)+r][j = lane&15]           4 f32 per lane
+// so every lane ends up with 4 CONSECUTIVE output features of ONE particle row:
+// the epilogue (bias, ReLU, dropout bit, stash) is lane-local and the result
+// goes back to LDS as one 16-byte store.
+//
+// k-permutation: four consecutive MFMAs cover 16 k-values; lane group g=lane>>4
+// takes k = 16*kb + 4*g + j for the j-th MFMA.  Both operands use the same
+// permutation (the sum over k is order-free up to rounding), which makes each
+// lane's 4 operand values 16 contiguous bytes: one ds_read_b128 for the
+// activations, one global_load_dwordx4 for the (pre-packed) weights.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmbrl.h"
+
+#define PM_NW 4                 // waves per workgroup (one per SIMD)
+#define PM_NT (PM_NW * 64)      // threads per workgroup
+#define PM_MAXL PMBRL_MAX_LAYERS
+#define PM_KS_NT 3              // max out tiles handled by the K-split GEMM (< PM_NW)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NetDev {
+  int nl;                         // Linear layers
+  int dim[PM_MAXL + 1];           // true widths
+  int nt[PM_MAXL + 1];            // ceil(width / 16)
+  float keep[PM_MAXL];            // divide masked activations by this (1 = no-op)
+  const float* wf[PM_MAXL];       // forward fragments  [nt[l+1]][nt[l]][64][4]
+  const float* wb[PM_MAXL];       // transposed fragments [nt[l]][nt[l+1]][64][4]
+  const float* bias[PM_MAXL];     // zero-padded to nt[l+1]*16
+  const uint16_t* mask[PM_MAXL];  // dropout bits of hidden layer l: [B][nt[l+1]]
+  uint16_t* abits[PM_MAXL];       // stash: mask & (pre-activation > 0): [H][B][nt[l+1]]
+};
+
+// Reward constants (device copy, built at plan creation).
+struct RewardDev {
+  int kind, expand, n_angle, n_other, k, De;
+  int angle_dims[PMBRL_MAX_ANGLE];
+  int other_dims[PMBRL_MAX_DIM];
+  float C[PMBRL_MAX_TIP * PMBRL_MAX_DIM];   // [k][De], already divided by norm
+  float tt[PMBRL_MAX_TIP];                  // tip_target / norm
+  float w;
+  float Q[PMBRL_MAX_TIP * PMBRL_MAX_TIP];
+  float QQ[PMBRL_MAX_TIP * PMBRL_MAX_TIP];  // Q + Q^T
+  float R[16 * 16];
+  float RR[16 * 16];                        // R + R^T
+};
+
+struct RolloutArgs {
+  int B, D, U, H, Bg, row_off, flags;
+  int G, M;            // moment-matching groups on this device, rows per group
+  int mm_mode;         // 0 none, 1 in-kernel (group fits a workgroup), 2 external kernel
+  int t0, t1;          // step range of this launch
+  int rows_per_wg, nwg, Rw;   // Rw = 16*RT = stash block width
+  int LD;              // LDS leading dimension of the activation buffers (floats)
+  float mls_pol, mls_dyn;
+  NetDev pol, dyn;
+  const RewardDev* rew;
+  const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn, *zmm, *zrr;
+  float *states, *actions, *rewards;
+  float* actT[PM_MAXL];   // policy layer inputs, feature-major blocks [H][nwg][nt*16][Rw]
+  float* gT[PM_MAXL];     // policy pre-activation grads, same layout
+  float *Tp, *Td;         // [H][B][U], [H][B][D]
+  float *xt, *rt;         // pre-moment-matching next state / reward [H][B][D], [H][B]
+  int* status;
+  // backward only
+  const float *grad_rewards, *grad_states;
+  float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
+  int gx_from_carry;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+
+// ---------------------------------------------------------------------------
+// Tile-split GEMM: wave `wid` owns output tiles wid, wid+NW, ...; NT of them are
+// in flight at once (independent accumulator chains hide the 40-cycle dependent
+// MFMA latency) and weight fragments are double-buffered in registers in chunks
+// of CK=4 k-blocks (64 k-values), one chunk ahead of the MFMAs.
+//   wf      : fragment-packed weights  [n_ot][n_kb][64 lanes][4]
+//   lds_in  : activations [16*RT][ld]  (ld % 16 == 8 -> conflict-free b128 reads)
+//   epi(ot, rt, acc) : lane holds rows rt*16+(lane&15), features ot*16+4*(lane>>4)+r
+// ---------------------------------------------------------------------------
+#define PM_CK 4
+
+template <int RT, int NT>
+struct FragBuf {
+  f32x4 a[NT][PM_CK];
+};
+
+template <int RT, int NT, class Epi>
+__device__ __forceinline__ void gemm_tiles_group(const float* __restrict__ wf, int n_kb,
+                                                 int ot0, int n_ot, const float* lds_in,
+                                                 int ld, int lane, Epi& epi) {
+  const int arow = lane & 15, g = lane >> 4;
+  const float* bbase = lds_in + arow * ld + 4 * g;
+  f32x4 acc[NT][RT];
+  bool val[NT];
+  const float* wp[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int ot = ot0 + k * PM_NW;
+    val[k] = ot < n_ot;
+    wp[k] = wf + ((size_t)(val[k] ? ot : ot0) * n_kb) * 256 + lane * 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  FragBuf<RT, NT> f0, f1;
+
+  auto load = [&](FragBuf<RT, NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c) {
+      if (kb0 + c < n_kb) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+          if (val[k]) f.a[k][c] = ldg4(wp[k] + (size_t)(kb0 + c) * 256);
+      }
+    }
+  };
+  auto compute = [&](const FragBuf<RT, NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c) {
+      if (kb0 + c < n_kb) {
+        f32x4 b[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld + (kb0 + c) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            if (val[k]) {
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+                acc[k][rt] = mfma4(f.a[k][c][j], b[rt][j], acc[k][rt]);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  load(f0, 0);
+  for (int kb0 = 0; kb0 < n_kb; kb0 += 2 * PM_CK) {
+    load(f1, kb0 + PM_CK);
+    compute(f0, kb0);
+    load(f0, kb0 + 2 * PM_CK);
+    compute(f1, kb0 + PM_CK);
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (val[k]) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt]);
+    }
+  }
+}
+
+template <int RT, class Epi>
+__device__ __forceinline__ void gemm_tiles(const float* __restrict__ wf, int n_ot, int n_kb,
+                                           const float* lds_in, int ld, int wid, int lane,
+                                           Epi& epi) {
+  constexpr int NT = (RT >= 4) ? 1 : 2;
+  for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
+    gemm_tiles_group<RT, NT>(wf, n_kb, ot0, n_ot, lds_in, ld, lane, epi);
+}
+
+// ---------------------------------------------------------------------------
+// K-split GEMM for narrow outputs (n_ot <= PM_KS_NT tiles, e.g. the 2U / 2D
+// heads): every wave reduces its slice of k-blocks for ALL output tiles, the
+// partial tiles meet in LDS (`part`, [NW][PM_KS_NT][RT][64][4] floats) and are
+// summed in fixed wave order (deterministic) by gemm_ksplit_combine.
+// ---------------------------------------------------------------------------
+template <int RT>
+__device__ __forceinline__ void gemm_ksplit(const float* __restrict__ wf, int n_ot, int n_kb,
+                                            const float* lds_in, int ld, int wid, int lane,
+                                            float* part) {
+  const int arow = lane & 15, g = lane >> 4;
+  const float* bbase = lds_in + arow * ld + 4 * g;
+  const int per = (n_kb + PM_NW - 1) / PM_NW;
+  const int k_lo = wid * per;
+  const int k_hi = min(n_kb, k_lo + per);
+  f32x4 acc[PM_KS_NT][RT];
+#pragma unroll
+  for (int k = 0; k < PM_KS_NT; ++k)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb0 = k_lo; kb0 < k_hi; kb0 += PM_CK) {
+    f32x4 a[PM_KS_NT][PM_CK];
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c)
+      if (kb0 + c < k_hi) {
+#pragma unroll
+        for (int k = 0; k < PM_KS_NT; ++k)
+          if (k < n_ot) a[k][c] = ldg4(wf + ((size_t)k * n_kb + kb0 + c) * 256 + lane * 4);
+      }
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c)
+      if (kb0 + c < k_hi) {
+        f32x4 b[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld + (kb0 + c) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < PM_KS_NT; ++k)
+            if (k < n_ot) {
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) acc[k][rt] = mfma4(a[k][c][j], b[rt][j], acc[k][rt]);
+            }
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < PM_KS_NT; ++k)
+    if (k < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        *reinterpret_cast<f32x4*>(part + (((wid * PM_KS_NT + k) * RT + rt) * 64 + lane) * 4) =
+            acc[k][rt];
+    }
+}
+
+// after __syncthreads(): out[row][feature] = bias + sum_w part[w]; caller syncs after.
+template <int RT>
+__device__ __forceinline__ void gemm_ksplit_combine(const float* part, int n_ot,
+                                                    const float* bias, float* lds_out, int ld,
+                                                    int tid) {
+  for (int item = tid; item < n_ot * RT * 64; item += PM_NT) {
+    const int ln = item & 63;
+    const int rt = (item >> 6) % RT;
+    const int k = (item >> 6) / RT;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < PM_NW; ++w)
+      s += *reinterpret_cast<const f32x4*>(part + (((w * PM_KS_NT + k) * RT + rt) * 64 + ln) * 4);
+    const int f0 = k * 16 + 4 * (ln >> 4);
+    if (bias) s += ldg4(bias + f0);
+    *reinterpret_cast<f32x4*>(lds_out + (rt * 16 + (ln & 15)) * ld + f0) = s;
+  }
+}
+
+// plain "out = acc (+ bias)" epilogue of the tile-split GEMM (wide heads)
+struct EpiPlain {
+  const float* bias;
+  float* lds_out;
+  int ld, lane;
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+    const int f0 = ot * 16 + 4 * (lane >> 4);
+    if (bias) acc += ldg4(bias + f0);
+    *reinterpret_cast<f32x4*>(lds_out + (rt * 16 + (lane & 15)) * ld + f0) = acc;
+  }
+};
+
+// head / tail layer: picks K-split or tile-split by width.  Contains barriers:
+// must be called by all threads.  Result (with bias) in lds_out[row][0..n_ot*16).
+template <int RT>
+__device__ __forceinline__ void gemm_narrow(const float* __restrict__ wf, int n_ot, int n_kb,
+                                            const float* bias, const float* lds_in,
+                                            float* lds_out, int ld, float* part, int wid,
+                                            int lane, int tid) {
+  if (n_ot <= PM_KS_NT) {
+    gemm_ksplit<RT>(wf, n_ot, n_kb, lds_in, ld, wid, lane, part);
+    __syncthreads();
+    gemm_ksplit_combine<RT>(part, n_ot, bias, lds_out, ld, tid);
+  } else {
+    EpiPlain e{bias, lds_out, ld, lane};
+    gemm_tiles<RT>(wf, n_ot, n_kb, lds_in, ld, wid, lane, e);
+  }
+  __syncthreads();
+}
+
+// numerically careful scalar helpers (match torch CPU within fp32 rounding)
+__device__ __forceinline__ float softplusf(float x) {
+  // torch.nn.functional.softplus, threshold 20 (models/densities.py:97)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }

@@ -1,0 +1,193 @@
+// Moment matching (utils/rollout.py:20-29, mm_resample_) and its adjoint
+// (SURVEY.md Appendix A), one WAVEFRONT per group.
+//
+//   m = mean(s); Delta = s - m; S = Delta^T Delta/(M-1) + 1e-12 I; L = chol(S)
+//   zhat = (z - mean z)/std_unbiased(z)   (constant w.r.t. the gradient)
+//   out = m + zhat L^T
+//
+// The statistics, the Cholesky factor and the adjoint's two triangular solves
+// are carried in fp64: the reference's own fp32 result is ill-conditioned here
+// (the 1x1 reward "covariance" underflows when a group's rewards are nearly
+// equal and the adjoint divides by it), fp64 on a dxd matrix per group is free
+// on this part, and it moves the result towards the fp64 reference rather than
+// away from it.  Rows may live in LDS or in HBM (generic pointers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+__host__ __device__ inline size_t pm_mm_scratch_doubles(int d) {
+  return d > 0 ? (size_t)3 * d * d + 4 * d : 0;
+}
+
+// LDS traffic between lanes of ONE wave: make prior writes visible / ordered.
+__device__ __forceinline__ void pm_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct MMScratch {
+  double *mean, *zmean, *zistd, *mbar, *Lm, *P, *Sb;
+};
+__device__ inline MMScratch pm_mm_carve(double* scr, int d) {
+  MMScratch s;
+  s.mean = scr;
+  s.zmean = s.mean + d;
+  s.zistd = s.zmean + d;
+  s.mbar = s.zistd + d;
+  s.Lm = s.mbar + d;
+  s.P = s.Lm + d * d;
+  s.Sb = s.P + d * d;
+  return s;
+}
+
+// cyclic noise row of utils/rollout.py:53-59
+__device__ __forceinline__ int pm_zidx(int zrow0, int i, int Bg) { return (zrow0 + i) % Bg; }
+
+// means, z standardisation, covariance and its Cholesky factor.  Returns false
+// (wave-uniform) on a non-positive pivot.
+__device__ inline bool pm_mm_factor(const float* s, int s_ld, int M, int d, const float* z,
+                                    int z_ld, int zrow0, int Bg, const MMScratch& q, int lane) {
+  for (int j = lane; j < d; j += 64) {
+    double m = 0.0, zm = 0.0;
+    for (int i = 0; i < M; ++i) {
+      m += (double)s[i * s_ld + j];
+      zm += (double)z[(size_t)pm_zidx(zrow0, i, Bg) * z_ld + j];
+    }
+    m /= M;
+    zm /= M;
+    double zv = 0.0;
+    for (int i = 0; i < M; ++i) {
+      const double t = (double)z[(size_t)pm_zidx(zrow0, i, Bg) * z_ld + j] - zm;
+      zv += t * t;
+    }
+    q.mean[j] = m;
+    q.zmean[j] = zm;
+    q.zistd[j] = 1.0 / sqrt(zv / (M - 1));
+  }
+  pm_wave_sync();
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    double acc = 0.0;
+    if (j <= i) {
+      const double mi = q.mean[i], mj = q.mean[j];
+      for (int r = 0; r < M; ++r)
+        acc += ((double)s[r * s_ld + i] - mi) * ((double)s[r * s_ld + j] - mj);
+      acc = acc / (M - 1) + (i == j ? 1e-12 : 0.0);
+    }
+    q.Lm[e] = acc;
+  }
+  pm_wave_sync();
+  // The reference factors in fp32 and raises (-> RuntimeError, utils/rollout.py:154-157)
+  // when a pivot is lost to rounding; reproduce that contract: a pivot that has shed
+  // more than fp32 precision relative to its diagonal entry counts as non-positive.
+  for (int j = lane; j < d; j += 64) q.mbar[j] = q.Lm[j * d + j];
+  pm_wave_sync();
+  bool ok = true;
+  for (int k = 0; k < d; ++k) {
+    double piv = q.Lm[k * d + k];
+    if (!(piv > 6e-8 * q.mbar[k])) {
+      ok = false;
+      piv = 1.0;
+    }
+    const double lkk = sqrt(piv);
+    pm_wave_sync();   // everyone has read the pivot before lane 0 overwrites it
+    for (int i = k + 1 + lane; i < d; i += 64) q.Lm[i * d + k] /= lkk;
+    if (lane == 0) q.Lm[k * d + k] = lkk;
+    pm_wave_sync();
+    for (int e = lane; e < d * d; e += 64) {
+      const int i = e / d, j = e - i * d;
+      if (j > k && j <= i) q.Lm[e] -= q.Lm[i * d + k] * q.Lm[j * d + k];
+    }
+    pm_wave_sync();
+  }
+  return ok;
+}
+
+__device__ inline bool pm_mm_fwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
+                                 int zrow0, int Bg, bool infer_ns, float* out, int out_ld,
+                                 double* scr, int lane) {
+  (void)infer_ns;   // value of the infer_ns variant equals s; not offered on the device path
+  const MMScratch q = pm_mm_carve(scr, d);
+  const bool ok = pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
+  for (int e = lane; e < M * d; e += 64) {
+    const int r = e / d, j = e - r * d;
+    double acc = q.mean[j];
+    const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
+    for (int c = 0; c <= j; ++c)
+      acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * d + c];
+    out[r * out_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
+  return ok;
+}
+
+// g: upstream dL/d out [M][d]; gout: dL/d s [M][d] (may alias g).
+__device__ inline void pm_mm_bwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
+                                 int zrow0, int Bg, bool infer_ns, const float* g, int g_ld,
+                                 float* gout, int gout_ld, double* scr, int lane) {
+  (void)infer_ns;
+  const MMScratch q = pm_mm_carve(scr, d);
+  (void)pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
+  // mbar = sum_r g ;  Lbar = tril(g^T zhat)  -> q.P
+  for (int j = lane; j < d; j += 64) {
+    double a = 0.0;
+    for (int r = 0; r < M; ++r) a += (double)g[r * g_ld + j];
+    q.mbar[j] = a;
+  }
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    double acc = 0.0;
+    if (j <= i) {
+      const double zm = q.zmean[j], zs = q.zistd[j];
+      for (int r = 0; r < M; ++r)
+        acc += (double)g[r * g_ld + i] *
+               (((double)z[(size_t)pm_zidx(zrow0, r, Bg) * z_ld + j] - zm) * zs);
+    }
+    q.P[e] = acc;
+  }
+  pm_wave_sync();
+  // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    double acc = 0.0;
+    if (j <= i) {
+      for (int c = i; c < d; ++c) acc += q.Lm[c * d + i] * q.P[c * d + j];
+      if (i == j) acc *= 0.5;
+    }
+    q.Sb[e] = acc;
+  }
+  pm_wave_sync();
+  // X = Phi L^-1  (row i of X solves x L = phi_i), in place in q.Sb
+  for (int i = lane; i < d; i += 64) {
+    for (int j = d - 1; j >= 0; --j) {
+      double a = q.Sb[i * d + j];
+      for (int c = j + 1; c < d; ++c) a -= q.Sb[i * d + c] * q.Lm[c * d + j];
+      q.Sb[i * d + j] = a / q.Lm[j * d + j];
+    }
+  }
+  pm_wave_sync();
+  // Sbar = L^-T X  (column j solves L^T y = x_j), in place
+  for (int j = lane; j < d; j += 64) {
+    for (int i = d - 1; i >= 0; --i) {
+      double a = q.Sb[i * d + j];
+      for (int c = i + 1; c < d; ++c) a -= q.Lm[c * d + i] * q.Sb[c * d + j];
+      q.Sb[i * d + j] = a / q.Lm[i * d + i];
+    }
+  }
+  pm_wave_sync();
+  // symmetrise into q.P:  P = (Sbar + Sbar^T) / (M-1)   (= 2 * sym(Sbar) / (M-1))
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) / (double)(M - 1);
+  }
+  pm_wave_sync();
+  // sbar[r][j] = sum_c Delta[r][c] P[c][j] + mbar[j]/M      (mean_r of the first term is 0)
+  for (int e = lane; e < M * d; e += 64) {
+    const int r = e / d, j = e - r * d;
+    double acc = q.mbar[j] / M;
+    for (int c = 0; c < d; ++c) acc += ((double)s[r * s_ld + c] - q.mean[c]) * q.P[c * d + j];
+    // all reads of g happened before the first pm_wave_sync above: in-place is safe
+    gout[r * gout_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
+}

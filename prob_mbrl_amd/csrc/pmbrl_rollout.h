@@ -1,0 +1,562 @@
+// Fused H-step rollout kernels: one workgroup owns `rows_per_wg` particle rows
+// for ALL time steps (rows are independent except inside a moment-matching
+// group, and a workgroup always owns whole groups), so the whole rollout is ONE
+// launch with no grid-wide synchronisation.  The particle state never leaves
+// LDS between steps; HBM sees only the trajectory outputs and the stashes the
+// backward sweep / dW GEMM consume.
+#pragma once
+#include "pmbrl_dev.h"
+#include "pmbrl_mm.h"
+
+// ---------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------
+// hidden layer, forward:  h = relu(acc + b) * mask / keep     (models/modules.py:46-61,120-160)
+struct EpiHiddenFwd {
+  const float* bias;
+  const uint16_t* mask;   // [B][nt]
+  uint16_t* abits;        // [B][nt] slice of step t
+  float keep;
+  float* lds_out;
+  float* stash;           // feature-major block [nt*16][Rw] or nullptr
+  int ld, Rw, row0, nvalid, nt, lane;
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+    const int g = lane >> 4;
+    const int lrow = rt * 16 + (lane & 15);
+    const int f0 = ot * 16 + 4 * g;
+    const f32x4 b = ldg4(bias + f0);
+    const bool valid = lrow < nvalid;
+    unsigned mw = 0;
+    if (valid) mw = mask[(size_t)(row0 + lrow) * nt + ot];
+    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    f32x4 h;
+    unsigned act = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[r] + b[r];
+      const bool a = ((nib >> r) & 1u) && (v > 0.f);
+      h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
+      act |= (a ? 1u : 0u) << r;
+    }
+    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if (stash) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+    }
+    unsigned w16 = act << (4 * g);
+    w16 |= __shfl_xor(w16, 16);
+    w16 |= __shfl_xor(w16, 32);
+    if (g == 0 && valid) abits[(size_t)(row0 + lrow) * nt + ot] = (uint16_t)w16;
+  }
+};
+
+// hidden layer, backward: g_pre = active ? acc / keep : 0
+struct EpiHiddenBwd {
+  const uint16_t* abits;  // [B][nt] slice of step t
+  float keep;
+  float* lds_out;
+  float* stash;           // gT block or nullptr
+  int ld, Rw, row0, nvalid, nt, lane;
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+    const int g = lane >> 4;
+    const int lrow = rt * 16 + (lane & 15);
+    const int f0 = ot * 16 + 4 * g;
+    unsigned mw = 0;
+    if (lrow < nvalid) mw = abits[(size_t)(row0 + lrow) * nt + ot];
+    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
+    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if (stash) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// reward (envs/<env>/env.py:*Reward.forward); one thread per row
+// ---------------------------------------------------------------------------
+__device__ inline float reward_row(const RewardDev* __restrict__ rw, const float* x, int D,
+                                   const float* a, int U, float* delta_out) {
+  float phi[PMBRL_MAX_DIM];
+  int De;
+  if (rw->expand) {
+    const int no = rw->n_other, na = rw->n_angle;
+    for (int i = 0; i < no; ++i) phi[i] = x[rw->other_dims[i]];
+    for (int j = 0; j < na; ++j) {
+      const float th = x[rw->angle_dims[j]];
+      phi[no + j] = sinf(th);
+      phi[no + na + j] = cosf(th);
+    }
+    De = no + 2 * na;
+  } else {
+    for (int i = 0; i < D; ++i) phi[i] = x[i];
+    De = D;
+  }
+  const int k = rw->k;
+  float delta[PMBRL_MAX_TIP];
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < De; ++j) s = fmaf(phi[j], rw->C[i * De + j], s);
+    delta[i] = s - rw->tt[i];
+    if (delta_out) delta_out[i] = delta[i];
+  }
+  float cost = 0.f;
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s = fmaf(delta[j], rw->Q[j * k + i], s);
+    cost = fmaf(s, delta[i], cost);
+  }
+  for (int i = 0; i < U; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->R[j * U + i], s);
+    cost = fmaf(s, a[i], cost);
+  }
+  cost *= rw->w;
+  return rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
+}
+
+// adjoint of reward_row: adds d r / d x into gx[D], writes d r / d a into ga[U],
+// both scaled by the upstream gr.
+__device__ inline void reward_row_bwd(const RewardDev* __restrict__ rw, const float* x, int D,
+                                      const float* a, int U, float r, float gr, float* gx,
+                                      float* ga) {
+  float delta[PMBRL_MAX_TIP];
+  (void)reward_row(rw, x, D, a, U, delta);   // recompute delta (cheap)
+  const float gc = (rw->kind == PMBRL_REWARD_EXP ? -gr * r : -gr) * rw->w;
+  const int k = rw->k;
+  const int De = rw->expand ? rw->n_other + 2 * rw->n_angle : D;
+  float gdelta[PMBRL_MAX_TIP];
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s = fmaf(delta[j], rw->QQ[j * k + i], s);
+    gdelta[i] = gc * s;
+  }
+  for (int i = 0; i < U; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->RR[j * U + i], s);
+    ga[i] = gc * s;
+  }
+  float gphi[PMBRL_MAX_DIM];
+  for (int j = 0; j < De; ++j) {
+    float s = 0.f;
+    for (int i = 0; i < k; ++i) s = fmaf(gdelta[i], rw->C[i * De + j], s);
+    gphi[j] = s;
+  }
+  if (rw->expand) {
+    const int no = rw->n_other, na = rw->n_angle;
+    for (int i = 0; i < no; ++i) gx[rw->other_dims[i]] += gphi[i];
+    for (int j = 0; j < na; ++j) {
+      const float th = x[rw->angle_dims[j]];
+      gx[rw->angle_dims[j]] += gphi[no + j] * cosf(th) - gphi[no + na + j] * sinf(th);
+    }
+  } else {
+    for (int i = 0; i < D; ++i) gx[i] += gphi[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LDS carve-up (floats).  Must match pmbrl_lds_floats() on the host.
+// ---------------------------------------------------------------------------
+struct LdsMap {
+  float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr, *part;
+  double* mm;
+};
+__host__ __device__ inline size_t pm_lds_floats(int R, int LD, int D, int U, int RT, int mm_d) {
+  size_t n = 2 * (size_t)R * LD;          // bufA, bufB
+  n += 2 * (size_t)R * D;                 // xa, xb
+  n += (size_t)R * U;                     // av
+  n += (size_t)R * 16;                    // gad (action gradient, U <= 16)
+  n += 2 * (size_t)R;                     // rr, gr
+  n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials
+  n = (n + 3) & ~(size_t)3;
+  n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);  // per-wave fp64 scratch
+  return n;
+}
+__device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, int RT) {
+  LdsMap m;
+  m.bufA = base;
+  m.bufB = m.bufA + (size_t)R * LD;
+  m.xa = m.bufB + (size_t)R * LD;
+  m.xb = m.xa + (size_t)R * D;
+  m.av = m.xb + (size_t)R * D;
+  m.gad = m.av + (size_t)R * U;
+  m.rr = m.gad + (size_t)R * 16;
+  m.gr = m.rr + R;
+  m.part = m.gr + R;
+  size_t n = (size_t)(m.part - base) + (size_t)PM_NW * PM_KS_NT * RT * 256;
+  n = (n + 3) & ~(size_t)3;
+  m.mm = reinterpret_cast<double*>(base + n);
+  return m;
+}
+
+// ===========================================================================
+// forward
+// ===========================================================================
+template <int RT>
+__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row0 = wg * A.rows_per_wg;
+  const int nvalid = min(A.rows_per_wg, A.B - row0);
+  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT);
+  float* xa = L.xa;   // current state x_t
+  float* xb = L.xb;   // pre-moment-matching next state
+
+  // initial state (states[t0] is x0 for t0 == 0, the previous launch's output otherwise)
+  {
+    const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
+    for (int i = tid; i < R * D; i += PM_NT) {
+      const int r = i / D, d = i - r * D;
+      const float v = (r < nvalid) ? src[(size_t)(row0 + r) * D + d] : 0.f;
+      xa[i] = v;
+      if (A.t0 == 0 && r < nvalid) A.states[(size_t)(row0 + r) * D + d] = v;
+    }
+  }
+  __syncthreads();
+
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+
+  for (int t = A.t0; t < A.t1; ++t) {
+    const size_t blk = (size_t)t * A.nwg + wg;
+    float* X = L.bufA;
+    float* Y = L.bufB;
+    // ---- policy input (no normalisation in Policy.forward, models/core.py:221-248)
+    {
+      const int K16 = P.nt[0] * 16;
+      float* st = A.actT[0] + blk * (size_t)K16 * A.Rw;
+      for (int i = tid; i < R * K16; i += PM_NT) {
+        const int k = i / R, r = i - k * R;
+        const float v = (k < D) ? xa[r * D + k] : 0.f;
+        X[r * LD + k] = v;
+        st[(size_t)k * A.Rw + r] = v;
+      }
+    }
+    __syncthreads();
+    // ---- policy hidden layers
+    for (int l = 0; l < P.nl - 1; ++l) {
+      const int nt = P.nt[l + 1];
+      EpiHiddenFwd e{P.bias[l], P.mask[l], P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+                     A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
+      gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
+      __syncthreads();
+      float* tmp = X; X = Y; Y = tmp;
+    }
+    // ---- policy head -> Y[r][0..2U)
+    gemm_narrow<RT>(P.wf[P.nl - 1], P.nt[P.nl], P.nt[P.nl - 1], P.bias[P.nl - 1], X, Y, LD, L.part,
+                    wid, lane, tid);
+    // ---- squash + dynamics input (models/densities.py:87-121, models/core.py:243,169-177)
+    {
+      const int K16 = F.nt[0] * 16;
+      for (int i = tid; i < R * K16; i += PM_NT) {
+        const int r = i / K16, k = i - r * K16;
+        float v = 0.f;
+        if (k < D) {
+          v = (xa[r * D + k] - A.mx[k]) * A.iSx[k];
+        } else if (k < D + U) {
+          const int j = k - D;
+          const float mu = Y[r * LD + j];
+          const float ls = Y[r * LD + U + j];
+          const float z = (r < nvalid) ? A.zpol[(size_t)(row0 + r) * U + j] : 0.f;
+          const float lc = -softplusf(-ls + A.mls_pol) + A.mls_pol;
+          const float e = expf(lc);
+          const float u = mu + z * e;
+          const float a = A.pscale[j] * tanhf(u) + A.pbias[j];
+          L.av[r * U + j] = a;
+          if (r < nvalid) {
+            const size_t o = ((size_t)t * B + row0 + r) * U + j;
+            A.actions[o] = a;
+            A.Tp[o] = z * e * sigmoidf(-ls + A.mls_pol);
+          }
+          v = (a - A.mx[k]) * A.iSx[k];
+        }
+        X[r * LD + k] = v;
+      }
+    }
+    __syncthreads();
+    // ---- dynamics hidden layers
+    for (int l = 0; l < F.nl - 1; ++l) {
+      const int nt = F.nt[l + 1];
+      EpiHiddenFwd e{F.bias[l], F.mask[l], F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
+                     nullptr, LD, A.Rw, row0, nvalid, nt, lane};
+      gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
+      __syncthreads();
+      float* tmp = X; X = Y; Y = tmp;
+    }
+    // ---- dynamics head -> Y[r][0..2D)
+    gemm_narrow<RT>(F.wf[F.nl - 1], F.nt[F.nl], F.nt[F.nl - 1], F.bias[F.nl - 1], X, Y, LD, L.part,
+                    wid, lane, tid);
+    // ---- sample next state (models/densities.py:97-121 with scaling_params, core.py:298)
+    for (int i = tid; i < R * D; i += PM_NT) {
+      const int r = i / D, d = i - r * D;
+      const float mu = Y[r * LD + d];
+      const float ls = Y[r * LD + D + d];
+      const float z = (r < nvalid) ? A.zdyn[(size_t)(row0 + r) * D + d] : 0.f;
+      const float Sy = A.Sy[d];
+      const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + logf(Sy);
+      const float e = expf(lc);
+      const float xn = xa[i] + (mu * Sy + A.my[d] + z * e);
+      xb[i] = xn;
+      if (r < nvalid) {
+        const size_t o = ((size_t)t * B + row0 + r) * D + d;
+        A.Td[o] = z * e * sigmoidf(-ls + A.mls_dyn);
+        if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
+        else A.states[o + (size_t)B * D] = xn;
+      }
+    }
+    __syncthreads();
+    // ---- reward on the sampled (pre-mm) next state; failure detection
+    for (int r = tid; r < R; r += PM_NT) {
+      float rv = 0.f;
+      if (r < nvalid) {
+        rv = reward_row(A.rew, xb + r * D, D, L.av + r * U, U, nullptr);
+        bool ok = isfinite(rv);
+        for (int d = 0; d < D; ++d) ok = ok && isfinite(xb[r * D + d]);
+        if (!ok) atomicMin(A.status, t);
+        const size_t o = (size_t)t * B + row0 + r;
+        if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
+        else A.rewards[o] = rv;
+      }
+      L.rr[r] = rv;
+    }
+    if (A.mm_mode == 1) {
+      __syncthreads();
+      // moment matching inside the workgroup (utils/rollout.py:121-145)
+      const int gpw = A.rows_per_wg / A.M;   // whole groups per workgroup
+      for (int gi = wid; gi < gpw; gi += PM_NW) {
+        const int lr0 = gi * A.M;
+        if (lr0 >= nvalid) break;
+        double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
+        if (A.flags & PMBRL_FLAG_MM_STATES) {
+          const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, A.zmm, D, t + A.row_off + row0 + lr0,
+                                    A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0, xa + lr0 * D, D,
+                                    scr, lane);
+          if (!ok && lane == 0) atomicMin(A.status, t);
+        }
+        if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+          const bool ok = pm_mm_fwd(L.rr + lr0, 1, A.M, 1, A.zrr, 1, t + A.row_off + row0 + lr0,
+                                    A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0, L.gr + lr0, 1,
+                                    scr, lane);
+          if (!ok && lane == 0) atomicMin(A.status, t);
+        }
+      }
+      __syncthreads();
+      // publish the moment-matched results
+      if (A.flags & PMBRL_FLAG_MM_STATES) {
+        for (int i = tid; i < nvalid * D; i += PM_NT)
+          A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
+      }
+      if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+        for (int r = tid; r < nvalid; r += PM_NT) A.rewards[(size_t)t * B + row0 + r] = L.gr[r];
+      }
+      if (!(A.flags & PMBRL_FLAG_MM_STATES)) {
+        float* tmp = xa; xa = xb; xb = tmp;
+      }
+    } else {
+      float* tmp = xa; xa = xb; xb = tmp;
+    }
+    __syncthreads();
+  }
+}
+
+// ===========================================================================
+// backward sweep.  Produces the G stash consumed by the
+// dW GEMM; policy dW/db are NOT accumulated here.
+// ===========================================================================
+template <int RT>
+__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row0 = wg * A.rows_per_wg;
+  const int nvalid = min(A.rows_per_wg, A.B - row0);
+  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT);
+  float* gx = L.xa;    // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
+  float* gxt = L.xb;   // dL/dx~ (pre-mm next state)
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+  const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
+  const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+
+  // dL/dx_H: zero, the carried value from the previous launch, or the terminal grad_states
+  for (int i = tid; i < R * D; i += PM_NT) {
+    const int r = i / D, d = i - r * D;
+    float v = 0.f;
+    if (r < nvalid) {
+      if (A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
+      else if (A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
+    }
+    gx[i] = v;
+  }
+  __syncthreads();
+
+  for (int t = A.t1 - 1; t >= A.t0; --t) {
+    const size_t blk = (size_t)t * A.nwg + wg;
+    float* X = L.bufA;
+    float* Y = L.bufB;
+    // ---- load x~ rows (for reward / mm recompute) into Y scratch columns, actions, upstream gr
+    //      Y[r][0..D) = x~ ; L.av = a ; L.gr = dL/dr ; L.rr = r~
+    {
+      const float* xsrc = mms ? A.xt + (size_t)t * B * D : A.states + (size_t)(t + 1) * B * D;
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, d = i - r * D;
+        Y[r * LD + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
+      }
+      for (int i = tid; i < R * U; i += PM_NT) {
+        const int r = i / U;
+        L.av[i] = (r < nvalid) ? A.actions[((size_t)t * B + row0) * U + i] : 0.f;
+      }
+      const float* rsrc = mmr ? A.rt : A.rewards;
+      for (int r = tid; r < R; r += PM_NT) {
+        const bool v = r < nvalid;
+        L.gr[r] = v ? A.grad_rewards[(size_t)t * B + row0 + r] : 0.f;
+        L.rr[r] = v ? rsrc[(size_t)t * B + row0 + r] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- adjoint of moment matching (in-kernel groups)
+    if (A.mm_mode == 1) {
+      const int gpw = A.rows_per_wg / A.M;
+      for (int gi = wid; gi < gpw; gi += PM_NW) {
+        const int lr0 = gi * A.M;
+        if (lr0 >= nvalid) break;
+        double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
+        if (mms)
+          pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, A.zmm, D, t + A.row_off + row0 + lr0, A.Bg,
+                    (A.flags & PMBRL_FLAG_INFER_NS) != 0, gx + lr0 * D, D, gxt + lr0 * D, D, scr,
+                    lane);
+        if (mmr)
+          pm_mm_bwd(L.rr + lr0, 1, A.M, 1, A.zrr, 1, t + A.row_off + row0 + lr0, A.Bg,
+                    (A.flags & PMBRL_FLAG_INFER_NS) != 0, L.gr + lr0, 1, L.gr + lr0, 1, scr, lane);
+      }
+      __syncthreads();
+      if (!mms) {
+        for (int i = tid; i < R * D; i += PM_NT) gxt[i] = gx[i];
+        __syncthreads();
+      }
+    } else if (A.mm_mode == 2) {
+      // external mm-adjoint kernel already turned (gx_carry, grad_rewards) into
+      // (dL/dx~, dL/dr~): gx holds dL/dx~ and L.gr holds dL/dr~ here.
+      for (int i = tid; i < R * D; i += PM_NT) gxt[i] = gx[i];
+      __syncthreads();
+    } else {
+      for (int i = tid; i < R * D; i += PM_NT) gxt[i] = gx[i];
+      __syncthreads();
+    }
+    // ---- reward adjoint: gxt += dr/dx~ * gr ; ga_direct -> X scratch column block
+    //      (X[r][0..U) holds the direct action gradient until phase B)
+    for (int r = tid; r < R; r += PM_NT) {
+      float ga[16];
+      float xrow[PMBRL_MAX_DIM], gxr[PMBRL_MAX_DIM];
+      for (int j = 0; j < U; ++j) ga[j] = 0.f;
+      if (r < nvalid) {
+        for (int d = 0; d < D; ++d) { xrow[d] = Y[r * LD + d]; gxr[d] = 0.f; }
+        reward_row_bwd(A.rew, xrow, D, L.av + r * U, U, L.rr[r], L.gr[r], gxr, ga);
+        for (int d = 0; d < D; ++d) gxt[r * D + d] += gxr[d];
+      }
+      for (int j = 0; j < U; ++j) L.gad[r * 16 + j] = ga[j];
+    }
+    __syncthreads();
+    // ---- dynamics head adjoint input: [gxt*Sy | gxt*Td | 0] -> X
+    {
+      const int K16 = F.nt[F.nl] * 16;
+      for (int i = tid; i < R * K16; i += PM_NT) {
+        const int r = i / K16, k = i - r * K16;
+        float v = 0.f;
+        if (r < nvalid) {
+          if (k < D) v = gxt[r * D + k] * A.Sy[k];
+          else if (k < 2 * D) v = gxt[r * D + k - D] * A.Td[((size_t)t * B + row0 + r) * D + k - D];
+        }
+        X[r * LD + k] = v;
+      }
+    }
+    __syncthreads();
+    // ---- dynamics trunk, dX only (weights frozen: no dV)
+    for (int l = F.nl - 1; l >= 1; --l) {
+      const int nt = F.nt[l];
+      EpiHiddenBwd e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw,
+                     row0, nvalid, nt, lane};
+      gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
+      __syncthreads();
+      float* tmp = X; X = Y; Y = tmp;
+    }
+    // grad wrt normalised dynamics input [x | a] -> Y[r][0..D+U)
+    gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    // ---- phase B: split into state / action parts; policy head adjoint -> X
+    {
+      const int K16 = P.nt[P.nl] * 16;
+      float* gst = A.gT[P.nl - 1] + blk * (size_t)K16 * A.Rw;
+      const int W = max(K16, D + U);
+      for (int i = tid; i < R * W; i += PM_NT) {
+        const int r = i / W, k = i - r * W;
+        if (k < D) {
+          gxt[r * D + k] += Y[r * LD + k] * A.iSx[k];     // dL/dx_t via identity + dynamics input
+        } else if (k < D + U) {
+          const int j = k - D;
+          float go_mu = 0.f, go_ls = 0.f;
+          if (r < nvalid) {
+            const float ga = L.gad[r * 16 + j] + Y[r * LD + k] * A.iSx[k];
+            L.gad[r * 16 + j] = ga;   // total dL/da_t (for the priority hook below)
+            const float sc = A.pscale[j];
+            const float th = (L.av[r * U + j] - A.pbias[j]) / sc;
+            const float gu = ga * sc * (1.f - th * th);
+            go_mu = gu;
+            go_ls = gu * A.Tp[((size_t)t * B + row0 + r) * U + j];
+          }
+          X[r * LD + j] = go_mu;
+          X[r * LD + U + j] = go_ls;
+          gst[(size_t)j * A.Rw + r] = go_mu;
+          gst[(size_t)(U + j) * A.Rw + r] = go_ls;
+        }
+        // zero the K-padding of the head-gradient tile (columns 2U..K16)
+        if (k >= 2 * U && k < K16) {
+          X[r * LD + k] = 0.f;
+          gst[(size_t)k * A.Rw + r] = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (A.agn) {   // ||dL/da_t|| per row: the prioritised-replay hook (mc_pilco.py:156-188)
+      for (int r = tid; r < nvalid; r += PM_NT) {
+        float s2 = 0.f;
+        for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
+        A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
+      }
+    }
+    // ---- policy trunk: dX chain + G stash
+    for (int l = P.nl - 1; l >= 1; --l) {
+      const int nt = P.nt[l];
+      EpiHiddenBwd e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
+                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
+      gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
+      __syncthreads();
+      float* tmp = X; X = Y; Y = tmp;
+    }
+    gemm_narrow<RT>(P.wb[0], P.nt[0], P.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    // ---- phase C: dL/dx_t
+    for (int i = tid; i < R * D; i += PM_NT) {
+      const int r = i / D, d = i - r * D;
+      float v = gxt[i] + Y[r * LD + d];
+      if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
+      gx[i] = v;
+    }
+    __syncthreads();
+  }
+  // hand dL/dx_{t0} to the next launch / the caller
+  for (int i = tid; i < nvalid * D; i += PM_NT) {
+    const size_t o = (size_t)row0 * D + i;
+    if (A.gx_carry) A.gx_carry[o] = gx[i];
+    if (A.t0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
+  }
+}

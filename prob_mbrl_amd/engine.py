@@ -1,0 +1,236 @@
+"""Thin Python wrapper over one pmbrl plan: owns the workspace and trajectory
+tensors (torch tensors are device storage only) and issues the C-ABI calls on
+torch's current HIP stream."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LOG_MAX_STD = math.log(5.0)   # reference models/densities.py:75
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, device):
+    """float32, contiguous, on device (no copy when already so)."""
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+def pack_mask(mask):
+    """{0,1} float mask [B,h] (any row stride) -> int16 tensor [B, ceil(h/16)] of
+    little-endian bit rows (pmbrl_pack_mask)."""
+    lib = _lib.load()
+    assert mask.is_cuda and mask.dim() == 2 and mask.dtype == torch.float32
+    if mask.stride(1) != 1:
+        mask = mask.contiguous()
+    B, h = mask.shape
+    bits = torch.empty((B, (h + 15) // 16), dtype=torch.int16, device=mask.device)
+    _lib.check(lib.pmbrl_pack_mask(_stream(), _ptr(mask), B, h, mask.stride(0),
+                                   _ptr(bits)), 'pmbrl_pack_mask')
+    return bits
+
+
+def make_reward_struct(spec, D, U):
+    """spec: dict(kind, expand, angle_dims, C [k,De], tip_target [k], norm, w,
+    Q [k,k], R [U,U]) with numpy / float entries."""
+    r = _lib.Reward()
+    r.kind = _lib.REWARD_EXP if spec['kind'] == 'exp' else _lib.REWARD_NEG
+    r.expand = 1 if spec['expand'] else 0
+    ad = [int(a) for a in spec['angle_dims']] if spec['expand'] else []
+    r.n_angle = len(ad)
+    for i, a in enumerate(ad):
+        r.angle_dims[i] = a
+    Cm = np.asarray(spec['C'], dtype=np.float32)
+    k, De = Cm.shape
+    assert De == D + len(ad), 'reward C has %d columns, expected %d' % (De, D + len(ad))
+    assert k <= _lib.MAX_TIP and De <= _lib.MAX_DIM
+    r.k = k
+    for i, v in enumerate(Cm.reshape(-1)):
+        r.C[i] = float(v)
+    for i, v in enumerate(np.asarray(spec['tip_target'], dtype=np.float32).reshape(-1)):
+        r.tip_target[i] = float(v)
+    r.norm = float(spec['norm'])
+    r.w = float(spec['w'])
+    Q = np.asarray(spec['Q'], dtype=np.float32).reshape(k, k)
+    for i, v in enumerate(Q.reshape(-1)):
+        r.Q[i] = float(v)
+    R = np.asarray(spec['R'], dtype=np.float32).reshape(U, U)
+    for i, v in enumerate(R.reshape(-1)):
+        r.R[i] = float(v)
+    return r
+
+
+class Engine:
+    """One (device, shape) plan.  forward() must precede backward()."""
+
+    def __init__(self, B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep,
+                 reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
+                 device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
+                 max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
+        self.device = torch.device(device if device is not None else
+                                   'cuda:%d' % torch.cuda.current_device())
+        cfg = _lib.Config()
+        cfg.B, cfg.D, cfg.U, cfg.H = B, D, U, H
+        cfg.B_global = B_global if B_global is not None else B
+        cfg.row_offset = row_offset
+        cfg.flags = ((_lib.FLAG_MM_STATES if mm_states else 0) |
+                     (_lib.FLAG_MM_REWARDS if mm_rewards else 0))
+        cfg.mm_groups = int(mm_groups) if mm_groups else 0
+        cfg.max_log_std_pol = max_log_std_pol
+        cfg.max_log_std_dyn = max_log_std_dyn
+        for mlp, dims, keep in ((cfg.pol, pol_dims, pol_keep), (cfg.dyn, dyn_dims, dyn_keep)):
+            mlp.n_layers = len(dims) - 1
+            assert mlp.n_layers <= _lib.MAX_LAYERS
+            for i, d in enumerate(dims):
+                mlp.dims[i] = int(d)
+            for i in range(_lib.MAX_LAYERS):
+                mlp.keep[i] = float(keep[i]) if i < len(keep) else 1.0
+        cfg.reward = make_reward_struct(reward_spec, D, U)
+        cfg.rows_per_wg_hint = rows_per_wg_hint
+        self.cfg = cfg
+        self.B, self.D, self.U, self.H = B, D, U, H
+        self.n_pol_layers = len(pol_dims) - 1
+        self.n_dyn_layers = len(dyn_dims) - 1
+        plan = C.c_void_p()
+        _lib.check(self.lib.pmbrl_plan_create(C.byref(cfg), self.device.index or 0,
+                                              C.byref(plan)), 'pmbrl_plan_create')
+        self.plan = plan
+        info = (C.c_int32 * _lib.INFO_COUNT)()
+        _lib.check(self.lib.pmbrl_plan_info(plan, info), 'pmbrl_plan_info')
+        self.info = dict(rows_per_wg=info[0], n_wg=info[1], row_tiles=info[2],
+                         lds_bytes=info[3], n_pol_params=info[4], n_dyn_params=info[5],
+                         dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9])
+        self.n_pol_params = info[4]
+        self.n_dyn_params = info[5]
+        ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)
+        self.ws_bytes = ws_bytes
+        self.workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = C.c_void_p(self.workspace.data_ptr() + off)
+        dev = self.device
+        self.states = torch.empty((H + 1, B, D), dtype=torch.float32, device=dev)
+        self.actions = torch.empty((H, B, U), dtype=torch.float32, device=dev)
+        self.rewards = torch.empty((H, B, 1), dtype=torch.float32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_flat = torch.empty(self.n_pol_params, dtype=torch.float32, device=dev)
+        self._inputs = None
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'plan', None):
+                self.lib.pmbrl_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def forward(self, x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias,
+                pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None):
+        dev = self.device
+        t = [_f32c(v, dev) for v in (x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale,
+                                     pol_bias, z_pol, z_dyn)]
+        x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias, z_pol, z_dyn = t
+        assert x0.shape == (self.B, self.D), x0.shape
+        assert pol_flat.numel() == self.n_pol_params and dyn_flat.numel() == self.n_dyn_params
+        assert mx.numel() == self.D + self.U and my.numel() == self.D
+        assert z_pol.shape[0] >= self.B and z_dyn.shape[0] >= self.B
+        assert len(pol_mask_bits) == self.n_pol_layers - 1
+        assert len(dyn_mask_bits) == self.n_dyn_layers - 1
+        if z_mm is not None:
+            z_mm = _f32c(z_mm, dev)
+            assert z_mm.shape[0] >= self.cfg.B_global
+        if z_rr is not None:
+            z_rr = _f32c(z_rr, dev)
+            assert z_rr.shape[0] >= self.cfg.B_global
+        inp = _lib.Inputs()
+        inp.x0, inp.pol_params, inp.dyn_params = x0.data_ptr(), pol_flat.data_ptr(), dyn_flat.data_ptr()
+        inp.mx, inp.iSx, inp.my, inp.Sy = mx.data_ptr(), iSx.data_ptr(), my.data_ptr(), Sy.data_ptr()
+        inp.pol_scale, inp.pol_bias = pol_scale.data_ptr(), pol_bias.data_ptr()
+        for i, b in enumerate(pol_mask_bits):
+            assert b.shape[0] >= self.B and b.is_contiguous()
+            inp.pol_mask_bits[i] = b.data_ptr()
+        for i, b in enumerate(dyn_mask_bits):
+            assert b.shape[0] >= self.B and b.is_contiguous()
+            inp.dyn_mask_bits[i] = b.data_ptr()
+        inp.z_pol, inp.z_dyn = z_pol.data_ptr(), z_dyn.data_ptr()
+        inp.z_mm = z_mm.data_ptr() if z_mm is not None else None
+        inp.z_rr = z_rr.data_ptr() if z_rr is not None else None
+        self._inputs = inp
+        self._keep = (t, z_mm, z_rr, list(pol_mask_bits), list(dyn_mask_bits))
+        _lib.check(self.lib.pmbrl_rollout_fwd(self.plan, _stream(), self._ws_ptr, C.byref(inp),
+                                              _ptr(self.states), _ptr(self.actions),
+                                              _ptr(self.rewards), _ptr(self.status)),
+                   'pmbrl_rollout_fwd')
+        return self.states, self.actions, self.rewards
+
+    def valid_steps(self):
+        """Host sync: number of steps completed before a numerical failure (H if none)."""
+        s = int(self.status.item())
+        return self.H if s >= self.H else s
+
+    def backward(self, grad_rewards, grad_states=None, want_x0=False, want_agn=False):
+        assert self._inputs is not None, 'forward() first'
+        dev = self.device
+        gr = _f32c(grad_rewards.reshape(self.H, self.B), dev)
+        gs = _f32c(grad_states, dev) if grad_states is not None else None
+        gx0 = torch.empty((self.B, self.D), dtype=torch.float32, device=dev) if want_x0 else None
+        agn = torch.empty((self.H, self.B), dtype=torch.float32, device=dev) if want_agn else None
+        _lib.check(self.lib.pmbrl_rollout_bwd(self.plan, _stream(), self._ws_ptr,
+                                              C.byref(self._inputs), _ptr(self.states),
+                                              _ptr(self.actions), _ptr(self.rewards), _ptr(gr),
+                                              _ptr(gs), _ptr(self.grad_flat), _ptr(gx0), _ptr(agn)),
+                   'pmbrl_rollout_bwd')
+        return self.grad_flat, gx0, agn
+
+    # ------------------------------------------------------------------
+    def weighted_sum(self, a, w, out=None):
+        a = _f32c(a.reshape(-1), self.device)
+        w = _f32c(w.reshape(-1), self.device)
+        if out is None:
+            out = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pmbrl_weighted_sum(_stream(), _ptr(a), _ptr(w), a.numel(), _ptr(out)),
+                   'pmbrl_weighted_sum')
+        return out
+
+
+def clip_adam(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+              max_norm=None, norm_out=None):
+    """Fused clip_grad_norm_ + Adam.step on flat fp32 buffers (pmbrl_clip_adam)."""
+    lib = _lib.load()
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    n = params.numel()
+    _lib.check(lib.pmbrl_clip_adam(_stream(), _ptr(params), _ptr(grads), _ptr(exp_avg),
+                                   _ptr(exp_avg_sq), n, int(step), float(lr), float(betas[0]),
+                                   float(betas[1]), float(eps),
+                                   float(max_norm) if max_norm else 0.0, _ptr(norm_out)),
+               'pmbrl_clip_adam')
+
+
+def debug_linear(x, W, b, transpose_w=False):
+    """Test hook: y = x W^T + b through the kernels' MFMA tile routine."""
+    lib = _lib.load()
+    R, K = x.shape
+    O = W.shape[1] if transpose_w else W.shape[0]
+    y = torch.empty((R, O), dtype=torch.float32, device=x.device)
+    n_kb, n_ot = (K + 15) // 16, (O + 15) // 16
+    scratch = torch.empty(n_kb * n_ot * 256 + n_ot * 16 + 64, dtype=torch.float32, device=x.device)
+    _lib.check(lib.pmbrl_debug_linear(_stream(), _ptr(x.contiguous()), _ptr(W.contiguous()),
+                                      _ptr(b.contiguous()), R, K, O, 1 if transpose_w else 0,
+                                      _ptr(y), _ptr(scratch)), 'pmbrl_debug_linear')
+    return y

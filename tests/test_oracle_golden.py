@@ -1,0 +1,85 @@
+"""CPU: the oracle (oracle/ref_torch.py, oracle/adjoint_np.py) against the golden
+vectors generated from the real reference (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adjoint_np as A
+from oracle import ref_torch as R
+from tests import common
+
+
+@pytest.mark.parametrize('name', common.fixture_names('iter'))
+def test_torch_oracle_matches_reference_fp32(name):
+    d = common.load(name)
+    torch.set_flush_denormal(True)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float32)
+    loss, g, (S, Ac, Rw) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, meta['maximize'],
+                                       meta['mm_states'], meta['mm_rewards'], meta['mm_groups'],
+                                       z_mm, z_rr, meta['infer_ns'])
+    # same op sequence as the reference -> fp32 agreement to rounding of the BLAS calls
+    assert np.allclose(torch.stack(S).detach().numpy(), d['ref32_states'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(torch.stack(Ac).detach().numpy(), d['ref32_actions'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(torch.stack(Rw).detach().numpy().reshape(d['ref32_rewards'].shape),
+                       d['ref32_rewards'], rtol=1e-5, atol=1e-7)
+    assert abs(float(loss) - float(d['ref32_loss'])) <= 1e-5 * abs(float(d['ref32_loss']))
+    assert common.rel(g.numpy(), d['ref32_grad']) < 1e-4
+
+
+@pytest.mark.parametrize('name', common.fixture_names('iter'))
+def test_torch_oracle_matches_reference_fp64(name):
+    d = common.load(name)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    loss, g, (S, Ac, Rw) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, meta['maximize'],
+                                       meta['mm_states'], meta['mm_rewards'], meta['mm_groups'],
+                                       z_mm, z_rr, meta['infer_ns'])
+    assert common.rel(torch.stack(S).detach().numpy(), d['ref64_states']) < 1e-6
+    assert abs(float(loss) - float(d['ref64_loss'])) <= 1e-7 * abs(float(d['ref64_loss']))
+    assert common.rel(g.numpy(), d['ref64_grad']) < 1e-6
+
+
+@pytest.mark.parametrize('name', common.fixture_names('iter'))
+def test_explicit_adjoint_matches_reference_fp64(name):
+    """The autograd-free forward/adjoint the HIP kernels implement."""
+    d = common.load(name)
+    P = A.Problem(d, np.float64)
+    st = A.forward(P)
+    g, gx0, _ = A.backward(P, st)
+    assert common.rel(np.stack(st['states']), d['ref64_states']) < 1e-6
+    assert common.rel(np.stack(st['rewards']).reshape(d['ref64_rewards'].shape),
+                      d['ref64_rewards']) < 1e-6
+    assert abs(A.loss(P, st) - float(d['ref64_loss'])) <= 1e-7 * abs(float(d['ref64_loss']))
+    assert common.rel(g, d['ref64_grad']) < 1e-6
+
+
+@pytest.mark.parametrize('name', common.fixture_names('mcp'))
+def test_oracle_mc_pilco_iterations(name):
+    """Multi-iteration fixture from the REAL algorithms.mc_pilco: pins clip + Adam."""
+    d = common.load(name)
+    torch.set_flush_denormal(True)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float32)
+    params = R.policy_params(pol)
+    ms = [torch.zeros_like(p) for p in params]
+    vs = [torch.zeros_like(p) for p in params]
+    losses = []
+    for it in range(int(d['mcp_n_iters'])):
+        loss, g, _ = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
+                                 meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+        losses.append(float(loss))
+        grads = [p.grad for p in params]
+        _, grads = R.clip_grad_norm(grads, float(d['mcp_clip']))
+        with torch.no_grad():
+            for p, gg, m, v in zip(params, grads, ms, vs):
+                R.adam_step(p, gg, m, v, it + 1, float(d['mcp_lr']))
+    assert np.allclose(losses, d['ref32_mcp_losses'], rtol=2e-5)
+    final = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+    assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=1e-6)
+
+
+def test_tile_layout():
+    x = torch.arange(6.).view(3, 2)
+    t = R.tile(x, 4)
+    assert t.shape == (12, 2)
+    for g in range(3):
+        for k in range(4):
+            assert torch.equal(t[g * 4 + k], x[g])
