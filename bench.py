@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Benchmark of the MC-PILCO hot path on MI355X.
+
+One "step" = one full optimiser iteration of algorithms/mc_pilco.py:86-216 on a
+synthetic Cartpole-shaped problem (BASELINE.json configs[1]: |x|=4, |u|=1,
+2x200 nets, 100 particles x 25 dropout samples = 2500 rows, H=40):
+  fused rollout forward -> discounted-return loss -> adjoint sweep -> dW GEMM ->
+  [RCCL all-reduce of the flat policy gradient when N > 1] -> fused clip + Adam.
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU
+(torch.distributed, backend nccl = RCCL), every rank owns its own 2500 rows of a
+global batch of N*2500 (weak scaling), the only collective is the gradient
+all-reduce.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='cartpole_nomm')
+    ap.add_argument('--rows-per-wg', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
+    ap.add_argument('--timing-steps', type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(d, budget_s=24.0):
+    """The oracle (a torch-CPU port of the reference's op sequence, incl. the
+    discarded dynamics-weight gradients) timed on the host: full iteration =
+    rollout + loss + backward + clip + Adam.  Bounded sample of the SAME workload."""
+    from oracle import ref_torch as R
+    torch.set_flush_denormal(True)   # the examples do (examples/deep_pilco_mm.py:68)
+    B = d['x0'].shape[0]
+    ncpu = os.cpu_count() or 1
+    best = None
+    tried = []
+    for threads in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+        torch.set_num_threads(threads)
+        x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float32)
+        params = R.policy_params(pol)
+        ms = [torch.zeros_like(p) for p in params]
+        vs = [torch.zeros_like(p) for p in params]
+
+        def it(step):
+            loss, g, _ = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, meta['maximize'],
+                                     meta['mm_states'], meta['mm_rewards'], meta['mm_groups'],
+                                     z_mm, z_rr, dyn_requires_grad=True)
+            grads = [p.grad for p in params]
+            _, grads = R.clip_grad_norm(grads, 1.0)
+            with torch.no_grad():
+                for p, gg, m, v in zip(params, grads, ms, vs):
+                    R.adam_step(p, gg, m, v, step, 1e-4)
+
+        it(1)
+        times = []
+        t_start = time.perf_counter()
+        step = 2
+        while len(times) < 6 and (time.perf_counter() - t_start) < budget_s / 4:
+            t0 = time.perf_counter()
+            it(step)
+            times.append(time.perf_counter() - t0)
+            step += 1
+        med = float(np.median(times))
+        tried.append((threads, med, len(times)))
+        if best is None or med < best[1]:
+            best = (threads, med, len(times))
+    threads, med, n = best
+    return dict(value=B / med, unit='rollouts/s', cores=threads, kind='port',
+                sample='%d full iterations (B=%d rows, H=%d) per thread setting, median; tried %s' %
+                       (n, B, int(d['H']), ', '.join('%dT:%.0fms' % (t, m * 1e3) for t, m, _ in tried)),
+                ms_per_step=med * 1e3, host_cpus=ncpu)
+
+
+def main():
+    a = parse()
+    from prob_mbrl_amd import problem as PB
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.cpu_only:
+        d = PB.synthetic_problem(a.config, seed=0, data_seed=0)
+        print(json.dumps(cpu_baseline(d)))
+        return
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    dev = torch.device('cuda:%d' % local_rank)
+    torch.cuda.set_device(dev)
+
+    from prob_mbrl_amd import engine as E
+    d = PB.synthetic_problem(a.config, seed=0, data_seed=rank)
+    B = d['x0'].shape[0]
+    H = int(d['H'])
+    Bg = B * world
+    eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=a.rows_per_wg, B_global=Bg,
+                                          row_offset=rank * B)
+    gw = torch.tensor(PB.loss_weights(d, Bg)[:, :B].copy(), device=dev)
+    params = args['pol_flat'].clone()
+    args['pol_flat'] = params
+    m = torch.zeros_like(params)
+    v = torch.zeros_like(params)
+    loss_buf = torch.zeros(1, device=dev)
+    state = dict(step=0)
+
+    def step():
+        state['step'] += 1
+        _, _, R = eng.forward(**args)
+        eng.weighted_sum(R, gw, out=loss_buf)
+        g, _, _ = eng.backward(gw)
+        if world > 1:
+            dist.all_reduce(g)
+        E.clip_adam(params, g, m, v, state['step'], 1e-4, max_norm=1.0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert eng.valid_steps() == H, 'numerical failure inside the benchmark rollout'
+    assert bool(torch.isfinite(params).all()) and bool(torch.isfinite(loss_buf).all())
+
+    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
+    timings = None
+    if rank == 0:
+        eng.set_timing(True)
+        acc = {}
+        for _ in range(a.timing_steps):
+            step()
+            for k, ms in eng.read_timing().items():
+                if ms >= 0:
+                    acc.setdefault(k, []).append(ms)
+        eng.set_timing(False)
+        timings = {k: float(np.mean(vv)) for k, vv in acc.items()}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
+        # algorithmic flops per launch of each kernel (one launch covers B rows x H steps)
+        kflops = dict(fwd=2.0 * H * B * (Pm + Fm), bwd=2.0 * H * B * (Pm + Fm), dw=2.0 * H * B * Pm)
+        dom = max(kflops, key=lambda k: timings.get(k, 0.0))
+        achieved = kflops[dom] / (timings[dom] * 1e-3) / 1e12
+        out = dict(
+            metric='particle_rollouts_per_sec', value=Bg * a.steps / dt, unit='rollouts/s',
+            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+            config=dict(workload='%s: D=%d U=%d pol=%s dyn=%s rows/GPU=%d (%s) H=%d mm=%s; full '
+                                 'iteration = rollout fwd + loss + adjoint + dW + %sclip + Adam' %
+                                 (a.config, d['x0'].shape[1], d['pol_z'].shape[1],
+                                  PB.layer_dims(d, 'pol'), PB.layer_dims(d, 'dyn'), B,
+                                  'particles x samples', H, bool(d['mm_states']),
+                                  'RCCL all-reduce + ' if world > 1 else ''),
+                        rows_per_gpu=B, global_rows=Bg, horizon=H, parallelism='dp%d' % world,
+                        rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
+                        mm_mode=eng.info['mm_mode']),
+            algorithmic_gflop_per_step=flops_rollout * B / 1e9,
+            algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
+            kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
+            roofline=dict(bound='mfma', kernel='pm_rollout_' + dom if dom != 'dw' else 'pm_dw_kernel',
+                          achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                          frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                          flops_per_launch=kflops[dom], avg_launch_ms=timings[dom]))
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(d)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -185,8 +185,23 @@ int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d,
  * like the reference. */
 int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d,
                     float* exp_avg_d, float* exp_avg_sq_d, int64_t n,
-                    int64_t step, float lr, float beta1, float beta2, float eps,
-                    float max_norm, float* norm_out_d);
+                    int64_t step, double lr, double beta1, double beta2, double eps,
+                    double max_norm, float* norm_out_d);
+
+/* Optional per-kernel timing for bench.py's roofline line: when enabled, the
+ * library brackets its kernels with hipEvents on the caller's stream;
+ * pmbrl_plan_read_timing waits for them and returns the last call's durations
+ * in milliseconds (-1 = not run). */
+enum {
+  PMBRL_TIMER_PACK = 0,      /* weight fragment packing */
+  PMBRL_TIMER_FWD = 1,       /* pm_rollout_fwd (+ external mm kernels) */
+  PMBRL_TIMER_BWD = 2,       /* pm_rollout_bwd (+ external mm kernels) */
+  PMBRL_TIMER_DW = 3,        /* pm_dw_kernel */
+  PMBRL_TIMER_DW_REDUCE = 4, /* pm_dw_reduce */
+  PMBRL_TIMER_COUNT = 8
+};
+int pmbrl_plan_set_timing(pmbrl_plan* plan, int on);
+int pmbrl_plan_read_timing(pmbrl_plan* plan, float* ms /* [PMBRL_TIMER_COUNT] */);
 
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout

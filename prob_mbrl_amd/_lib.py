@@ -17,6 +17,8 @@ MAX_DIM = 64
 FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS = 1, 2, 4
 REWARD_EXP, REWARD_NEG = 0, 1
 INFO_COUNT = 16
+TIMER_COUNT = 8
+TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce']
 
 
 class MLP(C.Structure):
@@ -59,6 +61,7 @@ EXPORTS = [
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
     'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
+    'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing',
 ]
 
 _lib = None
@@ -97,10 +100,15 @@ def load():
     lib.pmbrl_weighted_sum.restype = C.c_int
     lib.pmbrl_weighted_sum.argtypes = [vp, vp, vp, i64, vp]
     lib.pmbrl_clip_adam.restype = C.c_int
-    lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32,
-                                    f32, f32, vp]
+    f64 = C.c_double
+    lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64,
+                                    f64, f64, vp]
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.pmbrl_plan_set_timing.restype = C.c_int
+    lib.pmbrl_plan_set_timing.argtypes = [vp, C.c_int]
+    lib.pmbrl_plan_read_timing.restype = C.c_int
+    lib.pmbrl_plan_read_timing.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 

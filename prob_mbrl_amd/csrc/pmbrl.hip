@@ -91,6 +91,7 @@ __global__ __launch_bounds__(1024) void pm_clip_adam_kernel(float* __restrict__ 
                                                             float* __restrict__ m,
                                                             float* __restrict__ v, long long n,
                                                             float lr, float b1, float b2,
+                                                            float omb1, float omb2,
                                                             float eps, float bc1, float bc2_sqrt,
                                                             float max_norm,
                                                             float* __restrict__ norm_out) {
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(1024) void pm_clip_adam_kernel(float* __restrict__ 
   const float step_size = lr / bc1;
   for (long long i = threadIdx.x; i < n; i += blockDim.x) {
     const float gi = g[i] * coef;
-    const float mi = m[i] * b1 + (1.f - b1) * gi;
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float mi = m[i] * b1 + omb1 * gi;
+    const float vi = v[i] * b2 + omb2 * gi * gi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     g[i] = gi;
     m[i] = mi;
@@ -190,6 +191,20 @@ struct pmbrl_plan {
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
       off_gxc, off_grt, ws_bytes;
+  // optional per-kernel timing (hipEvents on the caller's stream)
+  int timing;
+  hipEvent_t ev[PMBRL_TIMER_COUNT][2];
+  bool ev_set[PMBRL_TIMER_COUNT];
+};
+
+struct ScopedTimer {
+  pmbrl_plan* p; int slot; hipStream_t s;
+  ScopedTimer(pmbrl_plan* p_, int slot_, hipStream_t s_) : p(p_), slot(slot_), s(s_) {
+    if (p->timing) (void)hipEventRecord(p->ev[slot][0], s);
+  }
+  ~ScopedTimer() {
+    if (p->timing) { (void)hipEventRecord(p->ev[slot][1], s); p->ev_set[slot] = true; }
+  }
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -422,8 +437,34 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   return 0;
 }
 
+extern "C" int pmbrl_plan_set_timing(pmbrl_plan* p, int on) {
+  if (!p) return fail(-1, "null argument");
+  if (on && !p->ev[0][0]) {
+    for (int i = 0; i < PMBRL_TIMER_COUNT; ++i)
+      for (int j = 0; j < 2; ++j) HIPCHK(hipEventCreate(&p->ev[i][j]));
+  }
+  p->timing = on ? 1 : 0;
+  for (int i = 0; i < PMBRL_TIMER_COUNT; ++i) p->ev_set[i] = false;
+  return 0;
+}
+
+extern "C" int pmbrl_plan_read_timing(pmbrl_plan* p, float* ms) {
+  if (!p || !ms) return fail(-1, "null argument");
+  for (int i = 0; i < PMBRL_TIMER_COUNT; ++i) {
+    ms[i] = -1.f;
+    if (p->timing && p->ev_set[i]) {
+      HIPCHK(hipEventSynchronize(p->ev[i][1]));
+      HIPCHK(hipEventElapsedTime(&ms[i], p->ev[i][0], p->ev[i][1]));
+    }
+  }
+  return 0;
+}
+
 extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
   if (!p) return;
+  if (p->ev[0][0])
+    for (int i = 0; i < PMBRL_TIMER_COUNT; ++i)
+      for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
   if (p->rew_d) (void)hipFree(p->rew_d);
   if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
   delete p;
@@ -566,10 +607,14 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   if (rc) return rc;
   A.states = states_d; A.actions = actions_d; A.rewards = rewards_d; A.status = status_d;
   char* ws = static_cast<char*>(workspace);
-  rc = pack_net(p->pol, ws, in->pol_params_d, s);
-  if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
+  {
+    ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
+    rc = pack_net(p->pol, ws, in->pol_params_d, s);
+    if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
+  }
+  ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
   if (p->mm_mode != 2) {
     launch_fwd_rt(p, A, s);
   } else {
@@ -606,9 +651,11 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.grad_x0 = grad_x0_d;
   A.agn = action_grad_norms_d;
   if (p->mm_mode != 2) {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     A.gx_from_carry = 0;
     launch_bwd_rt(p, A, s);
   } else {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
     float* grt = reinterpret_cast<float*>(ws + p->off_grt);
     const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
@@ -647,10 +694,16 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   }
   W.blocks = p->dw_blocks_d;
   W.part = reinterpret_cast<float*>(ws + p->off_part);
-  hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_wg_per_split * p->dw_nsplit), dim3(PM_NT), 0, s, W);
+  {
+    ScopedTimer tm(p, PMBRL_TIMER_DW, s);
+    hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_wg_per_split * p->dw_nsplit), dim3(PM_NT), 0, s, W);
+  }
   const int n = (int)p->pol.n_params;
-  hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(256), 0, s, W.part, p->dw_nsplit, n,
-                     grad_pol_flat_d);
+  {
+    ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
+    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(256), 0, s, W.part, p->dw_nsplit, n,
+                       grad_pol_flat_d);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -665,15 +718,16 @@ extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w
 }
 
 extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, float* exp_avg_d,
-                               float* exp_avg_sq_d, int64_t n, int64_t step, float lr, float beta1,
-                               float beta2, float eps, float max_norm, float* norm_out_d) {
+                               float* exp_avg_sq_d, int64_t n, int64_t step, double lr, double beta1,
+                               double beta2, double eps, double max_norm, float* norm_out_d) {
   if (!params_d || !grads_d || !exp_avg_d || !exp_avg_sq_d || n < 1 || step < 1)
     return fail(-1, "bad argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params_d,
-                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2), max_norm, norm_out_d);
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, (float)lr, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d);
   HIPCHK(hipGetLastError());
   return 0;
 }

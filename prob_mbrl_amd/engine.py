@@ -197,6 +197,15 @@ class Engine:
                    'pmbrl_rollout_bwd')
         return self.grad_flat, gx0, agn
 
+    def set_timing(self, on=True):
+        _lib.check(self.lib.pmbrl_plan_set_timing(self.plan, 1 if on else 0), 'set_timing')
+
+    def read_timing(self):
+        """dict kernel-name -> ms of the last fwd/bwd calls (syncs on the events)."""
+        ms = (C.c_float * _lib.TIMER_COUNT)()
+        _lib.check(self.lib.pmbrl_plan_read_timing(self.plan, ms), 'read_timing')
+        return {n: float(ms[i]) for i, n in enumerate(_lib.TIMER_NAMES)}
+
     # ------------------------------------------------------------------
     def weighted_sum(self, a, w, out=None):
         a = _f32c(a.reshape(-1), self.device)

@@ -21,7 +21,7 @@ def dev():
 
 
 @pytest.mark.parametrize('R,K,O', [(16, 4, 200), (16, 200, 200), (16, 200, 2), (7, 5, 33),
-                                   (32, 200, 8), (32, 208, 200), (64, 512, 512), (64, 40, 64),
+                                   (32, 200, 8), (32, 208, 200), (32, 512, 512), (64, 40, 64),
                                    (16, 16, 16), (48, 130, 70)])
 @pytest.mark.parametrize('transpose', [False, True])
 def test_mfma_linear(dev, R, K, O, transpose):
