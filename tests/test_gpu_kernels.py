@@ -89,7 +89,7 @@ def test_clip_adam_matches_torch(dev, n, clip):
         assert torch.allclose(gg, p_ref.grad, rtol=1e-5, atol=1e-8)
         assert torch.allclose(p, p_ref.detach(), rtol=1e-5, atol=1e-6), (p - p_ref).abs().max()
     st = opt.state[p_ref]
-    assert torch.allclose(m, st['exp_avg'], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(m, st['exp_avg'], rtol=1e-5, atol=1e-7)
     assert torch.allclose(v, st['exp_avg_sq'], rtol=1e-5, atol=1e-12)
 
 
