@@ -41,6 +41,9 @@ extern "C" {
 #define PMBRL_FLAG_MM_STATES 1   /* utils/rollout.py:121-132 */
 #define PMBRL_FLAG_MM_REWARDS 2  /* utils/rollout.py:135-145 */
 #define PMBRL_FLAG_INFER_NS 4    /* utils/rollout.py:6-17 (mm_resample_infer_ns_) */
+#define PMBRL_FLAG_ZMM_PER_STEP 8 /* z_mm/z_rr are [H, B_global, .] fresh draws per step
+                                     (utils/rollout.py:58-59, z=None) instead of the cyclic
+                                     PEGASUS buffer of utils/rollout.py:53-57 */
 
 #define PMBRL_REWARD_EXP 0 /* r = exp(-w (d'Qd + u'Ru)): envs/cartpole/env.py:41-86 */
 #define PMBRL_REWARD_NEG 1 /* r = -w (d'Qd + u'Ru):      envs/rendezvous/env.py:32-45 */
@@ -142,6 +145,9 @@ typedef struct pmbrl_inputs {
   const uint16_t* dyn_mask_bits_d[PMBRL_MAX_LAYERS];
   const float* z_pol_d;       /* [B, U]  models/densities.py:78,111-119 */
   const float* z_dyn_d;       /* [B, D] */
+  int64_t z_pol_step_stride;  /* elements between steps; 0 = the same frozen z at every step
+                                 (resample_noise=False), B*U = a fresh [H,B,U] draw per step */
+  int64_t z_dyn_step_stride;
   const float* z_mm_d;        /* [>= B_global, D] or NULL  algorithms/mc_pilco.py:57-62 */
   const float* z_rr_d;        /* [>= B_global, 1] or NULL */
 } pmbrl_inputs;
@@ -160,8 +166,9 @@ int pmbrl_rollout_fwd(pmbrl_plan* plan, void* stream, void* workspace_d,
 
 /* The adjoint of the above = what loss.backward() computes in
  * algorithms/mc_pilco.py:190-197 for loss = sum_{t,b} grad_rewards[t,b] *
- * rewards[t,b] (+ sum grad_states[t,b,:] . states[t,b,:] when grad_states_d is
- * given -- terminal value bootstrap, algorithms/mc_pilco.py:136-140).
+ * rewards[t,b] (+ sum grad_states[t,b,:] . states[t,b,:] when grad_states_d
+ * [H+1,B,D] is given -- terminal value bootstrap, algorithms/mc_pilco.py:136-140;
+ * + sum grad_actions[t,b,:] . actions[t,b,:] when grad_actions_d [H,B,U] is given).
  * Must follow a pmbrl_rollout_fwd on the same plan/workspace/inputs.
  * Outputs: grad_pol_flat_d [n_pol_params] (overwritten), optional grad_x0_d
  * [B,D], optional action_grad_norms_d [H,B] (||dL/da_t|| per row, the
@@ -170,8 +177,8 @@ int pmbrl_rollout_bwd(pmbrl_plan* plan, void* stream, void* workspace_d,
                       const pmbrl_inputs* in, const float* states_d,
                       const float* actions_d, const float* rewards_d,
                       const float* grad_rewards_d, const float* grad_states_d,
-                      float* grad_pol_flat_d, float* grad_x0_d,
-                      float* action_grad_norms_d);
+                      const float* grad_actions_d, float* grad_pol_flat_d,
+                      float* grad_x0_d, float* action_grad_norms_d);
 
 /* out[0] = sum_i a[i] * w[i]  (the discounted-return loss of
  * algorithms/mc_pilco.py:134-144,190 given w = dL/dr). Deterministic. */

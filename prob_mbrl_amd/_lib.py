@@ -14,7 +14,7 @@ MAX_LAYERS = 8
 MAX_ANGLE = 8
 MAX_TIP = 8
 MAX_DIM = 64
-FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS = 1, 2, 4
+FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
 REWARD_EXP, REWARD_NEG = 0, 1
 INFO_COUNT = 16
 TIMER_COUNT = 8
@@ -53,6 +53,7 @@ class Inputs(C.Structure):
                 ('pol_mask_bits', C.c_void_p * MAX_LAYERS),
                 ('dyn_mask_bits', C.c_void_p * MAX_LAYERS),
                 ('z_pol', C.c_void_p), ('z_dyn', C.c_void_p),
+                ('z_pol_step_stride', C.c_int64), ('z_dyn_step_stride', C.c_int64),
                 ('z_mm', C.c_void_p), ('z_rr', C.c_void_p)]
 
 
@@ -96,7 +97,7 @@ def load():
     lib.pmbrl_rollout_fwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp, vp]
     lib.pmbrl_rollout_bwd.restype = C.c_int
     lib.pmbrl_rollout_bwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp,
-                                      vp, vp, vp, vp, vp]
+                                      vp, vp, vp, vp, vp, vp]
     lib.pmbrl_weighted_sum.restype = C.c_int
     lib.pmbrl_weighted_sum.argtypes = [vp, vp, vp, i64, vp]
     lib.pmbrl_clip_adam.restype = C.c_int

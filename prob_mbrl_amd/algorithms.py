@@ -1,0 +1,261 @@
+"""`mc_pilco()` with the reference's call surface (algorithms/mc_pilco.py:13-267).
+
+Two execution paths, same semantics:
+ * fused (default): rollout forward -> loss -> adjoint sweep -> dW GEMM ->
+   [gradient all-reduce] -> clip + Adam are C-ABI calls on flat buffers; no
+   autograd graph, no torch.nn op, one host sync per iteration (status + loss).
+   Used when the optimiser is a plain torch.optim.Adam over the policy's Linear
+   parameters and no option needs autograd (CVaR, regulariser).
+ * autograd: `rollout()`'s single autograd node + torch's loss / clip / optimiser
+   for everything else the reference signature allows.
+"""
+import math
+import traceback
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import engine as E
+from . import rollout as RO
+from .utils import tile
+
+policy_update_counter = defaultdict(lambda: 0)   # algorithms/mc_pilco.py:8
+
+
+def _discount_fn(discount, steps):
+    """algorithms/mc_pilco.py:46-50."""
+    if discount is None:
+        return lambda i: 1.0 / steps
+    if not callable(discount):
+        factor = discount
+        return lambda i: factor**i
+    return discount
+
+
+def _adam_flat_state(opt, params, flat):
+    """If `opt` is a plain Adam over exactly `params`, return (m, v, step, group) with the
+    per-parameter state re-pointed at flat buffers (views), else None."""
+    if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False):
+        return None
+    gp = [p for p in g['params']]
+    if len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)):
+        return None
+    cache = getattr(opt, '_pmbrl_flat', None)
+    if cache is not None and cache['flat_ptr'] == flat.data_ptr():
+        st = opt.state.get(params[0], {})
+        if 'step' in st:   # torch may have stepped this optimiser in between
+            cache['step'] = int(st['step'])
+        return cache
+    m = torch.zeros_like(flat)
+    v = torch.zeros_like(flat)
+    step, off = 0, 0
+    for p in params:
+        n = p.numel()
+        st = opt.state.get(p, {})
+        if 'exp_avg' in st:
+            m[off:off + n] = st['exp_avg'].reshape(-1)
+            v[off:off + n] = st['exp_avg_sq'].reshape(-1)
+            step = int(st['step']) if not torch.is_tensor(st['step']) else int(st['step'].item())
+        off += n
+    cache = dict(m=m, v=v, step=step, group=g, flat_ptr=flat.data_ptr())
+    opt._pmbrl_flat = cache
+    return cache
+
+
+def _sync_adam_state(opt, params, cache):
+    """Expose the flat Adam state through opt.state (views) so state_dict()/later
+    opt.step() calls keep working."""
+    off = 0
+    for p in params:
+        n = p.numel()
+        st = opt.state[p]
+        st['step'] = torch.tensor(float(cache['step']))
+        st['exp_avg'] = cache['m'][off:off + n].view(p.shape)
+        st['exp_avg_sq'] = cache['v'][off:off + n].view(p.shape)
+        off += n
+
+
+def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters=1000,
+             value_func=None, pegasus=True, mm_states=False, mm_rewards=False, mm_groups=None,
+             maximize=True, clip_grad=1.0, cvar_eps=0.0, reg_weight=0.0, discount=None,
+             on_rollout=None, on_iteration=None, step_idx_to_sample=None, init_state_noise=0.0,
+             resampling_period=99, prioritized_replay=False, priority_alpha=0.6,
+             priority_eps=1e-8, init_priority_beta=1.0, priority_beta_increase=0.0, debug=False,
+             rollout_kwargs={}, process_group=None, frozen_noise=None, progress=False):
+    """Monte-Carlo PILCO policy search.  Mutates `policy` parameters and `opt` state in place.
+
+    Extra keyword arguments (not in the reference): `process_group` -- a torch.distributed
+    group over which the particle rows are sharded (this rank passes ITS rows; the flat policy
+    gradient is all-reduced over RCCL before the identical clip + Adam on every rank);
+    `frozen_noise` -- dict(z_mm=..., z_rr=...) to inject captured PEGASUS noise (tests);
+    `progress` -- print the reference's tqdm-style line every 50 iterations."""
+    global policy_update_counter
+    if value_func is not None:
+        raise NotImplementedError('value_func bootstrap is not offered yet (SURVEY.md 8f N3)')
+    if prioritized_replay:
+        raise NotImplementedError('prioritized_replay is not offered yet (SURVEY.md 8f N3)')
+    dynamics.eval()
+    policy.train()
+    H = int(steps)
+    disc = _discount_fn(discount, H)
+    if opt is None:
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, policy.parameters()))
+    dev = next(policy.parameters()).device
+    if dev.type != 'cuda':
+        raise RuntimeError('prob_mbrl_amd.mc_pilco needs the modules on a HIP device')
+    D = init_states.shape[-1]
+    N_particles = init_states.shape[0]
+    world, rank = 1, 0
+    if process_group is not None:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+    Bg = N_particles * world
+    z_mm = torch.randn(H + Bg, D, device=dev)
+    z_rr = torch.randn(H + Bg, 1, device=dev)
+    if frozen_noise is not None:
+        z_mm = frozen_noise['z_mm'].to(dev, torch.float32)
+        z_rr = frozen_noise['z_rr'].to(dev, torch.float32)
+
+    def resample():
+        if frozen_noise is not None:
+            return
+        seed = torch.randint(2**32, [1])
+        if world > 1:   # every rank must draw different masks: offset the seed by the rank
+            seed = seed + 7919 * rank
+        dynamics.resample(seed=seed)
+        policy.resample(seed=seed)
+        z_mm.normal_()
+        z_rr.normal_()
+
+    resample()
+    x0 = init_states
+    n_opt_steps = policy_update_counter[policy]
+    need_autograd = (cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0) or reg_weight > 0
+    gamma_full = [float(disc(i)) for i in range(H)]
+    sign = -1.0 if maximize else 1.0
+
+    for i in range(opt_iters):
+        if not pegasus or n_opt_steps % resampling_period == 0:
+            resample()
+        x0_ = x0
+        if mm_groups is not None and x0_.shape[0] == mm_groups:
+            x0_ = tile(x0_, int(N_particles / mm_groups))
+        x0_ = x0_.to(dev, torch.float32)
+        if not (isinstance(init_state_noise, float) and init_state_noise == 0.0):
+            x0_ = x0_ + torch.as_tensor(init_state_noise, device=dev) * torch.randn_like(x0_)
+        rk = dict(rollout_kwargs)
+        try:
+            bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus,
+                               mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
+                               z_rr if pegasus else None,
+                               B_global=Bg if world > 1 else None,
+                               row_offset=rank * N_particles if world > 1 else 0)
+            cache = None if need_autograd else _adam_flat_state(opt, bundle.pol_params,
+                                                                bundle.pol_flat)
+            if cache is None:
+                loss, states, actions, rewards = _autograd_iteration(
+                    x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups, z_mm,
+                    z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i, rk,
+                    process_group, world)
+            else:
+                eng = bundle.engine
+                S, A, R = bundle.forward(x0_)
+                n_valid = eng.valid_steps()       # the one host sync of the iteration
+                if n_valid < H:
+                    raise RuntimeError('rollout failed at step %d' % n_valid)
+                gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
+                loss = eng.weighted_sum(R, gw)[0]
+                states, actions, rewards = list(S.unbind(0)), list(A.unbind(0)), list(R.unbind(0))
+                if callable(on_rollout):
+                    on_rollout(i, states, actions, rewards, disc)
+                g, _, _ = eng.backward(gw)
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(g, group=process_group)
+                    dist.all_reduce(loss, group=process_group)
+                cache['step'] += 1
+                grp = cache['group']
+                E.clip_adam(bundle.pol_flat, g, cache['m'], cache['v'], cache['step'], grp['lr'],
+                            grp['betas'], grp['eps'], max_norm=clip_grad)
+        except RuntimeError:
+            # algorithms/mc_pilco.py:122-131: print, draw new random numbers, skip the step
+            traceback.print_exc()
+            print('RuntimeError')
+            resample()
+            opt.zero_grad()
+            continue
+        n_opt_steps += 1
+        if progress and i % 50 == 0:
+            msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
+            print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
+        if callable(on_iteration):
+            on_iteration(i, loss, states, actions, rewards, disc)
+        # new initial states (algorithms/mc_pilco.py:222-263)
+        if exp is not None:
+            n_draw = mm_groups if mm_groups is not None else N_particles
+            x0 = exp.sample_states(n_draw, timestep=step_idx_to_sample).to(dev, torch.float32)
+            init_states = x0
+        else:
+            x0 = init_states.detach()
+
+    cache = getattr(opt, '_pmbrl_flat', None)
+    if cache is not None and type(opt) is torch.optim.Adam:
+        _sync_adam_state(opt, [p for p in opt.param_groups[0]['params']], cache)
+    policy.eval()
+    dynamics.eval()
+    policy_update_counter[policy] = n_opt_steps
+
+
+_GW_CACHE = {}
+
+
+def _loss_weights(eng, gamma, sign, B_global, dev):
+    """dL/dr[t,b] = -/+ gamma_t / B  (algorithms/mc_pilco.py:134-144,190), cached per shape."""
+    key = (id(eng), tuple(gamma), sign, B_global)
+    gw = _GW_CACHE.get(key)
+    if gw is None:
+        if len(_GW_CACHE) > 8:
+            _GW_CACHE.clear()
+        col = torch.tensor(gamma, dtype=torch.float64) * (sign / B_global)
+        gw = col.float().to(dev)[:, None].expand(eng.H, eng.B).contiguous()
+        _GW_CACHE[key] = gw
+    return gw
+
+
+def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups,
+                        z_mm, z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i,
+                        rollout_kwargs, process_group, world):
+    """The reference loop body on top of the single-node autograd rollout."""
+    if world > 1:
+        raise NotImplementedError('sharded runs use the fused path (plain Adam, no CVaR/regulariser)')
+    policy.zero_grad()
+    opt.zero_grad()
+    states, actions, rewards = RO.rollout(
+        x0_, dynamics, policy, H, resample_state_noise=not pegasus,
+        resample_action_noise=not pegasus, mm_states=mm_states, mm_rewards=mm_rewards,
+        z_mm=z_mm if pegasus else None, z_rr=z_rr if pegasus else None, mm_groups=mm_groups,
+        **rollout_kwargs)
+    if callable(on_rollout):
+        on_rollout(i, states, actions, rewards, disc)
+    discounted = torch.stack([r * disc(t) for t, r in enumerate(rewards)])
+    returns = -discounted.sum(0) if maximize else discounted.sum(0)
+    if cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0:
+        rd = returns.detach()
+        if cvar_eps > 0:
+            q = np.quantile(rd.cpu().numpy(), cvar_eps)
+            returns = returns[rd < q]
+        else:
+            q = np.quantile(rd.cpu().numpy(), -cvar_eps)
+            returns = returns[rd > q]
+    loss = returns.mean()
+    if reg_weight > 0:
+        loss = loss + reg_weight * policy.regularization_loss()
+    loss.backward()
+    if clip_grad is not None:
+        torch.nn.utils.clip_grad_norm_(policy.parameters(), clip_grad)
+    opt.step()
+    return loss.detach(), states, actions, rewards

@@ -130,15 +130,17 @@ __global__ void pm_mm_fwd_kernel(RolloutArgs A, int t) {
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
   const int gi = blockIdx.x, lane = threadIdx.x;
   const int r0 = gi * A.M;
-  const int zrow0 = t + A.row_off + r0;
+  const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
+  const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
+  const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   if (A.flags & PMBRL_FLAG_MM_STATES) {
-    const bool ok = pm_mm_fwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, A.zmm, A.D, zrow0,
+    const bool ok = pm_mm_fwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, zmm, A.D, zrow0,
                               A.Bg, false, A.states + ((size_t)(t + 1) * A.B + r0) * A.D, A.D,
                               mmscr, lane);
     if (!ok && lane == 0) atomicMin(A.status, t);
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-    const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, A.zrr, 1, zrow0, A.Bg, false,
+    const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, false,
                               A.rewards + (size_t)t * A.B + r0, 1, mmscr, lane);
     if (!ok && lane == 0) atomicMin(A.status, t);
   }
@@ -148,18 +150,20 @@ __global__ void pm_mm_bwd_kernel(RolloutArgs A, int t, float* gr_tilde) {
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
   const int gi = blockIdx.x, lane = threadIdx.x;
   const int r0 = gi * A.M;
-  const int zrow0 = t + A.row_off + r0;
+  const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
+  const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
+  const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   if (A.flags & PMBRL_FLAG_MM_STATES) {
     float* g = A.gx_carry + (size_t)r0 * A.D;
     // in-place is NOT safe for d > 1 reads of g after writes: pm_mm_bwd reads g only
     // before its first wave sync, so aliasing g/gout is fine (see pmbrl_mm.h).
-    pm_mm_bwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, A.zmm, A.D, zrow0, A.Bg, false, g,
+    pm_mm_bwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, g,
               A.D, g, A.D, mmscr, lane);
   }
   const float* gsrc = A.grad_rewards + (size_t)t * A.B + r0;
   float* gdst = gr_tilde + (size_t)t * A.B + r0;
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-    pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, A.zrr, 1, zrow0, A.Bg, false, gsrc, 1, gdst, 1,
+    pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, false, gsrc, 1, gdst, 1,
               mmscr, lane);
   } else {
     for (int i = lane; i < A.M; i += 64) gdst[i] = gsrc[i];
@@ -538,6 +542,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.x0 = in->x0_d; A.mx = in->mx_d; A.iSx = in->iSx_d; A.my = in->my_d; A.Sy = in->Sy_d;
   A.pscale = in->pol_scale_d; A.pbias = in->pol_bias_d;
   A.zpol = in->z_pol_d; A.zdyn = in->z_dyn_d; A.zmm = in->z_mm_d; A.zrr = in->z_rr_d;
+  A.zpol_ss = in->z_pol_step_stride; A.zdyn_ss = in->z_dyn_step_stride;
   if (!A.x0 || !A.mx || !A.iSx || !A.my || !A.Sy || !A.pscale || !A.pbias || !A.zpol || !A.zdyn)
     return fail(-1, "null input pointer");
   if ((c.flags & PMBRL_FLAG_MM_STATES) && !A.zmm) return fail(-1, "mm_states needs z_mm");
@@ -632,8 +637,9 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
 extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
                                  const float* states_d, const float* actions_d,
                                  const float* rewards_d, const float* grad_rewards_d,
-                                 const float* grad_states_d, float* grad_pol_flat_d,
-                                 float* grad_x0_d, float* action_grad_norms_d) {
+                                 const float* grad_states_d, const float* grad_actions_d,
+                                 float* grad_pol_flat_d, float* grad_x0_d,
+                                 float* action_grad_norms_d) {
   if (!p || !workspace || !in || !states_d || !actions_d || !rewards_d || !grad_rewards_d ||
       !grad_pol_flat_d)
     return fail(-1, "null argument");
@@ -648,6 +654,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.rewards = const_cast<float*>(rewards_d);
   A.grad_rewards = grad_rewards_d;
   A.grad_states = grad_states_d;
+  A.grad_actions = grad_actions_d;
   A.grad_x0 = grad_x0_d;
   A.agn = action_grad_norms_d;
   if (p->mm_mode != 2) {

@@ -73,9 +73,10 @@ struct RolloutArgs {
   float *xt, *rt;         // pre-moment-matching next state / reward [H][B][D], [H][B]
   int* status;
   // backward only
-  const float *grad_rewards, *grad_states;
+  const float *grad_rewards, *grad_states, *grad_actions;
   float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
   int gx_from_carry;
+  long long zpol_ss, zdyn_ss;   // per-step strides of z_pol / z_dyn (0 = frozen)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

@@ -161,6 +161,14 @@ __device__ inline void reward_row_bwd(const RewardDev* __restrict__ rw, const fl
 // ---------------------------------------------------------------------------
 // LDS carve-up (floats).  Must match pmbrl_lds_floats() on the host.
 // ---------------------------------------------------------------------------
+// moment-matching noise addressing: cyclic PEGASUS buffer or fresh rows per step
+__device__ __forceinline__ const float* pm_zbase(const float* z, int ld, int t, int Bg, int flags) {
+  return (flags & PMBRL_FLAG_ZMM_PER_STEP) ? z + (size_t)t * Bg * ld : z;
+}
+__device__ __forceinline__ int pm_zrow0(int t, int row, int flags) {
+  return (flags & PMBRL_FLAG_ZMM_PER_STEP) ? row : t + row;
+}
+
 struct LdsMap {
   float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr, *part;
   double* mm;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           const int j = k - D;
           const float mu = Y[r * LD + j];
           const float ls = Y[r * LD + U + j];
-          const float z = (r < nvalid) ? A.zpol[(size_t)(row0 + r) * U + j] : 0.f;
+          const float z = (r < nvalid) ? A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j] : 0.f;
           const float lc = -softplusf(-ls + A.mls_pol) + A.mls_pol;
           const float e = expf(lc);
           const float u = mu + z * e;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       const int r = i / D, d = i - r * D;
       const float mu = Y[r * LD + d];
       const float ls = Y[r * LD + D + d];
-      const float z = (r < nvalid) ? A.zdyn[(size_t)(row0 + r) * D + d] : 0.f;
+      const float z = (r < nvalid) ? A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d] : 0.f;
       const float Sy = A.Sy[d];
       const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + logf(Sy);
       const float e = expf(lc);
@@ -336,13 +344,15 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
         if (A.flags & PMBRL_FLAG_MM_STATES) {
-          const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, A.zmm, D, t + A.row_off + row0 + lr0,
+          const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags),
                                     A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0, xa + lr0 * D, D,
                                     scr, lane);
           if (!ok && lane == 0) atomicMin(A.status, t);
         }
         if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-          const bool ok = pm_mm_fwd(L.rr + lr0, 1, A.M, 1, A.zrr, 1, t + A.row_off + row0 + lr0,
+          const bool ok = pm_mm_fwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags),
                                     A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0, L.gr + lr0, 1,
                                     scr, lane);
           if (!ok && lane == 0) atomicMin(A.status, t);
@@ -433,11 +443,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
         if (mms)
-          pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, A.zmm, D, t + A.row_off + row0 + lr0, A.Bg,
+          pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg,
                     (A.flags & PMBRL_FLAG_INFER_NS) != 0, gx + lr0 * D, D, gxt + lr0 * D, D, scr,
                     lane);
         if (mmr)
-          pm_mm_bwd(L.rr + lr0, 1, A.M, 1, A.zrr, 1, t + A.row_off + row0 + lr0, A.Bg,
+          pm_mm_bwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg,
                     (A.flags & PMBRL_FLAG_INFER_NS) != 0, L.gr + lr0, 1, L.gr + lr0, 1, scr, lane);
       }
       __syncthreads();
@@ -506,7 +518,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
           const int j = k - D;
           float go_mu = 0.f, go_ls = 0.f;
           if (r < nvalid) {
-            const float ga = L.gad[r * 16 + j] + Y[r * LD + k] * A.iSx[k];
+            float ga = L.gad[r * 16 + j] + Y[r * LD + k] * A.iSx[k];
+            if (A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
             L.gad[r * 16 + j] = ga;   // total dL/da_t (for the priority hook below)
             const float sc = A.pscale[j];
             const float th = (L.av[r * U + j] - A.pbias[j]) / sc;

@@ -77,7 +77,7 @@ class Engine:
     def __init__(self, B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep,
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
-                 max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD):
+                 max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -88,7 +88,8 @@ class Engine:
         cfg.B_global = B_global if B_global is not None else B
         cfg.row_offset = row_offset
         cfg.flags = ((_lib.FLAG_MM_STATES if mm_states else 0) |
-                     (_lib.FLAG_MM_REWARDS if mm_rewards else 0))
+                     (_lib.FLAG_MM_REWARDS if mm_rewards else 0) |
+                     (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
         cfg.max_log_std_pol = max_log_std_pol
         cfg.max_log_std_dyn = max_log_std_dyn
@@ -129,6 +130,7 @@ class Engine:
         self.grad_flat = torch.empty(self.n_pol_params, dtype=torch.float32, device=dev)
         self._inputs = None
         self._keep = None
+        self.generation = 0    # bumped by every forward(); backward must match
 
     def __del__(self):
         try:
@@ -140,7 +142,9 @@ class Engine:
 
     # ------------------------------------------------------------------
     def forward(self, x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias,
-                pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None):
+                pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None, out=None):
+        """z_pol / z_dyn: [B,.] (frozen, the same at every step) or [H,B,.] (a fresh
+        draw per step).  out: optional (states, actions, rewards) tensors to fill."""
         dev = self.device
         t = [_f32c(v, dev) for v in (x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale,
                                      pol_bias, z_pol, z_dyn)]
@@ -148,7 +152,17 @@ class Engine:
         assert x0.shape == (self.B, self.D), x0.shape
         assert pol_flat.numel() == self.n_pol_params and dyn_flat.numel() == self.n_dyn_params
         assert mx.numel() == self.D + self.U and my.numel() == self.D
-        assert z_pol.shape[0] >= self.B and z_dyn.shape[0] >= self.B
+        zps = zds = 0
+        if z_pol.dim() == 3:
+            assert z_pol.shape == (self.H, self.B, self.U)
+            zps = self.B * self.U
+        else:
+            assert z_pol.shape[0] >= self.B and z_pol.shape[1] == self.U
+        if z_dyn.dim() == 3:
+            assert z_dyn.shape == (self.H, self.B, self.D)
+            zds = self.B * self.D
+        else:
+            assert z_dyn.shape[0] >= self.B and z_dyn.shape[1] == self.D
         assert len(pol_mask_bits) == self.n_pol_layers - 1
         assert len(dyn_mask_bits) == self.n_dyn_layers - 1
         if z_mm is not None:
@@ -168,10 +182,17 @@ class Engine:
             assert b.shape[0] >= self.B and b.is_contiguous()
             inp.dyn_mask_bits[i] = b.data_ptr()
         inp.z_pol, inp.z_dyn = z_pol.data_ptr(), z_dyn.data_ptr()
+        inp.z_pol_step_stride, inp.z_dyn_step_stride = zps, zds
         inp.z_mm = z_mm.data_ptr() if z_mm is not None else None
         inp.z_rr = z_rr.data_ptr() if z_rr is not None else None
         self._inputs = inp
         self._keep = (t, z_mm, z_rr, list(pol_mask_bits), list(dyn_mask_bits))
+        if out is not None:
+            self.states, self.actions, self.rewards = out
+            assert self.states.shape == (self.H + 1, self.B, self.D) and self.states.is_contiguous()
+            assert self.actions.shape == (self.H, self.B, self.U) and self.actions.is_contiguous()
+            assert self.rewards.numel() == self.H * self.B and self.rewards.is_contiguous()
+        self.generation += 1
         _lib.check(self.lib.pmbrl_rollout_fwd(self.plan, _stream(), self._ws_ptr, C.byref(inp),
                                               _ptr(self.states), _ptr(self.actions),
                                               _ptr(self.rewards), _ptr(self.status)),
@@ -183,17 +204,24 @@ class Engine:
         s = int(self.status.item())
         return self.H if s >= self.H else s
 
-    def backward(self, grad_rewards, grad_states=None, want_x0=False, want_agn=False):
+    def backward(self, grad_rewards, grad_states=None, grad_actions=None, want_x0=False,
+                 want_agn=False):
         assert self._inputs is not None, 'forward() first'
         dev = self.device
         gr = _f32c(grad_rewards.reshape(self.H, self.B), dev)
         gs = _f32c(grad_states, dev) if grad_states is not None else None
+        ga = _f32c(grad_actions, dev) if grad_actions is not None else None
+        if gs is not None:
+            assert gs.shape == (self.H + 1, self.B, self.D)
+        if ga is not None:
+            assert ga.shape == (self.H, self.B, self.U)
         gx0 = torch.empty((self.B, self.D), dtype=torch.float32, device=dev) if want_x0 else None
         agn = torch.empty((self.H, self.B), dtype=torch.float32, device=dev) if want_agn else None
         _lib.check(self.lib.pmbrl_rollout_bwd(self.plan, _stream(), self._ws_ptr,
                                               C.byref(self._inputs), _ptr(self.states),
                                               _ptr(self.actions), _ptr(self.rewards), _ptr(gr),
-                                              _ptr(gs), _ptr(self.grad_flat), _ptr(gx0), _ptr(agn)),
+                                              _ptr(gs), _ptr(ga), _ptr(self.grad_flat), _ptr(gx0),
+                                              _ptr(agn)),
                    'pmbrl_rollout_bwd')
         return self.grad_flat, gx0, agn
 

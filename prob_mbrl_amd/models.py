@@ -1,0 +1,377 @@
+"""Host-side mirror of the reference's `prob_mbrl.models` module API for the
+MC-PILCO path (reference: models/core.py, models/modules.py, models/densities.py).
+
+These classes are STORAGE + bookkeeping: torch Parameters / buffers with the
+reference's names (`model.fc0.weight`, `model.drop0.noise`, `mx`, `Sy`, `scale`
+...), so reference checkpoints load and `resample()` / `set_dataset()` /
+`regularization_loss()` behave the same.  The arithmetic of the hot path
+(Linear -> ReLU -> dropout ... -> density sample -> squash / reward) is NOT done
+here: `prob_mbrl_amd.rollout.rollout` hands the tensors to the fused HIP kernels.
+"""
+import copy
+import inspect
+import math
+from collections import OrderedDict
+from collections.abc import Iterable
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+
+class StochasticModule(nn.Module):
+    """Marker base (models/modules.py:9-11)."""
+
+
+# ---------------------------------------------------------------------------
+# dropout layers: persistent (PEGASUS) masks
+# ---------------------------------------------------------------------------
+class BDropout(StochasticModule):
+    """Bernoulli dropout with a persistent mask (models/modules.py:14-70).
+    The masked activation is divided by the keep probability p."""
+
+    def __init__(self, rate=0.5, name=None, regularizer_scale=1.0, **kwargs):
+        super().__init__(**kwargs)
+        self.name = name
+        rate = rate if isinstance(rate, torch.Tensor) else torch.tensor(rate)
+        self.register_buffer('regularizer_scale', torch.tensor(0.5 * regularizer_scale))
+        self.register_buffer('rate', rate)
+        self.register_buffer('p', 1 - self.rate)
+        self.register_buffer('noise', torch.bernoulli(self.p))
+
+    # L2 terms of Gal & Ghahramani (models/modules.py:30-35)
+    def weights_regularizer(self, weights):
+        self.p = 1 - self.rate
+        return self.regularizer_scale * (self.p * (weights**2).sum(0)).sum()
+
+    def biases_regularizer(self, biases):
+        return self.regularizer_scale * ((biases**2).sum(0)).sum()
+
+    def resample(self, seed=None):
+        self.update_noise(self.noise, seed)
+
+    def update_noise(self, x, seed=None):
+        """Redraw the mask with the shape of x (models/modules.py:40-44); re-seeds the
+        GLOBAL torch RNG when a seed is given, like the reference."""
+        if seed is not None:
+            torch.manual_seed(int(seed))
+        self.p = 1 - self.rate
+        self.noise.data = torch.bernoulli(self.p.expand(x.shape).to(self.noise.device))
+
+    # --- what the fused rollout needs -------------------------------------
+    def keep_prob(self):
+        p = (1 - self.rate)
+        if p.numel() != 1:
+            raise NotImplementedError('per-unit BDropout rates are not offered on the device path')
+        return float(p)
+
+    def hard_mask(self, B, width):
+        """{0,1} mask [>=B, width]; (re)drawn when the stored one cannot be reused, with the
+        reference's rule (models/modules.py:48-54): wrong trailing shape or too few rows."""
+        n = self.noise
+        if n.dim() != 2 or n.shape[1] != width or n.shape[0] < B:
+            self.update_noise(torch.empty(B, width))
+        return self.noise
+
+    def forward(self, x, resample=True, mask_dims=2, seed=None, **kwargs):
+        raise NotImplementedError(
+            'stand-alone module forward is not part of the accelerated path; use '
+            'prob_mbrl_amd.utils.rollout / algorithms.mc_pilco')
+
+    def extra_repr(self):
+        return 'rate={}, regularizer_scale={}'.format(self.rate, self.regularizer_scale)
+
+
+class CDropout(BDropout):
+    """Concrete dropout (models/modules.py:73-171).  In eval mode (how mc_pilco runs the
+    dynamics model, algorithms/mc_pilco.py:43) the mask is a hard Bernoulli draw from the
+    concrete probabilities and is NOT divided by p."""
+
+    def __init__(self, rate=0.5, name=None, regularizer_scale=1.0, dropout_regularizer=1.0,
+                 temperature=0.1, **kwargs):
+        if not isinstance(rate, torch.Tensor):
+            rate = torch.tensor(np.asarray(rate), dtype=torch.get_default_dtype())
+        super().__init__(rate, name, regularizer_scale, **kwargs)
+        self.register_buffer('temp', torch.tensor(temperature))
+        self.register_buffer('dropout_regularizer', torch.tensor(dropout_regularizer))
+        self.logit_p = nn.Parameter(-torch.log(1.0 / self.p - 1.0))
+        self.register_buffer('concrete_noise', torch.bernoulli(self.p))
+
+    def weights_regularizer(self, weights):
+        p = self.p
+        reg = self.regularizer_scale * (p * (weights**2).sum(0))
+        reg = reg + self.dropout_regularizer * (p * p.log() + (1 - p) * (1 - p).log())
+        return reg.sum()
+
+    def update_noise(self, x, seed=None):
+        if seed is not None:
+            torch.manual_seed(int(seed))
+        self.noise.data = torch.rand(x.shape, device=self.noise.device, dtype=self.noise.dtype)
+        if not self.training:
+            self.update_concrete_noise(self.noise)
+
+    def update_concrete_noise(self, noise):
+        """models/modules.py:102-118: probs = sigmoid((logit_p + log((u+1e-7)/(1-(u-1e-7))))/temp),
+        hard sample with a straight-through value (exactly {0,1})."""
+        concrete_p = self.logit_p + ((noise + 1e-7) / (1 - (noise - 1e-7))).log()
+        probs = (concrete_p / self.temp).sigmoid()
+        hard = torch.bernoulli(probs)
+        self.concrete_noise = (hard - probs).detach() + probs
+        self.p = self.logit_p.sigmoid()
+
+    def keep_prob(self):
+        return 1.0   # x * concrete_noise, no division (models/modules.py:158-160)
+
+    def hard_mask(self, B, width):
+        if self.training:
+            raise NotImplementedError('training-mode (relaxed) concrete dropout is not on the '
+                                      'rollout path; call dynamics.eval() like mc_pilco does')
+        n, c = self.noise, self.concrete_noise
+        if (n.dim() != 2 or c.dim() != 2 or n.shape[1] != width or c.shape[1] != width
+                or c.shape[0] < B):
+            self.update_noise(torch.empty(B, width))
+        return self.concrete_noise.detach()
+
+
+# ---------------------------------------------------------------------------
+# output density
+# ---------------------------------------------------------------------------
+class DiagGaussianDensity(StochasticModule):
+    """Diagonal Gaussian head (models/densities.py:70-148): the network emits
+    [mean | log_std]; log_std is soft-clamped at log(max_noise_std); samples use the
+    persistent noise buffer z."""
+
+    def __init__(self, output_dims, max_noise_std=5.0):
+        super().__init__()
+        self.output_dims = output_dims
+        self.register_buffer('z', torch.ones([1, 1]))
+        self.register_buffer('max_log_std', torch.tensor(max_noise_std).log())
+        self.expl_scale = 1.0
+
+    def resample(self, seed=None):
+        if seed is not None:
+            torch.manual_seed(int(seed))
+        self.z.data = torch.randn_like(self.z)
+
+    def frozen_noise(self, B, resample_noise):
+        """z [B, dims] with the reference's refresh rule (models/densities.py:113-116)."""
+        D = int(self.output_dims)
+        if tuple(self.z.shape) != (B, D) or resample_noise:
+            self.z.data = torch.randn(B, D, device=self.z.device, dtype=self.z.dtype)
+        return self.z
+
+    def log_prob(self, z, mean, log_std=None):
+        """models/densities.py:123-144 (used by BNN training, not by the rollout)."""
+        deltas = mean - z
+        if log_std is None:
+            return -(deltas**2).sum(-1) * 0.5
+        return (-0.5 * ((deltas * (-log_std).exp())**2).sum(-1) - log_std.sum(-1) -
+                self.output_dims * 0.5 * math.log(2 * math.pi))
+
+    def forward(self, x, **kwargs):
+        raise NotImplementedError('stand-alone density forward is not part of the accelerated path')
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(output_dims=%d)' % self.output_dims
+
+
+# ---------------------------------------------------------------------------
+# containers
+# ---------------------------------------------------------------------------
+class BSequential(nn.Sequential):
+    """Sequential with resampling control and the dropout regulariser
+    (models/modules.py:198-274)."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.modules_to_regularize = []
+
+    def resample(self, seed=None):
+        i = 0
+        for module in self._modules.values():
+            if isinstance(module, BDropout):
+                module.resample(seed + i if seed is not None else None)
+                i += 1
+
+    def regularization_loss(self):
+        """For every dropout layer, regularise the next Linear's weights/biases."""
+        mods = list(self._modules.values())
+        total = 0
+        for i, m in enumerate(mods):
+            if hasattr(m, 'weights_regularizer'):
+                for nxt in mods[i:]:
+                    if isinstance(nxt, nn.Linear):
+                        total = total + m.weights_regularizer(nxt.weight)
+                        if nxt.bias is not None and hasattr(m, 'biases_regularizer'):
+                            total = total + m.biases_regularizer(nxt.bias)
+                        break
+            elif hasattr(m, 'regularization_loss'):
+                total = total + m.regularization_loss()
+        return total
+
+    def forward(self, input, **kwargs):
+        raise NotImplementedError('stand-alone network forward is not part of the accelerated path')
+
+    # --- structure the fused kernels understand ---------------------------
+    def layer_spec(self):
+        """Parse Linear -> [ReLU] -> [dropout] ... -> Linear [-> density] into
+        (linears, dropouts-per-hidden-layer, density)."""
+        linears, drops, density = [], [], None
+        pending = None
+        for name, m in self._modules.items():
+            if isinstance(m, nn.Linear):
+                if pending is not None:
+                    drops.append(pending['drop'])
+                    if not pending['relu']:
+                        raise NotImplementedError('hidden layers must use ReLU on the device path')
+                pending = dict(drop=None, relu=False)
+                linears.append(m)
+            elif isinstance(m, nn.ReLU):
+                pending['relu'] = True
+            elif isinstance(m, BDropout):
+                if pending is None:
+                    raise NotImplementedError('input dropout is not offered on the device path')
+                pending['drop'] = m
+            elif isinstance(m, DiagGaussianDensity):
+                density = m
+            else:
+                raise NotImplementedError('module %s (%s) is not offered on the device path' %
+                                          (name, type(m).__name__))
+        if pending is not None and (pending['drop'] is not None or pending['relu']):
+            raise NotImplementedError('the output layer must be a plain Linear')
+        return linears, drops, density
+
+
+def mlp(input_dims, output_dims, hidden_dims=[200, 200], nonlin=nn.ReLU, output_nonlin=None,
+        weights_initializer=partial(nn.init.xavier_normal_, gain=nn.init.calculate_gain('relu')),
+        biases_initializer=partial(nn.init.uniform_, a=-1e-1, b=1e-1), hidden_biases=True,
+        output_biases=True, dropout_layers=BDropout, input_dropout=None, spectral_norm=False,
+        spectral_norm_output=False, layer_norm=False):
+    """Same factory signature and module names as models/core.py:15-99
+    (fc%d / nonlin%d / drop%d / fc_out / fc_nonlin)."""
+    if spectral_norm or spectral_norm_output or layer_norm or input_dropout is not None:
+        raise NotImplementedError('spectral_norm / layer_norm / input_dropout are outside the '
+                                  'accelerated MC-PILCO path')
+    if not (hidden_biases and output_biases):
+        raise NotImplementedError('bias-free layers are not offered on the device path')
+    hidden_dims = list(hidden_dims)
+    dims = [int(input_dims)] + [int(h) for h in hidden_dims]
+    if not isinstance(dropout_layers, Iterable):
+        dropout_layers = [copy.deepcopy(dropout_layers)] * len(hidden_dims)
+    if not isinstance(nonlin, Iterable):
+        nonlin = [nonlin] * len(hidden_dims)
+    mods = OrderedDict()
+    for i, (din, dout) in enumerate(zip(dims[:-1], dims[1:])):
+        drop_i = dropout_layers[i]
+        if inspect.isclass(drop_i):
+            drop_i = drop_i(name='drop%d' % i)
+        mods['fc%d' % i] = nn.Linear(din, dout, bias=True)
+        if callable(nonlin[i]):
+            mods['nonlin%d' % i] = nonlin[i]()
+        if drop_i is not None:
+            mods['drop%d' % i] = drop_i
+    mods['fc_out'] = nn.Linear(dims[-1], int(output_dims), bias=True)
+    if callable(output_nonlin):
+        mods['fc_nonlin'] = output_nonlin()
+    net = BSequential(mods)
+    for m in net.modules():
+        if isinstance(m, nn.Linear):
+            if callable(weights_initializer):
+                weights_initializer(m.weight)
+            if callable(biases_initializer):
+                biases_initializer(m.bias)
+    net.float()
+    return net
+
+
+# ---------------------------------------------------------------------------
+# wrappers
+# ---------------------------------------------------------------------------
+class _Loadable(nn.Module):
+    def load(self, state_dict):
+        """Copy every matching parameter / buffer (models/core.py:154-159,214-219)."""
+        own = dict(self.named_parameters())
+        own.update(self.named_buffers())
+        for k, v in state_dict.items():
+            if k in own:
+                own[k].data = v.data.clone().to(own[k].device)
+
+    def regularization_loss(self):
+        return self.model.regularization_loss()
+
+
+class Regressor(_Loadable):
+    """models/core.py:121-187: input/output normalisation around a BNN."""
+
+    def __init__(self, model, output_density=None, angle_dims=[]):
+        super().__init__()
+        self.model = model
+        self.output_density = output_density
+        self.register_buffer('angle_dims', torch.tensor(angle_dims).long())
+        for name, val in (('X', 1.0), ('Y', 1.0), ('mx', 0.0), ('Sx', 1.0), ('iSx', 1.0),
+                          ('my', 0.0), ('Sy', 1.0), ('iSy', 1.0)):
+            self.register_buffer(name, torch.full([1, 1], val))
+
+    def set_dataset(self, X, Y, N_ensemble=-1, p=0.5):
+        if len(self.angle_dims):
+            raise NotImplementedError('angle_dims inside the dynamics model is not offered yet')
+        self.X.data = X
+        self.Y.data = Y
+        self.mx.data = self.X.mean(0, keepdim=True)
+        self.Sx.data = 4.0 * self.X.std(0, keepdim=True)
+        self.Sx.data[self.Sx == 0] = 4.0
+        self.iSx.data = self.Sx.reciprocal()
+        self.my.data = self.Y.mean(0, keepdim=True)
+        self.Sy.data = 4.0 * self.Y.std(0, keepdim=True)
+        self.Sy.data[self.Sy == 0] = 4.0
+        self.iSy.data = self.Sy.reciprocal()
+
+    def resample(self, *args, **kwargs):
+        self.model.resample(*args, **kwargs)
+        if self.output_density is not None:
+            self.output_density.resample(*args, **kwargs)
+
+    def forward(self, x, normalize=True, **kwargs):
+        raise NotImplementedError('stand-alone Regressor forward is not part of the accelerated path')
+
+
+class DynamicsModel(Regressor):
+    """models/core.py:251-303.  `reward_func` must be one of prob_mbrl_amd.rewards.*
+    (an analytic reward with a `.spec(D)`); a learned reward is not offered (the reference's
+    own learned-reward branch raises)."""
+
+    def __init__(self, model, reward_func=None, predict_done=False, **kwargs):
+        super().__init__(model, **kwargs)
+        self.register_buffer('maxR', torch.ones([1, 1]))
+        self.register_buffer('minR', torch.ones([1, 1]))
+        self.reward_func = reward_func
+
+    def set_dataset(self, X, Y):
+        super().set_dataset(X, Y)
+        D = self.Y.shape[-1] - 1
+        R = self.Y[..., D]
+        self.maxR.data = R.max()
+        self.minR.data = R.min()
+
+
+class Policy(_Loadable):
+    """models/core.py:190-248: BNN policy with tanh squashing to [minU, maxU]."""
+
+    def __init__(self, model, maxU=1.0, minU=None, angle_dims=[]):
+        super().__init__()
+        self.model = model
+        self.register_buffer('angle_dims', torch.tensor(angle_dims).long())
+        if minU is None:
+            minU = -maxU
+        scale = 0.5 * (maxU - minU)
+        bias = 0.5 * (maxU + minU)
+        self.register_buffer('scale', torch.as_tensor(scale).squeeze())
+        self.register_buffer('bias', torch.as_tensor(bias).squeeze())
+
+    def resample(self, *args, **kwargs):
+        self.model.resample(*args, **kwargs)
+
+    def forward(self, x, **kwargs):
+        raise NotImplementedError('stand-alone Policy forward is not part of the accelerated path '
+                                  'yet (SURVEY.md 8f N4); use prob_mbrl_amd.utils.rollout')

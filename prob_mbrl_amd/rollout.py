@@ -1,0 +1,283 @@
+"""`rollout()` with the reference's call surface (utils/rollout.py:62-163), backed
+by the fused HIP kernels.  Autograd sees ONE node per rollout
+(`RolloutFunction`), not thousands of aten ops: forward = pmbrl_rollout_fwd,
+backward = pmbrl_rollout_bwd (adjoint sweep + dW GEMM)."""
+import numpy as np
+import torch
+
+from . import engine as E
+from . import models as M
+
+
+# ---------------------------------------------------------------------------
+# flat parameter storage: the kernels take ONE pointer per network
+# ---------------------------------------------------------------------------
+def flat_parameters(linears, owner):
+    """Make the Linear weights/biases views of one flat fp32 buffer (torch parameter
+    order W0, b0, W1, b1, ...) and return it.  Re-done whenever the views were broken
+    (e.g. by module.cuda() / .float() / load())."""
+    params = []
+    for lin in linears:
+        params += [lin.weight, lin.bias]
+    flat = getattr(owner, '_pmbrl_flat', None)
+    ok = flat is not None
+    if ok:
+        off = 0
+        for p in params:
+            n = p.numel()
+            if (p.device != flat.device or p.dtype != torch.float32 or not p.is_contiguous()
+                    or p.data_ptr() != flat.data_ptr() + 4 * off):
+                ok = False
+                break
+            off += n
+        ok = ok and off == flat.numel()
+    if not ok:
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        owner._pmbrl_flat = flat
+    return flat, params
+
+
+class _MaskCache:
+    """bit-packed masks keyed on the identity + version of the float mask tensor"""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, mask, B):
+        sig = (mask.data_ptr(), mask._version, tuple(mask.shape), B)
+        hit = self.store.get(key)
+        if hit is None or hit[0] != sig:
+            m = mask[:B]
+            if m.dtype != torch.float32:
+                m = m.float()
+            hit = (sig, E.pack_mask(m.contiguous()))
+            self.store[key] = hit
+        return hit[1]
+
+    def ones(self, key, B, width, device):
+        sig = ('ones', B, width, str(device))
+        hit = self.store.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, E.pack_mask(torch.ones(B, width, device=device)))
+            self.store[key] = hit
+        return hit[1]
+
+
+_ENGINES = {}
+_MASKS = _MaskCache()
+
+
+def _reward_key(spec):
+    return (spec['kind'], spec['expand'], tuple(spec['angle_dims']),
+            np.asarray(spec['C'], dtype=np.float64).tobytes(),
+            np.asarray(spec['tip_target'], dtype=np.float64).tobytes(), float(spec['norm']),
+            float(spec['w']), np.asarray(spec['Q'], dtype=np.float64).tobytes(),
+            np.asarray(spec['R'], dtype=np.float64).tobytes())
+
+
+def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
+               mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
+               max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD)):
+    key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
+           tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
+           B_global, row_offset, zmm_per_step, max_log_std)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        if len(_ENGINES) > 16:
+            _ENGINES.clear()
+        eng = E.Engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec,
+                       mm_states=mm_states, mm_rewards=mm_rewards, mm_groups=mm_groups,
+                       device=device, B_global=B_global, row_offset=row_offset,
+                       zmm_per_step=zmm_per_step, max_log_std_pol=max_log_std[0],
+                       max_log_std_dyn=max_log_std[1])
+        _ENGINES[key] = eng
+    return eng
+
+
+class Bundle:
+    """Everything one rollout needs, gathered from the reference-shaped modules."""
+
+    def __init__(self, dynamics, policy, B, H, resample_state_noise, resample_action_noise,
+                 mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=None, row_offset=0):
+        if not isinstance(policy, M.Policy) or not isinstance(dynamics, M.DynamicsModel):
+            raise TypeError('rollout() needs prob_mbrl_amd.models.Policy / DynamicsModel')
+        if len(policy.angle_dims) or len(dynamics.angle_dims):
+            raise NotImplementedError('angle_dims inside Policy / DynamicsModel is not offered yet '
+                                      '(the examples feed the expanded state)')
+        if dynamics.reward_func is None or not hasattr(dynamics.reward_func, 'spec'):
+            raise NotImplementedError('DynamicsModel.reward_func must be a prob_mbrl_amd.rewards '
+                                      'module (learned rewards are not offered)')
+        plin, pdrop, pdens = policy.model.layer_spec()
+        dlin, ddrop, ddens_inner = dynamics.model.layer_spec()
+        ddens = dynamics.output_density
+        if not isinstance(pdens, M.DiagGaussianDensity) or not isinstance(ddens, M.DiagGaussianDensity) \
+                or ddens_inner is not None:
+            raise NotImplementedError('policy needs a DiagGaussianDensity output_nonlin and the '
+                                      'dynamics a DiagGaussianDensity output_density')
+        self.pol_flat, self.pol_params = flat_parameters(plin, policy.model)
+        self.dyn_flat, _ = flat_parameters(dlin, dynamics.model)
+        dev = self.pol_flat.device
+        if dev.type != 'cuda':
+            raise RuntimeError('prob_mbrl_amd: modules must live on a HIP device (no CPU fallback)')
+        if self.dyn_flat.device != dev:
+            raise RuntimeError('policy and dynamics must be on the same device')
+        self.device = dev
+        self.pol_dims = [plin[0].in_features] + [l.out_features for l in plin]
+        self.dyn_dims = [dlin[0].in_features] + [l.out_features for l in dlin]
+        self.D = self.pol_dims[0]
+        self.U = self.pol_dims[-1] // 2
+        if self.dyn_dims[0] != self.D + self.U or self.dyn_dims[-1] != 2 * self.D:
+            raise NotImplementedError('dynamics must map [x|u] (%d) to 2*|x| outputs; a learned '
+                                      'reward head is not offered' % (self.D + self.U))
+        self.B, self.H = B, H
+        if getattr(dynamics.reward_func, 'bind_action_dim', None):
+            dynamics.reward_func.bind_action_dim(self.U)
+        self.spec = dynamics.reward_func.spec(self.D)
+        self.pol_keep = [dr.keep_prob() if dr is not None else 1.0 for dr in pdrop]
+        self.dyn_keep = [dr.keep_prob() if dr is not None else 1.0 for dr in ddrop]
+        # masks (frozen unless resampled by the caller through .resample())
+        self.pol_bits, self.dyn_bits = [], []
+        for i, dr in enumerate(pdrop):
+            w = self.pol_dims[i + 1]
+            key = (id(policy), 'p', i)
+            self.pol_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else
+                                 _MASKS.get(key, dr.hard_mask(B, w), B))
+        for i, dr in enumerate(ddrop):
+            w = self.dyn_dims[i + 1]
+            key = (id(dynamics), 'd', i)
+            self.dyn_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else
+                                 _MASKS.get(key, dr.hard_mask(B, w), B))
+        # output noise: frozen buffer, or a fresh draw per step (models/densities.py:111-119)
+        if resample_action_noise:
+            self.z_pol = torch.randn(H, B, self.U, device=dev)
+            pdens.z.data = self.z_pol[-1]
+        else:
+            self.z_pol = pdens.frozen_noise(B, False)
+        if resample_state_noise:
+            self.z_dyn = torch.randn(H, B, self.D, device=dev)
+            ddens.z.data = self.z_dyn[-1]
+        else:
+            self.z_dyn = ddens.frozen_noise(B, False)
+        self.max_log_std = (float(pdens.max_log_std), float(ddens.max_log_std))
+        f = lambda t, n: t.detach().reshape(-1).float().expand(n).contiguous()  # noqa: E731
+        self.mx, self.iSx = f(dynamics.mx, self.D + self.U), f(dynamics.iSx, self.D + self.U)
+        self.my, self.Sy = f(dynamics.my, self.D), f(dynamics.Sy, self.D)
+        self.scale, self.bias = f(policy.scale, self.U), f(policy.bias, self.U)
+        # moment matching noise
+        self.mm_states, self.mm_rewards, self.mm_groups = mm_states, mm_rewards, mm_groups
+        Bg = B_global if B_global is not None else B
+        self.zmm_per_step = False
+        self.z_mm = self.z_rr = None
+        if mm_states:
+            if z_mm is None:   # utils/rollout.py:58-59: fresh noise every step
+                self.zmm_per_step = True
+                z_mm = torch.randn(H, Bg, self.D, device=dev)
+            self.z_mm = z_mm
+        if mm_rewards:
+            if z_rr is None:
+                self.zmm_per_step = True
+                z_rr = torch.randn(H, Bg, 1, device=dev)
+            self.z_rr = z_rr
+        if self.zmm_per_step and ((mm_states and self.z_mm.dim() != 3) or
+                                  (mm_rewards and self.z_rr.dim() != 3)):
+            raise NotImplementedError('pass both z_mm and z_rr, or neither')
+        self.engine = get_engine(B, self.D, self.U, H, self.pol_dims, self.pol_keep, self.dyn_dims,
+                                 self.dyn_keep, self.spec, mm_states, mm_rewards, mm_groups, dev,
+                                 B_global=B_global, row_offset=row_offset,
+                                 zmm_per_step=self.zmm_per_step, max_log_std=self.max_log_std)
+
+    def forward(self, x0, out=None):
+        return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
+                                   self.Sy, self.scale, self.bias, self.pol_bits, self.dyn_bits,
+                                   self.z_pol, self.z_dyn, self.z_mm, self.z_rr, out=out)
+
+
+class RolloutFunction(torch.autograd.Function):
+    """One autograd node for the whole H-step rollout."""
+
+    @staticmethod
+    def forward(ctx, bundle, x0, *pol_params):
+        eng = bundle.engine
+        dev = bundle.device
+        out = (torch.empty((eng.H + 1, eng.B, eng.D), device=dev),
+               torch.empty((eng.H, eng.B, eng.U), device=dev),
+               torch.empty((eng.H, eng.B, 1), device=dev))
+        S, A, R = bundle.forward(x0, out=out)
+        ctx.bundle = bundle
+        ctx.generation = eng.generation
+        ctx.set_materialize_grads(False)
+        return S, A, R
+
+    @staticmethod
+    def backward(ctx, gS, gA, gR):
+        bundle = ctx.bundle
+        eng = bundle.engine
+        if eng.generation != ctx.generation:
+            raise RuntimeError('stale rollout graph: another rollout ran on this plan before '
+                               'backward() (the stashes were overwritten)')
+        if gR is None:
+            gR = torch.zeros((eng.H, eng.B), device=bundle.device)
+        want_x0 = ctx.needs_input_grad[1]
+        g, gx0, _ = eng.backward(gR, grad_states=gS, grad_actions=gA, want_x0=want_x0)
+        g = g.clone()
+        grads, off = [], 0
+        for p in bundle.pol_params:
+            n = p.numel()
+            grads.append(g[off:off + n].view(p.shape))
+            off += n
+        return (None, gx0) + tuple(grads)
+
+
+def get_z_rnd(z, i, shape, device=None):
+    """utils/rollout.py:53-59 (kept for API parity; the kernels index the buffer themselves)."""
+    if z is not None:
+        idxs = torch.arange(i, i + shape[0], device=z.device) % shape[0]
+        return z[idxs]
+    return torch.randn(*shape, device=device)
+
+
+def rollout(states, dynamics, policy, steps, resample_model=False, resample_policy=False,
+            resample_state_noise=True, resample_action_noise=True, mm_states=False,
+            mm_rewards=False, infer_noise_variables=False, z_mm=None, z_rr=None, mm_groups=None,
+            breaking_condition=None, on_step=None, on_pol_eval=None, **kwargs):
+    """Trajectory distribution (s_0, a_0, r_0, s_1, ...) of `policy` on `dynamics` from the
+    given particles: returns [states (steps+1 x [B,D]), actions (steps x [B,U]),
+    rewards (steps x [B,1])], connected to policy.parameters() (and to `states`) for autograd.
+    Same arguments as the reference (utils/rollout.py:62-79)."""
+    if resample_model or resample_policy:
+        raise NotImplementedError('per-step mask resampling (resample_model / resample_policy) '
+                                  'is not offered on the device path')
+    if infer_noise_variables:
+        raise NotImplementedError('infer_noise_variables is not offered on the device path')
+    if callable(on_pol_eval):
+        raise NotImplementedError('on_pol_eval needs a per-step Python hook; not offered')
+    B = states.shape[0]
+    bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
+                    mm_states, mm_rewards, mm_groups, z_mm, z_rr,
+                    B_global=kwargs.pop('B_global', None), row_offset=kwargs.pop('row_offset', 0))
+    x0 = states.to(device=bundle.device, dtype=torch.float32)
+    S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
+    n = bundle.engine.valid_steps()
+    if n < steps:
+        # utils/rollout.py:154-157: keep a truncated horizon if enough steps succeeded
+        if n <= 5:
+            raise RuntimeError('rollout failed at step %d (non-finite state or non-positive '
+                               'Cholesky pivot in moment matching)' % n)
+    states_l = list(S[:n + 1].unbind(0))
+    actions_l = list(A[:n].unbind(0))
+    rewards_l = list(R[:n].unbind(0))
+    if callable(breaking_condition) or callable(on_step):
+        # the hooks see the trajectory prefix step by step, as in the reference loop
+        for t in range(n):
+            traj = list(zip(states_l[:t + 1], actions_l[:t + 1], rewards_l[:t + 1]))
+            if callable(breaking_condition) and breaking_condition(traj):
+                states_l, actions_l, rewards_l = states_l[:t + 2], actions_l[:t + 1], rewards_l[:t + 1]
+                break
+            if callable(on_step):
+                on_step(traj)
+    return [states_l, actions_l, rewards_l]

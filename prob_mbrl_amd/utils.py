@@ -1,0 +1,19 @@
+"""`prob_mbrl.utils` names used on the MC-PILCO path."""
+import torch
+
+from .rollout import get_z_rnd, rollout  # noqa: F401
+
+
+def tile(tensor, n):
+    """[G, D] -> [G*n, D] with row g*n+k = row g (utils/core.py:188-190): the
+    particle x sample layout (row = particle*S + sample) every kernel assumes."""
+    return tensor.repeat_interleave(int(n), dim=0)
+
+
+def to_complex(x, dims):
+    """utils/angles.py:7-42: [others, sin(angles), cos(angles)]."""
+    dims = [int(d) for d in dims]
+    if len(dims) == 0:
+        return x
+    others = [i for i in range(x.shape[-1]) if i not in dims]
+    return torch.cat([x[..., others], x[..., dims].sin(), x[..., dims].cos()], -1)

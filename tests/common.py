@@ -31,3 +31,59 @@ def rel(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def modules_from_fixture(d, name, device='cuda:0'):
+    """Build prob_mbrl_amd Policy / DynamicsModel (reference-shaped modules) holding the
+    fixture's weights, normalisation, frozen masks and noise."""
+    from functools import partial
+
+    import prob_mbrl_amd as pm
+    dev = torch.device(device)
+    B, D = d['x0'].shape
+    U = d['pol_z'].shape[1]
+    npl, ndl = int(d['pol_n_layers']), int(d['dyn_n_layers'])
+    pol_hid = [d['pol_W%d' % i].shape[0] for i in range(npl - 1)]
+    dyn_hid = [d['dyn_W%d' % i].shape[0] for i in range(ndl - 1)]
+    if name.startswith('dcp'):
+        rew = pm.rewards.DoubleCartpoleReward(pole1_length=torch.tensor(0.6),
+                                              pole2_length=torch.tensor(0.6))
+    elif name.startswith('pend'):
+        rew = pm.rewards.PendulumReward(pole_length=torch.tensor(1.0))
+    elif name.startswith('rdv'):
+        rew = pm.rewards.RendezvousReward()
+    else:
+        rew = pm.rewards.CartpoleReward(pole_length=torch.tensor(0.5))
+    dyn = pm.models.DynamicsModel(
+        pm.models.mlp(D + U, 2 * D, dyn_hid,
+                      dropout_layers=[pm.models.CDropout(0.1 * np.ones(h)) for h in dyn_hid],
+                      nonlin=torch.nn.ReLU),
+        reward_func=rew, output_density=pm.models.DiagGaussianDensity(D)).float()
+    maxU = np.asarray(d['pol_scale'], dtype=np.float32)
+    pol = pm.models.Policy(
+        pm.models.mlp(D, 2 * U, pol_hid,
+                      dropout_layers=[pm.models.BDropout(0.1) for _ in pol_hid],
+                      nonlin=torch.nn.ReLU,
+                      output_nonlin=partial(pm.models.DiagGaussianDensity, U)), maxU, -maxU).float()
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
+    with torch.no_grad():
+        for pre, mod, n in (('pol', pol.model, npl), ('dyn', dyn.model, ndl)):
+            lins = [m for m in mod._modules.values() if isinstance(m, torch.nn.Linear)]
+            for i, lin in enumerate(lins):
+                lin.weight.copy_(T(d['%s_W%d' % (pre, i)]))
+                lin.bias.copy_(T(d['%s_b%d' % (pre, i)]))
+        for i in range(npl - 1):
+            getattr(pol.model, 'drop%d' % i).noise.data = T(d['pol_mask%d' % i])
+        for i in range(ndl - 1):
+            dr = getattr(dyn.model, 'drop%d' % i)
+            dr.noise.data = torch.rand(B, dyn_hid[i])
+            dr.concrete_noise = T(d['dyn_mask%d' % i])
+        pol.model.fc_nonlin.z.data = T(d['pol_z'])
+        dyn.output_density.z.data = T(d['dyn_z'])
+        for k in ('mx', 'iSx', 'my', 'Sy'):
+            getattr(dyn, k).data = T(d['dyn_' + k]).reshape(1, -1)
+        dyn.Sx.data = dyn.iSx.reciprocal()
+    dyn = dyn.to(dev)
+    pol = pol.to(dev)
+    dyn.eval()
+    return dyn, pol

@@ -1,0 +1,149 @@
+"""GPU (-m gpu): the reference-shaped Python surface (models / utils.rollout /
+algorithms.mc_pilco) on top of the C ABI.  These read like the reference's own
+usage: build modules, call rollout(), loss.backward(), mc_pilco()."""
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _flat_grad(pol):
+    lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    return torch.cat([t.grad.reshape(-1) for l in lins for t in (l.weight, l.bias)]).cpu().numpy()
+
+
+@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if 'infer' not in n])
+def test_rollout_autograd_matches_reference(name):
+    """utils.rollout + the reference's loss + loss.backward() (algorithms/mc_pilco.py:134-197)."""
+    import prob_mbrl_amd as pm
+    d = common.load(name)
+    dyn, pol = common.modules_from_fixture(d, name, DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    H = int(d['H'])
+    G = int(d['mm_groups'])
+    kw = {}
+    if bool(d['mm_states']):
+        kw = dict(mm_states=True, mm_rewards=True, mm_groups=G if G > 0 else None,
+                  z_mm=torch.tensor(d['z_mm'], device=DEV), z_rr=torch.tensor(d['z_rr'], device=DEV))
+    states, actions, rewards = pm.utils.rollout(x0, dyn, pol, H, resample_state_noise=False,
+                                                resample_action_noise=False, **kw)
+    assert len(states) == H + 1 and len(actions) == H and len(rewards) == H
+    assert states[0].shape == x0.shape and rewards[0].shape == (x0.shape[0], 1)
+    gamma = [float(g) for g in d['gamma']]
+    disc = torch.stack([r * gamma[i] for i, r in enumerate(rewards)])
+    returns = -disc.sum(0) if bool(d['maximize']) else disc.sum(0)
+    loss = returns.mean()
+    pol.zero_grad()
+    loss.backward()
+    assert common.rel(torch.stack(states).detach().cpu().numpy(), d['ref64_states']) < 2e-5
+    assert abs(float(loss) - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+    assert common.rel(_flat_grad(pol), d['ref64_grad']) < 1e-4
+    # frozen buffers were used, not redrawn
+    assert torch.equal(pol.model.fc_nonlin.z.cpu(), torch.tensor(d['pol_z']))
+
+
+@pytest.mark.parametrize('name', common.fixture_names('mcp'))
+def test_mc_pilco_matches_reference_iterations(name):
+    """Fixtures from the REAL algorithms.mc_pilco (3-4 Adam iterations, fixed x0)."""
+    import prob_mbrl_amd as pm
+    d = common.load(name)
+    dyn, pol = common.modules_from_fixture(d, name, DEV)
+    opt = torch.optim.Adam(pol.parameters(), float(d['mcp_lr']))
+    x0 = torch.tensor(d['x0'], device=DEV)
+    losses = []
+    G = int(d['mm_groups'])
+    disc = None
+    gam = np.asarray(d['gamma'])
+    if not np.allclose(gam, gam[0]):
+        disc = float(gam[1] / gam[0])
+    pm.algorithms.mc_pilco(
+        x0, dyn, pol, int(d['H']), opt, None, int(d['mcp_n_iters']), mm_states=bool(d['mm_states']),
+        mm_rewards=bool(d['mm_rewards']), mm_groups=G if G > 0 else None, maximize=True,
+        clip_grad=float(d['mcp_clip']), discount=disc,
+        on_iteration=lambda i, loss, *a: losses.append(float(loss)),
+        frozen_noise=dict(z_mm=torch.tensor(d['z_mm']), z_rr=torch.tensor(d['z_rr'])))
+    assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
+    lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    final = torch.cat([t.detach().reshape(-1) for l in lins for t in (l.weight, l.bias)]).cpu().numpy()
+    assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+    # Adam state is visible through the torch optimiser object (drop-in: same opt reused later)
+    st = opt.state[lins[0].weight]
+    assert int(st['step']) == int(d['mcp_n_iters'])
+    m = torch.cat([opt.state[t]['exp_avg'].reshape(-1) for l in lins for t in (l.weight, l.bias)])
+    assert np.allclose(m.cpu().numpy(), d['ref32_mcp_exp_avg'], rtol=1e-3, atol=1e-7)
+
+
+def test_mc_pilco_autograd_path_options():
+    """CVaR + regulariser go through the autograd node; runs and moves the parameters."""
+    import prob_mbrl_amd as pm
+    d = common.load('nomm_d4')
+    dyn, pol = common.modules_from_fixture(d, 'nomm_d4', DEV)
+    before = pol.model.fc0.weight.detach().clone()
+    opt = torch.optim.Adam(pol.parameters(), 1e-3)
+    seen = []
+    pm.algorithms.mc_pilco(torch.tensor(d['x0'], device=DEV), dyn, pol, 8, opt, None, 3,
+                           cvar_eps=0.3, reg_weight=1e-3,
+                           on_iteration=lambda i, loss, s, a, r, disc: seen.append(float(loss)))
+    assert len(seen) == 3 and all(np.isfinite(seen))
+    assert not torch.equal(before, pol.model.fc0.weight.detach())
+
+
+def test_rollout_default_call_resamples_noise():
+    """rollout(x0, dyn, pol, H) with the reference defaults (fresh output noise per step)."""
+    import prob_mbrl_amd as pm
+    d = common.load('nomm_d5')
+    dyn, pol = common.modules_from_fixture(d, 'nomm_d5', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    with torch.no_grad():
+        s1, a1, r1 = pm.utils.rollout(x0, dyn, pol, 6)
+        s2, a2, r2 = pm.utils.rollout(x0, dyn, pol, 6)
+    assert len(s1) == 7 and torch.isfinite(torch.stack(s1)).all()
+    assert not torch.equal(s1[-1], s2[-1])            # new noise each call
+    assert torch.equal(s1[0], s2[0])
+    # moment matching without a PEGASUS buffer draws fresh z per step
+    s3, _, r3 = pm.utils.rollout(x0, dyn, pol, 6, mm_states=True, mm_rewards=True)
+    assert torch.isfinite(torch.stack(s3)).all() and torch.isfinite(torch.stack(r3)).all()
+
+
+def test_mc_pilco_failure_resamples_and_skips(capsys):
+    """Rank-deficient moment matching (M <= D rows per group): the reference prints the
+    traceback, resamples and skips the optimiser step (algorithms/mc_pilco.py:122-131)."""
+    import prob_mbrl_amd as pm
+    d = common.load('mmg_d4')
+    dyn, pol = common.modules_from_fixture(d, 'mmg_d4', DEV)
+    before = pol.model.fc1.weight.detach().clone()
+    opt = torch.optim.Adam(pol.parameters(), 1e-3)
+    calls = []
+    pm.algorithms.mc_pilco(torch.tensor(d['x0'], device=DEV), dyn, pol, 8, opt, None, 2,
+                           mm_states=True, mm_rewards=True, mm_groups=20,
+                           on_iteration=lambda *a: calls.append(1))
+    out = capsys.readouterr()
+    assert 'RuntimeError' in out.out
+    assert calls == [] and torch.equal(before, pol.model.fc1.weight.detach())
+
+
+def test_checkpoint_roundtrip_and_resample():
+    import prob_mbrl_amd as pm
+    d = common.load('nomm_d4')
+    dyn, pol = common.modules_from_fixture(d, 'nomm_d4', DEV)
+    dyn2, pol2 = common.modules_from_fixture(common.load('mmg_d4'), 'mmg_d4', DEV)
+    pol2.load(pol.state_dict())
+    dyn2.load(dyn.state_dict())
+    assert torch.equal(pol2.model.fc1.weight, pol.model.fc1.weight)
+    assert torch.equal(dyn2.model.drop0.concrete_noise, dyn.model.drop0.concrete_noise)
+    m0 = pol.model.drop0.noise.clone()
+    pol.resample(seed=torch.tensor([5]))
+    assert pol.model.drop0.noise.shape == m0.shape and not torch.equal(pol.model.drop0.noise, m0)
+    keep = float(pol.model.drop0.noise.mean())
+    assert 0.8 < keep < 0.97
+    dyn.resample(seed=torch.tensor([5]))
+    cn = dyn.model.drop0.concrete_noise
+    assert set(np.unique(cn.detach().cpu().numpy())) <= {0.0, 1.0}
+    x0 = torch.tensor(d['x0'], device=DEV)
+    s, a, r = pm.utils.rollout(x0, dyn, pol, 4, resample_state_noise=False,
+                               resample_action_noise=False)
+    assert torch.isfinite(torch.stack(s)).all()
