@@ -76,6 +76,21 @@ class Problem:
         self.infer_ns = bool(d['infer_ns']) if 'infer_ns' in d else False
         self.z_mm = f('z_mm') if 'z_mm' in d else None
         self.z_rr = f('z_rr') if 'z_rr' in d else None
+        # shard placement in a larger global batch (multi-GPU decomposition)
+        self.row_offset = 0
+        self.Bg = self.x0.shape[0]
+
+    def shard(self, lo, hi, G_local):
+        """View of rows [lo, hi) of this problem as one rank's shard."""
+        import copy
+        q = copy.copy(self)
+        q.x0 = self.x0[lo:hi]
+        q.pmask = [m[lo:hi] for m in self.pmask]
+        q.dmask = [m[lo:hi] for m in self.dmask]
+        q.pz, q.dz = self.pz[lo:hi], self.dz[lo:hi]
+        q.row_offset, q.Bg = lo, self.x0.shape[0]
+        q.G = G_local if G_local else 1
+        return q
 
 
 # ---------------------------------------------------------------------------
@@ -187,7 +202,7 @@ def forward(P):
         xt = x + (mu2 * P.Sy + P.my + P.dz[:B] * e2)
         Td = P.dz[:B] * e2 * sigmoid(-l2 + LOG_MAX_STD)
         rt, _ = reward_fwd(P, xt, a)
-        idx = (t + np.arange(B)) % B
+        idx = (t + P.row_offset + np.arange(B)) % P.Bg
         xn, r = xt, rt
         mmc_s = mmc_r = None
         if P.mm_states:
@@ -225,7 +240,7 @@ def forward(P):
 def loss_weights(P, B):
     """g[t,b] = dL/dr[t,b]  (algorithms/mc_pilco.py:134-144,190)."""
     sign = -1.0 if P.maximize else 1.0
-    return sign * P.gamma[:, None] * np.ones((1, B)) / B
+    return sign * P.gamma[:, None] * np.ones((1, B)) / P.Bg
 
 
 def backward(P, st, gr_all=None):

@@ -167,10 +167,16 @@ class Engine:
         assert len(dyn_mask_bits) == self.n_dyn_layers - 1
         if z_mm is not None:
             z_mm = _f32c(z_mm, dev)
-            assert z_mm.shape[0] >= self.cfg.B_global
+            if z_mm.dim() == 3:   # fresh rows per step (PMBRL_FLAG_ZMM_PER_STEP)
+                assert z_mm.shape == (self.H, self.cfg.B_global, self.D)
+            else:
+                assert z_mm.shape[0] >= self.cfg.B_global
         if z_rr is not None:
             z_rr = _f32c(z_rr, dev)
-            assert z_rr.shape[0] >= self.cfg.B_global
+            if z_rr.dim() == 3:
+                assert z_rr.shape == (self.H, self.cfg.B_global, 1)
+            else:
+                assert z_rr.shape[0] >= self.cfg.B_global
         inp = _lib.Inputs()
         inp.x0, inp.pol_params, inp.dyn_params = x0.data_ptr(), pol_flat.data_ptr(), dyn_flat.data_ptr()
         inp.mx, inp.iSx, inp.my, inp.Sy = mx.data_ptr(), iSx.data_ptr(), my.data_ptr(), Sy.data_ptr()

@@ -401,6 +401,12 @@ CASES = {
                                           [24, 24, 24], [20, 20, 20],
                                           RendezvousReward, [1.0, 2.0, 3.0, 4.0],
                                           21, 6, seed=12, maximize=True),
+    # example default: mm_groups=None with 100 particles -> ONE group of 100 rows
+    # (larger than a workgroup's row tiles: exercises the external moment-matching kernels)
+    'mm1_b100': lambda: make_case('mm1_b100', 5, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 8,
+                                  mm=True, seed=15),
+    'mmg_m80': lambda: make_case('mmg_m80', 4, 1, [16, 16], [16, 16], _cartpole, 10.0, 160, 6,
+                                 mm=True, mm_groups=2, seed=16, P=2),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
