@@ -41,6 +41,7 @@ extern "C" {
 #define PMBRL_FLAG_MM_STATES 1   /* utils/rollout.py:121-132 */
 #define PMBRL_FLAG_MM_REWARDS 2  /* utils/rollout.py:135-145 */
 #define PMBRL_FLAG_INFER_NS 4    /* utils/rollout.py:6-17 (mm_resample_infer_ns_) */
+#define PMBRL_FLAG_FORCE_GENERIC 16 /* do not use the latency-optimised kernel variants (tests) */
 #define PMBRL_FLAG_ZMM_PER_STEP 8 /* z_mm/z_rr are [H, B_global, .] fresh draws per step
                                      (utils/rollout.py:58-59, z=None) instead of the cyclic
                                      PEGASUS buffer of utils/rollout.py:53-57 */
@@ -209,6 +210,10 @@ enum {
 };
 int pmbrl_plan_set_timing(pmbrl_plan* plan, int on);
 int pmbrl_plan_read_timing(pmbrl_plan* plan, float* ms /* [PMBRL_TIMER_COUNT] */);
+
+/* Debug: workgroup 0 writes shader-clock stamps [H][32] at its phase boundaries
+ * (forward into fwd_d, backward sweep into bwd_d; NULL = off). */
+int pmbrl_plan_set_prof(pmbrl_plan* plan, long long* fwd_d, long long* bwd_d);
 
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout

@@ -15,6 +15,7 @@ MAX_ANGLE = 8
 MAX_TIP = 8
 MAX_DIM = 64
 FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
+FLAG_FORCE_GENERIC = 16
 REWARD_EXP, REWARD_NEG = 0, 1
 INFO_COUNT = 16
 TIMER_COUNT = 8
@@ -62,7 +63,7 @@ EXPORTS = [
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
     'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
-    'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing',
+    'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
 ]
 
 _lib = None
@@ -110,6 +111,8 @@ def load():
     lib.pmbrl_plan_set_timing.argtypes = [vp, C.c_int]
     lib.pmbrl_plan_read_timing.restype = C.c_int
     lib.pmbrl_plan_read_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pmbrl_plan_set_prof.restype = C.c_int
+    lib.pmbrl_plan_set_prof.argtypes = [vp, vp, vp]
     _lib = lib
     return lib
 

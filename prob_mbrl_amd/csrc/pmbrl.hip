@@ -13,6 +13,7 @@
 #include "pmbrl_dev.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
+#include "pmbrl_fast.h"
 #include "pmbrl_dw.h"
 
 static thread_local std::string g_err;
@@ -186,7 +187,7 @@ struct NetPlan {
 struct pmbrl_plan {
   pmbrl_config cfg;
   int device;
-  int RT, rows_per_wg, nwg, LD, mm_mode, G, M;
+  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast;
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
@@ -196,6 +197,8 @@ struct pmbrl_plan {
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
       off_gxc, off_grt, ws_bytes;
   // optional per-kernel timing (hipEvents on the caller's stream)
+  long long* prof_fwd;
+  long long* prof_bwd;
   int timing;
   hipEvent_t ev[PMBRL_TIMER_COUNT][2];
   bool ev_set[PMBRL_TIMER_COUNT];
@@ -244,6 +247,10 @@ static int set_attr(size_t lds) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<RT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
 
@@ -273,7 +280,13 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
 
   const bool mm = (c.flags & (PMBRL_FLAG_MM_STATES | PMBRL_FLAG_MM_REWARDS)) != 0;
   const size_t lds_cap = 160 * 1024;
+  p->fast = !(c.flags & PMBRL_FLAG_FORCE_GENERIC) &&
+            pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
+            pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   auto lds_need = [&](int RT, int mmd) {
+    if (p->fast)
+      return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
+                                p->dyn.nl, mmd) * sizeof(float);
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
   };
   p->G = 1;
@@ -441,6 +454,13 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   return 0;
 }
 
+extern "C" int pmbrl_plan_set_prof(pmbrl_plan* p, long long* fwd_d, long long* bwd_d) {
+  if (!p) return fail(-1, "null argument");
+  p->prof_fwd = fwd_d;
+  p->prof_bwd = bwd_d;
+  return 0;
+}
+
 extern "C" int pmbrl_plan_set_timing(pmbrl_plan* p, int on) {
   if (!p) return fail(-1, "null argument");
   if (on && !p->ev[0][0]) {
@@ -489,6 +509,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[7] = p->mm_mode;
   info[8] = p->LD;
   info[9] = p->n_dw_blocks;
+  info[10] = p->fast;
   return 0;
 }
 
@@ -556,6 +577,31 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.xt = reinterpret_cast<float*>(ws + p->off_xt);
   A.rt = reinterpret_cast<float*>(ws + p->off_rt);
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
+  if (p->fast) {
+    // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
+    const NetDev& P = A.pol;
+    const NetDev& F = A.dyn;
+    StreamDesc& f = A.sd_fwd;
+    f.n = 0;
+    for (int l = 1; l < P.nl - 1; ++l) { f.wf[f.n] = P.wf[l]; f.n_ot[f.n] = P.nt[l + 1]; f.n_kb[f.n] = P.nt[l]; f.n++; }
+    for (int l = 1; l < F.nl - 1; ++l) { f.wf[f.n] = F.wf[l]; f.n_ot[f.n] = F.nt[l + 1]; f.n_kb[f.n] = F.nt[l]; f.n++; }
+    StreamDesc& b = A.sd_bwd;
+    b.n = 0;
+    for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = F.nt[l + 1]; b.n++; }
+    for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = P.nt[l + 1]; b.n++; }
+    const size_t R = 16 * (size_t)p->RT;
+    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + (size_t)PM_NW * R * PM_HJ;
+    for (int l = 0; l < P.nl; ++l) { A.fo.pbias[l] = (int)o; o += (size_t)P.nt[l + 1] * 16; }
+    for (int l = 0; l < F.nl; ++l) { A.fo.dbias[l] = (int)o; o += (size_t)F.nt[l + 1] * 16; }
+    for (int l = 0; l < P.nl - 1; ++l) { A.fo.pmask[l] = (int)o; o += (R * P.nt[l + 1] + 1) / 2; }
+    for (int l = 0; l < F.nl - 1; ++l) { A.fo.dmask[l] = (int)o; o += (R * F.nt[l + 1] + 1) / 2; }
+  }
+  if (in->pol_params_d && in->dyn_params_d) {
+    A.pol_head_w = in->pol_params_d + p->pol.w_off[p->pol.nl - 1];
+    A.dyn_head_w = in->dyn_params_d + p->dyn.w_off[p->dyn.nl - 1];
+    A.pol_first_w = in->pol_params_d + p->pol.w_off[0];
+    A.dyn_first_w = in->dyn_params_d + p->dyn.w_off[0];
+  }
   return 0;
 }
 
@@ -578,11 +624,17 @@ static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t
 
 template <int RT>
 static void launch_fwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
-  hipLaunchKernelGGL(pm_rollout_fwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  if (p->fast)
+    hipLaunchKernelGGL(pm_rollout_fwd_fast<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  else
+    hipLaunchKernelGGL(pm_rollout_fwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
-  hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  if (p->fast)
+    hipLaunchKernelGGL(pm_rollout_bwd_fast<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  else
+    hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   switch (p->RT) {
@@ -611,6 +663,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   int rc = fill_args(p, workspace, in, A);
   if (rc) return rc;
   A.states = states_d; A.actions = actions_d; A.rewards = rewards_d; A.status = status_d;
+  A.prof = p->prof_fwd;
   char* ws = static_cast<char*>(workspace);
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
@@ -657,6 +710,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.grad_actions = grad_actions_d;
   A.grad_x0 = grad_x0_d;
   A.agn = action_grad_norms_d;
+  A.prof = p->prof_bwd;
   if (p->mm_mode != 2) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     A.gx_from_carry = 0;

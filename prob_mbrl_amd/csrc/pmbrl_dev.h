@@ -55,6 +55,17 @@ struct RewardDev {
   float RR[16 * 16];                        // R + R^T
 };
 
+// weight stream of the fast kernels: the hidden->hidden layers in processing order
+struct StreamDesc {
+  int n;
+  const float* wf[2 * PM_MAXL];
+  int n_ot[2 * PM_MAXL], n_kb[2 * PM_MAXL];
+};
+// LDS offsets (floats) of the per-layer regions of the fast kernels
+struct FastOff {
+  int pbias[PM_MAXL], dbias[PM_MAXL], pmask[PM_MAXL], dmask[PM_MAXL];
+};
+
 struct RolloutArgs {
   int B, D, U, H, Bg, row_off, flags;
   int G, M;            // moment-matching groups on this device, rows per group
@@ -77,7 +88,17 @@ struct RolloutArgs {
   float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
   int gx_from_carry;
   long long zpol_ss, zdyn_ss;   // per-step strides of z_pol / z_dyn (0 = frozen)
+  // raw (row-major) weights the fast kernels stage in LDS: head layers [n_out][K], first layers [h][in]
+  const float *pol_head_w, *dyn_head_w, *pol_first_w, *dyn_first_w;
+  StreamDesc sd_fwd, sd_bwd;
+  FastOff fo;
+  long long* prof;              // debug: cycle stamps [H][32] of workgroup 0 (nullptr = off)
 };
+
+#define PM_MARK(slot)                                                        \
+  do {                                                                        \
+    if (A.prof && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + (slot)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

@@ -1,0 +1,949 @@
+// Latency-optimised rollout kernels for the common small-state shapes
+// (first-layer K <= 16, heads <= 16 outputs, <= 16 tiles per hidden layer... see
+// pm_fast_ok()).  Same math and same stash layout as pmbrl_rollout.h; what
+// changes is WHERE the per-step latencies go:
+//   * every per-row / per-feature constant (biases, dropout bit rows, frozen
+//     noise z, normalisation vectors, reward constants) is staged in LDS once per
+//     launch instead of being re-read from HBM/L2 in every epilogue;
+//   * the first layer of each net (K = one 16-block) and the adjoint's first GEMM
+//     (K = head width) keep their weight fragments in REGISTERS for the launch;
+//   * the narrow head (2U / 2D outputs) and the adjoint's narrow tail (D / D+U
+//     outputs) are not GEMMs at all: they are folded into the epilogue of the
+//     neighbouring hidden layer as lane-local dot products against an LDS-resident
+//     matrix, reduced across the 4 lane groups by DPP shuffles and across the 4
+//     waves in the next elementwise phase (2 barriers and 2 L2 round trips fewer);
+//   * hidden->hidden layers stream their fragment-packed weights from L2 through a
+//     double-buffered register stage that always holds the NEXT item (next tile
+//     group, next layer, next net, next step) while the current one feeds the
+//     MFMAs, so the weight latency is paid once per launch, not once per layer.
+#pragma once
+#include "pmbrl_dev.h"
+#include "pmbrl_mm.h"
+#include "pmbrl_rollout.h"
+
+// Streamed layers: ONE output tile per wave in flight, two accumulator chains per row tile
+// (even / odd k-blocks) to cover the 40-cycle dependent-MFMA latency, and a register stage
+// of CKB k-blocks per buffer (64 VGPRs) -- the arch-VGPR file is 256 per lane, so the
+// stage depth, not the tile count, is where the prefetch distance comes from.
+#define PM_CKB_OF(RT) (8 / (RT))    // k-blocks (of 16) per streamed chunk (32 MFMAs of lookahead)
+#define PM_FNT 1
+#define PM_L0T 4           // max resident first-layer tiles per wave
+#define PM_HJ 16           // max fused head / tail width
+
+__host__ __device__ inline bool pm_fast_net_ok(const int* dim, const int* nt, int nl) {
+  if (nl < 2) return false;
+  if (nt[0] != 1) return false;                       // first-layer K fits one 16-block
+  if (dim[nl] > PM_HJ) return false;                  // fused head width
+  for (int l = 1; l < nl; ++l)
+    if (nt[l] > PM_NW * PM_L0T) return false;         // <= 16 tiles per hidden layer
+  return true;
+}
+
+template <int RT>
+struct FragS {
+  static constexpr int CKB = PM_CKB_OF(RT);
+  f32x4 a[PM_CKB_OF(RT)];
+};
+
+struct Cursor {
+  int li, g, c, live;
+};
+
+__device__ __forceinline__ void cur_settle(const StreamDesc& sd, Cursor& q, int wid) {
+  // skip layers in which this wave owns no tile; `live` = the wave has work at all
+  if (!q.live) return;
+  for (int k = 0; k < 2 * sd.n + 2; ++k) {
+    if (q.li >= sd.n) q.li = 0;
+    if (wid + q.g * PM_FNT * PM_NW < sd.n_ot[q.li]) return;
+    q.li++;
+    q.g = 0;
+    q.c = 0;
+  }
+}
+__device__ __forceinline__ void cur_init(const StreamDesc& sd, Cursor& q, int wid) {
+  q.li = 0; q.g = 0; q.c = 0; q.live = 0;
+  for (int l = 0; l < sd.n; ++l)
+    if (wid < sd.n_ot[l]) q.live = 1;
+  cur_settle(sd, q, wid);
+}
+template <int RT>
+__device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int wid) {
+  if (!q.live) return;
+  q.c++;
+  if (q.c * PM_CKB_OF(RT) >= sd.n_kb[q.li]) {
+    q.c = 0;
+    q.g++;
+  }
+  cur_settle(sd, q, wid);
+}
+
+template <int RT>
+__device__ __forceinline__ void frag_load(FragS<RT>& f, const StreamDesc& sd, const Cursor& q,
+                                          int wid, int lane) {
+  if (!q.live) return;
+  constexpr int CKB = PM_CKB_OF(RT);
+  const int n_kb = sd.n_kb[q.li];
+  const int ot = wid + q.g * PM_NW;      // settled cursor: ot < n_ot
+  const float* wp = sd.wf[q.li] + ((size_t)ot * n_kb + (size_t)q.c * CKB) * 256 + lane * 4;
+#pragma unroll
+  for (int cc = 0; cc < CKB; ++cc)
+    if (q.c * CKB + cc < n_kb) f.a[cc] = ldg4(wp + (size_t)cc * 256);
+}
+
+template <int RT>
+__device__ __forceinline__ void frag_compute(const FragS<RT>& f, int n_kb, int c,
+                                             const float* lds_in, int ld, int lane,
+                                             f32x4 (&acc)[2][RT]) {
+  constexpr int CKB = PM_CKB_OF(RT);
+  const float* bbase = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
+#pragma unroll
+  for (int cc = 0; cc < CKB; ++cc) {
+    const int kb = c * CKB + cc;
+    if (kb < n_kb) {
+      f32x4 b[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld + kb * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[cc & 1][rt] = mfma4(f.a[cc][j], b[rt][j], acc[cc & 1][rt]);
+    }
+  }
+}
+
+// One streamed layer.  Invariant on entry and exit: buffer[par] holds the item the
+// processing order reaches next, `q` is the item after it.
+template <int RT, class Epi>
+__device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Cursor& q, FragS<RT>& fa,
+                                             FragS<RT>& fb, int& par, const float* lds_in, int ld,
+                                             int wid, int lane, Epi& epi) {
+  constexpr int CKB = PM_CKB_OF(RT);
+  const int n_ot = sd.n_ot[li], n_kb = sd.n_kb[li];
+  const int nch = (n_kb + CKB - 1) / CKB;
+  for (int ot = wid; ot < n_ot; ot += PM_NW) {
+    f32x4 acc[2][RT];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; ++c) {
+      if (par == 0) {
+        frag_load<RT>(fb, sd, q, wid, lane);
+        frag_compute<RT>(fa, n_kb, c, lds_in, ld, lane, acc);
+      } else {
+        frag_load<RT>(fa, sd, q, wid, lane);
+        frag_compute<RT>(fb, n_kb, c, lds_in, ld, lane, acc);
+      }
+      cur_advance<RT>(sd, q, wid);
+      par ^= 1;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[0][rt] + acc[1][rt]);
+  }
+}
+
+// Register-resident single-k-block layer (first layer forward / head adjoint backward).
+template <int RT>
+struct Res0 {
+  f32x4 w[PM_L0T];
+};
+template <int RT>
+__device__ __forceinline__ void res0_load(Res0<RT>& r, const float* wf, int n_ot, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < PM_L0T; ++i) {
+    const int ot = wid + i * PM_NW;
+    r.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ot < n_ot) r.w[i] = ldg4(wf + (size_t)ot * 256 + lane * 4);
+  }
+}
+template <int RT, class Epi>
+__device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const float* lds_in, int ld,
+                                           int wid, int lane, Epi& epi) {
+  const float* bbase = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
+  f32x4 b[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld);
+#pragma unroll
+  for (int i = 0; i < PM_L0T; ++i) {
+    const int ot = wid + i * PM_NW;
+    if (ot < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma4(r.w[i][j], b[rt][j], acc);
+        epi(ot, rt, acc);
+      }
+    }
+  }
+}
+
+// Narrow head / tail as VALU dot products on LDS operands (no GEMM, no weight traffic):
+//   out[r][j] = sum_k act[r][k] * M[j][k]      r < R, j < nj, k < K16
+// R*nj dot products of length K16 spread over the workgroup, `tpd` threads per product
+// (float4 strided slices + xor-shuffle reduce).  Caller syncs before reading `out`.
+template <int R>
+__device__ __forceinline__ void narrow_dot(const float* act, int ld, const float* M, int ldm, int nj,
+                                           int K16, float* out, int tid) {
+  const int nd = R * nj;
+  int tpd = 1;
+  while (tpd < 16 && nd * tpd * 2 <= PM_NT) tpd *= 2;
+  const int slice = tid & (tpd - 1);
+  const int dpr = PM_NT / tpd;                 // products per round
+  const int nk4 = K16 >> 2;
+  for (int base = 0; base < nd; base += dpr) {
+    const int dot = base + tid / tpd;
+    float s = 0.f;
+    int r = 0, j = 0;
+    if (dot < nd) {
+      r = dot / nj;
+      j = dot - r * nj;
+      const float* a = act + r * ld;
+      const float* m = M + j * ldm;
+      for (int k4 = slice; k4 < nk4; k4 += tpd) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + 4 * k4);
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * k4);
+        s = fmaf(av[0], mv[0], s);
+        s = fmaf(av[1], mv[1], s);
+        s = fmaf(av[2], mv[2], s);
+        s = fmaf(av[3], mv[3], s);
+      }
+    }
+    for (int o = tpd >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (dot < nd && slice == 0) out[r * PM_HJ + j] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// epilogues reading bias / masks from LDS
+// ---------------------------------------------------------------------------
+template <int RT>
+struct EpiFwdL {
+  const float* bias;        // LDS, padded
+  const uint16_t* mask;     // LDS [R][nt]
+  uint16_t* abits;          // HBM [B][nt] slice of step t
+  float keep;
+  float* lds_out;
+  float* stash;             // HBM block or nullptr
+  int ld, Rw, row0, nvalid, nt, lane;
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+    const int g = lane >> 4;
+    const int lrow = rt * 16 + (lane & 15);
+    const int f0 = ot * 16 + 4 * g;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
+    const unsigned mw = mask[lrow * nt + ot];
+    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    f32x4 h;
+    unsigned act = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[r] + b[r];
+      const bool a = ((nib >> r) & 1u) && (v > 0.f);
+      h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
+      act |= (a ? 1u : 0u) << r;
+    }
+    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if (stash) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+    }
+    unsigned w16 = act << (4 * g);
+    w16 |= __shfl_xor(w16, 16);
+    w16 |= __shfl_xor(w16, 32);
+    if (g == 0 && lrow < nvalid) abits[(size_t)(row0 + lrow) * nt + ot] = (uint16_t)w16;
+  }
+};
+
+template <int RT>
+struct EpiBwdL {
+  const uint16_t* abits;    // HBM [B][nt] slice of step t
+  float keep;
+  float* lds_out;
+  float* stash;
+  int ld, Rw, row0, nvalid, nt, lane;
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+    const int g = lane >> 4;
+    const int lrow = rt * 16 + (lane & 15);
+    const int f0 = ot * 16 + 4 * g;
+    unsigned mw = 0;
+    if (lrow < nvalid) mw = abits[(size_t)(row0 + lrow) * nt + ot];
+    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
+    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if (stash) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// reward on LDS rows with LDS-resident constants (no private arrays)
+// ---------------------------------------------------------------------------
+// phi row scratch: ph[De]; returns r, leaves delta in dl[k]
+__device__ inline float reward_lds(const RewardDev* rw, const float* x, int D, const float* a, int U,
+                                   float* ph, float* dl) {
+  int De = D;
+  if (rw->expand) {
+    const int no = rw->n_other, na = rw->n_angle;
+    for (int i = 0; i < no; ++i) ph[i] = x[rw->other_dims[i]];
+    for (int j = 0; j < na; ++j) {
+      const float th = x[rw->angle_dims[j]];
+      ph[no + j] = sinf(th);
+      ph[no + na + j] = cosf(th);
+    }
+    De = no + 2 * na;
+  } else {
+    for (int i = 0; i < D; ++i) ph[i] = x[i];
+  }
+  const int k = rw->k;
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < De; ++j) s = fmaf(ph[j], rw->C[i * De + j], s);
+    dl[i] = s - rw->tt[i];
+  }
+  float cost = 0.f;
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s = fmaf(dl[j], rw->Q[j * k + i], s);
+    cost = fmaf(s, dl[i], cost);
+  }
+  for (int i = 0; i < U; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->R[j * U + i], s);
+    cost = fmaf(s, a[i], cost);
+  }
+  cost *= rw->w;
+  return rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
+}
+
+// adjoint; ph/dl as left by reward_lds for the same row; gph: scratch [De]; adds into gx[D],
+// writes ga[U] (row-strided LDS)
+__device__ inline void reward_lds_bwd(const RewardDev* rw, const float* x, int D, const float* a,
+                                      int U, float r, float gr, const float* ph, const float* dl,
+                                      float* gph, float* gx, float* ga) {
+  const float gc = (rw->kind == PMBRL_REWARD_EXP ? -gr * r : -gr) * rw->w;
+  const int k = rw->k;
+  const int De = rw->expand ? rw->n_other + 2 * rw->n_angle : D;
+  for (int j = 0; j < De; ++j) gph[j] = 0.f;
+  for (int i = 0; i < k; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s = fmaf(dl[j], rw->QQ[j * k + i], s);
+    const float gd = gc * s;
+    for (int j = 0; j < De; ++j) gph[j] = fmaf(gd, rw->C[i * De + j], gph[j]);
+  }
+  for (int i = 0; i < U; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->RR[j * U + i], s);
+    ga[i] = gc * s;
+  }
+  if (rw->expand) {
+    const int no = rw->n_other, na = rw->n_angle;
+    for (int i = 0; i < no; ++i) gx[rw->other_dims[i]] += gph[i];
+    for (int j = 0; j < na; ++j)   // ph holds sin / cos of the angle already
+      gx[rw->angle_dims[j]] += gph[no + j] * ph[no + na + j] - gph[no + na + j] * ph[no + j];
+  } else {
+    for (int i = 0; i < D; ++i) gx[i] += gph[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LDS map of the fast kernels
+// ---------------------------------------------------------------------------
+struct FastLds {
+  float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr;
+  float *hp;                     // narrow head / tail results [R][PM_HJ]
+  float* base;
+  float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
+  float *mA, *mB;                // fused matrices (fwd: policy head, dynamics head; bwd: tails)
+  float *ph, *dl, *gph;          // reward scratch [R][PMBRL_MAX_DIM], [R][8], [R][PMBRL_MAX_DIM]
+  RewardDev* rew;
+  double* mm;
+};
+
+__host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
+                                                     const int* pnt, int pnl, const int* dnt,
+                                                     int dnl, int mm_d) {
+  size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
+  n += (size_t)R * PM_HJ;
+  for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
+  for (int l = 0; l < dnl; ++l) n += (size_t)dnt[l + 1] * 16;
+  for (int l = 0; l < pnl - 1; ++l) n += ((size_t)R * pnt[l + 1] + 1) / 2;
+  for (int l = 0; l < dnl - 1; ++l) n += ((size_t)R * dnt[l + 1] + 1) / 2;
+  n += (size_t)R * U + (size_t)R * D;                 // zp, zd
+  n += 2 * (size_t)(D + U) + 3 * (size_t)D + 2 * (size_t)U;
+  n = (n + 3) & ~(size_t)3;
+  n += 2 * (size_t)PM_HJ * LD;                        // mA, mB
+  n += (size_t)R * (2 * PMBRL_MAX_DIM + 8);           // ph, gph, dl
+  n += (sizeof(RewardDev) + 3) / 4;
+  n = (n + 3) & ~(size_t)3;
+  n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);
+  return n;
+}
+
+__device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
+                                        const NetDev& P, const NetDev& F) {
+  FastLds m;
+  float* p = base;
+  m.bufA = p; p += (size_t)R * LD;
+  m.bufB = p; p += (size_t)R * LD;
+  m.xa = p; p += (size_t)R * D;
+  m.xb = p; p += (size_t)R * D;
+  m.av = p; p += (size_t)R * U;
+  m.gad = p; p += (size_t)R * 16;
+  m.rr = p; p += R;
+  m.gr = p; p += R;
+  m.hp = p; p += (size_t)R * PM_HJ;
+  m.base = base;
+  for (int l = 0; l < P.nl; ++l) p += (size_t)P.nt[l + 1] * 16;
+  for (int l = 0; l < F.nl; ++l) p += (size_t)F.nt[l + 1] * 16;
+  for (int l = 0; l < P.nl - 1; ++l) p += ((size_t)R * P.nt[l + 1] + 1) / 2;
+  for (int l = 0; l < F.nl - 1; ++l) p += ((size_t)R * F.nt[l + 1] + 1) / 2;
+  m.zp = p; p += (size_t)R * U;
+  m.zd = p; p += (size_t)R * D;
+  m.mx = p; p += D + U;
+  m.iSx = p; p += D + U;
+  m.my = p; p += D;
+  m.Sy = p; p += D;
+  m.lSy = p; p += D;
+  m.psc = p; p += U;
+  m.pbi = p; p += U;
+  size_t n = ((size_t)(p - base) + 3) & ~(size_t)3;
+  p = base + n;
+  m.mA = p; p += (size_t)PM_HJ * LD;
+  m.mB = p; p += (size_t)PM_HJ * LD;
+  m.ph = p; p += (size_t)R * PMBRL_MAX_DIM;
+  m.gph = p; p += (size_t)R * PMBRL_MAX_DIM;
+  m.dl = p; p += (size_t)R * 8;
+  m.rew = reinterpret_cast<RewardDev*>(p);
+  p += (sizeof(RewardDev) + 3) / 4;
+  n = ((size_t)(p - base) + 3) & ~(size_t)3;
+  m.mm = reinterpret_cast<double*>(base + n);
+  return m;
+}
+
+// per-layer LDS regions: offsets (in floats from the LDS base) live in the kernel
+// arguments (FastOff, filled on the host with the same walk as pm_fast_carve) so that a
+// runtime layer index becomes a scalar load, not a private-memory array access
+#define PBIAS(l) (L.base + A.fo.pbias[l])
+#define DBIAS(l) (L.base + A.fo.dbias[l])
+#define PMASK(l) (reinterpret_cast<uint16_t*>(L.base + A.fo.pmask[l]))
+#define DMASK(l) (reinterpret_cast<uint16_t*>(L.base + A.fo.dmask[l]))
+
+// stage launch-invariant data in LDS
+template <int RT>
+__device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, int row0, int nvalid,
+                                       int tid) {
+  constexpr int R = 16 * RT;
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+  const int D = A.D, U = A.U;
+  for (int l = 0; l < P.nl; ++l)
+    for (int i = tid; i < P.nt[l + 1] * 16; i += PM_NT) PBIAS(l)[i] = P.bias[l][i];
+  for (int l = 0; l < F.nl; ++l)
+    for (int i = tid; i < F.nt[l + 1] * 16; i += PM_NT) DBIAS(l)[i] = F.bias[l][i];
+  for (int l = 0; l < P.nl - 1; ++l) {
+    const int nt = P.nt[l + 1];
+    for (int i = tid; i < R * nt; i += PM_NT) {
+      const int r = i / nt;
+      PMASK(l)[i] = (r < nvalid) ? P.mask[l][(size_t)(row0 + r) * nt + (i - r * nt)] : (uint16_t)0;
+    }
+  }
+  for (int l = 0; l < F.nl - 1; ++l) {
+    const int nt = F.nt[l + 1];
+    for (int i = tid; i < R * nt; i += PM_NT) {
+      const int r = i / nt;
+      DMASK(l)[i] = (r < nvalid) ? F.mask[l][(size_t)(row0 + r) * nt + (i - r * nt)] : (uint16_t)0;
+    }
+  }
+  for (int i = tid; i < R * U; i += PM_NT)
+    L.zp[i] = (i / U < nvalid && A.zpol_ss == 0) ? A.zpol[(size_t)row0 * U + i] : 0.f;
+  for (int i = tid; i < R * D; i += PM_NT)
+    L.zd[i] = (i / D < nvalid && A.zdyn_ss == 0) ? A.zdyn[(size_t)row0 * D + i] : 0.f;
+  for (int i = tid; i < D + U; i += PM_NT) {
+    L.mx[i] = A.mx[i];
+    L.iSx[i] = A.iSx[i];
+  }
+  for (int i = tid; i < D; i += PM_NT) {
+    L.my[i] = A.my[i];
+    L.Sy[i] = A.Sy[i];
+    L.lSy[i] = logf(A.Sy[i]);
+  }
+  for (int i = tid; i < U; i += PM_NT) {
+    L.psc[i] = A.pscale[i];
+    L.pbi[i] = A.pbias[i];
+  }
+  {
+    const int* src = reinterpret_cast<const int*>(A.rew);
+    int* dst = reinterpret_cast<int*>(L.rew);
+    for (int i = tid; i < (int)(sizeof(RewardDev) / 4); i += PM_NT) dst[i] = src[i];
+  }
+}
+
+// ===========================================================================
+// forward (fast)
+// ===========================================================================
+template <int RT>
+__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row0 = wg * A.rows_per_wg;
+  const int nvalid = min(A.rows_per_wg, A.B - row0);
+  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+  FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
+  float* xa = L.xa;
+  float* xb = L.xb;
+
+  pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  // fused head matrices: M[j][k] = W_head[j][k], zero padded to LD columns
+  {
+    const int Kp = P.dim[P.nl - 1], Op = P.dim[P.nl];
+    const float* Wp = A.pol_head_w;
+    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+      const int j = i / LD, k = i - j * LD;
+      L.mA[i] = (j < Op && k < Kp) ? Wp[(size_t)j * Kp + k] : 0.f;
+    }
+    const int Kd = F.dim[F.nl - 1], Od = F.dim[F.nl];
+    const float* Wd = A.dyn_head_w;
+    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+      const int j = i / LD, k = i - j * LD;
+      L.mB[i] = (j < Od && k < Kd) ? Wd[(size_t)j * Kd + k] : 0.f;
+    }
+  }
+  {
+    const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
+    for (int i = tid; i < R * D; i += PM_NT) {
+      const int r = i / D, d = i - r * D;
+      const float v = (r < nvalid) ? src[(size_t)(row0 + r) * D + d] : 0.f;
+      xa[i] = v;
+      if (A.t0 == 0 && r < nvalid) A.states[(size_t)(row0 + r) * D + d] = v;
+    }
+  }
+  // register-resident first layers
+  Res0<RT> w0p, w0d;
+  res0_load<RT>(w0p, P.wf[0], P.nt[1], wid, lane);
+  res0_load<RT>(w0d, F.wf[0], F.nt[1], wid, lane);
+  // weight stream over the hidden->hidden layers of both nets
+  const StreamDesc& sd = A.sd_fwd;      // policy hidden layers, then dynamics hidden layers
+  const int n_pol_stream = P.nl - 2;
+  Cursor q;
+  cur_init(sd, q, wid);
+  FragS<RT> fa, fb;
+  int par = 0;
+  if (sd.n > 0) {
+    frag_load<RT>(fa, sd, q, wid, lane);
+    cur_advance<RT>(sd, q, wid);
+  }
+  __syncthreads();
+
+  for (int t = A.t0; t < A.t1; ++t) {
+    const size_t blk = (size_t)t * A.nwg + wg;
+    float* X = L.bufA;
+    float* Y = L.bufB;
+    PM_MARK(0);
+    {
+      float* st = A.actT[0] + blk * (size_t)16 * A.Rw;
+      for (int i = tid; i < R * 16; i += PM_NT) {
+        const int k = i / R, r = i - k * R;
+        const float v = (k < D) ? xa[r * D + k] : 0.f;
+        X[r * LD + k] = v;
+        st[(size_t)k * A.Rw + r] = v;
+      }
+    }
+    __syncthreads();
+    PM_MARK(1);
+    // ---- policy: first layer (resident), hidden layers (streamed), head as LDS dot products
+    {
+      const int nt = P.nt[1];
+      EpiFwdL<RT> e{PBIAS(0), PMASK(0), P.abits[0] + (size_t)t * B * nt, P.keep[0], Y,
+                    A.actT[1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
+                    row0, nvalid, nt, lane};
+      res0_layer<RT>(w0p, nt, X, LD, wid, lane, e);
+    }
+    __syncthreads();
+    { float* tmp = X; X = Y; Y = tmp; }
+    PM_MARK(2);
+    for (int l = 1; l < P.nl - 1; ++l) {
+      const int nt = P.nt[l + 1];
+      EpiFwdL<RT> e{PBIAS(l), PMASK(l), P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+                    A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
+                    row0, nvalid, nt, lane};
+      stream_layer<RT>(sd, l - 1, q, fa, fb, par, X, LD, wid, lane, e);
+      __syncthreads();
+      { float* tmp = X; X = Y; Y = tmp; }
+      PM_MARK(2 + l);
+    }
+    narrow_dot<R>(X, LD, L.mA, LD, P.dim[P.nl], P.nt[P.nl - 1] * 16, L.hp, tid);
+    __syncthreads();
+    PM_MARK(10);
+    // ---- squash + dynamics input
+    {
+      const float* hb = PBIAS(P.nl - 1);
+      for (int i = tid; i < R * 16; i += PM_NT) {
+        const int r = i >> 4, k = i & 15;
+        float v = 0.f;
+        if (k < D) {
+          v = (xa[r * D + k] - L.mx[k]) * L.iSx[k];
+        } else if (k < D + U) {
+          const int j = k - D;
+          const float mu = hb[j] + L.hp[r * PM_HJ + j];
+          const float ls = hb[U + j] + L.hp[r * PM_HJ + U + j];
+          float z = L.zp[r * U + j];
+          if (A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
+          const float lc = -softplusf(-ls + A.mls_pol) + A.mls_pol;
+          const float e = expf(lc);
+          const float u = mu + z * e;
+          const float a = L.psc[j] * tanhf(u) + L.pbi[j];
+          L.av[r * U + j] = a;
+          if (r < nvalid) {
+            const size_t o = ((size_t)t * B + row0 + r) * U + j;
+            A.actions[o] = a;
+            A.Tp[o] = z * e * sigmoidf(-ls + A.mls_pol);
+          }
+          v = (a - L.mx[k]) * L.iSx[k];
+        }
+        X[r * LD + k] = v;
+      }
+    }
+    __syncthreads();
+    PM_MARK(11);
+    // ---- dynamics
+    {
+      const int nt = F.nt[1];
+      EpiFwdL<RT> e{DBIAS(0), DMASK(0), F.abits[0] + (size_t)t * B * nt, F.keep[0], Y, nullptr,
+                    LD, A.Rw, row0, nvalid, nt, lane};
+      res0_layer<RT>(w0d, nt, X, LD, wid, lane, e);
+    }
+    __syncthreads();
+    { float* tmp = X; X = Y; Y = tmp; }
+    PM_MARK(12);
+    for (int l = 1; l < F.nl - 1; ++l) {
+      const int nt = F.nt[l + 1];
+      EpiFwdL<RT> e{DBIAS(l), DMASK(l), F.abits[l] + (size_t)t * B * nt, F.keep[l], Y, nullptr,
+                    LD, A.Rw, row0, nvalid, nt, lane};
+      stream_layer<RT>(sd, n_pol_stream + l - 1, q, fa, fb, par, X, LD, wid, lane, e);
+      __syncthreads();
+      { float* tmp = X; X = Y; Y = tmp; }
+      PM_MARK(12 + l);
+    }
+    narrow_dot<R>(X, LD, L.mB, LD, F.dim[F.nl], F.nt[F.nl - 1] * 16, L.hp, tid);
+    __syncthreads();
+    PM_MARK(20);
+    // ---- sample next state
+    {
+      const float* hb = DBIAS(F.nl - 1);
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, d = i - r * D;
+        const float mu = hb[d] + L.hp[r * PM_HJ + d];
+        const float ls = hb[D + d] + L.hp[r * PM_HJ + D + d];
+        float z = L.zd[i];
+        if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
+        const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + L.lSy[d];
+        const float e = expf(lc);
+        const float xn = xa[i] + (mu * L.Sy[d] + L.my[d] + z * e);
+        xb[i] = xn;
+        if (r < nvalid) {
+          const size_t o = ((size_t)t * B + row0 + r) * D + d;
+          A.Td[o] = z * e * sigmoidf(-ls + A.mls_dyn);
+          if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
+          else A.states[o + (size_t)B * D] = xn;
+        }
+      }
+    }
+    __syncthreads();
+    PM_MARK(21);
+    for (int r = tid; r < R; r += PM_NT) {
+      float rv = 0.f;
+      if (r < nvalid) {
+        rv = reward_lds(L.rew, xb + r * D, D, L.av + r * U, U, L.ph + r * PMBRL_MAX_DIM, L.dl + r * 8);
+        bool ok = isfinite(rv);
+        for (int d = 0; d < D; ++d) ok = ok && isfinite(xb[r * D + d]);
+        if (!ok) atomicMin(A.status, t);
+        const size_t o = (size_t)t * B + row0 + r;
+        if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
+        else A.rewards[o] = rv;
+      }
+      L.rr[r] = rv;
+    }
+    if (A.mm_mode == 1) {
+      __syncthreads();
+      const int gpw = A.rows_per_wg / A.M;
+      for (int gi = wid; gi < gpw; gi += PM_NW) {
+        const int lr0 = gi * A.M;
+        if (lr0 >= nvalid) break;
+        double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
+        if (A.flags & PMBRL_FLAG_MM_STATES) {
+          const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
+                                    xa + lr0 * D, D, scr, lane);
+          if (!ok && lane == 0) atomicMin(A.status, t);
+        }
+        if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+          const bool ok = pm_mm_fwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
+                                    L.gr + lr0, 1, scr, lane);
+          if (!ok && lane == 0) atomicMin(A.status, t);
+        }
+      }
+      __syncthreads();
+      if (A.flags & PMBRL_FLAG_MM_STATES) {
+        for (int i = tid; i < nvalid * D; i += PM_NT)
+          A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
+      }
+      if (A.flags & PMBRL_FLAG_MM_REWARDS) {
+        for (int r = tid; r < nvalid; r += PM_NT) A.rewards[(size_t)t * B + row0 + r] = L.gr[r];
+      }
+      if (!(A.flags & PMBRL_FLAG_MM_STATES)) { float* tmp = xa; xa = xb; xb = tmp; }
+    } else {
+      float* tmp = xa; xa = xb; xb = tmp;
+    }
+    __syncthreads();
+    PM_MARK(22);
+  }
+}
+
+// ===========================================================================
+// backward sweep (fast)
+// ===========================================================================
+template <int RT>
+__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row0 = wg * A.rows_per_wg;
+  const int nvalid = min(A.rows_per_wg, A.B - row0);
+  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+  FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
+  float* gx = L.xa;
+  float* gxt = L.xb;
+  const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
+  const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+
+  pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  // fused tails: mA[j][k] = V0[k][j] (dynamics first layer, j < D+U), mB[j][k] = W0[k][j] (policy)
+  {
+    const int Kd = F.dim[1], Od = F.dim[0];
+    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+      const int j = i / LD, k = i - j * LD;
+      L.mA[i] = (j < Od && k < Kd) ? A.dyn_first_w[(size_t)k * Od + j] : 0.f;
+    }
+    const int Kp = P.dim[1], Op = P.dim[0];
+    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+      const int j = i / LD, k = i - j * LD;
+      L.mB[i] = (j < Op && k < Kp) ? A.pol_first_w[(size_t)k * Op + j] : 0.f;
+    }
+  }
+  for (int i = tid; i < R * D; i += PM_NT) {
+    const int r = i / D, d = i - r * D;
+    float v = 0.f;
+    if (r < nvalid) {
+      if (A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
+      else if (A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
+    }
+    gx[i] = v;
+  }
+  // resident head-adjoint weights (K = head width <= 16: one k-block)
+  Res0<RT> whd, whp;
+  res0_load<RT>(whd, F.wb[F.nl - 1], F.nt[F.nl - 1], wid, lane);
+  res0_load<RT>(whp, P.wb[P.nl - 1], P.nt[P.nl - 1], wid, lane);
+  // stream: dynamics hidden layers (reverse), then policy hidden layers (reverse)
+  const StreamDesc& sd = A.sd_bwd;      // dynamics hidden layers (reverse), then policy (reverse)
+  const int n_dyn_stream = F.nl - 2;
+  Cursor q;
+  cur_init(sd, q, wid);
+  FragS<RT> fa, fb;
+  int par = 0;
+  if (sd.n > 0) {
+    frag_load<RT>(fa, sd, q, wid, lane);
+    cur_advance<RT>(sd, q, wid);
+  }
+  __syncthreads();
+
+  for (int t = A.t1 - 1; t >= A.t0; --t) {
+    const size_t blk = (size_t)t * A.nwg + wg;
+    float* X = L.bufA;
+    float* Y = L.bufB;
+    PM_MARK(0);
+    {
+      const float* xsrc = mms ? A.xt + (size_t)t * B * D : A.states + (size_t)(t + 1) * B * D;
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, d = i - r * D;
+        Y[r * LD + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
+      }
+      for (int i = tid; i < R * U; i += PM_NT) {
+        const int r = i / U;
+        L.av[i] = (r < nvalid) ? A.actions[((size_t)t * B + row0) * U + i] : 0.f;
+      }
+      const float* rsrc = mmr ? A.rt : A.rewards;
+      for (int r = tid; r < R; r += PM_NT) {
+        const bool v = r < nvalid;
+        L.gr[r] = v ? A.grad_rewards[(size_t)t * B + row0 + r] : 0.f;
+        L.rr[r] = v ? rsrc[(size_t)t * B + row0 + r] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (A.mm_mode == 1) {
+      const int gpw = A.rows_per_wg / A.M;
+      for (int gi = wid; gi < gpw; gi += PM_NW) {
+        const int lr0 = gi * A.M;
+        if (lr0 >= nvalid) break;
+        double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
+        if (mms)
+          pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, gx + lr0 * D, D,
+                    gxt + lr0 * D, D, scr, lane);
+        if (mmr)
+          pm_mm_bwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, L.gr + lr0, 1,
+                    L.gr + lr0, 1, scr, lane);
+      }
+      __syncthreads();
+    }
+    PM_MARK(1);
+    // ---- reward adjoint (per row) ; gxt = (mm-adjoint of gx | gx) + dr/dx~ ; direct action grad
+    for (int r = tid; r < R; r += PM_NT) {
+      float* gxr = gxt + r * D;
+      if (!(A.mm_mode == 1 && mms))
+        for (int d = 0; d < D; ++d) gxr[d] = gx[r * D + d];
+      for (int j = 0; j < U; ++j) L.gad[r * 16 + j] = 0.f;
+      if (r < nvalid) {
+        const float rv = reward_lds(L.rew, Y + r * LD, D, L.av + r * U, U, L.ph + r * PMBRL_MAX_DIM,
+                                    L.dl + r * 8);
+        (void)rv;
+        reward_lds_bwd(L.rew, Y + r * LD, D, L.av + r * U, U, L.rr[r], L.gr[r],
+                       L.ph + r * PMBRL_MAX_DIM, L.dl + r * 8, L.gph + r * PMBRL_MAX_DIM, gxr,
+                       L.gad + r * 16);
+      }
+    }
+    __syncthreads();
+    PM_MARK(2);
+    // ---- dynamics head adjoint input [gxt*Sy | gxt*Td | 0] -> X (one 16-block)
+    for (int i = tid; i < R * 16; i += PM_NT) {
+      const int r = i >> 4, k = i & 15;
+      float v = 0.f;
+      if (r < nvalid) {
+        if (k < D) v = gxt[r * D + k] * L.Sy[k];
+        else if (k < 2 * D) v = gxt[r * D + k - D] * A.Td[((size_t)t * B + row0 + r) * D + k - D];
+      }
+      X[r * LD + k] = v;
+    }
+    __syncthreads();
+    PM_MARK(3);
+    // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) as LDS dot products
+    {
+      const int nt = F.nt[F.nl - 1];
+      EpiBwdL<RT> e{F.abits[F.nl - 2] + (size_t)t * B * nt, F.keep[F.nl - 2], Y, nullptr, LD, A.Rw,
+                    row0, nvalid, nt, lane};
+      res0_layer<RT>(whd, nt, X, LD, wid, lane, e);
+    }
+    __syncthreads();
+    { float* tmp = X; X = Y; Y = tmp; }
+    PM_MARK(4);
+    for (int l = F.nl - 2, si = 0; l >= 1; --l, ++si) {
+      const int nt = F.nt[l];
+      EpiBwdL<RT> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw, row0,
+                    nvalid, nt, lane};
+      stream_layer<RT>(sd, si, q, fa, fb, par, X, LD, wid, lane, e);
+      __syncthreads();
+      { float* tmp = X; X = Y; Y = tmp; }
+      PM_MARK(4 + l);
+    }
+    narrow_dot<R>(X, LD, L.mA, LD, F.dim[0], F.nt[1] * 16, L.hp, tid);
+    __syncthreads();
+    PM_MARK(12);
+    // ---- phase B: tail result; state part -> gxt, action part -> policy head adjoint
+    {
+      float* gst = A.gT[P.nl - 1] + blk * (size_t)16 * A.Rw;
+      for (int i = tid; i < R * 16; i += PM_NT) {
+        const int r = i >> 4, k = i & 15;
+        float tail = 0.f;
+        if (k < D + U) tail = L.hp[r * PM_HJ + k] * L.iSx[k];
+        if (k < D) gxt[r * D + k] += tail;
+        if (k >= D && k < D + U) {
+          const int j = k - D;
+          float go_mu = 0.f, go_ls = 0.f;
+          if (r < nvalid) {
+            float ga = L.gad[r * 16 + j] + tail;
+            if (A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
+            L.gad[r * 16 + j] = ga;
+            const float sc = L.psc[j];
+            const float th = (L.av[r * U + j] - L.pbi[j]) / sc;
+            const float gu = ga * sc * (1.f - th * th);
+            go_mu = gu;
+            go_ls = gu * A.Tp[((size_t)t * B + row0 + r) * U + j];
+          }
+          X[r * LD + j] = go_mu;
+          X[r * LD + U + j] = go_ls;
+          gst[(size_t)j * A.Rw + r] = go_mu;
+          gst[(size_t)(U + j) * A.Rw + r] = go_ls;
+        }
+      }
+      // zero the K padding of the head-gradient block (columns 2U..15)
+      for (int i = tid; i < R * 16; i += PM_NT) {
+        const int r = i >> 4, k = i & 15;
+        if (k >= 2 * U) {
+          X[r * LD + k] = 0.f;
+          gst[(size_t)k * A.Rw + r] = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (A.agn) {
+      for (int r = tid; r < nvalid; r += PM_NT) {
+        float s2 = 0.f;
+        for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
+        A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
+      }
+    }
+    PM_MARK(13);
+    // ---- policy trunk: dX chain + G stash; tail (grad wrt x) as LDS dot products
+    {
+      const int nt = P.nt[P.nl - 1];
+      EpiBwdL<RT> e{P.abits[P.nl - 2] + (size_t)t * B * nt, P.keep[P.nl - 2], Y,
+                    A.gT[P.nl - 2] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
+      res0_layer<RT>(whp, nt, X, LD, wid, lane, e);
+    }
+    __syncthreads();
+    { float* tmp = X; X = Y; Y = tmp; }
+    PM_MARK(14);
+    for (int l = P.nl - 2, si = 0; l >= 1; --l, ++si) {
+      const int nt = P.nt[l];
+      EpiBwdL<RT> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
+                    A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
+      stream_layer<RT>(sd, n_dyn_stream + si, q, fa, fb, par, X, LD, wid, lane, e);
+      __syncthreads();
+      { float* tmp = X; X = Y; Y = tmp; }
+      PM_MARK(14 + l);
+    }
+    narrow_dot<R>(X, LD, L.mB, LD, P.dim[0], P.nt[1] * 16, L.hp, tid);
+    __syncthreads();
+    PM_MARK(22);
+    for (int i = tid; i < R * D; i += PM_NT) {
+      const int r = i / D, d = i - r * D;
+      float v = gxt[i] + L.hp[r * PM_HJ + d];
+      if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
+      gx[i] = v;
+    }
+    __syncthreads();
+    PM_MARK(23);
+  }
+  for (int i = tid; i < nvalid * D; i += PM_NT) {
+    const size_t o = (size_t)row0 * D + i;
+    if (A.gx_carry) A.gx_carry[o] = gx[i];
+    if (A.t0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
+  }
+}

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
+    PM_MARK(0);
     // ---- policy input (no normalisation in Policy.forward, models/core.py:221-248)
     {
       const int K16 = P.nt[0] * 16;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       }
     }
     __syncthreads();
+    PM_MARK(1);
     // ---- policy hidden layers
     for (int l = 0; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
@@ -256,11 +258,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
                      A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
       __syncthreads();
+      PM_MARK(2 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // ---- policy head -> Y[r][0..2U)
     gemm_narrow<RT>(P.wf[P.nl - 1], P.nt[P.nl], P.nt[P.nl - 1], P.bias[P.nl - 1], X, Y, LD, L.part,
                     wid, lane, tid);
+    PM_MARK(10);
     // ---- squash + dynamics input (models/densities.py:87-121, models/core.py:243,169-177)
     {
       const int K16 = F.nt[0] * 16;
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       }
     }
     __syncthreads();
+    PM_MARK(11);
     // ---- dynamics hidden layers
     for (int l = 0; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
@@ -297,11 +302,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
                      nullptr, LD, A.Rw, row0, nvalid, nt, lane};
       gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
       __syncthreads();
+      PM_MARK(12 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // ---- dynamics head -> Y[r][0..2D)
     gemm_narrow<RT>(F.wf[F.nl - 1], F.nt[F.nl], F.nt[F.nl - 1], F.bias[F.nl - 1], X, Y, LD, L.part,
                     wid, lane, tid);
+    PM_MARK(20);
     // ---- sample next state (models/densities.py:97-121 with scaling_params, core.py:298)
     for (int i = tid; i < R * D; i += PM_NT) {
       const int r = i / D, d = i - r * D;
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       }
     }
     __syncthreads();
+    PM_MARK(21);
     // ---- reward on the sampled (pre-mm) next state; failure detection
     for (int r = tid; r < R; r += PM_NT) {
       float rv = 0.f;
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       float* tmp = xa; xa = xb; xb = tmp;
     }
     __syncthreads();
+    PM_MARK(22);
   }
 }
 
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
+    PM_MARK(0);
     // ---- load x~ rows (for reward / mm recompute) into Y scratch columns, actions, upstream gr
     //      Y[r][0..D) = x~ ; L.av = a ; L.gr = dL/dr ; L.rr = r~
     {
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
       for (int i = tid; i < R * D; i += PM_NT) gxt[i] = gx[i];
       __syncthreads();
     }
+    PM_MARK(1);
     // ---- reward adjoint: gxt += dr/dx~ * gr ; ga_direct -> X scratch column block
     //      (X[r][0..U) holds the direct action gradient until phase B)
     for (int r = tid; r < R; r += PM_NT) {
@@ -480,6 +491,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
       for (int j = 0; j < U; ++j) L.gad[r * 16 + j] = ga[j];
     }
     __syncthreads();
+    PM_MARK(2);
     // ---- dynamics head adjoint input: [gxt*Sy | gxt*Td | 0] -> X
     {
       const int K16 = F.nt[F.nl] * 16;
@@ -494,6 +506,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
       }
     }
     __syncthreads();
+    PM_MARK(3);
     // ---- dynamics trunk, dX only (weights frozen: no dV)
     for (int l = F.nl - 1; l >= 1; --l) {
       const int nt = F.nt[l];
@@ -501,10 +514,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
                      row0, nvalid, nt, lane};
       gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
+      PM_MARK(4 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // grad wrt normalised dynamics input [x | a] -> Y[r][0..D+U)
     gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    PM_MARK(12);
     // ---- phase B: split into state / action parts; policy head adjoint -> X
     {
       const int K16 = P.nt[P.nl] * 16;
@@ -547,6 +562,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
         A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
       }
     }
+    PM_MARK(13);
     // ---- policy trunk: dX chain + G stash
     for (int l = P.nl - 1; l >= 1; --l) {
       const int nt = P.nt[l];
@@ -554,9 +570,11 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
                      A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
+      PM_MARK(14 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     gemm_narrow<RT>(P.wb[0], P.nt[0], P.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    PM_MARK(22);
     // ---- phase C: dL/dx_t
     for (int i = tid; i < R * D; i += PM_NT) {
       const int r = i / D, d = i - r * D;
@@ -565,6 +583,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) 
       gx[i] = v;
     }
     __syncthreads();
+    PM_MARK(23);
   }
   // hand dL/dx_{t0} to the next launch / the caller
   for (int i = tid; i < nvalid * D; i += PM_NT) {

@@ -77,7 +77,8 @@ class Engine:
     def __init__(self, B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep,
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
-                 max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False):
+                 max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
+                 force_generic=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -89,7 +90,8 @@ class Engine:
         cfg.row_offset = row_offset
         cfg.flags = ((_lib.FLAG_MM_STATES if mm_states else 0) |
                      (_lib.FLAG_MM_REWARDS if mm_rewards else 0) |
-                     (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0))
+                     (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0) |
+                     (_lib.FLAG_FORCE_GENERIC if force_generic else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
         cfg.max_log_std_pol = max_log_std_pol
         cfg.max_log_std_dyn = max_log_std_dyn
@@ -114,7 +116,8 @@ class Engine:
         _lib.check(self.lib.pmbrl_plan_info(plan, info), 'pmbrl_plan_info')
         self.info = dict(rows_per_wg=info[0], n_wg=info[1], row_tiles=info[2],
                          lds_bytes=info[3], n_pol_params=info[4], n_dyn_params=info[5],
-                         dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9])
+                         dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9],
+                         fast=info[10])
         self.n_pol_params = info[4]
         self.n_dyn_params = info[5]
         ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)

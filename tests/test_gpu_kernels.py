@@ -93,8 +93,9 @@ def test_clip_adam_matches_torch(dev, n, clip):
     assert torch.allclose(v, st['exp_avg_sq'], rtol=1e-5, atol=1e-12)
 
 
-def _run(d, dev, hint=0):
-    eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint)
+def _run(d, dev, hint=0, generic=False):
+    eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint, force_generic=generic)
+    assert bool(eng.info['fast']) == (not generic)
     S, A, Rw = eng.forward(**args)
     B = d['x0'].shape[0]
     gw = torch.tensor(common.loss_weights(d, B), device=dev)
@@ -105,12 +106,14 @@ def _run(d, dev, hint=0):
         g.cpu().numpy().copy(), gx0.cpu().numpy(), agn.cpu().numpy()
 
 
+@pytest.mark.parametrize('generic', [False, True], ids=['fast', 'generic'])
 @pytest.mark.parametrize('name', common.fixture_names('iter'))
-def test_rollout_parity(dev, name):
+def test_rollout_parity(dev, name, generic):
+    """Both kernel families (latency-optimised 'fast' and the generic one) vs the fixtures."""
     d = common.load(name)
     if bool(d.get('infer_ns', False)):
         pytest.skip('infer_noise_variables is not offered on the device path')
-    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev)
+    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev, generic=generic)
     assert eng.valid_steps() == int(d['H'])
     assert common.rel(S, d['ref64_states']) < TOL_TRAJ
     assert common.rel(A, d['ref64_actions']) < TOL_TRAJ
@@ -123,12 +126,13 @@ def test_rollout_parity(dev, name):
     assert common.rel(g, d['ref32_grad']) < TOL_GRAD + common.rel(d['ref32_grad'], d['ref64_grad'])
 
 
+@pytest.mark.parametrize('generic', [False, True], ids=['fast', 'generic'])
 @pytest.mark.parametrize('name', ['nomm_d4', 'mmg_d4', 'full200_nomm', 'rdv_d8_u4_3layer'])
-def test_grad_x0_and_action_norms(dev, name):
+def test_grad_x0_and_action_norms(dev, name, generic):
     """dL/dx0 and the per-step ||dL/da_t|| (prioritised replay hook) vs the explicit adjoint."""
     from oracle import adjoint_np as ADJ
     d = common.load(name)
-    _, S, A, Rw, loss, g, gx0, agn = _run(d, dev)
+    _, S, A, Rw, loss, g, gx0, agn = _run(d, dev, generic=generic)
     P = ADJ.Problem(d, np.float64)
     st = ADJ.forward(P)
     g_ref, gx0_ref, Gst = ADJ.backward(P, st)
@@ -139,9 +143,10 @@ def test_grad_x0_and_action_norms(dev, name):
 @pytest.mark.parametrize('name,hint', [('nomm_d4', 32), ('nomm_d4', 64), ('full200_nomm', 32),
                                        ('full200_nomm', 64), ('mmg_d4', 16), ('mmg_d4', 32),
                                        ('rdv_d8_u4_3layer', 64)])
-def test_row_tile_variants(dev, name, hint):
+@pytest.mark.parametrize('generic', [False, True], ids=['fast', 'generic'])
+def test_row_tile_variants(dev, name, hint, generic):
     d = common.load(name)
-    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev, hint)
+    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev, hint, generic)
     assert common.rel(S, d['ref64_states']) < TOL_TRAJ
     assert common.rel(g, d['ref64_grad']) < TOL_GRAD
 

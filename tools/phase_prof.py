@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""In-kernel phase profile of workgroup 0 (shader-clock stamps, pmbrl_plan_set_prof)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from prob_mbrl_amd import _lib, problem as PB  # noqa: E402
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else 'cartpole_nomm'
+    dev = torch.device('cuda:0')
+    d = PB.synthetic_problem(cfg, seed=0, data_seed=0)
+    eng, args, _ = PB.engine_from_problem(d, dev)
+    H = eng.H
+    pf = torch.zeros(H * 32, dtype=torch.int64, device=dev)
+    pb = torch.zeros(H * 32, dtype=torch.int64, device=dev)
+    gw = torch.tensor(PB.loss_weights(d, eng.B), device=dev)
+    for it in range(3):
+        eng.forward(**args)
+        eng.backward(gw)
+    _lib.check(eng.lib.pmbrl_plan_set_prof(eng.plan, C.c_void_p(pf.data_ptr()), C.c_void_p(pb.data_ptr())), 'prof')
+    eng.forward(**args)
+    eng.backward(gw)
+    torch.cuda.synchronize()
+    for name, buf in (('fwd', pf), ('bwd', pb)):
+        a = buf.cpu().numpy().reshape(H, 32)
+        print('== %s: cycles between marks, median over steps (slot: delta)' % name)
+        slots = [s for s in range(32) if a[H // 2, s] != 0]
+        order = sorted(slots, key=lambda s: a[H // 2, s])
+        prev = None
+        tot = 0
+        for s in order:
+            if prev is not None:
+                dl = np.median(a[1:-1, s] - a[1:-1, prev])
+                tot += dl
+                print('   %2d -> %2d : %8.0f cycles' % (prev, s, dl))
+            prev = s
+        print('   step total (marked span): %.0f cycles; step period: %.0f' %
+              (tot, np.median(np.abs(np.diff(a[:, order[0]])))))
+
+
+if __name__ == '__main__':
+    main()
