@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpmbrl_hip.so')
+LIB_PATH = os.environ.get('PMBRL_LIB_PATH', os.path.join(_HERE, 'csrc', 'libpmbrl_hip.so'))
 
 MAX_LAYERS = 8
 MAX_ANGLE = 8

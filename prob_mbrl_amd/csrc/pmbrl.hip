@@ -36,10 +36,11 @@ extern "C" int pmbrl_version(void) { return 1; }
 // ---------------------------------------------------------------------------
 // fragment packing: dst[((ot*n_kb + kb)*64 + lane)*4 + j] = W[ot*16 + (lane&15)][kb*16 + 4*(lane>>4) + j]
 // (transpose=1: the roles of the two indices of W[O][K] are swapped)
-__global__ void pm_pack_frag(const float* __restrict__ W, int O, int K, int transpose,
+__global__ void pm_pack_frag(const float* __restrict__ W, int O, int K, int transpose, int kb_mult,
                              float* __restrict__ dst) {
   const int n_out = transpose ? K : O, n_in = transpose ? O : K;
-  const int n_ot = (n_out + 15) / 16, n_kb = (n_in + 15) / 16;
+  const int n_ot = (n_out + 15) / 16;
+  const int n_kb = ((n_in + 15) / 16 + kb_mult - 1) / kb_mult * kb_mult;   // zero-padded k-blocks
   const size_t total = (size_t)n_ot * n_kb * 256;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -187,7 +188,7 @@ struct NetPlan {
 struct pmbrl_plan {
   pmbrl_config cfg;
   int device;
-  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast;
+  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CKB;
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
@@ -241,15 +242,20 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   return 0;
 }
 
+template <int RT, int CKB>
+static int set_attr_fast(size_t lds) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CKB>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CKB>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return 0;
+}
+
 template <int RT>
 static int set_attr(size_t lds) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<RT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<RT>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
@@ -283,7 +289,35 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->fast = !(c.flags & PMBRL_FLAG_FORCE_GENERIC) &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
+  const int LD_generic = p->LD;
+  // chunk size (k-blocks) of the streamed layers: every layer is padded to an even number of
+  // chunks; pick, among the instantiated sizes, the one that pads the least
+  auto stream_work = [&](int ckb) {
+    long w = 0;
+    const NetPlan* nets[2] = {&p->pol, &p->dyn};
+    for (const NetPlan* n : nets)
+      for (int l = 1; l <= n->nl - 2; ++l) {
+        const int m = 2 * ckb;
+        w += (long)n->nt[l + 1] * ((n->nt[l] + m - 1) / m * m) + (long)n->nt[l] * ((n->nt[l + 1] + m - 1) / m * m);
+      }
+    return w;
+  };
+  auto ckb_for = [&](int RT) {
+    const int cand1[] = {8, 7, 4, 2}, cand2[] = {4, 2}, cand4[] = {2, 1};
+    const int* cand = RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
+    const int nc = RT == 1 ? 4 : 2;
+    int best = cand[0];
+    for (int i = 1; i < nc; ++i)
+      if (stream_work(cand[i]) < stream_work(best)) best = cand[i];
+    return best;
+  };
+  auto ld_for = [&](int RT) {
+    if (!p->fast) return LD_generic;
+    const int ckb = ckb_for(RT);
+    return (maxnt + 2 * ckb - 1) / (2 * ckb) * (2 * ckb) * 16 + 8;   // room for the zero K padding
+  };
   auto lds_need = [&](int RT, int mmd) {
+    p->LD = ld_for(RT);
     if (p->fast)
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
                                 p->dyn.nl, mmd) * sizeof(float);
@@ -326,7 +360,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     const int want = std::max(p->M, (c.rows_per_wg_hint / p->M) * p->M);
     if (want <= 16 * p->RT) p->rows_per_wg = want;
   }
-  p->lds_bytes = lds_need(p->RT, p->mm_mode == 1 ? c.D : 0);
+  p->lds_bytes = lds_need(p->RT, p->mm_mode == 1 ? c.D : 0);   // also fixes p->LD for the chosen RT
+  p->CKB = ckb_for(p->RT);
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
   p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
 
@@ -412,7 +447,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     NetPlan* nets[2] = {&p->pol, &p->dyn};
     for (NetPlan* n : nets) {
       for (int l = 0; l < n->nl; ++l) {
-        const size_t fr = (size_t)n->nt[l + 1] * n->nt[l] * 256 * sizeof(float);
+        const size_t fr = (size_t)(n->nt[l + 1] + 15) * (n->nt[l] + 15) * 256 * sizeof(float);
         n->wf[l] = take(fr);
         n->wb[l] = take(fr);
         n->bias[l] = take((size_t)n->nt[l + 1] * 16 * sizeof(float));
@@ -435,10 +470,18 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->ws_bytes = off;
   }
   int rc2 = 0;
-  switch (p->RT) {
-    case 1: rc2 = set_attr<1>(p->lds_bytes); break;
-    case 2: rc2 = set_attr<2>(p->lds_bytes); break;
-    default: rc2 = set_attr<4>(p->lds_bytes); break;
+  if (!p->fast) {
+    switch (p->RT) {
+      case 1: rc2 = set_attr<1>(p->lds_bytes); break;
+      case 2: rc2 = set_attr<2>(p->lds_bytes); break;
+      default: rc2 = set_attr<4>(p->lds_bytes); break;
+    }
+  } else {
+#define PM_FAST_CASE(RTV, CK) \
+  if (p->RT == RTV && p->CKB == CK) rc2 = set_attr_fast<RTV, CK>(p->lds_bytes);
+    PM_FAST_CASE(1, 8) PM_FAST_CASE(1, 7) PM_FAST_CASE(1, 4) PM_FAST_CASE(1, 2)
+    PM_FAST_CASE(2, 4) PM_FAST_CASE(2, 2) PM_FAST_CASE(4, 2) PM_FAST_CASE(4, 1)
+#undef PM_FAST_CASE
   }
   if (p->mm_mode == 2) {
     const int smem = (int)(pm_mm_scratch_doubles(c.D) * sizeof(double));
@@ -510,6 +553,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[8] = p->LD;
   info[9] = p->n_dw_blocks;
   info[10] = p->fast;
+  info[11] = p->CKB;
   return 0;
 }
 
@@ -581,16 +625,18 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
     const NetDev& P = A.pol;
     const NetDev& F = A.dyn;
+    const int ckb = p->CKB;
+    auto padk = [ckb](int nkb) { return (nkb + 2 * ckb - 1) / (2 * ckb) * (2 * ckb); };
     StreamDesc& f = A.sd_fwd;
     f.n = 0;
-    for (int l = 1; l < P.nl - 1; ++l) { f.wf[f.n] = P.wf[l]; f.n_ot[f.n] = P.nt[l + 1]; f.n_kb[f.n] = P.nt[l]; f.n++; }
-    for (int l = 1; l < F.nl - 1; ++l) { f.wf[f.n] = F.wf[l]; f.n_ot[f.n] = F.nt[l + 1]; f.n_kb[f.n] = F.nt[l]; f.n++; }
+    for (int l = 1; l < P.nl - 1; ++l) { f.wf[f.n] = P.wf[l]; f.n_ot[f.n] = P.nt[l + 1]; f.n_kb[f.n] = padk(P.nt[l]); f.n++; }
+    for (int l = 1; l < F.nl - 1; ++l) { f.wf[f.n] = F.wf[l]; f.n_ot[f.n] = F.nt[l + 1]; f.n_kb[f.n] = padk(F.nt[l]); f.n++; }
     StreamDesc& b = A.sd_bwd;
     b.n = 0;
-    for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = F.nt[l + 1]; b.n++; }
-    for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = P.nt[l + 1]; b.n++; }
+    for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = padk(F.nt[l + 1]); b.n++; }
+    for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = padk(P.nt[l + 1]); b.n++; }
     const size_t R = 16 * (size_t)p->RT;
-    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + (size_t)PM_NW * R * PM_HJ;
+    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + R * PM_HJ;   // up to L.hp
     for (int l = 0; l < P.nl; ++l) { A.fo.pbias[l] = (int)o; o += (size_t)P.nt[l + 1] * 16; }
     for (int l = 0; l < F.nl; ++l) { A.fo.dbias[l] = (int)o; o += (size_t)F.nt[l + 1] * 16; }
     for (int l = 0; l < P.nl - 1; ++l) { A.fo.pmask[l] = (int)o; o += (R * P.nt[l + 1] + 1) / 2; }
@@ -605,14 +651,16 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   return 0;
 }
 
-static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t s) {
+static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t s, int ckb) {
   for (int l = 0; l < n.nl; ++l) {
     const int O = n.dim[l + 1], K = n.dim[l];
-    const size_t tot = (size_t)n.nt[l + 1] * n.nt[l] * 256;
+    // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to CKB
+    const int mult = (ckb >= 1 && l >= 1 && l <= n.nl - 2) ? 2 * ckb : 1;
+    const size_t tot = (size_t)(n.nt[l + 1] + 15) * (n.nt[l] + 15) * 256;
     const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 0,
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 0, mult,
                        reinterpret_cast<float*>(ws + n.wf[l]));
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 1,
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 1, mult,
                        reinterpret_cast<float*>(ws + n.wb[l]));
     const int O16 = n.nt[l + 1] * 16;
     hipLaunchKernelGGL(pm_pack_bias, dim3((O16 + 255) / 256), dim3(256), 0, s,
@@ -624,19 +672,28 @@ static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t
 
 template <int RT>
 static void launch_fwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
-  if (p->fast)
-    hipLaunchKernelGGL(pm_rollout_fwd_fast<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
-  else
-    hipLaunchKernelGGL(pm_rollout_fwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  hipLaunchKernelGGL(pm_rollout_fwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
-  if (p->fast)
-    hipLaunchKernelGGL(pm_rollout_bwd_fast<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+  hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+}
+template <int RT, int CKB>
+static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  if (fwd)
+    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CKB>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
   else
-    hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CKB>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+}
+static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+#define PM_FAST_CASE(RTV, CK) \
+  if (p->RT == RTV && p->CKB == CK) return launch_fast<RTV, CK>(p, A, s, fwd);
+  PM_FAST_CASE(1, 8) PM_FAST_CASE(1, 7) PM_FAST_CASE(1, 4) PM_FAST_CASE(1, 2)
+  PM_FAST_CASE(2, 4) PM_FAST_CASE(2, 2) PM_FAST_CASE(4, 2) PM_FAST_CASE(4, 1)
+#undef PM_FAST_CASE
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  if (p->fast) return launch_fast_rt(p, A, s, true);
   switch (p->RT) {
     case 1: launch_fwd<1>(p, A, s); break;
     case 2: launch_fwd<2>(p, A, s); break;
@@ -644,6 +701,7 @@ static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t
   }
 }
 static void launch_bwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
+  if (p->fast) return launch_fast_rt(p, A, s, false);
   switch (p->RT) {
     case 1: launch_bwd<1>(p, A, s); break;
     case 2: launch_bwd<2>(p, A, s); break;
@@ -667,8 +725,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   char* ws = static_cast<char*>(workspace);
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
-    rc = pack_net(p->pol, ws, in->pol_params_d, s);
-    if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s);
+    rc = pack_net(p->pol, ws, in->pol_params_d, s, p->fast ? p->CKB : 0);
+    if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s, p->fast ? p->CKB : 0);
     if (rc) return rc;
     hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }
@@ -839,9 +897,9 @@ extern "C" int pmbrl_debug_linear(void* stream, const float* x_d, const float* W
   const size_t tot = (size_t)n_ot * n_kb * 256;
   const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
   if (!transpose_w)
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, O, K, 0, wf);
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, O, K, 0, 1, wf);
   else  // W_d is [K][O]: out feature index is the second one
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, K, O, 1, wf);
+    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, K, O, 1, 1, wf);
   hipLaunchKernelGGL(pm_pack_bias, dim3((n_ot * 16 + 255) / 256), dim3(256), 0, s, b_d, O, n_ot * 16,
                      bias);
   const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);

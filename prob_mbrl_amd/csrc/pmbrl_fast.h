@@ -25,7 +25,11 @@
 // (even / odd k-blocks) to cover the 40-cycle dependent-MFMA latency, and a register stage
 // of CKB k-blocks per buffer (64 VGPRs) -- the arch-VGPR file is 256 per lane, so the
 // stage depth, not the tile count, is where the prefetch distance comes from.
-#define PM_CKB_OF(RT) (8 / (RT))    // k-blocks (of 16) per streamed chunk (32 MFMAs of lookahead)
+// CKB = k-blocks (of 16) per streamed chunk, a kernel template parameter chosen by the plan
+// (CKB*RT*4 = 28..32 MFMAs of lookahead).  The fragment-packed weights of the streamed
+// layers are zero-padded to a multiple of CKB k-blocks and the LDS activation buffers carry
+// matching zero columns, so every chunk is full: the inner loops are straight-line code
+// (a branchy tail defeats the scheduler and, worse, SROA: the stage then lives in scratch).
 #define PM_FNT 1
 #define PM_L0T 4           // max resident first-layer tiles per wave
 #define PM_HJ 16           // max fused head / tail width
@@ -39,106 +43,143 @@ __host__ __device__ inline bool pm_fast_net_ok(const int* dim, const int* nt, in
   return true;
 }
 
-template <int RT>
+template <int CKB>
 struct FragS {
-  static constexpr int CKB = PM_CKB_OF(RT);
-  f32x4 a[PM_CKB_OF(RT)];
+  f32x4 a[CKB];
 };
 
+// Position of the weight stream, one chunk ahead of the MFMAs.  Everything the hot loop
+// needs (load pointer, tile / chunk counters, the current layer's shape) lives in SGPRs and
+// is advanced incrementally; the kernel-argument table is consulted only when the stream
+// moves to another layer (a scalar-memory round trip per chunk was costing more than the
+// MFMAs of the chunk).
 struct Cursor {
-  int li, g, c, live;
+  int li, ot, c, live;
+  int n_ot, n_kb;            // of layer li (n_kb padded to the chunk size)
+  const float* wp;           // next chunk to load (lane offset not included)
 };
 
-__device__ __forceinline__ void cur_settle(const StreamDesc& sd, Cursor& q, int wid) {
-  // skip layers in which this wave owns no tile; `live` = the wave has work at all
-  if (!q.live) return;
-  for (int k = 0; k < 2 * sd.n + 2; ++k) {
+__device__ __forceinline__ void cur_enter(const StreamDesc& sd, Cursor& q, int wid) {
+  // settle on the next layer (cyclically, starting at q.li) in which this wave owns a tile
+  for (int k = 0; k < 2 * PM_MAXL + 1; ++k) {
     if (q.li >= sd.n) q.li = 0;
-    if (wid + q.g * PM_FNT * PM_NW < sd.n_ot[q.li]) return;
+    if (wid < sd.n_ot[q.li]) break;
     q.li++;
-    q.g = 0;
-    q.c = 0;
   }
+  q.n_ot = sd.n_ot[q.li];
+  q.n_kb = sd.n_kb[q.li];
+  q.ot = wid;
+  q.c = 0;
+  q.wp = sd.wf[q.li] + (size_t)wid * q.n_kb * 256;
 }
 __device__ __forceinline__ void cur_init(const StreamDesc& sd, Cursor& q, int wid) {
-  q.li = 0; q.g = 0; q.c = 0; q.live = 0;
+  q.li = 0; q.ot = 0; q.c = 0; q.live = 0; q.n_ot = 0; q.n_kb = 0; q.wp = nullptr;
   for (int l = 0; l < sd.n; ++l)
     if (wid < sd.n_ot[l]) q.live = 1;
-  cur_settle(sd, q, wid);
+  if (q.live) cur_enter(sd, q, wid);
 }
-template <int RT>
+template <int CKB>
 __device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int wid) {
   if (!q.live) return;
-  q.c++;
-  if (q.c * PM_CKB_OF(RT) >= sd.n_kb[q.li]) {
+  q.c += CKB;
+  q.wp += (size_t)CKB * 256;
+  if (q.c >= q.n_kb) {
     q.c = 0;
-    q.g++;
-  }
-  cur_settle(sd, q, wid);
-}
-
-template <int RT>
-__device__ __forceinline__ void frag_load(FragS<RT>& f, const StreamDesc& sd, const Cursor& q,
-                                          int wid, int lane) {
-  if (!q.live) return;
-  constexpr int CKB = PM_CKB_OF(RT);
-  const int n_kb = sd.n_kb[q.li];
-  const int ot = wid + q.g * PM_NW;      // settled cursor: ot < n_ot
-  const float* wp = sd.wf[q.li] + ((size_t)ot * n_kb + (size_t)q.c * CKB) * 256 + lane * 4;
-#pragma unroll
-  for (int cc = 0; cc < CKB; ++cc)
-    if (q.c * CKB + cc < n_kb) f.a[cc] = ldg4(wp + (size_t)cc * 256);
-}
-
-template <int RT>
-__device__ __forceinline__ void frag_compute(const FragS<RT>& f, int n_kb, int c,
-                                             const float* lds_in, int ld, int lane,
-                                             f32x4 (&acc)[2][RT]) {
-  constexpr int CKB = PM_CKB_OF(RT);
-  const float* bbase = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
-#pragma unroll
-  for (int cc = 0; cc < CKB; ++cc) {
-    const int kb = c * CKB + cc;
-    if (kb < n_kb) {
-      f32x4 b[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld + kb * 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[cc & 1][rt] = mfma4(f.a[cc][j], b[rt][j], acc[cc & 1][rt]);
+    q.ot += PM_NW;
+    q.wp += (size_t)(PM_NW - 1) * q.n_kb * 256;
+    if (q.ot >= q.n_ot) {
+      q.li++;
+      cur_enter(sd, q, wid);
     }
   }
 }
 
-// One streamed layer.  Invariant on entry and exit: buffer[par] holds the item the
-// processing order reaches next, `q` is the item after it.
-template <int RT, class Epi>
-__device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Cursor& q, FragS<RT>& fa,
-                                             FragS<RT>& fb, int& par, const float* lds_in, int ld,
-                                             int wid, int lane, Epi& epi) {
-  constexpr int CKB = PM_CKB_OF(RT);
-  const int n_ot = sd.n_ot[li], n_kb = sd.n_kb[li];
-  const int nch = (n_kb + CKB - 1) / CKB;
+// straight-line load / compute of one full chunk: the compiler hoists the CKB LDS reads
+// ahead of the MFMAs and interleaves the two accumulator chains (even / odd k-blocks)
+template <int CKB>
+__device__ __forceinline__ void frag_load(FragS<CKB>& f, const StreamDesc& sd, const Cursor& q,
+                                          int wid, int lane) {
+#ifdef PM_EXP_NOLOAD
+  return;
+#endif
+  if (!q.live) return;
+  const float* wp = q.wp + lane * 4;
+#pragma unroll
+  for (int cc = 0; cc < CKB; ++cc) f.a[cc] = ldg4(wp + (size_t)cc * 256);
+}
+
+template <int RT, int CKB>
+__device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, const float* lds_in, int ld,
+                                             int lane, f32x4 (&acc)[2][RT]) {
+  // Explicit one-pair-ahead software pipeline of the LDS (B operand) reads: while the 8*RT
+  // MFMAs of k-block pair p issue, the reads of pair p+1 are already in flight.  The
+  // sched_barriers pin that order (left alone, the scheduler sinks each read to just before
+  // its first use and every pair pays the LDS latency).
+  const float* bp = lds_in + (lane & 15) * ld + 4 * (lane >> 4) + c * CKB * 16;
+  constexpr int NP = (CKB + 1) / 2;
+  f32x4 b[2][2][RT];   // [stage][k-block within pair][row tile]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      b[0][h][rt] = *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + (h < CKB ? h : 0) * 16);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int cur = p & 1, nxt = cur ^ 1;
+    if (p + 1 < NP) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = 2 * (p + 1) + h;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          b[nxt][h][rt] =
+              *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + (cc < CKB ? cc : 0) * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = 2 * p + h;
+        if (cc < CKB) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[h][rt] = mfma4(f.a[cc < CKB ? cc : 0][j], b[cur][h][rt][j], acc[h][rt]);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// One streamed layer.  The plan pads every streamed layer to an EVEN number of chunks, so
+// the two register stages keep fixed roles (fa: even chunks, fb: odd chunks) and no stage is
+// ever copied: invariant on entry and exit -- fa holds the chunk the processing order
+// reaches next, `q` is the chunk after it.
+template <int RT, int CKB, class Epi>
+__device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Cursor& q, FragS<CKB>& fa,
+                                             FragS<CKB>& fb, const float* lds_in, int ld,
+                                             int wid, int lane, Epi& epi,
+                                             long long* prof = nullptr) {
+  const int n_ot = sd.n_ot[li];
+  const int nch2 = sd.n_kb[li] / (2 * CKB);
+  int pslot = 24;
   for (int ot = wid; ot < n_ot; ot += PM_NW) {
+    if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
     f32x4 acc[2][RT];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nch; ++c) {
-      if (par == 0) {
-        frag_load<RT>(fb, sd, q, wid, lane);
-        frag_compute<RT>(fa, n_kb, c, lds_in, ld, lane, acc);
-      } else {
-        frag_load<RT>(fa, sd, q, wid, lane);
-        frag_compute<RT>(fb, n_kb, c, lds_in, ld, lane, acc);
-      }
-      cur_advance<RT>(sd, q, wid);
-      par ^= 1;
+    for (int c2 = 0; c2 < nch2; ++c2) {
+      frag_load<CKB>(fb, sd, q, wid, lane);
+      cur_advance<CKB>(sd, q, wid);
+      frag_compute<RT, CKB>(fa, 2 * c2, lds_in, ld, lane, acc);
+      frag_load<CKB>(fa, sd, q, wid, lane);
+      cur_advance<CKB>(sd, q, wid);
+      frag_compute<RT, CKB>(fb, 2 * c2 + 1, lds_in, ld, lane, acc);
     }
+    if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[0][rt] + acc[1][rt]);
   }
@@ -165,17 +206,25 @@ __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const fl
   f32x4 b[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld);
+  // all resident tiles at once, branch-free (absent tiles carry zero weights): the
+  // PM_L0T * RT accumulator chains interleave
+  f32x4 acc[PM_L0T][RT];
+#pragma unroll
+  for (int i = 0; i < PM_L0T; ++i)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[i][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < PM_L0T; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma4(r.w[i][j], b[rt][j], acc[i][rt]);
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
     const int ot = wid + i * PM_NW;
     if (ot < n_ot) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = mfma4(r.w[i][j], b[rt][j], acc);
-        epi(ot, rt, acc);
-      }
+      for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[i][rt]);
     }
   }
 }
@@ -245,10 +294,12 @@ struct EpiFwdL {
       act |= (a ? 1u : 0u) << r;
     }
     *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+#ifndef PM_EXP_NOSTASH
     if (stash) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
     }
+#endif
     unsigned w16 = act << (4 * g);
     w16 |= __shfl_xor(w16, 16);
     w16 |= __shfl_xor(w16, 32);
@@ -275,10 +326,12 @@ struct EpiBwdL {
     for (int r = 0; r < 4; ++r)
       h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
     *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+#ifndef PM_EXP_NOSTASH
     if (stash) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
     }
+#endif
   }
 };
 
@@ -488,7 +541,7 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 // ===========================================================================
 // forward (fast)
 // ===========================================================================
-template <int RT>
+template <int RT, int CKB>
 __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -505,6 +558,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
   float* xb = L.xb;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  for (int i = tid; i < 2 * R * LD; i += PM_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   // fused head matrices: M[j][k] = W_head[j][k], zero padded to LD columns
   {
     const int Kp = P.dim[P.nl - 1], Op = P.dim[P.nl];
@@ -538,11 +592,10 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
   const int n_pol_stream = P.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
-  FragS<RT> fa, fb;
-  int par = 0;
+  FragS<CKB> fa, fb;
   if (sd.n > 0) {
-    frag_load<RT>(fa, sd, q, wid, lane);
-    cur_advance<RT>(sd, q, wid);
+    frag_load<CKB>(fa, sd, q, wid, lane);
+    cur_advance<CKB>(sd, q, wid);
   }
   __syncthreads();
 
@@ -578,7 +631,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
       EpiFwdL<RT> e{PBIAS(l), PMASK(l), P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
                     A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
                     row0, nvalid, nt, lane};
-      stream_layer<RT>(sd, l - 1, q, fa, fb, par, X, LD, wid, lane, e);
+      stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, e,
+                            (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
       __syncthreads();
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(2 + l);
@@ -631,7 +685,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
       const int nt = F.nt[l + 1];
       EpiFwdL<RT> e{DBIAS(l), DMASK(l), F.abits[l] + (size_t)t * B * nt, F.keep[l], Y, nullptr,
                     LD, A.Rw, row0, nvalid, nt, lane};
-      stream_layer<RT>(sd, n_pol_stream + l - 1, q, fa, fb, par, X, LD, wid, lane, e);
+      stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(12 + l);
@@ -715,7 +769,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
 // ===========================================================================
 // backward sweep (fast)
 // ===========================================================================
-template <int RT>
+template <int RT, int CKB>
 __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -734,6 +788,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
   const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  for (int i = tid; i < 2 * R * LD; i += PM_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   // fused tails: mA[j][k] = V0[k][j] (dynamics first layer, j < D+U), mB[j][k] = W0[k][j] (policy)
   {
     const int Kd = F.dim[1], Od = F.dim[0];
@@ -765,11 +820,10 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
   const int n_dyn_stream = F.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
-  FragS<RT> fa, fb;
-  int par = 0;
+  FragS<CKB> fa, fb;
   if (sd.n > 0) {
-    frag_load<RT>(fa, sd, q, wid, lane);
-    cur_advance<RT>(sd, q, wid);
+    frag_load<CKB>(fa, sd, q, wid, lane);
+    cur_advance<CKB>(sd, q, wid);
   }
   __syncthreads();
 
@@ -857,7 +911,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
       const int nt = F.nt[l];
       EpiBwdL<RT> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw, row0,
                     nvalid, nt, lane};
-      stream_layer<RT>(sd, si, q, fa, fb, par, X, LD, wid, lane, e);
+      stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(4 + l);
@@ -924,7 +978,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
       const int nt = P.nt[l];
       EpiBwdL<RT> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      stream_layer<RT>(sd, n_dyn_stream + si, q, fa, fb, par, X, LD, wid, lane, e);
+      stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(14 + l);

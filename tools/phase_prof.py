@@ -13,9 +13,11 @@ from prob_mbrl_amd import _lib, problem as PB  # noqa: E402
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else 'cartpole_nomm'
+    hint = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dev = torch.device('cuda:0')
     d = PB.synthetic_problem(cfg, seed=0, data_seed=0)
-    eng, args, _ = PB.engine_from_problem(d, dev)
+    eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=hint)
+    print(eng.info)
     H = eng.H
     pf = torch.zeros(H * 32, dtype=torch.int64, device=dev)
     pb = torch.zeros(H * 32, dtype=torch.int64, device=dev)
