@@ -196,7 +196,7 @@ struct pmbrl_plan {
   int n_dw_blocks, dw_wg_per_split, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
-      off_gxc, off_grt, ws_bytes;
+      off_gxc, off_grt, off_Jx, off_Ja, ws_bytes;
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -452,7 +452,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         n->wb[l] = take(fr);
         n->bias[l] = take((size_t)n->nt[l + 1] * 16 * sizeof(float));
         if (l < n->nl - 1)
-          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * sizeof(uint16_t));
+          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * 4);   // u16 (generic) or 4 nibble-bytes (fast)
       }
     }
     const size_t Rw = 16 * p->RT;
@@ -464,6 +464,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Td = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_xt = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_rt = take((size_t)c.H * c.B * sizeof(float));
+    p->off_Jx = take((size_t)c.H * c.B * c.D * sizeof(float));
+    p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     p->off_part = take((size_t)p->dw_nsplit * p->pol.n_params * sizeof(float));
@@ -620,6 +622,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.Td = reinterpret_cast<float*>(ws + p->off_Td);
   A.xt = reinterpret_cast<float*>(ws + p->off_xt);
   A.rt = reinterpret_cast<float*>(ws + p->off_rt);
+  A.Jx = reinterpret_cast<float*>(ws + p->off_Jx);
+  A.Ja = reinterpret_cast<float*>(ws + p->off_Ja);
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
   if (p->fast) {
     // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
@@ -681,9 +685,9 @@ static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s)
 template <int RT, int CKB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   if (fwd)
-    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CKB>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CKB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
   else
-    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CKB>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CKB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
 }
 static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
 #define PM_FAST_CASE(RTV, CK) \
@@ -731,15 +735,27 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
+  const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   if (p->mm_mode != 2) {
     launch_fwd_rt(p, A, s);
   } else {
     const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+    RolloutArgs Am = A;
+    if (p->fast) Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // fast family: rewards are handled after the sweep
     for (int t = 0; t < p->cfg.H; ++t) {
       A.t0 = t; A.t1 = t + 1;
       launch_fwd_rt(p, A, s);
-      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(64), smem, s, A, t);
+      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t);
     }
+  }
+  if (p->fast) {
+    // rewards (+ Jacobians) of all row-steps in one parallel pass, then their moment matching
+    A.t0 = 0; A.t1 = p->cfg.H;
+    const long long n = (long long)p->cfg.H * p->cfg.B;
+    hipLaunchKernelGGL(pm_reward_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    if (mm_r)
+      hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
+                         pm_mm_scratch_doubles(1) * sizeof(double), s, A);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -769,6 +785,14 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.grad_x0 = grad_x0_d;
   A.agn = action_grad_norms_d;
   A.prof = p->prof_bwd;
+  float* grt = reinterpret_cast<float*>(ws + p->off_grt);
+  const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+  if (p->fast && mm_r) {
+    // fast family: adjoint of the reward moment matching for all (t, group) up front
+    hipLaunchKernelGGL(pm_mm_rewards_bwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
+                       pm_mm_scratch_doubles(1) * sizeof(double), s, A, grt);
+    A.grad_rewards = grt;
+  }
   if (p->mm_mode != 2) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     A.gx_from_carry = 0;
@@ -776,11 +800,14 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   } else {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
-    float* grt = reinterpret_cast<float*>(ws + p->off_grt);
     const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
     HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
     RolloutArgs Am = A;
-    A.grad_rewards = grt;
+    if (p->fast) {
+      Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
+    } else {
+      A.grad_rewards = grt;
+    }
     A.gx_from_carry = 1;
     for (int t = p->cfg.H - 1; t >= 0; --t) {
       hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t, grt);

@@ -82,6 +82,7 @@ struct RolloutArgs {
   float* gT[PM_MAXL];     // policy pre-activation grads, same layout
   float *Tp, *Td;         // [H][B][U], [H][B][D]
   float *xt, *rt;         // pre-moment-matching next state / reward [H][B][D], [H][B]
+  float *Jx, *Ja;         // reward Jacobian d r~/d x~ [H][B][D], d r~/d a [H][B][U] (fast kernels)
   int* status;
   // backward only
   const float *grad_rewards, *grad_states, *grad_actions;

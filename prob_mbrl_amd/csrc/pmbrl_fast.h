@@ -30,8 +30,12 @@
 // layers are zero-padded to a multiple of CKB k-blocks and the LDS activation buffers carry
 // matching zero columns, so every chunk is full: the inner loops are straight-line code
 // (a branchy tail defeats the scheduler and, worse, SROA: the stage then lives in scratch).
-#define PM_FNT 1
-#define PM_L0T 4           // max resident first-layer tiles per wave
+// The fast kernels run EIGHT waves per workgroup (two per SIMD): the two co-resident waves
+// of a SIMD share its MFMA pipe, so one wave's LDS / weight-load waits and epilogue overlap
+// the other's MFMAs.  Tile ot of a layer belongs to wave ot % 8.
+#define PF_NW 8
+#define PF_NT (PF_NW * 64)
+#define PM_L0T 2           // max resident first-layer tiles per wave (<= 16 tiles per layer)
 #define PM_HJ 16           // max fused head / tail width
 
 __host__ __device__ inline bool pm_fast_net_ok(const int* dim, const int* nt, int nl) {
@@ -39,7 +43,7 @@ __host__ __device__ inline bool pm_fast_net_ok(const int* dim, const int* nt, in
   if (nt[0] != 1) return false;                       // first-layer K fits one 16-block
   if (dim[nl] > PM_HJ) return false;                  // fused head width
   for (int l = 1; l < nl; ++l)
-    if (nt[l] > PM_NW * PM_L0T) return false;         // <= 16 tiles per hidden layer
+    if (nt[l] > PF_NW * PM_L0T) return false;         // <= 16 tiles per hidden layer
   return true;
 }
 
@@ -85,8 +89,8 @@ __device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int
   q.wp += (size_t)CKB * 256;
   if (q.c >= q.n_kb) {
     q.c = 0;
-    q.ot += PM_NW;
-    q.wp += (size_t)(PM_NW - 1) * q.n_kb * 256;
+    q.ot += PF_NW;
+    q.wp += (size_t)(PF_NW - 1) * q.n_kb * 256;
     if (q.ot >= q.n_ot) {
       q.li++;
       cur_enter(sd, q, wid);
@@ -164,7 +168,7 @@ __device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Curso
   const int n_ot = sd.n_ot[li];
   const int nch2 = sd.n_kb[li] / (2 * CKB);
   int pslot = 24;
-  for (int ot = wid; ot < n_ot; ot += PM_NW) {
+  for (int ot = wid; ot < n_ot; ot += PF_NW) {
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
     f32x4 acc[2][RT];
 #pragma unroll
@@ -194,7 +198,7 @@ template <int RT>
 __device__ __forceinline__ void res0_load(Res0<RT>& r, const float* wf, int n_ot, int wid, int lane) {
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
-    const int ot = wid + i * PM_NW;
+    const int ot = wid + i * PF_NW;
     r.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ot < n_ot) r.w[i] = ldg4(wf + (size_t)ot * 256 + lane * 4);
   }
@@ -221,7 +225,7 @@ __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const fl
       for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma4(r.w[i][j], b[rt][j], acc[i][rt]);
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
-    const int ot = wid + i * PM_NW;
+    const int ot = wid + i * PF_NW;
     if (ot < n_ot) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[i][rt]);
@@ -238,9 +242,9 @@ __device__ __forceinline__ void narrow_dot(const float* act, int ld, const float
                                            int K16, float* out, int tid) {
   const int nd = R * nj;
   int tpd = 1;
-  while (tpd < 16 && nd * tpd * 2 <= PM_NT) tpd *= 2;
+  while (tpd < 16 && nd * tpd * 2 <= PF_NT) tpd *= 2;
   const int slice = tid & (tpd - 1);
-  const int dpr = PM_NT / tpd;                 // products per round
+  const int dpr = PF_NT / tpd;                 // products per round
   const int nk4 = K16 >> 2;
   for (int base = 0; base < nd; base += dpr) {
     const int dot = base + tid / tpd;
@@ -272,7 +276,7 @@ template <int RT>
 struct EpiFwdL {
   const float* bias;        // LDS, padded
   const uint16_t* mask;     // LDS [R][nt]
-  uint16_t* abits;          // HBM [B][nt] slice of step t
+  uint8_t* abits;           // HBM [B][nt][4] slice of step t: one nibble-byte per lane group
   float keep;
   float* lds_out;
   float* stash;             // HBM block or nullptr
@@ -300,16 +304,13 @@ struct EpiFwdL {
       for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
     }
 #endif
-    unsigned w16 = act << (4 * g);
-    w16 |= __shfl_xor(w16, 16);
-    w16 |= __shfl_xor(w16, 32);
-    if (g == 0 && lrow < nvalid) abits[(size_t)(row0 + lrow) * nt + ot] = (uint16_t)w16;
+    if (lrow < nvalid) abits[((size_t)(row0 + lrow) * nt + ot) * 4 + g] = (uint8_t)act;
   }
 };
 
 template <int RT>
 struct EpiBwdL {
-  const uint16_t* abits;    // HBM [B][nt] slice of step t
+  const uint8_t* abits;     // HBM [B][nt][4] slice of step t
   float keep;
   float* lds_out;
   float* stash;
@@ -318,9 +319,8 @@ struct EpiBwdL {
     const int g = lane >> 4;
     const int lrow = rt * 16 + (lane & 15);
     const int f0 = ot * 16 + 4 * g;
-    unsigned mw = 0;
-    if (lrow < nvalid) mw = abits[(size_t)(row0 + lrow) * nt + ot];
-    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    unsigned nib = 0;
+    if (lrow < nvalid) nib = abits[((size_t)(row0 + lrow) * nt + ot) * 4 + g];
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -405,6 +405,77 @@ __device__ inline void reward_lds_bwd(const RewardDev* rw, const float* x, int D
   }
 }
 
+// reward + its Jacobian for one row (one lane): r~, d r~/d x~ -> Jx, d r~/d a -> Ja (stashed
+// for the adjoint sweep, which then needs neither the reward constants nor sin/cos)
+struct FastLds;
+__device__ inline void reward_row_eval(const RolloutArgs& A, const RewardDev* rew, float* ph, float* dl,
+                                       float* gph, float* jx, float* ja, const float* x,
+                                       const float* a, int r, int t, int row0, float* rr_out) {
+  const int D = A.D, U = A.U, B = A.B;
+  const float rv = reward_lds(rew, x, D, a, U, ph, dl);
+  bool ok = isfinite(rv);
+  for (int d = 0; d < D; ++d) {
+    ok = ok && isfinite(x[d]);
+    jx[d] = 0.f;
+  }
+  if (!ok) atomicMin(A.status, t);
+  reward_lds_bwd(rew, x, D, a, U, rv, 1.f, ph, dl, gph, jx, ja);
+  const size_t o = (size_t)t * B + row0 + r;
+  for (int d = 0; d < D; ++d) A.Jx[o * D + d] = jx[d];
+  for (int j = 0; j < U; ++j) A.Ja[o * U + j] = ja[j];
+  if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
+  else A.rewards[o] = rv;
+  if (rr_out) *rr_out = rv;
+}
+
+// All rewards of a rollout in one fully parallel pass: thread = one (t, b) row-step.
+// r~ -> rt (if rewards are moment matched afterwards) or rewards; d r~/d x~ -> Jx; d r~/d a -> Ja;
+// non-finite states / rewards are reported through the status word like in the sweep.
+__global__ void pm_reward_all_kernel(const RolloutArgs A) {
+  const long long n = (long long)A.H * A.B;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i / A.B);
+  const int D = A.D, U = A.U;
+  const float* xs = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i * D
+                                                     : A.states + ((size_t)i + A.B) * D;
+  float x[PMBRL_MAX_DIM], a[16], jx[PMBRL_MAX_DIM], ja[16];
+  bool ok = true;
+  for (int d = 0; d < D; ++d) {
+    x[d] = xs[d];
+    jx[d] = 0.f;
+    ok = ok && isfinite(x[d]);
+  }
+  for (int j = 0; j < U; ++j) a[j] = A.actions[(size_t)i * U + j];
+  const float rv = reward_row(A.rew, x, D, a, U, nullptr);
+  ok = ok && isfinite(rv);
+  if (!ok) atomicMin(A.status, t);
+  reward_row_bwd(A.rew, x, D, a, U, rv, 1.f, jx, ja);
+  for (int d = 0; d < D; ++d) A.Jx[(size_t)i * D + d] = jx[d];
+  for (int j = 0; j < U; ++j) A.Ja[(size_t)i * U + j] = ja[j];
+  if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[i] = rv;
+  else A.rewards[i] = rv;
+}
+
+// moment matching of the rewards for all (t, group) at once (one wave each), and its adjoint
+__global__ void pm_mm_rewards_fwd_kernel(const RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr_r[];
+  const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
+  const int r0 = gi * A.M;
+  const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+                            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false,
+                            A.rewards + (size_t)t * A.B + r0, 1, mmscr_r, lane);
+  if (!ok && lane == 0) atomicMin(A.status, t);
+}
+__global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr_r[];
+  const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
+  const int r0 = gi * A.M;
+  pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
+            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false, A.grad_rewards + (size_t)t * A.B + r0, 1,
+            gr_tilde + (size_t)t * A.B + r0, 1, mmscr_r, lane);
+}
+
 // ---------------------------------------------------------------------------
 // LDS map of the fast kernels
 // ---------------------------------------------------------------------------
@@ -415,6 +486,8 @@ struct FastLds {
   float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
   float *mA, *mB;                // fused matrices (fwd: policy head, dynamics head; bwd: tails)
   float *ph, *dl, *gph;          // reward scratch [R][PMBRL_MAX_DIM], [R][8], [R][PMBRL_MAX_DIM]
+  float *jx, *ja;                // reward Jacobian rows [R][16] each
+  float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
   RewardDev* rew;
   double* mm;
 };
@@ -433,9 +506,10 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PM_HJ * LD;                        // mA, mB
   n += (size_t)R * (2 * PMBRL_MAX_DIM + 8);           // ph, gph, dl
+  n += (size_t)R * 32 + (size_t)R * (1 + 2 * D + 3 * U);   // jx, ja, stg
   n += (sizeof(RewardDev) + 3) / 4;
   n = (n + 3) & ~(size_t)3;
-  n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);
+  n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
   return n;
 }
 
@@ -473,6 +547,9 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   m.ph = p; p += (size_t)R * PMBRL_MAX_DIM;
   m.gph = p; p += (size_t)R * PMBRL_MAX_DIM;
   m.dl = p; p += (size_t)R * 8;
+  m.jx = p; p += (size_t)R * 16;
+  m.ja = p; p += (size_t)R * 16;
+  m.stg = p; p += (size_t)R * (1 + 2 * D + 3 * U);
   m.rew = reinterpret_cast<RewardDev*>(p);
   p += (sizeof(RewardDev) + 3) / 4;
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
@@ -497,44 +574,44 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
   const NetDev& F = A.dyn;
   const int D = A.D, U = A.U;
   for (int l = 0; l < P.nl; ++l)
-    for (int i = tid; i < P.nt[l + 1] * 16; i += PM_NT) PBIAS(l)[i] = P.bias[l][i];
+    for (int i = tid; i < P.nt[l + 1] * 16; i += PF_NT) PBIAS(l)[i] = P.bias[l][i];
   for (int l = 0; l < F.nl; ++l)
-    for (int i = tid; i < F.nt[l + 1] * 16; i += PM_NT) DBIAS(l)[i] = F.bias[l][i];
+    for (int i = tid; i < F.nt[l + 1] * 16; i += PF_NT) DBIAS(l)[i] = F.bias[l][i];
   for (int l = 0; l < P.nl - 1; ++l) {
     const int nt = P.nt[l + 1];
-    for (int i = tid; i < R * nt; i += PM_NT) {
+    for (int i = tid; i < R * nt; i += PF_NT) {
       const int r = i / nt;
       PMASK(l)[i] = (r < nvalid) ? P.mask[l][(size_t)(row0 + r) * nt + (i - r * nt)] : (uint16_t)0;
     }
   }
   for (int l = 0; l < F.nl - 1; ++l) {
     const int nt = F.nt[l + 1];
-    for (int i = tid; i < R * nt; i += PM_NT) {
+    for (int i = tid; i < R * nt; i += PF_NT) {
       const int r = i / nt;
       DMASK(l)[i] = (r < nvalid) ? F.mask[l][(size_t)(row0 + r) * nt + (i - r * nt)] : (uint16_t)0;
     }
   }
-  for (int i = tid; i < R * U; i += PM_NT)
+  for (int i = tid; i < R * U; i += PF_NT)
     L.zp[i] = (i / U < nvalid && A.zpol_ss == 0) ? A.zpol[(size_t)row0 * U + i] : 0.f;
-  for (int i = tid; i < R * D; i += PM_NT)
+  for (int i = tid; i < R * D; i += PF_NT)
     L.zd[i] = (i / D < nvalid && A.zdyn_ss == 0) ? A.zdyn[(size_t)row0 * D + i] : 0.f;
-  for (int i = tid; i < D + U; i += PM_NT) {
+  for (int i = tid; i < D + U; i += PF_NT) {
     L.mx[i] = A.mx[i];
     L.iSx[i] = A.iSx[i];
   }
-  for (int i = tid; i < D; i += PM_NT) {
+  for (int i = tid; i < D; i += PF_NT) {
     L.my[i] = A.my[i];
     L.Sy[i] = A.Sy[i];
     L.lSy[i] = logf(A.Sy[i]);
   }
-  for (int i = tid; i < U; i += PM_NT) {
+  for (int i = tid; i < U; i += PF_NT) {
     L.psc[i] = A.pscale[i];
     L.pbi[i] = A.pbias[i];
   }
   {
     const int* src = reinterpret_cast<const int*>(A.rew);
     int* dst = reinterpret_cast<int*>(L.rew);
-    for (int i = tid; i < (int)(sizeof(RewardDev) / 4); i += PM_NT) dst[i] = src[i];
+    for (int i = tid; i < (int)(sizeof(RewardDev) / 4); i += PF_NT) dst[i] = src[i];
   }
 }
 
@@ -542,7 +619,7 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 // forward (fast)
 // ===========================================================================
 template <int RT, int CKB>
-__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArgs A) {
+__global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -558,25 +635,25 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
   float* xb = L.xb;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-  for (int i = tid; i < 2 * R * LD; i += PM_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
+  for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   // fused head matrices: M[j][k] = W_head[j][k], zero padded to LD columns
   {
     const int Kp = P.dim[P.nl - 1], Op = P.dim[P.nl];
     const float* Wp = A.pol_head_w;
-    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
       const int j = i / LD, k = i - j * LD;
       L.mA[i] = (j < Op && k < Kp) ? Wp[(size_t)j * Kp + k] : 0.f;
     }
     const int Kd = F.dim[F.nl - 1], Od = F.dim[F.nl];
     const float* Wd = A.dyn_head_w;
-    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
       const int j = i / LD, k = i - j * LD;
       L.mB[i] = (j < Od && k < Kd) ? Wd[(size_t)j * Kd + k] : 0.f;
     }
   }
   {
     const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
-    for (int i = tid; i < R * D; i += PM_NT) {
+    for (int i = tid; i < R * D; i += PF_NT) {
       const int r = i / D, d = i - r * D;
       const float v = (r < nvalid) ? src[(size_t)(row0 + r) * D + d] : 0.f;
       xa[i] = v;
@@ -606,7 +683,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     PM_MARK(0);
     {
       float* st = A.actT[0] + blk * (size_t)16 * A.Rw;
-      for (int i = tid; i < R * 16; i += PM_NT) {
+      for (int i = tid; i < R * 16; i += PF_NT) {
         const int k = i / R, r = i - k * R;
         const float v = (k < D) ? xa[r * D + k] : 0.f;
         X[r * LD + k] = v;
@@ -618,7 +695,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     // ---- policy: first layer (resident), hidden layers (streamed), head as LDS dot products
     {
       const int nt = P.nt[1];
-      EpiFwdL<RT> e{PBIAS(0), PMASK(0), P.abits[0] + (size_t)t * B * nt, P.keep[0], Y,
+      EpiFwdL<RT> e{PBIAS(0), PMASK(0), reinterpret_cast<uint8_t*>(P.abits[0]) + (size_t)t * B * nt * 4, P.keep[0], Y,
                     A.actT[1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
                     row0, nvalid, nt, lane};
       res0_layer<RT>(w0p, nt, X, LD, wid, lane, e);
@@ -628,7 +705,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     PM_MARK(2);
     for (int l = 1; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
-      EpiFwdL<RT> e{PBIAS(l), PMASK(l), P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+      EpiFwdL<RT> e{PBIAS(l), PMASK(l), reinterpret_cast<uint8_t*>(P.abits[l]) + (size_t)t * B * nt * 4, P.keep[l], Y,
                     A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
                     row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, e,
@@ -643,7 +720,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     // ---- squash + dynamics input
     {
       const float* hb = PBIAS(P.nl - 1);
-      for (int i = tid; i < R * 16; i += PM_NT) {
+      for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float v = 0.f;
         if (k < D) {
@@ -674,7 +751,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     // ---- dynamics
     {
       const int nt = F.nt[1];
-      EpiFwdL<RT> e{DBIAS(0), DMASK(0), F.abits[0] + (size_t)t * B * nt, F.keep[0], Y, nullptr,
+      EpiFwdL<RT> e{DBIAS(0), DMASK(0), reinterpret_cast<uint8_t*>(F.abits[0]) + (size_t)t * B * nt * 4, F.keep[0], Y, nullptr,
                     LD, A.Rw, row0, nvalid, nt, lane};
       res0_layer<RT>(w0d, nt, X, LD, wid, lane, e);
     }
@@ -683,7 +760,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     PM_MARK(12);
     for (int l = 1; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
-      EpiFwdL<RT> e{DBIAS(l), DMASK(l), F.abits[l] + (size_t)t * B * nt, F.keep[l], Y, nullptr,
+      EpiFwdL<RT> e{DBIAS(l), DMASK(l), reinterpret_cast<uint8_t*>(F.abits[l]) + (size_t)t * B * nt * 4, F.keep[l], Y, nullptr,
                     LD, A.Rw, row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
@@ -696,7 +773,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     // ---- sample next state
     {
       const float* hb = DBIAS(F.nl - 1);
-      for (int i = tid; i < R * D; i += PM_NT) {
+      for (int i = tid; i < R * D; i += PF_NT) {
         const int r = i / D, d = i - r * D;
         const float mu = hb[d] + L.hp[r * PM_HJ + d];
         const float ls = hb[D + d] + L.hp[r * PM_HJ + D + d];
@@ -716,48 +793,24 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
     }
     __syncthreads();
     PM_MARK(21);
-    for (int r = tid; r < R; r += PM_NT) {
-      float rv = 0.f;
-      if (r < nvalid) {
-        rv = reward_lds(L.rew, xb + r * D, D, L.av + r * U, U, L.ph + r * PMBRL_MAX_DIM, L.dl + r * 8);
-        bool ok = isfinite(rv);
-        for (int d = 0; d < D; ++d) ok = ok && isfinite(xb[r * D + d]);
-        if (!ok) atomicMin(A.status, t);
-        const size_t o = (size_t)t * B + row0 + r;
-        if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
-        else A.rewards[o] = rv;
-      }
-      L.rr[r] = rv;
-    }
-    if (A.mm_mode == 1) {
-      __syncthreads();
+    // The reward is NOT evaluated here: r~[t,b] depends only on the stored (x~, a), never feeds
+    // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
+    // after the sweep (so is the moment matching of rewards).  Only the moment matching of
+    // STATES is part of the recursion.
+    if (A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES)) {
       const int gpw = A.rows_per_wg / A.M;
-      for (int gi = wid; gi < gpw; gi += PM_NW) {
+      for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        if (A.flags & PMBRL_FLAG_MM_STATES) {
-          const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
-                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
-                                    xa + lr0 * D, D, scr, lane);
-          if (!ok && lane == 0) atomicMin(A.status, t);
-        }
-        if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-          const bool ok = pm_mm_fwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-                                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
-                                    L.gr + lr0, 1, scr, lane);
-          if (!ok && lane == 0) atomicMin(A.status, t);
-        }
+        const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                                  pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
+                                  xa + lr0 * D, D, scr, lane);
+        if (!ok && lane == 0) atomicMin(A.status, t);
       }
       __syncthreads();
-      if (A.flags & PMBRL_FLAG_MM_STATES) {
-        for (int i = tid; i < nvalid * D; i += PM_NT)
-          A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
-      }
-      if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-        for (int r = tid; r < nvalid; r += PM_NT) A.rewards[(size_t)t * B + row0 + r] = L.gr[r];
-      }
-      if (!(A.flags & PMBRL_FLAG_MM_STATES)) { float* tmp = xa; xa = xb; xb = tmp; }
+      for (int i = tid; i < nvalid * D; i += PF_NT)
+        A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
     } else {
       float* tmp = xa; xa = xb; xb = tmp;
     }
@@ -770,7 +823,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd_fast(const RolloutArg
 // backward sweep (fast)
 // ===========================================================================
 template <int RT, int CKB>
-__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArgs A) {
+__global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -782,27 +835,27 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
   FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
-  float* gx = L.xa;
-  float* gxt = L.xb;
+  float* gx = L.xa;     // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
+  float* gxt = L.xb;    // moment-matching adjoint of gx (in-kernel mm only)
+  float* gxn = L.jx;    // dL/dx~ incl. the reward term, then + dynamics-input term
   const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
-  const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-  for (int i = tid; i < 2 * R * LD; i += PM_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
+  for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   // fused tails: mA[j][k] = V0[k][j] (dynamics first layer, j < D+U), mB[j][k] = W0[k][j] (policy)
   {
     const int Kd = F.dim[1], Od = F.dim[0];
-    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
       const int j = i / LD, k = i - j * LD;
       L.mA[i] = (j < Od && k < Kd) ? A.dyn_first_w[(size_t)k * Od + j] : 0.f;
     }
     const int Kp = P.dim[1], Op = P.dim[0];
-    for (int i = tid; i < PM_HJ * LD; i += PM_NT) {
+    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
       const int j = i / LD, k = i - j * LD;
       L.mB[i] = (j < Op && k < Kp) ? A.pol_first_w[(size_t)k * Op + j] : 0.f;
     }
   }
-  for (int i = tid; i < R * D; i += PM_NT) {
+  for (int i = tid; i < R * D; i += PF_NT) {
     const int r = i / D, d = i - r * D;
     float v = 0.f;
     if (r < nvalid) {
@@ -827,80 +880,85 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
   }
   __syncthreads();
 
+  // Per-row inputs of one step, staged in LDS: [gr | Jx(D) | Ja(U) | Td(D) | Tp(U) | a(U)].
+  // The values of step t-1 are fetched into registers at the START of step t and parked in
+  // LDS at its end, so their HBM latency is covered by a whole step of GEMM work.
+  const int S = 1 + 2 * D + 3 * U;
+  constexpr int PFV = (R * (1 + 2 * 16 + 3 * 8) + PF_NT - 1) / PF_NT;   // staged values per thread (bound)
+  auto stage_fetch = [&](int ts, int idx) -> float {
+    const int r = idx / S, c = idx - r * S;
+    if (r >= nvalid) return 0.f;
+    const size_t row = (size_t)ts * B + row0 + r;
+    if (c == 0) return A.grad_rewards[row];
+    if (c < 1 + D) return A.Jx[row * D + (c - 1)];
+    if (c < 1 + D + U) return A.Ja[row * U + (c - 1 - D)];
+    if (c < 1 + 2 * D + U) return A.Td[row * D + (c - 1 - D - U)];
+    if (c < 1 + 2 * D + 2 * U) return A.Tp[row * U + (c - 1 - 2 * D - U)];
+    return A.actions[row * U + (c - 1 - 2 * D - 2 * U)];
+  };
+  for (int i = tid; i < R * S; i += PF_NT) L.stg[i] = stage_fetch(A.t1 - 1, i);
+  __syncthreads();
+
   for (int t = A.t1 - 1; t >= A.t0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
-    {
-      const float* xsrc = mms ? A.xt + (size_t)t * B * D : A.states + (size_t)(t + 1) * B * D;
-      for (int i = tid; i < R * D; i += PM_NT) {
+    float pfv[PFV];
+#pragma unroll
+    for (int u = 0; u < PFV; ++u) {
+      const int i = tid + u * PF_NT;
+      pfv[u] = (t > A.t0 && i < R * S) ? stage_fetch(t - 1, i) : 0.f;
+    }
+    const float* stg = L.stg;
+    if (A.mm_mode == 1 && mms) {
+      // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
+      const float* xsrc = A.xt + (size_t)t * B * D;
+      for (int i = tid; i < R * D; i += PF_NT) {
         const int r = i / D, d = i - r * D;
         Y[r * LD + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
       }
-      for (int i = tid; i < R * U; i += PM_NT) {
-        const int r = i / U;
-        L.av[i] = (r < nvalid) ? A.actions[((size_t)t * B + row0) * U + i] : 0.f;
-      }
-      const float* rsrc = mmr ? A.rt : A.rewards;
-      for (int r = tid; r < R; r += PM_NT) {
-        const bool v = r < nvalid;
-        L.gr[r] = v ? A.grad_rewards[(size_t)t * B + row0 + r] : 0.f;
-        L.rr[r] = v ? rsrc[(size_t)t * B + row0 + r] : 0.f;
-      }
-    }
-    __syncthreads();
-    if (A.mm_mode == 1) {
+      __syncthreads();
       const int gpw = A.rows_per_wg / A.M;
-      for (int gi = wid; gi < gpw; gi += PM_NW) {
+      for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        if (mms)
-          pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
-                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, gx + lr0 * D, D,
-                    gxt + lr0 * D, D, scr, lane);
-        if (mmr)
-          pm_mm_bwd(L.rr + lr0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-                    pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, L.gr + lr0, 1,
-                    L.gr + lr0, 1, scr, lane);
+        pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
+                  pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, gx + lr0 * D, D,
+                  gxt + lr0 * D, D, scr, lane);
       }
       __syncthreads();
     }
     PM_MARK(1);
-    // ---- reward adjoint (per row) ; gxt = (mm-adjoint of gx | gx) + dr/dx~ ; direct action grad
-    for (int r = tid; r < R; r += PM_NT) {
-      float* gxr = gxt + r * D;
-      if (!(A.mm_mode == 1 && mms))
-        for (int d = 0; d < D; ++d) gxr[d] = gx[r * D + d];
-      for (int j = 0; j < U; ++j) L.gad[r * 16 + j] = 0.f;
-      if (r < nvalid) {
-        const float rv = reward_lds(L.rew, Y + r * LD, D, L.av + r * U, U, L.ph + r * PMBRL_MAX_DIM,
-                                    L.dl + r * 8);
-        (void)rv;
-        reward_lds_bwd(L.rew, Y + r * LD, D, L.av + r * U, U, L.rr[r], L.gr[r],
-                       L.ph + r * PMBRL_MAX_DIM, L.dl + r * 8, L.gph + r * PMBRL_MAX_DIM, gxr,
-                       L.gad + r * 16);
+    // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input:
+    //      gxt = (mm-adjoint of gx | gx) + gr~ Jx ;  X = [gxt*Sy | gxt*Td | 0] ;  gad = gr~ Ja
+    {
+      const bool from_mm = (A.mm_mode == 1 && mms);
+      for (int i = tid; i < R * 16; i += PF_NT) {
+        const int r = i >> 4, k = i & 15;
+        float v = 0.f;
+        if (r < nvalid && k < 2 * D) {
+          const int d = k < D ? k : k - D;
+          const float grv = stg[r * S];   // dL/dr~ (already through the reward mm adjoint)
+          const float g = (from_mm ? gxt[r * D + d] : gx[r * D + d]) + grv * stg[r * S + 1 + d];
+          if (k < D) {
+            gxn[r * D + d] = g;
+            v = g * L.Sy[d];
+          } else {
+            v = g * stg[r * S + 1 + D + U + d];
+          }
+        }
+        X[r * LD + k] = v;
+        if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
       }
-    }
-    __syncthreads();
-    PM_MARK(2);
-    // ---- dynamics head adjoint input [gxt*Sy | gxt*Td | 0] -> X (one 16-block)
-    for (int i = tid; i < R * 16; i += PM_NT) {
-      const int r = i >> 4, k = i & 15;
-      float v = 0.f;
-      if (r < nvalid) {
-        if (k < D) v = gxt[r * D + k] * L.Sy[k];
-        else if (k < 2 * D) v = gxt[r * D + k - D] * A.Td[((size_t)t * B + row0 + r) * D + k - D];
-      }
-      X[r * LD + k] = v;
     }
     __syncthreads();
     PM_MARK(3);
     // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) as LDS dot products
     {
       const int nt = F.nt[F.nl - 1];
-      EpiBwdL<RT> e{F.abits[F.nl - 2] + (size_t)t * B * nt, F.keep[F.nl - 2], Y, nullptr, LD, A.Rw,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[F.nl - 2]) + (size_t)t * B * nt * 4, F.keep[F.nl - 2], Y, nullptr, LD, A.Rw,
                     row0, nvalid, nt, lane};
       res0_layer<RT>(whd, nt, X, LD, wid, lane, e);
     }
@@ -909,7 +967,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     PM_MARK(4);
     for (int l = F.nl - 2, si = 0; l >= 1; --l, ++si) {
       const int nt = F.nt[l];
-      EpiBwdL<RT> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw, row0,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[l - 1]) + (size_t)t * B * nt * 4, F.keep[l - 1], Y, nullptr, LD, A.Rw, row0,
                     nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
@@ -922,11 +980,11 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     // ---- phase B: tail result; state part -> gxt, action part -> policy head adjoint
     {
       float* gst = A.gT[P.nl - 1] + blk * (size_t)16 * A.Rw;
-      for (int i = tid; i < R * 16; i += PM_NT) {
+      for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float tail = 0.f;
         if (k < D + U) tail = L.hp[r * PM_HJ + k] * L.iSx[k];
-        if (k < D) gxt[r * D + k] += tail;
+        if (k < D) gxn[r * D + k] += tail;
         if (k >= D && k < D + U) {
           const int j = k - D;
           float go_mu = 0.f, go_ls = 0.f;
@@ -935,10 +993,10 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
             if (A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
             L.gad[r * 16 + j] = ga;
             const float sc = L.psc[j];
-            const float th = (L.av[r * U + j] - L.pbi[j]) / sc;
+            const float th = (stg[r * S + 1 + 2 * D + 2 * U + j] - L.pbi[j]) / sc;
             const float gu = ga * sc * (1.f - th * th);
             go_mu = gu;
-            go_ls = gu * A.Tp[((size_t)t * B + row0 + r) * U + j];
+            go_ls = gu * stg[r * S + 1 + 2 * D + U + j];
           }
           X[r * LD + j] = go_mu;
           X[r * LD + U + j] = go_ls;
@@ -947,7 +1005,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
         }
       }
       // zero the K padding of the head-gradient block (columns 2U..15)
-      for (int i = tid; i < R * 16; i += PM_NT) {
+      for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         if (k >= 2 * U) {
           X[r * LD + k] = 0.f;
@@ -957,7 +1015,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     }
     __syncthreads();
     if (A.agn) {
-      for (int r = tid; r < nvalid; r += PM_NT) {
+      for (int r = tid; r < nvalid; r += PF_NT) {
         float s2 = 0.f;
         for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
         A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
@@ -967,7 +1025,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     // ---- policy trunk: dX chain + G stash; tail (grad wrt x) as LDS dot products
     {
       const int nt = P.nt[P.nl - 1];
-      EpiBwdL<RT> e{P.abits[P.nl - 2] + (size_t)t * B * nt, P.keep[P.nl - 2], Y,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[P.nl - 2]) + (size_t)t * B * nt * 4, P.keep[P.nl - 2], Y,
                     A.gT[P.nl - 2] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       res0_layer<RT>(whp, nt, X, LD, wid, lane, e);
     }
@@ -976,7 +1034,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     PM_MARK(14);
     for (int l = P.nl - 2, si = 0; l >= 1; --l, ++si) {
       const int nt = P.nt[l];
-      EpiBwdL<RT> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[l - 1]) + (size_t)t * B * nt * 4, P.keep[l - 1], Y,
                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
@@ -986,16 +1044,22 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd_fast(const RolloutArg
     narrow_dot<R>(X, LD, L.mB, LD, P.dim[0], P.nt[1] * 16, L.hp, tid);
     __syncthreads();
     PM_MARK(22);
-    for (int i = tid; i < R * D; i += PM_NT) {
+    for (int i = tid; i < R * D; i += PF_NT) {
       const int r = i / D, d = i - r * D;
-      float v = gxt[i] + L.hp[r * PM_HJ + d];
+      float v = gxn[i] + L.hp[r * PM_HJ + d];
       if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
       gx[i] = v;
+    }
+    // park the prefetched inputs of step t-1
+#pragma unroll
+    for (int u = 0; u < PFV; ++u) {
+      const int i = tid + u * PF_NT;
+      if (i < R * S) L.stg[i] = pfv[u];
     }
     __syncthreads();
     PM_MARK(23);
   }
-  for (int i = tid; i < nvalid * D; i += PM_NT) {
+  for (int i = tid; i < nvalid * D; i += PF_NT) {
     const size_t o = (size_t)row0 * D + i;
     if (A.gx_carry) A.gx_carry[o] = gx[i];
     if (A.t0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
