@@ -73,48 +73,81 @@ __global__ void pm_pack_mask_kernel(const float* __restrict__ m, int B, int h, i
 }
 __global__ void pm_set_int(int* p, int v) { *p = v; }
 
-__global__ void pm_weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                       long long n, float* __restrict__ out) {
-  __shared__ double sm[1024];
-  double s = 0.0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)a[i] * (double)w[i];
+// Small reductions: per-block partial sums in a per-device scratch, finished in FIXED order
+// (bit-reproducible).  The scratch is shared by all calls on a device: calls are expected to
+// be stream-ordered (one optimisation loop per device), like the rest of a plan's work.
+#define PM_RED_MAXB 128
+__device__ double g_red_part[2][PM_RED_MAXB];
+__device__ unsigned g_red_count;
+
+__device__ __forceinline__ double pm_block_sum(double s, double* sm) {
   sm[threadIdx.x] = s;
   __syncthreads();
   for (int o = blockDim.x / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)sm[0];
+  return sm[0];
 }
 
-// clip_grad_norm_ + Adam, one workgroup (policy nets are 1e4..1e6 parameters)
-__global__ __launch_bounds__(1024) void pm_clip_adam_kernel(float* __restrict__ p,
-                                                            float* __restrict__ g,
-                                                            float* __restrict__ m,
-                                                            float* __restrict__ v, long long n,
-                                                            float lr, float b1, float b2,
-                                                            float omb1, float omb2,
-                                                            float eps, float bc1, float bc2_sqrt,
-                                                            float max_norm,
-                                                            float* __restrict__ norm_out) {
-  __shared__ double sm[1024];
+__global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __restrict__ a,
+                                                              const float* __restrict__ w,
+                                                              long long n, float* __restrict__ out) {
+  __shared__ double sm[256];
+  __shared__ unsigned ticket;
   double s = 0.0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    s += (double)a[i] * (double)w[i];
+  const double tot = pm_block_sum(s, sm);
+  if (threadIdx.x == 0) {
+    g_red_part[0][blockIdx.x] = tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ticket = __hip_atomic_fetch_add(&g_red_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (ticket == gridDim.x - 1) {          // last block: every partial is published
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      double t = 0.0;
+      for (unsigned b = 0; b < gridDim.x; ++b)
+        t += __hip_atomic_load(&g_red_part[0][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[0] = (float)t;
+      __hip_atomic_store(&g_red_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// clip_grad_norm_ + Adam in two launches: (1) per-block partial sums of g^2, (2) every block
+// adds the partials in the same order (identical norm everywhere) and updates its slice.
+__global__ __launch_bounds__(256) void pm_gradnorm_kernel(const float* __restrict__ g, long long n) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
     const double x = g[i];
     s += x * x;
   }
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-    __syncthreads();
-  }
-  const float norm = (float)sqrt(sm[0]);
-  if (threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  const double tot = pm_block_sum(s, sm);
+  if (threadIdx.x == 0) g_red_part[1][blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           long long n, int n_part, float lr, float b1,
+                                                           float b2, float omb1, float omb2, float eps,
+                                                           float bc1, float bc2_sqrt, float max_norm,
+                                                           float* __restrict__ norm_out) {
+  double t = 0.0;
+  for (int b = 0; b < n_part; ++b) t += g_red_part[1][b];
+  const float norm = (float)sqrt(t);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
   const float step_size = lr / bc1;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
     const float mi = m[i] * b1 + omb1 * gi;
     const float vi = v[i] * b2 + omb2 * gi * gi;
@@ -123,6 +156,42 @@ __global__ __launch_bounds__(1024) void pm_clip_adam_kernel(float* __restrict__ 
     m[i] = mi;
     v[i] = vi;
     p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+// all weight / bias repacking of one forward call in ONE launch (blockIdx.y = job)
+struct PackJob {
+  const float* src;
+  float* dst;
+  int O, K, transpose, mult, is_bias;
+};
+struct PackArgs {
+  int n;
+  PackJob job[6 * PM_MAXL];
+};
+__global__ void pm_pack_all(const PackArgs P) {
+  const PackJob j = P.job[blockIdx.y];
+  if (j.is_bias) {
+    const int O16 = (j.O + 15) / 16 * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < O16; i += gridDim.x * blockDim.x)
+      j.dst[i] = i < j.O ? j.src[i] : 0.f;
+    return;
+  }
+  const int n_out = j.transpose ? j.K : j.O, n_in = j.transpose ? j.O : j.K;
+  const int n_ot = (n_out + 15) / 16;
+  const int n_kb = ((n_in + 15) / 16 + j.mult - 1) / j.mult * j.mult;
+  const size_t total = (size_t)n_ot * n_kb * 256;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int jj = i & 3, lane = (i >> 2) & 63;
+    const size_t tb = i >> 8;
+    const int kb = tb % n_kb, ot = tb / n_kb;
+    const int o = ot * 16 + (lane & 15);
+    const int k = kb * 16 + 4 * (lane >> 4) + jj;
+    float v = 0.f;
+    if (o < n_out && k < n_in)
+      v = j.transpose ? j.src[(size_t)k * j.K + o] : j.src[(size_t)o * j.K + k];
+    j.dst[i] = v;
   }
 }
 
@@ -655,23 +724,15 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   return 0;
 }
 
-static int pack_net(const NetPlan& n, char* ws, const float* params, hipStream_t s, int ckb) {
+static void pack_jobs(const NetPlan& n, char* ws, const float* params, int ckb, PackArgs& P) {
   for (int l = 0; l < n.nl; ++l) {
     const int O = n.dim[l + 1], K = n.dim[l];
-    // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to CKB
+    // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to 2*CKB
     const int mult = (ckb >= 1 && l >= 1 && l <= n.nl - 2) ? 2 * ckb : 1;
-    const size_t tot = (size_t)(n.nt[l + 1] + 15) * (n.nt[l] + 15) * 256;
-    const int grid = (int)std::min<size_t>((tot + 255) / 256, 1024);
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 0, mult,
-                       reinterpret_cast<float*>(ws + n.wf[l]));
-    hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, params + n.w_off[l], O, K, 1, mult,
-                       reinterpret_cast<float*>(ws + n.wb[l]));
-    const int O16 = n.nt[l + 1] * 16;
-    hipLaunchKernelGGL(pm_pack_bias, dim3((O16 + 255) / 256), dim3(256), 0, s,
-                       params + n.b_off[l], O, O16, reinterpret_cast<float*>(ws + n.bias[l]));
+    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wf[l]), O, K, 0, mult, 0};
+    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wb[l]), O, K, 1, mult, 0};
+    P.job[P.n++] = PackJob{params + n.b_off[l], reinterpret_cast<float*>(ws + n.bias[l]), O, K, 0, 1, 1};
   }
-  HIPCHK(hipGetLastError());
-  return 0;
 }
 
 template <int RT>
@@ -729,9 +790,11 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   char* ws = static_cast<char*>(workspace);
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
-    rc = pack_net(p->pol, ws, in->pol_params_d, s, p->fast ? p->CKB : 0);
-    if (rc == 0) rc = pack_net(p->dyn, ws, in->dyn_params_d, s, p->fast ? p->CKB : 0);
-    if (rc) return rc;
+    PackArgs PK;
+    PK.n = 0;
+    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CKB : 0, PK);
+    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CKB : 0, PK);
+    hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
     hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
@@ -857,7 +920,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
 extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d, int64_t n,
                                   float* out_d) {
   if (!a_d || !w_d || !out_d || n < 0) return fail(-1, "bad argument");
-  hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a_d, w_d,
+  const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 2047) / 2048));
+  hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a_d, w_d,
                      (long long)n, out_d);
   HIPCHK(hipGetLastError());
   return 0;
@@ -870,8 +934,11 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
     return fail(-1, "bad argument");
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params_d,
-                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, (float)lr, (float)beta1,
+  const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
+  hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
+                     (long long)n);
+  hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                      (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d);
   HIPCHK(hipGetLastError());
