@@ -262,7 +262,7 @@ struct pmbrl_plan {
   NetPlan pol, dyn;
   RewardDev* rew_d;
   DwBlock* dw_blocks_d;
-  int n_dw_blocks, dw_wg_per_split, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  int n_dw_blocks, dw_npass, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
       off_gxc, off_grt, off_Jx, off_Ja, ws_bytes;
@@ -476,29 +476,51 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
   }
-  // dW wave blocks
+  // dW wave blocks: balanced splits of every layer's output tile grid into <= 4 x 8 tile
+  // blocks, consecutive blocks (neighbours in the grid) fill the 8 wave slots of a pass
   {
     std::vector<DwBlock> blocks;
-    for (int l = 0; l < p->pol.nl; ++l) {
-      const int OT = p->pol.nt[l + 1], IT = p->pol.nt[l];
-      for (int o = 0; o < OT; o += PM_DW_TM)
-        for (int i = 0; i < IT; i += PM_DW_TN) {
+    auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
+      const int parts = (n + maxsz - 1) / maxsz;
+      int lo = 0;
+      for (int i = 0; i < parts; ++i) {
+        const int sz = n / parts + (i < n % parts ? 1 : 0);
+        out.push_back({lo, sz});
+        lo += sz;
+      }
+    };
+    // widest layers first so that a pass is filled with blocks of one layer when possible
+    std::vector<int> order;
+    for (int l = 0; l < p->pol.nl; ++l) order.push_back(l);
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      return p->pol.nt[a] * p->pol.nt[a + 1] > p->pol.nt[b] * p->pol.nt[b + 1];
+    });
+    for (int l : order) {
+      std::vector<std::pair<int, int>> os, is;
+      split(p->pol.nt[l + 1], PM_DW_TM, os);
+      split(p->pol.nt[l], PM_DW_TN, is);
+      for (auto& o : os)
+        for (auto& i : is) {
           DwBlock b;
           b.layer = (int16_t)l;
-          b.ot0 = (int16_t)o;
-          b.it0 = (int16_t)i;
-          b.n_ot = (int16_t)std::min(PM_DW_TM, OT - o);
-          b.n_it = (int16_t)std::min(PM_DW_TN, IT - i);
+          b.ot0 = (int16_t)o.first;
+          b.n_ot = (int16_t)o.second;
+          b.it0 = (int16_t)i.first;
+          b.n_it = (int16_t)i.second;
           b.pad = 0;
           blocks.push_back(b);
         }
     }
-    // heaviest blocks first within a workgroup quartet does not matter; keep layer order
     p->n_dw_blocks = (int)blocks.size();
-    p->dw_wg_per_split = (p->n_dw_blocks + PM_NW - 1) / PM_NW;
+    p->dw_npass = (p->n_dw_blocks + PM_DW_NW - 1) / PM_DW_NW;
+    while ((int)blocks.size() < p->dw_npass * PM_DW_NW) {
+      DwBlock b;
+      memset(&b, 0, sizeof(b));
+      b.layer = -1;
+      blocks.push_back(b);
+    }
     p->dw_n_chunks = c.H * p->nwg * p->RT;
-    int nsplit = std::max(1, 1024 / p->dw_wg_per_split);
-    nsplit = std::min(nsplit, p->dw_n_chunks);
+    int nsplit = std::min(256, p->dw_n_chunks);   // one 8-wave workgroup per CU
     p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
     p->dw_nsplit = (p->dw_n_chunks + p->dw_chunks_per_split - 1) / p->dw_chunks_per_split;
     HIPCHK(hipMalloc(&p->dw_blocks_d, blocks.size() * sizeof(DwBlock)));
@@ -882,12 +904,10 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   DwArgs W;
   memset(&W, 0, sizeof(W));
   W.nl = p->pol.nl;
-  W.n_blocks = p->n_dw_blocks;
-  W.n_wg_per_split = p->dw_wg_per_split;
+  W.npass = p->dw_npass;
   W.nsplit = p->dw_nsplit;
   W.n_chunks = p->dw_n_chunks;
   W.chunks_per_split = p->dw_chunks_per_split;
-  W.nwg_rollout = p->nwg;
   W.RT = p->RT;
   W.Rw = 16 * p->RT;
   W.n_params = (int)p->pol.n_params;
@@ -905,12 +925,12 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   W.part = reinterpret_cast<float*>(ws + p->off_part);
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW, s);
-    hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_wg_per_split * p->dw_nsplit), dim3(PM_NT), 0, s, W);
+    hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
   }
   const int n = (int)p->pol.n_params;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
-    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(256), 0, s, W.part, p->dw_nsplit, n,
+    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 31) / 32), dim3(256), 0, s, W.part, p->dw_nsplit, n,
                        grad_pol_flat_d);
   }
   HIPCHK(hipGetLastError());

@@ -5,93 +5,93 @@
 // makes the reduction index n the contiguous one: each lane's MFMA operand for
 // four consecutive k-steps is one 16-byte global load, no LDS staging needed.
 //
-// Decomposition: the output tile grid of every layer is cut into wave blocks of
-// up to 4x4 tiles (64 accumulator registers); a workgroup takes PM_NW
-// consecutive wave blocks; the n range is split `nsplit` ways across
-// workgroups.  Partial sums go to `part[split][n_params]` and are summed in a
-// fixed order by pm_dw_reduce -> deterministic gradients.
+// Decomposition: a workgroup = 8 waves (2 per SIMD) owns a contiguous range of
+// row-step chunks (split-K) and walks ALL output wave blocks of all layers in
+// `npass` passes of 8 wave blocks.  A wave block is up to 4 x 8 tiles (128
+// accumulator registers); the 8 blocks of a pass are neighbours in the output
+// tile grid of one layer, so a stash chunk is fetched from HBM once per
+// workgroup and re-read by the other waves through L1/L2 (the first version,
+// 4x4 blocks spread over independent workgroups, read every chunk ~2.5 times
+// and was bound by that traffic).  Partial sums go to part[split][n_params] and
+// are added in a fixed order by pm_dw_reduce -> bit-reproducible gradients.
 #pragma once
 #include "pmbrl_dev.h"
 
+#define PM_DW_NW 8
+#define PM_DW_NT (PM_DW_NW * 64)
 #define PM_DW_TM 4
-#define PM_DW_TN 4
+#define PM_DW_TN 8
 
-struct DwBlock {      // one wave block
+struct DwBlock {      // one wave block; layer < 0: idle slot
   int16_t layer, ot0, it0, n_ot, n_it, pad;
 };
 
 struct DwArgs {
-  int nl, n_blocks, n_wg_per_split, nsplit, n_chunks, chunks_per_split;
-  int nwg_rollout, RT, Rw, n_params;
+  int nl, npass, nsplit, n_chunks, chunks_per_split;
+  int RT, Rw, n_params;
   int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
   int w_off[PM_MAXL], b_off[PM_MAXL];    // offsets in the flat parameter vector
   const float* actT[PM_MAXL];
   const float* gT[PM_MAXL];
-  const DwBlock* blocks;
+  const DwBlock* blocks;  // [npass][PM_DW_NW]
   float* part;            // [nsplit][n_params]
 };
 
-__global__ __launch_bounds__(PM_NT, 1) void pm_dw_kernel(const DwArgs A) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x / A.n_wg_per_split;
-  const int bidx = (blockIdx.x - split * A.n_wg_per_split) * PM_NW + wid;
-  if (bidx >= A.n_blocks) return;
-  const DwBlock blk = A.blocks[bidx];
+// one wave block with at most NJ input-tile columns (NJ is static so that narrow layers --
+// the first layer's K <= 16, the head's 2U outputs -- do not pay for 8 columns)
+template <int NJ>
+__device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
+                                            float* part, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
   const int l = blk.layer;
   const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
-  const int g = lane >> 4, c16 = lane & 15;
   const float* gbase = A.gT[l];
   const float* abase = A.actT[l];
   const size_t gblk = (size_t)Fo16 * A.Rw, ablk = (size_t)Fi16 * A.Rw;
   // per-lane offsets inside a (t,wg) block for row tile rt: (feature)*Rw + rt*16 + 4g
-  int goff[PM_DW_TM], aoff[PM_DW_TN];
-#pragma unroll
-  for (int i = 0; i < PM_DW_TM; ++i) goff[i] = ((blk.ot0 + i) * 16 + c16) * A.Rw + 4 * g;
-#pragma unroll
-  for (int j = 0; j < PM_DW_TN; ++j) aoff[j] = ((blk.it0 + j) * 16 + c16) * A.Rw + 4 * g;
+  const int goff0 = (blk.ot0 * 16 + c16) * A.Rw + 4 * g;
+  const int aoff0 = (blk.it0 * 16 + c16) * A.Rw + 4 * g;
+  const int tstride = 16 * A.Rw;
 
-  f32x4 acc[PM_DW_TM][PM_DW_TN];
+  f32x4 acc[PM_DW_TM][NJ];
   float bsum[PM_DW_TM];
 #pragma unroll
   for (int i = 0; i < PM_DW_TM; ++i) {
     bsum[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < PM_DW_TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int c_lo = split * A.chunks_per_split;
-  const int c_hi = min(A.n_chunks, c_lo + A.chunks_per_split);
   const bool do_bias = blk.it0 == 0;
-
-  f32x4 ga[2][PM_DW_TM], aa[2][PM_DW_TN];
+  // register double buffer: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
+  f32x4 ga[2][PM_DW_TM], aa[2][NJ];
   auto load = [&](int buf, int c) {
     if (c < c_hi) {
       const int b = c / A.RT, rt = c - b * A.RT;
-      const float* gp = gbase + (size_t)b * gblk + rt * 16;
-      const float* ap = abase + (size_t)b * ablk + rt * 16;
+      const float* gp = gbase + (size_t)b * gblk + rt * 16 + goff0;
+      const float* ap = abase + (size_t)b * ablk + rt * 16 + aoff0;
 #pragma unroll
       for (int i = 0; i < PM_DW_TM; ++i)
-        if (i < blk.n_ot) ga[buf][i] = ldg4(gp + goff[i]);
+        ga[buf][i] = (i < blk.n_ot) ? ldg4(gp + i * tstride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < PM_DW_TN; ++j)
-        if (j < blk.n_it) aa[buf][j] = ldg4(ap + aoff[j]);
+      for (int j = 0; j < NJ; ++j)
+        aa[buf][j] = (j < blk.n_it) ? ldg4(ap + j * tstride) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto compute = [&](int buf, int c) {
     if (c < c_hi) {
+      // absent columns carry zero operands; absent rows are skipped with one uniform branch
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int i = 0; i < PM_DW_TM; ++i)
           if (i < blk.n_ot) {
 #pragma unroll
-            for (int j = 0; j < PM_DW_TN; ++j)
-              if (j < blk.n_it) acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
           }
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < PM_DW_TM; ++i)
-          if (i < blk.n_ot) bsum[i] += (ga[buf][i][0] + ga[buf][i][1]) + (ga[buf][i][2] + ga[buf][i][3]);
+          bsum[i] += (ga[buf][i][0] + ga[buf][i][1]) + (ga[buf][i][2] + ga[buf][i][3]);
       }
     }
   };
@@ -102,14 +102,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_dw_kernel(const DwArgs A) {
     load(0, c + 2);
     compute(1, c + 1);
   }
-  // write the partial tile: lane holds dW[o = (ot)*16 + 4g + r][k = it*16 + c16]
-  float* part = A.part + (size_t)split * A.n_params;
+  // write the partial tile: lane holds dW[o = ot*16 + 4g + r][k = it*16 + c16]
   const int O = A.dim[l + 1], K = A.dim[l];
 #pragma unroll
   for (int i = 0; i < PM_DW_TM; ++i)
     if (i < blk.n_ot) {
 #pragma unroll
-      for (int j = 0; j < PM_DW_TN; ++j)
+      for (int j = 0; j < NJ; ++j)
         if (j < blk.n_it) {
           const int k = (blk.it0 + j) * 16 + c16;
 #pragma unroll
@@ -128,11 +127,40 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_dw_kernel(const DwArgs A) {
     }
 }
 
-// grad[i] = sum_s part[s][i]  in fixed order
-__global__ void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n, float* __restrict__ grad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int c_lo = split * A.chunks_per_split;
+  const int c_hi = min(A.n_chunks, c_lo + A.chunks_per_split);
+  float* part = A.part + (size_t)split * A.n_params;
+  for (int pass = 0; pass < A.npass; ++pass) {
+    const DwBlock blk = A.blocks[pass * PM_DW_NW + wid];
+    if (blk.layer < 0) continue;
+    if (blk.n_it <= 1) pm_dw_block<1>(A, blk, c_lo, c_hi, part, lane);
+    else if (blk.n_it <= 4) pm_dw_block<4>(A, blk, c_lo, c_hi, part, lane);
+    else pm_dw_block<PM_DW_TN>(A, blk, c_lo, c_hi, part, lane);
+  }
+}
+
+// grad[i] = sum_s part[s][i] in fixed order; 32 parameters x 8 split-slices per workgroup
+__global__ __launch_bounds__(256) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
+                                                    float* __restrict__ grad) {
+  __shared__ float sm[8][33];
+  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + pi;
+  const int per = (nsplit + 7) / 8;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-  grad[i] = s;
+  if (i < n) {
+    const int k_hi = min(nsplit, (sl + 1) * per);
+    for (int k = sl * per; k < k_hi; ++k) s += part[(size_t)k * n + i];
+  }
+  sm[sl][pi] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][pi];
+    grad[i] = t;
+  }
 }
