@@ -336,98 +336,8 @@ struct EpiBwdL {
 };
 
 // ---------------------------------------------------------------------------
-// reward on LDS rows with LDS-resident constants (no private arrays)
+// rewards: not part of the sweep kernels
 // ---------------------------------------------------------------------------
-// phi row scratch: ph[De]; returns r, leaves delta in dl[k]
-__device__ inline float reward_lds(const RewardDev* rw, const float* x, int D, const float* a, int U,
-                                   float* ph, float* dl) {
-  int De = D;
-  if (rw->expand) {
-    const int no = rw->n_other, na = rw->n_angle;
-    for (int i = 0; i < no; ++i) ph[i] = x[rw->other_dims[i]];
-    for (int j = 0; j < na; ++j) {
-      const float th = x[rw->angle_dims[j]];
-      ph[no + j] = sinf(th);
-      ph[no + na + j] = cosf(th);
-    }
-    De = no + 2 * na;
-  } else {
-    for (int i = 0; i < D; ++i) ph[i] = x[i];
-  }
-  const int k = rw->k;
-  for (int i = 0; i < k; ++i) {
-    float s = 0.f;
-    for (int j = 0; j < De; ++j) s = fmaf(ph[j], rw->C[i * De + j], s);
-    dl[i] = s - rw->tt[i];
-  }
-  float cost = 0.f;
-  for (int i = 0; i < k; ++i) {
-    float s = 0.f;
-    for (int j = 0; j < k; ++j) s = fmaf(dl[j], rw->Q[j * k + i], s);
-    cost = fmaf(s, dl[i], cost);
-  }
-  for (int i = 0; i < U; ++i) {
-    float s = 0.f;
-    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->R[j * U + i], s);
-    cost = fmaf(s, a[i], cost);
-  }
-  cost *= rw->w;
-  return rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
-}
-
-// adjoint; ph/dl as left by reward_lds for the same row; gph: scratch [De]; adds into gx[D],
-// writes ga[U] (row-strided LDS)
-__device__ inline void reward_lds_bwd(const RewardDev* rw, const float* x, int D, const float* a,
-                                      int U, float r, float gr, const float* ph, const float* dl,
-                                      float* gph, float* gx, float* ga) {
-  const float gc = (rw->kind == PMBRL_REWARD_EXP ? -gr * r : -gr) * rw->w;
-  const int k = rw->k;
-  const int De = rw->expand ? rw->n_other + 2 * rw->n_angle : D;
-  for (int j = 0; j < De; ++j) gph[j] = 0.f;
-  for (int i = 0; i < k; ++i) {
-    float s = 0.f;
-    for (int j = 0; j < k; ++j) s = fmaf(dl[j], rw->QQ[j * k + i], s);
-    const float gd = gc * s;
-    for (int j = 0; j < De; ++j) gph[j] = fmaf(gd, rw->C[i * De + j], gph[j]);
-  }
-  for (int i = 0; i < U; ++i) {
-    float s = 0.f;
-    for (int j = 0; j < U; ++j) s = fmaf(a[j], rw->RR[j * U + i], s);
-    ga[i] = gc * s;
-  }
-  if (rw->expand) {
-    const int no = rw->n_other, na = rw->n_angle;
-    for (int i = 0; i < no; ++i) gx[rw->other_dims[i]] += gph[i];
-    for (int j = 0; j < na; ++j)   // ph holds sin / cos of the angle already
-      gx[rw->angle_dims[j]] += gph[no + j] * ph[no + na + j] - gph[no + na + j] * ph[no + j];
-  } else {
-    for (int i = 0; i < D; ++i) gx[i] += gph[i];
-  }
-}
-
-// reward + its Jacobian for one row (one lane): r~, d r~/d x~ -> Jx, d r~/d a -> Ja (stashed
-// for the adjoint sweep, which then needs neither the reward constants nor sin/cos)
-struct FastLds;
-__device__ inline void reward_row_eval(const RolloutArgs& A, const RewardDev* rew, float* ph, float* dl,
-                                       float* gph, float* jx, float* ja, const float* x,
-                                       const float* a, int r, int t, int row0, float* rr_out) {
-  const int D = A.D, U = A.U, B = A.B;
-  const float rv = reward_lds(rew, x, D, a, U, ph, dl);
-  bool ok = isfinite(rv);
-  for (int d = 0; d < D; ++d) {
-    ok = ok && isfinite(x[d]);
-    jx[d] = 0.f;
-  }
-  if (!ok) atomicMin(A.status, t);
-  reward_lds_bwd(rew, x, D, a, U, rv, 1.f, ph, dl, gph, jx, ja);
-  const size_t o = (size_t)t * B + row0 + r;
-  for (int d = 0; d < D; ++d) A.Jx[o * D + d] = jx[d];
-  for (int j = 0; j < U; ++j) A.Ja[o * U + j] = ja[j];
-  if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
-  else A.rewards[o] = rv;
-  if (rr_out) *rr_out = rv;
-}
-
 // All rewards of a rollout in one fully parallel pass: thread = one (t, b) row-step.
 // r~ -> rt (if rewards are moment matched afterwards) or rewards; d r~/d x~ -> Jx; d r~/d a -> Ja;
 // non-finite states / rewards are reported through the status word like in the sweep.
@@ -485,10 +395,8 @@ struct FastLds {
   float* base;
   float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
   float *mA, *mB;                // fused matrices (fwd: policy head, dynamics head; bwd: tails)
-  float *ph, *dl, *gph;          // reward scratch [R][PMBRL_MAX_DIM], [R][8], [R][PMBRL_MAX_DIM]
-  float *jx, *ja;                // reward Jacobian rows [R][16] each
+  float *jx;                     // backward: dL/dx~ rows [R][16]
   float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
-  RewardDev* rew;
   double* mm;
 };
 
@@ -505,9 +413,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n += 2 * (size_t)(D + U) + 3 * (size_t)D + 2 * (size_t)U;
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PM_HJ * LD;                        // mA, mB
-  n += (size_t)R * (2 * PMBRL_MAX_DIM + 8);           // ph, gph, dl
-  n += (size_t)R * 32 + (size_t)R * (1 + 2 * D + 3 * U);   // jx, ja, stg
-  n += (sizeof(RewardDev) + 3) / 4;
+  n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U);   // jx, stg
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
   return n;
@@ -544,14 +450,8 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   p = base + n;
   m.mA = p; p += (size_t)PM_HJ * LD;
   m.mB = p; p += (size_t)PM_HJ * LD;
-  m.ph = p; p += (size_t)R * PMBRL_MAX_DIM;
-  m.gph = p; p += (size_t)R * PMBRL_MAX_DIM;
-  m.dl = p; p += (size_t)R * 8;
   m.jx = p; p += (size_t)R * 16;
-  m.ja = p; p += (size_t)R * 16;
   m.stg = p; p += (size_t)R * (1 + 2 * D + 3 * U);
-  m.rew = reinterpret_cast<RewardDev*>(p);
-  p += (sizeof(RewardDev) + 3) / 4;
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
   m.mm = reinterpret_cast<double*>(base + n);
   return m;
@@ -607,11 +507,6 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
   for (int i = tid; i < U; i += PF_NT) {
     L.psc[i] = A.pscale[i];
     L.pbi[i] = A.pbias[i];
-  }
-  {
-    const int* src = reinterpret_cast<const int*>(A.rew);
-    int* dst = reinterpret_cast<int*>(L.rew);
-    for (int i = tid; i < (int)(sizeof(RewardDev) / 4); i += PF_NT) dst[i] = src[i];
   }
 }
 
