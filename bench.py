@@ -175,6 +175,19 @@ def main():
         kflops = dict(fwd=2.0 * H * B * (Pm + Fm), bwd=2.0 * H * B * (Pm + Fm), dw=2.0 * H * B * Pm)
         dom = max(kflops, key=lambda k: timings.get(k, 0.0))
         achieved = kflops[dom] / (timings[dom] * 1e-3) / 1e12
+        kname = {'fwd': 'pm_rollout_fwd', 'bwd': 'pm_rollout_bwd', 'dw': 'pm_dw_kernel'}[dom]
+        if eng.info.get('fast') and dom != 'dw':
+            kname += '_fast'
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes);
+        # only valid for the configuration they were collected on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if a.config == 'cartpole_nomm' and world == 1 and kname in pmc['kernels']:
+                traffic = pmc['kernels'][kname]['hbm_bytes_per_launch']
+        except Exception:
+            traffic = None
         out = dict(
             metric='particle_rollouts_per_sec', value=Bg * a.steps / dt, unit='rollouts/s',
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
@@ -191,9 +204,9 @@ def main():
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
-            roofline=dict(bound='mfma', kernel='pm_rollout_' + dom if dom != 'dw' else 'pm_dw_kernel',
+            roofline=dict(bound='mfma', kernel=kname,
                           achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                          frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                          frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                           flops_per_launch=kflops[dom], avg_launch_ms=timings[dom]))
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(d)
