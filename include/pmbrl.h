@@ -206,6 +206,7 @@ enum {
   PMBRL_TIMER_BWD = 2,       /* pm_rollout_bwd (+ external mm kernels) */
   PMBRL_TIMER_DW = 3,        /* pm_dw_kernel */
   PMBRL_TIMER_DW_REDUCE = 4, /* pm_dw_reduce */
+  PMBRL_TIMER_REWARD = 5,    /* pm_reward_all_kernel (+ reward moment matching) */
   PMBRL_TIMER_COUNT = 8
 };
 int pmbrl_plan_set_timing(pmbrl_plan* plan, int on);

@@ -19,7 +19,7 @@ FLAG_FORCE_GENERIC = 16
 REWARD_EXP, REWARD_NEG = 0, 1
 INFO_COUNT = 16
 TIMER_COUNT = 8
-TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce']
+TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce', 'reward']
 
 
 class MLP(C.Structure):

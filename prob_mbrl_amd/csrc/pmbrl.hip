@@ -731,7 +731,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = padk(F.nt[l + 1]); b.n++; }
     for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = padk(P.nt[l + 1]); b.n++; }
     const size_t R = 16 * (size_t)p->RT;
-    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + R * PM_HJ;   // up to L.hp
+    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + (size_t)PF_NW * p->RT * 256;   // up to and incl. L.hp
     for (int l = 0; l < P.nl; ++l) { A.fo.pbias[l] = (int)o; o += (size_t)P.nt[l + 1] * 16; }
     for (int l = 0; l < F.nl; ++l) { A.fo.dbias[l] = (int)o; o += (size_t)F.nt[l + 1] * 16; }
     for (int l = 0; l < P.nl - 1; ++l) { A.fo.pmask[l] = (int)o; o += (R * P.nt[l + 1] + 1) / 2; }
@@ -819,8 +819,9 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
     hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }
-  ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+  {
+  ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
   if (p->mm_mode != 2) {
     launch_fwd_rt(p, A, s);
   } else {
@@ -833,8 +834,10 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
       hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t);
     }
   }
+  }
   if (p->fast) {
     // rewards (+ Jacobians) of all row-steps in one parallel pass, then their moment matching
+    ScopedTimer tm(p, PMBRL_TIMER_REWARD, s);
     A.t0 = 0; A.t1 = p->cfg.H;
     const long long n = (long long)p->cfg.H * p->cfg.B;
     hipLaunchKernelGGL(pm_reward_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);

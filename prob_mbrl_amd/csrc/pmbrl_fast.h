@@ -233,40 +233,56 @@ __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const fl
   }
 }
 
-// Narrow head / tail as VALU dot products on LDS operands (no GEMM, no weight traffic):
-//   out[r][j] = sum_k act[r][k] * M[j][k]      r < R, j < nj, k < K16
-// R*nj dot products of length K16 spread over the workgroup, `tpd` threads per product
-// (float4 strided slices + xor-shuffle reduce).  Caller syncs before reading `out`.
-template <int R>
-__device__ __forceinline__ void narrow_dot(const float* act, int ld, const float* M, int ldm, int nj,
-                                           int K16, float* out, int tid) {
-  const int nd = R * nj;
-  int tpd = 1;
-  while (tpd < 16 && nd * tpd * 2 <= PF_NT) tpd *= 2;
-  const int slice = tid & (tpd - 1);
-  const int dpr = PF_NT / tpd;                 // products per round
-  const int nk4 = K16 >> 2;
-  for (int base = 0; base < nd; base += dpr) {
-    const int dot = base + tid / tpd;
-    float s = 0.f;
-    int r = 0, j = 0;
-    if (dot < nd) {
-      r = dot / nj;
-      j = dot - r * nj;
-      const float* a = act + r * ld;
-      const float* m = M + j * ldm;
-      for (int k4 = slice; k4 < nk4; k4 += tpd) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(a + 4 * k4);
-        const f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * k4);
-        s = fmaf(av[0], mv[0], s);
-        s = fmaf(av[1], mv[1], s);
-        s = fmaf(av[2], mv[2], s);
-        s = fmaf(av[3], mv[3], s);
-      }
-    }
-    for (int o = tpd >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (dot < nd && slice == 0) out[r * PM_HJ + j] = s;
+// Narrow head / tail (<= 16 outputs = ONE output tile, K = hidden width): the K range is
+// split over the 8 waves, each wave keeps its <= 2 k-blocks of the (single-tile) weight
+// fragments in registers for the whole launch, issues 4-8 MFMAs per step and leaves its
+// partial tile in LDS; the consumer phase adds the 8 partials in fixed order.
+//   partial layout: hpart[(wave*RT + rt)*256 + lane*4 + c]  with the MFMA D mapping
+//   out j = 4*(lane>>4) + c, row = rt*16 + (lane&15)
+#define PM_HKB 2
+struct HeadW {
+  f32x4 w[PM_HKB];
+};
+__device__ __forceinline__ void head_load(HeadW& h, const float* wf, int n_kb, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < PM_HKB; ++i) {
+    const int kb = wid * PM_HKB + i;
+    h.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kb < n_kb) h.w[i] = ldg4(wf + (size_t)kb * 256 + lane * 4);
   }
+}
+template <int RT>
+__device__ __forceinline__ void head_partial(const HeadW& h, int n_kb, const float* lds_in, int ld,
+                                             float* hpart, int wid, int lane) {
+  const float* bp = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
+  f32x4 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < PM_HKB; ++i) {
+    const int kb = wid * PM_HKB + i;
+    const int kbs = kb < n_kb ? kb : 0;   // absent blocks: zero weights, in-range dummy read
+    f32x4 b[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      b[rt] = *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + kbs * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma4(h.w[i][j], b[rt][j], acc[rt]);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+    *reinterpret_cast<f32x4*>(hpart + ((size_t)(wid * RT + rt) * 64 + lane) * 4) = acc[rt];
+}
+// value of output j for local row r: sum of the 8 wave partials (fixed order)
+template <int RT>
+__device__ __forceinline__ float head_value(const float* hpart, int r, int j) {
+  const int rt = r >> 4, ln = ((j >> 2) << 4) + (r & 15), c = j & 3;
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < PF_NW; ++w) s += hpart[((size_t)(w * RT + rt) * 64 + ln) * 4 + c];
+  return s;
 }
 
 // ---------------------------------------------------------------------------
@@ -391,10 +407,9 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
 // ---------------------------------------------------------------------------
 struct FastLds {
   float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr;
-  float *hp;                     // narrow head / tail results [R][PM_HJ]
+  float *hp;                     // head / tail partial tiles [PF_NW][RT][64][4]
   float* base;
   float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
-  float *mA, *mB;                // fused matrices (fwd: policy head, dynamics head; bwd: tails)
   float *jx;                     // backward: dL/dx~ rows [R][16]
   float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
   double* mm;
@@ -404,7 +419,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
                                                      const int* pnt, int pnl, const int* dnt,
                                                      int dnl, int mm_d) {
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
-  n += (size_t)R * PM_HJ;
+  n += (size_t)PF_NW * RT * 256;
   for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
   for (int l = 0; l < dnl; ++l) n += (size_t)dnt[l + 1] * 16;
   for (int l = 0; l < pnl - 1; ++l) n += ((size_t)R * pnt[l + 1] + 1) / 2;
@@ -412,7 +427,6 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n += (size_t)R * U + (size_t)R * D;                 // zp, zd
   n += 2 * (size_t)(D + U) + 3 * (size_t)D + 2 * (size_t)U;
   n = (n + 3) & ~(size_t)3;
-  n += 2 * (size_t)PM_HJ * LD;                        // mA, mB
   n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U);   // jx, stg
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
@@ -431,7 +445,7 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   m.gad = p; p += (size_t)R * 16;
   m.rr = p; p += R;
   m.gr = p; p += R;
-  m.hp = p; p += (size_t)R * PM_HJ;
+  m.hp = p; p += (size_t)PF_NW * RT * 256;
   m.base = base;
   for (int l = 0; l < P.nl; ++l) p += (size_t)P.nt[l + 1] * 16;
   for (int l = 0; l < F.nl; ++l) p += (size_t)F.nt[l + 1] * 16;
@@ -448,8 +462,6 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   m.pbi = p; p += U;
   size_t n = ((size_t)(p - base) + 3) & ~(size_t)3;
   p = base + n;
-  m.mA = p; p += (size_t)PM_HJ * LD;
-  m.mB = p; p += (size_t)PM_HJ * LD;
   m.jx = p; p += (size_t)R * 16;
   m.stg = p; p += (size_t)R * (1 + 2 * D + 3 * U);
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
@@ -531,21 +543,6 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
-  // fused head matrices: M[j][k] = W_head[j][k], zero padded to LD columns
-  {
-    const int Kp = P.dim[P.nl - 1], Op = P.dim[P.nl];
-    const float* Wp = A.pol_head_w;
-    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
-      const int j = i / LD, k = i - j * LD;
-      L.mA[i] = (j < Op && k < Kp) ? Wp[(size_t)j * Kp + k] : 0.f;
-    }
-    const int Kd = F.dim[F.nl - 1], Od = F.dim[F.nl];
-    const float* Wd = A.dyn_head_w;
-    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
-      const int j = i / LD, k = i - j * LD;
-      L.mB[i] = (j < Od && k < Kd) ? Wd[(size_t)j * Kd + k] : 0.f;
-    }
-  }
   {
     const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
     for (int i = tid; i < R * D; i += PF_NT) {
@@ -555,7 +552,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       if (A.t0 == 0 && r < nvalid) A.states[(size_t)(row0 + r) * D + d] = v;
     }
   }
-  // register-resident first layers
+  // register-resident first layers and head slices
+  HeadW hwp, hwd;
+  head_load(hwp, P.wf[P.nl - 1], P.nt[P.nl - 1], wid, lane);
+  head_load(hwd, F.wf[F.nl - 1], F.nt[F.nl - 1], wid, lane);
   Res0<RT> w0p, w0d;
   res0_load<RT>(w0p, P.wf[0], P.nt[1], wid, lane);
   res0_load<RT>(w0d, F.wf[0], F.nt[1], wid, lane);
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     frag_load<CKB>(fa, sd, q, wid, lane);
     cur_advance<CKB>(sd, q, wid);
   }
+  const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   __syncthreads();
 
   for (int t = A.t0; t < A.t1; ++t) {
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(2 + l);
     }
-    narrow_dot<R>(X, LD, L.mA, LD, P.dim[P.nl], P.nt[P.nl - 1] * 16, L.hp, tid);
+    head_partial<RT>(hwp, P.nt[P.nl - 1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(10);
     // ---- squash + dynamics input
@@ -622,19 +623,21 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           v = (xa[r * D + k] - L.mx[k]) * L.iSx[k];
         } else if (k < D + U) {
           const int j = k - D;
-          const float mu = hb[j] + L.hp[r * PM_HJ + j];
-          const float ls = hb[U + j] + L.hp[r * PM_HJ + U + j];
+          const float mu = hb[j] + head_value<RT>(L.hp, r, j);
+          const float ls = hb[U + j] + head_value<RT>(L.hp, r, U + j);
           float z = L.zp[r * U + j];
           if (A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
-          const float lc = -softplusf(-ls + A.mls_pol) + A.mls_pol;
-          const float e = expf(lc);
+          // lc = c - softplus(c - ls)  =>  e = exp(lc) = exp(c) sigmoid(ls - c),
+          // d lc / d ls = sigmoid(c - ls) = 1 - sigmoid(ls - c): one exp instead of four
+          const float sg = 1.f / (1.f + expf(A.mls_pol - ls));
+          const float e = max_std_pol * sg;
           const float u = mu + z * e;
           const float a = L.psc[j] * tanhf(u) + L.pbi[j];
           L.av[r * U + j] = a;
           if (r < nvalid) {
             const size_t o = ((size_t)t * B + row0 + r) * U + j;
             A.actions[o] = a;
-            A.Tp[o] = z * e * sigmoidf(-ls + A.mls_pol);
+            A.Tp[o] = z * e * (1.f - sg);
           }
           v = (a - L.mx[k]) * L.iSx[k];
         }
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(12 + l);
     }
-    narrow_dot<R>(X, LD, L.mB, LD, F.dim[F.nl], F.nt[F.nl - 1] * 16, L.hp, tid);
+    head_partial<RT>(hwd, F.nt[F.nl - 1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(20);
     // ---- sample next state
@@ -670,17 +673,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       const float* hb = DBIAS(F.nl - 1);
       for (int i = tid; i < R * D; i += PF_NT) {
         const int r = i / D, d = i - r * D;
-        const float mu = hb[d] + L.hp[r * PM_HJ + d];
-        const float ls = hb[D + d] + L.hp[r * PM_HJ + D + d];
+        const float mu = hb[d] + head_value<RT>(L.hp, r, d);
+        const float ls = hb[D + d] + head_value<RT>(L.hp, r, D + d);
         float z = L.zd[i];
         if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
-        const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + L.lSy[d];
-        const float e = expf(lc);
+        const float sg = 1.f / (1.f + expf(A.mls_dyn - ls));
+        const float e = max_std_dyn * L.Sy[d] * sg;
         const float xn = xa[i] + (mu * L.Sy[d] + L.my[d] + z * e);
         xb[i] = xn;
         if (r < nvalid) {
           const size_t o = ((size_t)t * B + row0 + r) * D + d;
-          A.Td[o] = z * e * sigmoidf(-ls + A.mls_dyn);
+          A.Td[o] = z * e * (1.f - sg);
           if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
           else A.states[o + (size_t)B * D] = xn;
         }
@@ -737,19 +740,6 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
-  // fused tails: mA[j][k] = V0[k][j] (dynamics first layer, j < D+U), mB[j][k] = W0[k][j] (policy)
-  {
-    const int Kd = F.dim[1], Od = F.dim[0];
-    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
-      const int j = i / LD, k = i - j * LD;
-      L.mA[i] = (j < Od && k < Kd) ? A.dyn_first_w[(size_t)k * Od + j] : 0.f;
-    }
-    const int Kp = P.dim[1], Op = P.dim[0];
-    for (int i = tid; i < PM_HJ * LD; i += PF_NT) {
-      const int j = i / LD, k = i - j * LD;
-      L.mB[i] = (j < Op && k < Kp) ? A.pol_first_w[(size_t)k * Op + j] : 0.f;
-    }
-  }
   for (int i = tid; i < R * D; i += PF_NT) {
     const int r = i / D, d = i - r * D;
     float v = 0.f;
@@ -759,7 +749,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     }
     gx[i] = v;
   }
-  // resident head-adjoint weights (K = head width <= 16: one k-block)
+  // resident tail slices (grad wrt the nets' inputs) and head-adjoint weights
+  HeadW twd, twp;
+  head_load(twd, F.wb[0], F.nt[1], wid, lane);
+  head_load(twp, P.wb[0], P.nt[1], wid, lane);
   Res0<RT> whd, whp;
   res0_load<RT>(whd, F.wb[F.nl - 1], F.nt[F.nl - 1], wid, lane);
   res0_load<RT>(whp, P.wb[P.nl - 1], P.nt[P.nl - 1], wid, lane);
@@ -869,7 +862,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(4 + l);
     }
-    narrow_dot<R>(X, LD, L.mA, LD, F.dim[0], F.nt[1] * 16, L.hp, tid);
+    head_partial<RT>(twd, F.nt[1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(12);
     // ---- phase B: tail result; state part -> gxt, action part -> policy head adjoint
@@ -878,7 +871,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float tail = 0.f;
-        if (k < D + U) tail = L.hp[r * PM_HJ + k] * L.iSx[k];
+        if (k < D + U) tail = head_value<RT>(L.hp, r, k) * L.iSx[k];
         if (k < D) gxn[r * D + k] += tail;
         if (k >= D && k < D + U) {
           const int j = k - D;
@@ -936,12 +929,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       { float* tmp = X; X = Y; Y = tmp; }
       PM_MARK(14 + l);
     }
-    narrow_dot<R>(X, LD, L.mB, LD, P.dim[0], P.nt[1] * 16, L.hp, tid);
+    head_partial<RT>(twp, P.nt[1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(22);
     for (int i = tid; i < R * D; i += PF_NT) {
       const int r = i / D, d = i - r * D;
-      float v = gxn[i] + L.hp[r * PM_HJ + d];
+      float v = gxn[i] + head_value<RT>(L.hp, r, d);
       if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
       gx[i] = v;
     }
