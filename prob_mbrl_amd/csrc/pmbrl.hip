@@ -672,6 +672,7 @@ static void fill_net(const NetPlan& n, char* ws, const uint16_t* const* masks, N
   }
   for (int l = 0; l < n.nl; ++l) {
     d.keep[l] = n.keep[l];
+    d.inv_keep[l] = 1.f / n.keep[l];
     d.wf[l] = reinterpret_cast<const float*>(ws + n.wf[l]);
     d.wb[l] = reinterpret_cast<const float*>(ws + n.wb[l]);
     d.bias[l] = reinterpret_cast<const float*>(ws + n.bias[l]);

@@ -34,6 +34,7 @@ struct NetDev {
   int dim[PM_MAXL + 1];           // true widths
   int nt[PM_MAXL + 1];            // ceil(width / 16)
   float keep[PM_MAXL];            // divide masked activations by this (1 = no-op)
+  float inv_keep[PM_MAXL];        // 1 / keep (fast kernels multiply)
   const float* wf[PM_MAXL];       // forward fragments  [nt[l+1]][nt[l]][64][4]
   const float* wb[PM_MAXL];       // transposed fragments [nt[l]][nt[l+1]][64][4]
   const float* bias[PM_MAXL];     // zero-padded to nt[l+1]*16

@@ -58,29 +58,54 @@ struct FragS {
 // moves to another layer (a scalar-memory round trip per chunk was costing more than the
 // MFMAs of the chunk).
 struct Cursor {
-  int li, ot, c, live;
+  int li, ot, c, live, all_live;
   int n_ot, n_kb;            // of layer li (n_kb padded to the chunk size)
   const float* wp;           // next chunk to load (lane offset not included)
+  // descriptor of the layer the stream enters after li, fetched (scalar loads) when li was
+  // entered: by the time it is needed the loads have long landed -- a layer switch costs no
+  // scalar-memory round trip on the critical path
+  int nli, nn_ot, nn_kb;
+  const float* nwf;
 };
 
-__device__ __forceinline__ void cur_enter(const StreamDesc& sd, Cursor& q, int wid) {
-  // settle on the next layer (cyclically, starting at q.li) in which this wave owns a tile
-  for (int k = 0; k < 2 * PM_MAXL + 1; ++k) {
-    if (q.li >= sd.n) q.li = 0;
-    if (wid < sd.n_ot[q.li]) break;
-    q.li++;
+__device__ __forceinline__ void cur_fetch_next(const StreamDesc& sd, Cursor& q, int wid) {
+  int l = q.li;
+  if (q.all_live) {
+    l = (l + 1 >= sd.n) ? 0 : l + 1;
+  } else {
+    // next layer (cyclically) in which this wave owns a tile
+    for (int k = 0; k < 2 * PM_MAXL; ++k) {
+      l = (l + 1 >= sd.n) ? 0 : l + 1;
+      if (wid < sd.n_ot[l]) break;
+    }
   }
-  q.n_ot = sd.n_ot[q.li];
-  q.n_kb = sd.n_kb[q.li];
+  q.nli = l;
+  q.nn_ot = sd.n_ot[l];
+  q.nn_kb = sd.n_kb[l];
+  q.nwf = sd.wf[l];
+}
+__device__ __forceinline__ void cur_switch(const StreamDesc& sd, Cursor& q, int wid) {
+  q.li = q.nli;
+  q.n_ot = q.nn_ot;
+  q.n_kb = q.nn_kb;
   q.ot = wid;
   q.c = 0;
-  q.wp = sd.wf[q.li] + (size_t)wid * q.n_kb * 256;
+  q.wp = q.nwf + (size_t)wid * q.n_kb * 256;
+  cur_fetch_next(sd, q, wid);
 }
 __device__ __forceinline__ void cur_init(const StreamDesc& sd, Cursor& q, int wid) {
-  q.li = 0; q.ot = 0; q.c = 0; q.live = 0; q.n_ot = 0; q.n_kb = 0; q.wp = nullptr;
-  for (int l = 0; l < sd.n; ++l)
-    if (wid < sd.n_ot[l]) q.live = 1;
-  if (q.live) cur_enter(sd, q, wid);
+  q.li = 0; q.ot = 0; q.c = 0; q.live = 0; q.all_live = 1; q.n_ot = 0; q.n_kb = 0; q.wp = nullptr;
+  q.nli = 0; q.nn_ot = 0; q.nn_kb = 0; q.nwf = nullptr;
+  int first = -1;
+  for (int l = sd.n - 1; l >= 0; --l) {
+    if (wid < sd.n_ot[l]) { q.live = 1; first = l; }
+    else q.all_live = 0;
+  }
+  if (q.live) {
+    // enter `first` through the same path as every later switch
+    q.nli = first; q.nn_ot = sd.n_ot[first]; q.nn_kb = sd.n_kb[first]; q.nwf = sd.wf[first];
+    cur_switch(sd, q, wid);
+  }
 }
 template <int CKB>
 __device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int wid) {
@@ -91,10 +116,7 @@ __device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int
     q.c = 0;
     q.ot += PF_NW;
     q.wp += (size_t)(PF_NW - 1) * q.n_kb * 256;
-    if (q.ot >= q.n_ot) {
-      q.li++;
-      cur_enter(sd, q, wid);
-    }
+    if (q.ot >= q.n_ot) cur_switch(sd, q, wid);
   }
 }
 
@@ -112,34 +134,42 @@ __device__ __forceinline__ void frag_load(FragS<CKB>& f, const StreamDesc& sd, c
   for (int cc = 0; cc < CKB; ++cc) f.a[cc] = ldg4(wp + (size_t)cc * 256);
 }
 
+// B operands (LDS activations) of one k-block pair
+template <int RT>
+struct BPair {
+  f32x4 v[2][RT];
+};
 template <int RT, int CKB>
-__device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, const float* lds_in, int ld,
-                                             int lane, f32x4 (&acc)[2][RT]) {
-  // Explicit one-pair-ahead software pipeline of the LDS (B operand) reads: while the 8*RT
-  // MFMAs of k-block pair p issue, the reads of pair p+1 are already in flight.  The
-  // sched_barriers pin that order (left alone, the scheduler sinks each read to just before
-  // its first use and every pair pays the LDS latency).
-  const float* bp = lds_in + (lane & 15) * ld + 4 * (lane >> 4) + c * CKB * 16;
-  constexpr int NP = (CKB + 1) / 2;
-  f32x4 b[2][2][RT];   // [stage][k-block within pair][row tile]
+__device__ __forceinline__ void bpair_load(BPair<RT>& b, const float* bp, int ld, int pair) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h) {
+    const int cc = 2 * pair + h;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
-      b[0][h][rt] = *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + (h < CKB ? h : 0) * 16);
+      b.v[h][rt] = *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + (cc < CKB ? cc : 0) * 16);
+  }
+}
+
+template <int RT, int CKB>
+__device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, int c_next, const float* lds_in,
+                                             int ld, int lane, f32x4 (&acc)[2][RT], BPair<RT>& b0) {
+  // Explicit one-pair-ahead software pipeline of the LDS (B operand) reads: while the 8*RT
+  // MFMAs of k-block pair p issue, the reads of pair p+1 are already in flight -- ACROSS chunk
+  // and tile boundaries too: b0 enters holding pair 0 of this chunk and leaves holding pair 0
+  // of chunk c_next, so the LDS latency is exposed once per layer, not once per chunk.  The
+  // sched_barriers pin that order (left alone, the scheduler sinks each read to just before
+  // its first use and every pair pays the LDS latency).
+  const float* base = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
+  const float* bp = base + c * CKB * 16;
+  const float* bpn = base + c_next * CKB * 16;
+  constexpr int NP = (CKB + 1) / 2;
+  BPair<RT> b[2];
+  b[0] = b0;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int cur = p & 1, nxt = cur ^ 1;
-    if (p + 1 < NP) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cc = 2 * (p + 1) + h;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          b[nxt][h][rt] =
-              *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + (cc < CKB ? cc : 0) * 16);
-      }
-    }
+    if (p + 1 < NP) bpair_load<RT, CKB>(b[nxt], bp, ld, p + 1);
+    else bpair_load<RT, CKB>(b[nxt], bpn, ld, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -149,11 +179,12 @@ __device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, const f
         if (cc < CKB) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            acc[h][rt] = mfma4(f.a[cc < CKB ? cc : 0][j], b[cur][h][rt][j], acc[h][rt]);
+            acc[h][rt] = mfma4(f.a[cc < CKB ? cc : 0][j], b[cur].v[h][rt][j], acc[h][rt]);
         }
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+  b0 = b[NP & 1];
 }
 
 // One streamed layer.  The plan pads every streamed layer to an EVEN number of chunks, so
@@ -168,6 +199,8 @@ __device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Curso
   const int n_ot = sd.n_ot[li];
   const int nch2 = sd.n_kb[li] / (2 * CKB);
   int pslot = 24;
+  BPair<RT> b0;
+  if (wid < n_ot) bpair_load<RT, CKB>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
   for (int ot = wid; ot < n_ot; ot += PF_NW) {
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
     f32x4 acc[2][RT];
@@ -178,10 +211,10 @@ __device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Curso
     for (int c2 = 0; c2 < nch2; ++c2) {
       frag_load<CKB>(fb, sd, q, wid, lane);
       cur_advance<CKB>(sd, q, wid);
-      frag_compute<RT, CKB>(fa, 2 * c2, lds_in, ld, lane, acc);
+      frag_compute<RT, CKB>(fa, 2 * c2, 2 * c2 + 1, lds_in, ld, lane, acc, b0);
       frag_load<CKB>(fa, sd, q, wid, lane);
       cur_advance<CKB>(sd, q, wid);
-      frag_compute<RT, CKB>(fb, 2 * c2 + 1, lds_in, ld, lane, acc);
+      frag_compute<RT, CKB>(fb, 2 * c2 + 1, (c2 + 1 < nch2) ? 2 * c2 + 2 : 0, lds_in, ld, lane, acc, b0);
     }
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
@@ -288,21 +321,26 @@ __device__ __forceinline__ float head_value(const float* hpart, int r, int j) {
 // ---------------------------------------------------------------------------
 // epilogues reading bias / masks from LDS
 // ---------------------------------------------------------------------------
+// Both epilogues run once per output tile on the critical path of a phase (the partner wave
+// of the SIMD is in ITS epilogue at the same time, so the MFMA pipe idles): they are kept to
+// a few dozen VALU instructions -- 32-bit offsets from uniform bases (the stash row block is
+// Rw = 16*RT, a compile-time constant), a multiply by the precomputed 1/keep.
 template <int RT>
 struct EpiFwdL {
   const float* bias;        // LDS, padded
   const uint16_t* mask;     // LDS [R][nt]
   uint8_t* abits;           // HBM [B][nt][4] slice of step t: one nibble-byte per lane group
-  float keep;
+  float inv_keep;
   float* lds_out;
   float* stash;             // HBM block or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
-    const int g = lane >> 4;
-    const int lrow = rt * 16 + (lane & 15);
-    const int f0 = ot * 16 + 4 * g;
+    constexpr unsigned RW = 16 * RT;
+    const unsigned g = (unsigned)lane >> 4;
+    const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
+    const unsigned f0 = ot * 16 + 4 * g;
     const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
-    const unsigned mw = mask[lrow * nt + ot];
+    const unsigned mw = mask[lrow * (unsigned)nt + ot];
     const unsigned nib = (mw >> (4 * g)) & 0xFu;
     f32x4 h;
     unsigned act = 0;
@@ -310,42 +348,52 @@ struct EpiFwdL {
     for (int r = 0; r < 4; ++r) {
       const float v = acc[r] + b[r];
       const bool a = ((nib >> r) & 1u) && (v > 0.f);
-      h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
+      h[r] = a ? v * inv_keep : 0.f;
       act |= (a ? 1u : 0u) << r;
     }
-    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
 #ifndef PM_EXP_NOSTASH
     if (stash) {
+      float* sp = stash + (unsigned)ot * (16u * RW);          // uniform
+      const unsigned lo = 4 * g * RW + lrow;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+      for (int r = 0; r < 4; ++r) sp[lo + r * RW] = h[r];
     }
 #endif
-    if (lrow < nvalid) abits[((size_t)(row0 + lrow) * nt + ot) * 4 + g] = (uint8_t)act;
+    if ((int)lrow < nvalid) {
+      uint8_t* ap = abits + (unsigned)ot * 4u;                // uniform
+      ap[((unsigned)row0 + lrow) * (unsigned)nt * 4u + g] = (uint8_t)act;
+    }
   }
 };
 
 template <int RT>
 struct EpiBwdL {
   const uint8_t* abits;     // HBM [B][nt][4] slice of step t
-  float keep;
+  float inv_keep;
   float* lds_out;
   float* stash;
   int ld, Rw, row0, nvalid, nt, lane;
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
-    const int g = lane >> 4;
-    const int lrow = rt * 16 + (lane & 15);
-    const int f0 = ot * 16 + 4 * g;
+    constexpr unsigned RW = 16 * RT;
+    const unsigned g = (unsigned)lane >> 4;
+    const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
+    const unsigned f0 = ot * 16 + 4 * g;
     unsigned nib = 0;
-    if (lrow < nvalid) nib = abits[((size_t)(row0 + lrow) * nt + ot) * 4 + g];
+    if ((int)lrow < nvalid) {
+      const uint8_t* ap = abits + (unsigned)ot * 4u;          // uniform
+      nib = ap[((unsigned)row0 + lrow) * (unsigned)nt * 4u + g];
+    }
     f32x4 h;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
-    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    for (int r = 0; r < 4; ++r) h[r] = ((nib >> r) & 1u) ? acc[r] * inv_keep : 0.f;
+    *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
 #ifndef PM_EXP_NOSTASH
     if (stash) {
+      float* sp = stash + (unsigned)ot * (16u * RW);          // uniform
+      const unsigned lo = 4 * g * RW + lrow;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+      for (int r = 0; r < 4; ++r) sp[lo + r * RW] = h[r];
     }
 #endif
   }
@@ -570,14 +618,18 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     cur_advance<CKB>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
+  const bool mm_in = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
   __syncthreads();
 
   for (int t = A.t0; t < A.t1; ++t) {
     const size_t blk = (size_t)t * A.nwg + wg;
+    int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
-    {
+    if (t == A.t0 || mm_in) {
+      // dynamics-state rows -> policy input tile (+ dW stash); later steps of the plain path
+      // get this written by the previous step's sampling phase
       float* st = A.actT[0] + blk * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int k = i / R, r = i - k * R;
@@ -585,29 +637,29 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         X[r * LD + k] = v;
         st[(size_t)k * A.Rw + r] = v;
       }
+      __syncthreads();
     }
-    __syncthreads();
     PM_MARK(1);
     // ---- policy: first layer (resident), hidden layers (streamed), head as LDS dot products
     {
       const int nt = P.nt[1];
-      EpiFwdL<RT> e{PBIAS(0), PMASK(0), reinterpret_cast<uint8_t*>(P.abits[0]) + (size_t)t * B * nt * 4, P.keep[0], Y,
+      EpiFwdL<RT> e{PBIAS(0), PMASK(0), reinterpret_cast<uint8_t*>(P.abits[0]) + (size_t)t * B * nt * 4, P.inv_keep[0], Y,
                     A.actT[1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
                     row0, nvalid, nt, lane};
       res0_layer<RT>(w0p, nt, X, LD, wid, lane, e);
     }
     __syncthreads();
-    { float* tmp = X; X = Y; Y = tmp; }
+    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
     PM_MARK(2);
     for (int l = 1; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
-      EpiFwdL<RT> e{PBIAS(l), PMASK(l), reinterpret_cast<uint8_t*>(P.abits[l]) + (size_t)t * B * nt * 4, P.keep[l], Y,
+      EpiFwdL<RT> e{PBIAS(l), PMASK(l), reinterpret_cast<uint8_t*>(P.abits[l]) + (size_t)t * B * nt * 4, P.inv_keep[l], Y,
                     A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
                     row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, e,
                             (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
       __syncthreads();
-      { float* tmp = X; X = Y; Y = tmp; }
+      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
       PM_MARK(2 + l);
     }
     head_partial<RT>(hwp, P.nt[P.nl - 1], X, LD, L.hp, wid, lane);
@@ -626,6 +678,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           const float mu = hb[j] + head_value<RT>(L.hp, r, j);
           const float ls = hb[U + j] + head_value<RT>(L.hp, r, U + j);
           float z = L.zp[r * U + j];
+          asm volatile("" : "+v"(z));   // keep the LDS load a load (no select of LDS / HBM addresses -> FLAT)
           if (A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
           // lc = c - softplus(c - ls)  =>  e = exp(lc) = exp(c) sigmoid(ls - c),
           // d lc / d ls = sigmoid(c - ls) = 1 - sigmoid(ls - c): one exp instead of four
@@ -649,53 +702,64 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     // ---- dynamics
     {
       const int nt = F.nt[1];
-      EpiFwdL<RT> e{DBIAS(0), DMASK(0), reinterpret_cast<uint8_t*>(F.abits[0]) + (size_t)t * B * nt * 4, F.keep[0], Y, nullptr,
+      EpiFwdL<RT> e{DBIAS(0), DMASK(0), reinterpret_cast<uint8_t*>(F.abits[0]) + (size_t)t * B * nt * 4, F.inv_keep[0], Y, nullptr,
                     LD, A.Rw, row0, nvalid, nt, lane};
       res0_layer<RT>(w0d, nt, X, LD, wid, lane, e);
     }
     __syncthreads();
-    { float* tmp = X; X = Y; Y = tmp; }
+    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
     PM_MARK(12);
     for (int l = 1; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
-      EpiFwdL<RT> e{DBIAS(l), DMASK(l), reinterpret_cast<uint8_t*>(F.abits[l]) + (size_t)t * B * nt * 4, F.keep[l], Y, nullptr,
+      EpiFwdL<RT> e{DBIAS(l), DMASK(l), reinterpret_cast<uint8_t*>(F.abits[l]) + (size_t)t * B * nt * 4, F.inv_keep[l], Y, nullptr,
                     LD, A.Rw, row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
-      { float* tmp = X; X = Y; Y = tmp; }
+      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
       PM_MARK(12 + l);
     }
     head_partial<RT>(hwd, F.nt[F.nl - 1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(20);
-    // ---- sample next state
+    // ---- sample next state; on the plain path also the next step's policy input tile
     {
       const float* hb = DBIAS(F.nl - 1);
-      for (int i = tid; i < R * D; i += PF_NT) {
-        const int r = i / D, d = i - r * D;
-        const float mu = hb[d] + head_value<RT>(L.hp, r, d);
-        const float ls = hb[D + d] + head_value<RT>(L.hp, r, D + d);
-        float z = L.zd[i];
-        if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
-        const float sg = 1.f / (1.f + expf(A.mls_dyn - ls));
-        const float e = max_std_dyn * L.Sy[d] * sg;
-        const float xn = xa[i] + (mu * L.Sy[d] + L.my[d] + z * e);
-        xb[i] = xn;
-        if (r < nvalid) {
-          const size_t o = ((size_t)t * B + row0 + r) * D + d;
-          A.Td[o] = z * e * (1.f - sg);
-          if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
-          else A.states[o + (size_t)B * D] = xn;
+      const bool feed = !mm_in && (t + 1 < A.t1);
+      float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * A.Rw;
+      for (int i = tid; i < R * 16; i += PF_NT) {
+        const int r = i >> 4, d = i & 15;
+        float xn = 0.f;
+        if (d < D) {
+          const int o_l = r * D + d;
+          const float mu = hb[d] + head_value<RT>(L.hp, r, d);
+          const float ls = hb[D + d] + head_value<RT>(L.hp, r, D + d);
+          float z = L.zd[o_l];
+          asm volatile("" : "+v"(z));
+          if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
+          const float sg = 1.f / (1.f + expf(A.mls_dyn - ls));
+          const float e = max_std_dyn * L.Sy[d] * sg;
+          xn = xa[o_l] + (mu * L.Sy[d] + L.my[d] + z * e);
+          xb[o_l] = xn;
+          if (r < nvalid) {
+            const size_t o = ((size_t)t * B + row0 + r) * D + d;
+            A.Td[o] = z * e * (1.f - sg);
+            if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
+            else A.states[o + (size_t)B * D] = xn;
+          }
+        }
+        if (feed) {
+          L.bufA[r * LD + d] = xn;                 // free: the heads were read before the barrier
+          stn[(size_t)d * A.Rw + r] = xn;
         }
       }
     }
-    __syncthreads();
     PM_MARK(21);
     // The reward is NOT evaluated here: r~[t,b] depends only on the stored (x~, a), never feeds
     // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
     // after the sweep (so is the moment matching of rewards).  Only the moment matching of
     // STATES is part of the recursion.
-    if (A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES)) {
+    if (mm_in) {
+      __syncthreads();
       const int gpw = A.rows_per_wg / A.M;
       for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
@@ -770,36 +834,71 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
 
   // Per-row inputs of one step, staged in LDS: [gr | Jx(D) | Ja(U) | Td(D) | Tp(U) | a(U)].
   // The values of step t-1 are fetched into registers at the START of step t and parked in
-  // LDS at its end, so their HBM latency is covered by a whole step of GEMM work.
+  // LDS in the middle of it (after phase B, the last reader of step t's values), so their HBM
+  // latency is covered by half a step of GEMM work.  Each thread's source pointer / step
+  // stride is fixed for the launch.
   const int S = 1 + 2 * D + 3 * U;
   constexpr int PFV = (R * (1 + 2 * 16 + 3 * 8) + PF_NT - 1) / PF_NT;   // staged values per thread (bound)
-  auto stage_fetch = [&](int ts, int idx) -> float {
+  const float* pf_base[PFV];
+  unsigned pf_str[PFV];
+#pragma unroll
+  for (int u = 0; u < PFV; ++u) {
+    const int idx = tid + u * PF_NT;
     const int r = idx / S, c = idx - r * S;
-    if (r >= nvalid) return 0.f;
-    const size_t row = (size_t)ts * B + row0 + r;
-    if (c == 0) return A.grad_rewards[row];
-    if (c < 1 + D) return A.Jx[row * D + (c - 1)];
-    if (c < 1 + D + U) return A.Ja[row * U + (c - 1 - D)];
-    if (c < 1 + 2 * D + U) return A.Td[row * D + (c - 1 - D - U)];
-    if (c < 1 + 2 * D + 2 * U) return A.Tp[row * U + (c - 1 - 2 * D - U)];
-    return A.actions[row * U + (c - 1 - 2 * D - 2 * U)];
-  };
-  for (int i = tid; i < R * S; i += PF_NT) L.stg[i] = stage_fetch(A.t1 - 1, i);
+    pf_base[u] = nullptr;
+    pf_str[u] = 0;
+    if (idx < R * S && r < nvalid) {
+      const size_t row = (size_t)row0 + r;
+      if (c == 0) { pf_base[u] = A.grad_rewards + row; pf_str[u] = B; }
+      else if (c < 1 + D) { pf_base[u] = A.Jx + row * D + (c - 1); pf_str[u] = B * D; }
+      else if (c < 1 + D + U) { pf_base[u] = A.Ja + row * U + (c - 1 - D); pf_str[u] = B * U; }
+      else if (c < 1 + 2 * D + U) { pf_base[u] = A.Td + row * D + (c - 1 - D - U); pf_str[u] = B * D; }
+      else if (c < 1 + 2 * D + 2 * U) { pf_base[u] = A.Tp + row * U + (c - 1 - 2 * D - U); pf_str[u] = B * U; }
+      else { pf_base[u] = A.actions + row * U + (c - 1 - 2 * D - 2 * U); pf_str[u] = B * U; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PFV; ++u) {
+    const int idx = tid + u * PF_NT;
+    if (idx < R * S) L.stg[idx] = pf_base[u] ? pf_base[u][(size_t)(A.t1 - 1) * pf_str[u]] : 0.f;
+  }
   __syncthreads();
+
+  // Phase A of a step, element (r, k) of the 16-wide dynamics-head adjoint input:
+  //   g = g0 + gr~ Jx ;  k < D: gxn = g, X = g*Sy ;  D <= k < 2D: X = g*Td ;  gad = gr~ Ja
+  // g0 = dL/dx_{t+1} (after the moment-matching adjoint if that runs in the kernel).
+  const float* stg = L.stg;
+  auto phase_a = [&](int r, int k, float g0, float* gxn_dst) {
+    float v = 0.f;
+    if (r < nvalid && k < 2 * D) {
+      const int d = k < D ? k : k - D;
+      const float grv = stg[r * S];   // dL/dr~ (already through the reward mm adjoint)
+      const float g = g0 + grv * stg[r * S + 1 + d];
+      if (k < D) {
+        gxn_dst[r * D + d] = g;
+        v = g * L.Sy[d];
+      } else {
+        v = g * stg[r * S + 1 + D + U + d];
+      }
+    }
+    L.bufA[r * LD + k] = v;
+    if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
+  };
+  const bool mm_in = (A.mm_mode == 1 && mms);
+  int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
+  const int xb_off = (int)(L.xb - L.jx);
 
   for (int t = A.t1 - 1; t >= A.t0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
+    int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
     float pfv[PFV];
 #pragma unroll
-    for (int u = 0; u < PFV; ++u) {
-      const int i = tid + u * PF_NT;
-      pfv[u] = (t > A.t0 && i < R * S) ? stage_fetch(t - 1, i) : 0.f;
-    }
-    const float* stg = L.stg;
-    if (A.mm_mode == 1 && mms) {
+    for (int u = 0; u < PFV; ++u)
+      pfv[u] = (t > A.t0 && pf_base[u]) ? pf_base[u][(size_t)(t - 1) * pf_str[u]] : 0.f;
+    if (mm_in) {
       // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
       const float* xsrc = A.xt + (size_t)t * B * D;
       for (int i = tid; i < R * D; i += PF_NT) {
@@ -819,47 +918,35 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       __syncthreads();
     }
     PM_MARK(1);
-    // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input:
-    //      gxt = (mm-adjoint of gx | gx) + gr~ Jx ;  X = [gxt*Sy | gxt*Td | 0] ;  gad = gr~ Ja
-    {
-      const bool from_mm = (A.mm_mode == 1 && mms);
+    // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input.
+    //      On the plain path the previous step's last phase has already done this.
+    if (mm_in || t == A.t1 - 1) {
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
-        float v = 0.f;
-        if (r < nvalid && k < 2 * D) {
-          const int d = k < D ? k : k - D;
-          const float grv = stg[r * S];   // dL/dr~ (already through the reward mm adjoint)
-          const float g = (from_mm ? gxt[r * D + d] : gx[r * D + d]) + grv * stg[r * S + 1 + d];
-          if (k < D) {
-            gxn[r * D + d] = g;
-            v = g * L.Sy[d];
-          } else {
-            v = g * stg[r * S + 1 + D + U + d];
-          }
-        }
-        X[r * LD + k] = v;
-        if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
+        const int d = k < D ? k : k - D;
+        const float g0 = (k < 2 * D) ? (mm_in ? gxt[r * D + d] : gx[r * D + d]) : 0.f;
+        phase_a(r, k, g0, gxn);
       }
+      __syncthreads();
     }
-    __syncthreads();
     PM_MARK(3);
     // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) as LDS dot products
     {
       const int nt = F.nt[F.nl - 1];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[F.nl - 2]) + (size_t)t * B * nt * 4, F.keep[F.nl - 2], Y, nullptr, LD, A.Rw,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[F.nl - 2]) + (size_t)t * B * nt * 4, F.inv_keep[F.nl - 2], Y, nullptr, LD, A.Rw,
                     row0, nvalid, nt, lane};
       res0_layer<RT>(whd, nt, X, LD, wid, lane, e);
     }
     __syncthreads();
-    { float* tmp = X; X = Y; Y = tmp; }
+    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
     PM_MARK(4);
     for (int l = F.nl - 2, si = 0; l >= 1; --l, ++si) {
       const int nt = F.nt[l];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[l - 1]) + (size_t)t * B * nt * 4, F.keep[l - 1], Y, nullptr, LD, A.Rw, row0,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[l - 1]) + (size_t)t * B * nt * 4, F.inv_keep[l - 1], Y, nullptr, LD, A.Rw, row0,
                     nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
-      { float* tmp = X; X = Y; Y = tmp; }
+      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
       PM_MARK(4 + l);
     }
     head_partial<RT>(twd, F.nt[1], X, LD, L.hp, wid, lane);
@@ -902,6 +989,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       }
     }
     __syncthreads();
+    // park the prefetched inputs of step t-1 (phase B was the last reader of step t's)
+#pragma unroll
+    for (int u = 0; u < PFV; ++u) {
+      const int i = tid + u * PF_NT;
+      if (i < R * S) L.stg[i] = pfv[u];
+    }
     if (A.agn) {
       for (int r = tid; r < nvalid; r += PF_NT) {
         float s2 = 0.f;
@@ -913,36 +1006,42 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     // ---- policy trunk: dX chain + G stash; tail (grad wrt x) as LDS dot products
     {
       const int nt = P.nt[P.nl - 1];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[P.nl - 2]) + (size_t)t * B * nt * 4, P.keep[P.nl - 2], Y,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[P.nl - 2]) + (size_t)t * B * nt * 4, P.inv_keep[P.nl - 2], Y,
                     A.gT[P.nl - 2] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       res0_layer<RT>(whp, nt, X, LD, wid, lane, e);
     }
     __syncthreads();
-    { float* tmp = X; X = Y; Y = tmp; }
+    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
     PM_MARK(14);
     for (int l = P.nl - 2, si = 0; l >= 1; --l, ++si) {
       const int nt = P.nt[l];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[l - 1]) + (size_t)t * B * nt * 4, P.keep[l - 1], Y,
+      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[l - 1]) + (size_t)t * B * nt * 4, P.inv_keep[l - 1], Y,
                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, e);
       __syncthreads();
-      { float* tmp = X; X = Y; Y = tmp; }
+      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
       PM_MARK(14 + l);
     }
     head_partial<RT>(twp, P.nt[1], X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(22);
-    for (int i = tid; i < R * D; i += PF_NT) {
-      const int r = i / D, d = i - r * D;
-      float v = gxn[i] + head_value<RT>(L.hp, r, d);
-      if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
-      gx[i] = v;
-    }
-    // park the prefetched inputs of step t-1
-#pragma unroll
-    for (int u = 0; u < PFV; ++u) {
-      const int i = tid + u * PF_NT;
-      if (i < R * S) L.stg[i] = pfv[u];
+    // ---- dL/dx_t = gxn + policy tail (+ external state gradient); on the plain path the same
+    //      threads go straight on to phase A of step t-1 (its inputs were parked mid-step)
+    {
+      if (!mm_in) gsel ^= 1;
+      float* gxn_next = L.jx + (gsel ? xb_off : 0);
+      for (int i = tid; i < R * 16; i += PF_NT) {
+        const int r = i >> 4, k = i & 15;
+        const int d = k < D ? k : k - D;
+        float v = 0.f;
+        if (k < 2 * D) {
+          v = gxn[r * D + d] + head_value<RT>(L.hp, r, d);
+          if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
+          if (k < D) gx[r * D + d] = v;
+        }
+        if (!mm_in && t > A.t0) phase_a(r, k, v, gxn_next);
+      }
+      gxn = gxn_next;
     }
     __syncthreads();
     PM_MARK(23);
