@@ -57,6 +57,37 @@ struct FragS {
 // is advanced incrementally; the kernel-argument table is consulted only when the stream
 // moves to another layer (a scalar-memory round trip per chunk was costing more than the
 // MFMAs of the chunk).
+// Per-layer descriptors live in the LANES of one VGPR per table and are read back with
+// v_readlane (uniform lane index): a runtime layer index costs a few VALU issue slots instead
+// of a scalar-memory round trip whose wait (lgkmcnt is shared with LDS) lands on the critical
+// path of every phase and of every layer switch of the weight stream.
+__device__ __forceinline__ int pm_rl(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ float pm_rlf(int v, int i) { return __int_as_float(__builtin_amdgcn_readlane(v, i)); }
+// pointers rebuilt from integers carry no address space: stores through them would be FLAT
+// (FLAT completes out of order with LDS, which degrades every LDS wait to lgkmcnt(0))
+#define PM_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T* pm_rlp(int v, int i) {
+  const unsigned long long lo = (unsigned)__builtin_amdgcn_readlane(v, i);
+  const unsigned long long hi = (unsigned)__builtin_amdgcn_readlane(v, i + 1);
+  return reinterpret_cast<T*>(lo | (hi << 32));
+}
+__device__ __forceinline__ int pm_lo32(const void* p) { return (int)(unsigned)(reinterpret_cast<unsigned long long>(p)); }
+__device__ __forceinline__ int pm_hi32(const void* p) { return (int)(unsigned)(reinterpret_cast<unsigned long long>(p) >> 32); }
+
+// weight-stream table: lane 4*l + {0: n_ot, 1: n_kb, 2/3: wf lo/hi} of streamed layer l (<= 16)
+struct SdV {
+  int n, v;
+};
+__device__ __forceinline__ SdV sdv_make(const StreamDesc& sd, int lane) {
+  SdV r;
+  r.n = sd.n;
+  r.v = 0;
+  const int l = lane >> 2, f = lane & 3;
+  if (l < sd.n) r.v = f == 0 ? sd.n_ot[l] : f == 1 ? sd.n_kb[l] : f == 2 ? pm_lo32(sd.wf[l]) : pm_hi32(sd.wf[l]);
+  return r;
+}
+
 struct Cursor {
   int li, ot, c, live, all_live;
   int n_ot, n_kb;            // of layer li (n_kb padded to the chunk size)
@@ -68,7 +99,10 @@ struct Cursor {
   const float* nwf;
 };
 
-__device__ __forceinline__ void cur_fetch_next(const StreamDesc& sd, Cursor& q, int wid) {
+#define SD_NOT(sd, l) pm_rl((sd).v, 4 * (l))
+#define SD_NKB(sd, l) pm_rl((sd).v, 4 * (l) + 1)
+#define SD_WF(sd, l) pm_rlp<const float>((sd).v, 4 * (l) + 2)
+__device__ __forceinline__ void cur_fetch_next(const SdV& sd, Cursor& q, int wid) {
   int l = q.li;
   if (q.all_live) {
     l = (l + 1 >= sd.n) ? 0 : l + 1;
@@ -76,15 +110,15 @@ __device__ __forceinline__ void cur_fetch_next(const StreamDesc& sd, Cursor& q, 
     // next layer (cyclically) in which this wave owns a tile
     for (int k = 0; k < 2 * PM_MAXL; ++k) {
       l = (l + 1 >= sd.n) ? 0 : l + 1;
-      if (wid < sd.n_ot[l]) break;
+      if (wid < SD_NOT(sd, l)) break;
     }
   }
   q.nli = l;
-  q.nn_ot = sd.n_ot[l];
-  q.nn_kb = sd.n_kb[l];
-  q.nwf = sd.wf[l];
+  q.nn_ot = SD_NOT(sd, l);
+  q.nn_kb = SD_NKB(sd, l);
+  q.nwf = SD_WF(sd, l);
 }
-__device__ __forceinline__ void cur_switch(const StreamDesc& sd, Cursor& q, int wid) {
+__device__ __forceinline__ void cur_switch(const SdV& sd, Cursor& q, int wid) {
   q.li = q.nli;
   q.n_ot = q.nn_ot;
   q.n_kb = q.nn_kb;
@@ -93,23 +127,25 @@ __device__ __forceinline__ void cur_switch(const StreamDesc& sd, Cursor& q, int 
   q.wp = q.nwf + (size_t)wid * q.n_kb * 256;
   cur_fetch_next(sd, q, wid);
 }
-__device__ __forceinline__ void cur_init(const StreamDesc& sd, Cursor& q, int wid) {
+__device__ __forceinline__ void cur_init(const SdV& sd, Cursor& q, int wid) {
   q.li = 0; q.ot = 0; q.c = 0; q.live = 0; q.all_live = 1; q.n_ot = 0; q.n_kb = 0; q.wp = nullptr;
   q.nli = 0; q.nn_ot = 0; q.nn_kb = 0; q.nwf = nullptr;
   int first = -1;
   for (int l = sd.n - 1; l >= 0; --l) {
-    if (wid < sd.n_ot[l]) { q.live = 1; first = l; }
+    if (wid < SD_NOT(sd, l)) { q.live = 1; first = l; }
     else q.all_live = 0;
   }
   if (q.live) {
     // enter `first` through the same path as every later switch
-    q.nli = first; q.nn_ot = sd.n_ot[first]; q.nn_kb = sd.n_kb[first]; q.nwf = sd.wf[first];
+    q.nli = first;
+    q.nn_ot = SD_NOT(sd, first);
+    q.nn_kb = SD_NKB(sd, first);
+    q.nwf = SD_WF(sd, first);
     cur_switch(sd, q, wid);
   }
 }
 template <int CKB>
-__device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int wid) {
-  if (!q.live) return;
+__device__ __forceinline__ void cur_advance(const SdV& sd, Cursor& q, int wid) {
   q.c += CKB;
   q.wp += (size_t)CKB * 256;
   if (q.c >= q.n_kb) {
@@ -120,18 +156,38 @@ __device__ __forceinline__ void cur_advance(const StreamDesc& sd, Cursor& q, int
   }
 }
 
-// straight-line load / compute of one full chunk: the compiler hoists the CKB LDS reads
-// ahead of the MFMAs and interleaves the two accumulator chains (even / odd k-blocks)
+// The weight stream is issued with INLINE-ASM loads and waited for with explicit s_waitcnt:
+// the compiler's own waitcnt insertion loses track of which stage a load belongs to across
+// this loop nest (it fell back to vmcnt(0/1) right after issuing the next stage, i.e. a full
+// L2 round trip per chunk, depending on unrelated code changes).  Rules that keep this safe:
+//   * a stage register is "in flight" from pm_ldw to the frag_wait that names it; nothing may
+//     read, copy or spill it in between (tools/check_inflight.py verifies the generated ISA);
+//   * frag_wait<CKB> leaves exactly the CKB loads of the OTHER stage outstanding: it is placed
+//     right after those are issued, before any store of an epilogue, so vmcnt(CKB) is exact;
+//   * loads the compiler does not know about only make ITS vmcnt waits longer, never shorter.
+template <int OFF>
+__device__ __forceinline__ void pm_ldw(f32x4& d, unsigned voff, const float* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
 template <int CKB>
-__device__ __forceinline__ void frag_load(FragS<CKB>& f, const StreamDesc& sd, const Cursor& q,
-                                          int wid, int lane) {
-#ifdef PM_EXP_NOLOAD
-  return;
-#endif
-  if (!q.live) return;
-  const float* wp = q.wp + lane * 4;
+__device__ __forceinline__ void frag_load(FragS<CKB>& f, const Cursor& q, unsigned vo0, unsigned vo1) {
+  const float* wp = q.wp;
+  static_assert(CKB >= 1 && CKB <= 8, "stage depth");
+  if constexpr (CKB > 0) pm_ldw<0>(f.a[0], vo0, wp);
+  if constexpr (CKB > 1) pm_ldw<1024>(f.a[1], vo0, wp);
+  if constexpr (CKB > 2) pm_ldw<2048>(f.a[2], vo0, wp);
+  if constexpr (CKB > 3) pm_ldw<3072>(f.a[3], vo0, wp);
+  if constexpr (CKB > 4) pm_ldw<0>(f.a[4], vo1, wp);
+  if constexpr (CKB > 5) pm_ldw<1024>(f.a[5], vo1, wp);
+  if constexpr (CKB > 6) pm_ldw<2048>(f.a[6], vo1, wp);
+  if constexpr (CKB > 7) pm_ldw<3072>(f.a[7], vo1, wp);
+}
+// everything older than the CKB most recent VMEM operations has landed; `f` is usable
+template <int CKB>
+__device__ __forceinline__ void frag_wait(FragS<CKB>& f) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CKB));
 #pragma unroll
-  for (int cc = 0; cc < CKB; ++cc) f.a[cc] = ldg4(wp + (size_t)cc * 256);
+  for (int cc = 0; cc < CKB; ++cc) asm volatile("" : "+v"(f.a[cc]));
 }
 
 // B operands (LDS activations) of one k-block pair
@@ -189,36 +245,66 @@ __device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, int c_n
 
 // One streamed layer.  The plan pads every streamed layer to an EVEN number of chunks, so
 // the two register stages keep fixed roles (fa: even chunks, fb: odd chunks) and no stage is
-// ever copied: invariant on entry and exit -- fa holds the chunk the processing order
-// reaches next, `q` is the chunk after it.
+// ever copied: invariant on entry and exit -- fa holds (or is receiving) the chunk the
+// processing order reaches next, `q` is the chunk after it.  The epilogue of tile i runs at
+// the start of tile i+1, after that tile's first loads have been issued and waited for:
+// at every frag_wait the only younger VMEM operations are the CKB loads just issued.
 template <int RT, int CKB, class Epi>
-__device__ __forceinline__ void stream_layer(const StreamDesc& sd, int li, Cursor& q, FragS<CKB>& fa,
+__device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, FragS<CKB>& fa,
                                              FragS<CKB>& fb, const float* lds_in, int ld,
-                                             int wid, int lane, Epi& epi,
+                                             int wid, int lane, Epi& epi, unsigned vo0, unsigned vo1,
                                              long long* prof = nullptr) {
-  const int n_ot = sd.n_ot[li];
-  const int nch2 = sd.n_kb[li] / (2 * CKB);
+  // On entry the load cursor is one chunk ahead INSIDE layer li (every layer has >= 2 chunks per
+  // tile), unless this wave owns no tile of it: the layer shape is already in SGPRs.
+  if (!q.live || q.li != li) return;
+  const int n_ot = q.n_ot;
+  const int nch2 = q.n_kb / (2 * CKB);
   int pslot = 24;
   BPair<RT> b0;
-  if (wid < n_ot) bpair_load<RT, CKB>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
+  bpair_load<RT, CKB>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
+  f32x4 pacc[RT];
+  typename Epi::Pre ppre[RT];
+  int pot = -1;
   for (int ot = wid; ot < n_ot; ot += PF_NW) {
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
+    typename Epi::Pre pre[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot, rt);
     f32x4 acc[2][RT];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c2 = 0; c2 < nch2; ++c2) {
-      frag_load<CKB>(fb, sd, q, wid, lane);
+    int c2 = 0;
+    do {   // nch2 >= 1: the body (and its waits) runs at least once per tile
+      frag_load<CKB>(fb, q, vo0, vo1);
       cur_advance<CKB>(sd, q, wid);
+      frag_wait<CKB>(fa);
+      if (c2 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) epi.landed(pre[rt], rt);
+        if (pot >= 0) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
+        }
+      }
       frag_compute<RT, CKB>(fa, 2 * c2, 2 * c2 + 1, lds_in, ld, lane, acc, b0);
-      frag_load<CKB>(fa, sd, q, wid, lane);
+      frag_load<CKB>(fa, q, vo0, vo1);
       cur_advance<CKB>(sd, q, wid);
+      frag_wait<CKB>(fb);
       frag_compute<RT, CKB>(fb, 2 * c2 + 1, (c2 + 1 < nch2) ? 2 * c2 + 2 : 0, lds_in, ld, lane, acc, b0);
-    }
+    } while (++c2 < nch2);
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[0][rt] + acc[1][rt]);
+    for (int rt = 0; rt < RT; ++rt) {
+      pacc[rt] = acc[0][rt] + acc[1][rt];
+      ppre[rt] = pre[rt];
+    }
+    pot = ot;
+  }
+  if (pot >= 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
   }
 }
 
@@ -237,8 +323,23 @@ __device__ __forceinline__ void res0_load(Res0<RT>& r, const float* wf, int n_ot
   }
 }
 template <int RT, class Epi>
+struct Res0Pre {
+  typename Epi::Pre p[PM_L0T][RT];
+};
+// epilogue operands of a resident layer: issued BEFORE the barrier that opens its phase
+template <int RT, class Epi>
+__device__ __forceinline__ void res0_prefetch(Res0Pre<RT, Epi>& pp, const Epi& epi, int n_ot, int wid) {
+#pragma unroll
+  for (int i = 0; i < PM_L0T; ++i) {
+    const int ot = wid + i * PF_NW;
+    const int ots = ot < n_ot ? ot : wid;     // absent tile: harmless duplicate fetch
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) pp.p[i][rt] = epi.pre(ots, rt);
+  }
+}
+template <int RT, class Epi>
 __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const float* lds_in, int ld,
-                                           int wid, int lane, Epi& epi) {
+                                           int wid, int lane, Epi& epi, Res0Pre<RT, Epi>& pp) {
   const float* bbase = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
   f32x4 b[RT];
 #pragma unroll
@@ -256,12 +357,14 @@ __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const fl
     for (int i = 0; i < PM_L0T; ++i)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[i][rt] = mfma4(r.w[i][j], b[rt][j], acc[i][rt]);
+  Epi::wait_all();
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
     const int ot = wid + i * PF_NW;
-    if (ot < n_ot) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) epi(ot, rt, acc[i][rt]);
+    for (int rt = 0; rt < RT; ++rt) {
+      epi.landed(pp.p[i][rt], rt);
+      if (ot < n_ot) epi(ot, rt, acc[i][rt], pp.p[i][rt]);
     }
   }
 }
@@ -334,14 +437,29 @@ struct EpiFwdL {
   float* lds_out;
   float* stash;             // HBM block or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
-  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+  struct Pre {
+    f32x4 b;
+    unsigned mw;
+  };
+  // operands of the epilogue of tile (ot, rt): fetched when the tile STARTS, so their latency
+  // hides behind the tile's MFMAs
+  __device__ __forceinline__ Pre pre(int ot, int rt) const {
+    const unsigned g = (unsigned)lane >> 4;
+    const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
+    Pre p;
+    p.b = *reinterpret_cast<const f32x4*>(bias + ot * 16 + 4 * g);
+    p.mw = mask[lrow * (unsigned)nt + ot];
+    return p;
+  }
+  __device__ __forceinline__ void landed(Pre&, int) const {}   // LDS operands: the compiler tracks them
+  static __device__ __forceinline__ void wait_all() {}
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     constexpr unsigned RW = 16 * RT;
     const unsigned g = (unsigned)lane >> 4;
     const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
     const unsigned f0 = ot * 16 + 4 * g;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
-    const unsigned mw = mask[lrow * (unsigned)nt + ot];
-    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    const f32x4 b = pr.b;
+    const unsigned nib = (pr.mw >> (4 * g)) & 0xFu;
     f32x4 h;
     unsigned act = 0;
 #pragma unroll
@@ -354,14 +472,14 @@ struct EpiFwdL {
     *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
 #ifndef PM_EXP_NOSTASH
     if (stash) {
-      float* sp = stash + (unsigned)ot * (16u * RW);          // uniform
+      PM_GLOBAL float* sp = (PM_GLOBAL float*)(stash + (unsigned)ot * (16u * RW));   // uniform
       const unsigned lo = 4 * g * RW + lrow;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sp[lo + r * RW] = h[r];
     }
 #endif
     if ((int)lrow < nvalid) {
-      uint8_t* ap = abits + (unsigned)ot * 4u;                // uniform
+      PM_GLOBAL uint8_t* ap = (PM_GLOBAL uint8_t*)(abits + (unsigned)ot * 4u);   // uniform
       ap[((unsigned)row0 + lrow) * (unsigned)nt * 4u + g] = (uint8_t)act;
     }
   }
@@ -374,23 +492,43 @@ struct EpiBwdL {
   float* lds_out;
   float* stash;
   int ld, Rw, row0, nvalid, nt, lane;
-  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+  struct Pre {
+    unsigned nib;
+  };
+  // the activation bits come from HBM / L2: fetched when the tile starts (or, for the
+  // resident layers, before the barrier that opens the phase)
+  // Issued as an inline-asm load (see frag_load): in flight until landed() after a wait that
+  // covers it.  Rows past the end of the batch read a valid row's bits (clamped) and are
+  // masked in landed().
+  __device__ __forceinline__ Pre pre(int ot, int rt) const {
+    const unsigned g = (unsigned)lane >> 4;
+    const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
+    const unsigned rowc = (int)lrow < nvalid ? lrow : (unsigned)(nvalid - 1);
+    const uint8_t* ap = abits + (unsigned)ot * 4u;          // uniform
+    const unsigned off = ((unsigned)row0 + rowc) * (unsigned)nt * 4u + g;
+    Pre p;
+    asm volatile("global_load_ubyte %0, %1, %2" : "=&v"(p.nib) : "v"(off), "s"(ap));
+    return p;
+  }
+  __device__ __forceinline__ void landed(Pre& p, int rt) const {
+    asm volatile("" : "+v"(p.nib));
+    const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
+    if ((int)lrow >= nvalid) p.nib = 0;
+  }
+  static __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)"); }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     constexpr unsigned RW = 16 * RT;
     const unsigned g = (unsigned)lane >> 4;
     const unsigned lrow = rt * 16 + ((unsigned)lane & 15u);
     const unsigned f0 = ot * 16 + 4 * g;
-    unsigned nib = 0;
-    if ((int)lrow < nvalid) {
-      const uint8_t* ap = abits + (unsigned)ot * 4u;          // uniform
-      nib = ap[((unsigned)row0 + lrow) * (unsigned)nt * 4u + g];
-    }
+    const unsigned nib = pr.nib;
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = ((nib >> r) & 1u) ? acc[r] * inv_keep : 0.f;
     *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
 #ifndef PM_EXP_NOSTASH
     if (stash) {
-      float* sp = stash + (unsigned)ot * (16u * RW);          // uniform
+      PM_GLOBAL float* sp = (PM_GLOBAL float*)(stash + (unsigned)ot * (16u * RW));   // uniform
       const unsigned lo = 4 * g * RW + lrow;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sp[lo + r * RW] = h[r];
@@ -570,6 +708,8 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
   }
 }
 
+#define PM_SWAP_XY() { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+
 // ===========================================================================
 // forward (fast)
 // ===========================================================================
@@ -608,18 +748,56 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   res0_load<RT>(w0p, P.wf[0], P.nt[1], wid, lane);
   res0_load<RT>(w0d, F.wf[0], F.nt[1], wid, lane);
   // weight stream over the hidden->hidden layers of both nets
-  const StreamDesc& sd = A.sd_fwd;      // policy hidden layers, then dynamics hidden layers
+  const SdV sd = sdv_make(A.sd_fwd, lane);   // policy hidden layers, then dynamics hidden layers
   const int n_pol_stream = P.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
   FragS<CKB> fa, fb;
-  if (sd.n > 0) {
-    frag_load<CKB>(fa, sd, q, wid, lane);
+  const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
+  if (q.live) {
+    frag_load<CKB>(fa, q, vo0, vo1);
     cur_advance<CKB>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
-  __syncthreads();
+  // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
+  // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
+  // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
+  // wait.  The barrier that closes a step is the one that opens the next step's first phase.
+  // net tables: lane 8*l + {0: nt[l+1], 1: bias offset, 2: mask offset, 3/4: abits, 5: 1/keep, 6/7: stash}
+  int vdp = 0, vdd = 0;
+  {
+    const int l = lane >> 3, f = lane & 7;
+    if (l < P.nl) {
+      const bool hid = l < P.nl - 1;
+      vdp = f == 0 ? P.nt[l + 1] : f == 1 ? A.fo.pbias[l] : f == 2 ? (hid ? A.fo.pmask[l] : 0)
+          : f == 3 ? (hid ? pm_lo32(P.abits[l]) : 0) : f == 4 ? (hid ? pm_hi32(P.abits[l]) : 0)
+          : f == 5 ? __float_as_int(P.inv_keep[l]) : f == 6 ? (hid ? pm_lo32(A.actT[l + 1]) : 0)
+          : (hid ? pm_hi32(A.actT[l + 1]) : 0);
+    }
+    if (l < F.nl) {
+      const bool hid = l < F.nl - 1;
+      vdd = f == 0 ? F.nt[l + 1] : f == 1 ? A.fo.dbias[l] : f == 2 ? (hid ? A.fo.dmask[l] : 0)
+          : f == 3 ? (hid ? pm_lo32(F.abits[l]) : 0) : f == 4 ? (hid ? pm_hi32(F.abits[l]) : 0)
+          : f == 5 ? __float_as_int(F.inv_keep[l]) : 0;
+    }
+  }
+  auto pol_epi = [&](int l, int t, size_t blk, float* out) {
+    const int nt = pm_rl(vdp, 8 * l);
+    return EpiFwdL<RT>{L.base + pm_rl(vdp, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdp, 8 * l + 2)),
+                       pm_rlp<uint8_t>(vdp, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * l + 5), out,
+                       pm_rlp<float>(vdp, 8 * l + 6) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
+  };
+  auto dyn_epi = [&](int l, int t, float* out) {
+    const int nt = pm_rl(vdd, 8 * l);
+    return EpiFwdL<RT>{L.base + pm_rl(vdd, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdd, 8 * l + 2)),
+                       pm_rlp<uint8_t>(vdd, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * l + 5), out,
+                       nullptr, LD, R, row0, nvalid, nt, lane};
+  };
+  const float* pol_head_bias = L.base + pm_rl(vdp, 8 * (P.nl - 1) + 1);
+  const float* dyn_head_bias = L.base + pm_rl(vdd, 8 * (F.nl - 1) + 1);
+  const int pol_head_kb = P.nt[P.nl - 1], dyn_head_kb = F.nt[F.nl - 1];
+  const int pnl = P.nl, fnl = F.nl;
 
   for (int t = A.t0; t < A.t1; ++t) {
     const size_t blk = (size_t)t * A.nwg + wg;
@@ -630,6 +808,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     if (t == A.t0 || mm_in) {
       // dynamics-state rows -> policy input tile (+ dW stash); later steps of the plain path
       // get this written by the previous step's sampling phase
+      __syncthreads();
       float* st = A.actT[0] + blk * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int k = i / R, r = i - k * R;
@@ -637,37 +816,35 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         X[r * LD + k] = v;
         st[(size_t)k * A.Rw + r] = v;
       }
-      __syncthreads();
     }
-    PM_MARK(1);
-    // ---- policy: first layer (resident), hidden layers (streamed), head as LDS dot products
+    // ---- policy: first layer (resident), hidden layers (streamed), head K-split over the waves
+    EpiFwdL<RT> es{};
     {
-      const int nt = P.nt[1];
-      EpiFwdL<RT> e{PBIAS(0), PMASK(0), reinterpret_cast<uint8_t*>(P.abits[0]) + (size_t)t * B * nt * 4, P.inv_keep[0], Y,
-                    A.actT[1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
-                    row0, nvalid, nt, lane};
-      res0_layer<RT>(w0p, nt, X, LD, wid, lane, e);
+      EpiFwdL<RT> e = pol_epi(0, t, blk, Y);
+      Res0Pre<RT, EpiFwdL<RT>> pp;
+      res0_prefetch<RT>(pp, e, e.nt, wid);
+      __syncthreads();
+      PM_MARK(1);
+      res0_layer<RT>(w0p, e.nt, X, LD, wid, lane, e, pp);
+      if (pnl > 2) es = pol_epi(1, t, blk, X);     // layer 1 writes the buffer that is X now
     }
     __syncthreads();
-    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+    PM_SWAP_XY();
     PM_MARK(2);
-    for (int l = 1; l < P.nl - 1; ++l) {
-      const int nt = P.nt[l + 1];
-      EpiFwdL<RT> e{PBIAS(l), PMASK(l), reinterpret_cast<uint8_t*>(P.abits[l]) + (size_t)t * B * nt * 4, P.inv_keep[l], Y,
-                    A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw,
-                    row0, nvalid, nt, lane};
-      stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, e,
+    for (int l = 1; l < pnl - 1; ++l) {
+      stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1,
                             (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
+      if (l + 1 < pnl - 1) es = pol_epi(l + 1, t, blk, X);
       __syncthreads();
-      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+      PM_SWAP_XY();
       PM_MARK(2 + l);
     }
-    head_partial<RT>(hwp, P.nt[P.nl - 1], X, LD, L.hp, wid, lane);
+    head_partial<RT>(hwp, pol_head_kb, X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(10);
     // ---- squash + dynamics input
     {
-      const float* hb = PBIAS(P.nl - 1);
+      const float* hb = pol_head_bias;
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float v = 0.f;
@@ -697,33 +874,32 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         X[r * LD + k] = v;
       }
     }
-    __syncthreads();
-    PM_MARK(11);
     // ---- dynamics
     {
-      const int nt = F.nt[1];
-      EpiFwdL<RT> e{DBIAS(0), DMASK(0), reinterpret_cast<uint8_t*>(F.abits[0]) + (size_t)t * B * nt * 4, F.inv_keep[0], Y, nullptr,
-                    LD, A.Rw, row0, nvalid, nt, lane};
-      res0_layer<RT>(w0d, nt, X, LD, wid, lane, e);
+      EpiFwdL<RT> e = dyn_epi(0, t, Y);
+      Res0Pre<RT, EpiFwdL<RT>> pp;
+      res0_prefetch<RT>(pp, e, e.nt, wid);
+      __syncthreads();
+      PM_MARK(11);
+      res0_layer<RT>(w0d, e.nt, X, LD, wid, lane, e, pp);
+      if (fnl > 2) es = dyn_epi(1, t, X);
     }
     __syncthreads();
-    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+    PM_SWAP_XY();
     PM_MARK(12);
-    for (int l = 1; l < F.nl - 1; ++l) {
-      const int nt = F.nt[l + 1];
-      EpiFwdL<RT> e{DBIAS(l), DMASK(l), reinterpret_cast<uint8_t*>(F.abits[l]) + (size_t)t * B * nt * 4, F.inv_keep[l], Y, nullptr,
-                    LD, A.Rw, row0, nvalid, nt, lane};
-      stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, e);
+    for (int l = 1; l < fnl - 1; ++l) {
+      stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      if (l + 1 < fnl - 1) es = dyn_epi(l + 1, t, X);
       __syncthreads();
-      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+      PM_SWAP_XY();
       PM_MARK(12 + l);
     }
-    head_partial<RT>(hwd, F.nt[F.nl - 1], X, LD, L.hp, wid, lane);
+    head_partial<RT>(hwd, dyn_head_kb, X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(20);
     // ---- sample next state; on the plain path also the next step's policy input tile
     {
-      const float* hb = DBIAS(F.nl - 1);
+      const float* hb = dyn_head_bias;
       const bool feed = !mm_in && (t + 1 < A.t1);
       float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
@@ -776,8 +952,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     } else {
       float* tmp = xa; xa = xb; xb = tmp;
     }
-    __syncthreads();
     PM_MARK(22);
+    // (no closing barrier: the next step's first phase opens with one)
   }
 }
 
@@ -821,13 +997,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   res0_load<RT>(whd, F.wb[F.nl - 1], F.nt[F.nl - 1], wid, lane);
   res0_load<RT>(whp, P.wb[P.nl - 1], P.nt[P.nl - 1], wid, lane);
   // stream: dynamics hidden layers (reverse), then policy hidden layers (reverse)
-  const StreamDesc& sd = A.sd_bwd;      // dynamics hidden layers (reverse), then policy (reverse)
+  const SdV sd = sdv_make(A.sd_bwd, lane);   // dynamics hidden layers (reverse), then policy (reverse)
   const int n_dyn_stream = F.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
   FragS<CKB> fa, fb;
-  if (sd.n > 0) {
-    frag_load<CKB>(fa, sd, q, wid, lane);
+  const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
+  if (q.live) {
+    frag_load<CKB>(fa, q, vo0, vo1);
     cur_advance<CKB>(sd, q, wid);
   }
   __syncthreads();
@@ -888,6 +1065,34 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
+  // net tables: lane 8*idx + {0: nt[idx+1], 1/2: abits, 3: 1/keep, 4/5: G stash} of hidden layer idx
+  int vdp = 0, vdd = 0;
+  {
+    const int l = lane >> 3, f = lane & 7;
+    if (l < P.nl - 1)
+      vdp = f == 0 ? P.nt[l + 1] : f == 1 ? pm_lo32(P.abits[l]) : f == 2 ? pm_hi32(P.abits[l])
+          : f == 3 ? __float_as_int(P.inv_keep[l]) : f == 4 ? pm_lo32(A.gT[l]) : f == 5 ? pm_hi32(A.gT[l]) : 0;
+    if (l < F.nl - 1)
+      vdd = f == 0 ? F.nt[l + 1] : f == 1 ? pm_lo32(F.abits[l]) : f == 2 ? pm_hi32(F.abits[l])
+          : f == 3 ? __float_as_int(F.inv_keep[l]) : 0;
+  }
+  // epilogue of the adjoint GEMM whose output carries the activation pattern of layer idx
+  auto dyn_epi = [&](int idx, int t, float* out) {
+    const int nt = pm_rl(vdd, 8 * idx);
+    return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdd, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * idx + 3),
+                       out, nullptr, LD, R, row0, nvalid, nt, lane};
+  };
+  auto pol_epi = [&](int idx, int t, size_t blk, float* out) {
+    const int nt = pm_rl(vdp, 8 * idx);
+    return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdp, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * idx + 3),
+                       out, pm_rlp<float>(vdp, 8 * idx + 4) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
+  };
+  const int pnl = P.nl, fnl = F.nl;
+  const int dyn_tail_kb = F.nt[1], pol_tail_kb = P.nt[1];
+  float* const gT_head = A.gT[P.nl - 1];
+
+  // Same phase pattern as the forward sweep: descriptors and the epilogue's activation bits
+  // (HBM / L2 reads) are issued before the barrier that opens a phase.
   for (int t = A.t1 - 1; t >= A.t0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
@@ -915,46 +1120,46 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
                   pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, gx + lr0 * D, D,
                   gxt + lr0 * D, D, scr, lane);
       }
-      __syncthreads();
     }
     PM_MARK(1);
     // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input.
     //      On the plain path the previous step's last phase has already done this.
     if (mm_in || t == A.t1 - 1) {
+      __syncthreads();
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         const int d = k < D ? k : k - D;
         const float g0 = (k < 2 * D) ? (mm_in ? gxt[r * D + d] : gx[r * D + d]) : 0.f;
         phase_a(r, k, g0, gxn);
       }
-      __syncthreads();
     }
-    PM_MARK(3);
-    // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) as LDS dot products
+    // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) K-split over the waves
+    EpiBwdL<RT> es{};
     {
-      const int nt = F.nt[F.nl - 1];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[F.nl - 2]) + (size_t)t * B * nt * 4, F.inv_keep[F.nl - 2], Y, nullptr, LD, A.Rw,
-                    row0, nvalid, nt, lane};
-      res0_layer<RT>(whd, nt, X, LD, wid, lane, e);
+      EpiBwdL<RT> e = dyn_epi(fnl - 2, t, Y);
+      Res0Pre<RT, EpiBwdL<RT>> pp;
+      res0_prefetch<RT>(pp, e, e.nt, wid);
+      __syncthreads();
+      PM_MARK(3);
+      res0_layer<RT>(whd, e.nt, X, LD, wid, lane, e, pp);
+      if (fnl > 2) es = dyn_epi(fnl - 3, t, X);
     }
     __syncthreads();
-    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+    PM_SWAP_XY();
     PM_MARK(4);
-    for (int l = F.nl - 2, si = 0; l >= 1; --l, ++si) {
-      const int nt = F.nt[l];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(F.abits[l - 1]) + (size_t)t * B * nt * 4, F.inv_keep[l - 1], Y, nullptr, LD, A.Rw, row0,
-                    nvalid, nt, lane};
-      stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, e);
+    for (int l = fnl - 2, si = 0; l >= 1; --l, ++si) {
+      stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      if (l - 1 >= 1) es = dyn_epi(l - 2, t, X);
       __syncthreads();
-      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+      PM_SWAP_XY();
       PM_MARK(4 + l);
     }
-    head_partial<RT>(twd, F.nt[1], X, LD, L.hp, wid, lane);
+    head_partial<RT>(twd, dyn_tail_kb, X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(12);
-    // ---- phase B: tail result; state part -> gxt, action part -> policy head adjoint
+    // ---- phase B: tail result; state part -> gxn, action part -> policy head adjoint
     {
-      float* gst = A.gT[P.nl - 1] + blk * (size_t)16 * A.Rw;
+      float* gst = gT_head + blk * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float tail = 0.f;
@@ -988,41 +1193,40 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         }
       }
     }
-    __syncthreads();
-    // park the prefetched inputs of step t-1 (phase B was the last reader of step t's)
-#pragma unroll
-    for (int u = 0; u < PFV; ++u) {
-      const int i = tid + u * PF_NT;
-      if (i < R * S) L.stg[i] = pfv[u];
-    }
-    if (A.agn) {
-      for (int r = tid; r < nvalid; r += PF_NT) {
-        float s2 = 0.f;
-        for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
-        A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
-      }
-    }
-    PM_MARK(13);
-    // ---- policy trunk: dX chain + G stash; tail (grad wrt x) as LDS dot products
+    // ---- policy trunk: dX chain + G stash; tail (grad wrt x) K-split over the waves
     {
-      const int nt = P.nt[P.nl - 1];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[P.nl - 2]) + (size_t)t * B * nt * 4, P.inv_keep[P.nl - 2], Y,
-                    A.gT[P.nl - 2] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      res0_layer<RT>(whp, nt, X, LD, wid, lane, e);
+      EpiBwdL<RT> e = pol_epi(pnl - 2, t, blk, Y);
+      Res0Pre<RT, EpiBwdL<RT>> pp;
+      res0_prefetch<RT>(pp, e, e.nt, wid);
+      __syncthreads();
+      PM_MARK(13);
+      // park the prefetched inputs of step t-1 (phase B was the last reader of step t's)
+#pragma unroll
+      for (int u = 0; u < PFV; ++u) {
+        const int i = tid + u * PF_NT;
+        if (i < R * S) L.stg[i] = pfv[u];
+      }
+      if (A.agn) {
+        for (int r = tid; r < nvalid; r += PF_NT) {
+          float s2 = 0.f;
+          for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
+          A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
+        }
+      }
+      res0_layer<RT>(whp, e.nt, X, LD, wid, lane, e, pp);
+      if (pnl > 2) es = pol_epi(pnl - 3, t, blk, X);
     }
     __syncthreads();
-    { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+    PM_SWAP_XY();
     PM_MARK(14);
-    for (int l = P.nl - 2, si = 0; l >= 1; --l, ++si) {
-      const int nt = P.nt[l];
-      EpiBwdL<RT> e{reinterpret_cast<const uint8_t*>(P.abits[l - 1]) + (size_t)t * B * nt * 4, P.inv_keep[l - 1], Y,
-                    A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, e);
+    for (int l = pnl - 2, si = 0; l >= 1; --l, ++si) {
+      stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      if (l - 1 >= 1) es = pol_epi(l - 2, t, blk, X);
       __syncthreads();
-      { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+      PM_SWAP_XY();
       PM_MARK(14 + l);
     }
-    head_partial<RT>(twp, P.nt[1], X, LD, L.hp, wid, lane);
+    head_partial<RT>(twp, pol_tail_kb, X, LD, L.hp, wid, lane);
     __syncthreads();
     PM_MARK(22);
     // ---- dL/dx_t = gxn + policy tail (+ external state gradient); on the plain path the same
@@ -1043,9 +1247,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       }
       gxn = gxn_next;
     }
-    __syncthreads();
     PM_MARK(23);
+    // (no closing barrier: the next step's first phase opens with one)
   }
+  __syncthreads();
   for (int i = tid; i < nvalid * D; i += PF_NT) {
     const size_t o = (size_t)row0 * D + i;
     if (A.gx_carry) A.gx_carry[o] = gx[i];
