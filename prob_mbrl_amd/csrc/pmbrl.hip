@@ -257,7 +257,7 @@ struct NetPlan {
 struct pmbrl_plan {
   pmbrl_config cfg;
   int device;
-  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CKB;
+  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CA, CB;   // CA/CB: k-blocks per weight-stream stage
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
@@ -311,11 +311,15 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   return 0;
 }
 
-template <int RT, int CKB>
+// the instantiated (row tiles, stage pair) combinations -- keep in sync with stages_for()
+#define PM_FAST_CASES                                                                  \
+  PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
+  PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
+template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CKB>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CKB>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
@@ -359,31 +363,31 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   const int LD_generic = p->LD;
-  // chunk size (k-blocks) of the streamed layers: every layer is padded to an even number of
-  // chunks; pick, among the instantiated sizes, the one that pads the least
-  auto stream_work = [&](int ckb) {
+  // stage sizes (k-blocks) of the weight stream: every streamed layer is padded to a whole number
+  // of stage PAIRS (CA + CB k-blocks); pick, among the instantiated pairs, the one that pads least
+  struct StagePair { int ca, cb; };
+  auto stream_work = [&](int m) {
     long w = 0;
     const NetPlan* nets[2] = {&p->pol, &p->dyn};
     for (const NetPlan* n : nets)
-      for (int l = 1; l <= n->nl - 2; ++l) {
-        const int m = 2 * ckb;
+      for (int l = 1; l <= n->nl - 2; ++l)
         w += (long)n->nt[l + 1] * ((n->nt[l] + m - 1) / m * m) + (long)n->nt[l] * ((n->nt[l + 1] + m - 1) / m * m);
-      }
     return w;
   };
-  auto ckb_for = [&](int RT) {
-    const int cand1[] = {8, 7, 4, 2}, cand2[] = {4, 2}, cand4[] = {2, 1};
-    const int* cand = RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
+  auto stages_for = [&](int RT) {
+    static const StagePair cand1[] = {{8, 8}, {7, 6}, {4, 4}, {2, 2}}, cand2[] = {{4, 4}, {2, 2}}, cand4[] = {{2, 2}, {1, 1}};
+    const StagePair* cand = RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
     const int nc = RT == 1 ? 4 : 2;
-    int best = cand[0];
+    StagePair best = cand[0];
     for (int i = 1; i < nc; ++i)
-      if (stream_work(cand[i]) < stream_work(best)) best = cand[i];
+      if (stream_work(cand[i].ca + cand[i].cb) < stream_work(best.ca + best.cb)) best = cand[i];
     return best;
   };
   auto ld_for = [&](int RT) {
     if (!p->fast) return LD_generic;
-    const int ckb = ckb_for(RT);
-    return (maxnt + 2 * ckb - 1) / (2 * ckb) * (2 * ckb) * 16 + 8;   // room for the zero K padding
+    const StagePair sp = stages_for(RT);
+    const int m = sp.ca + sp.cb;
+    return (maxnt + m - 1) / m * m * 16 + 8;   // room for the zero K padding
   };
   auto lds_need = [&](int RT, int mmd) {
     p->LD = ld_for(RT);
@@ -430,7 +434,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     if (want <= 16 * p->RT) p->rows_per_wg = want;
   }
   p->lds_bytes = lds_need(p->RT, p->mm_mode == 1 ? c.D : 0);   // also fixes p->LD for the chosen RT
-  p->CKB = ckb_for(p->RT);
+  { const StagePair sp = stages_for(p->RT); p->CA = sp.ca; p->CB = sp.cb; }
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
   p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
 
@@ -570,10 +574,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       default: rc2 = set_attr<4>(p->lds_bytes); break;
     }
   } else {
-#define PM_FAST_CASE(RTV, CK) \
-  if (p->RT == RTV && p->CKB == CK) rc2 = set_attr_fast<RTV, CK>(p->lds_bytes);
-    PM_FAST_CASE(1, 8) PM_FAST_CASE(1, 7) PM_FAST_CASE(1, 4) PM_FAST_CASE(1, 2)
-    PM_FAST_CASE(2, 4) PM_FAST_CASE(2, 2) PM_FAST_CASE(4, 2) PM_FAST_CASE(4, 1)
+#define PM_FAST_CASE(RTV, CAV, CBV) \
+  if (p->RT == RTV && p->CA == CAV && p->CB == CBV) rc2 = set_attr_fast<RTV, CAV, CBV>(p->lds_bytes);
+    PM_FAST_CASES
 #undef PM_FAST_CASE
   }
   if (p->mm_mode == 2) {
@@ -646,7 +649,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[8] = p->LD;
   info[9] = p->n_dw_blocks;
   info[10] = p->fast;
-  info[11] = p->CKB;
+  info[11] = p->CA * 16 + p->CB;
   return 0;
 }
 
@@ -721,8 +724,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
     const NetDev& P = A.pol;
     const NetDev& F = A.dyn;
-    const int ckb = p->CKB;
-    auto padk = [ckb](int nkb) { return (nkb + 2 * ckb - 1) / (2 * ckb) * (2 * ckb); };
+    const int pm = p->CA + p->CB;
+    auto padk = [pm](int nkb) { return (nkb + pm - 1) / pm * pm; };
     StreamDesc& f = A.sd_fwd;
     f.n = 0;
     for (int l = 1; l < P.nl - 1; ++l) { f.wf[f.n] = P.wf[l]; f.n_ot[f.n] = P.nt[l + 1]; f.n_kb[f.n] = padk(P.nt[l]); f.n++; }
@@ -747,11 +750,11 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   return 0;
 }
 
-static void pack_jobs(const NetPlan& n, char* ws, const float* params, int ckb, PackArgs& P) {
+static void pack_jobs(const NetPlan& n, char* ws, const float* params, int pair_kb, PackArgs& P) {
   for (int l = 0; l < n.nl; ++l) {
     const int O = n.dim[l + 1], K = n.dim[l];
-    // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to 2*CKB
-    const int mult = (ckb >= 1 && l >= 1 && l <= n.nl - 2) ? 2 * ckb : 1;
+    // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to CA+CB
+    const int mult = (pair_kb >= 1 && l >= 1 && l <= n.nl - 2) ? pair_kb : 1;
     P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wf[l]), O, K, 0, mult, 0};
     P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wb[l]), O, K, 1, mult, 0};
     P.job[P.n++] = PackJob{params + n.b_off[l], reinterpret_cast<float*>(ws + n.bias[l]), O, K, 0, 1, 1};
@@ -766,18 +769,17 @@ template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
-template <int RT, int CKB>
+template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   if (fwd)
-    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CKB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
+    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CA, CB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
   else
-    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CKB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
+    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CA, CB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
 }
 static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-#define PM_FAST_CASE(RTV, CK) \
-  if (p->RT == RTV && p->CKB == CK) return launch_fast<RTV, CK>(p, A, s, fwd);
-  PM_FAST_CASE(1, 8) PM_FAST_CASE(1, 7) PM_FAST_CASE(1, 4) PM_FAST_CASE(1, 2)
-  PM_FAST_CASE(2, 4) PM_FAST_CASE(2, 2) PM_FAST_CASE(4, 2) PM_FAST_CASE(4, 1)
+#define PM_FAST_CASE(RTV, CAV, CBV) \
+  if (p->RT == RTV && p->CA == CAV && p->CB == CBV) return launch_fast<RTV, CAV, CBV>(p, A, s, fwd);
+  PM_FAST_CASES
 #undef PM_FAST_CASE
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
@@ -815,8 +817,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
     PackArgs PK;
     PK.n = 0;
-    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CKB : 0, PK);
-    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CKB : 0, PK);
+    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK);
+    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK);
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
     hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }

@@ -182,10 +182,11 @@ __device__ __forceinline__ void frag_load(FragS<CKB>& f, const Cursor& q, unsign
   if constexpr (CKB > 6) pm_ldw<2048>(f.a[6], vo1, wp);
   if constexpr (CKB > 7) pm_ldw<3072>(f.a[7], vo1, wp);
 }
-// everything older than the CKB most recent VMEM operations has landed; `f` is usable
-template <int CKB>
+// everything older than the NOTHER most recent VMEM operations (the loads of the other stage,
+// just issued) has landed; `f` is usable
+template <int CKB, int NOTHER>
 __device__ __forceinline__ void frag_wait(FragS<CKB>& f) {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CKB));
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOTHER));
 #pragma unroll
   for (int cc = 0; cc < CKB; ++cc) asm volatile("" : "+v"(f.a[cc]));
 }
@@ -207,7 +208,7 @@ __device__ __forceinline__ void bpair_load(BPair<RT>& b, const float* bp, int ld
 }
 
 template <int RT, int CKB>
-__device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, int c_next, const float* lds_in,
+__device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int kb0, int kb0_next, const float* lds_in,
                                              int ld, int lane, f32x4 (&acc)[2][RT], BPair<RT>& b0) {
   // Explicit one-pair-ahead software pipeline of the LDS (B operand) reads: while the 8*RT
   // MFMAs of k-block pair p issue, the reads of pair p+1 are already in flight -- ACROSS chunk
@@ -216,8 +217,8 @@ __device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, int c_n
   // sched_barriers pin that order (left alone, the scheduler sinks each read to just before
   // its first use and every pair pays the LDS latency).
   const float* base = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
-  const float* bp = base + c * CKB * 16;
-  const float* bpn = base + c_next * CKB * 16;
+  const float* bp = base + kb0 * 16;      // this chunk starts at k-block kb0
+  const float* bpn = base + kb0_next * 16;
   constexpr int NP = (CKB + 1) / 2;
   BPair<RT> b[2];
   b[0] = b0;
@@ -249,19 +250,19 @@ __device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int c, int c_n
 // processing order reaches next, `q` is the chunk after it.  The epilogue of tile i runs at
 // the start of tile i+1, after that tile's first loads have been issued and waited for:
 // at every frag_wait the only younger VMEM operations are the CKB loads just issued.
-template <int RT, int CKB, class Epi>
-__device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, FragS<CKB>& fa,
-                                             FragS<CKB>& fb, const float* lds_in, int ld,
+template <int RT, int CA, int CB, class Epi>
+__device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, FragS<CA>& fa,
+                                             FragS<CB>& fb, const float* lds_in, int ld,
                                              int wid, int lane, Epi& epi, unsigned vo0, unsigned vo1,
                                              long long* prof = nullptr) {
   // On entry the load cursor is one chunk ahead INSIDE layer li (every layer has >= 2 chunks per
   // tile), unless this wave owns no tile of it: the layer shape is already in SGPRs.
   if (!q.live || q.li != li) return;
   const int n_ot = q.n_ot;
-  const int nch2 = q.n_kb / (2 * CKB);
+  const int nch2 = q.n_kb / (CA + CB);
   int pslot = 24;
   BPair<RT> b0;
-  bpair_load<RT, CKB>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
+  bpair_load<RT, CA>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
   f32x4 pacc[RT];
   typename Epi::Pre ppre[RT];
   int pot = -1;
@@ -277,9 +278,9 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
       for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     int c2 = 0;
     do {   // nch2 >= 1: the body (and its waits) runs at least once per tile
-      frag_load<CKB>(fb, q, vo0, vo1);
-      cur_advance<CKB>(sd, q, wid);
-      frag_wait<CKB>(fa);
+      frag_load<CB>(fb, q, vo0, vo1);
+      cur_advance<CB>(sd, q, wid);
+      frag_wait<CA, CB>(fa);
       if (c2 == 0) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) epi.landed(pre[rt], rt);
@@ -288,11 +289,12 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
           for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
         }
       }
-      frag_compute<RT, CKB>(fa, 2 * c2, 2 * c2 + 1, lds_in, ld, lane, acc, b0);
-      frag_load<CKB>(fa, q, vo0, vo1);
-      cur_advance<CKB>(sd, q, wid);
-      frag_wait<CKB>(fb);
-      frag_compute<RT, CKB>(fb, 2 * c2 + 1, (c2 + 1 < nch2) ? 2 * c2 + 2 : 0, lds_in, ld, lane, acc, b0);
+      frag_compute<RT, CA>(fa, c2 * (CA + CB), c2 * (CA + CB) + CA, lds_in, ld, lane, acc, b0);
+      frag_load<CA>(fa, q, vo0, vo1);
+      cur_advance<CA>(sd, q, wid);
+      frag_wait<CB, CA>(fb);
+      frag_compute<RT, CB>(fb, c2 * (CA + CB) + CA, (c2 + 1 < nch2) ? (c2 + 1) * (CA + CB) : 0, lds_in, ld, lane,
+                           acc, b0);
     } while (++c2 < nch2);
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
@@ -713,7 +715,7 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 // ===========================================================================
 // forward (fast)
 // ===========================================================================
-template <int RT, int CKB>
+template <int RT, int CA, int CB>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -752,11 +754,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int n_pol_stream = P.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
-  FragS<CKB> fa, fb;
+  FragS<CA> fa;
+  FragS<CB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
-    frag_load<CKB>(fa, q, vo0, vo1);
-    cur_advance<CKB>(sd, q, wid);
+    frag_load<CA>(fa, q, vo0, vo1);
+    cur_advance<CA>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(2);
     for (int l = 1; l < pnl - 1; ++l) {
-      stream_layer<RT, CKB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1,
+      stream_layer<RT, CA, CB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1,
                             (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
       if (l + 1 < pnl - 1) es = pol_epi(l + 1, t, blk, X);
       __syncthreads();
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(12);
     for (int l = 1; l < fnl - 1; ++l) {
-      stream_layer<RT, CKB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      stream_layer<RT, CA, CB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
       if (l + 1 < fnl - 1) es = dyn_epi(l + 1, t, X);
       __syncthreads();
       PM_SWAP_XY();
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 // ===========================================================================
 // backward sweep (fast)
 // ===========================================================================
-template <int RT, int CKB>
+template <int RT, int CA, int CB>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -1001,11 +1004,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int n_dyn_stream = F.nl - 2;
   Cursor q;
   cur_init(sd, q, wid);
-  FragS<CKB> fa, fb;
+  FragS<CA> fa;
+  FragS<CB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
-    frag_load<CKB>(fa, q, vo0, vo1);
-    cur_advance<CKB>(sd, q, wid);
+    frag_load<CA>(fa, q, vo0, vo1);
+    cur_advance<CA>(sd, q, wid);
   }
   __syncthreads();
 
@@ -1148,7 +1152,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(4);
     for (int l = fnl - 2, si = 0; l >= 1; --l, ++si) {
-      stream_layer<RT, CKB>(sd, si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      stream_layer<RT, CA, CB>(sd, si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
       if (l - 1 >= 1) es = dyn_epi(l - 2, t, X);
       __syncthreads();
       PM_SWAP_XY();
@@ -1220,7 +1224,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(14);
     for (int l = pnl - 2, si = 0; l >= 1; --l, ++si) {
-      stream_layer<RT, CKB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      stream_layer<RT, CA, CB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
       if (l - 1 >= 1) es = pol_epi(l - 2, t, blk, X);
       __syncthreads();
       PM_SWAP_XY();
