@@ -262,7 +262,8 @@ struct pmbrl_plan {
   NetPlan pol, dyn;
   RewardDev* rew_d;
   DwBlock* dw_blocks_d;
-  int n_dw_blocks, dw_npass, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
       off_gxc, off_grt, off_Jx, off_Ja, ws_bytes;
@@ -480,8 +481,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
   }
-  // dW wave blocks: balanced splits of every layer's output tile grid into <= 4 x 8 tile
-  // blocks, consecutive blocks (neighbours in the grid) fill the 8 wave slots of a pass
+  // dW wave blocks: balanced splits of every layer's output tile grid into <= 4 x 7 tile
+  // blocks, dealt to the four SIMDs (waves w and w+4 share SIMD w) by decreasing size so that
+  // every SIMD issues the same number of MFMAs
   {
     std::vector<DwBlock> blocks;
     auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
@@ -493,13 +495,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         lo += sz;
       }
     };
-    // widest layers first so that a pass is filled with blocks of one layer when possible
-    std::vector<int> order;
-    for (int l = 0; l < p->pol.nl; ++l) order.push_back(l);
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-      return p->pol.nt[a] * p->pol.nt[a + 1] > p->pol.nt[b] * p->pol.nt[b + 1];
-    });
-    for (int l : order) {
+    for (int l = 0; l < p->pol.nl; ++l) {
       std::vector<std::pair<int, int>> os, is;
       split(p->pol.nt[l + 1], PM_DW_TM, os);
       split(p->pol.nt[l], PM_DW_TN, is);
@@ -516,13 +512,30 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         }
     }
     p->n_dw_blocks = (int)blocks.size();
-    p->dw_npass = (p->n_dw_blocks + PM_DW_NW - 1) / PM_DW_NW;
-    while ((int)blocks.size() < p->dw_npass * PM_DW_NW) {
-      DwBlock b;
-      memset(&b, 0, sizeof(b));
-      b.layer = -1;
-      blocks.push_back(b);
+    // cost of a block = MFMAs per chunk in the shape class it runs in (see pm_dw_kernel)
+    auto cost = [](const DwBlock& b) {
+      const int ni = b.n_ot <= 1 ? 1 : (b.n_ot <= 3 ? 3 : 4);
+      const int nj = b.n_it <= 1 ? 1 : (b.n_it <= 4 ? 4 : (b.n_it <= 6 ? 6 : 7));
+      return ni * nj;
+    };
+    std::stable_sort(blocks.begin(), blocks.end(),
+                     [&](const DwBlock& a, const DwBlock& b) { return cost(a) > cost(b); });
+    std::vector<DwBlock> per_wave[PM_DW_NW];
+    long wave_load[PM_DW_NW] = {0};
+    for (const DwBlock& b : blocks) {
+      int best_simd = 0;
+      for (int sm = 1; sm < 4; ++sm)
+        if (wave_load[sm] + wave_load[sm + 4] < wave_load[best_simd] + wave_load[best_simd + 4]) best_simd = sm;
+      const int w = wave_load[best_simd] <= wave_load[best_simd + 4] ? best_simd : best_simd + 4;
+      per_wave[w].push_back(b);
+      wave_load[w] += cost(b);
     }
+    blocks.clear();
+    for (int w = 0; w < PM_DW_NW; ++w) {
+      p->dw_wave_first[w] = (int)blocks.size();
+      for (const DwBlock& b : per_wave[w]) blocks.push_back(b);
+    }
+    p->dw_wave_first[PM_DW_NW] = (int)blocks.size();
     p->dw_n_chunks = c.H * p->nwg * p->RT;
     int nsplit = std::min(256, p->dw_n_chunks);   // one 8-wave workgroup per CU
     p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
@@ -910,7 +923,6 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   DwArgs W;
   memset(&W, 0, sizeof(W));
   W.nl = p->pol.nl;
-  W.npass = p->dw_npass;
   W.nsplit = p->dw_nsplit;
   W.n_chunks = p->dw_n_chunks;
   W.chunks_per_split = p->dw_chunks_per_split;
@@ -928,6 +940,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     W.gT[l] = A.gT[l];
   }
   W.blocks = p->dw_blocks_d;
+  for (int w = 0; w <= PM_DW_NW; ++w) W.wave_first[w] = p->dw_wave_first[w];
   W.part = reinterpret_cast<float*>(ws + p->off_part);
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW, s);

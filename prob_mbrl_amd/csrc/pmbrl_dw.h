@@ -6,40 +6,52 @@
 // four consecutive k-steps is one 16-byte global load, no LDS staging needed.
 //
 // Decomposition: a workgroup = 8 waves (2 per SIMD) owns a contiguous range of
-// row-step chunks (split-K) and walks ALL output wave blocks of all layers in
-// `npass` passes of 8 wave blocks.  A wave block is up to 4 x 8 tiles (128
-// accumulator registers); the 8 blocks of a pass are neighbours in the output
-// tile grid of one layer, so a stash chunk is fetched from HBM once per
-// workgroup and re-read by the other waves through L1/L2 (the first version,
-// 4x4 blocks spread over independent workgroups, read every chunk ~2.5 times
-// and was bound by that traffic).  Partial sums go to part[split][n_params] and
-// are added in a fixed order by pm_dw_reduce -> bit-reproducible gradients.
+// row-step chunks (split-K) and covers ALL output tiles of all layers.  The
+// output tile grid of every layer is cut into wave blocks of at most 4 x 7
+// tiles (112 accumulator registers); the host deals the blocks to the four SIMDs
+// by decreasing size (longest-processing-time first) so that every SIMD carries
+// the same number of MFMAs, and a wave walks its list of blocks one after the
+// other, each over the whole chunk range.  A stash chunk is fetched from HBM once
+// per workgroup and re-read by the other waves through L1/L2.  Partial sums go to
+// part[split][n_params] and are added in a fixed order by pm_dw_reduce ->
+// bit-reproducible gradients.
+//
+// Inner loop: a block is a compile-time NI x NJ tile shape (edge blocks repeat
+// their last tile: branch-free loads and MFMAs, the duplicates are not stored).
+// Operands are double-buffered in registers with inline-asm loads and explicit
+// s_waitcnt (same rules as the weight stream of pmbrl_fast.h, checked by
+// tools/check_inflight.py): the compiler's own waitcnt placement drained the
+// queue (vmcnt(0)) before every chunk, i.e. one exposed HBM round trip per chunk.
 #pragma once
 #include "pmbrl_dev.h"
 
 #define PM_DW_NW 8
 #define PM_DW_NT (PM_DW_NW * 64)
 #define PM_DW_TM 4
-#define PM_DW_TN 8
+#define PM_DW_TN 7
+#define PM_DW_MAXBLK 256
 
-struct DwBlock {      // one wave block; layer < 0: idle slot
+struct DwBlock {      // one wave block
   int16_t layer, ot0, it0, n_ot, n_it, pad;
 };
 
 struct DwArgs {
-  int nl, npass, nsplit, n_chunks, chunks_per_split;
+  int nl, nsplit, n_chunks, chunks_per_split;
   int RT, Rw, n_params;
   int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
   int w_off[PM_MAXL], b_off[PM_MAXL];    // offsets in the flat parameter vector
   const float* actT[PM_MAXL];
   const float* gT[PM_MAXL];
-  const DwBlock* blocks;  // [npass][PM_DW_NW]
-  float* part;            // [nsplit][n_params]
+  const DwBlock* blocks;                 // sorted by wave
+  int wave_first[PM_DW_NW + 1];          // wave w owns blocks [wave_first[w], wave_first[w+1])
+  float* part;                           // [nsplit][n_params]
 };
 
-// one wave block with at most NJ input-tile columns (NJ is static so that narrow layers --
-// the first layer's K <= 16, the head's 2U outputs -- do not pay for 8 columns)
-template <int NJ>
+__device__ __forceinline__ void pm_dw_ld(f32x4& d, unsigned voff, const float* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
+}
+
+template <int NI, int NJ>
 __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
                                             float* part, int lane) {
   const int g = lane >> 4, c16 = lane & 15;
@@ -48,64 +60,80 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
   const float* gbase = A.gT[l];
   const float* abase = A.actT[l];
   const size_t gblk = (size_t)Fo16 * A.Rw, ablk = (size_t)Fi16 * A.Rw;
-  // per-lane offsets inside a (t,wg) block for row tile rt: (feature)*Rw + rt*16 + 4g
-  const int goff0 = (blk.ot0 * 16 + c16) * A.Rw + 4 * g;
-  const int aoff0 = (blk.it0 * 16 + c16) * A.Rw + 4 * g;
-  const int tstride = 16 * A.Rw;
-
-  f32x4 acc[PM_DW_TM][NJ];
-  float bsum[PM_DW_TM];
+  // per-lane byte offsets inside a (t, wg) block: (feature) * Rw + 4g ; tiles past the edge of
+  // the block repeat its last tile
+  unsigned goff[NI], aoff[NJ];
 #pragma unroll
-  for (int i = 0; i < PM_DW_TM; ++i) {
+  for (int i = 0; i < NI; ++i) {
+    const int ot = blk.ot0 + (i < blk.n_ot ? i : blk.n_ot - 1);
+    goff[i] = (unsigned)(((ot * 16 + c16) * A.Rw + 4 * g) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int it = blk.it0 + (j < blk.n_it ? j : blk.n_it - 1);
+    aoff[j] = (unsigned)(((it * 16 + c16) * A.Rw + 4 * g) * 4);
+  }
+
+  f32x4 acc[NI][NJ];
+  float bsum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
     bsum[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool do_bias = blk.it0 == 0;
   // register double buffer: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
-  f32x4 ga[2][PM_DW_TM], aa[2][NJ];
+  f32x4 ga[2][NI], aa[2][NJ];
   auto load = [&](int buf, int c) {
-    if (c < c_hi) {
-      const int b = c / A.RT, rt = c - b * A.RT;
-      const float* gp = gbase + (size_t)b * gblk + rt * 16 + goff0;
-      const float* ap = abase + (size_t)b * ablk + rt * 16 + aoff0;
+    const int cc = c < c_hi ? c : c_hi - 1;     // past the end: harmless re-load of the last chunk
+    const int b = cc / A.RT, rt = cc - b * A.RT;
+    const float* gp = gbase + (size_t)b * gblk + rt * 16;
+    const float* ap = abase + (size_t)b * ablk + rt * 16;
 #pragma unroll
-      for (int i = 0; i < PM_DW_TM; ++i)
-        ga[buf][i] = (i < blk.n_ot) ? ldg4(gp + i * tstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; ++i) pm_dw_ld(ga[buf][i], goff[i], gp);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        aa[buf][j] = (j < blk.n_it) ? ldg4(ap + j * tstride) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < NJ; ++j) pm_dw_ld(aa[buf][j], aoff[j], ap);
   };
-  auto compute = [&](int buf, int c) {
-    if (c < c_hi) {
-      // absent columns carry zero operands; absent rows are skipped with one uniform branch
+  // everything but the NI+NJ loads just issued (the other buffer) has landed
+  auto wait = [&](int buf) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + NJ));
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(ga[buf][i]));
 #pragma unroll
-        for (int i = 0; i < PM_DW_TM; ++i)
-          if (i < blk.n_ot) {
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(aa[buf][j]));
+  };
+  auto compute = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
-          }
-      if (do_bias) {
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int i = 0; i < PM_DW_TM; ++i)
-          bsum[i] += (ga[buf][i][0] + ga[buf][i][1]) + (ga[buf][i][2] + ga[buf][i][3]);
-      }
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        bsum[i] += (ga[buf][i][0] + ga[buf][i][1]) + (ga[buf][i][2] + ga[buf][i][3]);
     }
   };
   load(0, c_lo);
   for (int c = c_lo; c < c_hi; c += 2) {
     load(1, c + 1);
-    compute(0, c);
+    wait(0);
+    compute(0);
     load(0, c + 2);
-    compute(1, c + 1);
+    wait(1);
+    if (c + 1 < c_hi) compute(1);
   }
+  asm volatile("s_waitcnt vmcnt(0)");   // drain the look-ahead loads before the registers are reused
+#pragma unroll
+  for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(ga[0][i]));
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(aa[0][j]));
   // write the partial tile: lane holds dW[o = ot*16 + 4g + r][k = it*16 + c16]
   const int O = A.dim[l + 1], K = A.dim[l];
 #pragma unroll
-  for (int i = 0; i < PM_DW_TM; ++i)
+  for (int i = 0; i < NI; ++i)
     if (i < blk.n_ot) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -127,19 +155,30 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
     }
 }
 
+// block shape classes: NI in {1, 3, 4}, NJ in {1, 4, 6, 7} (a block runs in the smallest
+// class that holds it)
+template <int NI>
+__device__ __forceinline__ void pm_dw_dispatch_j(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
+                                                 float* part, int lane) {
+  if (blk.n_it <= 1) pm_dw_block<NI, 1>(A, blk, c_lo, c_hi, part, lane);
+  else if (blk.n_it <= 4) pm_dw_block<NI, 4>(A, blk, c_lo, c_hi, part, lane);
+  else if (blk.n_it <= 6) pm_dw_block<NI, 6>(A, blk, c_lo, c_hi, part, lane);
+  else pm_dw_block<NI, 7>(A, blk, c_lo, c_hi, part, lane);
+}
+
 __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
   const int c_lo = split * A.chunks_per_split;
   const int c_hi = min(A.n_chunks, c_lo + A.chunks_per_split);
+  if (c_lo >= c_hi) return;
   float* part = A.part + (size_t)split * A.n_params;
-  for (int pass = 0; pass < A.npass; ++pass) {
-    const DwBlock blk = A.blocks[pass * PM_DW_NW + wid];
-    if (blk.layer < 0) continue;
-    if (blk.n_it <= 1) pm_dw_block<1>(A, blk, c_lo, c_hi, part, lane);
-    else if (blk.n_it <= 4) pm_dw_block<4>(A, blk, c_lo, c_hi, part, lane);
-    else pm_dw_block<PM_DW_TN>(A, blk, c_lo, c_hi, part, lane);
+  for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
+    const DwBlock blk = A.blocks[bi];
+    if (blk.n_ot <= 1) pm_dw_dispatch_j<1>(A, blk, c_lo, c_hi, part, lane);
+    else if (blk.n_ot <= 3) pm_dw_dispatch_j<3>(A, blk, c_lo, c_hi, part, lane);
+    else pm_dw_dispatch_j<4>(A, blk, c_lo, c_hi, part, lane);
   }
 }
 
