@@ -48,7 +48,11 @@ struct DwArgs {
 };
 
 __device__ __forceinline__ void pm_dw_ld(f32x4& d, unsigned voff, const float* sbase) {
+#ifdef PM_EXP_DW_NOLOAD
+  asm volatile("" : "=v"(d) : "v"(voff), "s"(sbase));
+#else
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
+#endif
 }
 
 template <int NI, int NJ>
@@ -109,7 +113,13 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) {
+#ifdef PM_EXP_DW_NOMFMA
+          if (kk == 0) acc[i][j][0] += ga[buf][i][0] * aa[buf][j][0];
+#else
+          acc[i][j] = mfma4(ga[buf][i][kk], aa[buf][j][kk], acc[i][j]);
+#endif
+        }
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
