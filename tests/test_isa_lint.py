@@ -1,0 +1,35 @@
+"""The fast sweep kernels and the dW GEMM issue some loads through inline asm and wait for them
+with explicit s_waitcnt (prob_mbrl_amd/csrc/pmbrl_fast.h, pmbrl_dw.h).  This compiles the
+device code to ISA and checks that no instruction touches a register whose load is still in
+flight (tools/check_inflight.py) -- a register-allocator copy or spill there would be a silent
+data corruption that only shows on some shapes."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = '/opt/rocm/bin/hipcc'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+def test_no_instruction_touches_in_flight_registers(tmp_path):
+    csrc = os.path.join(ROOT, 'prob_mbrl_amd', 'csrc')
+    out = str(tmp_path / 'pmbrl.s')
+    subprocess.check_call([HIPCC, '-w', '--offload-arch=gfx950', '-O3', '-std=c++17',
+                           '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
+                           os.path.join(csrc, 'pmbrl.hip'), '-o', out], cwd=csrc)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_inflight as CI
+    funcs = CI.parse_functions(out)
+    names = [n for n in funcs if 'fast' in n or 'pm_dw_kernel' in n]
+    assert len(names) >= 17, names          # 8 fwd + 8 bwd instantiations + the dW kernel
+    total_loads = 0
+    for n in names:
+        bad, nload, _ = CI.check_function(n, funcs[n])
+        assert bad == 0, '%s: %d in-flight register violations' % (n, bad)
+        total_loads += nload
+    assert total_loads > 500
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
