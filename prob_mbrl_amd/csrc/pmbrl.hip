@@ -108,12 +108,16 @@ __global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __res
   }
   __syncthreads();
   if (ticket == gridDim.x - 1) {          // last block: every partial is published
+    // fixed-shape tree over the published partials (deterministic), not a serial chain of
+    // L2 round trips
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double t = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+      t += __hip_atomic_load(&g_red_part[0][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tt = pm_block_sum(t, sm);
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      double t = 0.0;
-      for (unsigned b = 0; b < gridDim.x; ++b)
-        t += __hip_atomic_load(&g_red_part[0][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[0] = (float)t;
+      out[0] = (float)tt;
       __hip_atomic_store(&g_red_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -167,9 +171,11 @@ struct PackJob {
 };
 struct PackArgs {
   int n;
+  int* status;      // reset to "no failure" by the same launch (nullptr: leave alone)
   PackJob job[6 * PM_MAXL];
 };
 __global__ void pm_pack_all(const PackArgs P) {
+  if (P.status && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *P.status = 0x7fffffff;
   const PackJob j = P.job[blockIdx.y];
   if (j.is_bias) {
     const int O16 = (j.O + 15) / 16 * 16;
@@ -840,8 +846,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     PK.n = 0;
     pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK);
     pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK);
+    PK.status = status_d;
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
-    hipLaunchKernelGGL(pm_set_int, dim3(1), dim3(1), 0, s, status_d, 0x7fffffff);
   }
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   {
