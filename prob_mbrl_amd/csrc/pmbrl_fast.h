@@ -600,6 +600,7 @@ struct FastLds {
   float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
   float *jx;                     // backward: dL/dx~ rows [R][16]
   float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
+  float *zs;                     // in-kernel moment matching: this step's noise rows [R][D]
   double* mm;
 };
 
@@ -615,7 +616,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n += (size_t)R * U + (size_t)R * D;                 // zp, zd
   n += 2 * (size_t)(D + U) + 3 * (size_t)D + 2 * (size_t)U;
   n = (n + 3) & ~(size_t)3;
-  n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U);   // jx, stg
+  n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U) + (size_t)R * D;   // jx, stg, zs
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
   return n;
@@ -652,6 +653,7 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   p = base + n;
   m.jx = p; p += (size_t)R * 16;
   m.stg = p; p += (size_t)R * (1 + 2 * D + 3 * U);
+  m.zs = p; p += (size_t)R * D;
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
   m.mm = reinterpret_cast<double*>(base + n);
   return m;
@@ -819,6 +821,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         X[r * LD + k] = v;
         st[(size_t)k * A.Rw + r] = v;
       }
+      if (mm_in) {
+        // this step's moment-matching noise rows -> LDS, a whole step before they are needed (the
+        // statistics loops of pm_mm_* would otherwise chase them through HBM one at a time)
+        const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+        const int z0 = pm_zrow0(t, A.row_off + row0, A.flags);
+        for (int i = tid; i < nvalid * D; i += PF_NT) {
+          const int r = i / D, d = i - r * D;
+          L.zs[i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
+        }
+      }
     }
     // ---- policy: first layer (resident), hidden layers (streamed), head K-split over the waves
     EpiFwdL<RT> es{};
@@ -944,8 +956,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
-                                  pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false,
+        const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, L.zs + lr0 * D, D, 0, 0, false,
                                   xa + lr0 * D, D, scr, lane);
         if (!ok && lane == 0) atomicMin(A.status, t);
       }
@@ -1114,14 +1125,21 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         const int r = i / D, d = i - r * D;
         Y[r * LD + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
       }
+      {
+        const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+        const int z0 = pm_zrow0(t, A.row_off + row0, A.flags);
+        for (int i = tid; i < nvalid * D; i += PF_NT) {
+          const int r = i / D, d = i - r * D;
+          L.zs[i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
+        }
+      }
       __syncthreads();
       const int gpw = A.rows_per_wg / A.M;
       for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, pm_zbase(A.zmm, D, t, A.Bg, A.flags), D,
-                  pm_zrow0(t, A.row_off + row0 + lr0, A.flags), A.Bg, false, gx + lr0 * D, D,
+        pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
                   gxt + lr0 * D, D, scr, lane);
       }
     }
