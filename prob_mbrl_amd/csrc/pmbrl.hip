@@ -321,7 +321,7 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
 // the instantiated (row tiles, stage pair) combinations -- keep in sync with stages_for()
 #define PM_FAST_CASES                                                                  \
   PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
-  PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
+  PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB>),
@@ -382,9 +382,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     return w;
   };
   auto stages_for = [&](int RT) {
-    static const StagePair cand1[] = {{8, 8}, {7, 6}, {4, 4}, {2, 2}}, cand2[] = {{4, 4}, {2, 2}}, cand4[] = {{2, 2}, {1, 1}};
+    static const StagePair cand1[] = {{8, 8}, {7, 6}, {4, 4}, {2, 2}}, cand2[] = {{4, 4}, {4, 3}, {2, 2}}, cand4[] = {{2, 2}, {1, 1}};
     const StagePair* cand = RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
-    const int nc = RT == 1 ? 4 : 2;
+    const int nc = RT == 1 ? 4 : (RT == 2 ? 3 : 2);
     StagePair best = cand[0];
     for (int i = 1; i < nc; ++i)
       if (stream_work(cand[i].ca + cand[i].cb) < stream_work(best.ca + best.cb)) best = cand[i];
