@@ -762,7 +762,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = padk(F.nt[l + 1]); b.n++; }
     for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = padk(P.nt[l + 1]); b.n++; }
     const size_t R = 16 * (size_t)p->RT;
-    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R + (size_t)PF_NW * p->RT * 256;   // up to and incl. L.hp
+    size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R +
+               (pm_fast_hp_alias((int)R, p->LD, p->RT) ? 0 : (size_t)PF_NW * p->RT * 256);   // up to and incl. the hp region
     for (int l = 0; l < P.nl; ++l) { A.fo.pbias[l] = (int)o; o += (size_t)P.nt[l + 1] * 16; }
     for (int l = 0; l < F.nl; ++l) { A.fo.dbias[l] = (int)o; o += (size_t)F.nt[l + 1] * 16; }
     for (int l = 0; l < P.nl - 1; ++l) { A.fo.pmask[l] = (int)o; o += (R * P.nt[l + 1] + 1) / 2; }

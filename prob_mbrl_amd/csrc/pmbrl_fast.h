@@ -595,7 +595,8 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
 // ---------------------------------------------------------------------------
 struct FastLds {
   float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr;
-  float *hp;                     // head / tail partial tiles [PF_NW][RT][64][4]
+  int hp_off;                    // head / tail partial tiles [PF_NW][RT][64][4]: offset from bufA, or -1 when
+                                 // they live in whichever activation buffer is idle (pm_fast_hp_alias)
   float* base;
   float *zp, *zd, *mx, *iSx, *my, *Sy, *lSy, *psc, *pbi;
   float *jx;                     // backward: dL/dx~ rows [R][16]
@@ -604,11 +605,17 @@ struct FastLds {
   double* mm;
 };
 
+// The partial head tiles are written while one activation buffer (the head's input) is being
+// read and the other is dead: when that buffer is large enough they live there and cost no LDS.
+__host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
+  return RT >= 4 && (size_t)R * LD >= (size_t)PF_NW * RT * 256;   // only where LDS is the constraint (64-row workgroups)
+}
+
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
                                                      int dnl, int mm_d) {
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
-  n += (size_t)PF_NW * RT * 256;
+  if (!pm_fast_hp_alias(R, LD, RT)) n += (size_t)PF_NW * RT * 256;
   for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
   for (int l = 0; l < dnl; ++l) n += (size_t)dnt[l + 1] * 16;
   for (int l = 0; l < pnl - 1; ++l) n += ((size_t)R * pnt[l + 1] + 1) / 2;
@@ -634,7 +641,11 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   m.gad = p; p += (size_t)R * 16;
   m.rr = p; p += R;
   m.gr = p; p += R;
-  m.hp = p; p += (size_t)PF_NW * RT * 256;
+  m.hp_off = -1;
+  if (!pm_fast_hp_alias(R, LD, RT)) {
+    m.hp_off = (int)(p - base);
+    p += (size_t)PF_NW * RT * 256;
+  }
   m.base = base;
   for (int l = 0; l < P.nl; ++l) p += (size_t)P.nt[l + 1] * 16;
   for (int l = 0; l < F.nl; ++l) p += (size_t)F.nt[l + 1] * 16;
@@ -712,6 +723,8 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
   }
 }
 
+// partial head tiles: fixed region, or the idle activation buffer (Y)
+#define PM_HP() (L.bufA + (L.hp_off >= 0 ? L.hp_off : (xsel ^ 1) * (R * LD)))
 #define PM_SWAP_XY() { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
 
 // ===========================================================================
@@ -804,13 +817,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int pol_head_kb = P.nt[P.nl - 1], dyn_head_kb = F.nt[F.nl - 1];
   const int pnl = P.nl, fnl = F.nl;
 
+  bool fed = false;   // the previous step's sampling phase already wrote this step's policy input
   for (int t = A.t0; t < A.t1; ++t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
-    if (t == A.t0 || mm_in) {
+    if (!fed) {
       // dynamics-state rows -> policy input tile (+ dW stash); later steps of the plain path
       // get this written by the previous step's sampling phase
       __syncthreads();
@@ -854,12 +868,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       PM_SWAP_XY();
       PM_MARK(2 + l);
     }
-    head_partial<RT>(hwp, pol_head_kb, X, LD, L.hp, wid, lane);
+    head_partial<RT>(hwp, pol_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PM_MARK(10);
     // ---- squash + dynamics input
     {
       const float* hb = pol_head_bias;
+      const float* hp = PM_HP();
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float v = 0.f;
@@ -867,8 +882,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           v = (xa[r * D + k] - L.mx[k]) * L.iSx[k];
         } else if (k < D + U) {
           const int j = k - D;
-          const float mu = hb[j] + head_value<RT>(L.hp, r, j);
-          const float ls = hb[U + j] + head_value<RT>(L.hp, r, U + j);
+          const float mu = hb[j] + head_value<RT>(hp, r, j);
+          const float ls = hb[U + j] + head_value<RT>(hp, r, U + j);
           float z = L.zp[r * U + j];
           asm volatile("" : "+v"(z));   // keep the LDS load a load (no select of LDS / HBM addresses -> FLAT)
           if (A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
@@ -909,21 +924,24 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       PM_SWAP_XY();
       PM_MARK(12 + l);
     }
-    head_partial<RT>(hwd, dyn_head_kb, X, LD, L.hp, wid, lane);
+    head_partial<RT>(hwd, dyn_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PM_MARK(20);
     // ---- sample next state; on the plain path also the next step's policy input tile
     {
       const float* hb = dyn_head_bias;
-      const bool feed = !mm_in && (t + 1 < A.t1);
+      const float* hp = PM_HP();
+      // (not when the partial tiles sit in bufA: the feed below writes there)
+      const bool feed = !mm_in && (t + 1 < A.t1) && !(L.hp_off < 0 && xsel == 1);
+      fed = feed;
       float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, d = i & 15;
         float xn = 0.f;
         if (d < D) {
           const int o_l = r * D + d;
-          const float mu = hb[d] + head_value<RT>(L.hp, r, d);
-          const float ls = hb[D + d] + head_value<RT>(L.hp, r, D + d);
+          const float mu = hb[d] + head_value<RT>(hp, r, d);
+          const float ls = hb[D + d] + head_value<RT>(hp, r, D + d);
           float z = L.zd[o_l];
           asm volatile("" : "+v"(z));
           if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
@@ -1108,6 +1126,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
 
   // Same phase pattern as the forward sweep: descriptors and the epilogue's activation bits
   // (HBM / L2 reads) are issued before the barrier that opens a phase.
+  bool pa_done = false;   // the previous step's last phase already ran this step's phase A
   for (int t = A.t1 - 1; t >= A.t0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
@@ -1146,7 +1165,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PM_MARK(1);
     // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input.
     //      On the plain path the previous step's last phase has already done this.
-    if (mm_in || t == A.t1 - 1) {
+    if (!pa_done) {
       __syncthreads();
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
@@ -1176,16 +1195,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PM_SWAP_XY();
       PM_MARK(4 + l);
     }
-    head_partial<RT>(twd, dyn_tail_kb, X, LD, L.hp, wid, lane);
+    head_partial<RT>(twd, dyn_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PM_MARK(12);
     // ---- phase B: tail result; state part -> gxn, action part -> policy head adjoint
     {
       float* gst = gT_head + blk * (size_t)16 * A.Rw;
+      const float* hp = PM_HP();
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         float tail = 0.f;
-        if (k < D + U) tail = head_value<RT>(L.hp, r, k) * L.iSx[k];
+        if (k < D + U) tail = head_value<RT>(hp, r, k) * L.iSx[k];
         if (k < D) gxn[r * D + k] += tail;
         if (k >= D && k < D + U) {
           const int j = k - D;
@@ -1248,24 +1268,28 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PM_SWAP_XY();
       PM_MARK(14 + l);
     }
-    head_partial<RT>(twp, pol_tail_kb, X, LD, L.hp, wid, lane);
+    head_partial<RT>(twp, pol_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PM_MARK(22);
     // ---- dL/dx_t = gxn + policy tail (+ external state gradient); on the plain path the same
     //      threads go straight on to phase A of step t-1 (its inputs were parked mid-step)
     {
-      if (!mm_in) gsel ^= 1;
+      const float* hp = PM_HP();
+      // phase A of step t-1 writes bufA: not while the partial tiles sit there
+      const bool do_pa = !mm_in && t > A.t0 && !(L.hp_off < 0 && xsel == 1);
+      pa_done = do_pa;
+      if (do_pa) gsel ^= 1;
       float* gxn_next = L.jx + (gsel ? xb_off : 0);
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         const int d = k < D ? k : k - D;
         float v = 0.f;
         if (k < 2 * D) {
-          v = gxn[r * D + d] + head_value<RT>(L.hp, r, d);
+          v = gxn[r * D + d] + head_value<RT>(hp, r, d);
           if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
           if (k < D) gx[r * D + d] = v;
         }
-        if (!mm_in && t > A.t0) phase_a(r, k, v, gxn_next);
+        if (do_pa) phase_a(r, k, v, gxn_next);
       }
       gxn = gxn_next;
     }
