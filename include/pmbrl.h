@@ -216,6 +216,34 @@ int pmbrl_plan_read_timing(pmbrl_plan* plan, float* ms /* [PMBRL_TIMER_COUNT] */
  * (forward into fwd_d, backward sweep into bwd_d; NULL = off). */
 int pmbrl_plan_set_prof(pmbrl_plan* plan, long long* fwd_d, long long* bwd_d);
 
+/* ---- stand-alone network evaluation ------------------------------------- */
+/* One Bayesian MLP with a diagonal-Gaussian head evaluated on B independent rows: what the
+ * reference's Policy.forward (models/core.py:221-248) and Regressor / DynamicsModel.forward
+ * (models/core.py:169-187, 265-303) compute outside a rollout (apply_controller, model
+ * evaluation):
+ *   xin = (x - in_shift) * in_iscale                      (both NULL: xin = x)
+ *   h   = relu(xin W0^T + b0) * mask0 / keep0 ; ...       (mask NULL: no dropout on that layer)
+ *   (mu, l) = split(h W_L^T + b_L) ;  l <- -softplus(-l + max_log_std) + max_log_std
+ *   out_scale/out_shift given:  mu <- mu*out_scale + out_shift ;  l <- l + log(out_scale)
+ *   sample = mu + z * exp(l)                              (z NULL: sample = mu)
+ *   sq_scale/sq_bias given:    sample <- sq_scale * tanh(sample) + sq_bias
+ * Outputs may be NULL.  mask_bits are bit rows as produced by pmbrl_pack_mask. */
+typedef struct {
+  int32_t B;                  /* rows */
+  pmbrl_mlp net;              /* dims[0] = input width, dims[n_layers] = 2 * output width */
+  float max_log_std;
+} pmbrl_mlp_call;
+
+size_t pmbrl_mlp_workspace_bytes(const pmbrl_mlp_call* call);
+int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* call, void* workspace_d,
+                      const float* x_d, const float* params_flat_d,
+                      const uint16_t* const* mask_bits_d /* [n_layers-1], entries may be NULL */,
+                      const float* z_d /* [B][n_out] or NULL */,
+                      const float* in_shift_d, const float* in_iscale_d,
+                      const float* out_scale_d, const float* out_shift_d,
+                      const float* sq_scale_d, const float* sq_bias_d,
+                      float* sample_d /* [B][n_out] */, float* mean_d, float* log_std_d);
+
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout
  * kernels use (R <= 64). */

@@ -28,6 +28,10 @@ class MLP(C.Structure):
                 ('keep', C.c_float * MAX_LAYERS)]
 
 
+class MlpCall(C.Structure):
+    _fields_ = [('B', C.c_int32), ('net', MLP), ('max_log_std', C.c_float)]
+
+
 class Reward(C.Structure):
     _fields_ = [('kind', C.c_int32), ('expand', C.c_int32),
                 ('n_angle', C.c_int32), ('angle_dims', C.c_int32 * MAX_ANGLE),
@@ -64,6 +68,7 @@ EXPORTS = [
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
     'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
+    'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward',
 ]
 
 _lib = None
@@ -105,6 +110,10 @@ def load():
     f64 = C.c_double
     lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64,
                                     f64, f64, vp]
+    lib.pmbrl_mlp_workspace_bytes.restype = C.c_size_t
+    lib.pmbrl_mlp_workspace_bytes.argtypes = [C.POINTER(MlpCall)]
+    lib.pmbrl_mlp_forward.restype = C.c_int
+    lib.pmbrl_mlp_forward.argtypes = [vp, C.POINTER(MlpCall), vp, vp, vp, C.POINTER(vp)] + [vp] * 10
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.pmbrl_plan_set_timing.restype = C.c_int

@@ -41,6 +41,71 @@ def pack_mask(mask):
     return bits
 
 
+def mlp_forward(x, params_flat, dims, keep, mask_bits=None, z=None, in_shift=None, in_iscale=None,
+                out_scale=None, out_shift=None, sq_scale=None, sq_bias=None, max_log_std=math.log(5.0),
+                want=('sample',)):
+    """Stand-alone evaluation of one Bayesian MLP with a diagonal-Gaussian head on the rows of x
+    (pmbrl_mlp_forward; models/core.py:169-187, 221-248).  dims = [n_in, h..., 2*n_out];
+    mask_bits: per hidden layer an int16 bit-row tensor (pack_mask) or None.
+    Returns a dict with the requested outputs among 'sample', 'mean', 'log_std' ([B, n_out])."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    B = x.shape[0]
+    nl = len(dims) - 1
+    assert x.shape[1] == dims[0] and dims[-1] % 2 == 0
+    n_out = dims[-1] // 2
+    call = _lib.MlpCall()
+    call.B = B
+    call.net.n_layers = nl
+    for i, d in enumerate(dims):
+        call.net.dims[i] = int(d)
+    for l in range(nl - 1):
+        call.net.keep[l] = float(keep[l])
+    call.max_log_std = float(max_log_std)
+    nbytes = lib.pmbrl_mlp_workspace_bytes(C.byref(call))
+    if nbytes == 0:
+        msg = lib.pmbrl_last_error()
+        raise ValueError('pmbrl_mlp_workspace_bytes: %s' % (msg.decode() if msg else 'bad shape'))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    masks = (C.c_void_p * max(nl - 1, 1))()
+    keepalive = []
+    for l in range(nl - 1):
+        m = mask_bits[l] if mask_bits is not None else None
+        if m is not None:
+            assert m.is_cuda and m.dtype == torch.int16 and m.shape == (B, (dims[l + 1] + 15) // 16)
+            m = m.contiguous()
+            keepalive.append(m)
+        masks[l] = m.data_ptr() if m is not None else None
+
+    def vec(t, n):
+        if t is None:
+            return None
+        t = t.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if t.numel() == 1 and n > 1:
+            t = t.expand(n).contiguous()
+        assert t.numel() == n
+        keepalive.append(t)
+        return t
+
+    in_shift, in_iscale = vec(in_shift, dims[0]), vec(in_iscale, dims[0])
+    out_scale, out_shift = vec(out_scale, n_out), vec(out_shift, n_out)
+    sq_scale, sq_bias = vec(sq_scale, n_out), vec(sq_bias, n_out)
+    if z is not None:
+        assert z.is_cuda and z.dtype == torch.float32 and z.shape == (B, n_out)
+        z = z.contiguous()
+    out = {k: torch.empty((B, n_out), dtype=torch.float32, device=x.device) for k in want}
+    pf = params_flat.contiguous()
+
+    def p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    _lib.check(lib.pmbrl_mlp_forward(_stream(), C.byref(call), p(ws), p(x), p(pf), masks, p(z),
+                                     p(in_shift), p(in_iscale), p(out_scale), p(out_shift),
+                                     p(sq_scale), p(sq_bias), p(out.get('sample')), p(out.get('mean')),
+                                     p(out.get('log_std'))), 'pmbrl_mlp_forward')
+    return out
+
+
 def make_reward_struct(spec, D, U):
     """spec: dict(kind, expand, angle_dims, C [k,De], tip_target [k], norm, w,
     Q [k,k], R [U,U]) with numpy / float entries."""

@@ -74,10 +74,24 @@ class BDropout(StochasticModule):
             self.update_noise(torch.empty(B, width))
         return self.noise
 
+    def forward_mask(self, B, width, resample=True, seed=None):
+        """The {0,1} mask a stand-alone forward over B rows applies, with the reference's
+        rules (models/modules.py:46-61): redraw-and-store when the stored mask cannot be
+        reused, a fresh unstored draw when `resample`, else the stored rows."""
+        n = self.noise
+        if n.dim() != 2 or n.shape[1] != width or B > n.shape[0]:
+            self.update_noise(torch.empty(B, width), seed)
+        elif resample:
+            if seed is not None:
+                torch.manual_seed(int(seed))
+            self.p = 1 - self.rate
+            return torch.bernoulli(self.p.expand(B, width).to(self.noise.device))
+        return self.noise[:B]
+
     def forward(self, x, resample=True, mask_dims=2, seed=None, **kwargs):
         raise NotImplementedError(
-            'stand-alone module forward is not part of the accelerated path; use '
-            'prob_mbrl_amd.utils.rollout / algorithms.mc_pilco')
+            'a dropout layer is not evaluated on its own on the device path; call the network '
+            '(Policy / Regressor / DynamicsModel) or prob_mbrl_amd.utils.rollout')
 
     def extra_repr(self):
         return 'rate={}, regularizer_scale={}'.format(self.rate, self.regularizer_scale)
@@ -123,6 +137,28 @@ class CDropout(BDropout):
     def keep_prob(self):
         return 1.0   # x * concrete_noise, no division (models/modules.py:158-160)
 
+    def forward_mask(self, B, width, resample=False, seed=None):
+        """Eval-mode mask of a stand-alone forward (models/modules.py:120-160)."""
+        if self.training:
+            raise NotImplementedError('training-mode (relaxed) concrete dropout is not offered on '
+                                      'the device path; call .eval() first')
+        resampled = False
+        noise = self.noise
+        c = self.concrete_noise
+        if resample:
+            if seed is not None:
+                torch.manual_seed(int(seed))
+            noise = torch.rand(B, width, device=self.noise.device, dtype=self.noise.dtype)
+            resampled = True
+        elif (noise.dim() != 2 or c.dim() != 2 or noise.shape[1] != width or c.shape[1] != width
+              or B > c.shape[0]):
+            self.update_noise(torch.empty(B, width), seed)
+            noise = self.noise
+            resampled = True
+        if resampled:
+            self.update_concrete_noise(noise)
+        return self.concrete_noise.detach()[:B]
+
     def hard_mask(self, B, width):
         if self.training:
             raise NotImplementedError('training-mode (relaxed) concrete dropout is not on the '
@@ -154,10 +190,12 @@ class DiagGaussianDensity(StochasticModule):
             torch.manual_seed(int(seed))
         self.z.data = torch.randn_like(self.z)
 
-    def frozen_noise(self, B, resample_noise):
+    def frozen_noise(self, B, resample_noise, seed=None):
         """z [B, dims] with the reference's refresh rule (models/densities.py:113-116)."""
         D = int(self.output_dims)
         if tuple(self.z.shape) != (B, D) or resample_noise:
+            if seed is not None:
+                torch.manual_seed(int(seed))
             self.z.data = torch.randn(B, D, device=self.z.device, dtype=self.z.dtype)
         return self.z
 
@@ -211,7 +249,47 @@ class BSequential(nn.Sequential):
         return total
 
     def forward(self, input, **kwargs):
-        raise NotImplementedError('stand-alone network forward is not part of the accelerated path')
+        raise NotImplementedError('call the owning Policy / Regressor / DynamicsModel: the network is '
+                                  'evaluated by one device kernel together with its normalisation and head')
+
+    def device_forward(self, x, density, resample=True, seed=None, return_samples=False,
+                       resample_noise=True, in_shift=None, in_iscale=None, out_scale=None,
+                       out_shift=None, squash=None, **kwargs):
+        """Evaluate the network + Gaussian head on the rows of x with pmbrl_mlp_forward
+        (models/modules.py:215-232 + models/densities.py:87-121).  Returns samples [B, n_out]
+        (squashed if `squash=(scale, bias)`) or (mean, log_std)."""
+        from . import engine as E
+        from .rollout import flat_parameters
+        linears, drops, inner = self.layer_spec()
+        density = inner if inner is not None else density
+        if density is None:
+            raise NotImplementedError('a diagonal-Gaussian output density is required on the device path')
+        if not x.is_cuda:
+            raise RuntimeError('the network lives on a HIP device: pass a device tensor (no CPU fallback)')
+        x = x.to(torch.float32).contiguous()
+        B = x.shape[0]
+        dims = [linears[0].in_features] + [l.out_features for l in linears]
+        flat, _ = flat_parameters(linears, self)
+        keep, bits = [], []
+        for lin, dr in zip(linears[:-1], drops):
+            if dr is None:
+                keep.append(1.0)
+                bits.append(None)
+            else:
+                m = dr.forward_mask(B, lin.out_features, resample=resample, seed=seed)
+                keep.append(dr.keep_prob())
+                bits.append(E.pack_mask(m.to(device=x.device, dtype=torch.float32)))
+        z = None
+        if return_samples:
+            z = density.frozen_noise(B, resample_noise, seed).to(device=x.device, dtype=torch.float32)
+        out = E.mlp_forward(x, flat, dims, keep, bits, z, in_shift, in_iscale, out_scale, out_shift,
+                            squash[0] if (squash and return_samples) else None,
+                            squash[1] if (squash and return_samples) else None,
+                            max_log_std=float(density.max_log_std),
+                            want=('sample',) if return_samples else ('mean', 'log_std'))
+        if return_samples:
+            return out['sample']
+        return out['mean'], out['log_std']
 
     # --- structure the fused kernels understand ---------------------------
     def layer_spec(self):
@@ -333,7 +411,16 @@ class Regressor(_Loadable):
             self.output_density.resample(*args, **kwargs)
 
     def forward(self, x, normalize=True, **kwargs):
-        raise NotImplementedError('stand-alone Regressor forward is not part of the accelerated path')
+        """models/core.py:169-187: (mean, log_std) of the predictive Gaussian, or samples with
+        return_samples=True; one device kernel (pmbrl_mlp_forward)."""
+        if len(self.angle_dims) > 0:
+            from .utils import to_complex
+            x = to_complex(x, self.angle_dims)
+        kwargs.setdefault('resample', True)      # BSequential.forward's default (modules.py:215)
+        return self.model.device_forward(
+            x, self.output_density,
+            in_shift=self.mx if normalize else None, in_iscale=self.iSx if normalize else None,
+            out_scale=self.Sy if normalize else None, out_shift=self.my if normalize else None, **kwargs)
 
 
 class DynamicsModel(Regressor):
@@ -354,6 +441,27 @@ class DynamicsModel(Regressor):
         self.maxR.data = R.max()
         self.minR.data = R.min()
 
+    def forward(self, inputs, separate_outputs=False, deltas=True, **kwargs):
+        """models/core.py:265-303."""
+        as_tuple = isinstance(inputs, (tuple, list))
+        if as_tuple:
+            prev_states, actions = inputs[0], inputs[1]
+            inputs = torch.cat([prev_states, actions], -1)
+        outs = super().forward(inputs, **kwargs)
+        if not kwargs.get('return_samples', False):
+            return outs
+        if not as_tuple:
+            D = outs.shape[-1]
+            prev_states, actions = inputs[..., :D], inputs[..., D:]
+        if not callable(self.reward_func):
+            raise NotImplementedError('a learned reward head is not offered (the reference raises here too)')
+        dstates = outs
+        rewards = self.reward_func(prev_states + dstates, actions)
+        states = dstates if deltas else prev_states + dstates
+        if separate_outputs:
+            return states, rewards
+        return torch.cat([states, rewards], -1)
+
 
 class Policy(_Loadable):
     """models/core.py:190-248: BNN policy with tanh squashing to [minU, maxU]."""
@@ -373,5 +481,19 @@ class Policy(_Loadable):
         self.model.resample(*args, **kwargs)
 
     def forward(self, x, **kwargs):
-        raise NotImplementedError('stand-alone Policy forward is not part of the accelerated path '
-                                  'yet (SURVEY.md 8f N4); use prob_mbrl_amd.utils.rollout')
+        """models/core.py:221-248: squashed action samples for the rows of x (numpy in ->
+        numpy out, a single state -> one row), one device kernel (pmbrl_mlp_forward)."""
+        return_numpy = isinstance(x, np.ndarray)
+        kwargs['resample'] = kwargs.get('resample', True)
+        kwargs['return_samples'] = kwargs.get('return_samples', True)
+        x = torch.as_tensor(x, dtype=self.scale.dtype, device=self.scale.device)
+        if x.dim() == 1:
+            x = x[None, :]
+        if len(self.angle_dims) > 0:
+            from .utils import to_complex
+            x = to_complex(x, self.angle_dims)
+        u = self.model.device_forward(x, None, squash=(self.scale, self.bias), **kwargs)
+        if isinstance(u, tuple):
+            # return_samples=False: the reference adds the two heads before squashing (core.py:238-243)
+            u = self.scale * (u[0] + u[1]).tanh() + self.bias
+        return u.detach().cpu().numpy() if return_numpy else u

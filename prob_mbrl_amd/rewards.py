@@ -60,7 +60,22 @@ class AnalyticReward(nn.Module):
                     R=self.R.detach().cpu().numpy().astype(np.float64))
 
     def forward(self, x, u):
-        raise NotImplementedError('rewards are evaluated inside the fused rollout kernels')
+        """Stand-alone evaluation (what env.reward_func(x, u) does in the reference, outside
+        the rollout): a few small torch ops on whatever device x lives on.  Inside the fused
+        rollout the same constants are evaluated by the kernels."""
+        sp = self.spec(x.shape[-1])
+        kw = dict(dtype=x.dtype, device=x.device)
+        xa = x
+        if sp['expand']:
+            ad = list(sp['angle_dims'])
+            od = [i for i in range(x.shape[-1]) if i not in ad]
+            xa = torch.cat([x[..., od], x[..., ad].sin(), x[..., ad].cos()], -1)
+        Cm = torch.as_tensor(sp['C'], **kw)
+        delta = (xa @ Cm.t() - torch.as_tensor(sp['tip_target'], **kw)) / sp['norm']
+        Q = torch.as_tensor(sp['Q'], **kw)
+        R = torch.as_tensor(sp['R'], **kw)
+        cost = sp['w'] * (((delta @ Q) * delta).sum(-1, keepdim=True) + ((u @ R) * u).sum(-1, keepdim=True))
+        return (-cost).exp() if sp['kind'] == 'exp' else -cost
 
 
 class CartpoleReward(AnalyticReward):

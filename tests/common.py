@@ -12,7 +12,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 def fixture_names(kind=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
     if kind == 'iter':
-        return [n for n in names if not n.startswith('mcp_')]
+        return [n for n in names if not n.startswith('mcp_') and not n.startswith('standalone_')]
+    if kind == 'standalone':
+        return [n for n in names if n.startswith('standalone_')]
     if kind == 'mcp':
         return [n for n in names if n.startswith('mcp_')]
     return names
@@ -50,7 +52,7 @@ def modules_from_fixture(d, name, device='cuda:0'):
                                               pole2_length=torch.tensor(0.6))
     elif name.startswith('pend'):
         rew = pm.rewards.PendulumReward(pole_length=torch.tensor(1.0))
-    elif name.startswith('rdv'):
+    elif name.startswith('rdv') or name.endswith('_u4'):
         rew = pm.rewards.RendezvousReward()
     else:
         rew = pm.rewards.CartpoleReward(pole_length=torch.tensor(0.5))

@@ -147,3 +147,41 @@ def test_checkpoint_roundtrip_and_resample():
     s, a, r = pm.utils.rollout(x0, dyn, pol, 4, resample_state_noise=False,
                                resample_action_noise=False)
     assert torch.isfinite(torch.stack(s)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', common.fixture_names('standalone'))
+def test_standalone_forwards_match_reference(name):
+    """Policy.forward / Regressor.forward / DynamicsModel.forward outside a rollout
+    (models/core.py:169-187, 221-248, 265-303) through pmbrl_mlp_forward."""
+    d = common.load(name)
+    dyn, pol = common.modules_from_fixture(d, name)
+    dev = torch.device('cuda:0')
+    x = torch.tensor(d['x0'], dtype=torch.float32, device=dev)
+    tol = dict(rtol=3e-5, atol=3e-6)
+    a = pol(x, resample=False, return_samples=True, resample_noise=False)
+    assert a.shape == d['ref32_act'].shape and a.is_cuda
+    assert np.allclose(a.cpu().numpy(), d['ref64_act'], **tol)
+    a_ns = pol(x, resample=False, return_samples=False)
+    assert np.allclose(a_ns.cpu().numpy(), d['ref64_act_nosample'], **tol)
+    mean, log_std = dyn((x, a), resample=False)
+    assert np.allclose(mean.cpu().numpy(), d['ref64_dyn_mean'], **tol)
+    assert np.allclose(log_std.cpu().numpy(), d['ref64_dyn_log_std'], **tol)
+    nxt, rew = dyn((x, a), return_samples=True, separate_outputs=True, deltas=False, resample=False,
+                   resample_noise=False)
+    assert np.allclose(nxt.cpu().numpy(), d['ref64_next'], **tol)
+    assert np.allclose(rew.cpu().numpy().reshape(-1, 1), d['ref64_rew'], **tol)
+    dlt, _ = dyn((x, a), return_samples=True, separate_outputs=True, deltas=True, resample=False,
+                 resample_noise=False)
+    assert np.allclose(dlt.cpu().numpy(), d['ref64_delta'], rtol=1e-4, atol=1e-6)
+    # numpy in -> numpy out, a single state -> one row, fewer rows than the stored mask reuse its first rows
+    a1 = pol(np.asarray(d['x0'][0], dtype=np.float32), resample=False, resample_noise=False)
+    assert isinstance(a1, np.ndarray) and a1.shape == (1, a.shape[1])
+    a5 = pol(x[:5], resample=False, resample_noise=True)
+    assert a5.shape == (5, a.shape[1]) and bool(torch.isfinite(a5).all())
+    # resample=True: fresh masks -> different but bounded actions (|a| <= scale + |bias|)
+    b1 = pol(x, resample=True, resample_noise=True)
+    b2 = pol(x, resample=True, resample_noise=True)
+    assert not torch.equal(b1, b2)
+    bound = (pol.scale.abs() + pol.bias.abs()).to(dev) + 1e-5
+    assert bool((b1.abs() <= bound).all())

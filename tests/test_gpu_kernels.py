@@ -189,3 +189,43 @@ def test_failure_is_reported_not_nan(dev):
     eng, args, _ = common.engine_from_fixture(d, dev)
     eng.forward(**args)
     assert eng.valid_steps() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,dims', [(1, [5, 200, 200, 2]), (37, [9, 48, 24, 40, 8]), (100, [4, 16, 2])])
+def test_mlp_forward_matches_torch(B, dims):
+    """pmbrl_mlp_forward (stand-alone BNN + Gaussian head) against a plain torch fp32 evaluation
+    of the same formula (models/core.py:169-187, models/densities.py:87-121)."""
+    from prob_mbrl_amd import engine as E
+    g = torch.Generator().manual_seed(B + len(dims))
+    dev = torch.device('cuda:0')
+    nl = len(dims) - 1
+    n_out = dims[-1] // 2
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i]) for i in range(nl)]
+    bs = [0.1 * torch.randn(dims[i + 1], generator=g) for i in range(nl)]
+    masks = [(torch.rand(B, dims[i + 1], generator=g) < 0.8).float() for i in range(nl - 1)]
+    masks[0] = None if nl > 2 else masks[0]          # one layer without dropout
+    keep = [0.8 if m is not None else 1.0 for m in masks]
+    x = torch.randn(B, dims[0], generator=g)
+    z = torch.randn(B, n_out, generator=g)
+    shift, iscale = torch.randn(dims[0], generator=g), 0.5 + torch.rand(dims[0], generator=g)
+    osc, osh = 0.5 + torch.rand(n_out, generator=g), torch.randn(n_out, generator=g)
+    sqs, sqb = 1.0 + torch.rand(n_out, generator=g), 0.1 * torch.randn(n_out, generator=g)
+    h = (x - shift) * iscale
+    for i in range(nl - 1):
+        h = torch.relu(h @ Ws[i].t() + bs[i])
+        if masks[i] is not None:
+            h = h * masks[i] / keep[i]
+    o = h @ Ws[-1].t() + bs[-1]
+    mu, ls = o[:, :n_out], o[:, n_out:]
+    mls = float(np.log(5.0))
+    ls = -torch.nn.functional.softplus(-ls + mls) + mls + osc.log()
+    mu = mu * osc + osh
+    want = sqs * torch.tanh(mu + z * ls.exp()) + sqb
+    flat = torch.cat([t.reshape(-1) for pair in zip(Ws, bs) for t in pair]).to(dev)
+    bits = [E.pack_mask(m.to(dev)) if m is not None else None for m in masks]
+    out = E.mlp_forward(x.to(dev), flat, dims, keep, bits, z.to(dev), shift, iscale, osc, osh, sqs, sqb,
+                        max_log_std=mls, want=('sample', 'mean', 'log_std'))
+    assert np.allclose(out['mean'].cpu().numpy(), mu.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.allclose(out['log_std'].cpu().numpy(), ls.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.allclose(out['sample'].cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)

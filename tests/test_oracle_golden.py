@@ -83,3 +83,17 @@ def test_tile_layout():
     for g in range(3):
         for k in range(4):
             assert torch.equal(t[g * 4 + k], x[g])
+
+
+@pytest.mark.parametrize('name', common.fixture_names('standalone'))
+def test_oracle_standalone_forwards_match_reference(name):
+    """Policy.forward / DynamicsModel.forward outside a rollout (models/core.py:221-248, 265-303)."""
+    d = common.load(name)
+    for dt, tag, tol in ((torch.float32, 'ref32_', 2e-6), (torch.float64, 'ref64_', 3e-7)):   # the reference's .double() run keeps a few fp32-rounded constants
+        x, pol, dyn, spec, _, _, _, _ = R.problem_from_npz(d, dt)
+        a = R.policy_forward(x, pol)
+        assert np.allclose(a.numpy(), d[tag + 'act'], rtol=tol, atol=tol)
+        nxt, rew = R.dynamics_forward(x, a, dyn, spec)
+        assert np.allclose(nxt.numpy(), d[tag + 'next'], rtol=tol, atol=tol)
+        assert np.allclose(rew.numpy().reshape(-1, 1), d[tag + 'rew'], rtol=tol, atol=tol)
+        assert np.allclose((nxt - x).numpy(), d[tag + 'delta'], rtol=10 * tol, atol=10 * tol)

@@ -14,6 +14,7 @@ Usage:  python tools/make_golden.py [--out tests/golden] [--only name]
 import argparse
 import collections
 import collections.abc
+import copy
 import os
 import sys
 import types
@@ -353,6 +354,41 @@ def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
     return d
 
 
+def make_standalone_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, seed=11):
+    """Stand-alone Policy.forward / DynamicsModel.forward of the reference (models/core.py:221-248,
+    265-303) on B rows with the stored masks and noise (resample=False, resample_noise=False),
+    fp32 and fp64."""
+    print('[standalone] %s' % name)
+    rew = rew_fn()
+    dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
+    dyn.eval()
+    torch.manual_seed(seed + 1)
+    x = (0.3 * torch.randn(B, D)).float()
+    # prime masks / noise for B rows through the reference's own code paths
+    a0 = pol(x, resample=True, return_samples=True, resample_noise=True)
+    # resample=False: a shape mismatch makes CDropout redraw AND store noise of the batch shape
+    dyn((x, a0), return_samples=True, separate_outputs=True, resample=False, resample_noise=True)
+    d = capture_inputs(dyn, pol, x, 1, [1.0], False, False, None, None, None, True, False, rew)
+
+    def run(dt):
+        p2, d2 = pol.to(dt), dyn.to(dt)      # in place (the concrete masks are non-leaf: no deepcopy)
+        xx = x.to(dt)
+        a = p2(xx, resample=False, return_samples=True, resample_noise=False)
+        a_ms = p2(xx, resample=False, return_samples=False)      # squash(mean + log_std) quirk
+        mean, log_std = d2((xx, a), resample=False)
+        nxt, r = d2((xx, a), return_samples=True, separate_outputs=True, deltas=False,
+                    resample=False, resample_noise=False)
+        dlt, _ = d2((xx, a), return_samples=True, separate_outputs=True, deltas=True, resample=False,
+                    resample_noise=False)
+        return dict(act=a, act_nosample=a_ms, dyn_mean=mean, dyn_log_std=log_std, next=nxt,
+                    rew=r.reshape(-1, 1), delta=dlt)
+
+    for tag, dt in (('ref32_', torch.float32), ('ref64_', torch.float64)):
+        for k, v in run(dt).items():
+            d[tag + k] = v.detach().double().numpy()
+    return d
+
+
 def _cartpole():
     return CartpoleReward(pole_length=torch.tensor(0.5))
 
@@ -407,6 +443,9 @@ CASES = {
                                   mm=True, seed=15),
     'mmg_m80': lambda: make_case('mmg_m80', 4, 1, [16, 16], [16, 16], _cartpole, 10.0, 160, 6,
                                  mm=True, mm_groups=2, seed=16, P=2),
+    'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
+    'standalone_fwd_u4': lambda: make_standalone_case('standalone_fwd_u4', 8, 4, [48, 24, 40], [24, 24],
+                                                      lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
