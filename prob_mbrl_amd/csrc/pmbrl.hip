@@ -485,6 +485,17 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         r.R[i * c.U + j] = s.R[i * c.U + j];
         r.RR[i * c.U + j] = s.R[i * c.U + j] + s.R[j * c.U + i];
       }
+    for (int d = 0; d < PMBRL_MAX_DIM; ++d) r.d_copy[d] = r.d_sin[d] = r.d_cos[d] = -1;
+    if (s.expand) {
+      for (int i = 0; i < no; ++i) { r.phi_src[i] = r.other_dims[i]; r.phi_mode[i] = 0; r.d_copy[r.other_dims[i]] = i; }
+      for (int j = 0; j < r.n_angle; ++j) {
+        r.phi_src[no + j] = r.angle_dims[j]; r.phi_mode[no + j] = 1; r.d_sin[r.angle_dims[j]] = no + j;
+        r.phi_src[no + r.n_angle + j] = r.angle_dims[j]; r.phi_mode[no + r.n_angle + j] = 2;
+        r.d_cos[r.angle_dims[j]] = no + r.n_angle + j;
+      }
+    } else {
+      for (int i = 0; i < c.D; ++i) { r.phi_src[i] = i; r.phi_mode[i] = 0; r.d_copy[i] = i; }
+    }
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
   }

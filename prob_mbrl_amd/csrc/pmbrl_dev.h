@@ -54,6 +54,11 @@ struct RewardDev {
   float QQ[PMBRL_MAX_TIP * PMBRL_MAX_TIP];  // Q + Q^T
   float R[16 * 16];
   float RR[16 * 16];                        // R + R^T
+  // gather form of the feature map phi (pm_reward_all_kernel walks these instead of indexing
+  // per-thread arrays): phi_j = x[phi_src[j]] | sin(x[..]) | cos(x[..]) for phi_mode 0 | 1 | 2;
+  // state dim d feeds phi[d_copy[d]] (or -1) and, as an angle, phi[d_sin[d]] / phi[d_cos[d]]
+  int phi_src[PMBRL_MAX_DIM], phi_mode[PMBRL_MAX_DIM];
+  int d_copy[PMBRL_MAX_DIM], d_sin[PMBRL_MAX_DIM], d_cos[PMBRL_MAX_DIM];
 };
 
 // weight stream of the fast kernels: the hidden->hidden layers in processing order

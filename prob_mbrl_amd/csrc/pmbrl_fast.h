@@ -545,28 +545,86 @@ struct EpiBwdL {
 // All rewards of a rollout in one fully parallel pass: thread = one (t, b) row-step.
 // r~ -> rt (if rewards are moment matched afterwards) or rewards; d r~/d x~ -> Jx; d r~/d a -> Ja;
 // non-finite states / rewards are reported through the status word like in the sweep.
-__global__ void pm_reward_all_kernel(const RolloutArgs A) {
+__global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A) {
   const long long n = (long long)A.H * A.B;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int t = (int)(i / A.B);
   const int D = A.D, U = A.U;
+  const RewardDev* __restrict__ rw = A.rew;
   const float* xs = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i * D
                                                      : A.states + ((size_t)i + A.B) * D;
-  float x[PMBRL_MAX_DIM], a[16], jx[PMBRL_MAX_DIM], ja[16];
+  const float* as = A.actions + (size_t)i * U;
+  // No per-thread array is indexed at run time (that would live in scratch): the feature map is
+  // walked in gather form, x / a come from their (L1-resident) rows, only the k <= 8 tip
+  // residuals sit in registers with static indices.
+  const int k = rw->k, De = rw->De;
   bool ok = true;
-  for (int d = 0; d < D; ++d) {
-    x[d] = xs[d];
-    jx[d] = 0.f;
-    ok = ok && isfinite(x[d]);
+  for (int d = 0; d < D; ++d) ok = ok && isfinite(xs[d]);
+  float delta[PMBRL_MAX_TIP];
+#pragma unroll
+  for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] = 0.f;
+  for (int j = 0; j < De; ++j) {
+    const float xv = xs[rw->phi_src[j]];
+    const int md = rw->phi_mode[j];
+    const float ph = md == 0 ? xv : (md == 1 ? sinf(xv) : cosf(xv));
+#pragma unroll
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q)
+      if (q < k) delta[q] = fmaf(ph, rw->C[q * De + j], delta[q]);
   }
-  for (int j = 0; j < U; ++j) a[j] = A.actions[(size_t)i * U + j];
-  const float rv = reward_row(A.rew, x, D, a, U, nullptr);
+#pragma unroll
+  for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] -= (q < k) ? rw->tt[q] : 0.f;
+  float cost = 0.f;
+#pragma unroll
+  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p)
+      if (p < k && q < k) s = fmaf(delta[p], rw->Q[p * k + q], s);
+    if (q < k) cost = fmaf(s, delta[q], cost);
+  }
+  for (int q = 0; q < U; ++q) {
+    float s = 0.f;
+    for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->R[p * U + q], s);
+    cost = fmaf(s, as[q], cost);
+  }
+  cost *= rw->w;
+  const float rv = rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
   ok = ok && isfinite(rv);
   if (!ok) atomicMin(A.status, t);
-  reward_row_bwd(A.rew, x, D, a, U, rv, 1.f, jx, ja);
-  for (int d = 0; d < D; ++d) A.Jx[(size_t)i * D + d] = jx[d];
-  for (int j = 0; j < U; ++j) A.Ja[(size_t)i * U + j] = ja[j];
+  // adjoint with unit upstream gradient
+  const float gc = (rw->kind == PMBRL_REWARD_EXP ? -rv : -1.f) * rw->w;
+  float gdelta[PMBRL_MAX_TIP];
+#pragma unroll
+  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p)
+      if (p < k && q < k) s = fmaf(delta[p], rw->QQ[p * k + q], s);
+    gdelta[q] = gc * s;
+  }
+  auto gphi = [&](int j) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q)
+      if (q < k) s = fmaf(gdelta[q], rw->C[q * De + j], s);
+    return s;
+  };
+  for (int d = 0; d < D; ++d) {
+    float g = 0.f;
+    const int jc = rw->d_copy[d], js = rw->d_sin[d];
+    if (jc >= 0) g += gphi(jc);
+    if (js >= 0) {
+      const float th = xs[d];
+      g += gphi(js) * cosf(th) - gphi(rw->d_cos[d]) * sinf(th);
+    }
+    A.Jx[(size_t)i * D + d] = g;
+  }
+  for (int q = 0; q < U; ++q) {
+    float s = 0.f;
+    for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->RR[p * U + q], s);
+    A.Ja[(size_t)i * U + q] = gc * s;
+  }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[i] = rv;
   else A.rewards[i] = rv;
 }
