@@ -602,7 +602,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
-    p->off_part = take((size_t)p->dw_nsplit * p->pol.n_params * sizeof(float));
+    p->off_part = take((size_t)p->dw_nsplit * ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
   }
   int rc2 = 0;
@@ -956,6 +956,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   W.RT = p->RT;
   W.Rw = 16 * p->RT;
   W.n_params = (int)p->pol.n_params;
+  W.part_stride = (W.n_params + 3) / 4 * 4;
   for (int i = 0; i <= p->pol.nl; ++i) {
     W.dim[i] = p->pol.dim[i];
     W.nt[i] = p->pol.nt[i];
@@ -976,8 +977,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   const int n = (int)p->pol.n_params;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
-    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 31) / 32), dim3(256), 0, s, W.part, p->dw_nsplit, n,
-                       grad_pol_flat_d);
+    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
+                       W.part_stride, grad_pol_flat_d);
   }
   HIPCHK(hipGetLastError());
   return 0;

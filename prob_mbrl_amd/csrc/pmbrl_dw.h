@@ -38,6 +38,7 @@ struct DwBlock {      // one wave block
 struct DwArgs {
   int nl, nsplit, n_chunks, chunks_per_split;
   int RT, Rw, n_params;
+  int part_stride;                       // floats between the partial vectors of two splits (n_params rounded up to 4)
   int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
   int w_off[PM_MAXL], b_off[PM_MAXL];    // offsets in the flat parameter vector
   const float* actT[PM_MAXL];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
   const int c_lo = split * A.chunks_per_split;
   const int c_hi = min(A.n_chunks, c_lo + A.chunks_per_split);
   if (c_lo >= c_hi) return;
-  float* part = A.part + (size_t)split * A.n_params;
+  float* part = A.part + (size_t)split * A.part_stride;
   for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
     const DwBlock blk = A.blocks[bi];
     if (blk.n_ot <= 1) pm_dw_dispatch_j<1>(A, blk, c_lo, c_hi, part, lane);
@@ -192,24 +193,36 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
   }
 }
 
-// grad[i] = sum_s part[s][i] in fixed order; 32 parameters x 8 split-slices per workgroup
-__global__ __launch_bounds__(256) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
-                                                    float* __restrict__ grad) {
-  __shared__ float sm[8][33];
-  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + pi;
+// grad[i] = sum_s part[s][i] in fixed order.  A workgroup = 64 float4 columns x 8 slices of the
+// split range: every wave reads whole 1 KiB rows, a thread keeps 8 independent loads in flight.
+__global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
+                                                    int stride, float* __restrict__ grad) {
+  __shared__ f32x4 sm[8][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + col;            // float4 column
   const int per = (nsplit + 7) / 8;
-  float s = 0.f;
-  if (i < n) {
-    const int k_hi = min(nsplit, (sl + 1) * per);
-    for (int k = sl * per; k < k_hi; ++k) s += part[(size_t)k * n + i];
-  }
-  sm[sl][pi] = s;
-  __syncthreads();
-  if (sl == 0 && i < n) {
-    float t = 0.f;
+  const int k_lo = sl * per, k_hi = min(nsplit, k_lo + per);
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c4 * 4 < n) {
+    const float* p = part + (size_t)c4 * 4;
+    int k = k_lo;
+    for (; k + 8 <= k_hi; k += 8) {
+      f32x4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sm[k][pi];
-    grad[i] = t;
+      for (int u = 0; u < 8; ++u) v[u] = ldg4(p + (size_t)(k + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k_hi; ++k) s += ldg4(p + (size_t)k * stride);
+  }
+  sm[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && c4 * 4 < n) {
+    f32x4 t = sm[0][col];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sm[k][col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c4 * 4 + r < n) grad[c4 * 4 + r] = t[r];
   }
 }
