@@ -765,14 +765,27 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     const NetDev& F = A.dyn;
     const int pm = p->CA + p->CB;
     auto padk = [pm](int nkb) { return (nkb + pm - 1) / pm * pm; };
+    // streamed layer: weights, output tiles, padded / real k-blocks; a layer with 4m+1 output
+    // tiles hands its last tile to the K-split path (pm_fast_ksplit)
+    auto add_stream = [&](StreamDesc& sd, const float* wf, int n_ot, int n_kb_real, int& tw_off) {
+      const int i = sd.n++;
+      sd.wf[i] = wf;
+      sd.n_kb[i] = padk(n_kb_real);
+      sd.n_kb_real[i] = n_kb_real;
+      sd.ks[i] = pm_fast_ksplit(n_ot) ? 1 : 0;
+      sd.n_ot[i] = n_ot - sd.ks[i];
+      sd.tw_off[i] = tw_off;
+      if (sd.ks[i]) tw_off += n_kb_real * 256;
+    };
     StreamDesc& f = A.sd_fwd;
     f.n = 0;
-    for (int l = 1; l < P.nl - 1; ++l) { f.wf[f.n] = P.wf[l]; f.n_ot[f.n] = P.nt[l + 1]; f.n_kb[f.n] = padk(P.nt[l]); f.n++; }
-    for (int l = 1; l < F.nl - 1; ++l) { f.wf[f.n] = F.wf[l]; f.n_ot[f.n] = F.nt[l + 1]; f.n_kb[f.n] = padk(F.nt[l]); f.n++; }
+    int twf = 0, twb = 0;
+    for (int l = 1; l < P.nl - 1; ++l) add_stream(f, P.wf[l], P.nt[l + 1], P.nt[l], twf);
+    for (int l = 1; l < F.nl - 1; ++l) add_stream(f, F.wf[l], F.nt[l + 1], F.nt[l], twf);
     StreamDesc& b = A.sd_bwd;
     b.n = 0;
-    for (int l = F.nl - 2; l >= 1; --l) { b.wf[b.n] = F.wb[l]; b.n_ot[b.n] = F.nt[l]; b.n_kb[b.n] = padk(F.nt[l + 1]); b.n++; }
-    for (int l = P.nl - 2; l >= 1; --l) { b.wf[b.n] = P.wb[l]; b.n_ot[b.n] = P.nt[l]; b.n_kb[b.n] = padk(P.nt[l + 1]); b.n++; }
+    for (int l = F.nl - 2; l >= 1; --l) add_stream(b, F.wb[l], F.nt[l], F.nt[l + 1], twb);
+    for (int l = P.nl - 2; l >= 1; --l) add_stream(b, P.wb[l], P.nt[l], P.nt[l + 1], twb);
     const size_t R = 16 * (size_t)p->RT;
     size_t o = 2 * R * p->LD + 2 * R * c.D + R * c.U + R * 16 + 2 * R +
                (pm_fast_hp_alias((int)R, p->LD, p->RT) ? 0 : (size_t)PF_NW * p->RT * 256);   // up to and incl. the hp region

@@ -66,6 +66,9 @@ struct StreamDesc {
   int n;
   const float* wf[2 * PM_MAXL];
   int n_ot[2 * PM_MAXL], n_kb[2 * PM_MAXL];
+  // K-split of the LAST output tile (see pm_fast_ksplit): n_ot above already excludes it;
+  // tw_off = offset (floats) of its LDS-resident weight k-blocks, n_kb_real = unpadded K blocks
+  int ks[2 * PM_MAXL], tw_off[2 * PM_MAXL], n_kb_real[2 * PM_MAXL];
 };
 // LDS offsets (floats) of the per-layer regions of the fast kernels
 struct FastOff {

@@ -17,6 +17,7 @@
 //     group, next layer, next net, next step) while the current one feeds the
 //     MFMAs, so the weight latency is paid once per launch, not once per layer.
 #pragma once
+#include <type_traits>
 #include "pmbrl_dev.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
@@ -37,6 +38,29 @@
 #define PF_NT (PF_NW * 64)
 #define PM_L0T 2           // max resident first-layer tiles per wave (<= 16 tiles per layer)
 #define PM_HJ 16           // max fused head / tail width
+
+// Tile balance: tile ot runs on wave ot mod 8, i.e. SIMD ot mod 4.  A layer with 4m+1 output
+// tiles (13 for a 200-wide layer) would put m+1 tiles on SIMD 0 and m on the others: the phase
+// then lasts as long as SIMD 0's extra tile (+25 % at m = 3).  Instead the LAST tile of such a
+// layer is K-split over all 8 waves (<= 2 k-blocks each, weights LDS-resident for the launch):
+// every wave adds its partial tile to LDS at the START of the phase and bumps a counter; the
+// last wave, which owns at most one regular tile, waits for the 8 partials after its tile,
+// sums them in fixed order and runs the tile's normal epilogue before the phase barrier.
+__host__ __device__ inline bool pm_fast_ksplit(int n_ot) { return n_ot >= 5 && (n_ot % 4) == 1; }
+// LDS floats for the K-split tail weights of one sweep direction (bwd: transposed layers)
+__host__ __device__ inline size_t pm_fast_tail_floats(const int* pnt, int pnl, const int* dnt, int dnl,
+                                                      bool bwd) {
+  size_t n = 0;
+  for (int l = 1; l <= pnl - 2; ++l) {
+    const int n_ot = bwd ? pnt[l] : pnt[l + 1], n_kb = bwd ? pnt[l + 1] : pnt[l];
+    if (pm_fast_ksplit(n_ot)) n += (size_t)n_kb * 256;
+  }
+  for (int l = 1; l <= dnl - 2; ++l) {
+    const int n_ot = bwd ? dnt[l] : dnt[l + 1], n_kb = bwd ? dnt[l + 1] : dnt[l];
+    if (pm_fast_ksplit(n_ot)) n += (size_t)n_kb * 256;
+  }
+  return n;
+}
 
 __host__ __device__ inline bool pm_fast_net_ok(const int* dim, const int* nt, int nl) {
   if (nl < 2) return false;
@@ -78,13 +102,18 @@ __device__ __forceinline__ int pm_hi32(const void* p) { return (int)(unsigned)(r
 // weight-stream table: lane 4*l + {0: n_ot, 1: n_kb, 2/3: wf lo/hi} of streamed layer l (<= 16)
 struct SdV {
   int n, v;
+  int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l
 };
 __device__ __forceinline__ SdV sdv_make(const StreamDesc& sd, int lane) {
   SdV r;
   r.n = sd.n;
   r.v = 0;
+  r.k = 0;
   const int l = lane >> 2, f = lane & 3;
-  if (l < sd.n) r.v = f == 0 ? sd.n_ot[l] : f == 1 ? sd.n_kb[l] : f == 2 ? pm_lo32(sd.wf[l]) : pm_hi32(sd.wf[l]);
+  if (l < sd.n) {
+    r.v = f == 0 ? sd.n_ot[l] : f == 1 ? sd.n_kb[l] : f == 2 ? pm_lo32(sd.wf[l]) : pm_hi32(sd.wf[l]);
+    r.k = f == 0 ? sd.ks[l] : f == 1 ? sd.tw_off[l] : f == 2 ? sd.n_kb_real[l] : 0;
+  }
   return r;
 }
 
@@ -423,6 +452,51 @@ __device__ __forceinline__ float head_value(const float* hpart, int r, int j) {
   return s;
 }
 
+// K-split of a layer's last output tile (pm_fast_ksplit): partial tile of this wave's <= 2
+// k-blocks, weights read from LDS (tw: [n_kb][64 lanes][4]).
+template <int RT>
+__device__ __forceinline__ void tail_partial(const float* tw, int n_kb, const float* lds_in, int ld,
+                                             float* tp, int* tcnt, int wid, int lane) {
+  const float* bp = lds_in + (lane & 15) * ld + 4 * (lane >> 4);
+  f32x4 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < PM_HKB; ++i) {
+    const int kb = wid * PM_HKB + i;
+    if (kb < n_kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(tw + (size_t)kb * 256 + lane * 4);
+      f32x4 b[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) b[rt] = *reinterpret_cast<const f32x4*>(bp + rt * 16 * ld + kb * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma4(a[j], b[rt][j], acc[rt]);
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+    *reinterpret_cast<f32x4*>(tp + ((size_t)(wid * RT + rt) * 64 + lane) * 4) = acc[rt];
+  // LDS operations of a wave complete in order: the partial is visible before the count moves
+  if (lane == 0) __hip_atomic_fetch_add(tcnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// last wave: wait for the 8 partials of round `round`, add them in wave order
+template <int RT>
+__device__ __forceinline__ void tail_gather(const float* tp, int* tcnt, int round, int lane, f32x4 (&sum)[RT]) {
+  const int want = PF_NW * round;
+  while (__hip_atomic_load(tcnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < PF_NW; ++w)
+      s += *reinterpret_cast<const f32x4*>(tp + ((size_t)(w * RT + rt) * 64 + lane) * 4);
+    sum[rt] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // epilogues reading bias / masks from LDS
 // ---------------------------------------------------------------------------
@@ -660,6 +734,9 @@ struct FastLds {
   float *jx;                     // backward: dL/dx~ rows [R][16]
   float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
   float *zs;                     // in-kernel moment matching: this step's noise rows [R][D]
+  float *tp;                     // K-split last tile: partial tiles [PF_NW][RT][64][4]
+  int *tcnt;                     //   ... and the arrival counter
+  float *tw;                     //   ... and the LDS-resident weight k-blocks of those tiles
   double* mm;
 };
 
@@ -683,6 +760,11 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n = (n + 3) & ~(size_t)3;
   n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U) + (size_t)R * D;   // jx, stg, zs
   n = (n + 3) & ~(size_t)3;
+  {
+    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true);
+    const size_t tw = tf > tb ? tf : tb;
+    if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
+  }
   n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
   return n;
 }
@@ -724,7 +806,16 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   m.stg = p; p += (size_t)R * (1 + 2 * D + 3 * U);
   m.zs = p; p += (size_t)R * D;
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
-  m.mm = reinterpret_cast<double*>(base + n);
+  p = base + n;
+  {
+    const size_t tf = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, false), tb = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, true);
+    const size_t tw = tf > tb ? tf : tb;
+    m.tp = p;
+    m.tcnt = reinterpret_cast<int*>(p + (size_t)PF_NW * RT * 256);
+    m.tw = p + (size_t)PF_NW * RT * 256 + 4;
+    if (tw) p += (size_t)PF_NW * RT * 256 + 4 + tw;
+  }
+  m.mm = reinterpret_cast<double*>(p);
   return m;
 }
 
@@ -783,7 +874,44 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 
 // partial head tiles: fixed region, or the idle activation buffer (Y)
 #define PM_HP() (L.bufA + (L.hp_off >= 0 ? L.hp_off : (xsel ^ 1) * (R * LD)))
+// one streamed layer (index SI of the stream table) with epilogue ES and, when the layer's last
+// tile is K-split, that tile's partial / gather / epilogue around it
+#define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
+  {                                                                                                     \
+    const int ks_ = pm_rl(sd.k, 4 * (SI));                                                              \
+    typename std::remove_reference<decltype(ES)>::type::Pre tpre_[RT];                                  \
+    const int ot_last_ = pm_rl(sd.v, 4 * (SI));                                                         \
+    if (ks_) {                                                                                          \
+      if (wid == PF_NW - 1) {                                                                           \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) tpre_[rt] = (ES).pre(ot_last_, rt);          \
+      }                                                                                                 \
+      tail_partial<RT>(L.tw + pm_rl(sd.k, 4 * (SI) + 1), pm_rl(sd.k, 4 * (SI) + 2), X, LD, L.tp, L.tcnt, \
+                       wid, lane);                                                                      \
+      ++tround;                                                                                         \
+    }                                                                                                   \
+    stream_layer<RT, CA, CB>(sd, (SI), q, fa, fb, X, LD, wid, lane, (ES), vo0, vo1, (PROF));            \
+    if (ks_ && wid == PF_NW - 1) {                                                                      \
+      f32x4 tsum_[RT];                                                                                  \
+      tail_gather<RT>(L.tp, L.tcnt, tround, lane, tsum_);                                               \
+      std::remove_reference<decltype(ES)>::type::wait_all();                                            \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                              \
+        (ES).landed(tpre_[rt], rt);                                                                     \
+        (ES)(ot_last_, rt, tsum_[rt], tpre_[rt]);                                                       \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
 #define PM_SWAP_XY() { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+
+// K-split tails: weight k-blocks of the last tile of every such layer -> LDS, counter -> 0
+__device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds& L, int tid) {
+  if (tid == 0) *L.tcnt = 0;
+  for (int i = 0; i < sd.n; ++i) {
+    if (!sd.ks[i]) continue;
+    const float* src = sd.wf[i] + (size_t)sd.n_ot[i] * sd.n_kb[i] * 256;   // the tile after the streamed ones
+    float* dst = L.tw + sd.tw_off[i];
+    for (int e = tid; e < sd.n_kb_real[i] * 256; e += PF_NT) dst[e] = src[e];
+  }
+}
 
 // ===========================================================================
 // forward (fast)
@@ -805,6 +933,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   float* xb = L.xb;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  pm_fast_preload_tails(A.sd_fwd, L, tid);
+  int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   {
     const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
@@ -919,8 +1049,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(2);
     for (int l = 1; l < pnl - 1; ++l) {
-      stream_layer<RT, CA, CB>(sd, l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1,
-                            (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
+      PM_STREAM_LAYER(l - 1, es, 0, (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
       if (l + 1 < pnl - 1) es = pol_epi(l + 1, t, blk, X);
       __syncthreads();
       PM_SWAP_XY();
@@ -976,7 +1105,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(12);
     for (int l = 1; l < fnl - 1; ++l) {
-      stream_layer<RT, CA, CB>(sd, n_pol_stream + l - 1, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      PM_STREAM_LAYER(n_pol_stream + l - 1, es, 0, nullptr);
       if (l + 1 < fnl - 1) es = dyn_epi(l + 1, t, X);
       __syncthreads();
       PM_SWAP_XY();
@@ -1069,6 +1198,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+  pm_fast_preload_tails(A.sd_bwd, L, tid);
+  int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   for (int i = tid; i < R * D; i += PF_NT) {
     const int r = i / D, d = i - r * D;
@@ -1247,7 +1378,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(4);
     for (int l = fnl - 2, si = 0; l >= 1; --l, ++si) {
-      stream_layer<RT, CA, CB>(sd, si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      PM_STREAM_LAYER(si, es, 0, nullptr);
       if (l - 1 >= 1) es = dyn_epi(l - 2, t, X);
       __syncthreads();
       PM_SWAP_XY();
@@ -1320,7 +1451,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PM_SWAP_XY();
     PM_MARK(14);
     for (int l = pnl - 2, si = 0; l >= 1; --l, ++si) {
-      stream_layer<RT, CA, CB>(sd, n_dyn_stream + si, q, fa, fb, X, LD, wid, lane, es, vo0, vo1);
+      PM_STREAM_LAYER(n_dyn_stream + si, es, 0, nullptr);
       if (l - 1 >= 1) es = pol_epi(l - 2, t, blk, X);
       __syncthreads();
       PM_SWAP_XY();
