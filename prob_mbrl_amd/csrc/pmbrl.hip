@@ -772,7 +772,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
       sd.wf[i] = wf;
       sd.n_kb[i] = padk(n_kb_real);
       sd.n_kb_real[i] = n_kb_real;
-      sd.ks[i] = pm_fast_ksplit(n_ot) ? 1 : 0;
+      sd.ks[i] = pm_fast_ksplit(n_ot, p->RT) ? 1 : 0;
       sd.n_ot[i] = n_ot - sd.ks[i];
       sd.tw_off[i] = tw_off;
       if (sd.ks[i]) tw_off += n_kb_real * 256;

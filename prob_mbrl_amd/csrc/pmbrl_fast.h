@@ -46,18 +46,19 @@
 // every wave adds its partial tile to LDS at the START of the phase and bumps a counter; the
 // last wave, which owns at most one regular tile, waits for the 8 partials after its tile,
 // sums them in fixed order and runs the tile's normal epilogue before the phase barrier.
-__host__ __device__ inline bool pm_fast_ksplit(int n_ot) { return n_ot >= 5 && (n_ot % 4) == 1; }
+// (not with 64-row workgroups: LDS is the constraint there)
+__host__ __device__ inline bool pm_fast_ksplit(int n_ot, int RT) { return RT < 4 && n_ot >= 5 && (n_ot % 4) == 1; }
 // LDS floats for the K-split tail weights of one sweep direction (bwd: transposed layers)
 __host__ __device__ inline size_t pm_fast_tail_floats(const int* pnt, int pnl, const int* dnt, int dnl,
-                                                      bool bwd) {
+                                                      bool bwd, int RT) {
   size_t n = 0;
   for (int l = 1; l <= pnl - 2; ++l) {
     const int n_ot = bwd ? pnt[l] : pnt[l + 1], n_kb = bwd ? pnt[l + 1] : pnt[l];
-    if (pm_fast_ksplit(n_ot)) n += (size_t)n_kb * 256;
+    if (pm_fast_ksplit(n_ot, RT)) n += (size_t)n_kb * 256;
   }
   for (int l = 1; l <= dnl - 2; ++l) {
     const int n_ot = bwd ? dnt[l] : dnt[l + 1], n_kb = bwd ? dnt[l + 1] : dnt[l];
-    if (pm_fast_ksplit(n_ot)) n += (size_t)n_kb * 256;
+    if (pm_fast_ksplit(n_ot, RT)) n += (size_t)n_kb * 256;
   }
   return n;
 }
@@ -761,7 +762,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U) + (size_t)R * D;   // jx, stg, zs
   n = (n + 3) & ~(size_t)3;
   {
-    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true);
+    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT);
     const size_t tw = tf > tb ? tf : tb;
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
@@ -808,7 +809,7 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
   p = base + n;
   {
-    const size_t tf = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, false), tb = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, true);
+    const size_t tf = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, false, RT), tb = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, true, RT);
     const size_t tw = tf > tb ? tf : tb;
     m.tp = p;
     m.tcnt = reinterpret_cast<int*>(p + (size_t)PF_NW * RT * 256);
@@ -882,15 +883,15 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
     typename std::remove_reference<decltype(ES)>::type::Pre tpre_[RT];                                  \
     const int ot_last_ = pm_rl(sd.v, 4 * (SI));                                                         \
     if (ks_) {                                                                                          \
-      if (wid == PF_NW - 1) {                                                                           \
-        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) tpre_[rt] = (ES).pre(ot_last_, rt);          \
-      }                                                                                                 \
       tail_partial<RT>(L.tw + pm_rl(sd.k, 4 * (SI) + 1), pm_rl(sd.k, 4 * (SI) + 2), X, LD, L.tp, L.tcnt, \
                        wid, lane);                                                                      \
       ++tround;                                                                                         \
     }                                                                                                   \
     stream_layer<RT, CA, CB>(sd, (SI), q, fa, fb, X, LD, wid, lane, (ES), vo0, vo1, (PROF));            \
     if (ks_ && wid == PF_NW - 1) {                                                                      \
+      /* epilogue operands fetched here, in the block that waits for them (their latency hides behind */ \
+      /* the wait for the partials)                                                                   */ \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) tpre_[rt] = (ES).pre(ot_last_, rt);            \
       f32x4 tsum_[RT];                                                                                  \
       tail_gather<RT>(L.tp, L.tcnt, tround, lane, tsum_);                                               \
       std::remove_reference<decltype(ES)>::type::wait_all();                                            \
