@@ -244,6 +244,40 @@ int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* call, void* workspace_
                       const float* sq_scale_d, const float* sq_bias_d,
                       float* sample_d /* [B][n_out] */, float* mean_d, float* log_std_d);
 
+/* ---- BNN maximum-likelihood training of the dynamics model ---------------- */
+/* Loss and gradient of one minibatch: the iteration body of the reference's
+ * utils.train_regressor (utils/train_regressor.py:113-131) with the model in train() mode --
+ * Regressor.forward(x, normalize=False, resample=True) (models/core.py:169-187), concrete
+ * dropout with a straight-through Bernoulli sample (models/modules.py:102-118,120-160), Gaussian
+ * log-likelihood (losses.py:16-37) and the dropout regulariser (models/modules.py:30-35,88-93,
+ * 234-274):   loss = -mean_rows lml + reg_weight * reg / N.
+ * params / grad are flat in the module's parameter order: W0, b0, [logit_p0], W1, b1, [logit_p1],
+ * ..., W_L, b_L  (logit_p_l, one per unit of hidden layer l, present iff temperature[l] > 0).
+ * u / bvar: the uniform noise of the concrete relaxation and the uniform variate of the Bernoulli
+ * draw (hard = bvar < probs), per dropout layer a block [M][h_l], blocks concatenated in layer
+ * order.  The optimiser step is pmbrl_clip_adam on the same flat vectors. */
+typedef struct {
+  int32_t M;                  /* minibatch rows */
+  int32_t N;                  /* dataset rows (the regulariser is divided by N) */
+  pmbrl_mlp net;              /* dims[0] = input width, dims[n_layers] = 2 * output width; keep unused */
+  float max_log_std;
+  float temperature[PMBRL_MAX_LAYERS];   /* <= 0: hidden layer l has no dropout */
+  float reg_scale[PMBRL_MAX_LAYERS];     /* CDropout.regularizer_scale buffer (= 0.5 * ctor argument) */
+  float drop_reg[PMBRL_MAX_LAYERS];      /* CDropout.dropout_regularizer */
+  float reg_weight;
+} pmbrl_bnn_config;
+typedef struct pmbrl_bnn_plan pmbrl_bnn_plan;
+
+int pmbrl_bnn_plan_create(const pmbrl_bnn_config* cfg, int device, pmbrl_bnn_plan** out);
+void pmbrl_bnn_plan_destroy(pmbrl_bnn_plan* plan);
+size_t pmbrl_bnn_plan_workspace_bytes(const pmbrl_bnn_plan* plan);
+int64_t pmbrl_bnn_plan_n_params(const pmbrl_bnn_plan* plan);
+int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* plan, void* stream, void* workspace_d,
+                        const float* Xn_d /* [N][n_in] */, const float* Yn_d /* [N][n_out] */,
+                        const int32_t* idx_d /* [M] */, const float* params_flat_d,
+                        const float* u_d, const float* bvar_d,
+                        float* grad_flat_d, float* loss_out_d /* [3]: loss, -E[lml], reg */);
+
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout
  * kernels use (R <= 64). */

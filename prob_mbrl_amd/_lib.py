@@ -32,6 +32,12 @@ class MlpCall(C.Structure):
     _fields_ = [('B', C.c_int32), ('net', MLP), ('max_log_std', C.c_float)]
 
 
+class BnnConfig(C.Structure):
+    _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('net', MLP), ('max_log_std', C.c_float),
+                ('temperature', C.c_float * MAX_LAYERS), ('reg_scale', C.c_float * MAX_LAYERS),
+                ('drop_reg', C.c_float * MAX_LAYERS), ('reg_weight', C.c_float)]
+
+
 class Reward(C.Structure):
     _fields_ = [('kind', C.c_int32), ('expand', C.c_int32),
                 ('n_angle', C.c_int32), ('angle_dims', C.c_int32 * MAX_ANGLE),
@@ -69,6 +75,8 @@ EXPORTS = [
     'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward',
+    'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
+    'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad',
 ]
 
 _lib = None
@@ -114,6 +122,16 @@ def load():
     lib.pmbrl_mlp_workspace_bytes.argtypes = [C.POINTER(MlpCall)]
     lib.pmbrl_mlp_forward.restype = C.c_int
     lib.pmbrl_mlp_forward.argtypes = [vp, C.POINTER(MlpCall), vp, vp, vp, C.POINTER(vp)] + [vp] * 10
+    lib.pmbrl_bnn_plan_create.restype = C.c_int
+    lib.pmbrl_bnn_plan_create.argtypes = [C.POINTER(BnnConfig), C.c_int, C.POINTER(vp)]
+    lib.pmbrl_bnn_plan_destroy.restype = None
+    lib.pmbrl_bnn_plan_destroy.argtypes = [vp]
+    lib.pmbrl_bnn_plan_workspace_bytes.restype = C.c_size_t
+    lib.pmbrl_bnn_plan_workspace_bytes.argtypes = [vp]
+    lib.pmbrl_bnn_plan_n_params.restype = C.c_int64
+    lib.pmbrl_bnn_plan_n_params.argtypes = [vp]
+    lib.pmbrl_bnn_loss_grad.restype = C.c_int
+    lib.pmbrl_bnn_loss_grad.argtypes = [vp] * 11
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.pmbrl_plan_set_timing.restype = C.c_int

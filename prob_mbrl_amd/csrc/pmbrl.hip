@@ -16,6 +16,7 @@
 #include "pmbrl_fast.h"
 #include "pmbrl_dw.h"
 #include "pmbrl_mlp.h"
+#include "pmbrl_bnn.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -341,6 +342,69 @@ static int set_attr(size_t lds) {
   return 0;
 }
 
+// dW wave blocks: balanced splits of every layer's output tile grid into <= 4 x 7 tile
+// blocks, dealt to the four SIMDs (waves w and w+4 share SIMD w) by decreasing size so that
+// every SIMD issues the same number of MFMAs.  Returns the number of blocks; `blocks` comes back
+// sorted by wave, wave w owning [wave_first[w], wave_first[w+1]).
+static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, int* wave_first) {
+  blocks.clear();
+  auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
+    const int parts = (n + maxsz - 1) / maxsz;
+    int lo = 0;
+    for (int i = 0; i < parts; ++i) {
+      const int sz = n / parts + (i < n % parts ? 1 : 0);
+      out.push_back({lo, sz});
+      lo += sz;
+    }
+  };
+  for (int l = 0; l < nl; ++l) {
+    std::vector<std::pair<int, int>> os, is;
+    split(nt[l + 1], PM_DW_TM, os);
+    split(nt[l], PM_DW_TN, is);
+    for (auto& o : os)
+      for (auto& i : is) {
+        DwBlock b;
+        b.layer = (int16_t)l;
+        b.ot0 = (int16_t)o.first;
+        b.n_ot = (int16_t)o.second;
+        b.it0 = (int16_t)i.first;
+        b.n_it = (int16_t)i.second;
+        b.pad = 0;
+        blocks.push_back(b);
+      }
+  }
+  const int n_blocks = (int)blocks.size();
+  // cost of a block = MFMAs per chunk in the shape class it runs in (see pm_dw_kernel)
+  auto cost = [](const DwBlock& b) {
+    const int ni = b.n_ot <= 1 ? 1 : (b.n_ot <= 3 ? 3 : 4);
+    const int nj = b.n_it <= 1 ? 1 : (b.n_it <= 4 ? 4 : (b.n_it <= 6 ? 6 : 7));
+    return ni * nj;
+  };
+  std::stable_sort(blocks.begin(), blocks.end(),
+                   [&](const DwBlock& a, const DwBlock& b) { return cost(a) > cost(b); });
+  std::vector<DwBlock> per_wave[PM_DW_NW];
+  long wave_load[PM_DW_NW] = {0};
+  // waves w and w+4 of a workgroup share SIMD w (measured: pairing (2k, 2k+1) instead is 5% slower)
+  for (const DwBlock& b : blocks) {
+    int best_simd = 0;
+    for (int sm = 1; sm < 4; ++sm)
+      if (wave_load[sm] + wave_load[sm + 4] < wave_load[best_simd] + wave_load[best_simd + 4]) best_simd = sm;
+    const int w = wave_load[best_simd] <= wave_load[best_simd + 4] ? best_simd : best_simd + 4;
+    per_wave[w].push_back(b);
+    wave_load[w] += cost(b);
+  }
+  blocks.clear();
+  // the small blocks are latency-bound (a handful of MFMAs per chunk): the second wave of a SIMD runs
+  // its FIRST, while the SIMD's other wave keeps the MFMA pipe busy with its big block
+  for (int w = 0; w < PM_DW_NW; ++w) {
+    wave_first[w] = (int)blocks.size();
+    if (w >= 4) std::reverse(per_wave[w].begin(), per_wave[w].end());
+    for (const DwBlock& b : per_wave[w]) blocks.push_back(b);
+  }
+  wave_first[PM_DW_NW] = (int)blocks.size();
+  return n_blocks;
+}
+
 extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan** out) {
   if (!cfg || !out) return fail(-1, "null argument");
   const pmbrl_config& c = *cfg;
@@ -499,69 +563,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
   }
-  // dW wave blocks: balanced splits of every layer's output tile grid into <= 4 x 7 tile
-  // blocks, dealt to the four SIMDs (waves w and w+4 share SIMD w) by decreasing size so that
-  // every SIMD issues the same number of MFMAs
   {
     std::vector<DwBlock> blocks;
-    auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
-      const int parts = (n + maxsz - 1) / maxsz;
-      int lo = 0;
-      for (int i = 0; i < parts; ++i) {
-        const int sz = n / parts + (i < n % parts ? 1 : 0);
-        out.push_back({lo, sz});
-        lo += sz;
-      }
-    };
-    for (int l = 0; l < p->pol.nl; ++l) {
-      std::vector<std::pair<int, int>> os, is;
-      split(p->pol.nt[l + 1], PM_DW_TM, os);
-      split(p->pol.nt[l], PM_DW_TN, is);
-      for (auto& o : os)
-        for (auto& i : is) {
-          DwBlock b;
-          b.layer = (int16_t)l;
-          b.ot0 = (int16_t)o.first;
-          b.n_ot = (int16_t)o.second;
-          b.it0 = (int16_t)i.first;
-          b.n_it = (int16_t)i.second;
-          b.pad = 0;
-          blocks.push_back(b);
-        }
-    }
-    p->n_dw_blocks = (int)blocks.size();
-    // cost of a block = MFMAs per chunk in the shape class it runs in (see pm_dw_kernel)
-    auto cost = [](const DwBlock& b) {
-      const int ni = b.n_ot <= 1 ? 1 : (b.n_ot <= 3 ? 3 : 4);
-      const int nj = b.n_it <= 1 ? 1 : (b.n_it <= 4 ? 4 : (b.n_it <= 6 ? 6 : 7));
-      return ni * nj;
-    };
-    std::stable_sort(blocks.begin(), blocks.end(),
-                     [&](const DwBlock& a, const DwBlock& b) { return cost(a) > cost(b); });
-    std::vector<DwBlock> per_wave[PM_DW_NW];
-    long wave_load[PM_DW_NW] = {0};
-    // waves w and w+4 of a workgroup share SIMD w (measured: pairing (2k, 2k+1) instead is 5% slower)
-    auto w0 = [&](int sm) { return sm; };
-    auto w1 = [&](int sm) { return sm + 4; };
-    for (const DwBlock& b : blocks) {
-      int best_simd = 0;
-      for (int sm = 1; sm < 4; ++sm)
-        if (wave_load[w0(sm)] + wave_load[w1(sm)] < wave_load[w0(best_simd)] + wave_load[w1(best_simd)]) best_simd = sm;
-      const int w = wave_load[w0(best_simd)] <= wave_load[w1(best_simd)] ? w0(best_simd) : w1(best_simd);
-      per_wave[w].push_back(b);
-      wave_load[w] += cost(b);
-    }
-    blocks.clear();
-    // the small blocks are latency-bound (a handful of MFMAs per chunk): the second wave of a SIMD runs
-    // its FIRST, while the SIMD's other wave keeps the MFMA pipe busy with its big block
-    for (int w = 0; w < PM_DW_NW; ++w) {
-      p->dw_wave_first[w] = (int)blocks.size();
-      bool second = false;
-      for (int sm = 0; sm < 4; ++sm) second = second || (w == w1(sm));
-      if (second) std::reverse(per_wave[w].begin(), per_wave[w].end());
-      for (const DwBlock& b : per_wave[w]) blocks.push_back(b);
-    }
-    p->dw_wave_first[PM_DW_NW] = (int)blocks.size();
+    p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first);
     p->dw_n_chunks = c.H * p->nwg * p->RT;
     int nsplit = std::min(256, p->dw_n_chunks);   // one 8-wave workgroup per CU
     p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
@@ -1080,6 +1084,166 @@ extern "C" int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* c, void* wo
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   hipLaunchKernelGGL(pm_mlp_fwd_kernel, dim3((c->B + 15) / 16), dim3(PM_NT), L.lds, s, A);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// BNN training step
+// ---------------------------------------------------------------------------
+struct pmbrl_bnn_plan {
+  pmbrl_bnn_config cfg;
+  int device, nl, LD, nwg, sum_h, n_params;
+  int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
+  int w_off[PM_MAXL], b_off[PM_MAXL], lp_poff[PM_MAXL], lp_off[PM_MAXL], has_drop[PM_MAXL];
+  size_t off_wf[PM_MAXL], off_wb[PM_MAXL], off_bias[PM_MAXL], off_actT[PM_MAXL], off_gT[PM_MAXL];
+  size_t off_part_lp, off_part_loss, off_part, off_reg_part, ws_bytes, lds;
+  int part_stride, n_dw_blocks, dw_wave_first[PM_DW_NW + 1];
+  DwBlock* dw_blocks_d;
+};
+
+extern "C" int pmbrl_bnn_plan_create(const pmbrl_bnn_config* cfg, int device, pmbrl_bnn_plan** out) {
+  if (!cfg || !out) return fail(-1, "null argument");
+  const pmbrl_mlp& m = cfg->net;
+  if (m.n_layers < 2 || m.n_layers > PM_MAXL) return fail(-2, "bnn: 2..8 layers");
+  if (cfg->M < 1 || cfg->N < 1) return fail(-2, "bnn: M, N must be >= 1");
+  if (m.dims[m.n_layers] % 2) return fail(-2, "bnn: the output layer must be 2 x n_out wide");
+  pmbrl_bnn_plan* p = new pmbrl_bnn_plan();
+  p->cfg = *cfg;
+  p->device = device;
+  p->nl = m.n_layers;
+  int maxnt = 1, po = 0;
+  p->sum_h = 0;
+  for (int i = 0; i <= p->nl; ++i) {
+    if (m.dims[i] < 1 || m.dims[i] > 16 * 64) { delete p; return fail(-2, "bnn: layer width out of range"); }
+    p->dim[i] = m.dims[i];
+    p->nt[i] = (m.dims[i] + 15) / 16;
+    maxnt = std::max(maxnt, p->nt[i]);
+  }
+  for (int l = 0; l < p->nl; ++l) {
+    p->w_off[l] = po; po += p->dim[l + 1] * p->dim[l];
+    p->b_off[l] = po; po += p->dim[l + 1];
+    p->has_drop[l] = (l < p->nl - 1 && cfg->temperature[l] > 0.f) ? 1 : 0;
+    p->lp_poff[l] = po;
+    p->lp_off[l] = p->sum_h;
+    if (p->has_drop[l]) { po += p->dim[l + 1]; p->sum_h += p->dim[l + 1]; }
+  }
+  p->n_params = po;
+  p->LD = maxnt * 16 + 8;
+  p->nwg = (cfg->M + 15) / 16;
+  p->lds = pm_bnn_lds_floats(p->nl, p->LD) * sizeof(float);
+  if (p->lds > 160 * 1024) { delete p; return fail(-3, "bnn: network too wide / deep for the fused training step's LDS budget"); }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  for (int l = 0; l < p->nl; ++l) {
+    p->off_wf[l] = take((size_t)p->nt[l + 1] * p->nt[l] * 256 * sizeof(float));
+    p->off_wb[l] = take((size_t)p->nt[l + 1] * p->nt[l] * 256 * sizeof(float));
+    p->off_bias[l] = take((size_t)p->nt[l + 1] * 16 * sizeof(float));
+    p->off_actT[l] = take((size_t)p->nwg * p->nt[l] * 16 * 16 * sizeof(float));
+    p->off_gT[l] = take((size_t)p->nwg * p->nt[l + 1] * 16 * 16 * sizeof(float));
+  }
+  p->part_stride = (p->n_params + 3) / 4 * 4;
+  p->off_part_lp = take((size_t)p->nwg * std::max(p->sum_h, 1) * sizeof(float));
+  p->off_part_loss = take((size_t)p->nwg * sizeof(float));
+  p->off_part = take((size_t)p->nwg * p->part_stride * sizeof(float));
+  p->off_reg_part = take(1024 * sizeof(float));
+  p->ws_bytes = off;
+  HIPCHK(hipSetDevice(device));
+  std::vector<DwBlock> blocks;
+  p->n_dw_blocks = build_dw_blocks(p->nl, p->nt, blocks, p->dw_wave_first);
+  HIPCHK(hipMalloc(&p->dw_blocks_d, blocks.size() * sizeof(DwBlock)));
+  HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock), hipMemcpyHostToDevice));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_bnn_fwd_bwd),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
+  *out = p;
+  return 0;
+}
+
+extern "C" void pmbrl_bnn_plan_destroy(pmbrl_bnn_plan* p) {
+  if (!p) return;
+  if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
+  delete p;
+}
+extern "C" size_t pmbrl_bnn_plan_workspace_bytes(const pmbrl_bnn_plan* p) { return p ? p->ws_bytes : 0; }
+extern "C" int64_t pmbrl_bnn_plan_n_params(const pmbrl_bnn_plan* p) { return p ? p->n_params : 0; }
+
+extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* workspace_d, const float* Xn_d,
+                                   const float* Yn_d, const int32_t* idx_d, const float* params_flat_d,
+                                   const float* u_d, const float* bvar_d, float* grad_flat_d,
+                                   float* loss_out_d) {
+  if (!p || !workspace_d || !Xn_d || !Yn_d || !idx_d || !params_flat_d || !grad_flat_d || !loss_out_d)
+    return fail(-1, "null argument");
+  if (p->sum_h > 0 && (!u_d || !bvar_d)) return fail(-1, "bnn: dropout layers need u and bvar");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(p->device));
+  char* ws = static_cast<char*>(workspace_d);
+  PackArgs PK;
+  PK.n = 0;
+  PK.status = nullptr;
+  BnnArgs A;
+  memset(&A, 0, sizeof(A));
+  A.M = p->cfg.M; A.nl = p->nl; A.LD = p->LD; A.n_out = p->dim[p->nl] / 2; A.nwg = p->nwg;
+  A.n_in = p->dim[0]; A.sum_h = p->sum_h;
+  for (int i = 0; i <= p->nl; ++i) { A.dim[i] = p->dim[i]; A.nt[i] = p->nt[i]; }
+  for (int l = 0; l < p->nl; ++l) {
+    float* wf = reinterpret_cast<float*>(ws + p->off_wf[l]);
+    float* wb = reinterpret_cast<float*>(ws + p->off_wb[l]);
+    float* bs = reinterpret_cast<float*>(ws + p->off_bias[l]);
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wf, p->dim[l + 1], p->dim[l], 0, 1, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wb, p->dim[l + 1], p->dim[l], 1, 1, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->b_off[l], bs, p->dim[l + 1], p->dim[l], 0, 1, 1};
+    A.wf[l] = wf; A.wb[l] = wb; A.bias[l] = bs;
+    A.actT[l] = reinterpret_cast<float*>(ws + p->off_actT[l]);
+    A.gT[l] = reinterpret_cast<float*>(ws + p->off_gT[l]);
+    A.lp_off[l] = p->lp_off[l];
+    if (p->has_drop[l]) {
+      A.logit_p[l] = params_flat_d + p->lp_poff[l];
+      A.u[l] = u_d + (size_t)p->cfg.M * p->lp_off[l];
+      A.bvar[l] = bvar_d + (size_t)p->cfg.M * p->lp_off[l];
+      A.inv_temp[l] = 1.f / p->cfg.temperature[l];
+    }
+  }
+  A.X = Xn_d; A.Y = Yn_d; A.idx = idx_d;
+  A.mls = p->cfg.max_log_std;
+  A.inv_M = 1.f / (float)p->cfg.M;
+  A.part_lp = reinterpret_cast<float*>(ws + p->off_part_lp);
+  A.part_loss = reinterpret_cast<float*>(ws + p->off_part_loss);
+  hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
+  hipLaunchKernelGGL(pm_bnn_fwd_bwd, dim3(p->nwg), dim3(PM_NT), p->lds, s, A);
+  // dW / db of every layer: the policy-gradient GEMM over the same stash layout (one 16-row chunk per split)
+  DwArgs W;
+  memset(&W, 0, sizeof(W));
+  W.nl = p->nl; W.nsplit = p->nwg; W.n_chunks = p->nwg; W.chunks_per_split = 1;
+  W.RT = 1; W.Rw = 16; W.n_params = p->n_params; W.part_stride = p->part_stride;
+  for (int i = 0; i <= p->nl; ++i) { W.dim[i] = p->dim[i]; W.nt[i] = p->nt[i]; }
+  for (int l = 0; l < p->nl; ++l) {
+    W.w_off[l] = p->w_off[l]; W.b_off[l] = p->b_off[l];
+    W.actT[l] = A.actT[l]; W.gT[l] = A.gT[l];
+  }
+  W.blocks = p->dw_blocks_d;
+  for (int w = 0; w <= PM_DW_NW; ++w) W.wave_first[w] = p->dw_wave_first[w];
+  W.part = reinterpret_cast<float*>(ws + p->off_part);
+  hipLaunchKernelGGL(pm_dw_kernel, dim3(p->nwg), dim3(PM_DW_NT), 0, s, W);
+  hipLaunchKernelGGL(pm_dw_reduce, dim3((p->n_params + 255) / 256), dim3(512), 0, s, W.part, p->nwg, p->n_params,
+                     p->part_stride, grad_flat_d);
+  BnnFinishArgs Fa;
+  memset(&Fa, 0, sizeof(Fa));
+  Fa.nl = p->nl; Fa.nwg = p->nwg; Fa.sum_h = p->sum_h; Fa.N = p->cfg.N;
+  for (int i = 0; i <= p->nl; ++i) Fa.dim[i] = p->dim[i];
+  for (int l = 0; l < p->nl; ++l) {
+    Fa.w_off[l] = p->w_off[l]; Fa.b_off[l] = p->b_off[l]; Fa.lp_poff[l] = p->lp_poff[l]; Fa.lp_off[l] = p->lp_off[l];
+    Fa.has_drop[l] = p->has_drop[l];
+    Fa.reg_scale[l] = p->cfg.reg_scale[l]; Fa.drop_reg[l] = p->cfg.drop_reg[l];
+  }
+  Fa.reg_weight = p->cfg.reg_weight; Fa.inv_M = A.inv_M;
+  Fa.params = params_flat_d; Fa.grad = grad_flat_d; Fa.part_lp = A.part_lp; Fa.part_loss = A.part_loss;
+  Fa.loss_out = loss_out_d; Fa.reg_part = reinterpret_cast<float*>(ws + p->off_reg_part);
+  int nfb = 0;
+  for (int l = 0; l < p->nl - 1; ++l)
+    if (p->has_drop[l]) nfb += (p->dim[l + 1] + PM_BNN_CG - 1) / PM_BNN_CG;
+  if (nfb < 1) nfb = 1;
+  hipLaunchKernelGGL(pm_bnn_finish, dim3(nfb), dim3(256), 0, s, Fa);
+  hipLaunchKernelGGL(pm_bnn_loss, dim3(1), dim3(64), 0, s, Fa, nfb);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -106,6 +106,63 @@ def mlp_forward(x, params_flat, dims, keep, mask_bits=None, z=None, in_shift=Non
     return out
 
 
+class BnnStep:
+    """Loss + gradient of one BNN training minibatch on the device (pmbrl_bnn_loss_grad;
+    utils/train_regressor.py:113-131).  Flat parameter / gradient order = the module's:
+    W0, b0, [logit_p0], W1, b1, [logit_p1], ..., W_L, b_L."""
+
+    def __init__(self, dims, temperature, reg_scale, drop_reg, M, N, reg_weight=1.0,
+                 max_log_std=LOG_MAX_STD, device=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else 'cuda:0')
+        cfg = _lib.BnnConfig()
+        cfg.M, cfg.N = int(M), int(N)
+        nl = len(dims) - 1
+        cfg.net.n_layers = nl
+        for i, d in enumerate(dims):
+            cfg.net.dims[i] = int(d)
+        for l in range(nl - 1):
+            cfg.temperature[l] = float(temperature[l]) if temperature[l] else 0.0
+            cfg.reg_scale[l] = float(reg_scale[l])
+            cfg.drop_reg[l] = float(drop_reg[l])
+        cfg.max_log_std = float(max_log_std)
+        cfg.reg_weight = float(reg_weight)
+        self.M, self.N, self.dims = int(M), int(N), list(dims)
+        self.drop_widths = [dims[l + 1] for l in range(nl - 1) if cfg.temperature[l] > 0]
+        self.sum_h = sum(self.drop_widths)
+        self.plan = C.c_void_p()
+        _lib.check(self.lib.pmbrl_bnn_plan_create(C.byref(cfg), self.device.index or 0, C.byref(self.plan)),
+                   'pmbrl_bnn_plan_create')
+        self.n_params = int(self.lib.pmbrl_bnn_plan_n_params(self.plan))
+        self.ws = torch.empty(self.lib.pmbrl_bnn_plan_workspace_bytes(self.plan), dtype=torch.uint8,
+                              device=self.device)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if self.plan:
+                self.lib.pmbrl_bnn_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    def loss_grad(self, Xn, Yn, idx, params, u, bvar, grad=None):
+        """Xn [N, n_in], Yn [N, n_out] normalised dataset; idx int32 [M]; params flat fp32;
+        u, bvar: fp32 [M * sum_h] (per dropout layer a block [M, h_l]).  Returns (grad, loss[3])."""
+        for t in (Xn, Yn, params):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert idx.is_cuda and idx.dtype == torch.int32 and idx.numel() == self.M
+        assert params.numel() == self.n_params
+        if self.sum_h:
+            assert u.numel() == self.M * self.sum_h and bvar.numel() == self.M * self.sum_h
+        if grad is None:
+            grad = torch.empty_like(params)
+        _lib.check(self.lib.pmbrl_bnn_loss_grad(self.plan, _stream(), _ptr(self.ws), _ptr(Xn), _ptr(Yn),
+                                                _ptr(idx), _ptr(params), _ptr(u), _ptr(bvar), _ptr(grad),
+                                                _ptr(self.loss)), 'pmbrl_bnn_loss_grad')
+        return grad, self.loss
+
+
 def make_reward_struct(spec, D, U):
     """spec: dict(kind, expand, angle_dims, C [k,De], tip_target [k], norm, w,
     Q [k,k], R [U,U]) with numpy / float entries."""

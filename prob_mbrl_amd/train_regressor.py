@@ -1,0 +1,138 @@
+"""`prob_mbrl.utils.train_regressor` (utils/train_regressor.py:58-165): maximum-likelihood
+training of the Bayesian dynamics model.  The iteration body -- forward in train() mode with
+concrete dropout, Gaussian log-likelihood, dropout regulariser, backward -- is one device call
+(pmbrl_bnn_loss_grad), the optimiser step is the fused Adam of the policy path (pmbrl_clip_adam)."""
+import numpy as np
+import torch
+
+from . import engine as E
+from .algorithms import _adam_flat_state, _sync_adam_state
+from .models import CDropout
+
+
+def iterate_minibatches(N, batchsize):
+    """Index stream of utils/train_regressor.py:14-22 (np.random.shuffle every epoch)."""
+    while True:
+        indices = np.arange(0, max(N, batchsize)) % N
+        np.random.shuffle(indices)
+        for i in range(0, N, batchsize):
+            yield indices[i:i + batchsize]
+
+
+def flat_module_parameters(params, owner, key='_pmbrl_flat_all'):
+    """Make `params` (in order) views of ONE flat fp32 buffer and return it; redone when the
+    views were broken (module.cuda() / .float() / load())."""
+    flat = getattr(owner, key, None)
+    ok = flat is not None
+    if ok:
+        off = 0
+        for p in params:
+            n = p.numel()
+            if (p.device != flat.device or p.dtype != torch.float32 or not p.is_contiguous()
+                    or p.data_ptr() != flat.data_ptr() + 4 * off):
+                ok = False
+                break
+            off += n
+        ok = ok and off == flat.numel()
+    if not ok:
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        setattr(owner, key, flat)
+    return flat
+
+
+def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=None, log_likelihood=None,
+                    reg_weight=1.0, pbar_class=None, summary_writer=None, summary_scope='',
+                    decoupled_reg=False, prioritized_sampling=False, priority_eps=1e-3, priority_alpha=0.6):
+    """Same call as the reference.  Offered on the device: the default Gaussian likelihood,
+    coupled regularisation, uniform minibatches, a plain torch.optim.Adam."""
+    if log_likelihood is not None and getattr(log_likelihood, '__name__', '') != 'gaussian_log_likelihood':
+        raise NotImplementedError('only the diagonal-Gaussian log-likelihood is offered on the device path')
+    if decoupled_reg or prioritized_sampling:
+        raise NotImplementedError('decoupled_reg / prioritized_sampling are not offered on the device path')
+    model.train()
+    dev = model.mx.device
+    if dev.type != 'cuda':
+        raise RuntimeError('the model must live on a HIP device (no CPU fallback)')
+    Xn = ((model.X - model.mx) * model.iSx).to(torch.float32).contiguous()
+    Yn = ((model.Y - model.my) * model.iSy).to(torch.float32).contiguous()
+    N = Xn.shape[0]
+    print('train_regressor >', 'Dataset size [%d]' % int(N))
+    linears, drops, inner = model.model.layer_spec()
+    density = inner if inner is not None else model.output_density
+    if density is None:
+        raise NotImplementedError('a diagonal-Gaussian output density is required')
+    dims = [linears[0].in_features] + [l.out_features for l in linears]
+    # module parameter order: fc0.weight, fc0.bias, drop0.logit_p, fc1.weight, ...
+    params, temps, rscale, dreg = [], [], [], []
+    for l, lin in enumerate(linears):
+        params += [lin.weight, lin.bias]
+        if l < len(linears) - 1:
+            dr = drops[l]
+            if dr is None:
+                temps.append(0.0); rscale.append(0.0); dreg.append(0.0)
+            elif isinstance(dr, CDropout):
+                if dr.logit_p.numel() != lin.out_features:
+                    dr.logit_p.data = dr.logit_p.data.reshape(-1).expand(lin.out_features).clone()
+                params.append(dr.logit_p)
+                temps.append(float(dr.temp)); rscale.append(float(dr.regularizer_scale))
+                dreg.append(float(dr.dropout_regularizer))
+            else:
+                raise NotImplementedError('BNN training is offered for concrete dropout (CDropout) layers')
+    if any(not p.requires_grad for p in params):
+        raise NotImplementedError('frozen parameters are not offered on the device path')
+    model_params = [p for p in model.parameters() if p.requires_grad]
+    if len(model_params) != len(params) or any(a is not b for a, b in zip(model_params, params)):
+        raise NotImplementedError('the model has trainable parameters outside Linear / CDropout layers')
+    if optimizer is None:
+        optimizer = torch.optim.Adam(params, 1e-4)
+    flat = flat_module_parameters(params, model)
+    cache = _adam_flat_state(optimizer, params, flat)
+    if cache is None:
+        raise NotImplementedError('BNN training on the device needs a plain torch.optim.Adam over '
+                                  'model.parameters()')
+    steps = {}
+    grad = torch.empty_like(flat)
+    sum_h = sum(d for d, t in zip(dims[1:-1], temps) if t > 0)
+    u_fixed = None
+    batches = iterate_minibatches(N, batchsize)
+    rng = range(iters + 1)       # the reference runs iters + 1 steps (`if i == iters: break` after the step)
+    pbar = pbar_class(rng, total=iters) if pbar_class is not None else rng
+    last = None
+    for i in pbar:
+        idx_np = next(batches)
+        M = len(idx_np)
+        st = steps.get(M)
+        if st is None:
+            st = steps[M] = E.BnnStep(dims, temps, rscale, dreg, M, N, reg_weight,
+                                      max_log_std=float(density.max_log_std), device=dev)
+        idx = torch.as_tensor(idx_np.astype(np.int32), device=dev)
+        if resample or u_fixed is None or u_fixed.numel() != M * sum_h:
+            u_fixed = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
+        bvar = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
+        _, loss = st.loss_grad(Xn, Yn, idx, flat, u_fixed, bvar, grad)
+        cache['step'] += 1
+        g = cache['group']
+        E.clip_adam(flat, grad, cache['m'], cache['v'], cache['step'], g['lr'], g['betas'], g['eps'],
+                    max_norm=None)
+        last = loss
+        if summary_writer is not None:
+            lv = loss.tolist()
+            names = ['training_loss', 'E_lml', 'reg_loss']
+            if summary_scope:
+                names = ['/'.join([summary_scope, n]) for n in names]
+            summary_writer.add_scalar(names[0], lv[0], i)
+            summary_writer.add_scalar(names[1], -lv[1], i)
+            summary_writer.add_scalar(names[2], lv[2], i)
+        if hasattr(pbar, 'set_description') and (i % 50 == 0):
+            pbar.set_description('log-likelihood of data: %f' % (-float(loss[1])))
+    _sync_adam_state(optimizer, params, cache)
+    for dr in drops:
+        if isinstance(dr, CDropout):
+            dr.p = dr.logit_p.detach().sigmoid()
+    model.eval()
+    return last

@@ -17,3 +17,9 @@ def to_complex(x, dims):
         return x
     others = [i for i in range(x.shape[-1]) if i not in dims]
     return torch.cat([x[..., others], x[..., dims].sin(), x[..., dims].cos()], -1)
+
+
+def train_regressor(*args, **kwargs):
+    """utils/train_regressor.py:58-165 (see prob_mbrl_amd/train_regressor.py)."""
+    from .train_regressor import train_regressor as _tr
+    return _tr(*args, **kwargs)

@@ -12,7 +12,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 def fixture_names(kind=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
     if kind == 'iter':
-        return [n for n in names if not n.startswith('mcp_') and not n.startswith('standalone_')]
+        return [n for n in names if not n.startswith(('mcp_', 'standalone_', 'bnn_'))]
+    if kind == 'bnn':
+        return [n for n in names if n.startswith('bnn_')]
     if kind == 'standalone':
         return [n for n in names if n.startswith('standalone_')]
     if kind == 'mcp':

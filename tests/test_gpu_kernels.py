@@ -229,3 +229,54 @@ def test_mlp_forward_matches_torch(B, dims):
     assert np.allclose(out['mean'].cpu().numpy(), mu.numpy(), rtol=2e-5, atol=2e-6)
     assert np.allclose(out['log_std'].cpu().numpy(), ls.numpy(), rtol=2e-5, atol=2e-6)
     assert np.allclose(out['sample'].cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', common.fixture_names('bnn'))
+def test_bnn_training_matches_reference(name):
+    """pmbrl_bnn_loss_grad + pmbrl_clip_adam replaying the reference's train_regressor
+    iterations (recorded minibatch indices, concrete-dropout noise and Bernoulli draws):
+    losses, first-iteration gradients and final parameters."""
+    from prob_mbrl_amd import engine as E
+    d = np.load(common.os.path.join(common.GOLDEN, name + '.npz'))
+    dev = torch.device('cuda:0')
+    nl = int(d['n_layers'])
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
+    parts, keys = [], []
+    for l in range(nl):
+        parts += [T(d['W%d_init' % l]).reshape(-1), T(d['b%d_init' % l]).reshape(-1)]
+        keys += ['W%d' % l, 'b%d' % l]
+        if l < nl - 1:
+            parts.append(T(d['logit_p%d_init' % l]).reshape(-1))
+            keys.append('logit_p%d' % l)
+    flat = torch.cat(parts).contiguous()
+    sizes = [p.numel() for p in parts]
+    dims = [d['W0_init'].shape[1]] + [d['W%d_init' % l].shape[0] for l in range(nl)]
+    temps = [float(d['temp%d' % l]) for l in range(nl - 1)]
+    rs = [float(d['reg_scale%d' % l]) for l in range(nl - 1)]
+    dr = [float(d['drop_reg%d' % l]) for l in range(nl - 1)]
+    M, N = int(d['M']), int(d['N'])
+    step = E.BnnStep(dims, temps, rs, dr, M, N, float(d['reg_weight']), max_log_std=float(d['max_log_std']),
+                     device=dev)
+    assert step.n_params == flat.numel()
+    Xn, Yn = T(d['Xn']), T(d['Yn'])
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    for it in range(int(d['iters'])):
+        idx = torch.tensor(d['idx_it%d' % it].astype(np.int32), device=dev)
+        u = torch.cat([T(d['u%d_it%d' % (l, it)]).reshape(-1) for l in range(nl - 1)])
+        hard = torch.cat([T(d['hard%d_it%d' % (l, it)]).reshape(-1) for l in range(nl - 1)])
+        bvar = 1.0 - hard                      # bvar < probs  <=>  hard  (probs in (0, 1))
+        grad, loss = step.loss_grad(Xn, Yn, idx, flat, u.contiguous(), bvar.contiguous())
+        assert np.allclose(loss.cpu().numpy(), d['losses'][it], rtol=3e-5, atol=2e-6), (it, loss, d['losses'][it])
+        if it == 0:
+            off = 0
+            for key, n in zip(keys, sizes):
+                got = grad[off:off + n].cpu().numpy()
+                assert common.rel(got, d['g%s_it0' % key].reshape(-1)) < 5e-5, key
+                off += n
+        E.clip_adam(flat, grad, m, v, it + 1, float(d['lr']), max_norm=None)
+    off = 0
+    for key, n in zip(keys, sizes):
+        got = flat[off:off + n].cpu().numpy()
+        assert np.allclose(got, d[key + '_final'].reshape(-1), rtol=2e-5, atol=5e-7), key
+        off += n

@@ -97,3 +97,21 @@ def test_oracle_standalone_forwards_match_reference(name):
         assert np.allclose(nxt.numpy(), d[tag + 'next'], rtol=tol, atol=tol)
         assert np.allclose(rew.numpy().reshape(-1, 1), d[tag + 'rew'], rtol=tol, atol=tol)
         assert np.allclose((nxt - x).numpy(), d[tag + 'delta'], rtol=10 * tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize('name', common.fixture_names('bnn'))
+def test_oracle_bnn_training_matches_reference(name):
+    """utils.train_regressor's iteration body (forward in train() mode with concrete dropout,
+    Gaussian NLL, dropout regulariser, Adam) replayed with the recorded random draws."""
+    import numpy as np
+    d = np.load(common.os.path.join(common.GOLDEN, name + '.npz'))
+    params, losses, g0 = R.bnn_train(d, torch.float32)
+    nl = int(d['n_layers'])
+    assert np.allclose(np.array(losses), d['losses'], rtol=2e-5, atol=1e-6)
+    k = 0
+    for l in range(nl):
+        for key in ('W%d' % l, 'b%d' % l) + (('logit_p%d' % l,) if l < nl - 1 else ()):
+            gkey = 'g' + key + '_it0'
+            assert common.rel(g0[k].numpy(), d[gkey]) < 2e-5, gkey
+            assert np.allclose(params[k].detach().numpy(), d[key + '_final'], rtol=1e-5, atol=2e-7), key
+            k += 1

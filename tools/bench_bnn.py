@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Throughput of the BNN training step: utils.train_regressor's iteration body on
+the example shape (dynamics model 5 -> 200 -> 200 -> 8, minibatch 100, Adam), device path vs the
+torch-CPU oracle.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=2000)
+    ap.add_argument('--batch', type=int, default=100)
+    ap.add_argument('--N', type=int, default=1000)
+    ap.add_argument('--hidden', type=int, default=200)
+    ap.add_argument('--cpu-iters', type=int, default=60)
+    a = ap.parse_args()
+    import prob_mbrl_amd as pm
+    from prob_mbrl_amd import engine as E
+    dev = torch.device('cuda:0')
+    D, U, h = 4, 1, a.hidden
+    torch.manual_seed(0)
+    np.random.seed(0)
+    dims = [D + U, h, h, 2 * D]
+    Xn = torch.randn(a.N, D + U, device=dev)
+    Yn = torch.randn(a.N, D, device=dev)
+    parts = []
+    for l in range(3):
+        parts += [torch.randn(dims[l + 1], dims[l], device=dev).reshape(-1) / np.sqrt(dims[l]),
+                  torch.zeros(dims[l + 1], device=dev)]
+        if l < 2:
+            parts.append(torch.full((dims[l + 1],), 1.1, device=dev))
+    flat = torch.cat(parts).contiguous()
+    step = E.BnnStep(dims, [0.1, 0.1], [0.5, 0.5], [1.0, 1.0], a.batch, a.N, 1.0, device=dev)
+    m, v, g = torch.zeros_like(flat), torch.zeros_like(flat), torch.empty_like(flat)
+    sum_h = 2 * h
+
+    def it(i):
+        idx = torch.randint(0, a.N, (a.batch,), device=dev, dtype=torch.int32)
+        u = torch.rand(a.batch * sum_h, device=dev)
+        b = torch.rand(a.batch * sum_h, device=dev)
+        step.loss_grad(Xn, Yn, idx, flat, u, b, g)
+        E.clip_adam(flat, g, m, v, i + 1, 1e-4, max_norm=None)
+
+    for i in range(20):
+        it(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.iters):
+        it(20 + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(flat).all())
+    # CPU leg: the oracle's step (torch autograd on the host), bounded sample
+    from oracle import ref_torch as R
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    W = [(torch.randn(dims[l + 1], dims[l]) / np.sqrt(dims[l]), torch.zeros(dims[l + 1])) for l in range(3)]
+    lp = [torch.full((h,), 1.1) for _ in range(2)]
+    params = [t for pair in W for t in pair] + lp
+    for p in params:
+        p.requires_grad_(True)
+    ms = [torch.zeros_like(p) for p in params]
+    vs = [torch.zeros_like(p) for p in params]
+    Xc, Yc = Xn.cpu(), Yn.cpu()
+
+    def cpu_it(i):
+        idx = torch.randint(0, a.N, (a.batch,))
+        us = [torch.rand(a.batch, h) for _ in range(2)]
+        hs = []
+        for p in params:
+            p.grad = None
+        with torch.no_grad():
+            for l in range(2):
+                hs.append(torch.bernoulli(torch.full((a.batch, h), 0.7)))
+        loss, _, _ = R.bnn_loss(W, lp, [0.1, 0.1], [0.5, 0.5], [1.0, 1.0], Xc[idx], Yc[idx], us, hs, a.N)
+        loss.backward()
+        with torch.no_grad():
+            for p, mm, vv in zip(params, ms, vs):
+                R.adam_step(p, p.grad, mm, vv, i + 1, 1e-4)
+
+    for i in range(5):
+        cpu_it(i)
+    t0 = time.perf_counter()
+    for i in range(a.cpu_iters):
+        cpu_it(5 + i)
+    dtc = time.perf_counter() - t0
+    print(json.dumps(dict(metric='bnn_training_iterations_per_sec', value=a.iters / dt, unit='it/s',
+                          us_per_iteration=dt / a.iters * 1e6,
+                          config=dict(workload='dynamics BNN %s, minibatch %d of %d rows, concrete dropout, '
+                                               'Gaussian NLL + regulariser, Adam' % (dims, a.batch, a.N)),
+                          cpu_baseline=dict(value=a.cpu_iters / dtc, unit='it/s', cores=torch.get_num_threads(),
+                                            kind='port', sample='%d iterations' % a.cpu_iters))))
+
+
+if __name__ == '__main__':
+    main()

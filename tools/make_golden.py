@@ -389,6 +389,102 @@ def make_standalone_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, seed=11)
     return d
 
 
+def make_bnn_case(name, D, U, dyn_hid, N, M, iters, lr, seed=21, reg_weight=1.0):
+    """BNN maximum-likelihood training of the dynamics model: the body of utils.train_regressor
+    (utils/train_regressor.py:58-165) run for a few iterations with Adam, with the random draws
+    of the concrete-dropout layers (uniform noise and Bernoulli samples) recorded."""
+    print('[bnn] %s' % name)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    from prob_mbrl.losses import gaussian_log_likelihood
+    dyn_model = models.mlp(D + U, 2 * D, dyn_hid,
+                           dropout_layers=[models.modules.CDropout(0.25 * np.ones(h)) for h in dyn_hid],
+                           nonlin=torch.nn.ReLU)
+    dyn = models.DynamicsModel(dyn_model, reward_func=None,
+                               output_density=models.DiagGaussianDensity(D)).float()
+    Xd = torch.randn(N, D + U)
+    Yd = 0.3 * torch.randn(N, D) + 0.5 * Xd[:, :D] * Xd[:, D:D + 1]
+    dyn.set_dataset(Xd, Yd)
+    # non-trivial dropout logits
+    for m in dyn.model._modules.values():
+        if isinstance(m, models.modules.CDropout):
+            m.logit_p.data = m.logit_p.data + 0.3 * torch.randn_like(m.logit_p.data)
+    d = {}
+    f = lambda t: t.detach().double().cpu().numpy()  # noqa: E731
+    lins = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    drops = [m for m in dyn.model._modules.values() if isinstance(m, models.modules.CDropout)]
+    d['n_layers'] = len(lins)
+    for i, m in enumerate(lins):
+        d['W%d_init' % i] = f(m.weight)
+        d['b%d_init' % i] = f(m.bias)
+    for i, m in enumerate(drops):
+        d['logit_p%d_init' % i] = f(m.logit_p)
+        d['temp%d' % i] = float(m.temp)
+        d['reg_scale%d' % i] = float(m.regularizer_scale)
+        d['drop_reg%d' % i] = float(m.dropout_regularizer)
+    Xn = (dyn.X - dyn.mx) * dyn.iSx
+    Yn = (dyn.Y - dyn.my) * dyn.iSy
+    d['Xn'] = f(Xn)
+    d['Yn'] = f(Yn)
+    d['N'], d['M'], d['iters'], d['lr'], d['reg_weight'] = N, M, iters, lr, reg_weight
+    d['max_log_std'] = float(dyn.output_density.max_log_std)
+
+    rec = []
+    orig_rand_like, orig_bern = torch.rand_like, torch.bernoulli
+
+    def rand_like(x, *a, **k):
+        out = orig_rand_like(x, *a, **k)
+        rec.append(('u', out.clone()))
+        return out
+
+    def bern(p, *a, **k):
+        out = orig_bern(p, *a, **k)
+        rec.append(('b', out.clone()))
+        return out
+
+    dyn.train()
+    opt = torch.optim.Adam([p for p in dyn.parameters() if p.requires_grad], lr)
+    rng = np.random.RandomState(seed)
+    losses = []
+    for it in range(iters):
+        idx = rng.permutation(N)[:M]
+        x, y = Xn[idx], Yn[idx]
+        dyn.zero_grad()
+        del rec[:]
+        torch.rand_like, torch.bernoulli = rand_like, bern
+        try:
+            outs = dyn(x, normalize=False, resample=True)
+        finally:
+            torch.rand_like, torch.bernoulli = orig_rand_like, orig_bern
+        us = [t for k, t in rec if k == 'u']
+        bs = [t for k, t in rec if k == 'b']
+        assert len(us) == len(drops) and len(bs) == len(drops), (len(us), len(bs))
+        log_probs = gaussian_log_likelihood(y, *outs)
+        Enlml = -log_probs.mean()
+        reg = reg_weight * dyn.regularization_loss()
+        loss = Enlml + reg / N
+        loss.backward()
+        if it == 0:
+            for i, m in enumerate(lins):
+                d['gW%d_it0' % i] = f(m.weight.grad)
+                d['gb%d_it0' % i] = f(m.bias.grad)
+            for i, m in enumerate(drops):
+                d['glogit_p%d_it0' % i] = f(m.logit_p.grad)
+        opt.step()
+        d['idx_it%d' % it] = idx.astype(np.int64)
+        for i in range(len(drops)):
+            d['u%d_it%d' % (i, it)] = f(us[i])
+            d['hard%d_it%d' % (i, it)] = f(bs[i])
+        losses.append([float(loss), float(Enlml), float(reg)])
+    d['losses'] = np.array(losses)
+    for i, m in enumerate(lins):
+        d['W%d_final' % i] = f(m.weight)
+        d['b%d_final' % i] = f(m.bias)
+    for i, m in enumerate(drops):
+        d['logit_p%d_final' % i] = f(m.logit_p)
+    return d
+
+
 def _cartpole():
     return CartpoleReward(pole_length=torch.tensor(0.5))
 
@@ -446,6 +542,8 @@ CASES = {
     'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
     'standalone_fwd_u4': lambda: make_standalone_case('standalone_fwd_u4', 8, 4, [48, 24, 40], [24, 24],
                                                       lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
+    'bnn_small': lambda: make_bnn_case('bnn_small', 4, 1, [32, 32], 60, 20, 3, 1e-3),
+    'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
@@ -475,6 +573,9 @@ def main():
                 out[k] = v32 if np.array_equal(v32.astype(np.float64), v) else v
             else:
                 out[k] = v
+        for k in list(out):
+            if k.startswith('hard'):
+                out[k] = np.asarray(out[k]).astype(np.uint8)
         # masks are {0,1}: store as bit-packed uint8
         for k in list(out):
             if '_mask' in k:
