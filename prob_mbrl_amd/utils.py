@@ -23,3 +23,11 @@ def train_regressor(*args, **kwargs):
     """utils/train_regressor.py:58-165 (see prob_mbrl_amd/train_regressor.py)."""
     from .train_regressor import train_regressor as _tr
     return _tr(*args, **kwargs)
+
+
+def __getattr__(name):
+    # host data path (prob_mbrl_amd/experience.py), resolved lazily: it imports this module
+    if name in ('ExperienceDataset', 'SumTree', 'apply_controller', 'load_checkpoint'):
+        from . import experience
+        return getattr(experience, name)
+    raise AttributeError(name)

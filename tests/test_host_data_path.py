@@ -1,0 +1,121 @@
+"""Host data path: ExperienceDataset / SumTree / checkpoints against vectors
+captured from the reference (tools/make_golden.py: experience_host)."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from tests import common
+
+
+def _load():
+    return np.load(os.path.join(common.GOLDEN, 'experience_host.npz'), allow_pickle=False)
+
+
+def _dataset(d):
+    from prob_mbrl_amd.utils import ExperienceDataset
+    exp = ExperienceDataset()
+    for e in range(int(d['n_episodes'])):
+        S, A, R = d['S%d' % e], d['A%d' % e], d['R%d' % e]
+        exp.append_episode([s for s in S], [a for a in A], [r for r in R], dones=[False] * len(S),
+                           infos=[{}] * len(S), ts=list(range(len(S))))
+    return exp
+
+
+def test_get_dynmodel_dataset_matches_reference():
+    d = _load()
+    exp = _dataset(d)
+    assert exp.n_episodes() == 3 and exp.n_samples() == 24
+    for k in range(int(d['n_opts'])):
+        opts = dict(ast.literal_eval(str(d['opt%d' % k])))
+        X, Y = exp.get_dynmodel_dataset(**opts)
+        assert X.dtype == torch.float64 and Y.dtype == torch.float64
+        assert X.shape == d['X%d' % k].shape and Y.shape == d['Y%d' % k].shape, (opts, X.shape, d['X%d' % k].shape)
+        assert np.array_equal(X.numpy(), d['X%d' % k]), opts
+        assert np.array_equal(Y.numpy(), d['Y%d' % k]), opts
+
+
+def test_sum_tree_matches_reference():
+    from prob_mbrl_amd.utils import SumTree
+    d = _load()
+    tree = SumTree(16)
+    for i, p in enumerate(d['tree_pri']):
+        tree.append(i * 10, p)
+    tree.renormalize()
+    np.random.seed(3 + 1)
+    for k, (bs, beta) in enumerate(((4, 0.4), (40, 1.0), (8, 0.7))):
+        samples, idxs, w = tree.sample(bs, beta=beta)
+        assert np.array_equal(np.asarray(samples), d['tree_samples%d' % k])
+        assert np.array_equal(np.asarray(idxs), d['tree_idxs%d' % k])
+        assert np.allclose(np.asarray(w), d['tree_w%d' % k], rtol=1e-12, atol=0)
+        tree.update(int(idxs[0]), 0.37)
+        tree.renormalize()
+    assert np.allclose(tree.sum_tree, d['tree_sum_tree'], rtol=1e-12, atol=1e-15)
+    assert np.array_equal(tree.counts, d['tree_counts'])
+    assert np.allclose([tree.idx, tree.max_p, tree.max_count, tree.size, tree.norm_factor], d['tree_scalars'])
+    idx, p, data = tree.get(0.5 * tree.sum_tree[0])
+    assert data == tree.data[idx - tree.max_size + 1] and p == tree.sum_tree[idx]
+
+
+def test_experience_roundtrip_sampling_and_checkpoint(tmp_path):
+    from prob_mbrl_amd.utils import ExperienceDataset, load_checkpoint
+    d = _load()
+    exp = _dataset(d)
+    f = str(tmp_path / 'ckpt' / 'experience.pth.tar')
+    exp.save(f)
+    sd = torch.load(f, weights_only=False)
+    assert set(sd) == {'states', 'actions', 'rewards', 'info', 'done', 'time_stamps', 'curr_episode',
+                       'policy_parameters'}      # the reference's on-disk keys
+    exp2 = ExperienceDataset()
+    exp2.load(f)
+    assert exp2.n_samples() == exp.n_samples() and exp2.curr_episode == exp.curr_episode
+    np.random.seed(0)
+    x0 = exp2.sample_states(50, timestep=0)
+    assert x0.shape == (50, 4) and x0.dtype == torch.float64
+    firsts = np.stack([d['S%d' % e][0] for e in range(3)])
+    assert all(any(np.array_equal(r, f0) for f0 in firsts) for r in x0.numpy())
+    assert exp2.sample_states(5, timestep=None).shape == (5, 4)
+    # add_sample on a fresh dataset; truncate / reset
+    exp3 = ExperienceDataset()
+    for t in range(4):
+        exp3.add_sample(np.zeros(4) + t, np.ones(2), 0.5, False, {}, t)
+    assert exp3.n_episodes() == 1 and exp3.n_samples() == 4
+    exp2.truncate(1)
+    assert exp2.n_episodes() == 2
+    exp2.reset()
+    assert exp2.n_samples() == 0 and exp2.curr_episode == -1
+
+    class _M:
+        def load(self, sd):
+            self.sd = sd
+    dyn, pol = _M(), _M()
+    torch.save({'a': torch.ones(2)}, str(tmp_path / 'ckpt' / 'latest_policy.pth.tar'))
+    exp4 = ExperienceDataset()
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        load_checkpoint(str(tmp_path / 'ckpt'), dyn, pol, exp4)
+    assert hasattr(pol, 'sd') and not hasattr(dyn, 'sd') and exp4.n_samples() == 24
+    assert any('latest_dynamics' in str(x.message) for x in w)
+
+
+def test_apply_controller_loop():
+    from prob_mbrl_amd.utils import apply_controller
+
+    class Env:
+        dt = 0.1
+
+        def reset(self):
+            self.t = 0
+            return np.zeros(3)
+
+        def step(self, u):
+            self.t += 1
+            return np.full(3, self.t, dtype=float), float(u.sum()), self.t >= 5, {}
+
+    seen = []
+    states, actions, costs, dones, infos = apply_controller(
+        Env(), lambda x, t=None: np.array([[1.0, 2.0]]), 20, callback=lambda *a: seen.append(a))
+    assert len(states) == 5 and dones[-1] and costs[0] == 3.0 and len(seen) == 5
+    assert np.array_equal(states[3], np.full(3, 3.0)) and actions[0].shape == (2,)

@@ -485,6 +485,54 @@ def make_bnn_case(name, D, U, dyn_hid, N, M, iters, lr, seed=21, reg_weight=1.0)
     return d
 
 
+def make_experience_case(name, seed=3):
+    """Host data path: ExperienceDataset.get_dynmodel_dataset under several option sets and a
+    scripted SumTree session (utils/experience_dataset.py:122-234, 271-367)."""
+    print('[experience] %s' % name)
+    from prob_mbrl.utils import ExperienceDataset, SumTree
+    rng = np.random.RandomState(seed)
+    exp = ExperienceDataset()
+    d = {}
+    lens = [7, 12, 5]
+    d['n_episodes'] = len(lens)
+    for e, T in enumerate(lens):
+        S = rng.randn(T, 4)
+        A = rng.randn(T, 2)
+        R = rng.randn(T, 1)
+        exp.append_episode([s for s in S], [a for a in A], [r for r in R], dones=[False] * T, infos=[{}] * T,
+                           ts=list(range(T)))
+        d['S%d' % e], d['A%d' % e], d['R%d' % e] = S, A, R
+    opts = [dict(), dict(deltas=False), dict(angle_dims=[1, 3]), dict(x_steps=3, u_steps=2),
+            dict(x_steps=2, u_steps=2, output_steps=3, return_costs=True), dict(return_costs=True),
+            dict(filter_episodes=[1]), dict(x_steps=3, stack=True), dict(x_steps=2, output_steps=2, stack=True,
+                                                                          return_costs=True, angle_dims=[0])]
+    d['n_opts'] = len(opts)
+    for k, o in enumerate(opts):
+        X, Y = exp.get_dynmodel_dataset(**o)
+        d['opt%d' % k] = np.array(repr(sorted(o.items())))
+        d['X%d' % k], d['Y%d' % k] = X.numpy(), Y.numpy()
+    # sum tree: appends, updates, renormalisation, stratified samples (np.random stream recorded by seed)
+    tree = SumTree(16)
+    pri = rng.rand(11) + 0.1
+    for i, p in enumerate(pri):
+        tree.append(i * 10, p)
+    tree.renormalize()
+    np.random.seed(seed + 1)
+    out = []
+    for bs, beta in ((4, 0.4), (40, 1.0), (8, 0.7)):
+        samples, idxs, w = tree.sample(bs, beta=beta)
+        out.append((np.asarray(samples), np.asarray(idxs), np.asarray(w)))
+        tree.update(int(idxs[0]), 0.37)
+        tree.renormalize()
+    d['tree_pri'] = pri
+    for k, (sm, ix, w) in enumerate(out):
+        d['tree_samples%d' % k], d['tree_idxs%d' % k], d['tree_w%d' % k] = sm, ix, w
+    d['tree_sum_tree'] = tree.sum_tree.copy()
+    d['tree_counts'] = tree.counts.copy()
+    d['tree_scalars'] = np.array([tree.idx, tree.max_p, tree.max_count, tree.size, tree.norm_factor])
+    return d
+
+
 def _cartpole():
     return CartpoleReward(pole_length=torch.tensor(0.5))
 
@@ -544,6 +592,7 @@ CASES = {
                                                       lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
     'bnn_small': lambda: make_bnn_case('bnn_small', 4, 1, [32, 32], 60, 20, 3, 1e-3),
     'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
+    'experience_host': lambda: make_experience_case('experience_host'),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
