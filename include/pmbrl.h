@@ -244,6 +244,20 @@ int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* call, void* workspace_
                       const float* sq_scale_d, const float* sq_bias_d,
                       float* sample_d /* [B][n_out] */, float* mean_d, float* log_std_d);
 
+/* Gradient of pmbrl_mlp_forward's outputs with respect to its input rows (network constant):
+ * grad_x = (d sample / d x)^T g_sample + (d mean / d x)^T g_mean + (d log_std / d x)^T g_log_std,
+ * same arguments as the forward; any of the three upstream gradients may be NULL.  Used when a
+ * stand-alone network sits inside a differentiable computation (the terminal value V(x_H) of
+ * algorithms/mc_pilco.py:136-140). */
+int pmbrl_mlp_grad_input(void* stream, const pmbrl_mlp_call* call, void* workspace_d,
+                         const float* x_d, const float* params_flat_d,
+                         const uint16_t* const* mask_bits_d, const float* z_d,
+                         const float* in_shift_d, const float* in_iscale_d,
+                         const float* out_scale_d, const float* out_shift_d,
+                         const float* sq_scale_d, const float* sq_bias_d,
+                         const float* g_sample_d, const float* g_mean_d, const float* g_log_std_d,
+                         float* grad_x_d /* [B][n_in] */);
+
 /* ---- BNN maximum-likelihood training of the dynamics model ---------------- */
 /* Loss and gradient of one minibatch: the iteration body of the reference's
  * utils.train_regressor (utils/train_regressor.py:113-131) with the model in train() mode --

@@ -74,7 +74,7 @@ EXPORTS = [
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
     'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
-    'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward',
+    'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad',
 ]
@@ -122,6 +122,8 @@ def load():
     lib.pmbrl_mlp_workspace_bytes.argtypes = [C.POINTER(MlpCall)]
     lib.pmbrl_mlp_forward.restype = C.c_int
     lib.pmbrl_mlp_forward.argtypes = [vp, C.POINTER(MlpCall), vp, vp, vp, C.POINTER(vp)] + [vp] * 10
+    lib.pmbrl_mlp_grad_input.restype = C.c_int
+    lib.pmbrl_mlp_grad_input.argtypes = [vp, C.POINTER(MlpCall), vp, vp, vp, C.POINTER(vp)] + [vp] * 11
     lib.pmbrl_bnn_plan_create.restype = C.c_int
     lib.pmbrl_bnn_plan_create.argtypes = [C.POINTER(BnnConfig), C.c_int, C.POINTER(vp)]
     lib.pmbrl_bnn_plan_destroy.restype = None

@@ -1007,7 +1007,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
 struct MlpLayout {
   int nl, LD;
   int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
-  size_t wf[PM_MAXL], bias[PM_MAXL], w_off[PM_MAXL], b_off[PM_MAXL], bytes, lds;
+  size_t wf[PM_MAXL], wb[PM_MAXL], bias[PM_MAXL], w_off[PM_MAXL], b_off[PM_MAXL], bytes, lds, lds_bwd;
 };
 static int mlp_layout(const pmbrl_mlp_call* c, MlpLayout& L) {
   if (!c) return fail(-1, "null argument");
@@ -1028,12 +1028,14 @@ static int mlp_layout(const pmbrl_mlp_call* c, MlpLayout& L) {
     L.w_off[l] = po; po += (size_t)L.dim[l + 1] * L.dim[l];
     L.b_off[l] = po; po += (size_t)L.dim[l + 1];
     L.wf[l] = off; off += (size_t)L.nt[l + 1] * L.nt[l] * 256 * sizeof(float);
+    L.wb[l] = off; off += (size_t)L.nt[l + 1] * L.nt[l] * 256 * sizeof(float);
     L.bias[l] = off; off += (size_t)L.nt[l + 1] * 16 * sizeof(float);
     if (l < L.nl - 1 && !(m.keep[l] > 0.f)) return fail(-2, "mlp: keep must be > 0");
   }
   L.bytes = off;
   L.LD = maxnt * 16 + 8;
   L.lds = (2 * (size_t)16 * L.LD + (size_t)PM_NW * PM_KS_NT * 256) * sizeof(float);
+  L.lds_bwd = pm_mlp_bwd_lds_floats(L.nl, L.LD) * sizeof(float);
   if (L.lds > 160 * 1024) return fail(-3, "mlp: network too wide for LDS");
   return 0;
 }
@@ -1084,6 +1086,55 @@ extern "C" int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* c, void* wo
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds));
   hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   hipLaunchKernelGGL(pm_mlp_fwd_kernel, dim3((c->B + 15) / 16), dim3(PM_NT), L.lds, s, A);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_mlp_grad_input(void* stream, const pmbrl_mlp_call* c, void* workspace_d,
+                                    const float* x_d, const float* params_flat_d,
+                                    const uint16_t* const* mask_bits_d, const float* z_d,
+                                    const float* in_shift_d, const float* in_iscale_d,
+                                    const float* out_scale_d, const float* out_shift_d,
+                                    const float* sq_scale_d, const float* sq_bias_d,
+                                    const float* g_sample_d, const float* g_mean_d,
+                                    const float* g_log_std_d, float* grad_x_d) {
+  MlpLayout L;
+  int rc = mlp_layout(c, L);
+  if (rc) return rc;
+  if (!workspace_d || !x_d || !params_flat_d || !grad_x_d) return fail(-1, "null argument");
+  if (L.lds_bwd > 160 * 1024) return fail(-3, "mlp: network too wide / deep for the input-gradient kernel's LDS budget");
+  if ((in_shift_d == nullptr) != (in_iscale_d == nullptr) || (out_scale_d == nullptr) != (out_shift_d == nullptr) ||
+      (sq_scale_d == nullptr) != (sq_bias_d == nullptr))
+    return fail(-1, "mlp: shift/scale pointers come in pairs");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = static_cast<char*>(workspace_d);
+  PackArgs PK;
+  PK.n = 0;
+  PK.status = nullptr;
+  MlpBwdArgs Bw;
+  memset(&Bw, 0, sizeof(Bw));
+  MlpArgs& A = Bw.f;
+  A.B = c->B; A.nl = L.nl; A.LD = L.LD; A.n_out = L.dim[L.nl] / 2;
+  for (int i = 0; i <= L.nl; ++i) { A.dim[i] = L.dim[i]; A.nt[i] = L.nt[i]; }
+  for (int l = 0; l < L.nl; ++l) {
+    float* wf = reinterpret_cast<float*>(ws + L.wf[l]);
+    float* wb = reinterpret_cast<float*>(ws + L.wb[l]);
+    float* bs = reinterpret_cast<float*>(ws + L.bias[l]);
+    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wf, L.dim[l + 1], L.dim[l], 0, 1, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wb, L.dim[l + 1], L.dim[l], 1, 1, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.b_off[l], bs, L.dim[l + 1], L.dim[l], 0, 1, 1};
+    A.wf[l] = wf; Bw.wb[l] = wb; A.bias[l] = bs;
+    A.mask[l] = (l < L.nl - 1 && mask_bits_d) ? mask_bits_d[l] : nullptr;
+    A.keep[l] = l < L.nl - 1 ? c->net.keep[l] : 1.f;
+  }
+  A.x = x_d; A.z = z_d; A.in_shift = in_shift_d; A.in_iscale = in_iscale_d;
+  A.out_scale = out_scale_d; A.out_shift = out_shift_d; A.sq_scale = sq_scale_d; A.sq_bias = sq_bias_d;
+  A.mls = c->max_log_std;
+  Bw.g_sample = g_sample_d; Bw.g_mean = g_mean_d; Bw.g_log_std = g_log_std_d; Bw.grad_x = grad_x_d;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mlp_bwdx_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bwd));
+  hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
+  hipLaunchKernelGGL(pm_mlp_bwdx_kernel, dim3((c->B + 15) / 16), dim3(PM_NT), L.lds_bwd, s, Bw);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -41,69 +41,117 @@ def pack_mask(mask):
     return bits
 
 
+class _MlpCall:
+    """Marshalled arguments of one stand-alone network evaluation (kept alive for the backward)."""
+
+    def __init__(self, x, params_flat, dims, keep, mask_bits, z, in_shift, in_iscale, out_scale,
+                 out_shift, sq_scale, sq_bias, max_log_std):
+        self.lib = _lib.load()
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+        B = x.shape[0]
+        nl = len(dims) - 1
+        assert x.shape[1] == dims[0] and dims[-1] % 2 == 0
+        self.x, self.B, self.n_out, self.dims = x, B, dims[-1] // 2, list(dims)
+        call = _lib.MlpCall()
+        call.B = B
+        call.net.n_layers = nl
+        for i, d in enumerate(dims):
+            call.net.dims[i] = int(d)
+        for l in range(nl - 1):
+            call.net.keep[l] = float(keep[l])
+        call.max_log_std = float(max_log_std)
+        self.call = call
+        nbytes = self.lib.pmbrl_mlp_workspace_bytes(C.byref(call))
+        if nbytes == 0:
+            msg = self.lib.pmbrl_last_error()
+            raise ValueError('pmbrl_mlp_workspace_bytes: %s' % (msg.decode() if msg else 'bad shape'))
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        self.masks = (C.c_void_p * max(nl - 1, 1))()
+        self.keepalive = []
+        for l in range(nl - 1):
+            m = mask_bits[l] if mask_bits is not None else None
+            if m is not None:
+                assert m.is_cuda and m.dtype == torch.int16 and m.shape == (B, (dims[l + 1] + 15) // 16)
+                m = m.contiguous()
+                self.keepalive.append(m)
+            self.masks[l] = m.data_ptr() if m is not None else None
+
+        def vec(t, n):
+            if t is None:
+                return None
+            t = t.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+            if t.numel() == 1 and n > 1:
+                t = t.expand(n).contiguous()
+            assert t.numel() == n
+            return t
+
+        self.in_shift, self.in_iscale = vec(in_shift, dims[0]), vec(in_iscale, dims[0])
+        self.out_scale, self.out_shift = vec(out_scale, self.n_out), vec(out_shift, self.n_out)
+        self.sq_scale, self.sq_bias = vec(sq_scale, self.n_out), vec(sq_bias, self.n_out)
+        if z is not None:
+            assert z.is_cuda and z.dtype == torch.float32 and z.shape == (B, self.n_out)
+            z = z.contiguous()
+        self.z = z
+        self.pf = params_flat.detach().contiguous()
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _common(self):
+        p = self._p
+        return [p(self.x), p(self.pf), self.masks, p(self.z), p(self.in_shift), p(self.in_iscale),
+                p(self.out_scale), p(self.out_shift), p(self.sq_scale), p(self.sq_bias)]
+
+    def forward(self, want):
+        out = {k: torch.empty((self.B, self.n_out), dtype=torch.float32, device=self.x.device) for k in want}
+        p = self._p
+        _lib.check(self.lib.pmbrl_mlp_forward(_stream(), C.byref(self.call), p(self.ws), *self._common(),
+                                              p(out.get('sample')), p(out.get('mean')), p(out.get('log_std'))),
+                   'pmbrl_mlp_forward')
+        return out
+
+    def grad_input(self, g_sample=None, g_mean=None, g_log_std=None):
+        gx = torch.empty_like(self.x)
+        p = self._p
+        gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_sample, g_mean, g_log_std)]
+        _lib.check(self.lib.pmbrl_mlp_grad_input(_stream(), C.byref(self.call), p(self.ws), *self._common(),
+                                                 p(gs[0]), p(gs[1]), p(gs[2]), p(gx)), 'pmbrl_mlp_grad_input')
+        return gx
+
+
+class _MlpFunction(torch.autograd.Function):
+    """Differentiable with respect to the input rows only (the network is a constant here)."""
+
+    @staticmethod
+    def forward(ctx, x, call, want):
+        ctx.call, ctx.want = call, want
+        out = call.forward(want)
+        return tuple(out[k] for k in want)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g = dict(zip(ctx.want, grads))
+        gx = ctx.call.grad_input(g.get('sample'), g.get('mean'), g.get('log_std'))
+        return gx, None, None
+
+
 def mlp_forward(x, params_flat, dims, keep, mask_bits=None, z=None, in_shift=None, in_iscale=None,
                 out_scale=None, out_shift=None, sq_scale=None, sq_bias=None, max_log_std=math.log(5.0),
                 want=('sample',)):
     """Stand-alone evaluation of one Bayesian MLP with a diagonal-Gaussian head on the rows of x
     (pmbrl_mlp_forward; models/core.py:169-187, 221-248).  dims = [n_in, h..., 2*n_out];
     mask_bits: per hidden layer an int16 bit-row tensor (pack_mask) or None.
-    Returns a dict with the requested outputs among 'sample', 'mean', 'log_std' ([B, n_out])."""
-    lib = _lib.load()
-    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
-    B = x.shape[0]
-    nl = len(dims) - 1
-    assert x.shape[1] == dims[0] and dims[-1] % 2 == 0
-    n_out = dims[-1] // 2
-    call = _lib.MlpCall()
-    call.B = B
-    call.net.n_layers = nl
-    for i, d in enumerate(dims):
-        call.net.dims[i] = int(d)
-    for l in range(nl - 1):
-        call.net.keep[l] = float(keep[l])
-    call.max_log_std = float(max_log_std)
-    nbytes = lib.pmbrl_mlp_workspace_bytes(C.byref(call))
-    if nbytes == 0:
-        msg = lib.pmbrl_last_error()
-        raise ValueError('pmbrl_mlp_workspace_bytes: %s' % (msg.decode() if msg else 'bad shape'))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    masks = (C.c_void_p * max(nl - 1, 1))()
-    keepalive = []
-    for l in range(nl - 1):
-        m = mask_bits[l] if mask_bits is not None else None
-        if m is not None:
-            assert m.is_cuda and m.dtype == torch.int16 and m.shape == (B, (dims[l + 1] + 15) // 16)
-            m = m.contiguous()
-            keepalive.append(m)
-        masks[l] = m.data_ptr() if m is not None else None
-
-    def vec(t, n):
-        if t is None:
-            return None
-        t = t.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
-        if t.numel() == 1 and n > 1:
-            t = t.expand(n).contiguous()
-        assert t.numel() == n
-        keepalive.append(t)
-        return t
-
-    in_shift, in_iscale = vec(in_shift, dims[0]), vec(in_iscale, dims[0])
-    out_scale, out_shift = vec(out_scale, n_out), vec(out_shift, n_out)
-    sq_scale, sq_bias = vec(sq_scale, n_out), vec(sq_bias, n_out)
-    if z is not None:
-        assert z.is_cuda and z.dtype == torch.float32 and z.shape == (B, n_out)
-        z = z.contiguous()
-    out = {k: torch.empty((B, n_out), dtype=torch.float32, device=x.device) for k in want}
-    pf = params_flat.contiguous()
-
-    def p(t):
-        return C.c_void_p(t.data_ptr()) if t is not None else None
-
-    _lib.check(lib.pmbrl_mlp_forward(_stream(), C.byref(call), p(ws), p(x), p(pf), masks, p(z),
-                                     p(in_shift), p(in_iscale), p(out_scale), p(out_shift),
-                                     p(sq_scale), p(sq_bias), p(out.get('sample')), p(out.get('mean')),
-                                     p(out.get('log_std'))), 'pmbrl_mlp_forward')
-    return out
+    Returns a dict with the requested outputs among 'sample', 'mean', 'log_std' ([B, n_out]).
+    If x requires grad the outputs are differentiable with respect to x (pmbrl_mlp_grad_input)."""
+    want = tuple(want)
+    xc = x.contiguous()
+    call = _MlpCall(xc.detach(), params_flat, dims, keep, mask_bits, z, in_shift, in_iscale, out_scale,
+                    out_shift, sq_scale, sq_bias, max_log_std)
+    if x.requires_grad and torch.is_grad_enabled():
+        outs = _MlpFunction.apply(xc, call, want)
+        return dict(zip(want, outs))
+    return call.forward(want)
 
 
 class BnnStep:

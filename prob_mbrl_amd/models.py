@@ -266,7 +266,7 @@ class BSequential(nn.Sequential):
             raise NotImplementedError('a diagonal-Gaussian output density is required on the device path')
         if not x.is_cuda:
             raise RuntimeError('the network lives on a HIP device: pass a device tensor (no CPU fallback)')
-        x = x.to(torch.float32).contiguous()
+        x = x.to(torch.float32)
         B = x.shape[0]
         dims = [linears[0].in_features] + [l.out_features for l in linears]
         flat, _ = flat_parameters(linears, self)

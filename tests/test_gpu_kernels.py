@@ -280,3 +280,43 @@ def test_bnn_training_matches_reference(name):
         got = flat[off:off + n].cpu().numpy()
         assert np.allclose(got, d[key + '_final'].reshape(-1), rtol=2e-5, atol=5e-7), key
         off += n
+
+
+@pytest.mark.gpu
+def test_mlp_input_gradient_matches_torch():
+    """pmbrl_mlp_grad_input (autograd through a stand-alone network) against torch autograd on
+    the same formula."""
+    from prob_mbrl_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device('cuda:0')
+    B, dims = 45, [6, 40, 56, 6]
+    nl, n_out = 3, 3
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i]) for i in range(nl)]
+    bs = [0.1 * torch.randn(dims[i + 1], generator=g) for i in range(nl)]
+    masks = [(torch.rand(B, dims[i + 1], generator=g) < 0.8).float() for i in range(nl - 1)]
+    keep = [0.8, 1.0]
+    x = torch.randn(B, dims[0], generator=g, dtype=torch.float64).requires_grad_(True)
+    z = torch.randn(B, n_out, generator=g)
+    shift, iscale = torch.randn(dims[0], generator=g), 0.5 + torch.rand(dims[0], generator=g)
+    osc, osh = 0.5 + torch.rand(n_out, generator=g), torch.randn(n_out, generator=g)
+    sqs, sqb = 1.0 + torch.rand(n_out, generator=g), 0.1 * torch.randn(n_out, generator=g)
+    cs, cm, cl = (torch.randn(B, n_out, generator=g) for _ in range(3))
+    d = lambda t: t.double()  # noqa: E731
+    h = (x - d(shift)) * d(iscale)
+    for i in range(nl - 1):
+        h = torch.relu(h @ d(Ws[i]).t() + d(bs[i])) * d(masks[i]) / keep[i]
+    o = h @ d(Ws[-1]).t() + d(bs[-1])
+    mu, ls = o[:, :n_out], o[:, n_out:]
+    mls = float(np.log(5.0))
+    ls = -torch.nn.functional.softplus(-ls + mls) + mls + d(osc).log()
+    mu = mu * d(osc) + d(osh)
+    smp = d(sqs) * torch.tanh(mu + d(z) * ls.exp()) + d(sqb)
+    ((smp * d(cs)).sum() + (mu * d(cm)).sum() + (ls * d(cl)).sum()).backward()
+    flat = torch.cat([t.reshape(-1) for pair in zip(Ws, bs) for t in pair]).to(dev)
+    bits = [E.pack_mask(m.to(dev)) for m in masks]
+    xg = x.detach().float().to(dev).requires_grad_(True)
+    out = E.mlp_forward(xg, flat, dims, keep, bits, z.to(dev), shift, iscale, osc, osh, sqs, sqb,
+                        max_log_std=mls, want=('sample', 'mean', 'log_std'))
+    ((out['sample'] * cs.to(dev)).sum() + (out['mean'] * cm.to(dev)).sum() +
+     (out['log_std'] * cl.to(dev)).sum()).backward()
+    assert common.rel(xg.grad.cpu().numpy(), x.grad.numpy()) < 2e-5
