@@ -5,9 +5,12 @@ Two execution paths, same semantics:
    [gradient all-reduce] -> clip + Adam are C-ABI calls on flat buffers; no
    autograd graph, no torch.nn op, one host sync per iteration (status + loss).
    Used when the optimiser is a plain torch.optim.Adam over the policy's Linear
-   parameters and no option needs autograd (CVaR, regulariser).
+   parameters and no option needs autograd (CVaR, regulariser, value_func,
+   prioritized_replay).
  * autograd: `rollout()`'s single autograd node + torch's loss / clip / optimiser
-   for everything else the reference signature allows.
+   for everything else the reference signature allows.  value_func is evaluated by
+   pmbrl_mlp_forward and differentiated by pmbrl_mlp_grad_input; the priorities of
+   prioritized_replay come from pmbrl_rollout_bwd's action_grad_norms output.
 """
 import math
 import traceback
@@ -21,6 +24,8 @@ from . import rollout as RO
 from .utils import tile
 
 policy_update_counter = defaultdict(lambda: 0)   # algorithms/mc_pilco.py:8
+x0_tree = None          # SumTree(2**20) of start states, built on first use (mc_pilco.py:9)
+episode_counter = 0     # episodes of `exp` already in x0_tree (mc_pilco.py:10)
 
 
 def _discount_fn(discount, steps):
@@ -93,11 +98,12 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     gradient is all-reduced over RCCL before the identical clip + Adam on every rank);
     `frozen_noise` -- dict(z_mm=..., z_rr=...) to inject captured PEGASUS noise (tests);
     `progress` -- print the reference's tqdm-style line every 50 iterations."""
-    global policy_update_counter
-    if value_func is not None:
-        raise NotImplementedError('value_func bootstrap is not offered yet (SURVEY.md 8f N3)')
-    if prioritized_replay:
-        raise NotImplementedError('prioritized_replay is not offered yet (SURVEY.md 8f N3)')
+    global policy_update_counter, x0_tree, episode_counter
+    if (value_func is not None or prioritized_replay) and process_group is not None:
+        raise NotImplementedError('value_func / prioritized_replay run on the single-process path')
+    if prioritized_replay and x0_tree is None:
+        from .experience import SumTree
+        x0_tree = SumTree(2**20)
     dynamics.eval()
     policy.train()
     H = int(steps)
@@ -128,13 +134,20 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
             seed = seed + 7919 * rank
         dynamics.resample(seed=seed)
         policy.resample(seed=seed)
+        if value_func is not None:
+            value_func.resample(seed=seed)
         z_mm.normal_()
         z_rr.normal_()
 
     resample()
     x0 = init_states
     n_opt_steps = policy_update_counter[policy]
-    need_autograd = (cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0) or reg_weight > 0
+    need_autograd = ((cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0) or reg_weight > 0
+                     or value_func is not None or prioritized_replay)
+    replay = None
+    if prioritized_replay:      # algorithms/mc_pilco.py:80-84
+        replay = dict(idxs=None, weights=None, beta=init_priority_beta, eps=priority_eps,
+                      alpha=priority_alpha, tree=x0_tree, N=N_particles)
     gamma_full = [float(disc(i)) for i in range(H)]
     sign = -1.0 if maximize else 1.0
 
@@ -160,7 +173,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 loss, states, actions, rewards = _autograd_iteration(
                     x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups, z_mm,
                     z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i, rk,
-                    process_group, world)
+                    process_group, world, value_func, replay)
             else:
                 eng = bundle.engine
                 S, A, R = bundle.forward(x0_)
@@ -181,6 +194,8 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 grp = cache['group']
                 E.clip_adam(bundle.pol_flat, g, cache['m'], cache['v'], cache['step'], grp['lr'],
                             grp['betas'], grp['eps'], max_norm=clip_grad)
+        except NotImplementedError:      # an option the device path does not offer: not a failed rollout
+            raise
         except RuntimeError:
             # algorithms/mc_pilco.py:122-131: print, draw new random numbers, skip the step
             traceback.print_exc()
@@ -197,8 +212,22 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
         # new initial states (algorithms/mc_pilco.py:222-263)
         if exp is not None:
             n_draw = mm_groups if mm_groups is not None else N_particles
-            x0 = exp.sample_states(n_draw, timestep=step_idx_to_sample).to(dev, torch.float32)
-            init_states = x0
+            if prioritized_replay:
+                # grow the tree with the episodes it has not seen (mc_pilco.py:224-231)
+                if exp.n_samples() > x0_tree.size:
+                    for idx in range(episode_counter, exp.n_episodes()):
+                        for x in torch.as_tensor(np.asarray(exp.states[idx])):
+                            x0_tree.append(x, x0_tree.max_p)
+                            x0_tree.renormalize()
+                    episode_counter = exp.n_episodes()
+                xs, replay['idxs'], w = x0_tree.sample(n_draw, beta=replay['beta'])
+                # (sic) max, not min: beta never drops below 1 (mc_pilco.py:240-241)
+                replay['beta'] = max(1.0, replay['beta'] + priority_beta_increase)
+                x0 = torch.stack([torch.as_tensor(x) for x in xs]).to(dev, torch.float32)
+                replay['weights'] = torch.as_tensor(np.stack(w)).to(dev, torch.float32)
+            else:
+                x0 = exp.sample_states(n_draw, timestep=step_idx_to_sample).to(dev, torch.float32)
+                init_states = x0
         else:
             x0 = init_states.detach()
 
@@ -226,22 +255,43 @@ def _loss_weights(eng, gamma, sign, B_global, dev):
     return gw
 
 
+def _update_priorities(replay, m_norms, mm_groups):
+    """New priorities of the sampled start states from the per-step ||dL/da_t|| of their
+    particles (mc_pilco.py:163-182; the reference collects the same norms with tensor hooks on
+    actions[t], here they are an output of the adjoint sweep)."""
+    tree, idxs = replay['tree'], replay['idxs']
+    if mm_groups is not None:
+        m_norms = m_norms.reshape(-1, mm_groups, int(replay['N'] / mm_groups)).mean(-1)
+    scores = m_norms.mean(0).detach().cpu().numpy() / tree.counts[idxs - tree.max_size + 1]
+    priorities = (scores + replay['eps'])**replay['alpha']
+    for idx, p in zip(idxs, priorities):
+        tree.update(idx, p)
+    tree.renormalize()
+
+
 def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups,
                         z_mm, z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i,
-                        rollout_kwargs, process_group, world):
+                        rollout_kwargs, process_group, world, value_func=None, replay=None):
     """The reference loop body on top of the single-node autograd rollout."""
     if world > 1:
         raise NotImplementedError('sharded runs use the fused path (plain Adam, no CVaR/regulariser)')
     policy.zero_grad()
     opt.zero_grad()
+    weighted = replay is not None and replay['idxs'] is not None
+    norms_out = [] if weighted else None
     states, actions, rewards = RO.rollout(
         x0_, dynamics, policy, H, resample_state_noise=not pegasus,
         resample_action_noise=not pegasus, mm_states=mm_states, mm_rewards=mm_rewards,
         z_mm=z_mm if pegasus else None, z_rr=z_rr if pegasus else None, mm_groups=mm_groups,
-        **rollout_kwargs)
+        action_grad_norms_out=norms_out, **rollout_kwargs)
     if callable(on_rollout):
         on_rollout(i, states, actions, rewards, disc)
     discounted = torch.stack([r * disc(t) for t, r in enumerate(rewards)])
+    if value_func is not None:
+        # terminal-value bootstrap (mc_pilco.py:136-140); dV/ds_H comes from pmbrl_mlp_grad_input
+        # and enters the adjoint sweep as grad_states[H]
+        Vend = value_func(states[-1], resample=False, return_samples=True)
+        discounted = torch.cat([discounted, disc(H) * Vend.unsqueeze(0)], 0)
     returns = -discounted.sum(0) if maximize else discounted.sum(0)
     if cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0:
         rd = returns.detach()
@@ -251,10 +301,16 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
         else:
             q = np.quantile(rd.cpu().numpy(), -cvar_eps)
             returns = returns[rd > q]
+    if weighted:
+        # importance-sampling weights, broadcast exactly as the reference does ([B,1] * [n],
+        # mc_pilco.py:156-158)
+        returns = returns * replay['weights']
     loss = returns.mean()
     if reg_weight > 0:
         loss = loss + reg_weight * policy.regularization_loss()
     loss.backward()
+    if weighted:
+        _update_priorities(replay, norms_out[0][:len(actions)], mm_groups)
     if clip_grad is not None:
         torch.nn.utils.clip_grad_norm_(policy.parameters(), clip_grad)
     opt.step()

@@ -262,14 +262,23 @@ class BSequential(nn.Sequential):
         from .rollout import flat_parameters
         linears, drops, inner = self.layer_spec()
         density = inner if inner is not None else density
-        if density is None:
-            raise NotImplementedError('a diagonal-Gaussian output density is required on the device path')
         if not x.is_cuda:
             raise RuntimeError('the network lives on a HIP device: pass a device tensor (no CPU fallback)')
         x = x.to(torch.float32)
         B = x.shape[0]
         dims = [linears[0].in_features] + [l.out_features for l in linears]
         flat, _ = flat_parameters(linears, self)
+        plain = density is None
+        if plain:
+            # a network without an output density (the critic of
+            # examples/deep_pilco_no_mm_with_value.py:269-278; models/core.py:185-186:
+            # out * Sy + my).  The kernel always evaluates a Gaussian head, so give it one whose
+            # log-std rows are zero and read back the (scaled) mean.
+            O, K = dims[-1], dims[-2]
+            n_last = O * K + O
+            flat = torch.cat([flat[:flat.numel() - n_last], flat[-n_last:-O], flat.new_zeros(O * K),
+                              flat[-O:], flat.new_zeros(O)])
+            dims = dims[:-1] + [2 * O]
         keep, bits = [], []
         for lin, dr in zip(linears[:-1], drops):
             if dr is None:
@@ -279,6 +288,9 @@ class BSequential(nn.Sequential):
                 m = dr.forward_mask(B, lin.out_features, resample=resample, seed=seed)
                 keep.append(dr.keep_prob())
                 bits.append(E.pack_mask(m.to(device=x.device, dtype=torch.float32)))
+        if plain:
+            return E.mlp_forward(x, flat, dims, keep, bits, None, in_shift, in_iscale, out_scale,
+                                 out_shift, want=('mean',))['mean']
         z = None
         if return_samples:
             z = density.frozen_noise(B, resample_noise, seed).to(device=x.device, dtype=torch.float32)

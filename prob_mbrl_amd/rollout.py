@@ -223,7 +223,11 @@ class RolloutFunction(torch.autograd.Function):
         if gR is None:
             gR = torch.zeros((eng.H, eng.B), device=bundle.device)
         want_x0 = ctx.needs_input_grad[1]
-        g, gx0, _ = eng.backward(gR, grad_states=gS, grad_actions=gA, want_x0=want_x0)
+        agn_out = getattr(bundle, 'agn_out', None)
+        g, gx0, agn = eng.backward(gR, grad_states=gS, grad_actions=gA, want_x0=want_x0,
+                                   want_agn=agn_out is not None)
+        if agn_out is not None:
+            agn_out.append(agn)
         g = g.clone()
         grads, off = [], 0
         for p in bundle.pol_params:
@@ -260,6 +264,8 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
                     mm_states, mm_rewards, mm_groups, z_mm, z_rr,
                     B_global=kwargs.pop('B_global', None), row_offset=kwargs.pop('row_offset', 0))
+    # a list that backward() appends the [H, B] matrix of ||dL/da_t|| to (prioritised replay)
+    bundle.agn_out = kwargs.pop('action_grad_norms_out', None)
     x0 = states.to(device=bundle.device, dtype=torch.float32)
     S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
     n = bundle.engine.valid_steps()

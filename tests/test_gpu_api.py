@@ -216,3 +216,99 @@ def test_train_regressor_fits_a_dataset():
     mean, log_std = dyn(X[:32], resample=False)
     err = (mean - Y[:32]).abs().mean()
     assert float(err) < 0.35 and bool(torch.isfinite(log_std).all())
+
+
+def _value_from_fixture(d):
+    """The critic of examples/deep_pilco_no_mm_with_value.py:269-278 (no output density,
+    concrete dropout, eval mode) holding the fixture's weights and masks."""
+    import prob_mbrl_amd as pm
+    n = int(d['val_n_layers'])
+    hid = [d['val_W%d' % i].shape[0] for i in range(n - 1)]
+    D = d['val_W0'].shape[1]
+    V = pm.models.Regressor(pm.models.mlp(
+        D, 1, hid, dropout_layers=[pm.models.CDropout(0.1 * np.ones(h)) for h in hid],
+        nonlin=torch.nn.ReLU)).float()
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
+    with torch.no_grad():
+        lins = [m for m in V.model._modules.values() if isinstance(m, torch.nn.Linear)]
+        for i, lin in enumerate(lins):
+            lin.weight.copy_(T(d['val_W%d' % i]))
+            lin.bias.copy_(T(d['val_b%d' % i]))
+        for i in range(n - 1):
+            dr = getattr(V.model, 'drop%d' % i)
+            dr.noise.data = torch.rand(d['val_mask%d' % i].shape)
+            dr.concrete_noise = T(d['val_mask%d' % i])
+        for k in ('mx', 'iSx', 'my', 'Sy'):
+            getattr(V, k).data = T(d['val_' + k]).reshape(1, -1)
+    return V.to(DEV).eval()
+
+
+def _flat_params(pol):
+    lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    return torch.cat([t.detach().reshape(-1) for l in lins for t in (l.weight, l.bias)]).cpu().numpy()
+
+
+def test_mc_pilco_value_bootstrap_matches_reference():
+    """mc_pilco(value_func=V): fixture from the reference's own run (algorithms/mc_pilco.py:136-140).
+    dV/ds_H comes from pmbrl_mlp_grad_input and enters the adjoint sweep as grad_states[H]."""
+    import prob_mbrl_amd as pm
+    d = common.load('ext_value')
+    dyn, pol = common.modules_from_fixture(d, 'ext_value', DEV)
+    V = _value_from_fixture(d)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    # the critic alone: value and input gradient against the oracle
+    from oracle import ref_torch as R
+    val = R.value_from_npz(d, torch.float64)
+    xr = torch.tensor(d['x0'], dtype=torch.float64, requires_grad=True)
+    vr = R.value_forward(xr, val)
+    vr.sum().backward()
+    xd = x0.clone().requires_grad_(True)
+    vd = V(xd, resample=False, return_samples=True)
+    assert vd.shape == (x0.shape[0], 1)
+    vd.sum().backward()
+    assert common.rel(vd.detach().cpu().numpy(), vr.detach().numpy()) < 2e-6
+    assert common.rel(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5
+    opt = torch.optim.Adam(pol.parameters(), float(d['mcp_lr']))
+    losses = []
+    pm.algorithms.mc_pilco(
+        x0, dyn, pol, int(d['H']), opt, None, int(d['mcp_n_iters']), value_func=V, maximize=True,
+        clip_grad=float(d['mcp_clip']), on_iteration=lambda i, loss, *a: losses.append(float(loss)),
+        frozen_noise=dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1)))
+    assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
+    assert np.allclose(_flat_params(pol), d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+
+
+def test_mc_pilco_prioritized_replay_matches_reference():
+    """mc_pilco(prioritized_replay=True) over an ExperienceDataset: same sampled start states in
+    every iteration, same losses / parameters / final priorities as the reference's run
+    (algorithms/mc_pilco.py:80-84, 156-188, 222-246).  The per-step ||dL/da_t|| come out of the
+    adjoint sweep (pmbrl_rollout_bwd's action_grad_norms) instead of tensor hooks."""
+    import prob_mbrl_amd as pm
+    from prob_mbrl_amd import algorithms as ALG
+    d = common.load('ext_replay')
+    dyn, pol = common.modules_from_fixture(d, 'ext_replay', DEV)
+    exp = pm.utils.ExperienceDataset()
+    for e in range(int(d['replay_n_episodes'])):
+        st = d['replay_states%d' % e]
+        T = len(st)
+        exp.append_episode(list(st), list(np.zeros((T, 1), np.float32)), list(np.zeros(T)), [None] * T, None)
+    ALG.x0_tree, ALG.episode_counter = None, 0
+    np.random.seed(int(d['replay_np_seed']))
+    opt = torch.optim.Adam(pol.parameters(), float(d['mcp_lr']))
+    losses, x0s = [], []
+    pm.algorithms.mc_pilco(
+        torch.tensor(d['x0'], device=DEV), dyn, pol, int(d['H']), opt, exp, int(d['mcp_n_iters']),
+        maximize=True, clip_grad=float(d['mcp_clip']), prioritized_replay=True, priority_alpha=0.6,
+        init_priority_beta=0.4, priority_beta_increase=0.1,
+        on_rollout=lambda i, s, a, r, disc: x0s.append(s[0].detach().cpu().numpy()),
+        on_iteration=lambda i, loss, *a: losses.append(float(loss)),
+        frozen_noise=dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1)))
+    assert np.array_equal(np.stack(x0s), d['replay_x0s'].astype(np.float32))
+    assert np.allclose(losses, d['ref32_mcp_losses'], rtol=1e-4)
+    assert np.allclose(_flat_params(pol), d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+    tree = ALG.x0_tree
+    n = len(d['replay_final_counts'])
+    assert tree.size == n and np.array_equal(tree.counts[:n], d['replay_final_counts'])
+    assert np.allclose(tree.sum_tree[tree.max_size - 1:tree.max_size - 1 + n],
+                       d['replay_final_leaves'], rtol=1e-3)
+    ALG.x0_tree, ALG.episode_counter = None, 0

@@ -295,13 +295,42 @@ def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
 
 def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
                       mm=False, mm_groups=None, lr=1e-3, clip=1.0, seed=0,
-                      discount=None):
+                      discount=None, value_hid=None, replay=False):
     """Run the REAL algorithms.mc_pilco for n_iters with a fixed x0 and capture
-    the frozen randomness through a wrapper around utils.rollout."""
+    the frozen randomness through a wrapper around utils.rollout.
+
+    value_hid: also pass a critic (the network of examples/deep_pilco_no_mm_with_value.py:
+    269-278, in eval mode) as value_func.  replay: run with prioritized_replay=True over a small
+    synthetic ExperienceDataset (numpy seeded right before the call: SumTree.sample draws from
+    np.random)."""
     rew = rew_fn()
     dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
     torch.manual_seed(seed + 1000)
     x0 = 0.1 * torch.randn(B, D)
+    V, exp, extra_kw = None, None, {}
+    if value_hid is not None:
+        torch.manual_seed(seed + 77)
+        V = models.Regressor(models.mlp(
+            D, 1, value_hid, dropout_layers=[models.modules.CDropout(0.1 * np.ones(h)) for h in value_hid],
+            nonlin=torch.nn.ReLU)).float()
+        V.set_dataset(0.2 * torch.randn(200, D), 0.5 + 0.3 * torch.randn(200, 1))
+        V.eval()
+        with torch.no_grad():
+            V(x0, resample=False)          # shape mismatch: draws and stores masks for B rows
+        extra_kw['value_func'] = V
+    if replay:
+        rs = np.random.RandomState(seed + 31)
+        exp = utils.ExperienceDataset()
+        episodes = []
+        for e in range(3):
+            T = 12 + 3 * e
+            st = (0.1 * rs.randn(T, D)).astype(np.float32)
+            ac = rs.randn(T, U).astype(np.float32)
+            exp.append_episode(list(st), list(ac), list(np.zeros(T)), [None] * T, None)
+            episodes.append(st)
+        assert sys.modules['prob_mbrl.algorithms.mc_pilco'].x0_tree.size == 0
+        extra_kw.update(prioritized_replay=True, priority_alpha=0.6, init_priority_beta=0.4,
+                        priority_beta_increase=0.1)
     torch.manual_seed(seed + 5)
     with torch.no_grad():
         dyn.eval()
@@ -329,14 +358,45 @@ def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
         losses.append(float(loss))
 
     utils.rollout = wrapped
+    x0s = []
+    if replay:
+        np.random.seed(seed + 99)
+
+    def wrapped_x0(states, *a, **kw):
+        x0s.append(states.detach().clone())
+        return wrapped(states, *a, **kw)
+
+    utils.rollout = wrapped_x0
     try:
-        algorithms.mc_pilco(x0, dyn, pol, H, opt, None, n_iters, mm_states=mm,
+        algorithms.mc_pilco(x0, dyn, pol, H, opt, exp, n_iters, mm_states=mm,
                             mm_rewards=mm, mm_groups=mm_groups, maximize=True,
                             clip_grad=clip, discount=discount,
-                            on_iteration=on_iteration, resampling_period=99)
+                            on_iteration=on_iteration, resampling_period=99, **extra_kw)
     finally:
         utils.rollout = orig_rollout
     d = cap['d']
+    if V is not None:
+        f = lambda t: t.detach().double().cpu().numpy()  # noqa: E731
+        lin = [m for m in V.model._modules.values() if isinstance(m, torch.nn.Linear)]
+        drops = [m for m in V.model._modules.values() if isinstance(m, models.modules.CDropout)]
+        d['val_n_layers'] = len(lin)
+        for i, m in enumerate(lin):
+            d['val_W%d' % i] = f(m.weight)
+            d['val_b%d' % i] = f(m.bias)
+        for i, dr in enumerate(drops):
+            d['val_mask%d' % i] = f(dr.concrete_noise)
+        for k in ['mx', 'iSx', 'my', 'Sy']:
+            d['val_' + k] = f(getattr(V, k)).reshape(-1)
+    if replay:
+        d['replay_n_episodes'] = len(episodes)
+        for e, st in enumerate(episodes):
+            d['replay_states%d' % e] = st
+        d['replay_np_seed'] = seed + 99
+        d['replay_x0s'] = torch.stack(x0s).double().numpy()       # start states of every iteration
+        tree = sys.modules['prob_mbrl.algorithms.mc_pilco'].x0_tree
+        n = tree.size
+        d['replay_final_counts'] = tree.counts[:n].copy()
+        d['replay_final_leaves'] = tree.sum_tree[tree.max_size - 1:tree.max_size - 1 + n].copy()
     for i, p in enumerate(init_params):
         pass
     assert len(losses) == n_iters, losses
@@ -596,6 +656,10 @@ CASES = {
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
+    'ext_value': lambda: make_mcpilco_case('ext_value', 4, 1, [32, 32], [32, 32],
+                                           _cartpole, 10.0, 30, 10, 4, seed=15, value_hid=[24, 24]),
+    'ext_replay': lambda: make_mcpilco_case('ext_replay', 4, 1, [32, 32], [32, 32],
+                                            _cartpole, 10.0, 36, 8, 4, seed=16, replay=True),
     'mcp_mm1': lambda: make_mcpilco_case('mcp_mm1', 5, 1, [32, 32], [32, 32],
                                          _cartpole, 10.0, 30, 10, 3,
                                          mm=True, seed=14, discount=0.95),
