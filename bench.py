@@ -39,6 +39,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
+    # debugging aids for the N>1 control flow on a box with ONE GPU (tests/test_gpu_api.py):
+    # every rank on cuda:0, collectives over gloo.  Never used for a reported number.
+    ap.add_argument('--dist-backend', default='nccl')
+    ap.add_argument('--one-device', action='store_true')
     return ap.parse_args()
 
 
@@ -103,8 +107,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
     dev = torch.device('cuda:%d' % local_rank)
     torch.cuda.set_device(dev)
@@ -154,20 +160,18 @@ def main():
     assert eng.valid_steps() == H, 'numerical failure inside the benchmark rollout'
     assert bool(torch.isfinite(params).all()) and bool(torch.isfinite(loss_buf).all())
 
-    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
-    timings = None
-    if rank == 0:
-        eng.set_timing(True)
-        acc = {}
-        for _ in range(a.timing_steps):
-            step()
-            for k, ms in eng.read_timing().items():
-                if ms >= 0:
-                    acc.setdefault(k, []).append(ms)
-        eng.set_timing(False)
-        timings = {k: float(np.mean(vv)) for k, vv in acc.items()}
-    if world > 1:
-        dist.barrier()
+    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region.
+    # Every rank runs these steps (step() contains the gradient all-reduce); rank 0 reports its own.
+    eng.set_timing(True)
+    acc = {}
+    for _ in range(a.timing_steps):
+        step()
+        for k, ms in eng.read_timing().items():
+            if ms >= 0:
+                acc.setdefault(k, []).append(ms)
+    eng.set_timing(False)
+    timings = {k: float(np.mean(vv)) for k, vv in acc.items()}
+    sync()
 
     if rank == 0:
         flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
@@ -200,7 +204,7 @@ def main():
                                   'RCCL all-reduce + ' if world > 1 else ''),
                         rows_per_gpu=B, global_rows=Bg, horizon=H, parallelism='dp%d' % world,
                         rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
-                        mm_mode=eng.info['mm_mode']),
+                        mm_mode=eng.info['mm_mode'], **({'debug_one_device': True} if a.one_device else {})),
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},

@@ -1,0 +1,94 @@
+"""GPU (-m gpu), world_size 2 on ONE device: the N>1 control flow of bench.py and of
+mc_pilco(process_group=...) with both ranks on cuda:0 and the collectives over gloo (RCCL refuses
+two ranks on one GPU; the driver's multi-GPU bench is the RCCL run).  What is checked is what
+cannot be checked on CPU: every rank issues the same sequence of collectives around real kernel
+launches, and the sharded iteration reproduces the reference's single-process result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+ROOT = common.ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_one_device():
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_rows'] == 2 * out['config']['rows_per_gpu']
+    assert out['scaling'] == 'weak' and out['value'] > 0 and out['config']['debug_one_device']
+    assert 'cpu_baseline' not in out
+
+
+def _mcp_worker(rank, world, port, name, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import prob_mbrl_amd as pm
+        from prob_mbrl_amd import distributed as D
+        d = dict(common.load(name))
+        B = d['x0'].shape[0]
+        lo, hi = D.shard_bounds(B, None, world, rank)
+        for k in list(d):
+            if k == 'x0' or k in ('pol_z', 'dyn_z') or '_mask' in k:
+                d[k] = d[k][lo:hi]
+        dyn, pol = common.modules_from_fixture(d, name, 'cuda:0')
+        opt = torch.optim.Adam(pol.parameters(), float(d['mcp_lr']))
+        losses = []
+        pm.algorithms.mc_pilco(
+            torch.tensor(d['x0'], device='cuda:0'), dyn, pol, int(d['H']), opt, None,
+            int(d['mcp_n_iters']), maximize=True, clip_grad=float(d['mcp_clip']),
+            on_iteration=lambda i, loss, *a: losses.append(float(loss)),
+            frozen_noise=dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1)),
+            process_group=dist.group.WORLD)
+        lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+        final = torch.cat([t.detach().reshape(-1) for l in lins for t in (l.weight, l.bias)])
+        out.put((rank, losses, final.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mc_pilco_two_ranks_match_reference():
+    """Rows sharded over two ranks (15 + 15 of the fixture's 30), gradient and loss all-reduced:
+    the reference's single-process losses and final parameters on BOTH ranks."""
+    import torch.multiprocessing as mp
+    name = 'mcp_nomm'
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mcp_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = common.load(name)
+    for rank, losses, final in res:
+        assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
+        assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(res[0][2], res[1][2])      # replicas stay bit-identical
