@@ -273,7 +273,7 @@ struct pmbrl_plan {
   int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
   int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
-  size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part,
+  size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
       off_gxc, off_grt, off_Jx, off_Ja, ws_bytes;
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
@@ -326,10 +326,15 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void* fns[] = {
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_LEAN>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_LEAN>),
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_EXT>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_EXT>),
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MM>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM>)};
+  for (const void* f : fns)
+    HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
 
@@ -602,6 +607,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Td = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_xt = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_rt = take((size_t)c.H * c.B * sizeof(float));
+    p->off_mmfac = take(p->mm_mode == 1 ? (size_t)c.H * (c.B / p->M) * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
     p->off_Jx = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
@@ -760,6 +766,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.Td = reinterpret_cast<float*>(ws + p->off_Td);
   A.xt = reinterpret_cast<float*>(ws + p->off_xt);
   A.rt = reinterpret_cast<float*>(ws + p->off_rt);
+  A.mmfac = reinterpret_cast<double*>(ws + p->off_mmfac);
+  A.mmfac_groups = p->mm_mode == 1 ? c.B / p->M : 0;
   A.Jx = reinterpret_cast<float*>(ws + p->off_Jx);
   A.Ja = reinterpret_cast<float*>(ws + p->off_Ja);
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
@@ -828,10 +836,21 @@ static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s)
 }
 template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-  if (fwd)
-    hipLaunchKernelGGL((pm_rollout_fwd_fast<RT, CA, CB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
-  else
-    hipLaunchKernelGGL((pm_rollout_bwd_fast<RT, CA, CB>), dim3(p->nwg), dim3(PF_NT), p->lds_bytes, s, A);
+  // variant: see pmbrl_fast.h (PF_VAR_*)
+  const bool mm = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
+  const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0;
+  const dim3 g(p->nwg), b(PF_NT);
+#define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
+  if (fwd) {
+    if (mm) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);
+    else if (ext) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_EXT);
+    else PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_LEAN);
+  } else {
+    if (mm) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MM);
+    else if (ext) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_EXT);
+    else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_LEAN);
+  }
+#undef PM_LAUNCH_VAR
 }
 static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
 #define PM_FAST_CASE(RTV, CAV, CBV) \

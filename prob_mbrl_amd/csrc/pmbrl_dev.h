@@ -91,6 +91,8 @@ struct RolloutArgs {
   float* gT[PM_MAXL];     // policy pre-activation grads, same layout
   float *Tp, *Td;         // [H][B][U], [H][B][D]
   float *xt, *rt;         // pre-moment-matching next state / reward [H][B][D], [H][B]
+  double* mmfac;          // in-kernel moment matching: statistics + factor per (step, group), forward -> adjoint
+  int mmfac_groups;       // groups per step in mmfac (= B / M)
   float *Jx, *Ja;         // reward Jacobian d r~/d x~ [H][B][D], d r~/d a [H][B][U] (fast kernels)
   int* status;
   // backward only

@@ -917,9 +917,28 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 // ===========================================================================
 // forward (fast)
 // ===========================================================================
-template <int RT, int CA, int CB>
+// Kernel variants (template parameter VAR).  The sweep kernels are one long register- and
+// SGPR-bound body: code that a launch never executes still costs every phase registers, so the
+// rarely used paths are compiled only into the variants that need them.
+//   LEAN  what mc_pilco's fused iteration and bench.py launch: no moment matching inside the
+//         sweep, frozen output noise, no external state / action gradients, no action-gradient
+//         norms, no cycle stamps
+//   EXT   + per-step output noise (resample_*_noise), grad_states / grad_actions inputs,
+//         action_grad_norms output, cycle stamps (pmbrl_plan_set_prof)
+//   MM    EXT + the in-kernel moment matching of states (mm_mode 1)
+#define PF_VAR_LEAN 0
+#define PF_VAR_EXT 1
+#define PF_VAR_MM 2
+#define PF_MARK(slot)                                                                              \
+  do {                                                                                             \
+    if (EXT && A.prof && wg == 0 && tid == 0)                                                      \
+      A.prof[(size_t)t * 32 + (slot)] = (long long)__builtin_readcyclecounter();                   \
+  } while (0)
+
+template <int RT, int CA, int CB, int VAR>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -966,7 +985,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     cur_advance<CA>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
-  const bool mm_in = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
+  const bool mm_in = MM && A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
   // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
@@ -1012,7 +1031,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
     float* Y = L.bufB;
-    PM_MARK(0);
+    PF_MARK(0);
     if (!fed) {
       // dynamics-state rows -> policy input tile (+ dW stash); later steps of the plain path
       // get this written by the previous step's sampling phase
@@ -1042,23 +1061,23 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       Res0Pre<RT, EpiFwdL<RT>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
-      PM_MARK(1);
+      PF_MARK(1);
       res0_layer<RT>(w0p, e.nt, X, LD, wid, lane, e, pp);
       if (pnl > 2) es = pol_epi(1, t, blk, X);     // layer 1 writes the buffer that is X now
     }
     __syncthreads();
     PM_SWAP_XY();
-    PM_MARK(2);
+    PF_MARK(2);
     for (int l = 1; l < pnl - 1; ++l) {
-      PM_STREAM_LAYER(l - 1, es, 0, (A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
+      PM_STREAM_LAYER(l - 1, es, 0, (EXT && A.prof && wg == 0 && tid == 0) ? A.prof + (size_t)t * 32 : nullptr);
       if (l + 1 < pnl - 1) es = pol_epi(l + 1, t, blk, X);
       __syncthreads();
       PM_SWAP_XY();
-      PM_MARK(2 + l);
+      PF_MARK(2 + l);
     }
     head_partial<RT>(hwp, pol_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
-    PM_MARK(10);
+    PF_MARK(10);
     // ---- squash + dynamics input
     {
       const float* hb = pol_head_bias;
@@ -1074,7 +1093,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           const float ls = hb[U + j] + head_value<RT>(hp, r, U + j);
           float z = L.zp[r * U + j];
           asm volatile("" : "+v"(z));   // keep the LDS load a load (no select of LDS / HBM addresses -> FLAT)
-          if (A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
+          if (EXT && A.zpol_ss != 0 && r < nvalid) z = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j];
           // lc = c - softplus(c - ls)  =>  e = exp(lc) = exp(c) sigmoid(ls - c),
           // d lc / d ls = sigmoid(c - ls) = 1 - sigmoid(ls - c): one exp instead of four
           const float sg = 1.f / (1.f + expf(A.mls_pol - ls));
@@ -1098,23 +1117,23 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       Res0Pre<RT, EpiFwdL<RT>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
-      PM_MARK(11);
+      PF_MARK(11);
       res0_layer<RT>(w0d, e.nt, X, LD, wid, lane, e, pp);
       if (fnl > 2) es = dyn_epi(1, t, X);
     }
     __syncthreads();
     PM_SWAP_XY();
-    PM_MARK(12);
+    PF_MARK(12);
     for (int l = 1; l < fnl - 1; ++l) {
       PM_STREAM_LAYER(n_pol_stream + l - 1, es, 0, nullptr);
       if (l + 1 < fnl - 1) es = dyn_epi(l + 1, t, X);
       __syncthreads();
       PM_SWAP_XY();
-      PM_MARK(12 + l);
+      PF_MARK(12 + l);
     }
     head_partial<RT>(hwd, dyn_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
-    PM_MARK(20);
+    PF_MARK(20);
     // ---- sample next state; on the plain path also the next step's policy input tile
     {
       const float* hb = dyn_head_bias;
@@ -1132,7 +1151,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           const float ls = hb[D + d] + head_value<RT>(hp, r, D + d);
           float z = L.zd[o_l];
           asm volatile("" : "+v"(z));
-          if (A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
+          if (EXT && A.zdyn_ss != 0 && r < nvalid) z = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d];
           const float sg = 1.f / (1.f + expf(A.mls_dyn - ls));
           const float e = max_std_dyn * L.Sy[d] * sg;
           xn = xa[o_l] + (mu * L.Sy[d] + L.my[d] + z * e);
@@ -1150,7 +1169,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         }
       }
     }
-    PM_MARK(21);
+    PF_MARK(21);
     // The reward is NOT evaluated here: r~[t,b] depends only on the stored (x~, a), never feeds
     // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
     // after the sweep (so is the moment matching of rewards).  Only the moment matching of
@@ -1163,7 +1182,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
         const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, L.zs + lr0 * D, D, 0, 0, false,
-                                  xa + lr0 * D, D, scr, lane);
+                                  xa + lr0 * D, D, scr, lane,
+                                  A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
         if (!ok && lane == 0) atomicMin(A.status, t);
       }
       __syncthreads();
@@ -1172,7 +1192,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     } else {
       float* tmp = xa; xa = xb; xb = tmp;
     }
-    PM_MARK(22);
+    PF_MARK(22);
     // (no closing barrier: the next step's first phase opens with one)
   }
 }
@@ -1180,9 +1200,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 // ===========================================================================
 // backward sweep (fast)
 // ===========================================================================
-template <int RT, int CA, int CB>
+template <int RT, int CA, int CB, int VAR>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1207,7 +1228,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     float v = 0.f;
     if (r < nvalid) {
       if (A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
-      else if (A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
+      else if (EXT && A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
     }
     gx[i] = v;
   }
@@ -1284,7 +1305,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     L.bufA[r * LD + k] = v;
     if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
   };
-  const bool mm_in = (A.mm_mode == 1 && mms);
+  const bool mm_in = MM && (A.mm_mode == 1 && mms);
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
@@ -1322,7 +1343,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
     float* Y = L.bufB;
-    PM_MARK(0);
+    PF_MARK(0);
     float pfv[PFV];
 #pragma unroll
     for (int u = 0; u < PFV; ++u)
@@ -1349,10 +1370,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
         pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
-                  gxt + lr0 * D, D, scr, lane);
+                  gxt + lr0 * D, D, scr, lane,
+                  A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
       }
     }
-    PM_MARK(1);
+    PF_MARK(1);
     // ---- reward adjoint from the stashed Jacobian, fused with the dynamics head adjoint input.
     //      On the plain path the previous step's last phase has already done this.
     if (!pa_done) {
@@ -1371,23 +1393,23 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       Res0Pre<RT, EpiBwdL<RT>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
-      PM_MARK(3);
+      PF_MARK(3);
       res0_layer<RT>(whd, e.nt, X, LD, wid, lane, e, pp);
       if (fnl > 2) es = dyn_epi(fnl - 3, t, X);
     }
     __syncthreads();
     PM_SWAP_XY();
-    PM_MARK(4);
+    PF_MARK(4);
     for (int l = fnl - 2, si = 0; l >= 1; --l, ++si) {
       PM_STREAM_LAYER(si, es, 0, nullptr);
       if (l - 1 >= 1) es = dyn_epi(l - 2, t, X);
       __syncthreads();
       PM_SWAP_XY();
-      PM_MARK(4 + l);
+      PF_MARK(4 + l);
     }
     head_partial<RT>(twd, dyn_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
-    PM_MARK(12);
+    PF_MARK(12);
     // ---- phase B: tail result; state part -> gxn, action part -> policy head adjoint
     {
       float* gst = gT_head + blk * (size_t)16 * A.Rw;
@@ -1402,7 +1424,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
           float go_mu = 0.f, go_ls = 0.f;
           if (r < nvalid) {
             float ga = L.gad[r * 16 + j] + tail;
-            if (A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
+            if (EXT && A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
             L.gad[r * 16 + j] = ga;
             const float sc = L.psc[j];
             const float th = (stg[r * S + 1 + 2 * D + 2 * U + j] - L.pbi[j]) / sc;
@@ -1431,14 +1453,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       Res0Pre<RT, EpiBwdL<RT>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
-      PM_MARK(13);
+      PF_MARK(13);
       // park the prefetched inputs of step t-1 (phase B was the last reader of step t's)
 #pragma unroll
       for (int u = 0; u < PFV; ++u) {
         const int i = tid + u * PF_NT;
         if (i < R * S) L.stg[i] = pfv[u];
       }
-      if (A.agn) {
+      if (EXT && A.agn) {
         for (int r = tid; r < nvalid; r += PF_NT) {
           float s2 = 0.f;
           for (int j = 0; j < U; ++j) s2 = fmaf(L.gad[r * 16 + j], L.gad[r * 16 + j], s2);
@@ -1450,17 +1472,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     }
     __syncthreads();
     PM_SWAP_XY();
-    PM_MARK(14);
+    PF_MARK(14);
     for (int l = pnl - 2, si = 0; l >= 1; --l, ++si) {
       PM_STREAM_LAYER(n_dyn_stream + si, es, 0, nullptr);
       if (l - 1 >= 1) es = pol_epi(l - 2, t, blk, X);
       __syncthreads();
       PM_SWAP_XY();
-      PM_MARK(14 + l);
+      PF_MARK(14 + l);
     }
     head_partial<RT>(twp, pol_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
-    PM_MARK(22);
+    PF_MARK(22);
     // ---- dL/dx_t = gxn + policy tail (+ external state gradient); on the plain path the same
     //      threads go straight on to phase A of step t-1 (its inputs were parked mid-step)
     {
@@ -1476,14 +1498,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         float v = 0.f;
         if (k < 2 * D) {
           v = gxn[r * D + d] + head_value<RT>(hp, r, d);
-          if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
+          if (EXT && A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
           if (k < D) gx[r * D + d] = v;
         }
         if (do_pa) phase_a(r, k, v, gxn_next);
       }
       gxn = gxn_next;
     }
-    PM_MARK(23);
+    PF_MARK(23);
     // (no closing barrier: the next step's first phase opens with one)
   }
   __syncthreads();

@@ -18,6 +18,10 @@ __host__ __device__ inline size_t pm_mm_scratch_doubles(int d) {
   return d > 0 ? (size_t)3 * d * d + 5 * d : 0;
 }
 
+// leading part of the scratch that the forward pass hands to the adjoint: mean, zmean, zistd,
+// (mbar), invd, L  -- see pm_mm_carve
+__host__ __device__ inline size_t pm_mm_fac_doubles(int d) { return (size_t)5 * d + (size_t)d * d; }
+
 // 1/sqrt(x) in fp64 from the hardware estimate + Newton steps (the IEEE sqrt and divide
 // expansions cost several hundred cycles each and sat on the serial path of every pivot and
 // every triangular-solve element)
@@ -151,10 +155,14 @@ __device__ __forceinline__ bool pm_mm_factor(const float* s, int s_ld, int M, in
 
 __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
                                  int zrow0, int Bg, bool infer_ns, float* out, int out_ld,
-                                 double* scr, int lane) {
+                                 double* scr, int lane, double* fac_out = nullptr) {
   (void)infer_ns;   // value of the infer_ns variant equals s; not offered on the device path
   const MMScratch q = pm_mm_carve(scr, d);
   const bool ok = pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
+  // the adjoint needs the same means / standardisation / factor: hand them over instead of
+  // having it redo the statistics and the factorisation (pm_mm_fac_doubles values)
+  if (fac_out)
+    for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) fac_out[e] = scr[e];
   for (int e = lane; e < M * d; e += 64) {
     const int r = e / d, j = e - r * d;
     double acc = q.mean[j];
@@ -170,10 +178,16 @@ __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d
 // g: upstream dL/d out [M][d]; gout: dL/d s [M][d] (may alias g).
 __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
                                  int zrow0, int Bg, bool infer_ns, const float* g, int g_ld,
-                                 float* gout, int gout_ld, double* scr, int lane) {
+                                 float* gout, int gout_ld, double* scr, int lane,
+                                 const double* fac = nullptr) {
   (void)infer_ns;
   const MMScratch q = pm_mm_carve(scr, d);
-  (void)pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
+  if (fac) {
+    for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) scr[e] = fac[e];
+    pm_wave_sync();
+  } else {
+    (void)pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
+  }
   const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
   // mbar = sum_r g ;  Lbar = tril(g^T zhat)  -> q.P
   {
@@ -254,3 +268,4 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
   }
   pm_wave_sync();
 }
+
