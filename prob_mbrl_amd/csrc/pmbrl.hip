@@ -838,7 +838,8 @@ template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   // variant: see pmbrl_fast.h (PF_VAR_*)
   const bool mm = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
-  const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0;
+  const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
+                   (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
   const dim3 g(p->nwg), b(PF_NT);
 #define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
   if (fwd) {

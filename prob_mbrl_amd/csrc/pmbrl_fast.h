@@ -874,7 +874,7 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 }
 
 // partial head tiles: fixed region, or the idle activation buffer (Y)
-#define PM_HP() (L.bufA + (L.hp_off >= 0 ? L.hp_off : (xsel ^ 1) * (R * LD)))
+#define PM_HP() (L.bufA + ((RT < 4 || L.hp_off >= 0) ? L.hp_off : (xsel ^ 1) * (R * LD)))   // aliasing: RT >= 4 only
 // one streamed layer (index SI of the stream table) with epilogue ES and, when the layer's last
 // tile is K-split, that tile's partial / gather / epilogue around it
 #define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
@@ -920,8 +920,8 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 // Kernel variants (template parameter VAR).  The sweep kernels are one long register- and
 // SGPR-bound body: code that a launch never executes still costs every phase registers, so the
 // rarely used paths are compiled only into the variants that need them.
-//   LEAN  what mc_pilco's fused iteration and bench.py launch: no moment matching inside the
-//         sweep, frozen output noise, no external state / action gradients, no action-gradient
+//   LEAN  what mc_pilco's fused iteration and bench.py launch: the whole horizon in one launch, no
+//         moment matching of states, frozen output noise, no external state / action gradients, no action-gradient
 //         norms, no cycle stamps
 //   EXT   + per-step output noise (resample_*_noise), grad_states / grad_actions inputs,
 //         action_grad_norms output, cycle stamps (pmbrl_plan_set_prof)
@@ -939,6 +939,9 @@ template <int RT, int CA, int CB, int VAR>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  // LEAN: whole horizon in one launch, no moment matching of states anywhere
+  const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
+  const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -957,12 +960,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   {
-    const float* src = (A.t0 == 0) ? A.x0 : A.states + (size_t)A.t0 * B * D;
+    const float* src = (T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D;
     for (int i = tid; i < R * D; i += PF_NT) {
       const int r = i / D, d = i - r * D;
       const float v = (r < nvalid) ? src[(size_t)(row0 + r) * D + d] : 0.f;
       xa[i] = v;
-      if (A.t0 == 0 && r < nvalid) A.states[(size_t)(row0 + r) * D + d] = v;
+      if (T0 == 0 && r < nvalid) A.states[(size_t)(row0 + r) * D + d] = v;
     }
   }
   // register-resident first layers and head slices
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     cur_advance<CA>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
-  const bool mm_in = MM && A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
+  const bool mm_in = MM && A.mm_mode == 1 && mm_states;
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
   // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int pnl = P.nl, fnl = F.nl;
 
   bool fed = false;   // the previous step's sampling phase already wrote this step's policy input
-  for (int t = A.t0; t < A.t1; ++t) {
+  for (int t = T0; t < T1; ++t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       const float* hb = dyn_head_bias;
       const float* hp = PM_HP();
       // (not when the partial tiles sit in bufA: the feed below writes there)
-      const bool feed = !mm_in && (t + 1 < A.t1) && !(L.hp_off < 0 && xsel == 1);
+      const bool feed = !mm_in && (t + 1 < T1) && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
       fed = feed;
       float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * A.Rw;
       for (int i = tid; i < R * 16; i += PF_NT) {
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           if (r < nvalid) {
             const size_t o = ((size_t)t * B + row0 + r) * D + d;
             A.Td[o] = z * e * (1.f - sg);
-            if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
+            if (mm_states) A.xt[o] = xn;
             else A.states[o + (size_t)B * D] = xn;
           }
         }
@@ -1204,6 +1207,9 @@ template <int RT, int CA, int CB, int VAR>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  // LEAN: whole horizon in one launch, no moment matching of states anywhere
+  const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
+  const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1217,7 +1223,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   float* gx = L.xa;     // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;    // moment-matching adjoint of gx (in-kernel mm only)
   float* gxn = L.jx;    // dL/dx~ incl. the reward term, then + dynamics-input term
-  const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
+  const bool mms = mm_states;
 
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
   pm_fast_preload_tails(A.sd_bwd, L, tid);
@@ -1227,7 +1233,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     const int r = i / D, d = i - r * D;
     float v = 0.f;
     if (r < nvalid) {
-      if (A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
+      if (EXT && A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
       else if (EXT && A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
     }
     gx[i] = v;
@@ -1281,7 +1287,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
 #pragma unroll
   for (int u = 0; u < PFV; ++u) {
     const int idx = tid + u * PF_NT;
-    if (idx < R * S) L.stg[idx] = pf_base[u] ? pf_base[u][(size_t)(A.t1 - 1) * pf_str[u]] : 0.f;
+    if (idx < R * S) L.stg[idx] = pf_base[u] ? pf_base[u][(size_t)(T1 - 1) * pf_str[u]] : 0.f;
   }
   __syncthreads();
 
@@ -1338,7 +1344,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // Same phase pattern as the forward sweep: descriptors and the epilogue's activation bits
   // (HBM / L2 reads) are issued before the barrier that opens a phase.
   bool pa_done = false;   // the previous step's last phase already ran this step's phase A
-  for (int t = A.t1 - 1; t >= A.t0; --t) {
+  for (int t = T1 - 1; t >= T0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
     float* X = L.bufA;
@@ -1347,7 +1353,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     float pfv[PFV];
 #pragma unroll
     for (int u = 0; u < PFV; ++u)
-      pfv[u] = (t > A.t0 && pf_base[u]) ? pf_base[u][(size_t)(t - 1) * pf_str[u]] : 0.f;
+      pfv[u] = (t > T0 && pf_base[u]) ? pf_base[u][(size_t)(t - 1) * pf_str[u]] : 0.f;
     if (mm_in) {
       // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
       const float* xsrc = A.xt + (size_t)t * B * D;
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     {
       const float* hp = PM_HP();
       // phase A of step t-1 writes bufA: not while the partial tiles sit there
-      const bool do_pa = !mm_in && t > A.t0 && !(L.hp_off < 0 && xsel == 1);
+      const bool do_pa = !mm_in && t > T0 && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
       pa_done = do_pa;
       if (do_pa) gsel ^= 1;
       float* gxn_next = L.jx + (gsel ? xb_off : 0);
@@ -1511,7 +1517,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   __syncthreads();
   for (int i = tid; i < nvalid * D; i += PF_NT) {
     const size_t o = (size_t)row0 * D + i;
-    if (A.gx_carry) A.gx_carry[o] = gx[i];
-    if (A.t0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
+    if (EXT && A.gx_carry) A.gx_carry[o] = gx[i];
+    if (T0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
   }
 }
