@@ -46,7 +46,9 @@ def _adam_flat_state(opt, params, flat):
     g = opt.param_groups[0]
     if g.get('weight_decay', 0) != 0 or g.get('amsgrad', False) or g.get('maximize', False):
         return None
-    gp = [p for p in g['params']]
+    # frozen tensors (e.g. the reward module's constants inside DynamicsModel.parameters()) sit in
+    # the group but never receive a gradient: Adam skips them, so do we
+    gp = [p for p in g['params'] if p.requires_grad]
     if len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)):
         return None
     cache = getattr(opt, '_pmbrl_flat', None)
@@ -233,7 +235,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
 
     cache = getattr(opt, '_pmbrl_flat', None)
     if cache is not None and type(opt) is torch.optim.Adam:
-        _sync_adam_state(opt, [p for p in opt.param_groups[0]['params']], cache)
+        _sync_adam_state(opt, [p for p in opt.param_groups[0]['params'] if p.requires_grad], cache)
     policy.eval()
     dynamics.eval()
     policy_update_counter[policy] = n_opt_steps

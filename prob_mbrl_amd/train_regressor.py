@@ -45,12 +45,21 @@ def flat_module_parameters(params, owner, key='_pmbrl_flat_all'):
     return flat
 
 
+def _is_diag_gaussian_ll(fn):
+    """None, losses.gaussian_log_likelihood, or the bound DiagGaussianDensity.log_prob the example
+    scripts pass (examples/deep_pilco_mm.py:224; same formula, models/densities.py:123-144)."""
+    if fn is None or getattr(fn, '__name__', '') == 'gaussian_log_likelihood':
+        return True
+    from .models import DiagGaussianDensity
+    return isinstance(getattr(fn, '__self__', None), DiagGaussianDensity) and fn.__name__ == 'log_prob'
+
+
 def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=None, log_likelihood=None,
                     reg_weight=1.0, pbar_class=None, summary_writer=None, summary_scope='',
                     decoupled_reg=False, prioritized_sampling=False, priority_eps=1e-3, priority_alpha=0.6):
     """Same call as the reference.  Offered on the device: the default Gaussian likelihood,
     coupled regularisation, uniform minibatches, a plain torch.optim.Adam."""
-    if log_likelihood is not None and getattr(log_likelihood, '__name__', '') != 'gaussian_log_likelihood':
+    if not _is_diag_gaussian_ll(log_likelihood):
         raise NotImplementedError('only the diagonal-Gaussian log-likelihood is offered on the device path')
     if decoupled_reg or prioritized_sampling:
         raise NotImplementedError('decoupled_reg / prioritized_sampling are not offered on the device path')

@@ -312,3 +312,40 @@ def test_mc_pilco_prioritized_replay_matches_reference():
     assert np.allclose(tree.sum_tree[tree.max_size - 1:tree.max_size - 1 + n],
                        d['replay_final_leaves'], rtol=1e-3)
     ALG.x0_tree, ALG.episode_counter = None, 0
+
+
+def test_example_script_end_to_end(tmp_path):
+    """examples/deep_pilco.py = the loop of the reference's example scripts (apply_controller ->
+    ExperienceDataset -> train_regressor -> mc_pilco, checkpoints on disk) on the self-contained
+    cart-pole: two short policy-search rounds, with and without moment matching."""
+    import importlib.util
+    import os
+    import prob_mbrl_amd as pm
+    spec = importlib.util.spec_from_file_location('deep_pilco_example',
+                                                  os.path.join(common.ROOT, 'examples', 'deep_pilco.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for extra in ([], ['--no_mm']):
+        folder, hist = mod.main(['-o', str(tmp_path), '--ps_iters', '2', '--control_H', '25', '--pred_H', '10',
+                                 '--dyn_opt_iters', '150', '--pol_opt_iters', '25', '--pol_batch_size', '50',
+                                 '--dyn_shape', '64,64', '--pol_shape', '64,64', '--n_initial_epi', '2'] + extra)
+        assert len(hist) == 2 and all(np.isfinite(h['last_loss']) for h in hist)
+        assert hist[-1]['n_samples'] == 4 * 25
+        for f in ('experience.pth.tar', 'latest_dynamics.pth.tar', 'latest_policy.pth.tar', 'args.pth.tar'):
+            assert os.path.exists(os.path.join(folder, f))
+        # the checkpoint loads back into fresh modules (utils.load_checkpoint)
+        env = pm.envs.Cartpole()
+        dyn = pm.models.DynamicsModel(
+            pm.models.mlp(5, 8, [64, 64], dropout_layers=[pm.models.CDropout(0.1 * np.ones(64)) for _ in range(2)],
+                          nonlin=torch.nn.ReLU),
+            reward_func=env.reward_func, output_density=pm.models.DiagGaussianDensity(4)).float()
+        from functools import partial
+        pol = pm.models.Policy(
+            pm.models.mlp(4, 2, [64, 64], dropout_layers=[pm.models.BDropout(0.1) for _ in range(2)],
+                          nonlin=torch.nn.ReLU, output_nonlin=partial(pm.models.DiagGaussianDensity, 1)),
+            env.action_space.high, env.action_space.low).float()
+        exp = pm.utils.ExperienceDataset()
+        pm.utils.load_checkpoint(folder, dyn, pol, exp)
+        assert exp.n_samples() == 100 and exp.n_episodes() == 4
+        sd = torch.load(os.path.join(folder, 'latest_policy.pth.tar'), weights_only=False)
+        assert torch.equal(pol.model.fc0.weight.cpu(), sd['model.fc0.weight'].cpu())
