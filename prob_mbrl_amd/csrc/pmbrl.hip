@@ -324,6 +324,18 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
 #define PM_FAST_CASES                                                                  \
   PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
   PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
+// shape-specialised instantiations (pmbrl_fast.h: PfShape): RT, CA, CB, variant, D, U, LD, layers.
+// The shipped configurations: cart-pole (D=4) and double cart-pole (D=6) states, one action,
+// 2 x 200 hidden units; plain / per-step / in-kernel moment matching.
+#define PM_FAST_SHAPED_CASES                                  \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 4, 1, 216, 3)          \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3)           \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3)          \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3)          \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3)            \
+  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3)            \
+  PM_FAST_SHAPED(4, 2, 2, PF_VAR_MM, 6, 1, 264, 3)
+
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
   const void* fns[] = {
@@ -335,6 +347,17 @@ static int set_attr_fast(size_t lds) {
       reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM>)};
   for (const void* f : fns)
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV)                                            \
+  if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
+    HIPCHK(hipFuncSetAttribute(                                                                          \
+        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
+    HIPCHK(hipFuncSetAttribute(                                                                          \
+        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
+  }
+  PM_FAST_SHAPED_CASES
+#undef PM_FAST_SHAPED
   return 0;
 }
 
@@ -837,10 +860,25 @@ static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s)
 template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   // variant: see pmbrl_fast.h (PF_VAR_*)
-  const bool mm = A.mm_mode == 1 && (A.flags & PMBRL_FLAG_MM_STATES);
+  const bool mm = A.mm_mode == 1;     // whole groups per workgroup, moment matching inside the sweep
   const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
                    (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
+  const int var = mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
   const dim3 g(p->nwg), b(PF_NT);
+  // a shape-specialised instantiation if there is one for this plan
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV)                                               \
+  if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
+      A.pol.nl == NLV && A.dyn.nl == NLV) {                                                                 \
+    if (fwd)                                                                                                \
+      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), g, b,       \
+                         p->lds_bytes, s, A);                                                               \
+    else                                                                                                    \
+      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), g, b,       \
+                         p->lds_bytes, s, A);                                                               \
+    return;                                                                                                 \
+  }
+  PM_FAST_SHAPED_CASES
+#undef PM_FAST_SHAPED
 #define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
   if (fwd) {
     if (mm) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);

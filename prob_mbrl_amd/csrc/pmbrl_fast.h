@@ -926,6 +926,17 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 //   EXT   + per-step output noise (resample_*_noise), grad_states / grad_actions inputs,
 //         action_grad_norms output, cycle stamps (pmbrl_plan_set_prof)
 //   MM    EXT + the in-kernel moment matching of states (mm_mode 1)
+// Shape specialisation (template parameter SH): the state / action widths, the activation
+// leading dimension and the layer count as compile-time constants (0 = read from the
+// arguments).  The LDS carve-up, every row / column index and the layer loops then fold into
+// immediates: 9 % on the C2 sweep.  Instantiated for the shapes of the shipped
+// configurations (PM_FAST_SHAPED_CASES in pmbrl.hip); anything else runs the general kernels.
+template <int D_, int U_, int LD_, int NL_>
+struct PfShape {
+  static constexpr int D = D_, U = U_, LD = LD_, NL = NL_;
+};
+typedef PfShape<0, 0, 0, 0> PfShapeAny;
+
 #define PF_VAR_LEAN 0
 #define PF_VAR_EXT 1
 #define PF_VAR_MM 2
@@ -935,7 +946,7 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
       A.prof[(size_t)t * 32 + (slot)] = (long long)__builtin_readcyclecounter();                   \
   } while (0)
 
-template <int RT, int CA, int CB, int VAR>
+template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
@@ -946,9 +957,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
-  const int row0 = wg * A.rows_per_wg;
-  const int nvalid = min(A.rows_per_wg, A.B - row0);
-  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  const int rows_per_wg = (VAR == PF_VAR_MM) ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
+  const int row0 = wg * rows_per_wg;
+  const int nvalid = min(rows_per_wg, A.B - row0);
+  const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
   FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
@@ -1026,7 +1038,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const float* pol_head_bias = L.base + pm_rl(vdp, 8 * (P.nl - 1) + 1);
   const float* dyn_head_bias = L.base + pm_rl(vdd, 8 * (F.nl - 1) + 1);
   const int pol_head_kb = P.nt[P.nl - 1], dyn_head_kb = F.nt[F.nl - 1];
-  const int pnl = P.nl, fnl = F.nl;
+  const int pnl = SH::NL ? SH::NL : P.nl, fnl = SH::NL ? SH::NL : F.nl;
 
   bool fed = false;   // the previous step's sampling phase already wrote this step's policy input
   for (int t = T0; t < T1; ++t) {
@@ -1039,12 +1051,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       // dynamics-state rows -> policy input tile (+ dW stash); later steps of the plain path
       // get this written by the previous step's sampling phase
       __syncthreads();
-      float* st = A.actT[0] + blk * (size_t)16 * A.Rw;
+      float* st = A.actT[0] + blk * (size_t)16 * (16 * RT);
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int k = i / R, r = i - k * R;
         const float v = (k < D) ? xa[r * D + k] : 0.f;
         X[r * LD + k] = v;
-        st[(size_t)k * A.Rw + r] = v;
+        st[(size_t)k * (16 * RT) + r] = v;
       }
       if (mm_in) {
         // this step's moment-matching noise rows -> LDS, a whole step before they are needed (the
@@ -1144,7 +1156,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       // (not when the partial tiles sit in bufA: the feed below writes there)
       const bool feed = !mm_in && (t + 1 < T1) && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
       fed = feed;
-      float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * A.Rw;
+      float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * (16 * RT);
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, d = i & 15;
         float xn = 0.f;
@@ -1168,7 +1180,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         }
         if (feed) {
           L.bufA[r * LD + d] = xn;                 // free: the heads were read before the barrier
-          stn[(size_t)d * A.Rw + r] = xn;
+          stn[(size_t)d * (16 * RT) + r] = xn;
         }
       }
     }
@@ -1179,7 +1191,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     // STATES is part of the recursion.
     if (mm_in) {
       __syncthreads();
-      const int gpw = A.rows_per_wg / A.M;
+      const int gpw = rows_per_wg / A.M;
       for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
@@ -1203,7 +1215,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 // ===========================================================================
 // backward sweep (fast)
 // ===========================================================================
-template <int RT, int CA, int CB, int VAR>
+template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
@@ -1214,9 +1226,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
-  const int row0 = wg * A.rows_per_wg;
-  const int nvalid = min(A.rows_per_wg, A.B - row0);
-  const int D = A.D, U = A.U, LD = A.LD, B = A.B;
+  const int rows_per_wg = (VAR == PF_VAR_MM) ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
+  const int row0 = wg * rows_per_wg;
+  const int nvalid = min(rows_per_wg, A.B - row0);
+  const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
   FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
@@ -1337,7 +1350,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdp, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * idx + 3),
                        out, pm_rlp<float>(vdp, 8 * idx + 4) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
   };
-  const int pnl = P.nl, fnl = F.nl;
+  const int pnl = SH::NL ? SH::NL : P.nl, fnl = SH::NL ? SH::NL : F.nl;
   const int dyn_tail_kb = F.nt[1], pol_tail_kb = P.nt[1];
   float* const gT_head = A.gT[P.nl - 1];
 
@@ -1370,7 +1383,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         }
       }
       __syncthreads();
-      const int gpw = A.rows_per_wg / A.M;
+      const int gpw = rows_per_wg / A.M;
       for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
@@ -1418,7 +1431,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PF_MARK(12);
     // ---- phase B: tail result; state part -> gxn, action part -> policy head adjoint
     {
-      float* gst = gT_head + blk * (size_t)16 * A.Rw;
+      float* gst = gT_head + blk * (size_t)16 * (16 * RT);
       const float* hp = PM_HP();
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
@@ -1440,8 +1453,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
           }
           X[r * LD + j] = go_mu;
           X[r * LD + U + j] = go_ls;
-          gst[(size_t)j * A.Rw + r] = go_mu;
-          gst[(size_t)(U + j) * A.Rw + r] = go_ls;
+          gst[(size_t)j * (16 * RT) + r] = go_mu;
+          gst[(size_t)(U + j) * (16 * RT) + r] = go_ls;
         }
       }
       // zero the K padding of the head-gradient block (columns 2U..15)
@@ -1449,7 +1462,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         const int r = i >> 4, k = i & 15;
         if (k >= 2 * U) {
           X[r * LD + k] = 0.f;
-          gst[(size_t)k * A.Rw + r] = 0.f;
+          gst[(size_t)k * (16 * RT) + r] = 0.f;
         }
       }
     }
