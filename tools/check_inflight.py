@@ -51,11 +51,12 @@ def parse_functions(path):
             cur.append(('label', m.group(1), ln, raw))
             continue
         code = st.split(';')[0].strip()
+        if code.startswith('.Lfunc_end'):     # (not the first s_endpgm: blocks may follow it)
+            cur = None
+            continue
         if not code or code.startswith('.') or code.endswith(':'):
             continue
         cur.append(('asm' if in_asm else 'ins', code, ln, raw))
-        if code.startswith('s_endpgm'):
-            cur = None
     return funcs
 
 
