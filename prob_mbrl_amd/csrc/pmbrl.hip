@@ -324,17 +324,17 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
 #define PM_FAST_CASES                                                                  \
   PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
   PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
-// shape-specialised instantiations (pmbrl_fast.h: PfShape): RT, CA, CB, variant, D, U, LD, layers.
+// shape-specialised instantiations (pmbrl_fast.h: PfShape): RT, CA, CB, variant, D, U, LD, layers,
+// 16-wide tiles per hidden layer.
 // The shipped configurations: cart-pole (D=4) and double cart-pole (D=6) states, one action,
 // 2 x 200 hidden units; plain / per-step / in-kernel moment matching.
 #define PM_FAST_SHAPED_CASES                                  \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 4, 1, 216, 3)          \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3)           \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3)          \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3)          \
-  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3)            \
-  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3)            \
-  PM_FAST_SHAPED(4, 2, 2, PF_VAR_MM, 6, 1, 264, 3)
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 4, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)
 
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
@@ -347,13 +347,13 @@ static int set_attr_fast(size_t lds) {
       reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM>)};
   for (const void* f : fns)
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV)                                            \
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                          \
   if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
     HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), \
+        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
     HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), \
+        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
   }
   PM_FAST_SHAPED_CASES
@@ -857,6 +857,13 @@ template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
+// 16-wide tiles of the hidden layers if every hidden layer of both nets has the same width, else -1
+static int hidden_tiles(const RolloutArgs& A) {
+  const int nt = A.pol.nt[1];
+  for (int l = 1; l < A.pol.nl; ++l) if (A.pol.nt[l] != nt) return -1;
+  for (int l = 1; l < A.dyn.nl; ++l) if (A.dyn.nt[l] != nt) return -1;
+  return nt;
+}
 template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   // variant: see pmbrl_fast.h (PF_VAR_*)
@@ -866,14 +873,14 @@ static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
   const int var = mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
   const dim3 g(p->nwg), b(PF_NT);
   // a shape-specialised instantiation if there is one for this plan
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV)                                               \
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
   if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
-      A.pol.nl == NLV && A.dyn.nl == NLV) {                                                                 \
+      A.pol.nl == NLV && A.dyn.nl == NLV && hidden_tiles(A) == NTV) {                                                                \
     if (fwd)                                                                                                \
-      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), g, b,       \
+      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), g, b,       \
                          p->lds_bytes, s, A);                                                               \
     else                                                                                                    \
-      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV>>), g, b,       \
+      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), g, b,       \
                          p->lds_bytes, s, A);                                                               \
     return;                                                                                                 \
   }

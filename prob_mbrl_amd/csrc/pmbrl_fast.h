@@ -47,7 +47,7 @@
 // last wave, which owns at most one regular tile, waits for the 8 partials after its tile,
 // sums them in fixed order and runs the tile's normal epilogue before the phase barrier.
 // (not with 64-row workgroups: LDS is the constraint there)
-__host__ __device__ inline bool pm_fast_ksplit(int n_ot, int RT) { return RT < 4 && n_ot >= 5 && (n_ot % 4) == 1; }
+__host__ __device__ constexpr bool pm_fast_ksplit(int n_ot, int RT) { return RT < 4 && n_ot >= 5 && (n_ot % 4) == 1; }
 // LDS floats for the K-split tail weights of one sweep direction (bwd: transposed layers)
 __host__ __device__ inline size_t pm_fast_tail_floats(const int* pnt, int pnl, const int* dnt, int dnl,
                                                       bool bwd, int RT) {
@@ -105,9 +105,10 @@ struct SdV {
   int n, v;
   int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l
 };
+template <class SC>
 __device__ __forceinline__ SdV sdv_make(const StreamDesc& sd, int lane) {
   SdV r;
-  r.n = sd.n;
+  r.n = SC::NS ? SC::NS : sd.n;
   r.v = 0;
   r.k = 0;
   const int l = lane >> 2, f = lane & 3;
@@ -129,60 +130,72 @@ struct Cursor {
   const float* nwf;
 };
 
-#define SD_NOT(sd, l) pm_rl((sd).v, 4 * (l))
-#define SD_NKB(sd, l) pm_rl((sd).v, 4 * (l) + 1)
+// Compile-time shape of the weight stream (shape-specialised kernels: every streamed layer has
+// the same tile / k-block counts); zeros = read the lane table.
+template <int NOT_, int NKB_, int NS_>
+struct PfStream {
+  static constexpr int NOT = NOT_, NKB = NKB_, NS = NS_;   // streamed tiles, padded k-blocks, layers
+};
+typedef PfStream<0, 0, 0> PfStreamAny;
+#define SD_N(SC, sd) (SC::NS ? SC::NS : (sd).n)
+#define SD_NOT(SC, sd, l) (SC::NOT ? SC::NOT : pm_rl((sd).v, 4 * (l)))
+#define SD_NKB(SC, sd, l) (SC::NKB ? SC::NKB : pm_rl((sd).v, 4 * (l) + 1))
 #define SD_WF(sd, l) pm_rlp<const float>((sd).v, 4 * (l) + 2)
+template <class SC>
 __device__ __forceinline__ void cur_fetch_next(const SdV& sd, Cursor& q, int wid) {
   int l = q.li;
   if (q.all_live) {
-    l = (l + 1 >= sd.n) ? 0 : l + 1;
+    l = (l + 1 >= SD_N(SC, sd)) ? 0 : l + 1;
   } else {
     // next layer (cyclically) in which this wave owns a tile
     for (int k = 0; k < 2 * PM_MAXL; ++k) {
-      l = (l + 1 >= sd.n) ? 0 : l + 1;
-      if (wid < SD_NOT(sd, l)) break;
+      l = (l + 1 >= SD_N(SC, sd)) ? 0 : l + 1;
+      if (wid < SD_NOT(SC, sd, l)) break;
     }
   }
   q.nli = l;
-  q.nn_ot = SD_NOT(sd, l);
-  q.nn_kb = SD_NKB(sd, l);
+  q.nn_ot = SD_NOT(SC, sd, l);
+  q.nn_kb = SD_NKB(SC, sd, l);
   q.nwf = SD_WF(sd, l);
 }
+template <class SC>
 __device__ __forceinline__ void cur_switch(const SdV& sd, Cursor& q, int wid) {
   q.li = q.nli;
   q.n_ot = q.nn_ot;
   q.n_kb = q.nn_kb;
   q.ot = wid;
   q.c = 0;
-  q.wp = q.nwf + (size_t)wid * q.n_kb * 256;
-  cur_fetch_next(sd, q, wid);
+  q.wp = q.nwf + (size_t)wid * (SC::NKB ? SC::NKB : q.n_kb) * 256;
+  cur_fetch_next<SC>(sd, q, wid);
 }
+template <class SC>
 __device__ __forceinline__ void cur_init(const SdV& sd, Cursor& q, int wid) {
   q.li = 0; q.ot = 0; q.c = 0; q.live = 0; q.all_live = 1; q.n_ot = 0; q.n_kb = 0; q.wp = nullptr;
   q.nli = 0; q.nn_ot = 0; q.nn_kb = 0; q.nwf = nullptr;
   int first = -1;
-  for (int l = sd.n - 1; l >= 0; --l) {
-    if (wid < SD_NOT(sd, l)) { q.live = 1; first = l; }
+  for (int l = SD_N(SC, sd) - 1; l >= 0; --l) {
+    if (wid < SD_NOT(SC, sd, l)) { q.live = 1; first = l; }
     else q.all_live = 0;
   }
   if (q.live) {
     // enter `first` through the same path as every later switch
     q.nli = first;
-    q.nn_ot = SD_NOT(sd, first);
-    q.nn_kb = SD_NKB(sd, first);
+    q.nn_ot = SD_NOT(SC, sd, first);
+    q.nn_kb = SD_NKB(SC, sd, first);
     q.nwf = SD_WF(sd, first);
-    cur_switch(sd, q, wid);
+    cur_switch<SC>(sd, q, wid);
   }
 }
-template <int CKB>
+template <int CKB, class SC>
 __device__ __forceinline__ void cur_advance(const SdV& sd, Cursor& q, int wid) {
+  const int n_kb = SC::NKB ? SC::NKB : q.n_kb, n_ot = SC::NOT ? SC::NOT : q.n_ot;
   q.c += CKB;
   q.wp += (size_t)CKB * 256;
-  if (q.c >= q.n_kb) {
+  if (q.c >= n_kb) {
     q.c = 0;
     q.ot += PF_NW;
-    q.wp += (size_t)(PF_NW - 1) * q.n_kb * 256;
-    if (q.ot >= q.n_ot) cur_switch(sd, q, wid);
+    q.wp += (size_t)(PF_NW - 1) * n_kb * 256;
+    if (q.ot >= n_ot) cur_switch<SC>(sd, q, wid);
   }
 }
 
@@ -280,7 +293,7 @@ __device__ __forceinline__ void frag_compute(const FragS<CKB>& f, int kb0, int k
 // processing order reaches next, `q` is the chunk after it.  The epilogue of tile i runs at
 // the start of tile i+1, after that tile's first loads have been issued and waited for:
 // at every frag_wait the only younger VMEM operations are the CKB loads just issued.
-template <int RT, int CA, int CB, class Epi>
+template <int RT, int CA, int CB, class SC, class Epi>
 __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, FragS<CA>& fa,
                                              FragS<CB>& fb, const float* lds_in, int ld,
                                              int wid, int lane, Epi& epi, unsigned vo0, unsigned vo1,
@@ -288,8 +301,8 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
   // On entry the load cursor is one chunk ahead INSIDE layer li (every layer has >= 2 chunks per
   // tile), unless this wave owns no tile of it: the layer shape is already in SGPRs.
   if (!q.live || q.li != li) return;
-  const int n_ot = q.n_ot;
-  const int nch2 = q.n_kb / (CA + CB);
+  const int n_ot = SC::NOT ? SC::NOT : q.n_ot;
+  const int nch2 = (SC::NKB ? SC::NKB : q.n_kb) / (CA + CB);
   int pslot = 24;
   BPair<RT> b0;
   bpair_load<RT, CA>(b0, lds_in + (lane & 15) * ld + 4 * (lane >> 4), ld, 0);
@@ -309,7 +322,7 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
     int c2 = 0;
     do {   // nch2 >= 1: the body (and its waits) runs at least once per tile
       frag_load<CB>(fb, q, vo0, vo1);
-      cur_advance<CB>(sd, q, wid);
+      cur_advance<CB, SC>(sd, q, wid);
       frag_wait<CA, CB>(fa);
       if (c2 == 0) {
 #pragma unroll
@@ -321,7 +334,7 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
       }
       frag_compute<RT, CA>(fa, c2 * (CA + CB), c2 * (CA + CB) + CA, lds_in, ld, lane, acc, b0);
       frag_load<CA>(fa, q, vo0, vo1);
-      cur_advance<CA>(sd, q, wid);
+      cur_advance<CA, SC>(sd, q, wid);
       frag_wait<CB, CA>(fb);
       frag_compute<RT, CB>(fb, c2 * (CA + CB) + CA, (c2 + 1 < nch2) ? (c2 + 1) * (CA + CB) : 0, lds_in, ld, lane,
                            acc, b0);
@@ -879,15 +892,15 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 // tile is K-split, that tile's partial / gather / epilogue around it
 #define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
   {                                                                                                     \
-    const int ks_ = pm_rl(sd.k, 4 * (SI));                                                              \
+    const int ks_ = SKS_KNOWN ? 1 : (SC::NOT ? 0 : pm_rl(sd.k, 4 * (SI)));                                                            \
     typename std::remove_reference<decltype(ES)>::type::Pre tpre_[RT];                                  \
-    const int ot_last_ = pm_rl(sd.v, 4 * (SI));                                                         \
+    const int ot_last_ = SD_NOT(SC, sd, (SI));                                                          \
     if (ks_) {                                                                                          \
-      tail_partial<RT>(L.tw + pm_rl(sd.k, 4 * (SI) + 1), pm_rl(sd.k, 4 * (SI) + 2), X, LD, L.tp, L.tcnt, \
+      tail_partial<RT>(L.tw + pm_rl(sd.k, 4 * (SI) + 1), (SH::NT ? SH::NT : pm_rl(sd.k, 4 * (SI) + 2)), X, LD, L.tp, L.tcnt, \
                        wid, lane);                                                                      \
       ++tround;                                                                                         \
     }                                                                                                   \
-    stream_layer<RT, CA, CB>(sd, (SI), q, fa, fb, X, LD, wid, lane, (ES), vo0, vo1, (PROF));            \
+    stream_layer<RT, CA, CB, SC>(sd, (SI), q, fa, fb, X, LD, wid, lane, (ES), vo0, vo1, (PROF));           \
     if (ks_ && wid == PF_NW - 1) {                                                                      \
       /* epilogue operands fetched here, in the block that waits for them (their latency hides behind */ \
       /* the wait for the partials)                                                                   */ \
@@ -931,11 +944,12 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 // arguments).  The LDS carve-up, every row / column index and the layer loops then fold into
 // immediates: 9 % on the C2 sweep.  Instantiated for the shapes of the shipped
 // configurations (PM_FAST_SHAPED_CASES in pmbrl.hip); anything else runs the general kernels.
-template <int D_, int U_, int LD_, int NL_>
+//   NT = 16-wide tiles of every hidden layer (both nets), which also fixes the weight stream
+template <int D_, int U_, int LD_, int NL_, int NT_>
 struct PfShape {
-  static constexpr int D = D_, U = U_, LD = LD_, NL = NL_;
+  static constexpr int D = D_, U = U_, LD = LD_, NL = NL_, NT = NT_;
 };
-typedef PfShape<0, 0, 0, 0> PfShapeAny;
+typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
 
 #define PF_VAR_LEAN 0
 #define PF_VAR_EXT 1
@@ -950,6 +964,11 @@ template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
+  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
+  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
+                   SH::NT ? (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB) : 0,
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
   const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
@@ -988,16 +1007,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   res0_load<RT>(w0p, P.wf[0], P.nt[1], wid, lane);
   res0_load<RT>(w0d, F.wf[0], F.nt[1], wid, lane);
   // weight stream over the hidden->hidden layers of both nets
-  const SdV sd = sdv_make(A.sd_fwd, lane);   // policy hidden layers, then dynamics hidden layers
+  const SdV sd = sdv_make<SC>(A.sd_fwd, lane);   // policy hidden layers, then dynamics hidden layers
   const int n_pol_stream = P.nl - 2;
   Cursor q;
-  cur_init(sd, q, wid);
+  cur_init<SC>(sd, q, wid);
   FragS<CA> fa;
   FragS<CB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
     frag_load<CA>(fa, q, vo0, vo1);
-    cur_advance<CA>(sd, q, wid);
+    cur_advance<CA, SC>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = MM && A.mm_mode == 1 && mm_states;
@@ -1024,13 +1043,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     }
   }
   auto pol_epi = [&](int l, int t, size_t blk, float* out) {
-    const int nt = pm_rl(vdp, 8 * l);
+    const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * l);
     return EpiFwdL<RT>{L.base + pm_rl(vdp, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdp, 8 * l + 2)),
                        pm_rlp<uint8_t>(vdp, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * l + 5), out,
                        pm_rlp<float>(vdp, 8 * l + 6) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
   };
   auto dyn_epi = [&](int l, int t, float* out) {
-    const int nt = pm_rl(vdd, 8 * l);
+    const int nt = SH::NT ? SH::NT : pm_rl(vdd, 8 * l);
     return EpiFwdL<RT>{L.base + pm_rl(vdd, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdd, 8 * l + 2)),
                        pm_rlp<uint8_t>(vdd, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * l + 5), out,
                        nullptr, LD, R, row0, nvalid, nt, lane};
@@ -1219,6 +1238,11 @@ template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
+  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
+  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
+                   SH::NT ? (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB) : 0,
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
   const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
@@ -1259,16 +1283,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   res0_load<RT>(whd, F.wb[F.nl - 1], F.nt[F.nl - 1], wid, lane);
   res0_load<RT>(whp, P.wb[P.nl - 1], P.nt[P.nl - 1], wid, lane);
   // stream: dynamics hidden layers (reverse), then policy hidden layers (reverse)
-  const SdV sd = sdv_make(A.sd_bwd, lane);   // dynamics hidden layers (reverse), then policy (reverse)
+  const SdV sd = sdv_make<SC>(A.sd_bwd, lane);   // dynamics hidden layers (reverse), then policy (reverse)
   const int n_dyn_stream = F.nl - 2;
   Cursor q;
-  cur_init(sd, q, wid);
+  cur_init<SC>(sd, q, wid);
   FragS<CA> fa;
   FragS<CB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
     frag_load<CA>(fa, q, vo0, vo1);
-    cur_advance<CA>(sd, q, wid);
+    cur_advance<CA, SC>(sd, q, wid);
   }
   __syncthreads();
 
@@ -1341,12 +1365,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   }
   // epilogue of the adjoint GEMM whose output carries the activation pattern of layer idx
   auto dyn_epi = [&](int idx, int t, float* out) {
-    const int nt = pm_rl(vdd, 8 * idx);
+    const int nt = SH::NT ? SH::NT : pm_rl(vdd, 8 * idx);
     return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdd, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * idx + 3),
                        out, nullptr, LD, R, row0, nvalid, nt, lane};
   };
   auto pol_epi = [&](int idx, int t, size_t blk, float* out) {
-    const int nt = pm_rl(vdp, 8 * idx);
+    const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * idx);
     return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdp, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * idx + 3),
                        out, pm_rlp<float>(vdp, 8 * idx + 4) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
   };
