@@ -783,8 +783,9 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   return n;
 }
 
-__device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
-                                        const NetDev& P, const NetDev& F) {
+// (pnt / dnt: 16-wide tile counts of layer inputs / outputs, nl + 1 entries each)
+__device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
+                                                 const int* pnt, int pnl, const int* dnt, int dnl) {
   FastLds m;
   float* p = base;
   m.bufA = p; p += (size_t)R * LD;
@@ -801,10 +802,10 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
     p += (size_t)PF_NW * RT * 256;
   }
   m.base = base;
-  for (int l = 0; l < P.nl; ++l) p += (size_t)P.nt[l + 1] * 16;
-  for (int l = 0; l < F.nl; ++l) p += (size_t)F.nt[l + 1] * 16;
-  for (int l = 0; l < P.nl - 1; ++l) p += ((size_t)R * P.nt[l + 1] + 1) / 2;
-  for (int l = 0; l < F.nl - 1; ++l) p += ((size_t)R * F.nt[l + 1] + 1) / 2;
+  for (int l = 0; l < pnl; ++l) p += (size_t)pnt[l + 1] * 16;
+  for (int l = 0; l < dnl; ++l) p += (size_t)dnt[l + 1] * 16;
+  for (int l = 0; l < pnl - 1; ++l) p += ((size_t)R * pnt[l + 1] + 1) / 2;
+  for (int l = 0; l < dnl - 1; ++l) p += ((size_t)R * dnt[l + 1] + 1) / 2;
   m.zp = p; p += (size_t)R * U;
   m.zd = p; p += (size_t)R * D;
   m.mx = p; p += D + U;
@@ -822,7 +823,7 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
   p = base + n;
   {
-    const size_t tf = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, false, RT), tb = pm_fast_tail_floats(P.nt, P.nl, F.nt, F.nl, true, RT);
+    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT);
     const size_t tw = tf > tb ? tf : tb;
     m.tp = p;
     m.tcnt = reinterpret_cast<int*>(p + (size_t)PF_NW * RT * 256);
@@ -831,6 +832,24 @@ __device__ inline FastLds pm_fast_carve(float* base, int R, int LD, int D, int U
   }
   m.mm = reinterpret_cast<double*>(p);
   return m;
+}
+__device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
+                                                 const NetDev& P, const NetDev& F) {
+  return pm_fast_carve(base, R, LD, D, U, RT, P.nt, P.nl, F.nt, F.nl);
+}
+// shape-specialised kernels: the whole carve-up from compile-time constants (-> immediate
+// LDS offsets); layer widths 1 | NT ... NT | 1 tiles
+template <class SH, int RT>
+__device__ __forceinline__ FastLds pm_fast_carve_shaped(float* base, const NetDev& P, const NetDev& F,
+                                                        int R, int LD, int D, int U) {
+  if constexpr (SH::NT != 0 && SH::NL != 0) {
+    int nt[PM_MAXL + 1];
+#pragma unroll
+    for (int l = 0; l <= PM_MAXL; ++l) nt[l] = (l == 0 || l >= SH::NL) ? 1 : SH::NT;
+    return pm_fast_carve(base, R, LD, D, U, RT, nt, SH::NL, nt, SH::NL);
+  } else {
+    return pm_fast_carve(base, R, LD, D, U, RT, P, F);
+  }
 }
 
 // per-layer LDS regions: offsets (in floats from the LDS base) live in the kernel
@@ -982,7 +1001,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
-  FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
+  FastLds L = pm_fast_carve_shaped<SH, RT>(smem, P, F, R, LD, D, U);
   float* xa = L.xa;
   float* xb = L.xb;
 
@@ -1256,7 +1275,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
-  FastLds L = pm_fast_carve(smem, R, LD, D, U, RT, P, F);
+  FastLds L = pm_fast_carve_shaped<SH, RT>(smem, P, F, R, LD, D, U);
   float* gx = L.xa;     // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;    // moment-matching adjoint of gx (in-kernel mm only)
   float* gxn = L.jx;    // dL/dx~ incl. the reward term, then + dynamics-input term
