@@ -42,6 +42,7 @@ extern "C" {
 #define PMBRL_FLAG_MM_REWARDS 2  /* utils/rollout.py:135-145 */
 #define PMBRL_FLAG_INFER_NS 4    /* utils/rollout.py:6-17 (mm_resample_infer_ns_) */
 #define PMBRL_FLAG_FORCE_GENERIC 16 /* do not use the latency-optimised kernel variants (tests) */
+#define PMBRL_FLAG_NO_SHAPED 32 /* do not use the shape-specialised instantiations (tests) */
 #define PMBRL_FLAG_ZMM_PER_STEP 8 /* z_mm/z_rr are [H, B_global, .] fresh draws per step
                                      (utils/rollout.py:58-59, z=None) instead of the cyclic
                                      PEGASUS buffer of utils/rollout.py:53-57 */

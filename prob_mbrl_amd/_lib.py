@@ -16,6 +16,7 @@ MAX_TIP = 8
 MAX_DIM = 64
 FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
 FLAG_FORCE_GENERIC = 16
+FLAG_NO_SHAPED = 32
 REWARD_EXP, REWARD_NEG = 0, 1
 INFO_COUNT = 16
 TIMER_COUNT = 8

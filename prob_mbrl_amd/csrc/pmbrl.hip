@@ -884,7 +884,9 @@ static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
                          p->lds_bytes, s, A);                                                               \
     return;                                                                                                 \
   }
-  PM_FAST_SHAPED_CASES
+  if (!(A.flags & PMBRL_FLAG_NO_SHAPED)) {
+    PM_FAST_SHAPED_CASES
+  }
 #undef PM_FAST_SHAPED
 #define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
   if (fwd) {

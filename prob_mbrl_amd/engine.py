@@ -248,7 +248,7 @@ class Engine:
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
-                 force_generic=False):
+                 force_generic=False, no_shaped=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -261,7 +261,8 @@ class Engine:
         cfg.flags = ((_lib.FLAG_MM_STATES if mm_states else 0) |
                      (_lib.FLAG_MM_REWARDS if mm_rewards else 0) |
                      (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0) |
-                     (_lib.FLAG_FORCE_GENERIC if force_generic else 0))
+                     (_lib.FLAG_FORCE_GENERIC if force_generic else 0) |
+                     (_lib.FLAG_NO_SHAPED if no_shaped else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
         cfg.max_log_std_pol = max_log_std_pol
         cfg.max_log_std_dyn = max_log_std_dyn

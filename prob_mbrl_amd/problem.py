@@ -167,7 +167,7 @@ def loss_weights(d, B_global):
 
 
 def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_global=None,
-                        row_offset=None, force_generic=False):
+                        row_offset=None, force_generic=False, no_shaped=False):
     """Build an Engine + its device input tensors from a problem dict.
     shard=(rank, world): this rank's contiguous block of rows (whole mm groups) of ONE
     global batch described by d.  B_global/row_offset instead place the whole of d as a
@@ -194,7 +194,8 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    layer_dims(d, 'dyn'), list(np.asarray(d['dyn_keep'])),
                    reward_spec_from_problem(d), mm_states=bool(d['mm_states']),
                    mm_rewards=bool(d['mm_rewards']), mm_groups=Gl, device=dev, B_global=Bg,
-                   row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic)
+                   row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic,
+                   no_shaped=no_shaped)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
     args = dict(
         x0=T(d['x0'][lo:hi]), pol_flat=T(flat_params(d, 'pol')), dyn_flat=T(flat_params(d, 'dyn')),

@@ -1,0 +1,94 @@
+"""GPU (-m gpu): BASELINE.json's FULL-SIZE configurations (2500 x 40 cart-pole rows with and without
+in-kernel moment matching, the 50-row-group double cart-pole shape).  These are the shapes the
+shape-specialised LEAN / MM instantiations serve (what bench.py and mc_pilco's fused iteration
+launch), which the small fixtures never reach.  Checked against the oracle where it finishes in
+seconds, and through size-independent properties everywhere: the specialised, the general and
+the EXT instantiations are the same arithmetic (bit-identical results), the gradient is linear in
+the loss weights, and rows are independent (a row permutation permutes the trajectories)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _run(d, lean=True, **kw):
+    from prob_mbrl_amd import problem as PB
+    eng, args, _ = PB.engine_from_problem(d, DEV, **kw)
+    B = d['x0'].shape[0]
+    gw = torch.tensor(PB.loss_weights(d, B), device=DEV)
+    S, A, R = eng.forward(**args)
+    loss = float(eng.weighted_sum(R, gw))
+    if lean:
+        g, _, _ = eng.backward(gw)
+    else:   # optional outputs select the EXT instantiation
+        g, _, _ = eng.backward(gw, want_x0=True, want_agn=True)
+    assert eng.valid_steps() == int(d['H'])
+    return eng, S.cpu().numpy(), A.cpu().numpy(), R.cpu().numpy(), loss, g.cpu().numpy().copy(), gw
+
+
+def _problem(config, H=None):
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem(config, seed=0, data_seed=0))
+    if H is not None:
+        d['H'] = np.asarray(H)
+        d['gamma'] = np.asarray(d['gamma'])[:H] * (len(np.asarray(d['gamma'])) / H)
+    return d
+
+
+@pytest.mark.parametrize('config', ['cartpole_nomm', 'cartpole_mm'])
+def test_full_size_matches_oracle(config):
+    """C2 / C3 at full size against the torch-CPU restatement of the reference in fp64."""
+    from oracle import ref_torch as R
+    d = _problem(config)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    assert eng.info['fast'] == 1 and eng.info['rows_per_wg'] == (16 if config == 'cartpole_nomm' else 25)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(8)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
+                                            meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert common.rel(A, torch.stack(A64).detach().numpy()) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize('config,H', [('cartpole_nomm', None), ('cartpole_mm', None), ('dcartpole_mm', 12)])
+def test_instantiations_agree_bitwise(config, H):
+    """Shape-specialised vs general instantiation, LEAN vs EXT variant: identical arithmetic."""
+    d = _problem(config, H)
+    ref = _run(d)
+    for kw, lean in ((dict(no_shaped=True), True), (dict(), False), (dict(no_shaped=True), False)):
+        out = _run(d, lean=lean, **kw)
+        assert np.array_equal(ref[1], out[1]) and np.array_equal(ref[2], out[2]) and np.array_equal(ref[3], out[3])
+        assert np.array_equal(ref[5], out[5])
+
+
+def test_gradient_is_linear_in_loss_weights():
+    d = _problem('cartpole_nomm')
+    eng, S, A, Rw, loss, g, gw = _run(d)
+    g2, _, _ = eng.backward(2.0 * gw)
+    assert common.rel(g2.cpu().numpy(), 2.0 * g) < 1e-6        # (not bit-exact: denormals are flushed)
+    w1 = gw * torch.rand_like(gw)
+    ga = eng.backward(w1)[0].cpu().numpy().copy()
+    gb = eng.backward(gw - w1)[0].cpu().numpy().copy()
+    assert common.rel(ga + gb, g) < 2e-6
+
+
+def test_rows_are_independent():
+    """Without moment matching a row's trajectory depends on nothing but its own inputs: reversing
+    the row order reverses the trajectories bit for bit (different workgroups, different tile
+    positions) and leaves the gradient unchanged up to summation order."""
+    d = _problem('cartpole_nomm')
+    ref = _run(d)
+    e = dict(d)
+    for k in list(e):
+        v = np.asarray(e[k])
+        if k == 'x0' or k in ('pol_z', 'dyn_z') or ('_mask' in k and v.ndim == 2 and v.shape[0] == d['x0'].shape[0]):
+            e[k] = v[::-1].copy()
+    out = _run(e)
+    assert np.array_equal(ref[1][:, ::-1], out[1]) and np.array_equal(ref[2][:, ::-1], out[2])
+    assert common.rel(out[5], ref[5]) < 2e-6
