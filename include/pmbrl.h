@@ -197,6 +197,20 @@ int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d,
                     int64_t step, double lr, double beta1, double beta2, double eps,
                     double max_norm, float* norm_out_d);
 
+/* The same step, decided on the device: taken only if the rollout that produced
+ * the gradient completed (*status_d >= expect, status_d = the word
+ * pmbrl_rollout_fwd wrote, expect = H), in which case the device-side step
+ * counter *step_d is advanced first and its bias corrections are used;
+ * otherwise parameters, moments and counter are left untouched.  This is the
+ * reference's "RuntimeError -> skip the optimiser step" (algorithms/
+ * mc_pilco.py:122-131) without a host round trip per iteration: the host may
+ * read the status word one iteration late. */
+int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* grads_d,
+                            float* exp_avg_d, float* exp_avg_sq_d, int64_t n,
+                            int64_t* step_d, double lr, double beta1, double beta2,
+                            double eps, double max_norm, float* norm_out_d,
+                            const int32_t* status_d, int32_t expect);
+
 /* Optional per-kernel timing for bench.py's roofline line: when enabled, the
  * library brackets its kernels with hipEvents on the caller's stream;
  * pmbrl_plan_read_timing waits for them and returns the last call's durations

@@ -73,7 +73,7 @@ EXPORTS = [
     'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
-    'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_debug_linear',
+    'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
@@ -119,6 +119,8 @@ def load():
     f64 = C.c_double
     lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64,
                                     f64, f64, vp]
+    lib.pmbrl_clip_adam_guarded.restype = C.c_int
+    lib.pmbrl_clip_adam_guarded.argtypes = [vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, vp, vp, i32]
     lib.pmbrl_mlp_workspace_bytes.restype = C.c_size_t
     lib.pmbrl_mlp_workspace_bytes.argtypes = [C.POINTER(MlpCall)]
     lib.pmbrl_mlp_forward.restype = C.c_int

@@ -153,7 +153,41 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     gamma_full = [float(disc(i)) for i in range(H)]
     sign = -1.0 if maximize else 1.0
 
+    # Pipelined fused path (single process, no on_rollout hook): the optimiser step is decided on
+    # the device from the rollout's status word (pmbrl_clip_adam_guarded) and the host reads that
+    # word one iteration late, from a pinned snapshot queued right behind the forward sweep.  The
+    # host then never waits for a whole iteration: while it prepares iteration i+1 the device still
+    # has the adjoint sweep, the dW GEMM and the Adam step of iteration i to run.
+    pipelined = (world == 1) and not callable(on_rollout) and not need_autograd
+    pending = None          # (i, event, pinned status, loss, S, A, R) of the iteration in flight
+    pipe = dict(snap=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(2)],
+                ev=[torch.cuda.Event() for _ in range(2)], step_dev=None) if pipelined else None
+
+    def settle(pend):
+        """Host side of a pipelined iteration, once its status word has arrived."""
+        nonlocal n_opt_steps
+        j, ev, snap, loss_j, S_j, A_j, R_j = pend
+        ev.synchronize()
+        n_valid = int(snap[0])
+        if n_valid < H:
+            # algorithms/mc_pilco.py:122-131: report, draw new random numbers; the device already
+            # skipped the optimiser step
+            print('RuntimeError: rollout failed at step %d (iteration %d)' % (n_valid, j))
+            resample()
+            return
+        n_opt_steps += 1
+        if (progress and j % 50 == 0) or callable(on_iteration):
+            states, actions, rewards = list(S_j.unbind(0)), list(A_j.unbind(0)), list(R_j.unbind(0))
+            if progress and j % 50 == 0:
+                msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
+                print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
+            if callable(on_iteration):
+                on_iteration(j, loss_j, states, actions, rewards, disc)
+
     for i in range(opt_iters):
+        if pending is not None:
+            settle(pending)
+            pending = None
         if not pegasus or n_opt_steps % resampling_period == 0:
             resample()
         x0_ = x0
@@ -163,6 +197,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
         if not (isinstance(init_state_noise, float) and init_state_noise == 0.0):
             x0_ = x0_ + torch.as_tensor(init_state_noise, device=dev) * torch.randn_like(x0_)
         rk = dict(rollout_kwargs)
+        queued = False
         try:
             bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus,
                                mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
@@ -176,22 +211,48 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups, z_mm,
                     z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i, rk,
                     process_group, world, value_func, replay)
+            elif pipelined:
+                eng = bundle.engine
+                if pipe['step_dev'] is None:
+                    pipe['step_dev'] = torch.tensor([cache['step']], dtype=torch.int64, device=dev)
+                    pipe['cache'] = cache
+                S, A, R = bundle.forward(x0_)
+                k = i & 1
+                pipe['snap'][k].copy_(eng.status, non_blocking=True)
+                pipe['ev'][k].record()
+                gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
+                loss = eng.weighted_sum(R, gw)[0]
+                g, _, _ = eng.backward(gw)
+                grp = cache['group']
+                E.clip_adam_guarded(bundle.pol_flat, g, cache['m'], cache['v'], pipe['step_dev'], grp['lr'],
+                                    eng.status, H, grp['betas'], grp['eps'], max_norm=clip_grad)
+                pending = (i, pipe['ev'][k], pipe['snap'][k], loss, S, A, R)
+                queued = True
             else:
                 eng = bundle.engine
                 S, A, R = bundle.forward(x0_)
                 n_valid = eng.valid_steps()       # the one host sync of the iteration
-                if n_valid < H:
-                    raise RuntimeError('rollout failed at step %d' % n_valid)
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
                 loss = eng.weighted_sum(R, gw)[0]
+                if world > 1:
+                    # every rank must take the same branch: a failure anywhere poisons the summed
+                    # loss, which all ranks see after the all-reduce
+                    import torch.distributed as dist
+                    if n_valid < H:
+                        loss = loss + float('inf')
+                    loss = loss.reshape(1).clone()
+                    dist.all_reduce(loss, group=process_group)
+                    loss = loss[0]
+                    if not bool(torch.isfinite(loss)):
+                        raise RuntimeError('rollout failed (step %d on this rank)' % n_valid)
+                elif n_valid < H:
+                    raise RuntimeError('rollout failed at step %d' % n_valid)
                 states, actions, rewards = list(S.unbind(0)), list(A.unbind(0)), list(R.unbind(0))
                 if callable(on_rollout):
                     on_rollout(i, states, actions, rewards, disc)
                 g, _, _ = eng.backward(gw)
                 if world > 1:
-                    import torch.distributed as dist
                     dist.all_reduce(g, group=process_group)
-                    dist.all_reduce(loss, group=process_group)
                 cache['step'] += 1
                 grp = cache['group']
                 E.clip_adam(bundle.pol_flat, g, cache['m'], cache['v'], cache['step'], grp['lr'],
@@ -205,12 +266,13 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
             resample()
             opt.zero_grad()
             continue
-        n_opt_steps += 1
-        if progress and i % 50 == 0:
-            msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
-            print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
-        if callable(on_iteration):
-            on_iteration(i, loss, states, actions, rewards, disc)
+        if not queued:
+            n_opt_steps += 1
+            if progress and i % 50 == 0:
+                msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
+                print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
+            if callable(on_iteration):
+                on_iteration(i, loss, states, actions, rewards, disc)
         # new initial states (algorithms/mc_pilco.py:222-263)
         if exp is not None:
             n_draw = mm_groups if mm_groups is not None else N_particles
@@ -233,6 +295,10 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
         else:
             x0 = init_states.detach()
 
+    if pending is not None:
+        settle(pending)
+    if pipe is not None and pipe['step_dev'] is not None:
+        pipe['cache']['step'] = int(pipe['step_dev'].item())
     cache = getattr(opt, '_pmbrl_flat', None)
     if cache is not None and type(opt) is torch.optim.Adam:
         _sync_adam_state(opt, [p for p in opt.param_groups[0]['params'] if p.requires_grad], cache)

@@ -127,8 +127,19 @@ __global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __res
 
 // clip_grad_norm_ + Adam in two launches: (1) per-block partial sums of g^2, (2) every block
 // adds the partials in the same order (identical norm everywhere) and updates its slice.
-__global__ __launch_bounds__(256) void pm_gradnorm_kernel(const float* __restrict__ g, long long n) {
+// Guarded form (pmbrl_clip_adam_guarded): block 0 also decides whether the step is taken (the
+// rollout's status word says every horizon step completed) and, if so, advances the device-side
+// step counter; pm_clip_adam_kernel (next launch) reads both.
+__device__ int g_adam_go;
+__global__ __launch_bounds__(256) void pm_gradnorm_kernel(const float* __restrict__ g, long long n,
+                                                          const int* __restrict__ status, int expect,
+                                                          long long* __restrict__ step) {
   __shared__ double sm[256];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int go = (!status || *status >= expect) ? 1 : 0;
+    g_adam_go = go;
+    if (go && step) step[0] += 1;
+  }
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -144,7 +155,14 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
                                                            long long n, int n_part, float lr, float b1,
                                                            float b2, float omb1, float omb2, float eps,
                                                            float bc1, float bc2_sqrt, float max_norm,
-                                                           float* __restrict__ norm_out) {
+                                                           float* __restrict__ norm_out,
+                                                           const long long* __restrict__ step) {
+  if (!g_adam_go) return;       // guarded form: the rollout failed, leave parameters and moments alone
+  if (step) {                   // guarded form: bias corrections of the device-side step counter
+    const double st = (double)step[0];
+    bc1 = (float)(1.0 - pow((double)b1, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   double t = 0.0;
   for (int b = 0; b < n_part; ++b) t += g_red_part[1][b];
   const float norm = (float)sqrt(t);
@@ -1385,11 +1403,28 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
   hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
-                     (long long)n);
+                     (long long)n, (const int*)nullptr, 0, (long long*)nullptr);
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d);
+                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* grads_d, float* exp_avg_d,
+                                       float* exp_avg_sq_d, int64_t n, int64_t* step_d, double lr,
+                                       double beta1, double beta2, double eps, double max_norm,
+                                       float* norm_out_d, const int32_t* status_d, int32_t expect) {
+  if (!params_d || !grads_d || !exp_avg_d || !exp_avg_sq_d || !step_d || !status_d || n < 1)
+    return fail(-1, "bad argument");
+  const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
+  hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
+                     (long long)n, (const int*)status_d, (int)expect, reinterpret_cast<long long*>(step_d));
+  hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f,
+                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -439,6 +439,22 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                'pmbrl_clip_adam')
 
 
+def clip_adam_guarded(params, grads, exp_avg, exp_avg_sq, step_dev, lr, status, expect, betas=(0.9, 0.999),
+                      eps=1e-8, max_norm=None, norm_out=None):
+    """clip + Adam taken on the device only if `status` (the rollout's status word) says all
+    `expect` horizon steps completed; `step_dev` is the device-side int64 step counter
+    (pmbrl_clip_adam_guarded)."""
+    lib = _lib.load()
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert step_dev.is_cuda and step_dev.dtype == torch.int64 and status.is_cuda and status.dtype == torch.int32
+    _lib.check(lib.pmbrl_clip_adam_guarded(_stream(), _ptr(params), _ptr(grads), _ptr(exp_avg),
+                                           _ptr(exp_avg_sq), params.numel(), _ptr(step_dev), float(lr),
+                                           float(betas[0]), float(betas[1]), float(eps),
+                                           float(max_norm) if max_norm else 0.0, _ptr(norm_out),
+                                           _ptr(status), int(expect)), 'pmbrl_clip_adam_guarded')
+
+
 def debug_linear(x, W, b, transpose_w=False):
     """Test hook: y = x W^T + b through the kernels' MFMA tile routine."""
     lib = _lib.load()

@@ -61,10 +61,16 @@ class BDropout(StochasticModule):
 
     # --- what the fused rollout needs -------------------------------------
     def keep_prob(self):
+        # memoised: float() of a device tensor is a host-device sync
+        sig = (self.rate.data_ptr(), self.rate._version, str(self.rate.device))
+        hit = getattr(self, '_keep_cache', None)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
         p = (1 - self.rate)
         if p.numel() != 1:
             raise NotImplementedError('per-unit BDropout rates are not offered on the device path')
-        return float(p)
+        self._keep_cache = (sig, float(p))
+        return self._keep_cache[1]
 
     def hard_mask(self, B, width):
         """{0,1} mask [>=B, width]; (re)drawn when the stored one cannot be reused, with the

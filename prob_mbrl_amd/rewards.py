@@ -41,7 +41,18 @@ class AnalyticReward(nn.Module):
 
     def spec(self, D):
         """Constants for states of width D: the raw width (angles expanded inside the
-        reward) or the already-expanded width (envs/cartpole/env.py:60-63)."""
+        reward) or the already-expanded width (envs/cartpole/env.py:60-63).  Memoised on the
+        constants' storage and version counters: reading them from a device tensor is a
+        host-device sync, and mc_pilco asks once per iteration."""
+        sig = (D,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        hit = getattr(self, '_spec_cache', None)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        out = self._spec_uncached(D)
+        self._spec_cache = (sig, out)
+        return out
+
+    def _spec_uncached(self, D):
         C = np.asarray(self._tip_matrix(), dtype=np.float64)
         De = C.shape[1]
         na = len(self.angle_dims)

@@ -42,6 +42,19 @@ def flat_parameters(linears, owner):
     return flat, params
 
 
+def _scalar_of(module, name):
+    """float(module.<name>) without a host-device sync per call: memoised on the buffer's storage
+    and version counter."""
+    t = getattr(module, name)
+    sig = (t.data_ptr(), t._version, str(t.device))
+    cache = module.__dict__.setdefault('_pmbrl_scalars', {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != sig:
+        hit = (sig, float(t))
+        cache[name] = hit
+    return hit[1]
+
+
 class _MaskCache:
     """bit-packed masks keyed on the identity + version of the float mask tensor"""
 
@@ -163,7 +176,7 @@ class Bundle:
             ddens.z.data = self.z_dyn[-1]
         else:
             self.z_dyn = ddens.frozen_noise(B, False)
-        self.max_log_std = (float(pdens.max_log_std), float(ddens.max_log_std))
+        self.max_log_std = (_scalar_of(pdens, 'max_log_std'), _scalar_of(ddens, 'max_log_std'))
         f = lambda t, n: t.detach().reshape(-1).float().expand(n).contiguous()  # noqa: E731
         self.mx, self.iSx = f(dynamics.mx, self.D + self.U), f(dynamics.iSx, self.D + self.U)
         self.my, self.Sy = f(dynamics.my, self.D), f(dynamics.Sy, self.D)
