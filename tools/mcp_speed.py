@@ -28,3 +28,15 @@ for mm, B, G in ((False, 2500, None), (True, 2500, 100)):
     pm.algorithms.mc_pilco(init_states, dyn, pol, H, opt, None, n, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print('mm=%s: %.3f ms / mc_pilco iteration (%.0f rollouts/s)' % (mm, dt / n * 1e3, B * n / dt))
+
+# the reference examples' own shape: 100 particles, H=15, one moment-matching group over all rows
+dyn, pol = build()
+opt = torch.optim.Adam(pol.parameters(), 1e-3)
+x0 = 0.1 * torch.randn(100, D, device=dev)
+for mm in (True, False):
+    kw = dict(mm_states=mm, mm_rewards=mm, mm_groups=None)
+    pm.algorithms.mc_pilco(x0, dyn, pol, 15, opt, None, 20, **kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pm.algorithms.mc_pilco(x0, dyn, pol, 15, opt, None, 300, **kw)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print('example shape (B=100, H=15, mm=%s): %.3f ms / mc_pilco iteration' % (mm, dt / 300 * 1e3))
