@@ -221,49 +221,76 @@ __global__ void pm_pack_all(const PackArgs P) {
   }
 }
 
-// external moment matching (groups larger than a workgroup's rows): one
-// workgroup (one wave active) per group, rows in HBM.
-__global__ void pm_mm_fwd_kernel(RolloutArgs A, int t) {
+// external moment matching (groups larger than a workgroup's rows): one workgroup of PM_MM_NW
+// waves per group, rows in HBM; every wave takes a slice of the rows (pmbrl_mm.h, multi-wave
+// forms).  Widths without a compile-time instantiation run the general code on wave 0.
+#define PM_MM_NW 16
+__host__ __device__ inline size_t pm_mm_kernel_doubles(int D) {
+  return (size_t)PM_MM_NW * pm_mm_scratch_doubles(D) + (size_t)PM_MM_NW * 256;
+}
+#define PM_MM_MW_SWITCH(D, CALL, ELSE) \
+  switch (D) {                         \
+    case 1: { CALL(1); break; }        \
+    case 2: { CALL(2); break; }        \
+    case 3: { CALL(3); break; }        \
+    case 4: { CALL(4); break; }        \
+    case 5: { CALL(5); break; }        \
+    case 6: { CALL(6); break; }        \
+    default: { ELSE; }                 \
+  }
+__global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A, int t) {
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
-  const int gi = blockIdx.x, lane = threadIdx.x;
+  const int gi = blockIdx.x, lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
   const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
   const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
   const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   if (A.flags & PMBRL_FLAG_MM_STATES) {
-    const bool ok = pm_mm_fwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, zmm, A.D, zrow0,
-                              A.Bg, false, A.states + ((size_t)(t + 1) * A.B + r0) * A.D, A.D,
-                              mmscr, lane);
-    if (!ok && lane == 0) atomicMin(A.status, t);
+    const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
+    float* out = A.states + ((size_t)(t + 1) * A.B + r0) * A.D;
+    bool ok = true;
+#define PM_CALL(DD) ok = pm_mm_fwd_mw<DD>(s, A.D, A.M, zmm, A.D, zrow0, A.Bg, out, A.D, mmscr, part, PM_MM_NW, wid, lane)
+    PM_MM_MW_SWITCH(A.D, PM_CALL,
+                    if (wid == 0) ok = pm_mm_fwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, out, A.D, mmscr, lane))
+#undef PM_CALL
+    if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-    const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, false,
-                              A.rewards + (size_t)t * A.B + r0, 1, mmscr, lane);
-    if (!ok && lane == 0) atomicMin(A.status, t);
+    __syncthreads();
+    const bool ok = pm_mm_fwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg,
+                                    A.rewards + (size_t)t * A.B + r0, 1, mmscr, part, PM_MM_NW, wid, lane);
+    if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
   }
 }
 // adjoint: (gx_carry = dL/dx_{t+1}, grad_rewards[t]) -> (gx_carry = dL/dx~, gr_tilde[t] = dL/dr~)
-__global__ void pm_mm_bwd_kernel(RolloutArgs A, int t, float* gr_tilde) {
+__global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A, int t, float* gr_tilde) {
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
-  const int gi = blockIdx.x, lane = threadIdx.x;
+  const int gi = blockIdx.x, lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
   const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
   const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
   const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   if (A.flags & PMBRL_FLAG_MM_STATES) {
     float* g = A.gx_carry + (size_t)r0 * A.D;
-    // in-place is NOT safe for d > 1 reads of g after writes: pm_mm_bwd reads g only
-    // before its first wave sync, so aliasing g/gout is fine (see pmbrl_mm.h).
-    pm_mm_bwd(A.xt + ((size_t)t * A.B + r0) * A.D, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, g,
-              A.D, g, A.D, mmscr, lane);
+    const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
+    // in place (g -> g): every read of g happens before the first write (pmbrl_mm.h)
+#define PM_CALL(DD) pm_mm_bwd_mw<DD>(s, A.D, A.M, zmm, A.D, zrow0, A.Bg, g, A.D, g, A.D, mmscr, part, PM_MM_NW, wid, lane)
+    PM_MM_MW_SWITCH(A.D, PM_CALL,
+                    if (wid == 0) pm_mm_bwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, g, A.D, g, A.D, mmscr, lane))
+#undef PM_CALL
   }
   const float* gsrc = A.grad_rewards + (size_t)t * A.B + r0;
   float* gdst = gr_tilde + (size_t)t * A.B + r0;
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
-    pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, false, gsrc, 1, gdst, 1,
-              mmscr, lane);
+    __syncthreads();
+    pm_mm_bwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg, gsrc, 1, gdst, 1, mmscr, part,
+                    PM_MM_NW, wid, lane);
   } else {
-    for (int i = lane; i < A.M; i += 64) gdst[i] = gsrc[i];
+    for (int i = threadIdx.x; i < A.M; i += PM_MM_NW * 64) gdst[i] = gsrc[i];
   }
 }
 
@@ -670,7 +697,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
 #undef PM_FAST_CASE
   }
   if (p->mm_mode == 2) {
-    const int smem = (int)(pm_mm_scratch_doubles(c.D) * sizeof(double));
+    const int smem = (int)(pm_mm_kernel_doubles(c.D) * sizeof(double));
     if (smem > 64 * 1024) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_fwd_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -970,13 +997,13 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   if (p->mm_mode != 2) {
     launch_fwd_rt(p, A, s);
   } else {
-    const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+    const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
     RolloutArgs Am = A;
     if (p->fast) Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // fast family: rewards are handled after the sweep
     for (int t = 0; t < p->cfg.H; ++t) {
       A.t0 = t; A.t1 = t + 1;
       launch_fwd_rt(p, A, s);
-      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t);
+      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t);
     }
   }
   }
@@ -1033,7 +1060,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   } else {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
-    const size_t smem = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+    const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
     HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
     RolloutArgs Am = A;
     if (p->fast) {
@@ -1043,7 +1070,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     }
     A.gx_from_carry = 1;
     for (int t = p->cfg.H - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(64), smem, s, Am, t, grt);
+      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
       A.t0 = t; A.t1 = t + 1;
       launch_bwd_rt(p, A, s);
     }

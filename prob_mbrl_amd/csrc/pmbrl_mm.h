@@ -269,3 +269,380 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
   pm_wave_sync();
 }
 
+
+// ===========================================================================
+// Compile-time-d variants (2d+1 <= 16) for the stand-alone moment-matching kernels (groups
+// larger than a workgroup's rows: the reference examples' default, one group over all
+// particles).  The sums over the group's rows run on the fp64 matrix core: with
+// X = [s - s_0 | 1 | z] (one row per particle), ONE accumulator tile G = X^T X holds
+// sum s s^T, sum s, M, sum z and sum z^2 (v_mfma_f64_16x16x4_f64, a = b = X[row 4kb + (lane>>4)]
+// [col lane&15]; G[i][j] sits in lane ((i&3)<<4)|j, register i>>2).  The covariance entries stay
+// in the lanes that hold them and the Cholesky factorisation runs across lanes: per pivot the
+// pivot and its column are broadcast with v_readlane, every lane updates its own entries -- no
+// LDS round trip and no wave barrier inside the factorisation.  Products of fp32 inputs are
+// exact in fp64 and the rows are shifted by the group's first row, so the single-pass
+// covariance (sum s s^T - M m m^T) loses nothing that matters.
+// (Not used inside the sweep kernels: there the extra registers cost the other phases more than
+// the shorter phase gains -- DESIGN.md section 6.)
+typedef double pm_f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double pm_rl64(double v, int src_lane) {   // src_lane: wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ double pm_sel(const double (&v)[N], int idx) {
+  double o = v[0];
+#pragma unroll
+  for (int k = 1; k < N; ++k) o = (idx == k) ? v[k] : o;
+  return o;
+}
+
+// Gram tile of X = [s - ref | 1 | z] over rows [r_lo, r_hi) of the group (ref: the group's first row)
+template <int DD>
+__device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, const float* z, int z_ld,
+                                                    int zrow0, int Bg, int r_lo, int r_hi, int lane) {
+  static_assert(2 * DD + 1 <= 16, "the Gram tile holds 2d+1 columns");
+  const int g = lane >> 4, c = lane & 15;
+  const int cs = c < DD ? c : 0;
+  const int cz = (c > DD && c <= 2 * DD) ? c - DD - 1 : 0;
+  const double ref = (double)s[cs];
+  pm_f64x4 G = {0.0, 0.0, 0.0, 0.0};
+  if (r_hi <= r_lo) return G;
+  // rows r_lo + g, + 4, ...: the cyclic noise row advances with them (one modulo up front, then
+  // a conditional wrap), loads of 8 row quads are in flight together
+  int zr = pm_zidx(zrow0, min(r_lo + g, r_hi - 1), Bg);
+  const int zwrap = Bg ? Bg : 0x7fffffff;
+#pragma unroll 8
+  for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
+    const int r = r0 + g, rr = r < r_hi ? r : r_hi - 1;
+    const double sv = (double)s[(size_t)rr * s_ld + cs] - ref;
+    const double zv = (double)z[(size_t)zr * z_ld + cz];
+    double x = c < DD ? sv : (c == DD ? 1.0 : (c <= 2 * DD ? zv : 0.0));
+    if (r >= r_hi) x = 0.0;
+    G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
+    if (r + 4 < r_hi) {
+      zr += 4;
+      if (zr >= zwrap) zr -= zwrap;
+    }
+  }
+  return G;
+}
+
+// means / standardisation / Cholesky factor from the group's Gram tile -> q (LDS scratch of this wave)
+template <int DD>
+__device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const float* s, const MMScratch& q,
+                                                       int lane) {
+  constexpr int NR = (DD + 3) / 4;             // accumulator registers that hold covariance rows
+  const int g = lane >> 4, c = lane & 15;
+  const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
+  // wave-uniform first moments and the z standardisation
+  double sm[DD], zm[DD], zi[DD];
+#pragma unroll
+  for (int j = 0; j < DD; ++j) {
+    constexpr int rowS = DD;
+    const int rowZ = DD + 1 + j;
+    sm[j] = pm_rl64(G[rowS >> 2], ((rowS & 3) << 4) | j) * inv_m;
+    zm[j] = pm_rl64(G[rowS >> 2], ((rowS & 3) << 4) | (DD + 1 + j)) * inv_m;
+    const double szz = pm_rl64(G[rowZ >> 2], ((rowZ & 3) << 4) | rowZ);
+    zi[j] = pm_rsqrt((szz - dM * zm[j] * zm[j]) * inv_m1);
+  }
+  // covariance entry (i = g + 4r, j = c) in the lane that holds the Gram entry
+  double A[NR];
+  const double mj = pm_sel(sm, c);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = g + 4 * r;
+    double mi = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (4 * r + u < DD) mi = (g == u) ? sm[4 * r + u] : mi;
+    const double cov = (G[r] - dM * mi * mj) * inv_m1 + (i == c ? 1e-12 : 0.0);
+    A[r] = (i < DD && c <= i) ? cov : 0.0;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < DD; ++k) {
+    double piv = pm_rl64(A[k >> 2], ((k & 3) << 4) | k);
+    // same rule as pm_mm_factor: a pivot that has shed more than fp32 precision relative to its
+    // diagonal entry (= pivot + the squares eliminated so far) counts as non-positive
+    double d0 = piv;
+#pragma unroll
+    for (int c2 = 0; c2 < k; ++c2) {
+      const double l = pm_rl64(A[k >> 2], ((k & 3) << 4) | c2);
+      d0 += l * l;
+    }
+    if (!(piv > 6e-8 * d0)) {
+      ok = false;
+      piv = 1.0;
+    }
+    const double rs = pm_rsqrt(piv);
+    const double lkk = piv * rs;
+    double col[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) col[i] = i > k ? pm_rl64(A[i >> 2], ((i & 3) << 4) | k) * rs : 0.0;
+    const double lj = pm_sel(col, c);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = g + 4 * r;
+      double li = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * r + u < DD) li = (g == u) ? col[4 * r + u] : li;
+      if (i < DD) {
+        if (c == k) A[r] = (i == k) ? lkk : (i > k ? li : A[r]);
+        else if (c > k && c <= i) A[r] -= li * lj;
+      }
+    }
+    if (lane == k) q.invd[k] = rs;
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = g + 4 * r;
+    if (i < DD && c < DD) q.Lm[i * DD + c] = A[r];
+  }
+  if (lane < DD) {
+    q.mean[lane] = pm_sel(sm, lane) + (double)s[lane];
+    q.zmean[lane] = pm_sel(zm, lane);
+    q.zistd[lane] = pm_sel(zi, lane);
+  }
+  pm_wave_sync();
+  return ok;
+}
+template <int DD>
+__device__ __forceinline__ bool pm_mm_factor_t(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                               int zrow0, int Bg, const MMScratch& q, int lane) {
+  return pm_mm_factor_from_gram<DD>(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, 0, M, lane), M, s, q, lane);
+}
+
+template <int DD>
+__device__ __forceinline__ bool pm_mm_fwd_t(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                            int zrow0, int Bg, float* out, int out_ld, double* scr, int lane) {
+  const MMScratch q = pm_mm_carve(scr, DD);
+  const bool ok = pm_mm_factor_t<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, q, lane);
+  for (int e = lane; e < M * DD; e += 64) {
+    const int r = e / DD, j = e - r * DD;
+    double acc = q.mean[j];
+    const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
+    for (int c = 0; c <= j; ++c)
+      acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * DD + c];
+    out[(size_t)r * out_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
+  return ok;
+}
+
+// adjoint's d x d algebra on the scratch: Lbar (q.P) -> P = (Sbar + Sbar^T) / (M - 1)  (q.P)
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_tail(const MMScratch& q, int lane, int M) {
+  const double inv_m1 = 1.0 / (double)(M - 1);
+  // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
+  for (int e = lane; e < DD * DD; e += 64) {
+    const int i = e / DD, j = e - i * DD;
+    double acc = 0.0;
+    if (j <= i) {
+      for (int c = i; c < DD; ++c) acc += q.Lm[c * DD + i] * q.P[c * DD + j];
+      if (i == j) acc *= 0.5;
+    }
+    q.Sb[e] = acc;
+  }
+  pm_wave_sync();
+  // X = Phi L^-1  (row i of X solves x L = phi_i), in place in q.Sb
+  for (int i = lane; i < DD; i += 64) {
+    for (int j = DD - 1; j >= 0; --j) {
+      double a = q.Sb[i * DD + j];
+      for (int c = j + 1; c < DD; ++c) a -= q.Sb[i * DD + c] * q.Lm[c * DD + j];
+      q.Sb[i * DD + j] = a * q.invd[j];
+    }
+  }
+  pm_wave_sync();
+  // Sbar = L^-T X  (column j solves L^T y = x_j), in place
+  for (int j = lane; j < DD; j += 64) {
+    for (int i = DD - 1; i >= 0; --i) {
+      double a = q.Sb[i * DD + j];
+      for (int c = i + 1; c < DD; ++c) a -= q.Lm[c * DD + i] * q.Sb[c * DD + j];
+      q.Sb[i * DD + j] = a * q.invd[i];
+    }
+  }
+  pm_wave_sync();
+  for (int e = lane; e < DD * DD; e += 64) {
+    const int i = e / DD, j = e - i * DD;
+    q.P[e] = (q.Sb[i * DD + j] + q.Sb[j * DD + i]) * inv_m1;
+  }
+  pm_wave_sync();
+}
+
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_t(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                            int zrow0, int Bg, const float* g, int g_ld, float* gout,
+                                            int gout_ld, double* scr, int lane) {
+  constexpr int NR = (DD + 3) / 4;
+  const MMScratch q = pm_mm_carve(scr, DD);
+  (void)pm_mm_factor_t<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, q, lane);
+  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
+  // H = g^T [z | 1]  ->  mbar = sum_r g,  Lbar = tril(g^T zhat)
+  {
+    const int gq = lane >> 4, c = lane & 15;
+    const int cc = c < DD ? c : 0;
+    pm_f64x4 H = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int r0 = 0; r0 < M; r0 += 4) {
+      const int r = r0 + gq, rr = r < M ? r : M - 1;
+      const double gv = (double)g[(size_t)rr * g_ld + cc];
+      const double zv = (double)z[(size_t)pm_zidx(zrow0, rr, Bg) * z_ld + cc];
+      const double a = (c < DD && r < M) ? gv : 0.0;
+      const double b = r < M ? (c < DD ? zv : (c == DD ? 1.0 : 0.0)) : 0.0;
+      H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
+    }
+    double mb[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) mb[i] = pm_rl64(H[i >> 2], ((i & 3) << 4) | DD);
+    const double zmc = q.zmean[cc], zsc = q.zistd[cc];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = gq + 4 * r;
+      double mi = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * r + u < DD) mi = (gq == u) ? mb[4 * r + u] : mi;
+      if (i < DD && c < DD) q.P[i * DD + c] = (c <= i) ? (H[r] - zmc * mi) * zsc : 0.0;
+    }
+    if (lane < DD) q.mbar[lane] = pm_sel(mb, lane);
+  }
+  pm_wave_sync();
+  pm_mm_bwd_tail<DD>(q, lane, M);
+  for (int e = lane; e < M * DD; e += 64) {
+    const int r = e / DD, j = e - r * DD;
+    double acc = q.mbar[j] * inv_m;
+    for (int c = 0; c < DD; ++c) acc += ((double)s[(size_t)r * s_ld + c] - q.mean[c]) * q.P[c * DD + j];
+    gout[(size_t)r * gout_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
+}
+
+// --- multi-wave forms (one workgroup of NW waves per group): every wave takes a slice of the
+// group's rows for the row sums (partial Gram tiles meet in LDS, added in wave order by every
+// wave -> identical statistics everywhere, no further exchange) and for the per-row outputs; the
+// d x d algebra in between is repeated by every wave in its own scratch.  `part` holds NW * 256
+// doubles.  A group of any size costs a few microseconds instead of a walk by one wave.
+__device__ __forceinline__ pm_f64x4 pm_mm_sum_parts(pm_f64x4 mine, double* part, int nw, int wid, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[((size_t)wid * 64 + lane) * 4 + r] = mine[r];
+  __syncthreads();
+  pm_f64x4 t = {0.0, 0.0, 0.0, 0.0};
+  for (int w = 0; w < nw; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] += part[((size_t)w * 64 + lane) * 4 + r];
+  return t;
+}
+__device__ __forceinline__ void pm_mm_slice(int M, int nw, int wid, int& r_lo, int& r_hi) {
+  const int per = ((M + nw - 1) / nw + 3) & ~3;
+  r_lo = min(M, wid * per);
+  r_hi = min(M, r_lo + per);
+}
+template <int DD>
+__device__ __forceinline__ bool pm_mm_fwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                             int zrow0, int Bg, float* out, int out_ld, double* scr,
+                                             double* part, int nw, int wid, int lane) {
+  int r_lo, r_hi;
+  pm_mm_slice(M, nw, wid, r_lo, r_hi);
+  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
+                                     nw, wid, lane);
+  const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
+  const bool ok = pm_mm_factor_from_gram<DD>(G, M, s, q, lane);
+  for (int e = r_lo * DD + lane; e < r_hi * DD; e += 64) {
+    const int r = e / DD, j = e - r * DD;
+    double acc = q.mean[j];
+    const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
+    for (int c = 0; c <= j; ++c)
+      acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * DD + c];
+    out[(size_t)r * out_ld + j] = (float)acc;
+  }
+  return ok;
+}
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                             int zrow0, int Bg, const float* g, int g_ld, float* gout,
+                                             int gout_ld, double* scr, double* part, int nw, int wid,
+                                             int lane) {
+  constexpr int NR = (DD + 3) / 4;
+  int r_lo, r_hi;
+  pm_mm_slice(M, nw, wid, r_lo, r_hi);
+  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
+                                     nw, wid, lane);
+  const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
+  (void)pm_mm_factor_from_gram<DD>(G, M, s, q, lane);
+  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
+  {
+    const int gq = lane >> 4, c = lane & 15;
+    const int cc = c < DD ? c : 0;
+    pm_f64x4 H = {0.0, 0.0, 0.0, 0.0};
+    if (r_hi > r_lo) {
+#pragma unroll 4
+      for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
+        const int r = r0 + gq, rr = r < r_hi ? r : r_hi - 1;
+        const double gv = (double)g[(size_t)rr * g_ld + cc];
+        const double zv = (double)z[(size_t)pm_zidx(zrow0, rr, Bg) * z_ld + cc];
+        const double a = (c < DD && r < r_hi) ? gv : 0.0;
+        const double b = r < r_hi ? (c < DD ? zv : (c == DD ? 1.0 : 0.0)) : 0.0;
+        H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
+      }
+    }
+    __syncthreads();            // the Gram partials have been consumed; every read of g is done
+    H = pm_mm_sum_parts(H, part, nw, wid, lane);
+    double mb[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) mb[i] = pm_rl64(H[i >> 2], ((i & 3) << 4) | DD);
+    const double zmc = q.zmean[cc], zsc = q.zistd[cc];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = gq + 4 * r;
+      double mi = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * r + u < DD) mi = (gq == u) ? mb[4 * r + u] : mi;
+      if (i < DD && c < DD) q.P[i * DD + c] = (c <= i) ? (H[r] - zmc * mi) * zsc : 0.0;
+    }
+    if (lane < DD) q.mbar[lane] = pm_sel(mb, lane);
+  }
+  pm_wave_sync();
+  pm_mm_bwd_tail<DD>(q, lane, M);
+  for (int e = r_lo * DD + lane; e < r_hi * DD; e += 64) {
+    const int r = e / DD, j = e - r * DD;
+    double acc = q.mbar[j] * inv_m;
+    for (int c = 0; c < DD; ++c) acc += ((double)s[(size_t)r * s_ld + c] - q.mean[c]) * q.P[c * DD + j];
+    gout[(size_t)r * gout_ld + j] = (float)acc;
+  }
+  (void)inv_m1;
+}
+
+// d -> template dispatch; the general code for widths without an instantiation
+__device__ __forceinline__ bool pm_mm_fwd_auto(const float* s, int s_ld, int M, int d, const float* z,
+                                               int z_ld, int zrow0, int Bg, float* out, int out_ld,
+                                               double* scr, int lane) {
+  switch (d) {
+    case 1: return pm_mm_fwd_t<1>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    case 2: return pm_mm_fwd_t<2>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    case 3: return pm_mm_fwd_t<3>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    case 4: return pm_mm_fwd_t<4>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    case 5: return pm_mm_fwd_t<5>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    case 6: return pm_mm_fwd_t<6>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, scr, lane);
+    default: break;
+  }
+  return pm_mm_fwd(s, s_ld, M, d, z, z_ld, zrow0, Bg, false, out, out_ld, scr, lane);
+}
+__device__ __forceinline__ void pm_mm_bwd_auto(const float* s, int s_ld, int M, int d, const float* z,
+                                               int z_ld, int zrow0, int Bg, const float* g, int g_ld,
+                                               float* gout, int gout_ld, double* scr, int lane) {
+  switch (d) {
+    case 1: return pm_mm_bwd_t<1>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    case 2: return pm_mm_bwd_t<2>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    case 3: return pm_mm_bwd_t<3>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    case 4: return pm_mm_bwd_t<4>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    case 5: return pm_mm_bwd_t<5>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    case 6: return pm_mm_bwd_t<6>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, scr, lane);
+    default: break;
+  }
+  pm_mm_bwd(s, s_ld, M, d, z, z_ld, zrow0, Bg, false, g, g_ld, gout, gout_ld, scr, lane);
+}
