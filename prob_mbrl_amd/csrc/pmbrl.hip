@@ -319,7 +319,7 @@ struct pmbrl_plan {
   int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
-      off_gxc, off_grt, off_Jx, off_Ja, ws_bytes;
+      off_gxc, off_gxc2, off_grt, off_Jx, off_Ja, ws_bytes;
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -379,6 +379,7 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3, 13)      \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3, 13)      \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)
 
 template <int RT, int CA, int CB>
@@ -578,7 +579,14 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     const int want = std::max(p->M, (c.rows_per_wg_hint / p->M) * p->M);
     if (want <= 16 * p->RT) p->rows_per_wg = want;
   }
-  p->lds_bytes = lds_need(p->RT, p->mm_mode == 1 ? c.D : 0);   // also fixes p->LD for the chosen RT
+  // groups that span workgroups: the fast family does the state moment matching in the prologue of
+  // its per-step launches (mm_mode 3) when it has a compile-time-width instance and the partial
+  // Gram tiles fit the activation buffers; otherwise separate kernels per step (mm_mode 2)
+  if (p->mm_mode == 2 && p->fast && (c.flags & PMBRL_FLAG_MM_STATES) && c.D >= 4 && c.D <= 6 &&
+      !getenv("PMBRL_MM_MODE2") && lds_need(p->RT, c.D) <= lds_cap &&
+      (size_t)2 * 16 * p->RT * ld_for(p->RT) * sizeof(float) >= (size_t)8 * 256 * sizeof(double))
+    p->mm_mode = 3;
+  p->lds_bytes = lds_need(p->RT, (p->mm_mode == 1 || p->mm_mode == 3) ? c.D : 0);   // also fixes p->LD for the chosen RT
   { const StagePair sp = stages_for(p->RT); p->CA = sp.ca; p->CB = sp.cb; }
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
   p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
@@ -679,6 +687,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Jx = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
+    p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     p->off_part = take((size_t)p->dw_nsplit * ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
@@ -696,7 +705,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     PM_FAST_CASES
 #undef PM_FAST_CASE
   }
-  if (p->mm_mode == 2) {
+  if (p->mm_mode == 2 || p->mm_mode == 3) {
     const int smem = (int)(pm_mm_kernel_doubles(c.D) * sizeof(double));
     if (smem > 64 * 1024) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_fwd_kernel),
@@ -912,7 +921,7 @@ static int hidden_tiles(const RolloutArgs& A) {
 template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   // variant: see pmbrl_fast.h (PF_VAR_*)
-  const bool mm = A.mm_mode == 1;     // whole groups per workgroup, moment matching inside the sweep
+  const bool mm = A.mm_mode == 1 || A.mm_mode == 3;   // moment matching inside the sweep launches
   const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
                    (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
   const int var = mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
@@ -994,7 +1003,17 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   {
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
-  if (p->mm_mode != 2) {
+  if (p->mm_mode == 3) {
+    // one launch per step; step t's launch first moment-matches the states sampled by step t-1
+    for (int t = 0; t < p->cfg.H; ++t) {
+      A.t0 = t; A.t1 = t + 1;
+      launch_fwd_rt(p, A, s);
+    }
+    RolloutArgs Am = A;
+    Am.flags &= ~PMBRL_FLAG_MM_REWARDS;
+    hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64),
+                       pm_mm_kernel_doubles(p->cfg.D) * sizeof(double), s, Am, p->cfg.H - 1);   // x_H
+  } else if (p->mm_mode != 2) {
     launch_fwd_rt(p, A, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
@@ -1053,7 +1072,22 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
                        pm_mm_scratch_doubles(1) * sizeof(double), s, A, grt);
     A.grad_rewards = grt;
   }
-  if (p->mm_mode != 2) {
+  if (p->mm_mode == 3) {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
+    if (grad_states_d) return fail(-3, "grad_states with moment-matching groups spanning workgroups: not offered");
+    float* cbuf[2] = {A.gx_carry, reinterpret_cast<float*>(ws + p->off_gxc2)};
+    HIPCHK(hipMemsetAsync(cbuf[0], 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
+    A.gx_from_carry = 1;
+    int k = 0;
+    for (int t = p->cfg.H - 1; t >= 0; --t, k ^= 1) {
+      A.gx_carry = cbuf[k];           // dL/dx_{t+1}, all rows (read by every workgroup of the group)
+      A.gx_carry_out = cbuf[k ^ 1];   // dL/dx_t of this workgroup's rows
+      A.t0 = t; A.t1 = t + 1;
+      launch_bwd_rt(p, A, s);
+    }
+    A.gx_carry = cbuf[0];
+    A.gx_carry_out = nullptr;
+  } else if (p->mm_mode != 2) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     A.gx_from_carry = 0;
     launch_bwd_rt(p, A, s);

@@ -78,7 +78,8 @@ struct FastOff {
 struct RolloutArgs {
   int B, D, U, H, Bg, row_off, flags;
   int G, M;            // moment-matching groups on this device, rows per group
-  int mm_mode;         // 0 none, 1 in-kernel (group fits a workgroup), 2 external kernel
+  int mm_mode;         // 0 none, 1 in-kernel (group fits a workgroup), 2 external kernel, 3 per-step launches with the
+                       // moment matching in their prologue (fast family)
   int t0, t1;          // step range of this launch
   int rows_per_wg, nwg, Rw;   // Rw = 16*RT = stash block width
   int LD;              // LDS leading dimension of the activation buffers (floats)
@@ -97,6 +98,7 @@ struct RolloutArgs {
   int* status;
   // backward only
   const float *grad_rewards, *grad_states, *grad_actions;
+  float* gx_carry_out;   // mm_mode 3: the carried gradient is written here (ping-pong with gx_carry)
   float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
   int gx_from_carry;
   long long zpol_ss, zdyn_ss;   // per-step strides of z_pol / z_dyn (0 = frozen)

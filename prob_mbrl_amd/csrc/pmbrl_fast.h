@@ -957,7 +957,8 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 //         norms, no cycle stamps
 //   EXT   + per-step output noise (resample_*_noise), grad_states / grad_actions inputs,
 //         action_grad_norms output, cycle stamps (pmbrl_plan_set_prof)
-//   MM    EXT + the in-kernel moment matching of states (mm_mode 1)
+//   MM    EXT + the in-kernel moment matching of states (mm_mode 1: whole groups per workgroup,
+//         every step; mm_mode 3: groups spanning workgroups, in the prologue of per-step launches)
 // Shape specialisation (template parameter SH): the state / action widths, the activation
 // leading dimension and the layer count as compile-time constants (0 = read from the
 // arguments).  The LDS carve-up, every row / column index and the layer loops then fold into
@@ -1005,11 +1006,47 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   float* xa = L.xa;
   float* xb = L.xb;
 
+  // mm_mode 3 (a moment-matching group spans several workgroups; one launch per step): the
+  // moment matching of the PREVIOUS step's sampled states is done here, by every workgroup for
+  // its own rows -- the group statistics are recomputed per workgroup from all the group's rows
+  // in HBM (the previous launch wrote them), 8 waves sharing the row sums.  No separate kernel
+  // launch per step, and the work hides behind the rest of the prologue's memory traffic.
+  bool x_ready = false;
+  if (MM && A.mm_mode == 3 && mm_states && T0 > 0) {
+    const int tp = T0 - 1;
+    const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
+    double* part = reinterpret_cast<double*>(L.bufA);          // the activation buffers are still free
+    const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
+    for (int gi = g_lo; gi <= g_hi; ++gi) {
+      const int gr0 = gi * A.M;
+      const float* sp = A.xt + ((size_t)tp * B + gr0) * D;
+      const int zrow0 = pm_zrow0(tp, A.row_off + gr0, A.flags);
+      const int m_lo = max(row0, gr0) - gr0, m_hi = min(row0 + nvalid, gr0 + A.M) - gr0;
+      const int o_lo = wid == 0 ? m_lo : 0, o_hi = wid == 0 ? m_hi : 0;   // wave 0 writes this workgroup's rows
+      bool ok = true;
+#define PM_CALL(DD) ok = pm_mm_fwd_rows<DD>(sp, D, A.M, zmm, D, zrow0, A.Bg, xa, D, o_lo, o_hi, row0 - gr0, L.mm, \
+                                            part, PF_NW, wid, lane)
+      switch (D) {
+        case 4: PM_CALL(4); break;
+        case 5: PM_CALL(5); break;
+        case 6: PM_CALL(6); break;
+        default: ok = false; break;      // (the host only selects mm_mode 3 for these widths)
+      }
+#undef PM_CALL
+      if (!ok && tid == 0) atomicMin(A.status, tp);
+      __syncthreads();
+    }
+    for (int i = nvalid * D + tid; i < R * D; i += PF_NT) xa[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < nvalid * D; i += PF_NT) A.states[((size_t)T0 * B + row0) * D + i] = xa[i];
+    x_ready = true;
+  }
+
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
   pm_fast_preload_tails(A.sd_fwd, L, tid);
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
-  {
+  if (!x_ready) {
     const float* src = (T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D;
     for (int i = tid; i < R * D; i += PF_NT) {
       const int r = i / D, d = i - r * D;
@@ -1281,10 +1318,42 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   float* gxn = L.jx;    // dL/dx~ incl. the reward term, then + dynamics-input term
   const bool mms = mm_states;
 
+  // mm_mode 3: adjoint of the moment matching that produced x_{t+1} (t = this launch's step), per
+  // workgroup for its own rows, from the whole group's carried gradient -- see the forward kernel
+  bool g_ready = false;
+  if (MM && A.mm_mode == 3 && mms) {
+    const int tp = T0;
+    const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
+    double* part = reinterpret_cast<double*>(L.bufA);
+    const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
+    for (int gi = g_lo; gi <= g_hi; ++gi) {
+      const int gr0 = gi * A.M;
+      const float* sp = A.xt + ((size_t)tp * B + gr0) * D;
+      const float* gin = A.gx_carry + (size_t)gr0 * D;
+      const int zrow0 = pm_zrow0(tp, A.row_off + gr0, A.flags);
+      const int m_lo = max(row0, gr0) - gr0, m_hi = min(row0 + nvalid, gr0 + A.M) - gr0;
+      const int o_lo = wid == 0 ? m_lo : 0, o_hi = wid == 0 ? m_hi : 0;
+#define PM_CALL(DD) pm_mm_bwd_rows<DD>(sp, D, A.M, zmm, D, zrow0, A.Bg, gin, D, gx, D, o_lo, o_hi, row0 - gr0, L.mm, \
+                                       part, PF_NW, wid, lane)
+      switch (D) {
+        case 4: PM_CALL(4); break;
+        case 5: PM_CALL(5); break;
+        case 6: PM_CALL(6); break;
+        default: break;
+      }
+#undef PM_CALL
+      __syncthreads();
+    }
+    for (int i = nvalid * D + tid; i < R * D; i += PF_NT) gx[i] = 0.f;
+    __syncthreads();
+    g_ready = true;
+  }
+
   pm_fast_preload<RT>(A, L, row0, nvalid, tid);
   pm_fast_preload_tails(A.sd_bwd, L, tid);
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
+  if (!g_ready)
   for (int i = tid; i < R * D; i += PF_NT) {
     const int r = i / D, d = i - r * D;
     float v = 0.f;
@@ -1573,7 +1642,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   __syncthreads();
   for (int i = tid; i < nvalid * D; i += PF_NT) {
     const size_t o = (size_t)row0 * D + i;
-    if (EXT && A.gx_carry) A.gx_carry[o] = gx[i];
+    if (EXT && A.gx_carry) (A.gx_carry_out ? A.gx_carry_out : A.gx_carry)[o] = gx[i];
     if (T0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
   }
 }

@@ -521,6 +521,7 @@ __device__ __forceinline__ void pm_mm_bwd_t(const float* s, int s_ld, int M, con
   pm_wave_sync();
 }
 
+// Rows [o_lo, o_hi) ... see pm_mm_fwd_rows / pm_mm_bwd_rows.
 // --- multi-wave forms (one workgroup of NW waves per group): every wave takes a slice of the
 // group's rows for the row sums (partial Gram tiles meet in LDS, added in wave order by every
 // wave -> identical statistics everywhere, no further exchange) and for the per-row outputs; the
@@ -541,31 +542,41 @@ __device__ __forceinline__ void pm_mm_slice(int M, int nw, int wid, int& r_lo, i
   r_lo = min(M, wid * per);
   r_hi = min(M, r_lo + per);
 }
+// Rows [o_lo, o_hi) of the group are written by THIS wave, to out[(r - o_shift) * out_ld + j].
 template <int DD>
-__device__ __forceinline__ bool pm_mm_fwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
-                                             int zrow0, int Bg, float* out, int out_ld, double* scr,
-                                             double* part, int nw, int wid, int lane) {
+__device__ __forceinline__ bool pm_mm_fwd_rows(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                               int zrow0, int Bg, float* out, int out_ld, int o_lo, int o_hi,
+                                               int o_shift, double* scr, double* part, int nw, int wid,
+                                               int lane) {
   int r_lo, r_hi;
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
   const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
                                      nw, wid, lane);
   const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
   const bool ok = pm_mm_factor_from_gram<DD>(G, M, s, q, lane);
-  for (int e = r_lo * DD + lane; e < r_hi * DD; e += 64) {
+  for (int e = o_lo * DD + lane; e < o_hi * DD; e += 64) {
     const int r = e / DD, j = e - r * DD;
     double acc = q.mean[j];
     const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
     for (int c = 0; c <= j; ++c)
       acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * DD + c];
-    out[(size_t)r * out_ld + j] = (float)acc;
+    out[(size_t)(r - o_shift) * out_ld + j] = (float)acc;
   }
   return ok;
 }
 template <int DD>
-__device__ __forceinline__ void pm_mm_bwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
-                                             int zrow0, int Bg, const float* g, int g_ld, float* gout,
-                                             int gout_ld, double* scr, double* part, int nw, int wid,
-                                             int lane) {
+__device__ __forceinline__ bool pm_mm_fwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                             int zrow0, int Bg, float* out, int out_ld, double* scr,
+                                             double* part, int nw, int wid, int lane) {
+  int r_lo, r_hi;
+  pm_mm_slice(M, nw, wid, r_lo, r_hi);
+  return pm_mm_fwd_rows<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, r_lo, r_hi, 0, scr, part, nw, wid, lane);
+}
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                               int zrow0, int Bg, const float* g, int g_ld, float* gout,
+                                               int gout_ld, int o_lo, int o_hi, int o_shift, double* scr,
+                                               double* part, int nw, int wid, int lane) {
   constexpr int NR = (DD + 3) / 4;
   int r_lo, r_hi;
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
@@ -608,15 +619,25 @@ __device__ __forceinline__ void pm_mm_bwd_mw(const float* s, int s_ld, int M, co
   }
   pm_wave_sync();
   pm_mm_bwd_tail<DD>(q, lane, M);
-  for (int e = r_lo * DD + lane; e < r_hi * DD; e += 64) {
+  for (int e = o_lo * DD + lane; e < o_hi * DD; e += 64) {
     const int r = e / DD, j = e - r * DD;
     double acc = q.mbar[j] * inv_m;
     for (int c = 0; c < DD; ++c) acc += ((double)s[(size_t)r * s_ld + c] - q.mean[c]) * q.P[c * DD + j];
-    gout[(size_t)r * gout_ld + j] = (float)acc;
+    gout[(size_t)(r - o_shift) * gout_ld + j] = (float)acc;
   }
   (void)inv_m1;
 }
 
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_mw(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                             int zrow0, int Bg, const float* g, int g_ld, float* gout,
+                                             int gout_ld, double* scr, double* part, int nw, int wid,
+                                             int lane) {
+  int r_lo, r_hi;
+  pm_mm_slice(M, nw, wid, r_lo, r_hi);
+  pm_mm_bwd_rows<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, g, g_ld, gout, gout_ld, r_lo, r_hi, 0, scr, part, nw, wid,
+                     lane);
+}
 // d -> template dispatch; the general code for widths without an instantiation
 __device__ __forceinline__ bool pm_mm_fwd_auto(const float* s, int s_ld, int M, int d, const float* z,
                                                int z_ld, int zrow0, int Bg, float* out, int out_ld,
