@@ -92,3 +92,31 @@ def test_rows_are_independent():
     out = _run(e)
     assert np.array_equal(ref[1][:, ::-1], out[1]) and np.array_equal(ref[2][:, ::-1], out[2])
     assert common.rel(out[5], ref[5]) < 2e-6
+
+
+@pytest.mark.parametrize('groups', [25, 0], ids=['100-row groups', 'one 2500-row group'])
+def test_groups_spanning_workgroups_match_oracle(groups):
+    """Moment-matching groups larger than a workgroup's 16 rows (mm_mode 3: the statistics are
+    recomputed by every workgroup in the prologue of its per-step launch).  100-row groups straddle
+    workgroup boundaries (100 is not a multiple of 16); mm_groups=None is the reference examples'
+    default.  Against the fp64 oracle, and against the separate-kernel path (mm_mode 2)."""
+    import os
+    from oracle import ref_torch as R
+    d = _problem('cartpole_mm', 12)
+    d['mm_groups'] = np.asarray(groups)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    assert eng.info['mm_mode'] == 3 and eng.info['rows_per_wg'] == 16
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(8)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,
+                                            meta['mm_groups'], z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
+    os.environ['PMBRL_MM_MODE2'] = '1'
+    try:
+        eng2, S2, A2, Rw2, loss2, g2, _ = _run(d)
+    finally:
+        del os.environ['PMBRL_MM_MODE2']
+    assert eng2.info['mm_mode'] == 2
+    assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
