@@ -294,6 +294,10 @@ typedef struct {
   float reg_scale[PMBRL_MAX_LAYERS];     /* CDropout.regularizer_scale buffer (= 0.5 * ctor argument) */
   float drop_reg[PMBRL_MAX_LAYERS];      /* CDropout.dropout_regularizer */
   float reg_weight;
+  int32_t loss_kind;                     /* 0: Gaussian negative log-likelihood (losses.py:16-37);
+                                          * 1: mean squared error of the mean head against the targets
+                                          *    (the critic fit of examples/deep_pilco_no_mm_with_value.py:40-44;
+                                          *    the log-std half of the head is ignored) */
 } pmbrl_bnn_config;
 typedef struct pmbrl_bnn_plan pmbrl_bnn_plan;
 

@@ -1402,6 +1402,7 @@ extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* worksp
   }
   A.X = Xn_d; A.Y = Yn_d; A.idx = idx_d;
   A.mls = p->cfg.max_log_std;
+  A.mse = p->cfg.loss_kind == 1;
   A.inv_M = 1.f / (float)p->cfg.M;
   A.part_lp = reinterpret_cast<float*>(ws + p->off_part_lp);
   A.part_loss = reinterpret_cast<float*>(ws + p->off_part_loss);

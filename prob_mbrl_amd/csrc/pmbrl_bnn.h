@@ -29,6 +29,7 @@ struct BnnArgs {
   const float *X, *Y;              // normalised dataset [N][n_in], [N][n_out]
   const int* idx;                  // [M] minibatch rows
   float mls, inv_M;
+  int mse;                         // loss: mean squared error of the mean head instead of the Gaussian NLL
   float* actT[PM_MAXL];            // stash: input of layer l   [wg][nt[l]*16][16]
   float* gT[PM_MAXL];              // stash: grad wrt pre-activation of layer l [wg][nt[l+1]*16][16]
   float* part_lp;                  // [nwg][sum_h]
@@ -154,6 +155,14 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
         const int d = j < n ? j : j - n;
         const float mu = G1[r * LD + d];
         const float ls = G1[r * LD + n + d];
+        if (A.mse) {
+          // torch.nn.functional.mse_loss: mean over the M x n entries
+          const float dl = mu - A.Y[(size_t)A.idx[row0 + r] * n + d];
+          if (j < n) {
+            gval = 2.f * dl * A.inv_M / (float)n;
+            lsum += dl * dl / (float)n;
+          }
+        } else {
         const float lsc = -softplusf(-ls + A.mls) + A.mls;
         const float s = expf(-lsc);
         const float t = (mu - A.Y[(size_t)A.idx[row0 + r] * n + d]) * s;
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
           lsum += 0.5f * t * t + lsc + 0.9189385332046727f;   // + 1/2 log(2 pi)
         } else {
           gval = (1.f - t * t) * sigmoidf(A.mls - ls) * A.inv_M;
+        }
         }
       }
       G0[r * LD + j] = gval;

@@ -136,7 +136,8 @@ class CDropout(BDropout):
         hard sample with a straight-through value (exactly {0,1})."""
         concrete_p = self.logit_p + ((noise + 1e-7) / (1 - (noise - 1e-7))).log()
         probs = (concrete_p / self.temp).sigmoid()
-        hard = torch.bernoulli(probs)
+        forced = getattr(self, '_forced_sample', None)      # tests: replay recorded draws
+        hard = torch.bernoulli(probs) if forced is None else forced.to(probs)
         self.concrete_noise = (hard - probs).detach() + probs
         self.p = self.logit_p.sigmoid()
 
@@ -144,10 +145,11 @@ class CDropout(BDropout):
         return 1.0   # x * concrete_noise, no division (models/modules.py:158-160)
 
     def forward_mask(self, B, width, resample=False, seed=None):
-        """Eval-mode mask of a stand-alone forward (models/modules.py:120-160)."""
-        if self.training:
-            raise NotImplementedError('training-mode (relaxed) concrete dropout is not offered on '
-                                      'the device path; call .eval() first')
+        """Mask of a stand-alone forward (models/modules.py:120-160).  Eval mode: the stored hard
+        sample (redrawn only when the noise is).  Training mode: a fresh Bernoulli sample of the
+        relaxed probabilities at every call, like the reference -- its VALUE only: a stand-alone
+        forward is not differentiable with respect to the network here (the training step is
+        pmbrl_bnn_loss_grad)."""
         resampled = False
         noise = self.noise
         c = self.concrete_noise
@@ -161,7 +163,7 @@ class CDropout(BDropout):
             self.update_noise(torch.empty(B, width), seed)
             noise = self.noise
             resampled = True
-        if resampled:
+        if self.training or resampled:
             self.update_concrete_noise(noise)
         return self.concrete_noise.detach()[:B]
 

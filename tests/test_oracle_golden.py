@@ -161,6 +161,41 @@ def test_oracle_prioritized_replay():
                        rtol=1e-4)
 
 
+def test_oracle_critic_fit():
+    """update_value_function of the reference's example script (critic without an output density),
+    three Adam updates replayed with the recorded Bernoulli outcomes."""
+    d = common.load('critic_fit')
+    torch.set_flush_denormal(True)
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
+    n = int(d['n_layers'])
+    weights = [(T(d['W%d_init' % i]).requires_grad_(True), T(d['b%d_init' % i]).requires_grad_(True)) for i in range(n)]
+    logit_ps = [T(d['logit_p%d_init' % i]).requires_grad_(True) for i in range(n - 1)]
+    params = []
+    for i in range(n):
+        params += list(weights[i]) + ([logit_ps[i]] if i < n - 1 else [])
+    ms, vs = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    norm = {k: T(d[k]).reshape(1, -1) for k in ('mx', 'iSx', 'my', 'Sy')}
+    rewards = [T(r) for r in d['rewards']]
+    for it in range(int(d['n_updates'])):
+        for p in params:
+            p.grad = None
+        hards = [T(d['hard%d_it%d' % (k, it)]) for k in range(2 * (n - 1))]
+        loss = R.critic_update(weights, logit_ps, [float(d['temp%d' % i]) for i in range(n - 1)],
+                               [float(d['reg_scale%d' % i]) for i in range(n - 1)],
+                               [float(d['drop_reg%d' % i]) for i in range(n - 1)],
+                               [T(d['u%d' % i]) for i in range(n - 1)], norm, T(d['states0']), T(d['statesH']),
+                               rewards, float(d['gamma']), int(d['H']), hards, float(d['reg_weight']))
+        loss.backward()
+        with torch.no_grad():
+            for p, m, v in zip(params, ms, vs):
+                R.adam_step(p, p.grad, m, v, it + 1, float(d['lr']))
+        for i in range(n):
+            assert np.allclose(weights[i][0].detach().numpy(), d['W%d_it%d' % (i, it)], rtol=2e-4, atol=2e-6)
+            assert np.allclose(weights[i][1].detach().numpy(), d['b%d_it%d' % (i, it)], rtol=2e-4, atol=2e-6)
+        for i in range(n - 1):
+            assert np.allclose(logit_ps[i].detach().numpy(), d['logit_p%d_it%d' % (i, it)], rtol=2e-4, atol=2e-6)
+
+
 def test_tile_layout():
     x = torch.arange(6.).view(3, 2)
     t = R.tile(x, 4)

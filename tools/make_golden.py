@@ -593,6 +593,81 @@ def make_experience_case(name, seed=3):
     return d
 
 
+
+def make_critic_case(name, D=4, hid=(24, 24), B=40, H=6, n_updates=3, lr=1e-3, seed=31):
+    """The critic fit of the reference's example script (update_value_function,
+    examples/deep_pilco_no_mm_with_value.py:14-66) called n_updates times on fixed rollout data,
+    with the Bernoulli outcomes of the concrete-dropout layers recorded in call order."""
+    import importlib.util
+    print('[critic] %s' % name)
+    spec = importlib.util.spec_from_file_location(
+        'ref_example_with_value', '/root/reference/examples/deep_pilco_no_mm_with_value.py')
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    V = models.Regressor(models.mlp(
+        D, 1, list(hid), dropout_layers=[models.modules.CDropout(0.2 * np.ones(h)) for h in hid],
+        nonlin=torch.nn.ReLU)).float()
+    V.set_dataset(0.3 * torch.randn(200, D), 0.4 + 0.25 * torch.randn(200, 1))
+    for m in V.model._modules.values():
+        if isinstance(m, models.modules.CDropout):
+            m.logit_p.data = m.logit_p.data + 0.3 * torch.randn_like(m.logit_p.data)
+    states = [0.3 * torch.randn(B, D) for _ in range(H + 1)]
+    rewards = [torch.rand(B, 1) for _ in range(H)]
+    gam = 0.9
+    discount = lambda i: gam**i  # noqa: E731
+    V.train()
+    with torch.no_grad():
+        V(states[0], resample=False)          # stores uniform noise for B rows
+    d = {}
+    f = lambda t: t.detach().double().cpu().numpy()  # noqa: E731
+    lins = [m for m in V.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    drops = [m for m in V.model._modules.values() if isinstance(m, models.modules.CDropout)]
+    d['n_layers'] = len(lins)
+    for i, m in enumerate(lins):
+        d['W%d_init' % i] = f(m.weight)
+        d['b%d_init' % i] = f(m.bias)
+    for i, m in enumerate(drops):
+        d['logit_p%d_init' % i] = f(m.logit_p)
+        d['temp%d' % i] = float(m.temp)
+        d['reg_scale%d' % i] = float(m.regularizer_scale)
+        d['drop_reg%d' % i] = float(m.dropout_regularizer)
+        d['u%d' % i] = f(m.noise)
+    for k in ['mx', 'iSx', 'my', 'Sy']:
+        d[k] = f(getattr(V, k)).reshape(-1)
+    d['states0'] = f(states[0])
+    d['statesH'] = f(states[H])
+    d['rewards'] = f(torch.stack(rewards))
+    d['gamma'] = gam
+    d['H'], d['lr'], d['n_updates'], d['reg_weight'] = H, lr, n_updates, 1e-4
+    opt = torch.optim.Adam(V.parameters(), lr)
+    rec = []
+    orig_bern = torch.bernoulli
+
+    def bern(p, *a, **k):
+        out = orig_bern(p, *a, **k)
+        rec.append(out.clone())
+        return out
+
+    for it in range(n_updates):
+        del rec[:]
+        torch.bernoulli = bern
+        try:
+            ex.update_value_function(V, opt, H, it, states, None, rewards, discount)
+        finally:
+            torch.bernoulli = orig_bern
+        assert len(rec) == 2 * len(drops), len(rec)
+        for k, t in enumerate(rec):
+            d['hard%d_it%d' % (k, it)] = f(t)
+        for i, m in enumerate(lins):
+            d['W%d_it%d' % (i, it)] = f(m.weight)
+            d['b%d_it%d' % (i, it)] = f(m.bias)
+        for i, m in enumerate(drops):
+            d['logit_p%d_it%d' % (i, it)] = f(m.logit_p)
+    return d
+
+
 def _cartpole():
     return CartpoleReward(pole_length=torch.tensor(0.5))
 
@@ -653,6 +728,7 @@ CASES = {
     'bnn_small': lambda: make_bnn_case('bnn_small', 4, 1, [32, 32], 60, 20, 3, 1e-3),
     'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
     'experience_host': lambda: make_experience_case('experience_host'),
+    'critic_fit': lambda: make_critic_case('critic_fit'),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
