@@ -311,6 +311,19 @@ int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* plan, void* stream, void* workspace_d,
                         const float* u_d, const float* bvar_d,
                         float* grad_flat_d, float* loss_out_d /* [3]: loss, -E[lml], reg */);
 
+/* The same step with the options of utils/train_regressor.py:113-147:
+ *  - row_weight_d [M] (optional): importance-sampling weight of every minibatch
+ *    row's log-likelihood (prioritized_sampling, :117-131);
+ *  - row_logprob_d [M] (optional, out): the rows' unweighted log-likelihoods,
+ *    from which the caller updates its priorities;
+ *  - terms: 1 = likelihood only, 2 = regulariser only (its gradient alone, for
+ *    the separate SGD step of decoupled_reg, :133-147), 3 = both. */
+int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* plan, void* stream, void* workspace_d,
+                           const float* Xn_d, const float* Yn_d, const int32_t* idx_d,
+                           const float* params_flat_d, const float* u_d, const float* bvar_d,
+                           float* grad_flat_d, float* loss_out_d,
+                           const float* row_weight_d, float* row_logprob_d, int32_t terms);
+
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout
  * kernels use (R <= 64). */

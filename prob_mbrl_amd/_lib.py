@@ -77,7 +77,7 @@ EXPORTS = [
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
-    'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad',
+    'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def load():
     lib.pmbrl_bnn_plan_n_params.argtypes = [vp]
     lib.pmbrl_bnn_loss_grad.restype = C.c_int
     lib.pmbrl_bnn_loss_grad.argtypes = [vp] * 11
+    lib.pmbrl_bnn_loss_grad_ex.restype = C.c_int
+    lib.pmbrl_bnn_loss_grad_ex.argtypes = [vp] * 13 + [i32]
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.pmbrl_plan_set_timing.restype = C.c_int

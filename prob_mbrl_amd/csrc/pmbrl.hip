@@ -1364,13 +1364,29 @@ extern "C" void pmbrl_bnn_plan_destroy(pmbrl_bnn_plan* p) {
 extern "C" size_t pmbrl_bnn_plan_workspace_bytes(const pmbrl_bnn_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" int64_t pmbrl_bnn_plan_n_params(const pmbrl_bnn_plan* p) { return p ? p->n_params : 0; }
 
+extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* workspace_d, const float* Xn_d,
+                                      const float* Yn_d, const int32_t* idx_d, const float* params_flat_d,
+                                      const float* u_d, const float* bvar_d, float* grad_flat_d,
+                                      float* loss_out_d, const float* row_weight_d, float* row_logprob_d,
+                                      int32_t terms);
 extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* workspace_d, const float* Xn_d,
                                    const float* Yn_d, const int32_t* idx_d, const float* params_flat_d,
                                    const float* u_d, const float* bvar_d, float* grad_flat_d,
                                    float* loss_out_d) {
+  return pmbrl_bnn_loss_grad_ex(p, stream, workspace_d, Xn_d, Yn_d, idx_d, params_flat_d, u_d, bvar_d,
+                                grad_flat_d, loss_out_d, nullptr, nullptr, 3);
+}
+
+extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* workspace_d, const float* Xn_d,
+                                      const float* Yn_d, const int32_t* idx_d, const float* params_flat_d,
+                                      const float* u_d, const float* bvar_d, float* grad_flat_d,
+                                      float* loss_out_d, const float* row_weight_d, float* row_logprob_d,
+                                      int32_t terms) {
   if (!p || !workspace_d || !Xn_d || !Yn_d || !idx_d || !params_flat_d || !grad_flat_d || !loss_out_d)
     return fail(-1, "null argument");
-  if (p->sum_h > 0 && (!u_d || !bvar_d)) return fail(-1, "bnn: dropout layers need u and bvar");
+  if (!(terms & 3)) return fail(-1, "bnn: terms must select the likelihood (1), the regulariser (2) or both");
+  const bool lik = (terms & 1) != 0, regt = (terms & 2) != 0;
+  if (p->sum_h > 0 && lik && (!u_d || !bvar_d)) return fail(-1, "bnn: dropout layers need u and bvar");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(p->device));
   char* ws = static_cast<char*>(workspace_d);
@@ -1403,9 +1419,13 @@ extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* worksp
   A.X = Xn_d; A.Y = Yn_d; A.idx = idx_d;
   A.mls = p->cfg.max_log_std;
   A.mse = p->cfg.loss_kind == 1;
+  A.row_w = row_weight_d; A.row_lp = row_logprob_d;
   A.inv_M = 1.f / (float)p->cfg.M;
   A.part_lp = reinterpret_cast<float*>(ws + p->off_part_lp);
   A.part_loss = reinterpret_cast<float*>(ws + p->off_part_loss);
+  if (!lik) {
+    HIPCHK(hipMemsetAsync(grad_flat_d, 0, (size_t)p->n_params * sizeof(float), s));
+  } else {
   hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   hipLaunchKernelGGL(pm_bnn_fwd_bwd, dim3(p->nwg), dim3(PM_NT), p->lds, s, A);
   // dW / db of every layer: the policy-gradient GEMM over the same stash layout (one 16-row chunk per split)
@@ -1424,6 +1444,7 @@ extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* worksp
   hipLaunchKernelGGL(pm_dw_kernel, dim3(p->nwg), dim3(PM_DW_NT), 0, s, W);
   hipLaunchKernelGGL(pm_dw_reduce, dim3((p->n_params + 255) / 256), dim3(512), 0, s, W.part, p->nwg, p->n_params,
                      p->part_stride, grad_flat_d);
+  }
   BnnFinishArgs Fa;
   memset(&Fa, 0, sizeof(Fa));
   Fa.nl = p->nl; Fa.nwg = p->nwg; Fa.sum_h = p->sum_h; Fa.N = p->cfg.N;
@@ -1433,7 +1454,8 @@ extern "C" int pmbrl_bnn_loss_grad(pmbrl_bnn_plan* p, void* stream, void* worksp
     Fa.has_drop[l] = p->has_drop[l];
     Fa.reg_scale[l] = p->cfg.reg_scale[l]; Fa.drop_reg[l] = p->cfg.drop_reg[l];
   }
-  Fa.reg_weight = p->cfg.reg_weight; Fa.inv_M = A.inv_M;
+  Fa.reg_weight = regt ? p->cfg.reg_weight : 0.f; Fa.inv_M = A.inv_M;
+  Fa.reg_only = lik ? 0 : 1;
   Fa.params = params_flat_d; Fa.grad = grad_flat_d; Fa.part_lp = A.part_lp; Fa.part_loss = A.part_loss;
   Fa.loss_out = loss_out_d; Fa.reg_part = reinterpret_cast<float*>(ws + p->off_reg_part);
   int nfb = 0;

@@ -30,6 +30,8 @@ struct BnnArgs {
   const int* idx;                  // [M] minibatch rows
   float mls, inv_M;
   int mse;                         // loss: mean squared error of the mean head instead of the Gaussian NLL
+  const float* row_w;              // [M] per-row weight of the log-likelihood (importance sampling) or nullptr
+  float* row_lp;                   // [M] out: per-row log-likelihood (unweighted) or nullptr
   float* actT[PM_MAXL];            // stash: input of layer l   [wg][nt[l]*16][16]
   float* gT[PM_MAXL];              // stash: grad wrt pre-activation of layer l [wg][nt[l+1]*16][16]
   float* part_lp;                  // [nwg][sum_h]
@@ -148,6 +150,9 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
     const int n = A.n_out;
     float* gst = A.gT[nl - 1] + (size_t)wg * A.nt[nl] * 16 * 16;
     float lsum = 0.f;
+    __shared__ float rowlp[16];
+    if (tid < 16) rowlp[tid] = 0.f;
+    __syncthreads();
     for (int i = tid; i < R * A.nt[nl] * 16; i += PM_NT) {
       const int r = i / (A.nt[nl] * 16), j = i - r * (A.nt[nl] * 16);
       float gval = 0.f;
@@ -166,11 +171,14 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
         const float lsc = -softplusf(-ls + A.mls) + A.mls;
         const float s = expf(-lsc);
         const float t = (mu - A.Y[(size_t)A.idx[row0 + r] * n + d]) * s;
+        const float rw = A.row_w ? A.row_w[row0 + r] : 1.f;
         if (j < n) {
-          gval = t * s * A.inv_M;
-          lsum += 0.5f * t * t + lsc + 0.9189385332046727f;   // + 1/2 log(2 pi)
+          gval = rw * t * s * A.inv_M;
+          const float nl_d = 0.5f * t * t + lsc + 0.9189385332046727f;   // + 1/2 log(2 pi)
+          lsum += rw * nl_d;
+          if (A.row_lp) atomicAdd(&rowlp[r], -nl_d);
         } else {
-          gval = (1.f - t * t) * sigmoidf(A.mls - ls) * A.inv_M;
+          gval = rw * (1.f - t * t) * sigmoidf(A.mls - ls) * A.inv_M;
         }
         }
       }
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
       __syncthreads();
     }
     if (tid == 0) A.part_loss[wg] = red[0];
+    if (A.row_lp && tid < nvalid) A.row_lp[row0 + tid] = rowlp[tid];
   }
   __syncthreads();
   // ---- backward: dX chain, dropout-logit terms, G stash
@@ -217,6 +226,7 @@ struct BnnFinishArgs {
   int has_drop[PM_MAXL];
   float reg_scale[PM_MAXL], drop_reg[PM_MAXL];
   float reg_weight, inv_M;
+  int reg_only;      // gradient / loss of the regulariser alone (the likelihood partials are not read)
   const float* params;
   float* grad;
   const float* part_lp;
@@ -268,7 +278,8 @@ __global__ __launch_bounds__(256) void pm_bnn_finish(const BnnFinishArgs A) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) tot += s2s[q][col];
       float gdata = 0.f;
-      for (int w = 0; w < A.nwg; ++w) gdata += A.part_lp[(size_t)w * A.sum_h + A.lp_off[l] + k];
+      if (!A.reg_only)
+        for (int w = 0; w < A.nwg; ++w) gdata += A.part_lp[(size_t)w * A.sum_h + A.lp_off[l] + k];
       const float lgp = logf(p), lg1 = logf(1.f - p);
       A.grad[A.lp_poff[l] + k] = gdata + c * p * (1.f - p) * (rs * tot + dr * (lgp - lg1));
       reg += (double)(rs * p * tot + dr * (p * lgp + (1.f - p) * lg1));
@@ -295,7 +306,8 @@ __global__ void pm_bnn_loss(const BnnFinishArgs A, int n_reg_part) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double reg = 0.0, nll = 0.0;
   for (int i = 0; i < n_reg_part; ++i) reg += (double)A.reg_part[i];
-  for (int w = 0; w < A.nwg; ++w) nll += (double)A.part_loss[w];
+  if (!A.reg_only)
+    for (int w = 0; w < A.nwg; ++w) nll += (double)A.part_loss[w];
   reg *= (double)A.reg_weight;
   const double en = nll * (double)A.inv_M;
   A.loss_out[0] = (float)(en + reg / (double)A.N);

@@ -195,20 +195,25 @@ class BnnStep:
         except Exception:
             pass
 
-    def loss_grad(self, Xn, Yn, idx, params, u, bvar, grad=None):
+    def loss_grad(self, Xn, Yn, idx, params, u, bvar, grad=None, row_weight=None, row_logprob=None, terms=3):
         """Xn [N, n_in], Yn [N, n_out] normalised dataset; idx int32 [M]; params flat fp32;
-        u, bvar: fp32 [M * sum_h] (per dropout layer a block [M, h_l]).  Returns (grad, loss[3])."""
+        u, bvar: fp32 [M * sum_h] (per dropout layer a block [M, h_l]).  Optional: row_weight [M]
+        (importance weights of the rows' log-likelihoods), row_logprob [M] (out: the rows'
+        log-likelihoods), terms (1 likelihood, 2 regulariser, 3 both).  Returns (grad, loss[3])."""
         for t in (Xn, Yn, params):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         assert idx.is_cuda and idx.dtype == torch.int32 and idx.numel() == self.M
         assert params.numel() == self.n_params
-        if self.sum_h:
+        if self.sum_h and (terms & 1):
             assert u.numel() == self.M * self.sum_h and bvar.numel() == self.M * self.sum_h
+        for t in (row_weight, row_logprob):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == self.M and t.is_contiguous())
         if grad is None:
             grad = torch.empty_like(params)
-        _lib.check(self.lib.pmbrl_bnn_loss_grad(self.plan, _stream(), _ptr(self.ws), _ptr(Xn), _ptr(Yn),
-                                                _ptr(idx), _ptr(params), _ptr(u), _ptr(bvar), _ptr(grad),
-                                                _ptr(self.loss)), 'pmbrl_bnn_loss_grad')
+        _lib.check(self.lib.pmbrl_bnn_loss_grad_ex(self.plan, _stream(), _ptr(self.ws), _ptr(Xn), _ptr(Yn),
+                                                   _ptr(idx), _ptr(params), _ptr(u), _ptr(bvar), _ptr(grad),
+                                                   _ptr(self.loss), _ptr(row_weight), _ptr(row_logprob),
+                                                   int(terms)), 'pmbrl_bnn_loss_grad_ex')
         return grad, self.loss
 
 

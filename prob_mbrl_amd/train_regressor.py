@@ -19,6 +19,30 @@ def iterate_minibatches(N, batchsize):
             yield indices[i:i + batchsize]
 
 
+priority_tree = {}          # utils/train_regressor.py:11: one SumTree per model, kept across calls
+
+
+def iterate_priority_tree(N, batchsize, tree, warmup_iters=100):
+    """utils/train_regressor.py:25-46: uniform minibatches for warmup_iters steps (counting the
+    visits), then rows drawn from the priority tree with importance weights (beta 0.4 -> 1).
+    Yields (data indices, tree indices, weights or None)."""
+    if N > tree.size:
+        for i in range(tree.size, N):
+            tree.append(i, tree.max_p)
+        tree.renormalize()
+    it = iterate_minibatches(N, batchsize)
+    beta = 0.4
+    for _ in range(warmup_iters):
+        idxs = next(it)
+        tree.counts[idxs] += 1
+        tree.max_count = max(tree.max_count, tree.counts[idxs].max())
+        yield idxs, idxs + tree.max_size - 1, None
+    while True:
+        data_idxs, idxs, weights = tree.sample(batchsize, beta=beta)
+        beta = min(1.0, beta + 1e-3)
+        yield np.array(data_idxs), idxs, weights
+
+
 def flat_module_parameters(params, owner, key='_pmbrl_flat_all'):
     """Make `params` (in order) views of ONE flat fp32 buffer and return it; redone when the
     views were broken (module.cuda() / .float() / load())."""
@@ -56,13 +80,14 @@ def _is_diag_gaussian_ll(fn):
 
 def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=None, log_likelihood=None,
                     reg_weight=1.0, pbar_class=None, summary_writer=None, summary_scope='',
-                    decoupled_reg=False, prioritized_sampling=False, priority_eps=1e-3, priority_alpha=0.6):
-    """Same call as the reference.  Offered on the device: the default Gaussian likelihood,
-    coupled regularisation, uniform minibatches, a plain torch.optim.Adam."""
+                    decoupled_reg=False, prioritized_sampling=False, priority_eps=1e-3, priority_alpha=0.6,
+                    _replay=None, _warmup_iters=100):
+    """Same call as the reference.  Offered on the device: the default Gaussian likelihood with a
+    plain torch.optim.Adam; decoupled_reg (the regulariser's gradient applied by a separate plain
+    SGD step, :133-147) and prioritized_sampling (minibatches from a per-model SumTree with
+    importance weights, priorities from the rows' log-likelihoods, :88-131)."""
     if not _is_diag_gaussian_ll(log_likelihood):
         raise NotImplementedError('only the diagonal-Gaussian log-likelihood is offered on the device path')
-    if decoupled_reg or prioritized_sampling:
-        raise NotImplementedError('decoupled_reg / prioritized_sampling are not offered on the device path')
     model.train()
     dev = model.mx.device
     if dev.type != 'cuda':
@@ -108,26 +133,65 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
     grad = torch.empty_like(flat)
     sum_h = sum(d for d, t in zip(dims[1:-1], temps) if t > 0)
     u_fixed = None
-    batches = iterate_minibatches(N, batchsize)
+    tree = None
+    if prioritized_sampling:
+        from .experience import SumTree
+        tree = priority_tree.get(model)
+        if tree is None or N > tree.size:
+            old = tree
+            tree = SumTree(2 * N)
+            if old is not None:
+                tree.max_p = old.max_p
+                tree.counts[:len(old.counts)] = old.counts
+            priority_tree[model] = tree
+        batches = iterate_priority_tree(N, batchsize, tree, _warmup_iters)
+    else:
+        batches = ((ix, None, None) for ix in iterate_minibatches(N, batchsize))
     rng = range(iters + 1)       # the reference runs iters + 1 steps (`if i == iters: break` after the step)
     pbar = pbar_class(rng, total=iters) if pbar_class is not None else rng
     last = None
     for i in pbar:
-        idx_np = next(batches)
+        idx_np, tree_idx, w_np = next(batches)
         M = len(idx_np)
         st = steps.get(M)
         if st is None:
             st = steps[M] = E.BnnStep(dims, temps, rscale, dreg, M, N, reg_weight,
                                       max_log_std=float(density.max_log_std), device=dev)
         idx = torch.as_tensor(idx_np.astype(np.int32), device=dev)
-        if resample or u_fixed is None or u_fixed.numel() != M * sum_h:
-            u_fixed = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
-        bvar = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
-        _, loss = st.loss_grad(Xn, Yn, idx, flat, u_fixed, bvar, grad)
+        if _replay is not None:     # tests: the reference's recorded draws of this step
+            f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).reshape(-1)  # noqa: E731
+            u_fixed = torch.cat([f32(a) for a in _replay['u'][i]])
+            bvar = torch.cat([1.0 - f32(a) for a in _replay['hard'][i]])        # hard = (bvar < probs)
+        else:
+            if resample or u_fixed is None or u_fixed.numel() != M * sum_h:
+                u_fixed = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
+            bvar = torch.rand(M * sum_h, device=dev, dtype=torch.float32)
+        row_w = row_lp = None
+        if prioritized_sampling:
+            row_lp = torch.empty(M, dtype=torch.float32, device=dev)
+            if w_np is not None:
+                row_w = torch.as_tensor(np.stack(w_np).astype(np.float32), device=dev).contiguous()
+        _, loss = st.loss_grad(Xn, Yn, idx, flat, u_fixed, bvar, grad, row_weight=row_w, row_logprob=row_lp,
+                               terms=1 if decoupled_reg else 3)
         cache['step'] += 1
         g = cache['group']
         E.clip_adam(flat, grad, cache['m'], cache['v'], cache['step'], g['lr'], g['betas'], g['eps'],
                     max_norm=None)
+        if prioritized_sampling:
+            # new priorities from the rows' log-likelihoods (utils/train_regressor.py:117-128)
+            a = 2
+            p0 = 1 + (a - np.clip(row_lp.cpu().numpy().reshape(-1), -a, a)) / (2 * a)
+            pri = (p0 * tree.max_count / tree.counts[tree_idx - tree.max_size + 1] + priority_eps)**priority_alpha
+            for ti, pv in zip(tree_idx, pri):
+                tree.update(ti, pv)
+            tree.renormalize()
+        if decoupled_reg:
+            # the regulariser's own step: plain SGD with the optimiser's learning rate (:133-147)
+            if decoupled_reg and loss is not None:
+                loss = loss.clone()
+            _, lreg = st.loss_grad(Xn, Yn, idx, flat, u_fixed, bvar, grad, terms=2)
+            flat.add_(grad, alpha=-float(g['lr']))
+            loss[2] = lreg[2]
         last = loss
         if summary_writer is not None:
             lv = loss.tolist()

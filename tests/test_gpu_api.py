@@ -417,3 +417,49 @@ def test_mc_pilco_with_value_function_and_critic_hook():
     assert not torch.equal(v_before, V.model.fc0.weight.detach())
     assert not torch.equal(p_before, pol.model.fc0.weight.detach())
     assert torch.isfinite(V.model.fc0.weight).all() and int(optV.state[V.model.fc0.weight]['step']) == 4
+
+
+@pytest.mark.parametrize('mode', ['decoupled', 'prioritized'])
+def test_train_regressor_options_match_reference(mode):
+    """utils.train_regressor(decoupled_reg=True) / (prioritized_sampling=True): fixtures from the
+    reference's own function (10 steps, recorded concrete-dropout draws, numpy seeded)."""
+    import prob_mbrl_amd as pm
+    from prob_mbrl_amd import train_regressor as TR
+    d = common.load('bnnopt_' + mode)
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
+    n = int(d['n_layers'])
+    hid = [d['W%d_init' % i].shape[0] for i in range(n - 1)]
+    Din, Dout = d['W0_init'].shape[1], d['W%d_init' % (n - 1)].shape[0] // 2
+    dyn = pm.models.DynamicsModel(
+        pm.models.mlp(Din, 2 * Dout, hid, dropout_layers=[pm.models.CDropout(0.25 * np.ones(h)) for h in hid],
+                      nonlin=torch.nn.ReLU),
+        reward_func=None, output_density=pm.models.DiagGaussianDensity(Dout)).float()
+    lins = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for i, lin in enumerate(lins):
+            lin.weight.copy_(T(d['W%d_init' % i]))
+            lin.bias.copy_(T(d['b%d_init' % i]))
+        for i in range(n - 1):
+            getattr(dyn.model, 'drop%d' % i).logit_p.copy_(T(d['logit_p%d_init' % i]))
+    dyn.set_dataset(T(d['X']), T(d['Y']))
+    opt = torch.optim.Adam([p for p in dyn.parameters() if p.requires_grad], float(d['lr']))
+    dyn = dyn.to(DEV)
+    n_steps = int(d['iters']) + 1
+    replay = dict(u=[[d['u%d_it%d' % (i, it)] for i in range(n - 1)] for it in range(n_steps)],
+                  hard=[[d['hard%d_it%d' % (i, it)] for i in range(n - 1)] for it in range(n_steps)])
+    TR.priority_tree.clear()
+    np.random.seed(int(d['np_seed']))
+    pm.utils.train_regressor(dyn, int(d['iters']), int(d['M']), True, opt, decoupled_reg=(mode == 'decoupled'),
+                             prioritized_sampling=(mode == 'prioritized'), _replay=replay,
+                             _warmup_iters=int(d['warmup']))
+    for i, lin in enumerate(lins):
+        assert np.allclose(lin.weight.detach().cpu().numpy(), d['W%d_final' % i], rtol=2e-3, atol=2e-5), i
+        assert np.allclose(lin.bias.detach().cpu().numpy(), d['b%d_final' % i], rtol=2e-3, atol=2e-5)
+    for i in range(n - 1):
+        assert np.allclose(getattr(dyn.model, 'drop%d' % i).logit_p.detach().cpu().numpy(),
+                           d['logit_p%d_final' % i], rtol=2e-3, atol=2e-5)
+    if mode == 'prioritized':
+        tree = TR.priority_tree[dyn]
+        N = int(d['N'])
+        assert np.array_equal(tree.counts[:N], d['tree_counts'])
+        assert np.allclose(tree.sum_tree[tree.max_size - 1:tree.max_size - 1 + N], d['tree_leaves'], rtol=1e-3)

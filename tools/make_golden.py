@@ -668,6 +668,96 @@ def make_critic_case(name, D=4, hid=(24, 24), B=40, H=6, n_updates=3, lr=1e-3, s
     return d
 
 
+class _QuietBar:
+    """stand-in for tqdm in the reference's train_regressor"""
+
+    def __init__(self, it, total=None):
+        self.it = it
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def set_description(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def make_bnn_opts_case(name, mode, D=3, U=1, hid=(8, 8), N=40, M=10, iters=9, lr=2e-3, seed=41, warmup=4):
+    """The REAL utils.train_regressor with decoupled_reg=True or prioritized_sampling=True
+    (utils/train_regressor.py:58-165) for iters+1 steps; the concrete-dropout draws are recorded
+    per step, numpy is seeded right before the call (minibatch shuffles and SumTree.sample draw from
+    np.random).  The uniform warm-up of the priority sampler is shortened from 100 to `warmup`
+    steps (default argument of iterate_priority_tree) so that a short run reaches the tree."""
+    print('[bnn-opts] %s' % name)
+    TR = sys.modules['prob_mbrl.utils.train_regressor']
+    torch.manual_seed(seed)
+    dyn_model = models.mlp(D + U, 2 * D, list(hid),
+                           dropout_layers=[models.modules.CDropout(0.25 * np.ones(h)) for h in hid],
+                           nonlin=torch.nn.ReLU)
+    dyn = models.DynamicsModel(dyn_model, reward_func=None, output_density=models.DiagGaussianDensity(D)).float()
+    Xd = torch.randn(N, D + U)
+    Yd = 0.3 * torch.randn(N, D) + 0.5 * Xd[:, :D] * Xd[:, D:D + 1]
+    dyn.set_dataset(Xd, Yd)
+    d = {}
+    f = lambda t: t.detach().double().cpu().numpy()  # noqa: E731
+    lins = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)]
+    drops = [m for m in dyn.model._modules.values() if isinstance(m, models.modules.CDropout)]
+    d['n_layers'] = len(lins)
+    for i, m in enumerate(lins):
+        d['W%d_init' % i] = f(m.weight)
+        d['b%d_init' % i] = f(m.bias)
+    for i, m in enumerate(drops):
+        d['logit_p%d_init' % i] = f(m.logit_p)
+    d['X'], d['Y'] = f(Xd), f(Yd)
+    d['N'], d['M'], d['iters'], d['lr'], d['warmup'], d['np_seed'] = N, M, iters, lr, warmup, seed + 7
+    opt = torch.optim.Adam([p for p in dyn.parameters() if p.requires_grad], lr)
+    rec = []
+    orig_rand_like, orig_bern = torch.rand_like, torch.bernoulli
+
+    def rand_like(x, *a, **k):
+        out = orig_rand_like(x, *a, **k)
+        rec.append(('u', out.clone()))
+        return out
+
+    def bern(p, *a, **k):
+        out = orig_bern(p, *a, **k)
+        rec.append(('b', out.clone()))
+        return out
+
+    old_defaults = TR.iterate_priority_tree.__defaults__
+    TR.iterate_priority_tree.__defaults__ = (warmup,)
+    TR.priority_tree.clear()
+    TR.decoupled_optimizers.clear()
+    np.random.seed(seed + 7)
+    torch.rand_like, torch.bernoulli = rand_like, bern
+    try:
+        TR.train_regressor(dyn, iters, M, True, opt, pbar_class=_QuietBar,
+                           decoupled_reg=(mode == 'decoupled'), prioritized_sampling=(mode == 'prioritized'))
+    finally:
+        torch.rand_like, torch.bernoulli = orig_rand_like, orig_bern
+        TR.iterate_priority_tree.__defaults__ = old_defaults
+    us = [t for k, t in rec if k == 'u']
+    bs = [t for k, t in rec if k == 'b']
+    n_steps = iters + 1
+    assert len(us) == n_steps * len(drops) and len(bs) == n_steps * len(drops), (len(us), len(bs))
+    for it in range(n_steps):
+        for i in range(len(drops)):
+            d['u%d_it%d' % (i, it)] = f(us[it * len(drops) + i])
+            d['hard%d_it%d' % (i, it)] = f(bs[it * len(drops) + i])
+    for i, m in enumerate(lins):
+        d['W%d_final' % i] = f(m.weight)
+        d['b%d_final' % i] = f(m.bias)
+    for i, m in enumerate(drops):
+        d['logit_p%d_final' % i] = f(m.logit_p)
+    if mode == 'prioritized':
+        tree = TR.priority_tree[dyn]
+        d['tree_counts'] = tree.counts[:N].copy()
+        d['tree_leaves'] = tree.sum_tree[tree.max_size - 1:tree.max_size - 1 + N].copy()
+    return d
+
+
 def _cartpole():
     return CartpoleReward(pole_length=torch.tensor(0.5))
 
@@ -729,6 +819,8 @@ CASES = {
     'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
     'experience_host': lambda: make_experience_case('experience_host'),
     'critic_fit': lambda: make_critic_case('critic_fit'),
+    'bnnopt_decoupled': lambda: make_bnn_opts_case('bnnopt_decoupled', 'decoupled'),
+    'bnnopt_prioritized': lambda: make_bnn_opts_case('bnnopt_prioritized', 'prioritized'),
     'mcp_nomm': lambda: make_mcpilco_case('mcp_nomm', 4, 1, [32, 32], [32, 32],
                                           _cartpole, 10.0, 30, 10, 4,
                                           seed=13),
