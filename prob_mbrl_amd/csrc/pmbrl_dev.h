@@ -221,10 +221,25 @@ __device__ __forceinline__ void gemm_tiles(const float* __restrict__ wf, int n_o
 // partial tiles meet in LDS (`part`, [NW][PM_KS_NT][RT][64][4] floats) and are
 // summed in fixed wave order (deterministic) by gemm_ksplit_combine.
 // ---------------------------------------------------------------------------
+// Where the partial tiles live: a dedicated LDS region (`part`), or -- wide networks, where LDS is
+// what limits the workgroups per CU -- the columns >= 16 * PM_KS_NT of the OUTPUT buffer's rows,
+// which a narrow GEMM leaves untouched (`part` == nullptr, `alias` = that buffer; element e of the
+// region sits at row e / W, column 16 * PM_KS_NT + e % W with W = the free columns rounded down to 4).
+__host__ __device__ inline int pm_part_alias_w(int ld) { return (ld - 16 * PM_KS_NT) & ~3; }
+__host__ __device__ inline bool pm_part_alias_ok(int R, int ld, int RT) {
+  const int w = pm_part_alias_w(ld);
+  return w > 0 && (size_t)R * w >= (size_t)PM_NW * PM_KS_NT * RT * 256;
+}
+__device__ __forceinline__ float* pm_part_at(float* part, float* alias, int ld, int e) {
+  if (part) return part + e;
+  const int w = pm_part_alias_w(ld);
+  const int r = e / w;
+  return alias + (size_t)r * ld + 16 * PM_KS_NT + (e - r * w);
+}
 template <int RT>
 __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ wf, int n_ot, int n_kb,
                                             const float* lds_in, int ld, int wid, int lane,
-                                            float* part) {
+                                            float* part, float* alias = nullptr) {
   const int arow = lane & 15, g = lane >> 4;
   const float* bbase = lds_in + arow * ld + 4 * g;
   const int per = (n_kb + PM_NW - 1) / PM_NW;
@@ -266,16 +281,16 @@ __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ wf, int n_
     if (k < n_ot) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        *reinterpret_cast<f32x4*>(part + (((wid * PM_KS_NT + k) * RT + rt) * 64 + lane) * 4) =
+        *reinterpret_cast<f32x4*>(pm_part_at(part, alias, ld, (((wid * PM_KS_NT + k) * RT + rt) * 64 + lane) * 4)) =
             acc[k][rt];
     }
 }
 
 // after __syncthreads(): out[row][feature] = bias + sum_w part[w]; caller syncs after.
 template <int RT>
-__device__ __forceinline__ void gemm_ksplit_combine(const float* part, int n_ot,
+__device__ __forceinline__ void gemm_ksplit_combine(float* part, int n_ot,
                                                     const float* bias, float* lds_out, int ld,
-                                                    int tid) {
+                                                    int tid, float* alias = nullptr) {
   for (int item = tid; item < n_ot * RT * 64; item += PM_NT) {
     const int ln = item & 63;
     const int rt = (item >> 6) % RT;
@@ -283,7 +298,7 @@ __device__ __forceinline__ void gemm_ksplit_combine(const float* part, int n_ot,
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < PM_NW; ++w)
-      s += *reinterpret_cast<const f32x4*>(part + (((w * PM_KS_NT + k) * RT + rt) * 64 + ln) * 4);
+      s += *reinterpret_cast<const f32x4*>(pm_part_at(part, alias, ld, (((w * PM_KS_NT + k) * RT + rt) * 64 + ln) * 4));
     const int f0 = k * 16 + 4 * (ln >> 4);
     if (bias) s += ldg4(bias + f0);
     *reinterpret_cast<f32x4*>(lds_out + (rt * 16 + (ln & 15)) * ld + f0) = s;
@@ -310,9 +325,10 @@ __device__ __forceinline__ void gemm_narrow(const float* __restrict__ wf, int n_
                                             float* lds_out, int ld, float* part, int wid,
                                             int lane, int tid) {
   if (n_ot <= PM_KS_NT) {
-    gemm_ksplit<RT>(wf, n_ot, n_kb, lds_in, ld, wid, lane, part);
+    // (part == nullptr: the partial tiles go to the free columns of lds_out's rows)
+    gemm_ksplit<RT>(wf, n_ot, n_kb, lds_in, ld, wid, lane, part, lds_out);
     __syncthreads();
-    gemm_ksplit_combine<RT>(part, n_ot, bias, lds_out, ld, tid);
+    gemm_ksplit_combine<RT>(part, n_ot, bias, lds_out, ld, tid, lds_out);
   } else {
     EpiPlain e{bias, lds_out, ld, lane};
     gemm_tiles<RT>(wf, n_ot, n_kb, lds_in, ld, wid, lane, e);

@@ -179,7 +179,7 @@ __host__ __device__ inline size_t pm_lds_floats(int R, int LD, int D, int U, int
   n += (size_t)R * U;                     // av
   n += (size_t)R * 16;                    // gad (action gradient, U <= 16)
   n += 2 * (size_t)R;                     // rr, gr
-  n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials
+  if (!pm_part_alias_ok(R, LD, RT)) n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials (else: in the output buffer)
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);  // per-wave fp64 scratch
   return n;
@@ -195,7 +195,9 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
   m.rr = m.gad + (size_t)R * 16;
   m.gr = m.rr + R;
   m.part = m.gr + R;
-  size_t n = (size_t)(m.part - base) + (size_t)PM_NW * PM_KS_NT * RT * 256;
+  size_t n = (size_t)(m.part - base);
+  if (pm_part_alias_ok(R, LD, RT)) m.part = nullptr;
+  else n += (size_t)PM_NW * PM_KS_NT * RT * 256;
   n = (n + 3) & ~(size_t)3;
   m.mm = reinterpret_cast<double*>(base + n);
   return m;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
 // dW GEMM; policy dW/db are NOT accumulated here.
 // ===========================================================================
 template <int RT>
-__global__ __launch_bounds__(PM_NT, 1) void pm_rollout_bwd(const RolloutArgs A) {
+__global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;

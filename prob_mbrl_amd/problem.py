@@ -24,6 +24,10 @@ CONFIGS = {
     # configs[4]: MFMA stress, per-GPU share of 2048 x 64 over 8 GPUs
     'stress32': dict(D=32, U=8, pol_hid=[512, 512, 512], dyn_hid=[512, 512, 512], P=256, S=64,
                      H=100, mm=False, reward='generic', maxU=1.0),
+    # a small wide-network case for the parity tests of the general kernel family (hidden layers wide
+    # enough that the K-split partial tiles live in the output buffer's free columns)
+    'wide_small': dict(D=12, U=3, pol_hid=[272, 256], dyn_hid=[256, 288, 256], P=10, S=4, H=6,
+                       mm=False, reward='generic', maxU=1.0),
 }
 
 

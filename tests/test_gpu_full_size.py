@@ -120,3 +120,19 @@ def test_groups_spanning_workgroups_match_oracle(groups):
         del os.environ['PMBRL_MM_MODE2']
     assert eng2.info['mm_mode'] == 2
     assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
+
+
+def test_wide_network_general_family_matches_oracle():
+    """Hidden layers wider than the latency-optimised family takes (> 16 tiles) run the general
+    kernels; with leading dimension >= 240 their K-split partial tiles live in the output buffer's
+    free columns instead of a dedicated LDS region.  Against the fp64 oracle."""
+    from oracle import ref_torch as R
+    d = _problem('wide_small')
+    eng, S, A, Rw, loss, g, _ = _run(d, lean=False)
+    assert eng.info['fast'] == 0 and eng.info['LD'] >= 240
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, False, False, None,
+                                            z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
