@@ -378,6 +378,10 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3, 13)       \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3, 13)      \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 5, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 6, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 5, 1, 216, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 6, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)
