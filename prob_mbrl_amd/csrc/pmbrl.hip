@@ -574,6 +574,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // fill the chip first: >= 2 waves of workgroups over 256 CUs before growing tiles
       if ((c.B + 15) / 16 > 1024) RT = 2;
       if ((c.B + 31) / 32 > 1024) RT = 4;
+      // general family (wide networks, throughput-bound): 32-row workgroups halve the weight traffic
+      // per row as soon as they still give every CU two workgroups' worth of rows
+      if (!p->fast && RT == 1 && (c.B + 31) / 32 >= 512) RT = 2;
     }
     while (RT > 1 && lds_need(RT, 0) > lds_cap) RT /= 2;
     p->RT = RT;
@@ -1530,7 +1533,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_debug_linear_kernel(const float* 
   constexpr int RR = 16 * RT;
   float* X = smem;
   float* Y = X + RR * LD;
-  float* part = Y + RR * LD;
+  float* part = pm_part_alias_ok(RR, LD, RT) ? nullptr : Y + RR * LD;   // (same rule as the rollout kernels)
   const int n_kb = (K + 15) / 16, n_ot = (O + 15) / 16;
   for (int i = tid; i < RR * LD; i += PM_NT) {
     const int r = i / LD, k = i - r * LD;
@@ -1568,19 +1571,30 @@ extern "C" int pmbrl_debug_linear(void* stream, const float* x_d, const float* W
     hipLaunchKernelGGL(pm_pack_frag, dim3(grid), dim3(256), 0, s, W_d, K, O, 1, 1, wf);
   hipLaunchKernelGGL(pm_pack_bias, dim3((n_ot * 16 + 255) / 256), dim3(256), 0, s, b_d, O, n_ot * 16,
                      bias);
-  const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
-  const size_t lds = ((size_t)2 * 16 * RT * LD + (size_t)PM_NW * PM_KS_NT * RT * 256) * sizeof(float);
+  auto lds_for = [&](int RT) {
+    return ((size_t)2 * 16 * RT * LD +
+            (pm_part_alias_ok(16 * RT, LD, RT) ? 0 : (size_t)PM_NW * PM_KS_NT * RT * 256)) * sizeof(float);
+  };
   const int narrow = n_ot <= PM_KS_NT ? 1 : 0;
-#define DBG_LAUNCH(RTV)                                                                         \
+  // rows in slabs of the largest tile height whose LDS fits
+  int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
+  while (RT > 1 && lds_for(RT) > (size_t)160 * 1024) RT /= 2;
+  const size_t lds = lds_for(RT);
+#define DBG_LAUNCH(RTV, X0, Y0, RR)                                                             \
   do {                                                                                          \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_debug_linear_kernel<RTV>),     \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-    hipLaunchKernelGGL(pm_debug_linear_kernel<RTV>, dim3(1), dim3(PM_NT), lds, s, x_d, wf, bias, R, \
-                       K, O, LD, narrow, y_d);                                                  \
+    hipLaunchKernelGGL(pm_debug_linear_kernel<RTV>, dim3(1), dim3(PM_NT), lds, s, X0, wf, bias, RR, \
+                       K, O, LD, narrow, Y0);                                                   \
   } while (0)
-  if (RT == 1) DBG_LAUNCH(1);
-  else if (RT == 2) DBG_LAUNCH(2);
-  else DBG_LAUNCH(4);
+  for (int r0 = 0; r0 < R; r0 += 16 * RT) {
+    const int rr = std::min(R - r0, 16 * RT);
+    const float* x0 = x_d + (size_t)r0 * K;
+    float* y0 = y_d + (size_t)r0 * O;
+    if (RT == 1) DBG_LAUNCH(1, x0, y0, rr);
+    else if (RT == 2) DBG_LAUNCH(2, x0, y0, rr);
+    else DBG_LAUNCH(4, x0, y0, rr);
+  }
 #undef DBG_LAUNCH
   HIPCHK(hipGetLastError());
   return 0;

@@ -7,7 +7,7 @@
 //   losses.gaussian_log_likelihood                               losses.py:16-37
 //   CDropout / BSequential regularisers                          models/modules.py:88-93,30-35,234-274
 //
-// pm_bnn_fwd_bwd: a workgroup (4 waves) owns 16 minibatch rows; all layer inputs and the
+// pm_bnn_fwd_bwd: a workgroup (PM_NW waves) owns 16 minibatch rows; all layer inputs and the
 // dropout derivative terms stay in LDS between the forward and the backward pass; the
 // pre-activation gradients and layer inputs are stashed feature-major, exactly the layout the
 // policy-gradient dW GEMM (pmbrl_dw.h) consumes, so dW / db come from the same kernel.

@@ -22,7 +22,7 @@
 
 #include "pmbrl.h"
 
-#define PM_NW 4                 // waves per workgroup (one per SIMD)
+#define PM_NW 8                 // waves per workgroup (two per SIMD)
 #define PM_NT (PM_NW * 64)      // threads per workgroup
 #define PM_MAXL PMBRL_MAX_LAYERS
 #define PM_KS_NT 3              // max out tiles handled by the K-split GEMM (< PM_NW)

@@ -1,7 +1,7 @@
 // Stand-alone evaluation of one Bayesian MLP + diagonal-Gaussian head on B independent rows
 // (include/pmbrl.h: pmbrl_mlp_forward; reference: models/core.py:169-187, 221-248, 265-303,
 // models/densities.py:87-121).  Same MFMA tile routines and fragment-packed weights as the
-// rollout kernels; a workgroup (4 waves) owns 16 rows and walks the layers through two LDS
+// rollout kernels; a workgroup (PM_NW waves) owns 16 rows and walks the layers through two LDS
 // activation buffers.  This is the acting / model-evaluation path (a handful of rows per call),
 // not a throughput kernel.
 #pragma once
