@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
                                                            float b2, float omb1, float omb2, float eps,
                                                            float bc1, float bc2_sqrt, float max_norm,
                                                            float* __restrict__ norm_out,
-                                                           const long long* __restrict__ step) {
-  if (!g_adam_go) return;       // guarded form: the rollout failed, leave parameters and moments alone
+                                                           const long long* __restrict__ step, int guarded) {
+  if (guarded && !g_adam_go) return;   // the rollout failed: leave parameters and moments alone
   if (step) {                   // guarded form: bias corrections of the device-side step counter
     const double st = (double)step[0];
     bc1 = (float)(1.0 - pow((double)b1, st));
@@ -1493,12 +1493,15 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
-  hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
-                     (long long)n, (const int*)nullptr, 0, (long long*)nullptr);
+  // without clipping and without a norm to report there is nothing for the norm kernel to do
+  const bool need_norm = max_norm > 0.0 || norm_out_d != nullptr;
+  if (need_norm)
+    hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
+                       (long long)n, (const int*)nullptr, 0, (long long*)nullptr);
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
-                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, need_norm ? nb : 0, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr);
+                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1515,7 +1518,7 @@ extern "C" int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* gra
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f,
-                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d));
+                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1);
   HIPCHK(hipGetLastError());
   return 0;
 }
