@@ -147,6 +147,19 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
         batches = iterate_priority_tree(N, batchsize, tree, _warmup_iters)
     else:
         batches = ((ix, None, None) for ix in iterate_minibatches(N, batchsize))
+    # uniform minibatches: one host-to-device copy of the shuffled indices per epoch, not per step
+    epoch_dev = {}
+
+    def device_indices(idx_np):
+        if prioritized_sampling:
+            return torch.as_tensor(idx_np.astype(np.int32), device=dev)
+        base = idx_np.base if idx_np.base is not None else idx_np
+        hit = epoch_dev.get('base')
+        if hit is not base:
+            epoch_dev['base'] = base
+            epoch_dev['dev'] = torch.as_tensor(base.astype(np.int32), device=dev)
+        off = (idx_np.__array_interface__['data'][0] - base.__array_interface__['data'][0]) // base.itemsize
+        return epoch_dev['dev'][off:off + len(idx_np)]
     rng = range(iters + 1)       # the reference runs iters + 1 steps (`if i == iters: break` after the step)
     pbar = pbar_class(rng, total=iters) if pbar_class is not None else rng
     last = None
@@ -157,7 +170,7 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
         if st is None:
             st = steps[M] = E.BnnStep(dims, temps, rscale, dreg, M, N, reg_weight,
                                       max_log_std=float(density.max_log_std), device=dev)
-        idx = torch.as_tensor(idx_np.astype(np.int32), device=dev)
+        idx = device_indices(idx_np)
         if _replay is not None:     # tests: the reference's recorded draws of this step
             f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).reshape(-1)  # noqa: E731
             u_fixed = torch.cat([f32(a) for a in _replay['u'][i]])
