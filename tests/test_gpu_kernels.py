@@ -320,3 +320,37 @@ def test_mlp_input_gradient_matches_torch():
     ((out['sample'] * cs.to(dev)).sum() + (out['mean'] * cm.to(dev)).sum() +
      (out['log_std'] * cl.to(dev)).sum()).backward()
     assert common.rel(xg.grad.cpu().numpy(), x.grad.numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_invalid_plans_fail_cleanly():
+    """Bad configurations are usage errors with a message (negative status through the C ABI ->
+    RuntimeError on the Python side), never a crash or a silent fallback."""
+    from prob_mbrl_amd import engine as E
+    d = common.load('nomm_d4')
+    from prob_mbrl_amd import problem as PB
+    spec = PB.cartpole_reward_spec(4)
+    eng, args, _ = common.engine_from_fixture(d, torch.device('cuda:0'))
+    good = dict(B=eng.B, D=eng.D, U=eng.U, H=eng.H)
+    pol = [eng.D, 32, 32, 2 * eng.U]
+    dyn = [eng.D + eng.U, 32, 32, 2 * eng.D]
+
+    def make(**kw):
+        a = dict(good)
+        a.update(kw)
+        return E.Engine(a['B'], a['D'], a['U'], a['H'], kw.get('pol', pol), [0.9, 0.9], kw.get('dyn', dyn),
+                        [1.0, 1.0], spec, mm_states=kw.get('mm', False), mm_rewards=kw.get('mm', False),
+                        mm_groups=kw.get('groups'), device='cuda:0')
+
+    for bad in (dict(B=0), dict(H=0), dict(D=40, pol=[40, 32, 2], dyn=[41, 32, 80]),
+                dict(mm=True, groups=7),                      # B not divisible by the groups
+                dict(mm=True, groups=good['B'])):             # one row per group
+        with pytest.raises((RuntimeError, ValueError, AssertionError)):
+            make(**bad)
+    # a forward call with a missing input is refused, and the plan stays usable afterwards
+    broken = dict(args)
+    broken['z_pol'] = None
+    with pytest.raises((RuntimeError, AssertionError, AttributeError, TypeError)):
+        eng.forward(**broken)
+    S, A, R = eng.forward(**args)
+    assert torch.isfinite(S).all() and eng.valid_steps() == eng.H
