@@ -120,6 +120,10 @@ def test_groups_spanning_workgroups_match_oracle(groups):
         del os.environ['PMBRL_MM_MODE2']
     assert eng2.info['mm_mode'] == 2
     assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
+    # 32-row workgroups (two row tiles): same path, different tiling
+    eng3, S3, A3, Rw3, loss3, g3, _ = _run(d, rows_per_wg_hint=32)
+    assert eng3.info['mm_mode'] == 3 and eng3.info['rows_per_wg'] == 32
+    assert common.rel(S3, S) < 1e-6 and common.rel(g3, g) < 1e-5
 
 
 def test_wide_network_general_family_matches_oracle():
