@@ -206,13 +206,74 @@ __device__ __forceinline__ void gemm_tiles_group(const float* __restrict__ wf, i
   }
 }
 
+// The same with n_kb a multiple of 2 * PM_CK (every chunk whole) and absent tiles of the last group
+// computed as duplicates of the group's first tile and dropped: no branch inside the chunk loop
+// (the general form puts a scalar branch around every pair of MFMAs).
+template <int RT, int NT, class Epi>
+__device__ __forceinline__ void gemm_tiles_group_full(const float* __restrict__ wf, int n_kb,
+                                                      int ot0, int n_ot, const float* lds_in,
+                                                      int ld, int lane, Epi& epi) {
+  const int arow = lane & 15, g = lane >> 4;
+  const float* bbase = lds_in + arow * ld + 4 * g;
+  f32x4 acc[NT][RT];
+  const float* wp[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int ot = ot0 + k * PM_NW;
+    wp[k] = wf + ((size_t)(ot < n_ot ? ot : ot0) * n_kb) * 256 + lane * 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  FragBuf<RT, NT> f0, f1;
+  auto load = [&](FragBuf<RT, NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c)
+#pragma unroll
+      for (int k = 0; k < NT; ++k) f.a[k][c] = ldg4(wp[k] + (size_t)(kb0 + c) * 256);
+  };
+  auto compute = [&](const FragBuf<RT, NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_CK; ++c) {
+      f32x4 b[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        b[rt] = *reinterpret_cast<const f32x4*>(bbase + rt * 16 * ld + (kb0 + c) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[k][rt] = mfma4(f.a[k][c][j], b[rt][j], acc[k][rt]);
+    }
+  };
+  load(f0, 0);
+  for (int kb0 = 0; kb0 < n_kb; kb0 += 2 * PM_CK) {
+    load(f1, kb0 + PM_CK);
+    compute(f0, kb0);
+    load(f0, kb0 + 2 * PM_CK < n_kb ? kb0 + 2 * PM_CK : 0);   // past the end: a harmless re-load of chunk 0
+    compute(f1, kb0 + PM_CK);
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (ot0 + k * PM_NW < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt]);
+    }
+  }
+}
+
 template <int RT, class Epi>
 __device__ __forceinline__ void gemm_tiles(const float* __restrict__ wf, int n_ot, int n_kb,
                                            const float* lds_in, int ld, int wid, int lane,
                                            Epi& epi) {
   constexpr int NT = (RT >= 4) ? 1 : 2;
-  for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
-    gemm_tiles_group<RT, NT>(wf, n_kb, ot0, n_ot, lds_in, ld, lane, epi);
+  if (n_kb % (2 * PM_CK) == 0) {
+    for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
+      gemm_tiles_group_full<RT, NT>(wf, n_kb, ot0, n_ot, lds_in, ld, lane, epi);
+  } else {
+    for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
+      gemm_tiles_group<RT, NT>(wf, n_kb, ot0, n_ot, lds_in, ld, lane, epi);
+  }
 }
 
 // ---------------------------------------------------------------------------
