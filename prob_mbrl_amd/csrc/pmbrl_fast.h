@@ -991,6 +991,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
+  if (EXT && A.prof && blockIdx.x == 0 && threadIdx.x == 0)      // kernel entry (per-step launches: prologue cost)
+    A.prof[(size_t)T0 * 32 + 30] = (long long)__builtin_readcyclecounter();
   const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1301,6 +1303,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
+  if (EXT && A.prof && blockIdx.x == 0 && threadIdx.x == 0)      // kernel entry (per-step launches: prologue cost)
+    A.prof[(size_t)T0 * 32 + 30] = (long long)__builtin_readcyclecounter();
   const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
