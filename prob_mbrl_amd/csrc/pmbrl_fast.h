@@ -860,6 +860,7 @@ __device__ __forceinline__ FastLds pm_fast_carve_shaped(float* base, const NetDe
 #define PMASK(l) (reinterpret_cast<uint16_t*>(L.base + A.fo.pmask[l]))
 #define DMASK(l) (reinterpret_cast<uint16_t*>(L.base + A.fo.dmask[l]))
 
+__device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds& L, int tid);
 // stage launch-invariant data in LDS
 template <int RT>
 __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, int row0, int nvalid,
@@ -903,6 +904,111 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
     L.psc[i] = A.pscale[i];
     L.pbi[i] = A.pbias[i];
   }
+}
+
+// The same for a shape-specialised kernel (uniform hidden width: NT tiles, NL layers per net): every
+// trip count is a compile-time constant, every load is unconditional (clamped index), so ALL the
+// prologue's global loads are in flight together and are waited for once.  The general form above is
+// a chain of ~40 dependent memory round trips (one per short loop and conditional load): 20 us of a
+// sweep launch, paid once per iteration in the single-launch modes and once per STEP when a
+// moment-matching group spans workgroups.
+template <int RT, class SH>
+__device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, const FastLds& L, const StreamDesc& sd,
+                                                       int row0, int nvalid, int tid) {
+  constexpr int R = 16 * RT, NL = SH::NL, NT = SH::NT, D = SH::D, U = SH::U;
+  constexpr int NS = 2 * (NL - 2);                                   // streamed layers
+  constexpr int IT_B = (NT * 16 + PF_NT - 1) / PF_NT, IT_M = (R * NT + PF_NT - 1) / PF_NT;
+  constexpr int IT_T = (NT * 64 + PF_NT - 1) / PF_NT, IT_Z = (R * D + PF_NT - 1) / PF_NT;
+  static_assert(R * U <= PF_NT && D + U <= PF_NT, "one item per thread");
+  const NetDev& P = A.pol;
+  const NetDev& F = A.dyn;
+  const int nv1 = nvalid - 1;
+  float pb[NL][IT_B], db[NL][IT_B], zd[IT_Z], zp, c0, c1, c2, c3, c4, c5;
+  uint16_t pm[NL - 1][IT_M], dm[NL - 1][IT_M];
+  f32x4 tw[NS][IT_T];
+  // ---- loads (all unconditional)
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int n = (l < NL - 1 ? NT : 1) * 16;
+#pragma unroll
+    for (int it = 0; it < IT_B; ++it) {
+      const int i = min(tid + it * PF_NT, n - 1);
+      pb[l][it] = P.bias[l][i];
+      db[l][it] = F.bias[l][i];
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+    for (int it = 0; it < IT_M; ++it) {
+      const int i = min(tid + it * PF_NT, R * NT - 1);
+      const int r = i / NT, c = i - r * NT;
+      const size_t src = (size_t)(row0 + min(r, nv1)) * NT + c;
+      pm[l][it] = P.mask[l][src];
+      dm[l][it] = F.mask[l][src];
+    }
+#pragma unroll
+  for (int l = 0; l < NS; ++l)
+#pragma unroll
+    for (int it = 0; it < IT_T; ++it) {
+      const int i = min(tid + it * PF_NT, NT * 64 - 1);
+      // the tile after the streamed ones (clamped read when this layer has no K-split tile: not stored)
+      tw[l][it] = ldg4(sd.wf[l] + (size_t)sd.n_ot[l] * sd.n_kb[l] * 256 + (size_t)i * 4 * (sd.ks[l] ? 1 : 0));
+    }
+  {
+    const int i = min(tid, R * U - 1);
+    zp = A.zpol[(size_t)row0 * U + min(i, nvalid * U - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < IT_Z; ++it) {
+    const int i = min(tid + it * PF_NT, R * D - 1);
+    zd[it] = A.zdyn[(size_t)row0 * D + min(i, nvalid * D - 1)];
+  }
+  {
+    const int i = min(tid, D + U - 1), j = min(tid, D - 1), k = min(tid, U - 1);
+    c0 = A.mx[i]; c1 = A.iSx[i]; c2 = A.my[j]; c3 = A.Sy[j]; c4 = A.pscale[k]; c5 = A.pbias[k];
+  }
+  // ---- stores
+  if (tid == 0) *L.tcnt = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int n = (l < NL - 1 ? NT : 1) * 16;
+#pragma unroll
+    for (int it = 0; it < IT_B; ++it) {
+      const int i = tid + it * PF_NT;
+      if (i < n) {
+        PBIAS(l)[i] = pb[l][it];
+        DBIAS(l)[i] = db[l][it];
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+    for (int it = 0; it < IT_M; ++it) {
+      const int i = tid + it * PF_NT;
+      if (i < R * NT) {
+        const bool live = i / NT < nvalid;
+        PMASK(l)[i] = live ? pm[l][it] : (uint16_t)0;
+        DMASK(l)[i] = live ? dm[l][it] : (uint16_t)0;
+      }
+    }
+#pragma unroll
+  for (int l = 0; l < NS; ++l)
+#pragma unroll
+    for (int it = 0; it < IT_T; ++it) {
+      const int i = tid + it * PF_NT;
+      if (sd.ks[l] && i < NT * 64) *reinterpret_cast<f32x4*>(L.tw + sd.tw_off[l] + (size_t)i * 4) = tw[l][it];
+    }
+  if (tid < R * U) L.zp[tid] = (tid / U < nvalid && A.zpol_ss == 0) ? zp : 0.f;
+#pragma unroll
+  for (int it = 0; it < IT_Z; ++it) {
+    const int i = tid + it * PF_NT;
+    if (i < R * D) L.zd[i] = (i / D < nvalid && A.zdyn_ss == 0) ? zd[it] : 0.f;
+  }
+  if (tid < D + U) { L.mx[tid] = c0; L.iSx[tid] = c1; }
+  if (tid < D) { L.my[tid] = c2; L.Sy[tid] = c3; L.lSy[tid] = logf(c3); }
+  if (tid < U) { L.psc[tid] = c4; L.pbi[tid] = c5; }
 }
 
 // partial head tiles: fixed region, or the idle activation buffer (Y)
@@ -1044,8 +1150,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     x_ready = true;
   }
 
-  pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-  pm_fast_preload_tails(A.sd_fwd, L, tid);
+  if constexpr (SH::NL != 0 && SH::NT != 0) {
+    pm_fast_preload_shaped<RT, SH>(A, L, A.sd_fwd, row0, nvalid, tid);
+  } else {
+    pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+    pm_fast_preload_tails(A.sd_fwd, L, tid);
+  }
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   if (!x_ready) {
@@ -1353,8 +1463,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     g_ready = true;
   }
 
-  pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-  pm_fast_preload_tails(A.sd_bwd, L, tid);
+  if constexpr (SH::NL != 0 && SH::NT != 0) {
+    pm_fast_preload_shaped<RT, SH>(A, L, A.sd_bwd, row0, nvalid, tid);
+  } else {
+    pm_fast_preload<RT>(A, L, row0, nvalid, tid);
+    pm_fast_preload_tails(A.sd_bwd, L, tid);
+  }
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   if (!g_ready)
