@@ -112,10 +112,13 @@ __device__ __forceinline__ SdV sdv_make(const StreamDesc& sd, int lane) {
   r.v = 0;
   r.k = 0;
   const int l = lane >> 2, f = lane & 3;
-  if (l < sd.n) {
-    r.v = f == 0 ? sd.n_ot[l] : f == 1 ? sd.n_kb[l] : f == 2 ? pm_lo32(sd.wf[l]) : pm_hi32(sd.wf[l]);
-    r.k = f == 0 ? sd.ks[l] : f == 1 ? sd.tw_off[l] : f == 2 ? sd.n_kb_real[l] : 0;
-  }
+  // lane >> 2 < 2 * PM_MAXL: all loads in bounds, issued together, selected afterwards
+  const int n_ot = sd.n_ot[l], n_kb = sd.n_kb[l], ks = sd.ks[l], tw = sd.tw_off[l], kr = sd.n_kb_real[l];
+  const uint64_t wf = (uint64_t)sd.wf[l];
+  const int v = f == 0 ? n_ot : f == 1 ? n_kb : f == 2 ? (int)(uint32_t)wf : (int)(uint32_t)(wf >> 32);
+  const int k = f == 0 ? ks : f == 1 ? tw : f == 2 ? kr : 0;
+  r.v = l < sd.n ? v : 0;
+  r.k = l < sd.n ? k : 0;
   return r;
 }
 
@@ -362,9 +365,10 @@ template <int RT>
 __device__ __forceinline__ void res0_load(Res0<RT>& r, const float* wf, int n_ot, int wid, int lane) {
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
-    const int ot = wid + i * PF_NW;
-    r.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ot < n_ot) r.w[i] = ldg4(wf + (size_t)ot * 256 + lane * 4);
+    // unconditional load of a clamped tile, zeroed afterwards: the prologue's loads stay in one batch
+    const int ot = wid + i * PF_NW, otc = ot < n_ot ? ot : n_ot - 1;
+    const f32x4 v = ldg4(wf + (size_t)otc * 256 + lane * 4);
+    r.w[i] = ot < n_ot ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 template <int RT, class Epi>
@@ -427,9 +431,9 @@ struct HeadW {
 __device__ __forceinline__ void head_load(HeadW& h, const float* wf, int n_kb, int wid, int lane) {
 #pragma unroll
   for (int i = 0; i < PM_HKB; ++i) {
-    const int kb = wid * PM_HKB + i;
-    h.w[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (kb < n_kb) h.w[i] = ldg4(wf + (size_t)kb * 256 + lane * 4);
+    const int kb = wid * PM_HKB + i, kbc = kb < n_kb ? kb : n_kb - 1;
+    const f32x4 v = ldg4(wf + (size_t)kbc * 256 + lane * 4);
+    h.w[i] = kb < n_kb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 template <int RT>
@@ -1195,20 +1199,20 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // net tables: lane 8*l + {0: nt[l+1], 1: bias offset, 2: mask offset, 3/4: abits, 5: 1/keep, 6/7: stash}
   int vdp = 0, vdd = 0;
   {
-    const int l = lane >> 3, f = lane & 7;
-    if (l < P.nl) {
-      const bool hid = l < P.nl - 1;
-      vdp = f == 0 ? P.nt[l + 1] : f == 1 ? A.fo.pbias[l] : f == 2 ? (hid ? A.fo.pmask[l] : 0)
-          : f == 3 ? (hid ? pm_lo32(P.abits[l]) : 0) : f == 4 ? (hid ? pm_hi32(P.abits[l]) : 0)
-          : f == 5 ? __float_as_int(P.inv_keep[l]) : f == 6 ? (hid ? pm_lo32(A.actT[l + 1]) : 0)
-          : (hid ? pm_hi32(A.actT[l + 1]) : 0);
-    }
-    if (l < F.nl) {
-      const bool hid = l < F.nl - 1;
-      vdd = f == 0 ? F.nt[l + 1] : f == 1 ? A.fo.dbias[l] : f == 2 ? (hid ? A.fo.dmask[l] : 0)
-          : f == 3 ? (hid ? pm_lo32(F.abits[l]) : 0) : f == 4 ? (hid ? pm_hi32(F.abits[l]) : 0)
-          : f == 5 ? __float_as_int(F.inv_keep[l]) : 0;
-    }
+    // every table entry is loaded unconditionally (lane >> 3 < PM_MAXL keeps the indices in the
+    // argument arrays) and selected afterwards: one round trip to the kernel arguments, not one per field
+    const int l = lane >> 3, f = lane & 7, l1 = l + 1 < PM_MAXL ? l + 1 : PM_MAXL - 1;
+    const int p_nt = P.nt[l + 1], p_b = A.fo.pbias[l], p_m = A.fo.pmask[l], p_ik = __float_as_int(P.inv_keep[l]);
+    const int d_nt = F.nt[l + 1], d_b = A.fo.dbias[l], d_m = A.fo.dmask[l], d_ik = __float_as_int(F.inv_keep[l]);
+    const uint64_t p_ab = (uint64_t)P.abits[l], d_ab = (uint64_t)F.abits[l], p_at = (uint64_t)A.actT[l1];
+    const bool phid = l < P.nl - 1, dhid = l < F.nl - 1;
+    const int p64 = f == 3 ? (int)(uint32_t)p_ab : f == 4 ? (int)(uint32_t)(p_ab >> 32)
+                  : f == 6 ? (int)(uint32_t)p_at : (int)(uint32_t)(p_at >> 32);
+    const int pv = f == 0 ? p_nt : f == 1 ? p_b : f == 5 ? p_ik : (phid ? (f == 2 ? p_m : p64) : 0);
+    vdp = l < P.nl ? pv : 0;
+    const int d64 = f == 3 ? (int)(uint32_t)d_ab : (int)(uint32_t)(d_ab >> 32);
+    const int dv = f == 0 ? d_nt : f == 1 ? d_b : f == 5 ? d_ik : f >= 6 ? 0 : (dhid ? (f == 2 ? d_m : d64) : 0);
+    vdd = l < F.nl ? dv : 0;
   }
   auto pol_epi = [&](int l, int t, size_t blk, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * l);
@@ -1561,13 +1565,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // net tables: lane 8*idx + {0: nt[idx+1], 1/2: abits, 3: 1/keep, 4/5: G stash} of hidden layer idx
   int vdp = 0, vdd = 0;
   {
+    // loaded unconditionally, selected afterwards (one round trip to the kernel arguments)
     const int l = lane >> 3, f = lane & 7;
-    if (l < P.nl - 1)
-      vdp = f == 0 ? P.nt[l + 1] : f == 1 ? pm_lo32(P.abits[l]) : f == 2 ? pm_hi32(P.abits[l])
-          : f == 3 ? __float_as_int(P.inv_keep[l]) : f == 4 ? pm_lo32(A.gT[l]) : f == 5 ? pm_hi32(A.gT[l]) : 0;
-    if (l < F.nl - 1)
-      vdd = f == 0 ? F.nt[l + 1] : f == 1 ? pm_lo32(F.abits[l]) : f == 2 ? pm_hi32(F.abits[l])
-          : f == 3 ? __float_as_int(F.inv_keep[l]) : 0;
+    const int p_nt = P.nt[l + 1], p_ik = __float_as_int(P.inv_keep[l]);
+    const int d_nt = F.nt[l + 1], d_ik = __float_as_int(F.inv_keep[l]);
+    const uint64_t p_ab = (uint64_t)P.abits[l], d_ab = (uint64_t)F.abits[l], p_g = (uint64_t)A.gT[l];
+    const int pv = f == 0 ? p_nt : f == 1 ? (int)(uint32_t)p_ab : f == 2 ? (int)(uint32_t)(p_ab >> 32) : f == 3 ? p_ik
+                 : f == 4 ? (int)(uint32_t)p_g : f == 5 ? (int)(uint32_t)(p_g >> 32) : 0;
+    const int dv = f == 0 ? d_nt : f == 1 ? (int)(uint32_t)d_ab : f == 2 ? (int)(uint32_t)(d_ab >> 32) : f == 3 ? d_ik : 0;
+    vdp = l < P.nl - 1 ? pv : 0;
+    vdd = l < F.nl - 1 ? dv : 0;
   }
   // epilogue of the adjoint GEMM whose output carries the activation pattern of layer idx
   auto dyn_epi = [&](int idx, int t, float* out) {
