@@ -204,7 +204,7 @@ def main():
                                   'RCCL all-reduce + ' if world > 1 else ''),
                         rows_per_gpu=B, global_rows=Bg, horizon=H, parallelism='dp%d' % world,
                         rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
-                        mm_mode=eng.info['mm_mode'], **({'debug_one_device': True} if a.one_device else {})),
+                        mm_mode=eng.info['mm_mode'], mm_grid=eng.info.get('mm_grid', 0), **({'debug_one_device': True} if a.one_device else {})),
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},

@@ -319,7 +319,8 @@ struct pmbrl_plan {
   int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
-      off_gxc, off_gxc2, off_grt, off_Jx, off_Ja, ws_bytes;
+      off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, ws_bytes;
+  int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -384,7 +385,10 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 6, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
-  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)
+  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 4, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 5, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 6, 1, 216, 3, 13)
 
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
@@ -397,6 +401,12 @@ static int set_attr_fast(size_t lds) {
       reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM>)};
   for (const void* f : fns)
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if constexpr (RT == 1) {     // the one-launch form of mm_mode 3 exists for 16-row workgroups
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MMG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MMG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                          \
   if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
     HIPCHK(hipFuncSetAttribute(                                                                          \
@@ -597,6 +607,14 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   { const StagePair sp = stages_for(p->RT); p->CA = sp.ca; p->CB = sp.cb; }
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
   p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
+  // groups spanning workgroups, every workgroup resident at once (one per CU always fits): the
+  // per-step launches become one launch whose workgroups meet at a device-wide barrier per step
+  p->mm_grid = 0;
+  if (p->mm_mode == 3 && p->RT == 1 && !getenv("PMBRL_MM_PERSTEP")) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && p->nwg <= cus)
+      p->mm_grid = 1;
+  }
 
   HIPCHK(hipSetDevice(device));
   // reward constants
@@ -695,6 +713,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
     p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
+    p->off_gsync = take(64);   // arrival counters of the device-wide barriers (forward, backward)
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     p->off_part = take((size_t)p->dw_nsplit * ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
@@ -783,6 +802,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[9] = p->n_dw_blocks;
   info[10] = p->fast;
   info[11] = p->CA * 16 + p->CB;
+  info[12] = p->mm_grid;
   return 0;
 }
 
@@ -855,6 +875,9 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.Jx = reinterpret_cast<float*>(ws + p->off_Jx);
   A.Ja = reinterpret_cast<float*>(ws + p->off_Ja);
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
+  A.mm_grid = p->mm_grid;
+  A.gsync = reinterpret_cast<unsigned*>(ws + p->off_gsync);
+  A.gx_carry_out = nullptr;
   if (p->fast) {
     // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
     const NetDev& P = A.pol;
@@ -931,7 +954,8 @@ static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
   const bool mm = A.mm_mode == 1 || A.mm_mode == 3;   // moment matching inside the sweep launches
   const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
                    (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
-  const int var = mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
+  const bool mmg = RT == 1 && A.mm_mode == 3 && A.mm_grid;
+  const int var = mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
   const dim3 g(p->nwg), b(PF_NT);
   // a shape-specialised instantiation if there is one for this plan
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
@@ -950,6 +974,13 @@ static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
   }
 #undef PM_FAST_SHAPED
 #define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
+  if constexpr (RT == 1) {
+    if (mmg) {
+      if (fwd) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MMG);
+      else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MMG);
+      return;
+    }
+  }
   if (fwd) {
     if (mm) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);
     else if (ext) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_EXT);
@@ -1010,7 +1041,12 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   {
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
-  if (p->mm_mode == 3) {
+  if (p->mm_mode == 3 && p->mm_grid) {
+    // one launch; the workgroups meet after every step and moment-match the sampled states (x_H included)
+    HIPCHK(hipMemsetAsync(A.gsync, 0, sizeof(unsigned), s));
+    A.t0 = 0; A.t1 = p->cfg.H;
+    launch_fwd_rt(p, A, s);
+  } else if (p->mm_mode == 3) {
     // one launch per step; step t's launch first moment-matches the states sampled by step t-1
     for (int t = 0; t < p->cfg.H; ++t) {
       A.t0 = t; A.t1 = t + 1;
@@ -1086,6 +1122,13 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     HIPCHK(hipMemsetAsync(cbuf[0], 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
     A.gx_from_carry = 1;
     int k = 0;
+    if (p->mm_grid) {
+      A.gsync += 1;
+      HIPCHK(hipMemsetAsync(A.gsync, 0, sizeof(unsigned), s));
+      A.gx_carry_out = cbuf[1];
+      A.t0 = 0; A.t1 = p->cfg.H;
+      launch_bwd_rt(p, A, s);
+    } else
     for (int t = p->cfg.H - 1; t >= 0; --t, k ^= 1) {
       A.gx_carry = cbuf[k];           // dL/dx_{t+1}, all rows (read by every workgroup of the group)
       A.gx_carry_out = cbuf[k ^ 1];   // dL/dx_t of this workgroup's rows

@@ -99,6 +99,10 @@ struct RolloutArgs {
   // backward only
   const float *grad_rewards, *grad_states, *grad_actions;
   float* gx_carry_out;   // mm_mode 3: the carried gradient is written here (ping-pong with gx_carry)
+  // mm_mode 3 with every workgroup resident at once: ONE launch over the horizon, the workgroups
+  // meet at a device-wide barrier (arrival counter gsync) where the per-step launches ended
+  int mm_grid;
+  unsigned* gsync;
   float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
   int gx_from_carry;
   long long zpol_ss, zdyn_ss;   // per-step strides of z_pol / z_dyn (0 = frozen)

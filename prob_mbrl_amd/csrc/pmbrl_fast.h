@@ -101,6 +101,31 @@ __device__ __forceinline__ int pm_lo32(const void* p) { return (int)(unsigned)(r
 __device__ __forceinline__ int pm_hi32(const void* p) { return (int)(unsigned)(reinterpret_cast<unsigned long long>(p) >> 32); }
 
 // weight-stream table: lane 4*l + {0: n_ot, 1: n_kb, 2/3: wf lo/hi} of streamed layer l (<= 16)
+// Device-wide barrier of a launch whose workgroups are all resident (the host checks that):
+// every thread publishes its global writes, one thread per workgroup arrives on the counter and
+// waits for the others, every wave then drops what its caches may hold of the others' rows.
+// `target` = arrivals expected so far (monotonic: barrier k of a launch waits for k * nwg).  A
+// wait that does not end (it cannot, unless the residency assumption was broken) gives up after
+// ~1 s and reports through the status word instead of hanging the device.
+__device__ __forceinline__ bool pm_grid_barrier(unsigned* ctr, unsigned target) {
+  bool ok = true;
+  // the barrier waits for every wave's stores (they are in L2 then); ONE thread per workgroup then
+  // writes the L2 back / invalidates (cache maintenance is per CU and per L2, not per wave: a fence
+  // by all 8 waves of 150+ workgroups serialises hundreds of L2 walks per barrier)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    long long spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1ll << 20)) { ok = false; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return ok;
+}
+
 struct SdV {
   int n, v;
   int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l
@@ -1084,6 +1109,7 @@ typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
 #define PF_VAR_LEAN 0
 #define PF_VAR_EXT 1
 #define PF_VAR_MM 2
+#define PF_VAR_MMG 3   // mm_mode 3 as ONE launch: the workgroups meet at a device-wide barrier every step
 #define PF_MARK(slot)                                                                              \
   do {                                                                                             \
     if (EXT && A.prof && wg == 0 && tid == 0)                                                      \
@@ -1093,7 +1119,7 @@ typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
 template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  constexpr bool MMG = VAR == PF_VAR_MMG, MM = VAR == PF_VAR_MM || MMG, EXT = VAR != PF_VAR_LEAN;
   // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
   constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
@@ -1108,7 +1134,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
-  const int rows_per_wg = (VAR == PF_VAR_MM) ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
+  const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
   const int row0 = wg * rows_per_wg;
   const int nvalid = min(rows_per_wg, A.B - row0);
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
@@ -1124,8 +1150,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // in HBM (the previous launch wrote them), 8 waves sharing the row sums.  No separate kernel
   // launch per step, and the work hides behind the rest of the prologue's memory traffic.
   bool x_ready = false;
-  if (MM && A.mm_mode == 3 && mm_states && T0 > 0) {
-    const int tp = T0 - 1;
+  const bool mm_gs = MMG && mm_states;   // one launch, device-wide barrier per step
+  auto mm_span_fwd = [&](int tp) {
     const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
     double* part = reinterpret_cast<double*>(L.bufA);          // the activation buffers are still free
     const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
@@ -1150,7 +1176,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     }
     for (int i = nvalid * D + tid; i < R * D; i += PF_NT) xa[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < nvalid * D; i += PF_NT) A.states[((size_t)T0 * B + row0) * D + i] = xa[i];
+    for (int i = tid; i < nvalid * D; i += PF_NT) A.states[((size_t)(tp + 1) * B + row0) * D + i] = xa[i];
+  };
+  if (VAR == PF_VAR_MM && A.mm_mode == 3 && mm_states && T0 > 0) {
+    mm_span_fwd(T0 - 1);
     x_ready = true;
   }
 
@@ -1191,7 +1220,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     cur_advance<CA, SC>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
-  const bool mm_in = MM && A.mm_mode == 1 && mm_states;
+  const bool mm_in = VAR == PF_VAR_MM && A.mm_mode == 1 && mm_states;
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
   // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
@@ -1345,7 +1374,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       const float* hb = dyn_head_bias;
       const float* hp = PM_HP();
       // (not when the partial tiles sit in bufA: the feed below writes there)
-      const bool feed = !mm_in && (t + 1 < T1) && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
+      const bool feed = !mm_in && !mm_gs && (t + 1 < T1) && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
       fed = feed;
       float* stn = A.actT[0] + (blk + A.nwg) * (size_t)16 * (16 * RT);
       for (int i = tid; i < R * 16; i += PF_NT) {
@@ -1395,6 +1424,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       __syncthreads();
       for (int i = tid; i < nvalid * D; i += PF_NT)
         A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
+    } else if (mm_gs) {
+      // every workgroup's sampled rows of this step are in A.xt once all have passed the barrier
+      if (!pm_grid_barrier(A.gsync, (unsigned)(t - T0 + 1) * gridDim.x) && tid == 0) atomicMin(A.status, t);
+      mm_span_fwd(t);
+      // the row sums went through the activation buffers: restore their zero K padding
+      for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;
     } else {
       float* tmp = xa; xa = xb; xb = tmp;
     }
@@ -1409,7 +1444,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr bool MM = VAR == PF_VAR_MM, EXT = VAR != PF_VAR_LEAN;
+  constexpr bool MMG = VAR == PF_VAR_MMG, MM = VAR == PF_VAR_MM || MMG, EXT = VAR != PF_VAR_LEAN;
   // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
   constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
@@ -1424,7 +1459,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
-  const int rows_per_wg = (VAR == PF_VAR_MM) ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
+  const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
   const int row0 = wg * rows_per_wg;
   const int nvalid = min(rows_per_wg, A.B - row0);
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
@@ -1439,15 +1474,15 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // mm_mode 3: adjoint of the moment matching that produced x_{t+1} (t = this launch's step), per
   // workgroup for its own rows, from the whole group's carried gradient -- see the forward kernel
   bool g_ready = false;
-  if (MM && A.mm_mode == 3 && mms) {
-    const int tp = T0;
+  const bool mm_gs = MMG && mms;   // one launch, device-wide barrier per step
+  auto mm_span_bwd = [&](int tp, const float* carry) {
     const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
     double* part = reinterpret_cast<double*>(L.bufA);
     const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
     for (int gi = g_lo; gi <= g_hi; ++gi) {
       const int gr0 = gi * A.M;
       const float* sp = A.xt + ((size_t)tp * B + gr0) * D;
-      const float* gin = A.gx_carry + (size_t)gr0 * D;
+      const float* gin = carry + (size_t)gr0 * D;
       const int zrow0 = pm_zrow0(tp, A.row_off + gr0, A.flags);
       const int m_lo = max(row0, gr0) - gr0, m_hi = min(row0 + nvalid, gr0 + A.M) - gr0;
       const int o_lo = wid == 0 ? m_lo : 0, o_hi = wid == 0 ? m_hi : 0;
@@ -1464,6 +1499,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     }
     for (int i = nvalid * D + tid; i < R * D; i += PF_NT) gx[i] = 0.f;
     __syncthreads();
+  };
+  if (VAR == PF_VAR_MM && A.mm_mode == 3 && mms) {
+    mm_span_bwd(T0, A.gx_carry);
     g_ready = true;
   }
 
@@ -1558,7 +1596,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     L.bufA[r * LD + k] = v;
     if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
   };
-  const bool mm_in = MM && (A.mm_mode == 1 && mms);
+  const bool mm_in = VAR == PF_VAR_MM && (A.mm_mode == 1 && mms);
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
@@ -1604,6 +1642,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
 #pragma unroll
     for (int u = 0; u < PFV; ++u)
       pfv[u] = (t > T0 && pf_base[u]) ? pf_base[u][(size_t)(t - 1) * pf_str[u]] : 0.f;
+    if (mm_gs) {
+      // dL/dx_{t+1} of every row of the group is needed: own rows -> HBM, meet the other workgroups,
+      // then the adjoint of the moment matching that produced x_{t+1}.  The two carry buffers
+      // alternate (a workgroup may write step t-1's rows while another still reads step t's).
+      float* carry = ((T1 - 1 - t) & 1) ? A.gx_carry_out : A.gx_carry;
+      __syncthreads();
+      for (int i = tid; i < nvalid * D; i += PF_NT) carry[(size_t)row0 * D + i] = gx[i];
+      if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t) * gridDim.x) && tid == 0) atomicMin(A.status, t);
+      mm_span_bwd(t, carry);
+      for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // restore the zero K padding
+    }
     if (mm_in) {
       // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
       const float* xsrc = A.xt + (size_t)t * B * D;
@@ -1744,7 +1793,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     {
       const float* hp = PM_HP();
       // phase A of step t-1 writes bufA: not while the partial tiles sit there
-      const bool do_pa = !mm_in && t > T0 && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
+      const bool do_pa = !mm_in && !mm_gs && t > T0 && !(RT >= 4 && L.hp_off < 0 && xsel == 1);
       pa_done = do_pa;
       if (do_pa) gsel ^= 1;
       float* gxn_next = L.jx + (gsel ? xb_off : 0);
@@ -1764,10 +1813,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     PF_MARK(23);
     // (no closing barrier: the next step's first phase opens with one)
   }
+  // nothing of the weight stream is outstanding here (its last chunk was consumed by the last
+  // layer); stated for tools/check_inflight.py, which cannot know the loop ran at least once
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int i = tid; i < nvalid * D; i += PF_NT) {
     const size_t o = (size_t)row0 * D + i;
-    if (EXT && A.gx_carry) (A.gx_carry_out ? A.gx_carry_out : A.gx_carry)[o] = gx[i];
+    if (EXT && A.gx_carry && !mm_gs) (A.gx_carry_out ? A.gx_carry_out : A.gx_carry)[o] = gx[i];
     if (T0 == 0 && A.grad_x0) A.grad_x0[o] = gx[i];
   }
 }

@@ -294,7 +294,7 @@ class Engine:
         self.info = dict(rows_per_wg=info[0], n_wg=info[1], row_tiles=info[2],
                          lds_bytes=info[3], n_pol_params=info[4], n_dyn_params=info[5],
                          dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9],
-                         fast=info[10], stages=(info[11] >> 4, info[11] & 15))
+                         fast=info[10], stages=(info[11] >> 4, info[11] & 15), mm_grid=info[12])
         self.n_pol_params = info[4]
         self.n_dyn_params = info[5]
         ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)

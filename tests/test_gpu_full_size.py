@@ -97,7 +97,7 @@ def test_rows_are_independent():
 @pytest.mark.parametrize('groups', [25, 0], ids=['100-row groups', 'one 2500-row group'])
 def test_groups_spanning_workgroups_match_oracle(groups):
     """Moment-matching groups larger than a workgroup's 16 rows (mm_mode 3: the statistics are
-    recomputed by every workgroup in the prologue of its per-step launch).  100-row groups straddle
+    recomputed by every workgroup after a device-wide barrier, or in the prologue of per-step launches).  100-row groups straddle
     workgroup boundaries (100 is not a multiple of 16); mm_groups=None is the reference examples'
     default.  Against the fp64 oracle, and against the separate-kernel path (mm_mode 2)."""
     import os
@@ -105,7 +105,8 @@ def test_groups_spanning_workgroups_match_oracle(groups):
     d = _problem('cartpole_mm', 12)
     d['mm_groups'] = np.asarray(groups)
     eng, S, A, Rw, loss, g, _ = _run(d)
-    assert eng.info['mm_mode'] == 3 and eng.info['rows_per_wg'] == 16
+    # every workgroup is resident at once here: ONE launch per sweep, a device-wide barrier per step
+    assert eng.info['mm_mode'] == 3 and eng.info['rows_per_wg'] == 16 and eng.info['mm_grid'] == 1
     x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
     torch.set_num_threads(8)
     l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,
@@ -120,6 +121,15 @@ def test_groups_spanning_workgroups_match_oracle(groups):
         del os.environ['PMBRL_MM_MODE2']
     assert eng2.info['mm_mode'] == 2
     assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
+    # the per-step-launch form of the same path (what runs when the workgroups outnumber the CUs):
+    # same arithmetic in the same order, so the same bits
+    os.environ['PMBRL_MM_PERSTEP'] = '1'
+    try:
+        eng4, S4, A4, Rw4, loss4, g4, _ = _run(d)
+    finally:
+        del os.environ['PMBRL_MM_PERSTEP']
+    assert eng4.info['mm_mode'] == 3 and eng4.info['mm_grid'] == 0
+    assert np.array_equal(S4, S) and np.array_equal(g4, g)
     # 32-row workgroups (two row tiles): same path, different tiling
     eng3, S3, A3, Rw3, loss3, g3, _ = _run(d, rows_per_wg_hint=32)
     assert eng3.info['mm_mode'] == 3 and eng3.info['rows_per_wg'] == 32
