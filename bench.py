@@ -187,7 +187,7 @@ def main():
         # only valid for the configuration they were collected on
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01f_pmc_traffic.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_traffic.json')))
             if a.config == 'cartpole_nomm' and world == 1 and kname in pmc['kernels']:
                 traffic = pmc['kernels'][kname]['hbm_bytes_per_launch']
         except Exception:
