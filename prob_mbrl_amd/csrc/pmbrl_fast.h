@@ -101,26 +101,29 @@ __device__ __forceinline__ int pm_lo32(const void* p) { return (int)(unsigned)(r
 __device__ __forceinline__ int pm_hi32(const void* p) { return (int)(unsigned)(reinterpret_cast<unsigned long long>(p) >> 32); }
 
 // weight-stream table: lane 4*l + {0: n_ot, 1: n_kb, 2/3: wf lo/hi} of streamed layer l (<= 16)
-// Device-wide barrier of a launch whose workgroups are all resident (the host checks that):
-// every thread publishes its global writes, one thread per workgroup arrives on the counter and
-// waits for the others, every wave then drops what its caches may hold of the others' rows.
+// Device-wide barrier of a launch whose workgroups are all resident (the host checks that).  The
+// rows the workgroups exchange are written with device-scope stores (pm_st_dev: write-through to
+// the coherence point) and read with device-scope loads (pm_ldc<true>), so the barrier needs no
+// cache maintenance: a release / acquire pair would write back and invalidate a whole L2 per
+// workgroup and step (measured: 15+ us per barrier with 157 workgroups, against ~3 us).  Every
+// thread waits for its own stores, one thread per workgroup arrives on the counter and polls it.
 // `target` = arrivals expected so far (monotonic: barrier k of a launch waits for k * nwg).  A
 // wait that does not end (it cannot, unless the residency assumption was broken) gives up after
 // ~1 s and reports through the status word instead of hanging the device.
+__device__ __forceinline__ void pm_st_dev(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool pm_grid_barrier(unsigned* ctr, unsigned target) {
   bool ok = true;
-  // the barrier waits for every wave's stores (they are in L2 then); ONE thread per workgroup then
-  // writes the L2 back / invalidates (cache maintenance is per CU and per L2, not per wave: a fence
-  // by all 8 waves of 150+ workgroups serialises hundreds of L2 walks per barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long long spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1ll << 20)) { ok = false; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   return ok;
@@ -1151,7 +1154,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // launch per step, and the work hides behind the rest of the prologue's memory traffic.
   bool x_ready = false;
   const bool mm_gs = MMG && mm_states;   // one launch, device-wide barrier per step
-  auto mm_span_fwd = [&](int tp) {
+  auto mm_span_fwd = [&](int tp, auto coh) {
+    constexpr bool COH = decltype(coh)::value;   // the rows come from other workgroups of this launch
     const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
     double* part = reinterpret_cast<double*>(L.bufA);          // the activation buffers are still free
     const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
@@ -1162,7 +1166,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       const int m_lo = max(row0, gr0) - gr0, m_hi = min(row0 + nvalid, gr0 + A.M) - gr0;
       const int o_lo = wid == 0 ? m_lo : 0, o_hi = wid == 0 ? m_hi : 0;   // wave 0 writes this workgroup's rows
       bool ok = true;
-#define PM_CALL(DD) ok = pm_mm_fwd_rows<DD>(sp, D, A.M, zmm, D, zrow0, A.Bg, xa, D, o_lo, o_hi, row0 - gr0, L.mm, \
+#define PM_CALL(DD) ok = pm_mm_fwd_rows<DD, COH>(sp, D, A.M, zmm, D, zrow0, A.Bg, xa, D, o_lo, o_hi, row0 - gr0, L.mm, \
                                             part, PF_NW, wid, lane)
       switch (D) {
         case 4: PM_CALL(4); break;
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     for (int i = tid; i < nvalid * D; i += PF_NT) A.states[((size_t)(tp + 1) * B + row0) * D + i] = xa[i];
   };
   if (VAR == PF_VAR_MM && A.mm_mode == 3 && mm_states && T0 > 0) {
-    mm_span_fwd(T0 - 1);
+    mm_span_fwd(T0 - 1, std::false_type{});
     x_ready = true;
   }
 
@@ -1394,7 +1398,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           if (r < nvalid) {
             const size_t o = ((size_t)t * B + row0 + r) * D + d;
             A.Td[o] = z * e * (1.f - sg);
-            if (mm_states) A.xt[o] = xn;
+            if (mm_gs) pm_st_dev(A.xt + o, xn);        // read by the other workgroups after the barrier
+            else if (mm_states) A.xt[o] = xn;
             else A.states[o + (size_t)B * D] = xn;
           }
         }
@@ -1427,7 +1432,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     } else if (mm_gs) {
       // every workgroup's sampled rows of this step are in A.xt once all have passed the barrier
       if (!pm_grid_barrier(A.gsync, (unsigned)(t - T0 + 1) * gridDim.x) && tid == 0) atomicMin(A.status, t);
-      mm_span_fwd(t);
+      mm_span_fwd(t, std::true_type{});
       // the row sums went through the activation buffers: restore their zero K padding
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;
     } else {
@@ -1475,7 +1480,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // workgroup for its own rows, from the whole group's carried gradient -- see the forward kernel
   bool g_ready = false;
   const bool mm_gs = MMG && mms;   // one launch, device-wide barrier per step
-  auto mm_span_bwd = [&](int tp, const float* carry) {
+  auto mm_span_bwd = [&](int tp, const float* carry, auto coh) {
+    constexpr bool COH = decltype(coh)::value;   // the carried gradient comes from other workgroups of this launch
     const float* zmm = pm_zbase(A.zmm, D, tp, A.Bg, A.flags);
     double* part = reinterpret_cast<double*>(L.bufA);
     const int g_lo = row0 / A.M, g_hi = (row0 + nvalid - 1) / A.M;
@@ -1486,7 +1492,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       const int zrow0 = pm_zrow0(tp, A.row_off + gr0, A.flags);
       const int m_lo = max(row0, gr0) - gr0, m_hi = min(row0 + nvalid, gr0 + A.M) - gr0;
       const int o_lo = wid == 0 ? m_lo : 0, o_hi = wid == 0 ? m_hi : 0;
-#define PM_CALL(DD) pm_mm_bwd_rows<DD>(sp, D, A.M, zmm, D, zrow0, A.Bg, gin, D, gx, D, o_lo, o_hi, row0 - gr0, L.mm, \
+#define PM_CALL(DD) pm_mm_bwd_rows<DD, COH>(sp, D, A.M, zmm, D, zrow0, A.Bg, gin, D, gx, D, o_lo, o_hi, row0 - gr0, L.mm, \
                                        part, PF_NW, wid, lane)
       switch (D) {
         case 4: PM_CALL(4); break;
@@ -1501,7 +1507,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     __syncthreads();
   };
   if (VAR == PF_VAR_MM && A.mm_mode == 3 && mms) {
-    mm_span_bwd(T0, A.gx_carry);
+    mm_span_bwd(T0, A.gx_carry, std::false_type{});
     g_ready = true;
   }
 
@@ -1648,9 +1654,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       // alternate (a workgroup may write step t-1's rows while another still reads step t's).
       float* carry = ((T1 - 1 - t) & 1) ? A.gx_carry_out : A.gx_carry;
       __syncthreads();
-      for (int i = tid; i < nvalid * D; i += PF_NT) carry[(size_t)row0 * D + i] = gx[i];
+      for (int i = tid; i < nvalid * D; i += PF_NT) pm_st_dev(carry + (size_t)row0 * D + i, gx[i]);
       if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t) * gridDim.x) && tid == 0) atomicMin(A.status, t);
-      mm_span_bwd(t, carry);
+      mm_span_bwd(t, carry, std::true_type{});
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // restore the zero K padding
     }
     if (mm_in) {

@@ -299,15 +299,22 @@ __device__ __forceinline__ double pm_sel(const double (&v)[N], int idx) {
   return o;
 }
 
+// COH: the rows were written by OTHER workgroups of this launch (device-wide barrier form of the
+// sweeps): read them with device-scope loads, which do not hit this XCD's possibly stale L2 / L1 lines
+template <bool COH>
+__device__ __forceinline__ float pm_ldc(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
 // Gram tile of X = [s - ref | 1 | z] over rows [r_lo, r_hi) of the group (ref: the group's first row)
-template <int DD>
+template <int DD, bool COH = false>
 __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, const float* z, int z_ld,
                                                     int zrow0, int Bg, int r_lo, int r_hi, int lane) {
   static_assert(2 * DD + 1 <= 16, "the Gram tile holds 2d+1 columns");
   const int g = lane >> 4, c = lane & 15;
   const int cs = c < DD ? c : 0;
   const int cz = (c > DD && c <= 2 * DD) ? c - DD - 1 : 0;
-  const double ref = (double)s[cs];
+  const double ref = (double)pm_ldc<COH>(s + cs);
   pm_f64x4 G = {0.0, 0.0, 0.0, 0.0};
   if (r_hi <= r_lo) return G;
   // rows r_lo + g, + 4, ...: the cyclic noise row advances with them (one modulo up front, then
@@ -317,7 +324,7 @@ __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, co
 #pragma unroll 8
   for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
     const int r = r0 + g, rr = r < r_hi ? r : r_hi - 1;
-    const double sv = (double)s[(size_t)rr * s_ld + cs] - ref;
+    const double sv = (double)pm_ldc<COH>(s + (size_t)rr * s_ld + cs) - ref;
     const double zv = (double)z[(size_t)zr * z_ld + cz];
     double x = c < DD ? sv : (c == DD ? 1.0 : (c <= 2 * DD ? zv : 0.0));
     if (r >= r_hi) x = 0.0;
@@ -331,7 +338,7 @@ __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, co
 }
 
 // means / standardisation / Cholesky factor from the group's Gram tile -> q (LDS scratch of this wave)
-template <int DD>
+template <int DD, bool COH = false>
 __device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const float* s, const MMScratch& q,
                                                        int lane) {
   constexpr int NR = (DD + 3) / 4;             // accumulator registers that hold covariance rows
@@ -403,7 +410,7 @@ __device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const 
     if (i < DD && c < DD) q.Lm[i * DD + c] = A[r];
   }
   if (lane < DD) {
-    q.mean[lane] = pm_sel(sm, lane) + (double)s[lane];
+    q.mean[lane] = pm_sel(sm, lane) + (double)pm_ldc<COH>(s + lane);
     q.zmean[lane] = pm_sel(zm, lane);
     q.zistd[lane] = pm_sel(zi, lane);
   }
@@ -543,17 +550,17 @@ __device__ __forceinline__ void pm_mm_slice(int M, int nw, int wid, int& r_lo, i
   r_hi = min(M, r_lo + per);
 }
 // Rows [o_lo, o_hi) of the group are written by THIS wave, to out[(r - o_shift) * out_ld + j].
-template <int DD>
+template <int DD, bool COH = false>
 __device__ __forceinline__ bool pm_mm_fwd_rows(const float* s, int s_ld, int M, const float* z, int z_ld,
                                                int zrow0, int Bg, float* out, int out_ld, int o_lo, int o_hi,
                                                int o_shift, double* scr, double* part, int nw, int wid,
                                                int lane) {
   int r_lo, r_hi;
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
-  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
+  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD, COH>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
                                      nw, wid, lane);
   const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
-  const bool ok = pm_mm_factor_from_gram<DD>(G, M, s, q, lane);
+  const bool ok = pm_mm_factor_from_gram<DD, COH>(G, M, s, q, lane);
   for (int e = o_lo * DD + lane; e < o_hi * DD; e += 64) {
     const int r = e / DD, j = e - r * DD;
     double acc = q.mean[j];
@@ -572,7 +579,7 @@ __device__ __forceinline__ bool pm_mm_fwd_mw(const float* s, int s_ld, int M, co
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
   return pm_mm_fwd_rows<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, r_lo, r_hi, 0, scr, part, nw, wid, lane);
 }
-template <int DD>
+template <int DD, bool COH = false>   // COH: the carried gradient g comes from other workgroups of this launch
 __device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, const float* z, int z_ld,
                                                int zrow0, int Bg, const float* g, int g_ld, float* gout,
                                                int gout_ld, int o_lo, int o_hi, int o_shift, double* scr,
@@ -593,7 +600,7 @@ __device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, 
 #pragma unroll 4
       for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
         const int r = r0 + gq, rr = r < r_hi ? r : r_hi - 1;
-        const double gv = (double)g[(size_t)rr * g_ld + cc];
+        const double gv = (double)pm_ldc<COH>(g + (size_t)rr * g_ld + cc);
         const double zv = (double)z[(size_t)pm_zidx(zrow0, rr, Bg) * z_ld + cc];
         const double a = (c < DD && r < r_hi) ? gv : 0.0;
         const double b = r < r_hi ? (c < DD ? zv : (c == DD ? 1.0 : 0.0)) : 0.0;
