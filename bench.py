@@ -46,6 +46,42 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_baseline_bnn(dims, h, Xc, Yc, N, batch, iters):
+    """CPU leg of tools/bench_bnn.py (the BNN training step): the oracle's step (torch
+    autograd on the host + its Adam) on the same shapes; returns (iterations/s, threads used)."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    W = [(torch.randn(dims[l + 1], dims[l]) / np.sqrt(dims[l]), torch.zeros(dims[l + 1])) for l in range(3)]
+    lp = [torch.full((h,), 1.1) for _ in range(2)]
+    params = [t for pair in W for t in pair] + lp
+    for p in params:
+        p.requires_grad_(True)
+    ms = [torch.zeros_like(p) for p in params]
+    vs = [torch.zeros_like(p) for p in params]
+
+    def cpu_it(i):
+        idx = torch.randint(0, N, (batch,))
+        us = [torch.rand(batch, h) for _ in range(2)]
+        hs = []
+        for p in params:
+            p.grad = None
+        with torch.no_grad():
+            for l in range(2):
+                hs.append(torch.bernoulli(torch.full((batch, h), 0.7)))
+        loss, _, _ = R.bnn_loss(W, lp, [0.1, 0.1], [0.5, 0.5], [1.0, 1.0], Xc[idx], Yc[idx], us, hs, N)
+        loss.backward()
+        with torch.no_grad():
+            for p, mm, vv in zip(params, ms, vs):
+                R.adam_step(p, p.grad, mm, vv, i + 1, 1e-4)
+
+    for i in range(5):
+        cpu_it(i)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        cpu_it(5 + i)
+    return iters / (time.perf_counter() - t0), torch.get_num_threads()
+
+
 def cpu_baseline(d, budget_s=24.0):
     """The oracle (a torch-CPU port of the reference's op sequence, incl. the
     discarded dynamics-weight gradients) timed on the host: full iteration =

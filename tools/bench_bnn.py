@@ -59,44 +59,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(flat).all())
-    # CPU leg: the oracle's step (torch autograd on the host), bounded sample
-    from oracle import ref_torch as R
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
-    W = [(torch.randn(dims[l + 1], dims[l]) / np.sqrt(dims[l]), torch.zeros(dims[l + 1])) for l in range(3)]
-    lp = [torch.full((h,), 1.1) for _ in range(2)]
-    params = [t for pair in W for t in pair] + lp
-    for p in params:
-        p.requires_grad_(True)
-    ms = [torch.zeros_like(p) for p in params]
-    vs = [torch.zeros_like(p) for p in params]
-    Xc, Yc = Xn.cpu(), Yn.cpu()
-
-    def cpu_it(i):
-        idx = torch.randint(0, a.N, (a.batch,))
-        us = [torch.rand(a.batch, h) for _ in range(2)]
-        hs = []
-        for p in params:
-            p.grad = None
-        with torch.no_grad():
-            for l in range(2):
-                hs.append(torch.bernoulli(torch.full((a.batch, h), 0.7)))
-        loss, _, _ = R.bnn_loss(W, lp, [0.1, 0.1], [0.5, 0.5], [1.0, 1.0], Xc[idx], Yc[idx], us, hs, a.N)
-        loss.backward()
-        with torch.no_grad():
-            for p, mm, vv in zip(params, ms, vs):
-                R.adam_step(p, p.grad, mm, vv, i + 1, 1e-4)
-
-    for i in range(5):
-        cpu_it(i)
-    t0 = time.perf_counter()
-    for i in range(a.cpu_iters):
-        cpu_it(5 + i)
-    dtc = time.perf_counter() - t0
+    # CPU leg: bench.py's cpu_baseline code times the oracle's step on the host (bounded sample)
+    from bench import cpu_baseline_bnn
+    rate_cpu, cores = cpu_baseline_bnn(dims, h, Xn.cpu(), Yn.cpu(), a.N, a.batch, a.cpu_iters)
     print(json.dumps(dict(metric='bnn_training_iterations_per_sec', value=a.iters / dt, unit='it/s',
                           us_per_iteration=dt / a.iters * 1e6,
                           config=dict(workload='dynamics BNN %s, minibatch %d of %d rows, concrete dropout, '
                                                'Gaussian NLL + regulariser, Adam' % (dims, a.batch, a.N)),
-                          cpu_baseline=dict(value=a.cpu_iters / dtc, unit='it/s', cores=torch.get_num_threads(),
+                          cpu_baseline=dict(value=rate_cpu, unit='it/s', cores=cores,
                                             kind='port', sample='%d iterations' % a.cpu_iters))))
 
 
