@@ -612,7 +612,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->mm_grid = 0;
   if (p->mm_mode == 3 && p->RT == 1 && !getenv("PMBRL_MM_PERSTEP")) {
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && p->nwg <= cus)
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && p->nwg <= cus &&
+        p->nwg <= 1024)
       p->mm_grid = 1;
   }
 
@@ -713,7 +714,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
     p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
-    p->off_gsync = take(64);   // arrival counters of the device-wide barriers (forward, backward)
+    p->off_gsync = take(2 * 1024 * sizeof(unsigned));   // one flag per workgroup for the device-wide barriers (forward, backward)
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     p->off_part = take((size_t)p->dw_nsplit * ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
@@ -1043,7 +1044,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
   if (p->mm_mode == 3 && p->mm_grid) {
     // one launch; the workgroups meet after every step and moment-match the sampled states (x_H included)
-    HIPCHK(hipMemsetAsync(A.gsync, 0, sizeof(unsigned), s));
+    HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
     A.t0 = 0; A.t1 = p->cfg.H;
     launch_fwd_rt(p, A, s);
   } else if (p->mm_mode == 3) {
@@ -1123,8 +1124,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     A.gx_from_carry = 1;
     int k = 0;
     if (p->mm_grid) {
-      A.gsync += 1;
-      HIPCHK(hipMemsetAsync(A.gsync, 0, sizeof(unsigned), s));
+      A.gsync += 1024;
+      HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
       A.gx_carry_out = cbuf[1];
       A.t0 = 0; A.t1 = p->cfg.H;
       launch_bwd_rt(p, A, s);

@@ -105,24 +105,31 @@ __device__ __forceinline__ int pm_hi32(const void* p) { return (int)(unsigned)(r
 // rows the workgroups exchange are written with device-scope stores (pm_st_dev: write-through to
 // the coherence point) and read with device-scope loads (pm_ldc<true>), so the barrier needs no
 // cache maintenance: a release / acquire pair would write back and invalidate a whole L2 per
-// workgroup and step (measured: 15+ us per barrier with 157 workgroups, against ~3 us).  Every
-// thread waits for its own stores, one thread per workgroup arrives on the counter and polls it.
-// `target` = arrivals expected so far (monotonic: barrier k of a launch waits for k * nwg).  A
+// workgroup and step (measured: 15+ us per barrier with 157 workgroups, against ~3 us).  A
 // wait that does not end (it cannot, unless the residency assumption was broken) gives up after
 // ~1 s and reports through the status word instead of hanging the device.
 __device__ __forceinline__ void pm_st_dev(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool pm_grid_barrier(unsigned* ctr, unsigned target) {
+__device__ __forceinline__ bool pm_grid_barrier(unsigned* flags, unsigned k) {
+  // barrier k (1, 2, ...) of this launch: workgroup w publishes flags[w] = k once all its threads'
+  // stores have completed, wave 0 polls every workgroup's flag.  Plain device-scope stores and loads:
+  // no read-modify-write whose return the arriving workgroup would have to wait for, no single
+  // address that 150+ workgroups serialise on.
   bool ok = true;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(flags + blockIdx.x, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    const int n = (int)gridDim.x;
     long long spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1ll << 20)) { ok = false; break; }
+    for (;;) {
+      bool all = true;
+      for (int w = (int)threadIdx.x; w < n; w += 64)
+        all = all && __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
+      if (__all(all)) break;
+      if (++spins > (1ll << 19)) { ok = false; break; }
     }
   }
   __syncthreads();
@@ -1431,8 +1438,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         A.states[((size_t)(t + 1) * B + row0) * D + i] = xa[i];
     } else if (mm_gs) {
       // every workgroup's sampled rows of this step are in A.xt once all have passed the barrier
-      if (!pm_grid_barrier(A.gsync, (unsigned)(t - T0 + 1) * gridDim.x) && tid == 0) atomicMin(A.status, t);
+      if (!pm_grid_barrier(A.gsync, (unsigned)(t - T0 + 1)) && tid == 0) atomicMin(A.status, t);
+      PF_MARK(28);
       mm_span_fwd(t, std::true_type{});
+      PF_MARK(29);
       // the row sums went through the activation buffers: restore their zero K padding
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;
     } else {
@@ -1655,8 +1664,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       float* carry = ((T1 - 1 - t) & 1) ? A.gx_carry_out : A.gx_carry;
       __syncthreads();
       for (int i = tid; i < nvalid * D; i += PF_NT) pm_st_dev(carry + (size_t)row0 * D + i, gx[i]);
-      if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t) * gridDim.x) && tid == 0) atomicMin(A.status, t);
+      if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t)) && tid == 0) atomicMin(A.status, t);
+      PF_MARK(28);
       mm_span_bwd(t, carry, std::true_type{});
+      PF_MARK(29);
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // restore the zero K padding
     }
     if (mm_in) {

@@ -295,7 +295,12 @@ template <int N>
 __device__ __forceinline__ double pm_sel(const double (&v)[N], int idx) {
   double o = v[0];
 #pragma unroll
-  for (int k = 1; k < N; ++k) o = (idx == k) ? v[k] : o;
+  for (int k = 1; k < N; ++k) {
+    o = (idx == k) ? v[k] : o;
+    // keep this a chain of v_cndmask: left alone the compiler turns it into a private array indexed
+    // by lane -- a store / load round trip through scratch memory on the serial path of every pivot
+    asm volatile("" : "+v"(o));
+  }
   return o;
 }
 
@@ -309,12 +314,14 @@ __device__ __forceinline__ float pm_ldc(const float* p) {
 // Gram tile of X = [s - ref | 1 | z] over rows [r_lo, r_hi) of the group (ref: the group's first row)
 template <int DD, bool COH = false>
 __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, const float* z, int z_ld,
-                                                    int zrow0, int Bg, int r_lo, int r_hi, int lane) {
+                                                    int zrow0, int Bg, int r_lo, int r_hi, int lane,
+                                                    double* ref_out = nullptr) {
   static_assert(2 * DD + 1 <= 16, "the Gram tile holds 2d+1 columns");
   const int g = lane >> 4, c = lane & 15;
   const int cs = c < DD ? c : 0;
   const int cz = (c > DD && c <= 2 * DD) ? c - DD - 1 : 0;
   const double ref = (double)pm_ldc<COH>(s + cs);
+  if (ref_out) *ref_out = ref;     // lane j < DD: the group's first row, column j
   pm_f64x4 G = {0.0, 0.0, 0.0, 0.0};
   if (r_hi <= r_lo) return G;
   // rows r_lo + g, + 4, ...: the cyclic noise row advances with them (one modulo up front, then
@@ -338,9 +345,10 @@ __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, co
 }
 
 // means / standardisation / Cholesky factor from the group's Gram tile -> q (LDS scratch of this wave)
-template <int DD, bool COH = false>
-__device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const float* s, const MMScratch& q,
-                                                       int lane) {
+// ref_lane: in lane j < DD the reference row's column j (what pm_mm_gram_rows subtracted)
+template <int DD>
+__device__ __forceinline__ bool pm_mm_factor_from_gram_ref(pm_f64x4 G, int M, double ref_lane, const MMScratch& q,
+                                                           int lane) {
   constexpr int NR = (DD + 3) / 4;             // accumulator registers that hold covariance rows
   const int g = lane >> 4, c = lane & 15;
   const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
@@ -410,12 +418,17 @@ __device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const 
     if (i < DD && c < DD) q.Lm[i * DD + c] = A[r];
   }
   if (lane < DD) {
-    q.mean[lane] = pm_sel(sm, lane) + (double)pm_ldc<COH>(s + lane);
+    q.mean[lane] = pm_sel(sm, lane) + ref_lane;
     q.zmean[lane] = pm_sel(zm, lane);
     q.zistd[lane] = pm_sel(zi, lane);
   }
   pm_wave_sync();
   return ok;
+}
+template <int DD, bool COH = false>
+__device__ __forceinline__ bool pm_mm_factor_from_gram(pm_f64x4 G, int M, const float* s, const MMScratch& q,
+                                                       int lane) {
+  return pm_mm_factor_from_gram_ref<DD>(G, M, (double)pm_ldc<COH>(s + (lane < DD ? lane : 0)), q, lane);
 }
 template <int DD>
 __device__ __forceinline__ bool pm_mm_factor_t(const float* s, int s_ld, int M, const float* z, int z_ld,
@@ -557,16 +570,29 @@ __device__ __forceinline__ bool pm_mm_fwd_rows(const float* s, int s_ld, int M, 
                                                int lane) {
   int r_lo, r_hi;
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
-  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD, COH>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
-                                     nw, wid, lane);
+  // the noise row of this lane's first output element: loaded with the Gram's rows, not after the algebra
+  const int e0 = o_lo * DD + lane;
+  float zfirst[DD];
+  {
+    const int r = (e0 < o_hi * DD) ? e0 / DD : 0;
+    const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
+#pragma unroll
+    for (int c = 0; c < DD; ++c) zfirst[c] = z[zr + c];
+  }
+  double ref = 0.0;
+  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD, COH>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane, &ref),
+                                     part, nw, wid, lane);
   const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
-  const bool ok = pm_mm_factor_from_gram<DD, COH>(G, M, s, q, lane);
-  for (int e = o_lo * DD + lane; e < o_hi * DD; e += 64) {
+  const bool ok = pm_mm_factor_from_gram_ref<DD>(G, M, ref, q, lane);
+  for (int e = e0; e < o_hi * DD; e += 64) {
     const int r = e / DD, j = e - r * DD;
     double acc = q.mean[j];
     const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
-    for (int c = 0; c <= j; ++c)
-      acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * DD + c];
+#pragma unroll
+    for (int c = 0; c < DD; ++c) {
+      const float zc = (e == e0) ? zfirst[c] : z[zr + c];
+      if (c <= j) acc += ((double)zc - q.zmean[c]) * q.zistd[c] * q.Lm[j * DD + c];
+    }
     out[(size_t)(r - o_shift) * out_ld + j] = (float)acc;
   }
   return ok;
@@ -579,6 +605,41 @@ __device__ __forceinline__ bool pm_mm_fwd_mw(const float* s, int s_ld, int M, co
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
   return pm_mm_fwd_rows<DD>(s, s_ld, M, z, z_ld, zrow0, Bg, out, out_ld, r_lo, r_hi, 0, scr, part, nw, wid, lane);
 }
+// Gram tile (as pm_mm_gram_rows) and H = g^T [z | 1] over the same rows in ONE pass: the rows of s, z
+// and g are in flight together (one memory round trip instead of two), same accumulation order
+template <int DD, bool COH>
+__device__ __forceinline__ void pm_mm_gram_h_rows(const float* s, int s_ld, const float* z, int z_ld, int zrow0,
+                                                  int Bg, const float* g, int g_ld, int r_lo, int r_hi, int lane,
+                                                  pm_f64x4& G, pm_f64x4& H, double* ref_out) {
+  const int gq = lane >> 4, c = lane & 15;
+  const int cs = c < DD ? c : 0;
+  const int cz = (c > DD && c <= 2 * DD) ? c - DD - 1 : 0;
+  const double ref = (double)s[cs];
+  *ref_out = ref;
+  G = pm_f64x4{0.0, 0.0, 0.0, 0.0};
+  H = pm_f64x4{0.0, 0.0, 0.0, 0.0};
+  if (r_hi <= r_lo) return;
+  int zr = pm_zidx(zrow0, min(r_lo + gq, r_hi - 1), Bg);
+  const int zwrap = Bg ? Bg : 0x7fffffff;
+#pragma unroll 4
+  for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
+    const int r = r0 + gq, rr = r < r_hi ? r : r_hi - 1;
+    const double sv = (double)s[(size_t)rr * s_ld + cs] - ref;
+    const double zv = (double)z[(size_t)zr * z_ld + cz];
+    const double zh = (double)z[(size_t)zr * z_ld + cs];
+    const double gv = (double)pm_ldc<COH>(g + (size_t)rr * g_ld + cs);
+    double x = c < DD ? sv : (c == DD ? 1.0 : (c <= 2 * DD ? zv : 0.0));
+    if (r >= r_hi) x = 0.0;
+    G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
+    const double a = (c < DD && r < r_hi) ? gv : 0.0;
+    const double b = r < r_hi ? (c < DD ? zh : (c == DD ? 1.0 : 0.0)) : 0.0;
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
+    if (r + 4 < r_hi) {
+      zr += 4;
+      if (zr >= zwrap) zr -= zwrap;
+    }
+  }
+}
 template <int DD, bool COH = false>   // COH: the carried gradient g comes from other workgroups of this launch
 __device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, const float* z, int z_ld,
                                                int zrow0, int Bg, const float* g, int g_ld, float* gout,
@@ -587,26 +648,24 @@ __device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, 
   constexpr int NR = (DD + 3) / 4;
   int r_lo, r_hi;
   pm_mm_slice(M, nw, wid, r_lo, r_hi);
-  const pm_f64x4 G = pm_mm_sum_parts(pm_mm_gram_rows<DD>(s, s_ld, z, z_ld, zrow0, Bg, r_lo, r_hi, lane), part,
-                                     nw, wid, lane);
+  // this lane's first output element needs its row of s: loaded with the statistics' rows
+  const int e0 = o_lo * DD + lane;
+  float sfirst[DD];
+  {
+    const int r = (e0 < o_hi * DD) ? e0 / DD : 0;
+#pragma unroll
+    for (int c = 0; c < DD; ++c) sfirst[c] = s[(size_t)r * s_ld + c];
+  }
+  pm_f64x4 G0, H;
+  double ref = 0.0;
+  pm_mm_gram_h_rows<DD, COH>(s, s_ld, z, z_ld, zrow0, Bg, g, g_ld, r_lo, r_hi, lane, G0, H, &ref);
+  const pm_f64x4 G = pm_mm_sum_parts(G0, part, nw, wid, lane);
   const MMScratch q = pm_mm_carve(scr + (size_t)wid * pm_mm_scratch_doubles(DD), DD);
-  (void)pm_mm_factor_from_gram<DD>(G, M, s, q, lane);
+  (void)pm_mm_factor_from_gram_ref<DD>(G, M, ref, q, lane);
   const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
   {
     const int gq = lane >> 4, c = lane & 15;
     const int cc = c < DD ? c : 0;
-    pm_f64x4 H = {0.0, 0.0, 0.0, 0.0};
-    if (r_hi > r_lo) {
-#pragma unroll 4
-      for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
-        const int r = r0 + gq, rr = r < r_hi ? r : r_hi - 1;
-        const double gv = (double)pm_ldc<COH>(g + (size_t)rr * g_ld + cc);
-        const double zv = (double)z[(size_t)pm_zidx(zrow0, rr, Bg) * z_ld + cc];
-        const double a = (c < DD && r < r_hi) ? gv : 0.0;
-        const double b = r < r_hi ? (c < DD ? zv : (c == DD ? 1.0 : 0.0)) : 0.0;
-        H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
-      }
-    }
     __syncthreads();            // the Gram partials have been consumed; every read of g is done
     H = pm_mm_sum_parts(H, part, nw, wid, lane);
     double mb[DD];
@@ -626,10 +685,14 @@ __device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, 
   }
   pm_wave_sync();
   pm_mm_bwd_tail<DD>(q, lane, M);
-  for (int e = o_lo * DD + lane; e < o_hi * DD; e += 64) {
+  for (int e = e0; e < o_hi * DD; e += 64) {
     const int r = e / DD, j = e - r * DD;
     double acc = q.mbar[j] * inv_m;
-    for (int c = 0; c < DD; ++c) acc += ((double)s[(size_t)r * s_ld + c] - q.mean[c]) * q.P[c * DD + j];
+#pragma unroll
+    for (int c = 0; c < DD; ++c) {
+      const float sc = (e == e0) ? sfirst[c] : s[(size_t)r * s_ld + c];
+      acc += ((double)sc - q.mean[c]) * q.P[c * DD + j];
+    }
     gout[(size_t)(r - o_shift) * gout_ld + j] = (float)acc;
   }
   (void)inv_m1;

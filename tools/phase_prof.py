@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""In-kernel phase profile of workgroup 0 (shader-clock stamps, pmbrl_plan_set_prof)."""
+"""In-kernel phase profile of workgroup 0 (shader-clock stamps, pmbrl_plan_set_prof).
+usage: phase_prof.py [config [rows_per_wg_hint [particles samples [mm_groups]]]]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,12 @@ def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else 'cartpole_nomm'
     hint = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dev = torch.device('cuda:0')
-    d = PB.synthetic_problem(cfg, seed=0, data_seed=0)
+    # optional: particles, samples, moment-matching groups (0 = one group over all rows)
+    P = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    S = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    d = PB.synthetic_problem(cfg, seed=0, data_seed=0, P=P, S=S)
+    if len(sys.argv) > 5:
+        d['mm_groups'] = np.asarray(int(sys.argv[5]))
     eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=hint)
     print(eng.info)
     H = eng.H
