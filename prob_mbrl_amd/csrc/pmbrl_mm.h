@@ -325,20 +325,30 @@ __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, co
   pm_f64x4 G = {0.0, 0.0, 0.0, 0.0};
   if (r_hi <= r_lo) return G;
   // rows r_lo + g, + 4, ...: the cyclic noise row advances with them (one modulo up front, then
-  // a conditional wrap), loads of 8 row quads are in flight together
+  // a conditional wrap).  The rows of UB row quads are loaded together, then their MFMAs run: written
+  // as two fixed-count inner loops because the compiler does not unroll the single loop (it left one
+  // memory round trip per row quad: 80 k cycles for a 2500-row group)
+  constexpr int UB = 8;
   int zr = pm_zidx(zrow0, min(r_lo + g, r_hi - 1), Bg);
   const int zwrap = Bg ? Bg : 0x7fffffff;
-#pragma unroll 8
-  for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
-    const int r = r0 + g, rr = r < r_hi ? r : r_hi - 1;
-    const double sv = (double)pm_ldc<COH>(s + (size_t)rr * s_ld + cs) - ref;
-    const double zv = (double)z[(size_t)zr * z_ld + cz];
-    double x = c < DD ? sv : (c == DD ? 1.0 : (c <= 2 * DD ? zv : 0.0));
-    if (r >= r_hi) x = 0.0;
-    G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
-    if (r + 4 < r_hi) {
-      zr += 4;
-      if (zr >= zwrap) zr -= zwrap;
+  for (int r0 = r_lo; r0 < r_hi; r0 += 4 * UB) {
+    float sv[UB], zv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + 4 * u + g, rr = r < r_hi ? r : r_hi - 1;
+      sv[u] = pm_ldc<COH>(s + (size_t)rr * s_ld + cs);
+      zv[u] = z[(size_t)zr * z_ld + cz];
+      if (r + 4 < r_hi) {
+        zr += 4;
+        if (zr >= zwrap) zr -= zwrap;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + 4 * u + g;
+      double x = c < DD ? (double)sv[u] - ref : (c == DD ? 1.0 : (c <= 2 * DD ? (double)zv[u] : 0.0));
+      if (r >= r_hi) x = 0.0;
+      if (r0 + 4 * u < r_hi) G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
     }
   }
   return G;
@@ -621,22 +631,32 @@ __device__ __forceinline__ void pm_mm_gram_h_rows(const float* s, int s_ld, cons
   if (r_hi <= r_lo) return;
   int zr = pm_zidx(zrow0, min(r_lo + gq, r_hi - 1), Bg);
   const int zwrap = Bg ? Bg : 0x7fffffff;
-#pragma unroll 4
-  for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
-    const int r = r0 + gq, rr = r < r_hi ? r : r_hi - 1;
-    const double sv = (double)s[(size_t)rr * s_ld + cs] - ref;
-    const double zv = (double)z[(size_t)zr * z_ld + cz];
-    const double zh = (double)z[(size_t)zr * z_ld + cs];
-    const double gv = (double)pm_ldc<COH>(g + (size_t)rr * g_ld + cs);
-    double x = c < DD ? sv : (c == DD ? 1.0 : (c <= 2 * DD ? zv : 0.0));
-    if (r >= r_hi) x = 0.0;
-    G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
-    const double a = (c < DD && r < r_hi) ? gv : 0.0;
-    const double b = r < r_hi ? (c < DD ? zh : (c == DD ? 1.0 : 0.0)) : 0.0;
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
-    if (r + 4 < r_hi) {
-      zr += 4;
-      if (zr >= zwrap) zr -= zwrap;
+  constexpr int UB = 4;        // row quads whose loads are in flight together (see pm_mm_gram_rows)
+  for (int r0 = r_lo; r0 < r_hi; r0 += 4 * UB) {
+    float sv[UB], zv[UB], zh[UB], gv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + 4 * u + gq, rr = r < r_hi ? r : r_hi - 1;
+      sv[u] = s[(size_t)rr * s_ld + cs];
+      zv[u] = z[(size_t)zr * z_ld + cz];
+      zh[u] = z[(size_t)zr * z_ld + cs];
+      gv[u] = pm_ldc<COH>(g + (size_t)rr * g_ld + cs);
+      if (r + 4 < r_hi) {
+        zr += 4;
+        if (zr >= zwrap) zr -= zwrap;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + 4 * u + gq;
+      double x = c < DD ? (double)sv[u] - ref : (c == DD ? 1.0 : (c <= 2 * DD ? (double)zv[u] : 0.0));
+      if (r >= r_hi) x = 0.0;
+      const double a = (c < DD && r < r_hi) ? (double)gv[u] : 0.0;
+      const double b = r < r_hi ? (c < DD ? (double)zh[u] : (c == DD ? 1.0 : 0.0)) : 0.0;
+      if (r0 + 4 * u < r_hi) {
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G, 0, 0, 0);
+        H = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H, 0, 0, 0);
+      }
     }
   }
 }
