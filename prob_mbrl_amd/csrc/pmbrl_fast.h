@@ -119,8 +119,8 @@ __device__ __forceinline__ bool pm_grid_barrier(unsigned* flags, unsigned k) {
   bool ok = true;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_store(flags + blockIdx.x, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)      // (max, not store: a flag poisoned by a timed-out workgroup stays poisoned)
+    __hip_atomic_fetch_max(flags + blockIdx.x, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x < 64) {
     const int n = (int)gridDim.x;
     long long spins = 0;
@@ -129,8 +129,17 @@ __device__ __forceinline__ bool pm_grid_barrier(unsigned* flags, unsigned k) {
       for (int w = (int)threadIdx.x; w < n; w += 64)
         all = all && __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
       if (__all(all)) break;
-      if (++spins > (1ll << 19)) { ok = false; break; }
+      if (++spins > (1ll << 19)) {
+        // give up ONCE for the whole launch: every flag goes to its maximum, so this and all later
+        // barriers of all workgroups fall through (the launch finishes with the step marked failed)
+        ok = false;
+        for (int w = (int)threadIdx.x; w < n; w += 64)
+          __hip_atomic_fetch_max(flags + w, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
+    // a poisoned flag also means failure for the workgroups that did not time out themselves
+    if (__hip_atomic_load(flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) ok = false;
   }
   __syncthreads();
   return ok;
