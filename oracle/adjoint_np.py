@@ -24,6 +24,13 @@ import numpy as np
 LOG_MAX_STD = np.log(5.0)
 
 
+def _mm(a, b, role='fwd'):
+    """Every dense product of the path goes through here (role: 'fwd' layer, 'dx' adjoint chain,
+    'dw' weight gradient) so that tools/split_precision_study.py can swap in an emulation of the
+    split-bf16 matrix-core arithmetic; the oracle itself is the plain product."""
+    return a @ b
+
+
 def softplus(x):
     return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
 
@@ -134,7 +141,7 @@ def mlp_fwd(x, Ws, bs, masks, keeps):
     h = x
     n = len(Ws)
     for i in range(n):
-        p = h @ Ws[i].T + bs[i]
+        p = _mm(h, Ws[i].T) + bs[i]
         if i < n - 1:
             act = (p > 0) & (masks[i][:h.shape[0]] > 0)
             h = np.where(act, p, 0.0)
@@ -277,12 +284,12 @@ def backward(P, st, gr_all=None):
         gxt = gxt + gx_r
         # dynamics head and trunk (dX only -- dynamics weights are frozen)
         go = np.concatenate([gxt * P.Sy, gxt * st['Td'][t]], 1)
-        gh = go @ P.dW[ndl - 1]
+        gh = _mm(go, P.dW[ndl - 1], 'dx')
         for i in reversed(range(ndl - 1)):
             gp = np.where(st['dbits'][t][i], gh, 0.0)
             if P.dkeep[i] != 1.0:
                 gp = gp / P.dkeep[i]
-            gh = gp @ P.dW[i]
+            gh = _mm(gp, P.dW[i], 'dx')
         gxa = gh * P.iSx
         gx = gxt + gxa[:, :D]
         ga = ga + gxa[:, D:]
@@ -292,17 +299,17 @@ def backward(P, st, gr_all=None):
         go = np.concatenate([gu, gu * st['Tp'][t]], 1)
         Gs = [None] * npl
         Gs[npl - 1] = go
-        gW[npl - 1] += go.T @ st['pacts'][t][npl - 1]
+        gW[npl - 1] += _mm(go.T, st['pacts'][t][npl - 1], 'dw')
         gb[npl - 1] += go.sum(0)
-        gh = go @ P.pW[npl - 1]
+        gh = _mm(go, P.pW[npl - 1], 'dx')
         for i in reversed(range(npl - 1)):
             gp = np.where(st['pbits'][t][i], gh, 0.0)
             if P.pkeep[i] != 1.0:
                 gp = gp / P.pkeep[i]
             Gs[i] = gp
-            gW[i] += gp.T @ st['pacts'][t][i]
+            gW[i] += _mm(gp.T, st['pacts'][t][i], 'dw')
             gb[i] += gp.sum(0)
-            gh = gp @ P.pW[i]
+            gh = _mm(gp, P.pW[i], 'dx')
         gx = gx + gh
         Gst.append(Gs)
     flat = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)])

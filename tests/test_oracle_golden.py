@@ -23,7 +23,10 @@ def test_torch_oracle_matches_reference_fp32(name):
     assert np.allclose(torch.stack(Rw).detach().numpy().reshape(d['ref32_rewards'].shape),
                        d['ref32_rewards'], rtol=1e-5, atol=1e-7)
     assert abs(float(loss) - float(d['ref32_loss'])) <= 1e-5 * abs(float(d['ref32_loss']))
-    assert common.rel(g.numpy(), d['ref32_grad']) < 1e-4
+    if 'ref32_grad' in d:      # (wide fixtures keep the fp64 gradient only)
+        # ill-conditioned moment matching: two fp32 evaluations of the same formulas differ by about as
+        # much as the reference's fp32 run differs from its fp64 run
+        assert common.rel(g.numpy(), d['ref32_grad']) < 1e-4 + 2 * common.rel(d['ref32_grad'], d['ref64_grad'])
 
 
 @pytest.mark.parametrize('name', common.fixture_names('iter'))
@@ -64,7 +67,9 @@ def test_oracle_mc_pilco_iterations(name):
     losses = []
     for it in range(int(d['mcp_n_iters'])):
         loss, g, _ = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
-                                 meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+                                 meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr,
+                                 cvar_eps=float(d['mcp_cvar_eps']) if 'mcp_cvar_eps' in d else 0.0,
+                                 reg_weight=float(d['mcp_reg_weight']) if 'mcp_reg_weight' in d else 0.0)
         losses.append(float(loss))
         grads = [p.grad for p in params]
         _, grads = R.clip_grad_norm(grads, float(d['mcp_clip']))
@@ -74,6 +79,26 @@ def test_oracle_mc_pilco_iterations(name):
     assert np.allclose(losses, d['ref32_mcp_losses'], rtol=2e-5)
     final = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
     assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_truncated_horizon():
+    """utils/rollout.py:154-157: after a failure in step n > 5 the reference optimises on the first n
+    steps; fixture from the reference's own rollout with a RuntimeError raised in step 8 of 12."""
+    d = common.load('trunc_mm')
+    n = int(d['fail_step'])
+    for dt, tag, tol in ((torch.float32, 'ref32_', 1e-4), (torch.float64, 'ref64_', 1e-6)):
+        x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, dt)
+        loss, g, (S, Ac, Rw) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,
+                                           meta['mm_groups'], z_mm, z_rr, n_steps=n)
+        assert len(Rw) == n and d[tag + 'rewards'].shape[0] == n and d[tag + 'states'].shape[0] == n + 1
+        assert common.rel(torch.stack(S[:n]).detach().numpy(), d[tag + 'states'][:n]) < tol
+        assert abs(float(loss) - float(d[tag + 'loss'])) <= tol * abs(float(d[tag + 'loss']))
+        assert common.rel(g.numpy(), d[tag + 'grad']) < tol
+    P = A.Problem(d, np.float64)
+    P.H = n
+    st = A.forward(P)
+    g, _, _ = A.backward(P, st)
+    assert common.rel(g, d['ref64_grad']) < 1e-6
 
 
 def _adam_loop(d, x0_of, extra_of, after=None):

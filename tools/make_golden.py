@@ -48,8 +48,31 @@ from prob_mbrl.envs.double_cartpole.env import DoubleCartpoleReward  # noqa: E40
 from prob_mbrl.envs.pendulum.env import PendulumReward  # noqa: E402
 from prob_mbrl.envs.rendezvous.env import RendezvousReward  # noqa: E402
 
+from prob_mbrl import losses as ref_losses  # noqa: E402
+
 torch.set_num_threads(1)
 torch.set_flush_denormal(True)
+
+
+class SaturatingReward(torch.nn.Module):
+    """Reward for state widths none of the reference's env modules covers (the D=32 stress shape):
+    r = 1 - losses.quadratic_saturating_loss([x C^T | u], 0, blockdiag(Q, R))  (losses.py:60-75)
+      = exp(-1/2 (d'Qd + u'Ru)),  d = C x  -- the same form as envs/cartpole/env.py:41-86 with the
+    reference's own loss function doing the arithmetic."""
+
+    def __init__(self, C, Q, R):
+        super(SaturatingReward, self).__init__()
+        self.register_buffer('C', torch.as_tensor(C, dtype=torch.float32))
+        self.register_buffer('Q', torch.as_tensor(Q, dtype=torch.float32))
+        self.register_buffer('R', torch.as_tensor(R, dtype=torch.float32))
+
+    def forward(self, x, u):
+        k, U = self.Q.shape[0], self.R.shape[0]
+        QR = torch.zeros(k + U, k + U, dtype=x.dtype)
+        QR[:k, :k] = self.Q.to(x.dtype)
+        QR[k:, k:] = self.R.to(x.dtype)
+        z = torch.cat([x.mm(self.C.to(x.dtype).t()), u], -1)
+        return 1 - ref_losses.quadratic_saturating_loss(z, torch.zeros(1, k + U, dtype=x.dtype), QR)
 
 
 # ---------------------------------------------------------------------------
@@ -93,6 +116,11 @@ def reward_spec(rew, D):
             C[i, a], C[i, b] = 1.0, -1.0
         norm, w, kind = 1.0, 1.0, 'neg'
         target = torch.zeros(1, 8)
+    elif isinstance(rew, SaturatingReward):
+        adims, De = [], D
+        C = rew.C.detach().double().numpy()
+        norm, w, kind = 1.0, 0.5, 'exp'
+        target = torch.zeros(1, D)
     else:
         raise TypeError(rew)
     targeta = utils.angles.to_complex(target.double(), adims).numpy()
@@ -248,9 +276,21 @@ def ref_iteration(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
 
 def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
               mm_groups=None, discount=None, seed=0, infer_ns=False,
-              maximize=True, x0_scale=0.1, P=None):
+              maximize=True, x0_scale=0.1, P=None, weight_seed=None, pol_angle_dims=None,
+              dyn_angle_dims=None):
     rew = rew_fn()
     dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
+    if weight_seed is not None:
+        # wide networks: the weights come from a seed (oracle.ref_torch.seeded_weights) so that the
+        # fixture does not have to carry megabytes of them
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        from oracle.ref_torch import seeded_weights
+        for k, (net, dims) in enumerate(((pol.model, [D] + pol_hid + [2 * U]),
+                                         (dyn.model, [D + U] + dyn_hid + [2 * D]))):
+            lins = [m for m in net._modules.values() if isinstance(m, torch.nn.Linear)]
+            for lin, (W, b) in zip(lins, seeded_weights(dims, weight_seed + k)):
+                lin.weight.data = torch.tensor(W)
+                lin.bias.data = torch.tensor(b)
     dyn.eval()
     pol.train()
     torch.manual_seed(seed + 1000)
@@ -290,12 +330,22 @@ def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
     gerr = np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])
     print('%-22s B=%d H=%d loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' %
           (name, B, H, r32['loss'], r64['loss'], gerr))
+    if weight_seed is not None:
+        for pre, k, dims in (('pol', 0, [D] + pol_hid + [2 * U]), ('dyn', 1, [D + U] + dyn_hid + [2 * D])):
+            for i in range(len(dims) - 1):
+                del d['%s_W%d' % (pre, i)], d['%s_b%d' % (pre, i)]
+            d[pre + '_W_seed'] = weight_seed + k
+            d[pre + '_W_dims'] = np.asarray(dims, dtype=np.int64)
+        # half a million gradient entries: the fp64 reference gradient is kept rounded to fp32 (6e-8
+        # relative, four decades under the parity bar), the reference's own fp32 gradient is dropped
+        d['ref64_grad'] = d['ref64_grad'].astype(np.float32)
+        del d['ref32_grad']
     return d
 
 
 def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
                       mm=False, mm_groups=None, lr=1e-3, clip=1.0, seed=0,
-                      discount=None, value_hid=None, replay=False):
+                      discount=None, value_hid=None, replay=False, reg_weight=0.0, cvar_eps=0.0):
     """Run the REAL algorithms.mc_pilco for n_iters with a fixed x0 and capture
     the frozen randomness through a wrapper around utils.rollout.
 
@@ -308,6 +358,10 @@ def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
     torch.manual_seed(seed + 1000)
     x0 = 0.1 * torch.randn(B, D)
     V, exp, extra_kw = None, None, {}
+    if reg_weight > 0:
+        extra_kw['reg_weight'] = reg_weight     # algorithms/mc_pilco.py:193-194
+    if cvar_eps != 0:
+        extra_kw['cvar_eps'] = cvar_eps         # algorithms/mc_pilco.py:146-154
     if value_hid is not None:
         torch.manual_seed(seed + 77)
         V = models.Regressor(models.mlp(
@@ -401,6 +455,8 @@ def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
         pass
     assert len(losses) == n_iters, losses
     d['mcp_lr'] = lr
+    d['mcp_reg_weight'] = reg_weight
+    d['mcp_cvar_eps'] = cvar_eps
     d['mcp_clip'] = clip
     d['mcp_n_iters'] = n_iters
     d['ref32_mcp_losses'] = np.asarray(losses, dtype=np.float32)
@@ -411,6 +467,69 @@ def make_mcpilco_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, n_iters,
     d['ref32_mcp_exp_avg_sq'] = torch.cat(
         [opt.state[p]['exp_avg_sq'].reshape(-1) for p in pol.parameters()]).numpy()
     print('%-22s mc_pilco %d its, losses %s' % (name, n_iters, losses))
+    return d
+
+
+def make_trunc_case(name, D=4, U=1, hid=(32, 32), B=30, H=12, fail_step=8, seed=23, mm_groups=None):
+    """The reference's truncated-horizon continuation (utils/rollout.py:154-157): a RuntimeError
+    inside step `fail_step` (> 5 completed steps) makes the loop break, and the caller optimises on the
+    truncated trajectory with the discount 1/H of the FULL horizon (algorithms/mc_pilco.py:134-197).
+    The error is raised from the reference's own `on_pol_eval` hook (called inside the try block,
+    utils/rollout.py:104-108) -- a genuine Cholesky failure that late cannot be provoked through the
+    inputs with frozen noise (a non-finite value anywhere fails the first step).  What is pinned is
+    what the reference does AFTER the failure: which steps it keeps, the loss and the gradient."""
+    print('[trunc] %s' % name)
+    rew = _cartpole()
+    dyn, pol = build(D, U, list(hid), list(hid), rew, 10.0, seed)
+    dyn.eval()
+    pol.train()
+    torch.manual_seed(seed + 1000)
+    x0 = 0.1 * torch.randn(B, D)
+    z_mm = torch.randn(H + B, D)
+    z_rr = torch.randn(H + B, 1)
+    gamma = [1.0 / H] * H
+    with torch.no_grad():
+        utils.rollout(x0, dyn, pol, 1, resample_state_noise=False, resample_action_noise=False)
+    seed_t = torch.tensor([seed + 77])
+    dyn.resample(seed=seed_t)
+    pol.resample(seed=seed_t)
+    torch.manual_seed(seed + 5)
+    pol.model.fc_nonlin.z.data = torch.randn_like(pol.model.fc_nonlin.z)
+    d = capture_inputs(dyn, pol, x0, H, gamma, True, True, mm_groups, z_mm, z_rr, True, False, rew)
+    d['fail_step'] = fail_step
+
+    def hook(i, states, actions):
+        if i == fail_step:
+            raise RuntimeError('injected failure at step %d' % i)
+        return states, actions
+
+    def run(dt):
+        pol.zero_grad()
+        dyn.zero_grad()
+        states, actions, rewards = utils.rollout(
+            x0.to(dt), dyn, pol, H, resample_state_noise=False, resample_action_noise=False,
+            mm_states=True, mm_rewards=True, z_mm=z_mm.to(dt), z_rr=z_rr.to(dt), mm_groups=mm_groups,
+            on_pol_eval=hook)
+        assert len(rewards) == fail_step and len(actions) == fail_step and len(states) == fail_step + 1, len(rewards)
+        disc = torch.stack([r * gamma[i] for i, r in enumerate(rewards)])
+        loss = (-disc.sum(0)).mean()
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in pol.parameters()])
+        return dict(states=torch.stack(states).detach().numpy(), actions=torch.stack(actions).detach().numpy(),
+                    rewards=torch.stack(rewards).detach().numpy(), loss=float(loss), grad=g.detach().numpy().copy())
+
+    r32 = run(torch.float32)
+    dyn.double()
+    pol.double()
+    rew.double()
+    r64 = run(torch.float64)
+    for k, v in r32.items():
+        d['ref32_' + k] = np.asarray(v, dtype=np.float32)
+    for k, v in r64.items():
+        d['ref64_' + k] = np.asarray(v, dtype=np.float64)
+    print('   valid steps %d of %d, loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' % (
+        fail_step, H, r32['loss'], r64['loss'],
+        np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])))
     return d
 
 
@@ -767,6 +886,11 @@ def _dcartpole():
                                 pole2_length=torch.tensor(0.6))
 
 
+def _generic_reward(D, U, k=2, seed=7):
+    rs = np.random.RandomState(seed)
+    return SaturatingReward(rs.randn(k, D) / np.sqrt(D), np.eye(k), 1e-3 * np.eye(U))
+
+
 def _pendulum():
     return PendulumReward(pole_length=torch.tensor(1.0))
 
@@ -812,6 +936,15 @@ CASES = {
                                   mm=True, seed=15),
     'mmg_m80': lambda: make_case('mmg_m80', 4, 1, [16, 16], [16, 16], _cartpole, 10.0, 160, 6,
                                  mm=True, mm_groups=2, seed=16, P=2),
+    # SURVEY C5 shape (D=32, U=8, 3 x 512 both nets): general kernel family, 32-tile layers
+    'c5_small': lambda: make_case('c5_small', 32, 8, [512, 512, 512], [512, 512, 512],
+                                  lambda: _generic_reward(32, 8), [1.0] * 8, 16, 20, seed=19, weight_seed=190),
+    # moment matching at the examples' horizon (the regime SURVEY 7 flags as ill-conditioned)
+    'mm1_b100_h40': lambda: make_case('mm1_b100_h40', 5, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 40,
+                                      mm=True, seed=17),
+    'mmg_h40': lambda: make_case('mmg_h40', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 40,
+                                 mm=True, mm_groups=4, seed=18, P=4),
+    'trunc_mm': lambda: make_trunc_case('trunc_mm'),
     'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
     'standalone_fwd_u4': lambda: make_standalone_case('standalone_fwd_u4', 8, 4, [48, 24, 40], [24, 24],
                                                       lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
@@ -828,6 +961,12 @@ CASES = {
                                            _cartpole, 10.0, 30, 10, 4, seed=15, value_hid=[24, 24]),
     'ext_replay': lambda: make_mcpilco_case('ext_replay', 4, 1, [32, 32], [32, 32],
                                             _cartpole, 10.0, 36, 8, 4, seed=16, replay=True),
+    'mcp_reg': lambda: make_mcpilco_case('mcp_reg', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 30, 10, 3,
+                                         seed=21, reg_weight=1e-2),
+    'mcp_cvar': lambda: make_mcpilco_case('mcp_cvar', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 40, 10, 3,
+                                          seed=22, cvar_eps=0.3),
+    'mcp_cvar_neg_reg': lambda: make_mcpilco_case('mcp_cvar_neg_reg', 4, 1, [32, 32], [32, 32], _cartpole, 10.0,
+                                                  40, 10, 3, seed=23, cvar_eps=-0.25, reg_weight=3e-3, mm=True),
     'mcp_mm1': lambda: make_mcpilco_case('mcp_mm1', 5, 1, [32, 32], [32, 32],
                                          _cartpole, 10.0, 30, 10, 3,
                                          mm=True, seed=14, discount=0.95),
