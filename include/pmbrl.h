@@ -174,18 +174,32 @@ int pmbrl_rollout_fwd(pmbrl_plan* plan, void* stream, void* workspace_d,
  * Must follow a pmbrl_rollout_fwd on the same plan/workspace/inputs.
  * Outputs: grad_pol_flat_d [n_pol_params] (overwritten), optional grad_x0_d
  * [B,D], optional action_grad_norms_d [H,B] (||dL/da_t|| per row, the
- * prioritised-replay hook of algorithms/mc_pilco.py:156-188). */
+ * prioritised-replay hook of algorithms/mc_pilco.py:156-188).
+ * status_d (optional, device int32[2]): status_d[0] is the word pmbrl_rollout_fwd
+ * wrote; the adjoint is taken over the first n = min(H, status_d[0]) steps only --
+ * the truncated horizon the reference continues with after a late failure
+ * (utils/rollout.py:154-157): grad_rewards / grad_actions of steps >= n are ignored,
+ * the terminal state gradient is grad_states[n], action_grad_norms rows >= n are
+ * left untouched.  Read on the device: no host round trip between the sweeps.
+ * status_d[1] is cleared and then set non-zero if the sweep itself failed (the
+ * device-wide barrier of a moment-matching group spanning workgroups timed out).
+ * NULL: the full horizon. */
 int pmbrl_rollout_bwd(pmbrl_plan* plan, void* stream, void* workspace_d,
                       const pmbrl_inputs* in, const float* states_d,
                       const float* actions_d, const float* rewards_d,
                       const float* grad_rewards_d, const float* grad_states_d,
                       const float* grad_actions_d, float* grad_pol_flat_d,
-                      float* grad_x0_d, float* action_grad_norms_d);
+                      float* grad_x0_d, float* action_grad_norms_d, int32_t* status_d);
 
 /* out[0] = sum_i a[i] * w[i]  (the discounted-return loss of
  * algorithms/mc_pilco.py:134-144,190 given w = dL/dr). Deterministic. */
 int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d,
                        int64_t n, float* out_d);
+/* The same over the first min(n_steps, *status_d) blocks of n_per_step entries: the loss of
+ * a truncated horizon (status_d = the word pmbrl_rollout_fwd wrote, read on the device). */
+int pmbrl_weighted_sum_steps(void* stream, const float* a_d, const float* w_d,
+                             int64_t n_per_step, int32_t n_steps, const int32_t* status_d,
+                             float* out_d);
 
 /* torch.nn.utils.clip_grad_norm_ (algorithms/mc_pilco.py:209-210) fused with
  * torch.optim.Adam.step (examples/deep_pilco_mm.py:166; no weight decay, no
@@ -199,7 +213,9 @@ int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d,
 
 /* The same step, decided on the device: taken only if the rollout that produced
  * the gradient completed (*status_d >= expect, status_d = the word
- * pmbrl_rollout_fwd wrote, expect = H), in which case the device-side step
+ * pmbrl_rollout_fwd wrote; expect = H to require the whole horizon, or
+ * min(H, 6) to continue on a truncated horizon of more than 5 steps like
+ * utils/rollout.py:154-157), in which case the device-side step
  * counter *step_d is advanced first and its bias corrections are used;
  * otherwise parameters, moments and counter are left untouched.  This is the
  * reference's "RuntimeError -> skip the optimiser step" (algorithms/

@@ -73,7 +73,7 @@ EXPORTS = [
     'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
     'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
-    'pmbrl_weighted_sum', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
+    'pmbrl_weighted_sum', 'pmbrl_weighted_sum_steps', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
@@ -112,9 +112,11 @@ def load():
     lib.pmbrl_rollout_fwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp, vp]
     lib.pmbrl_rollout_bwd.restype = C.c_int
     lib.pmbrl_rollout_bwd.argtypes = [vp, vp, vp, C.POINTER(Inputs), vp, vp, vp,
-                                      vp, vp, vp, vp, vp, vp]
+                                      vp, vp, vp, vp, vp, vp, vp]
     lib.pmbrl_weighted_sum.restype = C.c_int
     lib.pmbrl_weighted_sum.argtypes = [vp, vp, vp, i64, vp]
+    lib.pmbrl_weighted_sum_steps.restype = C.c_int
+    lib.pmbrl_weighted_sum_steps.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     lib.pmbrl_clip_adam.restype = C.c_int
     f64 = C.c_double
     lib.pmbrl_clip_adam.argtypes = [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64,
@@ -151,8 +153,15 @@ def load():
     return lib
 
 
+class PmbrlError(Exception):
+    """A C-ABI call failed: bad configuration, unsupported shape or a HIP error.  Deliberately NOT a
+    RuntimeError: the reference's control flow treats RuntimeError as "this rollout failed
+    numerically, resample and carry on" (algorithms/mc_pilco.py:122-131, utils/rollout.py:154-157);
+    a usage error must surface instead of being retried for opt_iters iterations."""
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().pmbrl_last_error()
-        raise RuntimeError('%s failed (%d): %s' %
-                           (what, rc, msg.decode() if msg else ''))
+        raise PmbrlError('%s failed (%d): %s' %
+                         (what, rc, msg.decode() if msg else ''))

@@ -21,6 +21,7 @@ import torch
 
 from . import engine as E
 from . import rollout as RO
+from ._lib import PmbrlError
 from .utils import tile
 
 policy_update_counter = defaultdict(lambda: 0)   # algorithms/mc_pilco.py:8
@@ -121,6 +122,12 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     if process_group is not None:
         import torch.distributed as dist
         world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        if world > 1 and (mm_states or mm_rewards) and mm_groups is None:
+            # one Gaussian over ALL particles (the examples' default) would need the per-step
+            # sufficient statistics summed over the ranks; fitting one Gaussian per rank
+            # instead would silently be different mathematics
+            raise NotImplementedError('moment matching over one global group (mm_groups=None) is not offered on '
+                                      'sharded runs: pass mm_groups (whole groups per rank)')
     Bg = N_particles * world
     z_mm = torch.randn(H + Bg, D, device=dev)
     z_rr = torch.randn(H + Bg, 1, device=dev)
@@ -145,7 +152,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     x0 = init_states
     n_opt_steps = policy_update_counter[policy]
     need_autograd = ((cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0) or reg_weight > 0
-                     or value_func is not None or prioritized_replay)
+                     or value_func is not None or prioritized_replay or bool(rollout_kwargs))
     replay = None
     if prioritized_replay:      # algorithms/mc_pilco.py:80-84
         replay = dict(idxs=None, weights=None, beta=init_priority_beta, eps=priority_eps,
@@ -163,13 +170,17 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     pipe = dict(snap=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(2)],
                 ev=[torch.cuda.Event() for _ in range(2)], step_dev=None) if pipelined else None
 
+    # a rollout that failed after more than 5 steps is optimised on its truncated horizon
+    # (utils/rollout.py:154-157); earlier failures skip the step (algorithms/mc_pilco.py:122-131)
+    min_steps = min(H, 6)
+
     def settle(pend):
         """Host side of a pipelined iteration, once its status word has arrived."""
         nonlocal n_opt_steps
         j, ev, snap, loss_j, S_j, A_j, R_j = pend
         ev.synchronize()
-        n_valid = int(snap[0])
-        if n_valid < H:
+        n_valid = min(int(snap[0]), H)
+        if n_valid < min_steps:
             # algorithms/mc_pilco.py:122-131: report, draw new random numbers; the device already
             # skipped the optimiser step
             print('RuntimeError: rollout failed at step %d (iteration %d)' % (n_valid, j))
@@ -177,7 +188,10 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
             return
         n_opt_steps += 1
         if (progress and j % 50 == 0) or callable(on_iteration):
-            states, actions, rewards = list(S_j.unbind(0)), list(A_j.unbind(0)), list(R_j.unbind(0))
+            # fresh tensors, like the reference hands out: the engine's buffers are overwritten by the
+            # next iteration
+            states = list(S_j[:n_valid + 1].clone().unbind(0))
+            actions, rewards = list(A_j[:n_valid].clone().unbind(0)), list(R_j[:n_valid].clone().unbind(0))
             if progress and j % 50 == 0:
                 msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
                 print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
@@ -218,36 +232,46 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     pipe['cache'] = cache
                 S, A, R = bundle.forward(x0_)
                 k = i & 1
-                pipe['snap'][k].copy_(eng.status, non_blocking=True)
+                pipe['snap'][k].copy_(eng.status[0:1], non_blocking=True)
                 pipe['ev'][k].record()
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
                 loss = eng.weighted_sum(R, gw)[0]
                 g, _, _ = eng.backward(gw)
                 grp = cache['group']
                 E.clip_adam_guarded(bundle.pol_flat, g, cache['m'], cache['v'], pipe['step_dev'], grp['lr'],
-                                    eng.status, H, grp['betas'], grp['eps'], max_norm=clip_grad)
+                                    eng.status, min_steps, grp['betas'], grp['eps'], max_norm=clip_grad)
                 pending = (i, pipe['ev'][k], pipe['snap'][k], loss, S, A, R)
                 queued = True
             else:
                 eng = bundle.engine
                 S, A, R = bundle.forward(x0_)
                 n_valid = eng.valid_steps()       # the one host sync of the iteration
+                if world > 1:
+                    # every rank must take the same branch and the same horizon: a failure anywhere
+                    # truncates (or fails) the rollout everywhere, like one process would
+                    import torch.distributed as dist
+                    nv = torch.tensor([n_valid], dtype=torch.int32, device=dev)
+                    dist.all_reduce(nv, op=dist.ReduceOp.MIN, group=process_group)
+                    n_all = int(nv[0])
+                    if n_all < n_valid:
+                        eng.status[0:1].copy_(nv)         # what the adjoint sweep and the loss read
+                        n_valid = n_all
+                if n_valid < min_steps:
+                    raise RuntimeError('rollout failed at step %d' % n_valid)
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
                 loss = eng.weighted_sum(R, gw)[0]
                 if world > 1:
-                    # every rank must take the same branch: a failure anywhere poisons the summed
-                    # loss, which all ranks see after the all-reduce
-                    import torch.distributed as dist
-                    if n_valid < H:
-                        loss = loss + float('inf')
                     loss = loss.reshape(1).clone()
                     dist.all_reduce(loss, group=process_group)
                     loss = loss[0]
-                    if not bool(torch.isfinite(loss)):
-                        raise RuntimeError('rollout failed (step %d on this rank)' % n_valid)
-                elif n_valid < H:
-                    raise RuntimeError('rollout failed at step %d' % n_valid)
-                states, actions, rewards = list(S.unbind(0)), list(A.unbind(0)), list(R.unbind(0))
+                if callable(on_rollout) or callable(on_iteration):
+                    # the hooks get tensors of their own (the engine's buffers are reused by the next
+                    # iteration; the reference hands out fresh tensors)
+                    Sc, Ac, Rc = S.clone(), A.clone(), R.clone()
+                else:
+                    Sc, Ac, Rc = S, A, R
+                states, actions, rewards = list(Sc[:n_valid + 1].unbind(0)), list(Ac[:n_valid].unbind(0)), \
+                    list(Rc[:n_valid].unbind(0))
                 if callable(on_rollout):
                     on_rollout(i, states, actions, rewards, disc)
                 g, _, _ = eng.backward(gw)

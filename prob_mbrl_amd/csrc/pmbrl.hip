@@ -31,7 +31,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
-extern "C" int pmbrl_version(void) { return 1; }
+extern "C" int pmbrl_version(void) { return 2; }
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -94,9 +94,11 @@ __device__ __forceinline__ double pm_block_sum(double s, double* sm) {
 
 __global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __restrict__ a,
                                                               const float* __restrict__ w,
-                                                              long long n, float* __restrict__ out) {
+                                                              long long n, float* __restrict__ out,
+                                                              const int* __restrict__ nvalid, long long n_per_step) {
   __shared__ double sm[256];
   __shared__ unsigned ticket;
+  if (nvalid) n = min(n, (long long)max(0, *nvalid) * n_per_step);   // truncated horizon
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A,
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
+  const bool ins = (A.flags & PMBRL_FLAG_INFER_NS) != 0;
   const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
   const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
   const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
@@ -252,15 +255,25 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A,
     float* out = A.states + ((size_t)(t + 1) * A.B + r0) * A.D;
     bool ok = true;
 #define PM_CALL(DD) ok = pm_mm_fwd_mw<DD>(s, A.D, A.M, zmm, A.D, zrow0, A.Bg, out, A.D, mmscr, part, PM_MM_NW, wid, lane)
-    PM_MM_MW_SWITCH(A.D, PM_CALL,
-                    if (wid == 0) ok = pm_mm_fwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, out, A.D, mmscr, lane))
+    if (ins) {   // infer_noise_variables: the general single-wave routine
+      if (wid == 0) ok = pm_mm_fwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, true, out, A.D, mmscr, lane);
+    } else {
+      PM_MM_MW_SWITCH(A.D, PM_CALL,
+                      if (wid == 0) ok = pm_mm_fwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, out, A.D, mmscr, lane))
+    }
 #undef PM_CALL
     if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
     __syncthreads();
-    const bool ok = pm_mm_fwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg,
-                                    A.rewards + (size_t)t * A.B + r0, 1, mmscr, part, PM_MM_NW, wid, lane);
+    bool ok = true;
+    if (ins) {
+      if (wid == 0) ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, true,
+                                   A.rewards + (size_t)t * A.B + r0, 1, mmscr, lane);
+    } else {
+      ok = pm_mm_fwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg,
+                           A.rewards + (size_t)t * A.B + r0, 1, mmscr, part, PM_MM_NW, wid, lane);
+    }
     if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
   }
 }
@@ -271,6 +284,8 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A,
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
+  if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
+  const bool ins = (A.flags & PMBRL_FLAG_INFER_NS) != 0;
   const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
   const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
   const float* zrr = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
@@ -279,16 +294,24 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A,
     const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
     // in place (g -> g): every read of g happens before the first write (pmbrl_mm.h)
 #define PM_CALL(DD) pm_mm_bwd_mw<DD>(s, A.D, A.M, zmm, A.D, zrow0, A.Bg, g, A.D, g, A.D, mmscr, part, PM_MM_NW, wid, lane)
-    PM_MM_MW_SWITCH(A.D, PM_CALL,
-                    if (wid == 0) pm_mm_bwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, g, A.D, g, A.D, mmscr, lane))
+    if (ins) {
+      if (wid == 0) pm_mm_bwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, true, g, A.D, g, A.D, mmscr, lane);
+    } else {
+      PM_MM_MW_SWITCH(A.D, PM_CALL,
+                      if (wid == 0) pm_mm_bwd(s, A.D, A.M, A.D, zmm, A.D, zrow0, A.Bg, false, g, A.D, g, A.D, mmscr, lane))
+    }
 #undef PM_CALL
   }
   const float* gsrc = A.grad_rewards + (size_t)t * A.B + r0;
   float* gdst = gr_tilde + (size_t)t * A.B + r0;
   if (A.flags & PMBRL_FLAG_MM_REWARDS) {
     __syncthreads();
-    pm_mm_bwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg, gsrc, 1, gdst, 1, mmscr, part,
-                    PM_MM_NW, wid, lane);
+    if (ins) {
+      if (wid == 0) pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, zrr, 1, zrow0, A.Bg, true, gsrc, 1, gdst, 1, mmscr, lane);
+    } else {
+      pm_mm_bwd_mw<1>(A.rt + (size_t)t * A.B + r0, 1, A.M, zrr, 1, zrow0, A.Bg, gsrc, 1, gdst, 1, mmscr, part,
+                      PM_MM_NW, wid, lane);
+    }
   } else {
     for (int i = threadIdx.x; i < A.M; i += PM_MM_NW * 64) gdst[i] = gsrc[i];
   }
@@ -499,8 +522,6 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   if (c.B < 1 || c.D < 1 || c.U < 1 || c.H < 1) return fail(-2, "B, D, U, H must be >= 1");
   if (c.D > 32 || c.U > 16) return fail(-2, "supported widths: D <= 32, U <= 16");
   if (c.reward.k < 1 || c.reward.k > PMBRL_MAX_TIP) return fail(-2, "reward.k out of range");
-  if (c.flags & PMBRL_FLAG_INFER_NS)
-    return fail(-3, "infer_noise_variables is not offered on the device path");
   pmbrl_plan* p = new pmbrl_plan();
   memset(p, 0, sizeof(*p));
   p->cfg = c;
@@ -519,7 +540,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
 
   const bool mm = (c.flags & (PMBRL_FLAG_MM_STATES | PMBRL_FLAG_MM_REWARDS)) != 0;
   const size_t lds_cap = 160 * 1024;
-  p->fast = !(c.flags & PMBRL_FLAG_FORCE_GENERIC) &&
+  // infer_noise_variables (utils/rollout.py:6-17, not a default anywhere) lives in the general
+  // single-wave moment-matching routines only: general kernel family, mm_mode 1 or 2
+  p->fast = !(c.flags & (PMBRL_FLAG_FORCE_GENERIC | PMBRL_FLAG_INFER_NS)) &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   const int LD_generic = p->LD;
@@ -1089,7 +1112,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
                                  const float* rewards_d, const float* grad_rewards_d,
                                  const float* grad_states_d, const float* grad_actions_d,
                                  float* grad_pol_flat_d, float* grad_x0_d,
-                                 float* action_grad_norms_d) {
+                                 float* action_grad_norms_d, int32_t* status_d) {
   if (!p || !workspace || !in || !states_d || !actions_d || !rewards_d || !grad_rewards_d ||
       !grad_pol_flat_d)
     return fail(-1, "null argument");
@@ -1108,6 +1131,11 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.grad_x0 = grad_x0_d;
   A.agn = action_grad_norms_d;
   A.prof = p->prof_bwd;
+  // status_d[0]: valid steps of the forward sweep (the adjoint covers only those); status_d[1]: set by
+  // the sweep if its device-wide barrier timed out
+  A.nvalid = status_d;
+  A.status = status_d ? status_d + 1 : nullptr;
+  if (status_d) HIPCHK(hipMemsetAsync(status_d + 1, 0, sizeof(int32_t), s));
   float* grt = reinterpret_cast<float*>(ws + p->off_grt);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   if (p->fast && mm_r) {
@@ -1184,6 +1212,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   W.blocks = p->dw_blocks_d;
   for (int w = 0; w <= PM_DW_NW; ++w) W.wave_first[w] = p->dw_wave_first[w];
   W.part = reinterpret_cast<float*>(ws + p->off_part);
+  W.nvalid = status_d;
+  W.chunks_per_step = p->nwg * p->RT;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW, s);
     hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
@@ -1192,7 +1222,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
     hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
-                       W.part_stride, grad_pol_flat_d);
+                       W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1494,7 +1524,7 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
   W.part = reinterpret_cast<float*>(ws + p->off_part);
   hipLaunchKernelGGL(pm_dw_kernel, dim3(p->nwg), dim3(PM_DW_NT), 0, s, W);
   hipLaunchKernelGGL(pm_dw_reduce, dim3((p->n_params + 255) / 256), dim3(512), 0, s, W.part, p->nwg, p->n_params,
-                     p->part_stride, grad_flat_d);
+                     p->part_stride, grad_flat_d, (const int*)nullptr, 0, 1);
   }
   BnnFinishArgs Fa;
   memset(&Fa, 0, sizeof(Fa));
@@ -1524,7 +1554,18 @@ extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w
   if (!a_d || !w_d || !out_d || n < 0) return fail(-1, "bad argument");
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 2047) / 2048));
   hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a_d, w_d,
-                     (long long)n, out_d);
+                     (long long)n, out_d, (const int*)nullptr, 0ll);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_weighted_sum_steps(void* stream, const float* a_d, const float* w_d, int64_t n_per_step,
+                                        int32_t n_steps, const int32_t* status_d, float* out_d) {
+  if (!a_d || !w_d || !out_d || n_per_step < 0 || n_steps < 0) return fail(-1, "bad argument");
+  const long long n = (long long)n_per_step * n_steps;
+  const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 2047) / 2048));
+  hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a_d, w_d, n, out_d,
+                     (const int*)status_d, (long long)n_per_step);
   HIPCHK(hipGetLastError());
   return 0;
 }

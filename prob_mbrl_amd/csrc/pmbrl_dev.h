@@ -95,7 +95,8 @@ struct RolloutArgs {
   double* mmfac;          // in-kernel moment matching: statistics + factor per (step, group), forward -> adjoint
   int mmfac_groups;       // groups per step in mmfac (= B / M)
   float *Jx, *Ja;         // reward Jacobian d r~/d x~ [H][B][D], d r~/d a [H][B][U] (fast kernels)
-  int* status;
+  int* status;          // forward: number of valid steps (atomicMin); backward: failure flag of the sweep (or nullptr)
+  const int* nvalid;    // backward: the forward's status word; the sweep covers steps t < min(t1, *nvalid) (nullptr: t1)
   // backward only
   const float *grad_rewards, *grad_states, *grad_actions;
   float* gx_carry_out;   // mm_mode 3: the carried gradient is written here (ping-pong with gx_carry)

@@ -43,6 +43,8 @@ struct DwArgs {
   int w_off[PM_MAXL], b_off[PM_MAXL];    // offsets in the flat parameter vector
   const float* actT[PM_MAXL];
   const float* gT[PM_MAXL];
+  const int* nvalid;                     // forward status word: only chunks of steps t < *nvalid exist (nullptr: all)
+  int chunks_per_step;                   // nwg * RT
   const DwBlock* blocks;                 // sorted by wave
   int wave_first[PM_DW_NW + 1];          // wave w owns blocks [wave_first[w], wave_first[w+1])
   float* part;                           // [nsplit][n_params]
@@ -182,8 +184,12 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
   const int c_lo = split * A.chunks_per_split;
-  const int c_hi = min(A.n_chunks, c_lo + A.chunks_per_split);
-  if (c_lo >= c_hi) return;
+  int n_chunks = A.n_chunks;
+  if (A.nvalid)   // (the status word is INT_MAX after a complete sweep: 64-bit product)
+    n_chunks = (int)min((long long)n_chunks,
+                        (long long)max(0, __builtin_amdgcn_readfirstlane(*A.nvalid)) * A.chunks_per_step);
+  const int c_hi = min(n_chunks, c_lo + A.chunks_per_split);
+  if (c_lo >= c_hi) return;                // (pm_dw_reduce skips the splits without chunks)
   float* part = A.part + (size_t)split * A.part_stride;
   for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
     const DwBlock blk = A.blocks[bi];
@@ -196,8 +202,14 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
 // grad[i] = sum_s part[s][i] in fixed order.  A workgroup = 64 float4 columns x 8 slices of the
 // split range: every wave reads whole 1 KiB rows, a thread keeps 8 independent loads in flight.
 __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
-                                                    int stride, float* __restrict__ grad) {
+                                                    int stride, float* __restrict__ grad,
+                                                    const int* __restrict__ nvalid = nullptr, int chunks_per_step = 0,
+                                                    int chunks_per_split = 1) {
   __shared__ f32x4 sm[8][64];
+  if (nvalid) {   // truncated horizon: only the splits that own a chunk of a valid step wrote a partial
+    const long long nc = (long long)max(0, *nvalid) * chunks_per_step;
+    nsplit = (int)min((long long)nsplit, (nc + chunks_per_split - 1) / chunks_per_split);
+  }
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c4 = blockIdx.x * 64 + col;            // float4 column
   const int per = (nsplit + 7) / 8;

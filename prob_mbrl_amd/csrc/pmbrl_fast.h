@@ -779,6 +779,7 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
   extern __shared__ __attribute__((aligned(16))) double mmscr_r[];
   const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
   const int r0 = gi * A.M;
+  if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
   pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
             pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false, A.grad_rewards + (size_t)t * A.B + r0, 1,
             gr_tilde + (size_t)t * A.B + r0, 1, mmscr_r, lane);
@@ -1474,7 +1475,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
                    SH::NT ? (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB) : 0,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
-  const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
+  // Truncated horizon (utils/rollout.py:154-157): the sweep covers only the steps the forward sweep
+  // completed, read from its status word on the device (no host round trip in between).
+  const int T0 = EXT ? A.t0 : 0;
+  int T1 = EXT ? A.t1 : A.H;
+  if (A.nvalid) T1 = min(T1, __builtin_amdgcn_readfirstlane(*A.nvalid));
   if (EXT && A.prof && blockIdx.x == 0 && threadIdx.x == 0)      // kernel entry (per-step launches: prologue cost)
     A.prof[(size_t)T0 * 32 + 30] = (long long)__builtin_readcyclecounter();
   const bool mm_states = EXT && (A.flags & PMBRL_FLAG_MM_STATES);
@@ -1488,6 +1493,19 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
+  if (T1 <= T0) {
+    // nothing to sweep (a step of a per-step launch sequence past the valid horizon, or no valid step
+    // at all): hand the incoming gradient on unchanged
+    for (int i = tid; i < nvalid * D; i += PF_NT) {
+      const size_t o = (size_t)row0 * D + i;
+      float v = 0.f;
+      if (EXT && A.gx_from_carry) v = A.gx_carry[o];
+      else if (EXT && A.grad_states) v = A.grad_states[(size_t)T0 * B * D + o];
+      if (EXT && A.gx_carry && !(MMG && mm_states)) (A.gx_carry_out ? A.gx_carry_out : A.gx_carry)[o] = v;
+      if (T0 == 0 && A.grad_x0) A.grad_x0[o] = v;
+    }
+    return;
+  }
   FastLds L = pm_fast_carve_shaped<SH, RT>(smem, P, F, R, LD, D, U);
   float* gx = L.xa;     // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;    // moment-matching adjoint of gx (in-kernel mm only)
@@ -1543,7 +1561,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     float v = 0.f;
     if (r < nvalid) {
       if (EXT && A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
-      else if (EXT && A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
+      else if (EXT && A.grad_states) v = A.grad_states[((size_t)T1 * B + row0 + r) * D + d];
     }
     gx[i] = v;
   }
@@ -1673,7 +1691,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       float* carry = ((T1 - 1 - t) & 1) ? A.gx_carry_out : A.gx_carry;
       __syncthreads();
       for (int i = tid; i < nvalid * D; i += PF_NT) pm_st_dev(carry + (size_t)row0 * D + i, gx[i]);
-      if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t)) && tid == 0) atomicMin(A.status, t);
+      if (!pm_grid_barrier(A.gsync, (unsigned)(T1 - t)) && tid == 0 && A.status) atomicMax(A.status, 1);
       PF_MARK(28);
       mm_span_bwd(t, carry, std::true_type{});
       PF_MARK(29);

@@ -156,13 +156,22 @@ __device__ __forceinline__ bool pm_mm_factor(const float* s, int s_ld, int M, in
 __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
                                  int zrow0, int Bg, bool infer_ns, float* out, int out_ld,
                                  double* scr, int lane, double* fac_out = nullptr) {
-  (void)infer_ns;   // value of the infer_ns variant equals s; not offered on the device path
   const MMScratch q = pm_mm_carve(scr, d);
   const bool ok = pm_mm_factor(s, s_ld, M, d, z, z_ld, zrow0, Bg, q, lane);
   // the adjoint needs the same means / standardisation / factor: hand them over instead of
   // having it redo the statistics and the factorisation (pm_mm_fac_doubles values)
   if (fac_out)
     for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) fac_out[e] = scr[e];
+  if (infer_ns) {
+    // utils/rollout.py:6-17 (mm_resample_infer_ns_): zhat = Delta L^-T, so m + zhat L^T is the input
+    // again (the reference gets it back up to rounding); only the gradient differs -- pm_mm_bwd
+    for (int e = lane; e < M * d; e += 64) {
+      const int r = e / d, j = e - r * d;
+      out[r * out_ld + j] = s[r * s_ld + j];
+    }
+    pm_wave_sync();
+    return ok;
+  }
   for (int e = lane; e < M * d; e += 64) {
     const int r = e / d, j = e - r * d;
     double acc = q.mean[j];
@@ -180,7 +189,6 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
                                  int zrow0, int Bg, bool infer_ns, const float* g, int g_ld,
                                  float* gout, int gout_ld, double* scr, int lane,
                                  const double* fac = nullptr) {
-  (void)infer_ns;
   const MMScratch q = pm_mm_carve(scr, d);
   if (fac) {
     for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) scr[e] = fac[e];
@@ -223,6 +231,36 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
     }
   }
   pm_wave_sync();
+  if (infer_ns) {
+    // zhat = Delta L^-T (constant): Lbar = tril(g^T zhat) = tril((g^T Delta) L^-T).
+    // A = g^T Delta -> q.Sb, then row i of A L^-T by forward substitution (x L^T = A_i) -> q.P
+    {
+      const int e2 = pm_pow2ceil(d * d);
+      const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
+      const int part = lane % P;
+      for (int base = 0; base < d * d; base += per) {
+        const int e = base + lane / P;
+        const int i = e / d, j = e - i * d;
+        double acc = 0.0;
+        if (e < d * d) {
+          const double mj = q.mean[j];
+          for (int r = part; r < M; r += P) acc += (double)g[r * g_ld + i] * ((double)s[r * s_ld + j] - mj);
+        }
+        acc = pm_seg_sum(acc, P);
+        if (e < d * d && part == 0) q.Sb[e] = acc;
+      }
+    }
+    pm_wave_sync();
+    for (int i = lane; i < d; i += 64) {
+      for (int j = 0; j < d; ++j) {
+        double a = q.Sb[i * d + j];
+        for (int c = 0; c < j; ++c) a -= q.P[i * d + c] * q.Lm[j * d + c];
+        q.P[i * d + j] = a * q.invd[j];       // full row first (x_c for c < j feeds x_j) ...
+      }
+      for (int j = i + 1; j < d; ++j) q.P[i * d + j] = 0.0;   // ... then keep the lower triangle
+    }
+    pm_wave_sync();
+  }
   // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
   for (int e = lane; e < d * d; e += 64) {
     const int i = e / d, j = e - i * d;

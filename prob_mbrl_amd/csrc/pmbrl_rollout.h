@@ -409,20 +409,22 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
   const NetDev& F = A.dyn;
   const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
   const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+  // truncated horizon (utils/rollout.py:154-157): only the steps the forward sweep completed
+  const int T1 = A.nvalid ? min(A.t1, *A.nvalid) : A.t1;
 
-  // dL/dx_H: zero, the carried value from the previous launch, or the terminal grad_states
+  // dL/dx_T1: zero, the carried value from the previous launch, or the terminal grad_states
   for (int i = tid; i < R * D; i += PM_NT) {
     const int r = i / D, d = i - r * D;
     float v = 0.f;
     if (r < nvalid) {
       if (A.gx_from_carry) v = A.gx_carry[(size_t)(row0 + r) * D + d];
-      else if (A.grad_states) v = A.grad_states[((size_t)A.H * B + row0 + r) * D + d];
+      else if (A.grad_states) v = A.grad_states[((size_t)T1 * B + row0 + r) * D + d];
     }
     gx[i] = v;
   }
   __syncthreads();
 
-  for (int t = A.t1 - 1; t >= A.t0; --t) {
+  for (int t = T1 - 1; t >= A.t0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;

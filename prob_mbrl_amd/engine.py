@@ -254,7 +254,7 @@ class Engine:
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
-                 force_generic=False, no_shaped=False):
+                 force_generic=False, no_shaped=False, infer_ns=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -267,6 +267,7 @@ class Engine:
         cfg.flags = ((_lib.FLAG_MM_STATES if mm_states else 0) |
                      (_lib.FLAG_MM_REWARDS if mm_rewards else 0) |
                      (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0) |
+                     (_lib.FLAG_INFER_NS if infer_ns else 0) |
                      (_lib.FLAG_FORCE_GENERIC if force_generic else 0) |
                      (_lib.FLAG_NO_SHAPED if no_shaped else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
@@ -306,8 +307,10 @@ class Engine:
         self.states = torch.empty((H + 1, B, D), dtype=torch.float32, device=dev)
         self.actions = torch.empty((H, B, U), dtype=torch.float32, device=dev)
         self.rewards = torch.empty((H, B, 1), dtype=torch.float32, device=dev)
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # [0]: valid steps of the last forward sweep, [1]: failure flag of the last adjoint sweep
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
         self.grad_flat = torch.empty(self.n_pol_params, dtype=torch.float32, device=dev)
+        self._traj = (self.states, self.actions, self.rewards)
         self._inputs = None
         self._keep = None
         self.generation = 0    # bumped by every forward(); backward must match
@@ -373,22 +376,29 @@ class Engine:
         inp.z_rr = z_rr.data_ptr() if z_rr is not None else None
         self._inputs = inp
         self._keep = (t, z_mm, z_rr, list(pol_mask_bits), list(dyn_mask_bits))
-        if out is not None:
-            self.states, self.actions, self.rewards = out
-            assert self.states.shape == (self.H + 1, self.B, self.D) and self.states.is_contiguous()
-            assert self.actions.shape == (self.H, self.B, self.U) and self.actions.is_contiguous()
-            assert self.rewards.numel() == self.H * self.B and self.rewards.is_contiguous()
+        # `out`: the caller's tensors receive this rollout's trajectory and are what backward() reads;
+        # they are NOT adopted as the engine's own buffers (engines are shared between callers by
+        # shape: a later rollout must not write into tensors an earlier one handed out)
+        S, A, R = out if out is not None else (self.states, self.actions, self.rewards)
+        assert S.shape == (self.H + 1, self.B, self.D) and S.is_contiguous()
+        assert A.shape == (self.H, self.B, self.U) and A.is_contiguous()
+        assert R.numel() == self.H * self.B and R.is_contiguous()
+        self._traj = (S, A, R)
         self.generation += 1
         _lib.check(self.lib.pmbrl_rollout_fwd(self.plan, _stream(), self._ws_ptr, C.byref(inp),
-                                              _ptr(self.states), _ptr(self.actions),
-                                              _ptr(self.rewards), _ptr(self.status)),
+                                              _ptr(S), _ptr(A), _ptr(R), _ptr(self.status)),
                    'pmbrl_rollout_fwd')
-        return self.states, self.actions, self.rewards
+        return S, A, R
 
     def valid_steps(self):
         """Host sync: number of steps completed before a numerical failure (H if none)."""
-        s = int(self.status.item())
+        s = int(self.status[0].item())
         return self.H if s >= self.H else s
+
+    def sweep_failed(self):
+        """Host sync: did the last adjoint sweep report a failure of its own (device-wide barrier of a
+        moment-matching group spanning workgroups timed out)?"""
+        return int(self.status[1].item()) != 0
 
     def backward(self, grad_rewards, grad_states=None, grad_actions=None, want_x0=False,
                  want_agn=False):
@@ -403,11 +413,13 @@ class Engine:
             assert ga.shape == (self.H, self.B, self.U)
         gx0 = torch.empty((self.B, self.D), dtype=torch.float32, device=dev) if want_x0 else None
         agn = torch.empty((self.H, self.B), dtype=torch.float32, device=dev) if want_agn else None
+        S, A, R = self._traj
+        # the status word makes the adjoint cover exactly the steps the forward sweep completed
+        # (truncated horizon, utils/rollout.py:154-157), decided on the device
         _lib.check(self.lib.pmbrl_rollout_bwd(self.plan, _stream(), self._ws_ptr,
-                                              C.byref(self._inputs), _ptr(self.states),
-                                              _ptr(self.actions), _ptr(self.rewards), _ptr(gr),
+                                              C.byref(self._inputs), _ptr(S), _ptr(A), _ptr(R), _ptr(gr),
                                               _ptr(gs), _ptr(ga), _ptr(self.grad_flat), _ptr(gx0),
-                                              _ptr(agn)),
+                                              _ptr(agn), _ptr(self.status)),
                    'pmbrl_rollout_bwd')
         return self.grad_flat, gx0, agn
 
@@ -422,12 +434,16 @@ class Engine:
 
     # ------------------------------------------------------------------
     def weighted_sum(self, a, w, out=None):
+        """sum_{t < n, b} a[t, b] w[t, b] over the n valid steps of the last forward sweep (the status
+        word is read on the device); a, w: [H, B(,1)]."""
         a = _f32c(a.reshape(-1), self.device)
         w = _f32c(w.reshape(-1), self.device)
+        assert a.numel() == self.H * self.B and w.numel() == a.numel()
         if out is None:
             out = torch.empty(1, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pmbrl_weighted_sum(_stream(), _ptr(a), _ptr(w), a.numel(), _ptr(out)),
-                   'pmbrl_weighted_sum')
+        _lib.check(self.lib.pmbrl_weighted_sum_steps(_stream(), _ptr(a), _ptr(w), self.B, self.H,
+                                                     _ptr(self.status), _ptr(out)),
+                   'pmbrl_weighted_sum_steps')
         return out
 
 

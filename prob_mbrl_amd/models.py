@@ -58,6 +58,9 @@ class BDropout(StochasticModule):
             torch.manual_seed(int(seed))
         self.p = 1 - self.rate
         self.noise.data = torch.bernoulli(self.p.expand(x.shape).to(self.noise.device))
+        # `.data =` keeps the tensor's version counter and the allocator may hand back a previously
+        # used address: the packed-bit cache of the rollout keys on this counter as well
+        self._mask_gen = getattr(self, '_mask_gen', 0) + 1
 
     # --- what the fused rollout needs -------------------------------------
     def keep_prob(self):
@@ -128,6 +131,7 @@ class CDropout(BDropout):
         if seed is not None:
             torch.manual_seed(int(seed))
         self.noise.data = torch.rand(x.shape, device=self.noise.device, dtype=self.noise.dtype)
+        self._mask_gen = getattr(self, '_mask_gen', 0) + 1
         if not self.training:
             self.update_concrete_noise(self.noise)
 
@@ -139,6 +143,7 @@ class CDropout(BDropout):
         forced = getattr(self, '_forced_sample', None)      # tests: replay recorded draws
         hard = torch.bernoulli(probs) if forced is None else forced.to(probs)
         self.concrete_noise = (hard - probs).detach() + probs
+        self._mask_gen = getattr(self, '_mask_gen', 0) + 1
         self.p = self.logit_p.sigmoid()
 
     def keep_prob(self):
@@ -394,6 +399,9 @@ class _Loadable(nn.Module):
         for k, v in state_dict.items():
             if k in own:
                 own[k].data = v.data.clone().to(own[k].device)
+        for m in self.modules():      # stored masks may have changed under an unchanged version counter
+            if isinstance(m, BDropout):
+                m._mask_gen = getattr(m, '_mask_gen', 0) + 1
 
     def regularization_loss(self):
         return self.model.regularization_loss()

@@ -199,7 +199,7 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    reward_spec_from_problem(d), mm_states=bool(d['mm_states']),
                    mm_rewards=bool(d['mm_rewards']), mm_groups=Gl, device=dev, B_global=Bg,
                    row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic,
-                   no_shaped=no_shaped)
+                   no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
     args = dict(
         x0=T(d['x0'][lo:hi]), pol_flat=T(flat_params(d, 'pol')), dyn_flat=T(flat_params(d, 'dyn')),

@@ -57,6 +57,11 @@ def modules_from_fixture(d, name, device='cuda:0'):
         rew = pm.rewards.PendulumReward(pole_length=torch.tensor(1.0))
     elif name.startswith('rdv') or name.endswith('_u4'):
         rew = pm.rewards.RendezvousReward()
+    elif name.startswith('c5'):
+        rew = pm.rewards.LinearFeatureReward(torch.tensor(np.asarray(d['rew_C'], dtype=np.float32)),
+                                             torch.tensor(np.asarray(d['rew_tip_target'], dtype=np.float32)),
+                                             torch.tensor(np.asarray(d['rew_Q'], dtype=np.float32)),
+                                             torch.tensor(np.asarray(d['rew_R'], dtype=np.float32)))
     else:
         rew = pm.rewards.CartpoleReward(pole_length=torch.tensor(0.5))
     dyn = pm.models.DynamicsModel(

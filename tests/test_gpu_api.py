@@ -16,7 +16,7 @@ def _flat_grad(pol):
     return torch.cat([t.grad.reshape(-1) for l in lins for t in (l.weight, l.bias)]).cpu().numpy()
 
 
-@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if 'infer' not in n])
+@pytest.mark.parametrize('name', common.fixture_names('iter'))
 def test_rollout_autograd_matches_reference(name):
     """utils.rollout + the reference's loss + loss.backward() (algorithms/mc_pilco.py:134-197)."""
     import prob_mbrl_amd as pm
@@ -28,7 +28,8 @@ def test_rollout_autograd_matches_reference(name):
     kw = {}
     if bool(d['mm_states']):
         kw = dict(mm_states=True, mm_rewards=True, mm_groups=G if G > 0 else None,
-                  z_mm=torch.tensor(d['z_mm'], device=DEV), z_rr=torch.tensor(d['z_rr'], device=DEV))
+                  z_mm=torch.tensor(d['z_mm'], device=DEV), z_rr=torch.tensor(d['z_rr'], device=DEV),
+                  infer_noise_variables=bool(d['infer_ns']) if 'infer_ns' in d else False)
     states, actions, rewards = pm.utils.rollout(x0, dyn, pol, H, resample_state_noise=False,
                                                 resample_action_noise=False, **kw)
     assert len(states) == H + 1 and len(actions) == H and len(rewards) == H
@@ -64,6 +65,8 @@ def test_mc_pilco_matches_reference_iterations(name):
         x0, dyn, pol, int(d['H']), opt, None, int(d['mcp_n_iters']), mm_states=bool(d['mm_states']),
         mm_rewards=bool(d['mm_rewards']), mm_groups=G if G > 0 else None, maximize=True,
         clip_grad=float(d['mcp_clip']), discount=disc,
+        cvar_eps=float(d['mcp_cvar_eps']) if 'mcp_cvar_eps' in d else 0.0,       # algorithms/mc_pilco.py:146-154
+        reg_weight=float(d['mcp_reg_weight']) if 'mcp_reg_weight' in d else 0.0,  # algorithms/mc_pilco.py:193-194
         on_iteration=lambda i, loss, *a: losses.append(float(loss)),
         frozen_noise=dict(z_mm=torch.tensor(d['z_mm']), z_rr=torch.tensor(d['z_rr'])))
     assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
@@ -75,6 +78,46 @@ def test_mc_pilco_matches_reference_iterations(name):
     assert int(st['step']) == int(d['mcp_n_iters'])
     m = torch.cat([opt.state[t]['exp_avg'].reshape(-1) for l in lins for t in (l.weight, l.bias)])
     assert np.allclose(m.cpu().numpy(), d['ref32_mcp_exp_avg'], rtol=1e-3, atol=1e-7)
+
+
+def test_rollout_truncated_horizon_matches_reference(monkeypatch):
+    """rollout() after a failure in step 8 of 12 (> 5 steps done): the caller gets the first 8 steps
+    and optimises on them, like the reference (utils/rollout.py:154-157); fixture from the
+    reference's own rollout.  The failure is injected where the host learns about it (the status
+    word read by Engine.valid_steps); the trajectory tensors behind step 8 are poisoned."""
+    import prob_mbrl_amd as pm
+    from prob_mbrl_amd import engine as E
+    d = common.load('trunc_mm')
+    n = int(d['fail_step'])
+    dyn, pol = common.modules_from_fixture(d, 'trunc_mm', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    H = int(d['H'])
+    real = E.Engine.valid_steps
+
+    def failing(self):
+        assert real(self) == H
+        self.status[0] = n
+        S, A, R = self._traj
+        S[n + 1:], A[n:], R[n:] = float('nan'), float('nan'), float('nan')
+        return n
+
+    monkeypatch.setattr(E.Engine, 'valid_steps', failing)
+    states, actions, rewards = pm.utils.rollout(
+        x0, dyn, pol, H, resample_state_noise=False, resample_action_noise=False, mm_states=True,
+        mm_rewards=True, z_mm=torch.tensor(d['z_mm'], device=DEV), z_rr=torch.tensor(d['z_rr'], device=DEV))
+    assert len(states) == n + 1 and len(actions) == n and len(rewards) == n
+    gamma = [float(g) for g in d['gamma']]
+    loss = (-torch.stack([r * gamma[i] for i, r in enumerate(rewards)]).sum(0)).mean()
+    pol.zero_grad()
+    loss.backward()
+    assert common.rel(torch.stack(states).detach().cpu().numpy(), d['ref64_states']) < 2e-5
+    assert abs(float(loss) - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+    g = _flat_grad(pol)
+    assert np.all(np.isfinite(g)) and common.rel(g, d['ref64_grad']) < 1e-4
+    # five steps or fewer: the reference re-raises (utils/rollout.py:155-157)
+    monkeypatch.setattr(E.Engine, 'valid_steps', lambda self: 5)
+    with pytest.raises(RuntimeError):
+        pm.utils.rollout(x0, dyn, pol, H, resample_state_noise=False, resample_action_noise=False)
 
 
 def test_mc_pilco_autograd_path_options():

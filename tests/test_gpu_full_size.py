@@ -150,3 +150,44 @@ def test_wide_network_general_family_matches_oracle():
     assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
     assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
     assert common.rel(g, g64.numpy()) < 1e-4
+
+
+def test_c5_shape_matches_oracle():
+    """BASELINE.json configs[4] (D=32, U=8, 3 x 512 both nets, H=100, generic reward) on the general
+    kernel family, at a row count the fp64 oracle finishes in seconds (8 particles x 64 samples)."""
+    from oracle import ref_torch as R
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem('stress32', seed=0, data_seed=0, P=8, S=64))
+    assert int(d['H']) == 100 and d['x0'].shape == (512, 32) and d['pol_W1'].shape == (512, 512)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    assert eng.info['fast'] == 0
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(16)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, False, False, None,
+                                            z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert common.rel(A, torch.stack(A64).detach().numpy()) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
+    # 32-row workgroups (what the full-size configuration runs): same results up to summation order
+    eng2, S2, A2, Rw2, loss2, g2, _ = _run(d, rows_per_wg_hint=32)
+    assert eng2.info['rows_per_wg'] == 32
+    assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
+
+
+def test_c4_full_size_matches_oracle():
+    """BASELINE.json configs[3], one GPU's share: D=6, 100 x 50 rows in 50-row moment-matching groups,
+    the real horizon H=60, against the fp64 oracle."""
+    from oracle import ref_torch as R
+    d = _problem('dcartpole_mm')
+    assert int(d['H']) == 60 and d['x0'].shape == (5000, 6)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    assert eng.info['fast'] == 1 and eng.info['mm_mode'] == 1 and eng.info['rows_per_wg'] == 50
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(16)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,
+                                            meta['mm_groups'], z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert common.rel(Rw.reshape(60, 5000), torch.stack(R64).detach().numpy().reshape(60, 5000)) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
