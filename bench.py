@@ -7,9 +7,10 @@ synthetic Cartpole-shaped problem (BASELINE.json configs[1]: |x|=4, |u|=1,
   fused rollout forward -> discounted-return loss -> adjoint sweep -> dW GEMM ->
   [RCCL all-reduce of the flat policy gradient when N > 1] -> fused clip + Adam.
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU
-(torch.distributed, backend nccl = RCCL), every rank owns its own 2500 rows of a
-global batch of N*2500 (weak scaling), the only collective is the gradient
-all-reduce.
+(torch.distributed, backend nccl = RCCL); the only collective is the gradient
+all-reduce.  --scaling weak (default): every rank owns its own 2500 rows of a
+global batch of N*2500; --scaling strong: the 100 x 25 = 2500 rows of BASELINE.json's
+metric are divided over the N ranks (whole particle groups per rank).
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA (the 2:1-sparsity figure is not used)
+N_CUS = 256
 
 
 def parse():
@@ -36,6 +39,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='cartpole_nomm')
     ap.add_argument('--rows-per-wg', type=int, default=0)
+    ap.add_argument('--precision', default=None, choices=['f32', 'split', 'split_f16'],
+                    help='arithmetic of the hidden-width GEMMs (default: the library default)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='N > 1: per-GPU rows fixed (weak) or the global 100 x 25 rows divided over the GPUs (strong)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
@@ -92,7 +99,7 @@ def cpu_baseline(d, budget_s=24.0):
     ncpu = os.cpu_count() or 1
     best = None
     tried = []
-    for threads in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+    for threads in sorted({1, min(8, ncpu), min(32, ncpu)}):
         torch.set_num_threads(threads)
         x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float32)
         params = R.policy_params(pol)
@@ -110,10 +117,11 @@ def cpu_baseline(d, budget_s=24.0):
                     R.adam_step(p, gg, m, v, step, 1e-4)
 
         it(1)
+        it(2)                      # two warm-ups, then >= 10 timed iterations unless the budget runs out
         times = []
         t_start = time.perf_counter()
-        step = 2
-        while len(times) < 6 and (time.perf_counter() - t_start) < budget_s / 4:
+        step = 3
+        while len(times) < 10 and (time.perf_counter() - t_start) < budget_s / 3:
             t0 = time.perf_counter()
             it(step)
             times.append(time.perf_counter() - t0)
@@ -123,10 +131,12 @@ def cpu_baseline(d, budget_s=24.0):
         if best is None or med < best[1]:
             best = (threads, med, len(times))
     threads, med, n = best
+    one = [m for t, m, _ in tried if t == 1][0]
     return dict(value=B / med, unit='rollouts/s', cores=threads, kind='port',
-                sample='%d full iterations (B=%d rows, H=%d) per thread setting, median; tried %s' %
-                       (n, B, int(d['H']), ', '.join('%dT:%.0fms' % (t, m * 1e3) for t, m, _ in tried)),
-                ms_per_step=med * 1e3, host_cpus=ncpu)
+                sample='full iterations (B=%d rows, H=%d) after 2 warm-ups, median per thread setting; tried %s' %
+                       (B, int(d['H']), ', '.join('%dT:%.0fms(n=%d)' % (t, m * 1e3, k) for t, m, k in tried)),
+                ms_per_step=med * 1e3, host_cpus=ncpu,
+                one_thread=dict(value=B / one, ms_per_step=one * 1e3))   # the reference's default (examples/deep_pilco_mm.py:21,65)
 
 
 def main():
@@ -152,12 +162,19 @@ def main():
     torch.cuda.set_device(dev)
 
     from prob_mbrl_amd import engine as E
-    d = PB.synthetic_problem(a.config, seed=0, data_seed=rank)
+    if a.scaling == 'strong' and world > 1:
+        # the SAME global problem for every N: its particle groups are dealt to the ranks
+        cfg = PB.CONFIGS[a.config]
+        assert cfg['P'] % world == 0, 'strong scaling: the particle count must divide by the GPU count'
+        dg = PB.synthetic_problem(a.config, seed=0, data_seed=0)
+        d = PB.shard_problem(dg, rank, world)
+    else:
+        d = PB.synthetic_problem(a.config, seed=0, data_seed=rank)
     B = d['x0'].shape[0]
     H = int(d['H'])
     Bg = B * world
     eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=a.rows_per_wg, B_global=Bg,
-                                          row_offset=rank * B)
+                                          row_offset=rank * B, precision=a.precision)
     gw = torch.tensor(PB.loss_weights(d, Bg)[:, :B].copy(), device=dev)
     params = args['pol_flat'].clone()
     args['pol_flat'] = params
@@ -221,17 +238,34 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes);
         # only valid for the configuration they were collected on
-        traffic = None
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_traffic.json')))
+            src = 'profiles/r02_pmc_traffic_%s.json' % prec
+            pmc = json.load(open(os.path.join(ROOT, src)))
             if a.config == 'cartpole_nomm' and world == 1 and kname in pmc['kernels']:
                 traffic = pmc['kernels'][kname]['hbm_bytes_per_launch']
+                traffic_src = src + ' (rocprofv3 --pmc passes of this command, not measured in this run)'
         except Exception:
             traffic = None
+        prec = eng.info['precision']
+        # peak the dominant kernel is priced against: the dense MFMA peak of the instruction it issues --
+        # exact fp32 MFMA, or fp16 / bf16 MFMA at THREE instructions per fp32-equivalent product (two-piece
+        # split operands; the three-piece bf16 forward of 'split' issues six)
+        mfma_per_product = {('f32', 'fwd'): 1, ('f32', 'bwd'): 1, ('split', 'fwd'): 6, ('split', 'bwd'): 3,
+                            ('split_f16', 'fwd'): 3, ('split_f16', 'bwd'): 3}.get((prec, dom), 1)
+        if prec == 'f32' or dom == 'dw':
+            peak, peak_note = PEAK_F32_MFMA_TFLOPS, 'v_mfma_f32_16x16x4_f32 dense peak'
+        else:
+            peak = PEAK_F16_MFMA_TFLOPS / mfma_per_product
+            peak_note = ('v_mfma_f32_16x16x32_%s dense peak (2500 TFLOP/s) / %d MFMAs per fp32-equivalent product' %
+                         ('f16' if (prec == 'split_f16' and dom == 'fwd') else 'bf16', mfma_per_product))
+        dtype = {'f32': 'f32', 'split': 'f32 via split bf16 MFMA (3 pieces fwd / 2 adjoint), fp32 accumulate',
+                 'split_f16': 'f32 via split fp16 (fwd, 2 pieces) / bf16 (adjoint, 2 pieces) MFMA, fp32 accumulate'}[prec]
         out = dict(
             metric='particle_rollouts_per_sec', value=Bg * a.steps / dt, unit='rollouts/s',
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+            higher_is_better=True, scaling=a.scaling if world > 1 else 'weak', vs_baseline=None, dtype=dtype,
+            data='synthetic',
             config=dict(workload='%s: D=%d U=%d pol=%s dyn=%s rows/GPU=%d (%s) H=%d mm=%s; full '
                                  'iteration = rollout fwd + loss + adjoint + dW + %sclip + Adam' %
                                  (a.config, d['x0'].shape[1], d['pol_z'].shape[1],
@@ -239,14 +273,21 @@ def main():
                                   'particles x samples', H, bool(d['mm_states']),
                                   'RCCL all-reduce + ' if world > 1 else ''),
                         rows_per_gpu=B, global_rows=Bg, horizon=H, parallelism='dp%d' % world,
-                        rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
+                        precision=prec, rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
+                        cu_occupancy='%d of %d CUs hold a workgroup' % (min(eng.info['n_wg'], N_CUS), N_CUS),
                         mm_mode=eng.info['mm_mode'], mm_grid=eng.info.get('mm_grid', 0), **({'debug_one_device': True} if a.one_device else {})),
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
             roofline=dict(bound='mfma', kernel=kname,
-                          achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                          frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
+                          achieved=achieved, peak=peak, unit='TFLOP/s',
+                          frac=achieved / peak, traffic=traffic,
+                          traffic_source=traffic_src,
+                          peak_is=peak_note, frac_of_f32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
+                          # what binds this kernel at this size is not the matrix pipe: per-workgroup latency
+                          # of H sequential steps on %d of 256 CUs, and the weight stream L2 -> CU
+                          binding='latency: H sequential steps per workgroup, %d of %d CUs occupied; '
+                                  'weight stream L2->CU inside a step' % (min(eng.info['n_wg'], N_CUS), N_CUS),
                           flops_per_launch=kflops[dom], avg_launch_ms=timings[dom]))
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(d)

@@ -47,6 +47,22 @@ extern "C" {
                                      (utils/rollout.py:58-59, z=None) instead of the cyclic
                                      PEGASUS buffer of utils/rollout.py:53-57 */
 
+/* Arithmetic of the hidden-width (K >= 32) products of the sweep kernels.  Everything else (first
+ * layers, elementwise phases, moment matching, the dW GEMM, the optimiser) is fp32 / fp64 either way.
+ *  F32    v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (1/16 of the bf16 matrix rate)
+ *  SPLIT  every fp32 operand as a sum of bf16 pieces on v_mfma_f32_16x16x32_bf16 with fp32
+ *         accumulation: three pieces (6 MFMAs per K=32, fp32-equivalent) in the forward sweep, two
+ *         (3 MFMAs) in the adjoint sweep -- prob_mbrl_amd/csrc/pmbrl_split.h.  Offered by the
+ *         latency-optimised kernel family for workgroups of up to 32 rows; other plans run F32
+ *         (pmbrl_plan_info reports the arithmetic in use). */
+#define PMBRL_PREC_F32 0
+#define PMBRL_PREC_SPLIT 1
+/*  SPLIT_F16  as SPLIT, with the forward sweep on TWO fp16 pieces (22 significant bits, 3 MFMAs per K=32,
+ *         4 instead of 6 bytes per weight on the weight stream -- which is what bounds the sweeps).  fp16's
+ *         range applies to the forward sweep's hidden activations and weights: a value beyond +-65504
+ *         becomes inf and the rollout is reported as failed at that step (status word). */
+#define PMBRL_PREC_SPLIT_F16 2
+
 #define PMBRL_REWARD_EXP 0 /* r = exp(-w (d'Qd + u'Ru)): envs/cartpole/env.py:41-86 */
 #define PMBRL_REWARD_NEG 1 /* r = -w (d'Qd + u'Ru):      envs/rendezvous/env.py:32-45 */
 
@@ -98,6 +114,7 @@ typedef struct pmbrl_config {
   pmbrl_mlp dyn; /* dims[0] = D+U, dims[n] = 2D */
   pmbrl_reward reward;
   int32_t rows_per_wg_hint; /* 0 = choose automatically */
+  int32_t precision;        /* PMBRL_PREC_*: arithmetic of the hidden-width GEMMs of the sweeps */
 } pmbrl_config;
 
 typedef struct pmbrl_plan pmbrl_plan;
@@ -111,6 +128,7 @@ enum {
   PMBRL_INFO_N_POL_PARAMS = 4,
   PMBRL_INFO_N_DYN_PARAMS = 5,
   PMBRL_INFO_DW_SPLITS = 6,
+  PMBRL_INFO_PRECISION = 13, /* PMBRL_PREC_* actually in use */
   PMBRL_INFO_COUNT = 16
 };
 

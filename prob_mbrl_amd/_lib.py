@@ -18,6 +18,7 @@ FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
 FLAG_FORCE_GENERIC = 16
 FLAG_NO_SHAPED = 32
 REWARD_EXP, REWARD_NEG = 0, 1
+PREC_F32, PREC_SPLIT, PREC_SPLIT_F16 = 0, 1, 2
 INFO_COUNT = 16
 TIMER_COUNT = 8
 TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce', 'reward']
@@ -54,7 +55,7 @@ class Config(C.Structure):
                 ('row_offset', C.c_int32), ('flags', C.c_int32),
                 ('mm_groups', C.c_int32), ('max_log_std_pol', C.c_float),
                 ('max_log_std_dyn', C.c_float), ('pol', MLP), ('dyn', MLP),
-                ('reward', Reward), ('rows_per_wg_hint', C.c_int32)]
+                ('reward', Reward), ('rows_per_wg_hint', C.c_int32), ('precision', C.c_int32)]
 
 
 class Inputs(C.Structure):

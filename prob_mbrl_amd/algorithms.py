@@ -166,6 +166,9 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     # host then never waits for a whole iteration: while it prepares iteration i+1 the device still
     # has the adjoint sweep, the dW GEMM and the Adam step of iteration i to run.
     pipelined = (world == 1) and not callable(on_rollout) and not need_autograd
+    # arithmetic of the sweeps: the library default, until a rollout fails under fp16 pieces -- whose
+    # range, not the rollout, may be what failed: the rest of this call then runs on the bf16 pieces
+    prec = dict(name=None)
     pending = None          # (i, event, pinned status, loss, S, A, R) of the iteration in flight
     pipe = dict(snap=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(2)],
                 ev=[torch.cuda.Event() for _ in range(2)], step_dev=None) if pipelined else None
@@ -174,13 +177,23 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     # (utils/rollout.py:154-157); earlier failures skip the step (algorithms/mc_pilco.py:122-131)
     min_steps = min(H, 6)
 
+    pend_prec = [None]      # arithmetic of the iteration in flight
+
     def settle(pend):
         """Host side of a pipelined iteration, once its status word has arrived."""
         nonlocal n_opt_steps
         j, ev, snap, loss_j, S_j, A_j, R_j = pend
         ev.synchronize()
         n_valid = min(int(snap[0]), H)
-        if n_valid < min_steps:
+        if n_valid < H and prec['name'] is None and E.safe_precision(pend_prec[0]) is not None:
+            # (the device skipped or truncated this step on its own; no resampling: same random numbers,
+            #  wider exponent range from now on)
+            prec['name'] = E.safe_precision(pend_prec[0])
+            print('rollout failed at step %d under %s arithmetic (iteration %d): continuing with %s' %
+                  (n_valid, pend_prec[0], j, prec['name']))
+            if n_valid < min_steps:
+                return
+        elif n_valid < min_steps:
             # algorithms/mc_pilco.py:122-131: report, draw new random numbers; the device already
             # skipped the optimiser step
             print('RuntimeError: rollout failed at step %d (iteration %d)' % (n_valid, j))
@@ -217,7 +230,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                                mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
                                z_rr if pegasus else None,
                                B_global=Bg if world > 1 else None,
-                               row_offset=rank * N_particles if world > 1 else 0)
+                               row_offset=rank * N_particles if world > 1 else 0, precision=prec['name'])
             cache = None if need_autograd else _adam_flat_state(opt, bundle.pol_params,
                                                                 bundle.pol_flat)
             if cache is None:
@@ -231,6 +244,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     pipe['step_dev'] = torch.tensor([cache['step']], dtype=torch.int64, device=dev)
                     pipe['cache'] = cache
                 S, A, R = bundle.forward(x0_)
+                pend_prec[0] = eng.info['precision']
                 k = i & 1
                 pipe['snap'][k].copy_(eng.status[0:1], non_blocking=True)
                 pipe['ev'][k].record()
@@ -246,6 +260,16 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 eng = bundle.engine
                 S, A, R = bundle.forward(x0_)
                 n_valid = eng.valid_steps()       # the one host sync of the iteration
+                if n_valid < H and prec['name'] is None and world == 1 and \
+                        E.safe_precision(eng.info['precision']) is not None:
+                    # fp16 pieces: their range may be what failed -- decide on the bf16 path
+                    prec['name'] = E.safe_precision(eng.info['precision'])
+                    bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus, mm_states,
+                                       mm_rewards, mm_groups, z_mm if pegasus else None, z_rr if pegasus else None,
+                                       precision=prec['name'])
+                    eng = bundle.engine
+                    S, A, R = bundle.forward(x0_)
+                    n_valid = eng.valid_steps()
                 if world > 1:
                     # every rank must take the same branch and the same horizon: a failure anywhere
                     # truncates (or fails) the rollout everywhere, like one process would

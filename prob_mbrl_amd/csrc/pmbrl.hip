@@ -190,6 +190,8 @@ struct PackJob {
   const float* src;
   float* dst;
   int O, K, transpose, mult, is_bias;
+  int planes;   // 0: fp32 fragments of 16-wide k-blocks; 2 / 3: bf16 pieces of K32 blocks (pmbrl_split.h), mult in K32 blocks
+  int f16;      // pieces are fp16 instead of bf16
 };
 struct PackArgs {
   int n;
@@ -207,6 +209,41 @@ __global__ void pm_pack_all(const PackArgs P) {
   }
   const int n_out = j.transpose ? j.K : j.O, n_in = j.transpose ? j.O : j.K;
   const int n_ot = (n_out + 15) / 16;
+  if (j.planes) {
+    // dst[((ot*n_kb + kb)*planes + p)*64 + lane][8 bf16] = piece p of W[ot*16 + (lane&15)][kb*32 + 8*(lane>>4) + e]
+    const int n_kb = ((n_in + 31) / 32 + j.mult - 1) / j.mult * j.mult;
+    const size_t total = (size_t)n_ot * n_kb * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int lane = i & 63;
+      const size_t tb = i >> 6;
+      const int kb = tb % n_kb, ot = tb / n_kb;
+      const int o = ot * 16 + (lane & 15);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kb * 32 + 8 * (lane >> 4) + e;
+        v[e] = (o < n_out && k < n_in) ? (j.transpose ? j.src[(size_t)k * j.K + o] : j.src[(size_t)o * j.K + k]) : 0.f;
+      }
+      for (int p = 0; p < j.planes; ++p) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (j.f16) {
+            w[e] = pm_pk_f16(v[2 * e], v[2 * e + 1]);
+            const pm_f32x2 f = pm_unpk_f16(w[e]);
+            v[2 * e] -= f[0];
+            v[2 * e + 1] -= f[1];
+          } else {
+            w[e] = pm_pk_bf16(v[2 * e], v[2 * e + 1]);
+            v[2 * e] -= pm_bf_lo(w[e]);
+            v[2 * e + 1] -= pm_bf_hi(w[e]);
+          }
+        }
+        *reinterpret_cast<uint4*>(j.dst + ((tb * j.planes + p) * 64 + lane) * 4) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return;
+  }
   const int n_kb = ((n_in + 15) / 16 + j.mult - 1) / j.mult * j.mult;
   const size_t total = (size_t)n_ot * n_kb * 256;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -334,6 +371,7 @@ struct pmbrl_plan {
   pmbrl_config cfg;
   int device;
   int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CA, CB;   // CA/CB: k-blocks per weight-stream stage
+  int prec, LDB;   // PMBRL_PREC_* in use; split precision: leading dimension of the bf16 piece planes
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
@@ -412,6 +450,49 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 4, 1, 216, 3, 13)       \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 5, 1, 216, 3, 13)       \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 6, 1, 216, 3, 13)
+
+// split-bf16 instantiations (pmbrl_split.h): stage pairs in K32 blocks
+#define PM_SPLIT_CASES PM_SPLIT_CASE(1, 4, 3) PM_SPLIT_CASE(1, 1, 1) PM_SPLIT_CASE(2, 4, 3) PM_SPLIT_CASE(2, 1, 1)
+// shape-specialised split instantiations; LDV: floats per row of an activation buffer = piece planes x 240 / 2
+// (three bf16 planes: 360, two fp16 planes: 240)
+#define PM_SPLIT_SHAPED_CASES(LDV)                             \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 4, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_EXT, 4, 1, LDV, 3, 13)        \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)
+
+template <int RT, int CA, int CB, int PR>
+static int set_attr_split(size_t lds) {
+  const void* fns[] = {
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_EXT, PfShapeAny, PR>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_EXT, PfShapeAny, PR>),
+      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MM, PfShapeAny, PR>),
+      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM, PfShapeAny, PR>)};
+  for (const void* f : fns)
+    HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if constexpr (RT == 1) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MMG, PfShapeAny, PR>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MMG, PfShapeAny, PR>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                          \
+  if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
+    HIPCHK(hipFuncSetAttribute(                                                                          \
+        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
+    HIPCHK(hipFuncSetAttribute(                                                                          \
+        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
+  }
+  PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
+#undef PM_FAST_SHAPED
+  return 0;
+}
 
 template <int RT, int CA, int CB>
 static int set_attr_fast(size_t lds) {
@@ -549,25 +630,44 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // stage sizes (k-blocks) of the weight stream: every streamed layer is padded to a whole number
   // of stage PAIRS (CA + CB k-blocks); pick, among the instantiated pairs, the one that pads least
   struct StagePair { int ca, cb; };
-  auto stream_work = [&](int m) {
+  // split-bf16 precision: offered by the fast family for workgroups of up to 32 rows
+  const bool want_split = (c.precision == PMBRL_PREC_SPLIT || c.precision == PMBRL_PREC_SPLIT_F16) && p->fast &&
+                          !getenv("PMBRL_FORCE_F32");
+  auto prec_for = [&](int RT) { return (want_split && RT <= 2) ? c.precision : 0; };
+  // (kdiv: 16-wide k-blocks per stage unit -- 1 on the fp32 path, 2 = one K32 block on the split path)
+  auto stream_work = [&](int m, int kdiv) {
     long w = 0;
     const NetPlan* nets[2] = {&p->pol, &p->dyn};
     for (const NetPlan* n : nets)
-      for (int l = 1; l <= n->nl - 2; ++l)
-        w += (long)n->nt[l + 1] * ((n->nt[l] + m - 1) / m * m) + (long)n->nt[l] * ((n->nt[l + 1] + m - 1) / m * m);
+      for (int l = 1; l <= n->nl - 2; ++l) {
+        const int ki = (n->nt[l] + kdiv - 1) / kdiv, ko = (n->nt[l + 1] + kdiv - 1) / kdiv;
+        w += (long)n->nt[l + 1] * ((ki + m - 1) / m * m) + (long)n->nt[l] * ((ko + m - 1) / m * m);
+      }
     return w;
   };
   auto stages_for = [&](int RT) {
     static const StagePair cand1[] = {{8, 8}, {7, 6}, {4, 4}, {2, 2}}, cand2[] = {{4, 4}, {4, 3}, {2, 2}}, cand4[] = {{2, 2}, {1, 1}};
-    const StagePair* cand = RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
-    const int nc = RT == 1 ? 4 : (RT == 2 ? 3 : 2);
+    static const StagePair cands[] = {{4, 3}, {1, 1}};
+    const bool sp = prec_for(RT) != 0;
+    const StagePair* cand = sp ? cands : RT == 1 ? cand1 : (RT == 2 ? cand2 : cand4);
+    const int nc = sp ? 2 : RT == 1 ? 4 : (RT == 2 ? 3 : 2);
+    const int kdiv = sp ? 2 : 1;
     StagePair best = cand[0];
     for (int i = 1; i < nc; ++i)
-      if (stream_work(cand[i].ca + cand[i].cb) < stream_work(best.ca + best.cb)) best = cand[i];
+      if (stream_work(cand[i].ca + cand[i].cb, kdiv) < stream_work(best.ca + best.cb, kdiv)) best = cand[i];
     return best;
+  };
+  // split path: elements per row of a bf16 piece plane = padded K + 16 (conflict-free ds_read_b128)
+  auto ldb_for = [&](int RT) {
+    if (!prec_for(RT)) return 0;
+    const StagePair sp = stages_for(RT);
+    const int m = sp.ca + sp.cb;
+    return ((maxnt + 1) / 2 + m - 1) / m * m * 32 + 16;
   };
   auto ld_for = [&](int RT) {
     if (!p->fast) return LD_generic;
+    if (prec_for(RT))   // floats per row of a buffer holding the piece planes (3 bf16 / 2 fp16 forward, 2 bf16 adjoint)
+      return ((prec_for(RT) == PMBRL_PREC_SPLIT_F16 ? 2 : 3) * ldb_for(RT) / 2 + 3) / 4 * 4;
     const StagePair sp = stages_for(RT);
     const int m = sp.ca + sp.cb;
     return (maxnt + m - 1) / m * m * 16 + 8;   // room for the zero K padding
@@ -576,7 +676,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->LD = ld_for(RT);
     if (p->fast)
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
-                                p->dyn.nl, mmd) * sizeof(float);
+                                p->dyn.nl, mmd, prec_for(RT)) * sizeof(float);
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
   };
   p->G = 1;
@@ -628,6 +728,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->mm_mode = 3;
   p->lds_bytes = lds_need(p->RT, (p->mm_mode == 1 || p->mm_mode == 3) ? c.D : 0);   // also fixes p->LD for the chosen RT
   { const StagePair sp = stages_for(p->RT); p->CA = sp.ca; p->CB = sp.cb; }
+  p->prec = prec_for(p->RT);
+  p->LDB = ldb_for(p->RT);
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
   p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
   // groups spanning workgroups, every workgroup resident at once (one per CU always fits): the
@@ -749,6 +851,13 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       case 2: rc2 = set_attr<2>(p->lds_bytes); break;
       default: rc2 = set_attr<4>(p->lds_bytes); break;
     }
+  } else if (p->prec) {
+#define PM_SPLIT_CASE(RTV, CAV, CBV)                                 \
+  if (p->RT == RTV && p->CA == CAV && p->CB == CBV)                  \
+    rc2 = p->prec == PMBRL_PREC_SPLIT_F16 ? set_attr_split<RTV, CAV, CBV, 2>(p->lds_bytes) \
+                                          : set_attr_split<RTV, CAV, CBV, 1>(p->lds_bytes);
+    PM_SPLIT_CASES
+#undef PM_SPLIT_CASE
   } else {
 #define PM_FAST_CASE(RTV, CAV, CBV) \
   if (p->RT == RTV && p->CA == CAV && p->CB == CBV) rc2 = set_attr_fast<RTV, CAV, CBV>(p->lds_bytes);
@@ -827,6 +936,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[10] = p->fast;
   info[11] = p->CA * 16 + p->CB;
   info[12] = p->mm_grid;
+  info[PMBRL_INFO_PRECISION] = p->prec;
   return 0;
 }
 
@@ -869,7 +979,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.Bg = c.B_global; A.row_off = c.row_offset; A.flags = c.flags;
   A.G = p->G; A.M = p->M; A.mm_mode = p->mm_mode;
   A.t0 = 0; A.t1 = c.H;
-  A.rows_per_wg = p->rows_per_wg; A.nwg = p->nwg; A.Rw = 16 * p->RT; A.LD = p->LD;
+  A.rows_per_wg = p->rows_per_wg; A.nwg = p->nwg; A.Rw = 16 * p->RT; A.LD = p->LD; A.LDB = p->LDB;
   A.mls_pol = c.max_log_std_pol; A.mls_dyn = c.max_log_std_dyn;
   for (int l = 0; l < p->pol.nl - 1; ++l)
     if (!in->pol_mask_bits_d[l]) return fail(-1, "missing policy mask bits");
@@ -913,9 +1023,12 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
     auto add_stream = [&](StreamDesc& sd, const float* wf, int n_ot, int n_kb_real, int& tw_off) {
       const int i = sd.n++;
       sd.wf[i] = wf;
-      sd.n_kb[i] = padk(n_kb_real);
+      // split precision: the stream counts 1 KiB weight loads = pieces of K32 blocks (3 per block in the
+      // forward sweep's table, 2 in the adjoint's)
+      const int np = (&sd == &A.sd_fwd && p->prec != PMBRL_PREC_SPLIT_F16) ? 3 : 2;
+      sd.n_kb[i] = p->prec ? padk((n_kb_real + 1) / 2) * np : padk(n_kb_real);
       sd.n_kb_real[i] = n_kb_real;
-      sd.ks[i] = pm_fast_ksplit(n_ot, p->RT) ? 1 : 0;
+      sd.ks[i] = pm_fast_ksplit(n_ot, p->RT, p->prec) ? 1 : 0;
       sd.n_ot[i] = n_ot - sd.ks[i];
       sd.tw_off[i] = tw_off;
       if (sd.ks[i]) tw_off += n_kb_real * 256;
@@ -946,14 +1059,20 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   return 0;
 }
 
-static void pack_jobs(const NetPlan& n, char* ws, const float* params, int pair_kb, PackArgs& P) {
+static void pack_jobs(const NetPlan& n, char* ws, const float* params, int pair_kb, PackArgs& P, int prec = 0) {
   for (int l = 0; l < n.nl; ++l) {
     const int O = n.dim[l + 1], K = n.dim[l];
     // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to CA+CB
     const int mult = (pair_kb >= 1 && l >= 1 && l <= n.nl - 2) ? pair_kb : 1;
-    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wf[l]), O, K, 0, mult, 0};
-    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wb[l]), O, K, 1, mult, 0};
-    P.job[P.n++] = PackJob{params + n.b_off[l], reinterpret_cast<float*>(ws + n.bias[l]), O, K, 0, 1, 1};
+    // split precision: bf16 pieces for every product with K = a hidden width -- forward: hidden->hidden layers
+    // (streamed, padded to stage pairs) and the head (3 pieces); adjoint: their transposes and the tail (2 pieces)
+    const bool hid_in = l >= 1, hid_out = l <= n.nl - 2;   // K is a hidden width forward / in the transposed product
+    const int pf = (prec && hid_in) ? (prec == PMBRL_PREC_SPLIT_F16 ? 2 : 3) : 0, pb = (prec && hid_out) ? 2 : 0;
+    const int mf = pf ? ((l <= n.nl - 2) ? pair_kb : 1) : mult, mb = pb ? ((l >= 1) ? pair_kb : 1) : mult;
+    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wf[l]), O, K, 0, mf, 0, pf,
+                           prec == PMBRL_PREC_SPLIT_F16 ? 1 : 0};
+    P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wb[l]), O, K, 1, mb, 0, pb, 0};
+    P.job[P.n++] = PackJob{params + n.b_off[l], reinterpret_cast<float*>(ws + n.bias[l]), O, K, 0, 1, 1, 0, 0};
   }
 }
 
@@ -972,14 +1091,58 @@ static int hidden_tiles(const RolloutArgs& A) {
   for (int l = 1; l < A.dyn.nl; ++l) if (A.dyn.nt[l] != nt) return -1;
   return nt;
 }
-template <int RT, int CA, int CB>
-static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+static int fast_variant(int RT, const RolloutArgs& A) {
   // variant: see pmbrl_fast.h (PF_VAR_*)
   const bool mm = A.mm_mode == 1 || A.mm_mode == 3;   // moment matching inside the sweep launches
   const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
                    (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
   const bool mmg = RT == 1 && A.mm_mode == 3 && A.mm_grid;
-  const int var = mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
+  return mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
+}
+// split-bf16 precision (pmbrl_split.h): same variants and shape specialisation, PR = 1
+template <int RT, int CA, int CB, int PR>
+static void launch_split(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  const int var = fast_variant(RT, A);
+  const dim3 g(p->nwg), b(PF_NT);
+#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
+  if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
+      A.pol.nl == NLV && A.dyn.nl == NLV && hidden_tiles(A) == NTV) {                                        \
+    if (fwd)                                                                                                \
+      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), g, b,    \
+                         p->lds_bytes, s, A);                                                               \
+    else                                                                                                    \
+      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), g, b,    \
+                         p->lds_bytes, s, A);                                                               \
+    return;                                                                                                 \
+  }
+  if (!(A.flags & PMBRL_FLAG_NO_SHAPED)) {
+    PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
+  }
+#undef PM_FAST_SHAPED
+#define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V, PfShapeAny, PR>), g, b, p->lds_bytes, s, A)
+  if constexpr (RT == 1) {
+    if (var == PF_VAR_MMG) {
+      if (fwd) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MMG);
+      else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MMG);
+      return;
+    }
+  }
+  if (fwd) {
+    if (var == PF_VAR_MM) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);
+    else if (var == PF_VAR_EXT) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_EXT);
+    else PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_LEAN);
+  } else {
+    if (var == PF_VAR_MM) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MM);
+    else if (var == PF_VAR_EXT) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_EXT);
+    else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_LEAN);
+  }
+#undef PM_LAUNCH_VAR
+}
+
+template <int RT, int CA, int CB>
+static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  const int var = fast_variant(RT, A);
+  const bool mm = var == PF_VAR_MM, ext = var == PF_VAR_EXT, mmg = var == PF_VAR_MMG;
   const dim3 g(p->nwg), b(PF_NT);
   // a shape-specialised instantiation if there is one for this plan
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
@@ -1017,6 +1180,15 @@ static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
 #undef PM_LAUNCH_VAR
 }
 static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  if (p->prec) {
+#define PM_SPLIT_CASE(RTV, CAV, CBV)                                                       \
+  if (p->RT == RTV && p->CA == CAV && p->CB == CBV)                                        \
+    return p->prec == PMBRL_PREC_SPLIT_F16 ? launch_split<RTV, CAV, CBV, 2>(p, A, s, fwd)  \
+                                           : launch_split<RTV, CAV, CBV, 1>(p, A, s, fwd);
+    PM_SPLIT_CASES
+#undef PM_SPLIT_CASE
+    return;
+  }
 #define PM_FAST_CASE(RTV, CAV, CBV) \
   if (p->RT == RTV && p->CA == CAV && p->CB == CBV) return launch_fast<RTV, CAV, CBV>(p, A, s, fwd);
   PM_FAST_CASES
@@ -1057,8 +1229,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
     PackArgs PK;
     PK.n = 0;
-    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK);
-    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK);
+    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec);
+    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec);
     PK.status = status_d;
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   }
@@ -1298,8 +1470,8 @@ extern "C" int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* c, void* wo
   for (int l = 0; l < L.nl; ++l) {
     float* wf = reinterpret_cast<float*>(ws + L.wf[l]);
     float* bs = reinterpret_cast<float*>(ws + L.bias[l]);
-    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wf, L.dim[l + 1], L.dim[l], 0, 1, 0};
-    PK.job[PK.n++] = PackJob{params_flat_d + L.b_off[l], bs, L.dim[l + 1], L.dim[l], 0, 1, 1};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wf, L.dim[l + 1], L.dim[l], 0, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.b_off[l], bs, L.dim[l + 1], L.dim[l], 0, 1, 1, 0, 0};
     A.wf[l] = wf;
     A.bias[l] = bs;
     A.mask[l] = (l < L.nl - 1 && mask_bits_d) ? mask_bits_d[l] : nullptr;
@@ -1347,9 +1519,9 @@ extern "C" int pmbrl_mlp_grad_input(void* stream, const pmbrl_mlp_call* c, void*
     float* wf = reinterpret_cast<float*>(ws + L.wf[l]);
     float* wb = reinterpret_cast<float*>(ws + L.wb[l]);
     float* bs = reinterpret_cast<float*>(ws + L.bias[l]);
-    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wf, L.dim[l + 1], L.dim[l], 0, 1, 0};
-    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wb, L.dim[l + 1], L.dim[l], 1, 1, 0};
-    PK.job[PK.n++] = PackJob{params_flat_d + L.b_off[l], bs, L.dim[l + 1], L.dim[l], 0, 1, 1};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wf, L.dim[l + 1], L.dim[l], 0, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.w_off[l], wb, L.dim[l + 1], L.dim[l], 1, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + L.b_off[l], bs, L.dim[l + 1], L.dim[l], 0, 1, 1, 0, 0};
     A.wf[l] = wf; Bw.wb[l] = wb; A.bias[l] = bs;
     A.mask[l] = (l < L.nl - 1 && mask_bits_d) ? mask_bits_d[l] : nullptr;
     A.keep[l] = l < L.nl - 1 ? c->net.keep[l] : 1.f;
@@ -1483,9 +1655,9 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
     float* wf = reinterpret_cast<float*>(ws + p->off_wf[l]);
     float* wb = reinterpret_cast<float*>(ws + p->off_wb[l]);
     float* bs = reinterpret_cast<float*>(ws + p->off_bias[l]);
-    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wf, p->dim[l + 1], p->dim[l], 0, 1, 0};
-    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wb, p->dim[l + 1], p->dim[l], 1, 1, 0};
-    PK.job[PK.n++] = PackJob{params_flat_d + p->b_off[l], bs, p->dim[l + 1], p->dim[l], 0, 1, 1};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wf, p->dim[l + 1], p->dim[l], 0, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wb, p->dim[l + 1], p->dim[l], 1, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->b_off[l], bs, p->dim[l + 1], p->dim[l], 0, 1, 1, 0, 0};
     A.wf[l] = wf; A.wb[l] = wb; A.bias[l] = bs;
     A.actT[l] = reinterpret_cast<float*>(ws + p->off_actT[l]);
     A.gT[l] = reinterpret_cast<float*>(ws + p->off_gT[l]);

@@ -83,6 +83,7 @@ struct RolloutArgs {
   int t0, t1;          // step range of this launch
   int rows_per_wg, nwg, Rw;   // Rw = 16*RT = stash block width
   int LD;              // LDS leading dimension of the activation buffers (floats)
+  int LDB;             // split precision: leading dimension of the bf16 piece planes (elements; 0 = fp32 path)
   float mls_pol, mls_dyn;
   NetDev pol, dyn;
   const RewardDev* rew;

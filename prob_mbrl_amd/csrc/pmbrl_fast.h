@@ -21,6 +21,7 @@
 #include "pmbrl_dev.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
+#include "pmbrl_split.h"
 
 // Streamed layers: ONE output tile per wave in flight, two accumulator chains per row tile
 // (even / odd k-blocks) to cover the 40-cycle dependent-MFMA latency, and a register stage
@@ -47,11 +48,16 @@
 // last wave, which owns at most one regular tile, waits for the 8 partials after its tile,
 // sums them in fixed order and runs the tile's normal epilogue before the phase barrier.
 // (not with 64-row workgroups: LDS is the constraint there)
-__host__ __device__ constexpr bool pm_fast_ksplit(int n_ot, int RT) { return RT < 4 && n_ot >= 5 && (n_ot % 4) == 1; }
+// (split-bf16 precision: the tiles are short enough that the imbalance costs less than the K-split's
+// partial / gather round trip -- every tile is a regular tile there)
+__host__ __device__ constexpr bool pm_fast_ksplit(int n_ot, int RT, int prec = 0) {
+  return !prec && RT < 4 && n_ot >= 5 && (n_ot % 4) == 1;
+}
 // LDS floats for the K-split tail weights of one sweep direction (bwd: transposed layers)
 __host__ __device__ inline size_t pm_fast_tail_floats(const int* pnt, int pnl, const int* dnt, int dnl,
-                                                      bool bwd, int RT) {
+                                                      bool bwd, int RT, int prec = 0) {
   size_t n = 0;
+  if (prec) return 0;
   for (int l = 1; l <= pnl - 2; ++l) {
     const int n_ot = bwd ? pnt[l] : pnt[l + 1], n_kb = bwd ? pnt[l + 1] : pnt[l];
     if (pm_fast_ksplit(n_ot, RT)) n += (size_t)n_kb * 256;
@@ -262,7 +268,12 @@ __device__ __forceinline__ void pm_ldw(f32x4& d, unsigned voff, const float* sba
 template <int CKB>
 __device__ __forceinline__ void frag_load(FragS<CKB>& f, const Cursor& q, unsigned vo0, unsigned vo1) {
   const float* wp = q.wp;
-  static_assert(CKB >= 1 && CKB <= 8, "stage depth");
+  static_assert(CKB >= 1 && CKB <= 12, "stage depth");
+  const unsigned vo2 = vo1 + 4096u;
+  if constexpr (CKB > 8) pm_ldw<0>(f.a[8], vo2, wp);
+  if constexpr (CKB > 9) pm_ldw<1024>(f.a[9], vo2, wp);
+  if constexpr (CKB > 10) pm_ldw<2048>(f.a[10], vo2, wp);
+  if constexpr (CKB > 11) pm_ldw<3072>(f.a[11], vo2, wp);
   if constexpr (CKB > 0) pm_ldw<0>(f.a[0], vo0, wp);
   if constexpr (CKB > 1) pm_ldw<1024>(f.a[1], vo0, wp);
   if constexpr (CKB > 2) pm_ldw<2048>(f.a[2], vo0, wp);
@@ -385,6 +396,66 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
       frag_wait<CB, CA>(fb);
       frag_compute<RT, CB>(fb, c2 * (CA + CB) + CA, (c2 + 1 < nch2) ? (c2 + 1) * (CA + CB) : 0, lds_in, ld, lane,
                            acc, b0);
+    } while (++c2 < nch2);
+    if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      pacc[rt] = acc[0][rt] + acc[1][rt];
+      ppre[rt] = pre[rt];
+    }
+    pot = ot;
+  }
+  if (pot >= 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
+  }
+}
+
+// The same on the bf16 piece planes (pmbrl_split.h): stages of CA / CB K32 blocks = CA*NP / CB*NP weight
+// loads; the stream cursor counts loads, so every layer is padded to whole (CA + CB)-block pairs.
+template <int RT, int CA, int CB, int NP, bool F16, class SC, class Epi>
+__device__ __forceinline__ void stream_layer_s(const SdV& sd, int li, Cursor& q, FragS<CA * NP>& fa,
+                                               FragS<CB * NP>& fb, const float* buf_in, unsigned ldb,
+                                               int wid, int lane, Epi& epi, unsigned vo0, unsigned vo1,
+                                               long long* prof = nullptr) {
+  if (!q.live || q.li != li) return;
+  const int n_ot = SC::NOT ? SC::NOT : q.n_ot;
+  const int nch2 = (SC::NKB ? SC::NKB : q.n_kb) / ((CA + CB) * NP);
+  int pslot = 24;
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  BQ<RT, NP> b0;
+  bq_load<RT, NP>(b0, lb, ldb, 0);
+  f32x4 pacc[RT];
+  typename Epi::Pre ppre[RT];
+  int pot = -1;
+  for (int ot = wid; ot < n_ot; ot += PF_NW) {
+    if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
+    typename Epi::Pre pre[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot, rt);
+    f32x4 acc[2][RT];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c2 = 0;
+    do {
+      frag_load<CB * NP>(fb, q, vo0, vo1);
+      cur_advance<CB * NP, SC>(sd, q, wid);
+      frag_wait<CA * NP, CB * NP>(fa);
+      if (c2 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) epi.landed(pre[rt], rt);
+        if (pot >= 0) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
+        }
+      }
+      frag_compute_s<RT, CA, NP, F16>(fa, c2 * (CA + CB), c2 * (CA + CB) + CA, lb, ldb, acc, b0);
+      frag_load<CA * NP>(fa, q, vo0, vo1);
+      cur_advance<CA * NP, SC>(sd, q, wid);
+      frag_wait<CB * NP, CA * NP>(fb);
+      frag_compute_s<RT, CB, NP, F16>(fb, c2 * (CA + CB) + CA, (c2 + 1 < nch2) ? (c2 + 1) * (CA + CB) : 0, lb, ldb, acc, b0);
     } while (++c2 < nch2);
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
@@ -566,7 +637,9 @@ __device__ __forceinline__ void tail_gather(const float* tp, int* tcnt, int roun
 // of the SIMD is in ITS epilogue at the same time, so the MFMA pipe idles): they are kept to
 // a few dozen VALU instructions -- 32-bit offsets from uniform bases (the stash row block is
 // Rw = 16*RT, a compile-time constant), a multiply by the precomputed 1/keep.
-template <int RT>
+// NP = 0: the layer output goes to LDS as fp32 rows (leading dimension ld); NP > 0: as NP bf16 (F16: fp16)
+// piece planes (pmbrl_split.h; leading dimension ld in 16-bit elements)
+template <int RT, int NP = 0, bool F16 = false>
 struct EpiFwdL {
   const float* bias;        // LDS, padded
   const uint16_t* mask;     // LDS [R][nt]
@@ -575,6 +648,7 @@ struct EpiFwdL {
   float* lds_out;
   float* stash;             // HBM block or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
+  int* ovf;                 // F16: LDS word set when an activation leaves fp16's range (nullptr otherwise)
   struct Pre {
     f32x4 b;
     unsigned mw;
@@ -607,7 +681,14 @@ struct EpiFwdL {
       h[r] = a ? v * inv_keep : 0.f;
       act |= (a ? 1u : 0u) << r;
     }
-    *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    if constexpr (NP > 0) pm_store_planes<NP, 16 * RT, F16>(lds_out, (unsigned)ld, lrow, f0, h);
+    else *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    if constexpr (F16) {
+      // fp16 pieces: a value beyond the format's range would turn into inf - inf = NaN inside the next
+      // layer and vanish in its ReLU; report it instead (h >= 0 here; the sampling phase of this step
+      // turns the flag into a failed step)
+      if (fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3])) > 65504.f) *ovf = 1;
+    }
 #ifndef PM_EXP_NOSTASH
     if (stash) {
       PM_GLOBAL float* sp = (PM_GLOBAL float*)(stash + (unsigned)ot * (16u * RW));   // uniform
@@ -623,7 +704,7 @@ struct EpiFwdL {
   }
 };
 
-template <int RT>
+template <int RT, int NP = 0>
 struct EpiBwdL {
   const uint8_t* abits;     // HBM [B][nt][4] slice of step t
   float inv_keep;
@@ -663,7 +744,8 @@ struct EpiBwdL {
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = ((nib >> r) & 1u) ? acc[r] * inv_keep : 0.f;
-    *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    if constexpr (NP > 0) pm_store_planes<NP, 16 * RT>(lds_out, (unsigned)ld, lrow, f0, h);
+    else *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
 #ifndef PM_EXP_NOSTASH
     if (stash) {
       PM_GLOBAL float* sp = (PM_GLOBAL float*)(stash + (unsigned)ot * (16u * RW));   // uniform
@@ -797,6 +879,8 @@ struct FastLds {
   float *jx;                     // backward: dL/dx~ rows [R][16]
   float *stg;                    // backward: staged per-row inputs of one step [R][1+2D+3U]
   float *zs;                     // in-kernel moment matching: this step's noise rows [R][D]
+  float *xin;                    // split precision: fp32 input tile of the resident first layers [R][PM_XIN_LD]
+  int *ovf;                      // split precision, fp16 pieces: range-overflow flag of the launch
   float *tp;                     // K-split last tile: partial tiles [PF_NW][RT][64][4]
   int *tcnt;                     //   ... and the arrival counter
   float *tw;                     //   ... and the LDS-resident weight k-blocks of those tiles
@@ -809,9 +893,10 @@ __host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
   return RT >= 4 && (size_t)R * LD >= (size_t)PF_NW * RT * 256;   // only where LDS is the constraint (64-row workgroups)
 }
 
+#define PM_XIN_LD 24             // = 8 (mod 16): conflict-free ds_read_b128 of the MFMA B operand
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
-                                                     int dnl, int mm_d) {
+                                                     int dnl, int mm_d, int prec = 0) {
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
   if (!pm_fast_hp_alias(R, LD, RT)) n += (size_t)PF_NW * RT * 256;
   for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
@@ -823,8 +908,9 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   n = (n + 3) & ~(size_t)3;
   n += (size_t)R * 16 + (size_t)R * (1 + 2 * D + 3 * U) + (size_t)R * D;   // jx, stg, zs
   n = (n + 3) & ~(size_t)3;
+  if (prec) n += (size_t)R * PM_XIN_LD + 4;                                 // xin, ovf
   {
-    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT);
+    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT, prec), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT, prec);
     const size_t tw = tf > tb ? tf : tb;
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
@@ -834,7 +920,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
 
 // (pnt / dnt: 16-wide tile counts of layer inputs / outputs, nl + 1 entries each)
 __device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
-                                                 const int* pnt, int pnl, const int* dnt, int dnl) {
+                                                 const int* pnt, int pnl, const int* dnt, int dnl, int prec = 0) {
   FastLds m;
   float* p = base;
   m.bufA = p; p += (size_t)R * LD;
@@ -871,8 +957,11 @@ __device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int
   m.zs = p; p += (size_t)R * D;
   n = ((size_t)(p - base) + 3) & ~(size_t)3;
   p = base + n;
+  m.xin = p;
+  m.ovf = reinterpret_cast<int*>(p + (size_t)R * PM_XIN_LD);
+  if (prec) p += (size_t)R * PM_XIN_LD + 4;
   {
-    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT);
+    const size_t tf = pm_fast_tail_floats(pnt, pnl, dnt, dnl, false, RT, prec), tb = pm_fast_tail_floats(pnt, pnl, dnt, dnl, true, RT, prec);
     const size_t tw = tf > tb ? tf : tb;
     m.tp = p;
     m.tcnt = reinterpret_cast<int*>(p + (size_t)PF_NW * RT * 256);
@@ -883,21 +972,21 @@ __device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int
   return m;
 }
 __device__ __forceinline__ FastLds pm_fast_carve(float* base, int R, int LD, int D, int U, int RT,
-                                                 const NetDev& P, const NetDev& F) {
-  return pm_fast_carve(base, R, LD, D, U, RT, P.nt, P.nl, F.nt, F.nl);
+                                                 const NetDev& P, const NetDev& F, int prec = 0) {
+  return pm_fast_carve(base, R, LD, D, U, RT, P.nt, P.nl, F.nt, F.nl, prec);
 }
 // shape-specialised kernels: the whole carve-up from compile-time constants (-> immediate
 // LDS offsets); layer widths 1 | NT ... NT | 1 tiles
-template <class SH, int RT>
+template <class SH, int RT, int PR = 0>
 __device__ __forceinline__ FastLds pm_fast_carve_shaped(float* base, const NetDev& P, const NetDev& F,
                                                         int R, int LD, int D, int U) {
   if constexpr (SH::NT != 0 && SH::NL != 0) {
     int nt[PM_MAXL + 1];
 #pragma unroll
     for (int l = 0; l <= PM_MAXL; ++l) nt[l] = (l == 0 || l >= SH::NL) ? 1 : SH::NT;
-    return pm_fast_carve(base, R, LD, D, U, RT, nt, SH::NL, nt, SH::NL);
+    return pm_fast_carve(base, R, LD, D, U, RT, nt, SH::NL, nt, SH::NL, PR);
   } else {
-    return pm_fast_carve(base, R, LD, D, U, RT, P, F);
+    return pm_fast_carve(base, R, LD, D, U, RT, P, F, PR);
   }
 }
 
@@ -961,7 +1050,7 @@ __device__ inline void pm_fast_preload(const RolloutArgs& A, const FastLds& L, i
 // a chain of ~40 dependent memory round trips (one per short loop and conditional load): 20 us of a
 // sweep launch, paid once per iteration in the single-launch modes and once per STEP when a
 // moment-matching group spans workgroups.
-template <int RT, class SH>
+template <int RT, class SH, int PR = 0>
 __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, const FastLds& L, const StreamDesc& sd,
                                                        int row0, int nvalid, int tid) {
   constexpr int R = 16 * RT, NL = SH::NL, NT = SH::NT, D = SH::D, U = SH::U;
@@ -996,6 +1085,7 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
       pm[l][it] = P.mask[l][src];
       dm[l][it] = F.mask[l][src];
     }
+  if constexpr (!PR) {
 #pragma unroll
   for (int l = 0; l < NS; ++l)
 #pragma unroll
@@ -1004,6 +1094,7 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
       // the tile after the streamed ones (clamped read when this layer has no K-split tile: not stored)
       tw[l][it] = ldg4(sd.wf[l] + (size_t)sd.n_ot[l] * sd.n_kb[l] * 256 + (size_t)i * 4 * (sd.ks[l] ? 1 : 0));
     }
+  }
   {
     const int i = min(tid, R * U - 1);
     zp = A.zpol[(size_t)row0 * U + min(i, nvalid * U - 1)];
@@ -1018,7 +1109,7 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
     c0 = A.mx[i]; c1 = A.iSx[i]; c2 = A.my[j]; c3 = A.Sy[j]; c4 = A.pscale[k]; c5 = A.pbias[k];
   }
   // ---- stores
-  if (tid == 0) *L.tcnt = 0;
+  if (!PR && tid == 0) *L.tcnt = 0;
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     const int n = (l < NL - 1 ? NT : 1) * 16;
@@ -1042,6 +1133,7 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
         DMASK(l)[i] = live ? dm[l][it] : (uint16_t)0;
       }
     }
+  if constexpr (!PR) {
 #pragma unroll
   for (int l = 0; l < NS; ++l)
 #pragma unroll
@@ -1049,6 +1141,7 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
       const int i = tid + it * PF_NT;
       if (sd.ks[l] && i < NT * 64) *reinterpret_cast<f32x4*>(L.tw + sd.tw_off[l] + (size_t)i * 4) = tw[l][it];
     }
+  }
   if (tid < R * U) L.zp[tid] = (tid / U < nvalid && A.zpol_ss == 0) ? zp : 0.f;
 #pragma unroll
   for (int it = 0; it < IT_Z; ++it) {
@@ -1065,7 +1158,9 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
 // one streamed layer (index SI of the stream table) with epilogue ES and, when the layer's last
 // tile is K-split, that tile's partial / gather / epilogue around it
 #define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
-  {                                                                                                     \
+  if constexpr (PR != 0) {                                                                              \
+    stream_layer_s<RT, CA, CB, NP, F16, SC>(sd, (SI), q, fa, fb, X, (unsigned)LDB, wid, lane, (ES), vo0, vo1, (PROF)); \
+  } else {                                                                                              \
     const int ks_ = SKS_KNOWN ? 1 : (SC::NOT ? 0 : pm_rl(sd.k, 4 * (SI)));                                                            \
     typename std::remove_reference<decltype(ES)>::type::Pre tpre_[RT];                                  \
     const int ot_last_ = SD_NOT(SC, sd, (SI));                                                          \
@@ -1089,6 +1184,10 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
     }                                                                                                   \
   }
 #define PM_SWAP_XY() { xsel ^= 1; X = L.bufA + xsel * (R * LD); Y = L.bufA + (xsel ^ 1) * (R * LD); }
+// fp32 input tile of a resident (K <= 16) layer: the activation buffer itself, or -- split precision, where
+// the activation buffers hold bf16 piece planes -- the separate tile L.xin
+#define PM_XIN(Xbuf) (PR ? L.xin : (Xbuf))
+#define PM_XLD (PR ? PM_XIN_LD : LD)
 
 // K-split tails: weight k-blocks of the last tile of every such layer -> LDS, counter -> 0
 __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds& L, int tid) {
@@ -1136,15 +1235,26 @@ typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
       A.prof[(size_t)t * 32 + (slot)] = (long long)__builtin_readcyclecounter();                   \
   } while (0)
 
-template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
+// PR: precision of the hidden-width GEMMs -- 0: exact fp32 MFMA; 1: split bf16 (pmbrl_split.h; the forward
+// sweep uses three pieces, the fp32-equivalent form).  CA / CB then count K32 blocks per stage.
+template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny, int PR = 0>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MMG = VAR == PF_VAR_MMG, MM = VAR == PF_VAR_MM || MMG, EXT = VAR != PF_VAR_LEAN;
+  // PR = 1: three bf16 pieces; PR = 2: two fp16 pieces (4 bytes per weight on the stream instead of 6)
+  constexpr int NP = PR == 1 ? 3 : PR == 2 ? 2 : 0;
+  constexpr bool F16 = PR == 2;
+  constexpr int FA = PR ? CA * NP : CA, FB = PR ? CB * NP : CB;     // weight loads per stage
   // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
-  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
-  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
-                   SH::NT ? (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB) : 0,
+  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT, PR);
+  constexpr int NKBc = !SH::NT ? 0
+                       : PR ? ((SH::NT + 1) / 2 + CA + CB - 1) / (CA + CB) * (CA + CB) * NP     // loads per tile
+                            : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
+  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
+  constexpr int LDBc = (PR && SH::NT) ? NKBc / (PR ? NP : 1) * 32 + 16 : 0;
+  const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
+  const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);   // ... of whatever the hidden-layer epilogues write
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   const int T0 = EXT ? A.t0 : 0, T1 = EXT ? A.t1 : A.H;
   if (EXT && A.prof && blockIdx.x == 0 && threadIdx.x == 0)      // kernel entry (per-step launches: prologue cost)
@@ -1160,7 +1270,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
-  FastLds L = pm_fast_carve_shaped<SH, RT>(smem, P, F, R, LD, D, U);
+  FastLds L = pm_fast_carve_shaped<SH, RT, PR>(smem, P, F, R, LD, D, U);
   float* xa = L.xa;
   float* xb = L.xb;
 
@@ -1205,12 +1315,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   }
 
   if constexpr (SH::NL != 0 && SH::NT != 0) {
-    pm_fast_preload_shaped<RT, SH>(A, L, A.sd_fwd, row0, nvalid, tid);
+    pm_fast_preload_shaped<RT, SH, PR>(A, L, A.sd_fwd, row0, nvalid, tid);
   } else {
     pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-    pm_fast_preload_tails(A.sd_fwd, L, tid);
+    if constexpr (!PR) pm_fast_preload_tails(A.sd_fwd, L, tid);
   }
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
+  if (F16 && tid == 0) *L.ovf = 0;
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
   if (!x_ready) {
     const float* src = (T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D;
@@ -1223,8 +1334,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   }
   // register-resident first layers and head slices
   HeadW hwp, hwd;
-  head_load(hwp, P.wf[P.nl - 1], P.nt[P.nl - 1], wid, lane);
-  head_load(hwd, F.wf[F.nl - 1], F.nt[F.nl - 1], wid, lane);
+  HeadWS<PR ? NP : 1> hsp, hsd;
+  if constexpr (PR != 0) {
+    head_load_s(hsp, P.wf[P.nl - 1], (P.nt[P.nl - 1] + 1) / 2, wid, lane);
+    head_load_s(hsd, F.wf[F.nl - 1], (F.nt[F.nl - 1] + 1) / 2, wid, lane);
+  } else {
+    head_load(hwp, P.wf[P.nl - 1], P.nt[P.nl - 1], wid, lane);
+    head_load(hwd, F.wf[F.nl - 1], F.nt[F.nl - 1], wid, lane);
+  }
   Res0<RT> w0p, w0d;
   res0_load<RT>(w0p, P.wf[0], P.nt[1], wid, lane);
   res0_load<RT>(w0d, F.wf[0], F.nt[1], wid, lane);
@@ -1233,12 +1350,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int n_pol_stream = P.nl - 2;
   Cursor q;
   cur_init<SC>(sd, q, wid);
-  FragS<CA> fa;
-  FragS<CB> fb;
+  FragS<FA> fa;
+  FragS<FB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
-    frag_load<CA>(fa, q, vo0, vo1);
-    cur_advance<CA, SC>(sd, q, wid);
+    frag_load<FA>(fa, q, vo0, vo1);
+    cur_advance<FA, SC>(sd, q, wid);
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = VAR == PF_VAR_MM && A.mm_mode == 1 && mm_states;
@@ -1266,19 +1383,21 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   }
   auto pol_epi = [&](int l, int t, size_t blk, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * l);
-    return EpiFwdL<RT>{L.base + pm_rl(vdp, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdp, 8 * l + 2)),
-                       pm_rlp<uint8_t>(vdp, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * l + 5), out,
-                       pm_rlp<float>(vdp, 8 * l + 6) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
+    return EpiFwdL<RT, NP, F16>{L.base + pm_rl(vdp, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdp, 8 * l + 2)),
+                           pm_rlp<uint8_t>(vdp, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * l + 5), out,
+                           pm_rlp<float>(vdp, 8 * l + 6) + blk * (size_t)nt * 16 * R, ELD, R, row0, nvalid, nt, lane,
+                           F16 ? L.ovf : nullptr};
   };
   auto dyn_epi = [&](int l, int t, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdd, 8 * l);
-    return EpiFwdL<RT>{L.base + pm_rl(vdd, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdd, 8 * l + 2)),
-                       pm_rlp<uint8_t>(vdd, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * l + 5), out,
-                       nullptr, LD, R, row0, nvalid, nt, lane};
+    return EpiFwdL<RT, NP, F16>{L.base + pm_rl(vdd, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdd, 8 * l + 2)),
+                           pm_rlp<uint8_t>(vdd, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * l + 5), out,
+                           nullptr, ELD, R, row0, nvalid, nt, lane, F16 ? L.ovf : nullptr};
   };
   const float* pol_head_bias = L.base + pm_rl(vdp, 8 * (P.nl - 1) + 1);
   const float* dyn_head_bias = L.base + pm_rl(vdd, 8 * (F.nl - 1) + 1);
-  const int pol_head_kb = P.nt[P.nl - 1], dyn_head_kb = F.nt[F.nl - 1];
+  const int pol_head_kb = PR ? (P.nt[P.nl - 1] + 1) / 2 : P.nt[P.nl - 1];   // K blocks of the heads (K32 / K16)
+  const int dyn_head_kb = PR ? (F.nt[F.nl - 1] + 1) / 2 : F.nt[F.nl - 1];
   const int pnl = SH::NL ? SH::NL : P.nl, fnl = SH::NL ? SH::NL : F.nl;
 
   bool fed = false;   // the previous step's sampling phase already wrote this step's policy input
@@ -1296,7 +1415,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int k = i / R, r = i - k * R;
         const float v = (k < D) ? xa[r * D + k] : 0.f;
-        X[r * LD + k] = v;
+        PM_XIN(X)[r * PM_XLD + k] = v;
         st[(size_t)k * (16 * RT) + r] = v;
       }
       if (mm_in) {
@@ -1311,14 +1430,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       }
     }
     // ---- policy: first layer (resident), hidden layers (streamed), head K-split over the waves
-    EpiFwdL<RT> es{};
+    EpiFwdL<RT, NP, F16> es{};
     {
-      EpiFwdL<RT> e = pol_epi(0, t, blk, Y);
-      Res0Pre<RT, EpiFwdL<RT>> pp;
+      EpiFwdL<RT, NP, F16> e = pol_epi(0, t, blk, Y);
+      Res0Pre<RT, EpiFwdL<RT, NP, F16>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
       PF_MARK(1);
-      res0_layer<RT>(w0p, e.nt, X, LD, wid, lane, e, pp);
+      res0_layer<RT>(w0p, e.nt, PM_XIN(X), PM_XLD, wid, lane, e, pp);
       if (pnl > 2) es = pol_epi(1, t, blk, X);     // layer 1 writes the buffer that is X now
     }
     __syncthreads();
@@ -1331,7 +1450,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       PM_SWAP_XY();
       PF_MARK(2 + l);
     }
-    head_partial<RT>(hwp, pol_head_kb, X, LD, PM_HP(), wid, lane);
+    if constexpr (PR != 0) head_partial_s<RT, NP, F16>(hsp, pol_head_kb, X, (unsigned)LDB, PM_HP(), wid, lane);
+    else head_partial<RT>(hwp, pol_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PF_MARK(10);
     // ---- squash + dynamics input
@@ -1364,17 +1484,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           }
           v = (a - L.mx[k]) * L.iSx[k];
         }
-        X[r * LD + k] = v;
+        PM_XIN(X)[r * PM_XLD + k] = v;
       }
     }
     // ---- dynamics
     {
-      EpiFwdL<RT> e = dyn_epi(0, t, Y);
-      Res0Pre<RT, EpiFwdL<RT>> pp;
+      EpiFwdL<RT, NP, F16> e = dyn_epi(0, t, Y);
+      Res0Pre<RT, EpiFwdL<RT, NP, F16>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
       PF_MARK(11);
-      res0_layer<RT>(w0d, e.nt, X, LD, wid, lane, e, pp);
+      res0_layer<RT>(w0d, e.nt, PM_XIN(X), PM_XLD, wid, lane, e, pp);
       if (fnl > 2) es = dyn_epi(1, t, X);
     }
     __syncthreads();
@@ -1387,7 +1507,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       PM_SWAP_XY();
       PF_MARK(12 + l);
     }
-    head_partial<RT>(hwd, dyn_head_kb, X, LD, PM_HP(), wid, lane);
+    if constexpr (PR != 0) head_partial_s<RT, NP, F16>(hsd, dyn_head_kb, X, (unsigned)LDB, PM_HP(), wid, lane);
+    else head_partial<RT>(hwd, dyn_head_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PF_MARK(20);
     // ---- sample next state; on the plain path also the next step's policy input tile
@@ -1421,11 +1542,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           }
         }
         if (feed) {
-          L.bufA[r * LD + d] = xn;                 // free: the heads were read before the barrier
+          PM_XIN(L.bufA)[r * PM_XLD + d] = xn;     // free: the heads were read before the barrier
           stn[(size_t)d * (16 * RT) + r] = xn;
         }
       }
     }
+    if (F16 && tid == 0 && *L.ovf) atomicMin(A.status, t);   // an activation left fp16's range in this step (or earlier)
     PF_MARK(21);
     // The reward is NOT evaluated here: r~[t,b] depends only on the stored (x~, a), never feeds
     // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
@@ -1465,15 +1587,24 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
 // ===========================================================================
 // backward sweep (fast)
 // ===========================================================================
-template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny>
+// PR = 1: split bf16 with TWO pieces -- the adjoint is linear in the incoming gradient, its rounding does
+// not feed back into the trajectory (tools/split_precision_study.py: 4e-6 ... 7e-6 on the policy gradient)
+template <int RT, int CA, int CB, int VAR, class SH = PfShapeAny, int PR = 0>
 __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool MMG = VAR == PF_VAR_MMG, MM = VAR == PF_VAR_MM || MMG, EXT = VAR != PF_VAR_LEAN;
+  constexpr int NP = PR ? 2 : 0;
+  constexpr bool F16 = false;     // gradients of any magnitude: bf16 pieces
+  constexpr int FA = PR ? CA * NP : CA, FB = PR ? CB * NP : CB;     // weight loads per stage
   // weight stream of a shape-specialised kernel: every streamed layer is NT x NT tiles
-  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT);
-  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0,
-                   SH::NT ? (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB) : 0,
+  constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT, PR);
+  constexpr int NKB32c = ((SH::NT + 1) / 2 + CA + CB - 1) / (CA + CB) * (CA + CB);   // padded K32 blocks per tile
+  constexpr int NKBc = !SH::NT ? 0 : PR ? NKB32c * NP : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
+  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
+  constexpr int LDBc = (PR && SH::NT) ? NKB32c * 32 + 16 : 0;
+  const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
+  const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);
   // LEAN: whole horizon in one launch, no moment matching of states anywhere
   // Truncated horizon (utils/rollout.py:154-157): the sweep covers only the steps the forward sweep
   // completed, read from its status word on the device (no host round trip in between).
@@ -1506,7 +1637,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     }
     return;
   }
-  FastLds L = pm_fast_carve_shaped<SH, RT>(smem, P, F, R, LD, D, U);
+  FastLds L = pm_fast_carve_shaped<SH, RT, PR>(smem, P, F, R, LD, D, U);
   float* gx = L.xa;     // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;    // moment-matching adjoint of gx (in-kernel mm only)
   float* gxn = L.jx;    // dL/dx~ incl. the reward term, then + dynamics-input term
@@ -1548,10 +1679,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   }
 
   if constexpr (SH::NL != 0 && SH::NT != 0) {
-    pm_fast_preload_shaped<RT, SH>(A, L, A.sd_bwd, row0, nvalid, tid);
+    pm_fast_preload_shaped<RT, SH, PR>(A, L, A.sd_bwd, row0, nvalid, tid);
   } else {
     pm_fast_preload<RT>(A, L, row0, nvalid, tid);
-    pm_fast_preload_tails(A.sd_bwd, L, tid);
+    if constexpr (!PR) pm_fast_preload_tails(A.sd_bwd, L, tid);
   }
   int tround = 0;   // K-split rounds so far (the arrival counter is monotonic)
   for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // bufA, bufB: zero K padding
@@ -1567,8 +1698,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   }
   // resident tail slices (grad wrt the nets' inputs) and head-adjoint weights
   HeadW twd, twp;
-  head_load(twd, F.wb[0], F.nt[1], wid, lane);
-  head_load(twp, P.wb[0], P.nt[1], wid, lane);
+  HeadWS<PR ? NP : 1> tsd, tsp;
+  if constexpr (PR != 0) {
+    head_load_s(tsd, F.wb[0], (F.nt[1] + 1) / 2, wid, lane);
+    head_load_s(tsp, P.wb[0], (P.nt[1] + 1) / 2, wid, lane);
+  } else {
+    head_load(twd, F.wb[0], F.nt[1], wid, lane);
+    head_load(twp, P.wb[0], P.nt[1], wid, lane);
+  }
   Res0<RT> whd, whp;
   res0_load<RT>(whd, F.wb[F.nl - 1], F.nt[F.nl - 1], wid, lane);
   res0_load<RT>(whp, P.wb[P.nl - 1], P.nt[P.nl - 1], wid, lane);
@@ -1577,12 +1714,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int n_dyn_stream = F.nl - 2;
   Cursor q;
   cur_init<SC>(sd, q, wid);
-  FragS<CA> fa;
-  FragS<CB> fb;
+  FragS<FA> fa;
+  FragS<FB> fb;
   const unsigned vo0 = (unsigned)lane * 16u, vo1 = vo0 + 4096u;   // byte offsets of this lane in a chunk
   if (q.live) {
-    frag_load<CA>(fa, q, vo0, vo1);
-    cur_advance<CA, SC>(sd, q, wid);
+    frag_load<FA>(fa, q, vo0, vo1);
+    cur_advance<FA, SC>(sd, q, wid);
   }
   __syncthreads();
 
@@ -1635,7 +1772,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         v = g * stg[r * S + 1 + D + U + d];
       }
     }
-    L.bufA[r * LD + k] = v;
+    PM_XIN(L.bufA)[r * PM_XLD + k] = v;
     if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
   };
   const bool mm_in = VAR == PF_VAR_MM && (A.mm_mode == 1 && mms);
@@ -1659,16 +1796,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // epilogue of the adjoint GEMM whose output carries the activation pattern of layer idx
   auto dyn_epi = [&](int idx, int t, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdd, 8 * idx);
-    return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdd, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * idx + 3),
-                       out, nullptr, LD, R, row0, nvalid, nt, lane};
+    return EpiBwdL<RT, NP>{pm_rlp<const uint8_t>(vdd, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * idx + 3),
+                           out, nullptr, ELD, R, row0, nvalid, nt, lane};
   };
   auto pol_epi = [&](int idx, int t, size_t blk, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * idx);
-    return EpiBwdL<RT>{pm_rlp<const uint8_t>(vdp, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * idx + 3),
-                       out, pm_rlp<float>(vdp, 8 * idx + 4) + blk * (size_t)nt * 16 * R, LD, R, row0, nvalid, nt, lane};
+    return EpiBwdL<RT, NP>{pm_rlp<const uint8_t>(vdp, 8 * idx + 1) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * idx + 3),
+                           out, pm_rlp<float>(vdp, 8 * idx + 4) + blk * (size_t)nt * 16 * R, ELD, R, row0, nvalid, nt, lane};
   };
   const int pnl = SH::NL ? SH::NL : P.nl, fnl = SH::NL ? SH::NL : F.nl;
-  const int dyn_tail_kb = F.nt[1], pol_tail_kb = P.nt[1];
+  const int dyn_tail_kb = PR ? (F.nt[1] + 1) / 2 : F.nt[1], pol_tail_kb = PR ? (P.nt[1] + 1) / 2 : P.nt[1];
   float* const gT_head = A.gT[P.nl - 1];
 
   // Same phase pattern as the forward sweep: descriptors and the epilogue's activation bits
@@ -1699,10 +1836,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     }
     if (mm_in) {
       // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
+      // (scratch rows: the idle activation buffer, or -- split precision, where a stray fp32 row would
+      //  land in the piece planes' zero padding -- the input tile, which is free until phase A)
       const float* xsrc = A.xt + (size_t)t * B * D;
+      float* const xrows = PM_XIN(Y);
+      const int xrows_ld = PM_XLD;
       for (int i = tid; i < R * D; i += PF_NT) {
         const int r = i / D, d = i - r * D;
-        Y[r * LD + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
+        xrows[r * xrows_ld + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
       }
       {
         const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
@@ -1718,7 +1859,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        pm_mm_bwd(Y + lr0 * LD, LD, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
+        pm_mm_bwd(xrows + lr0 * xrows_ld, xrows_ld, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
                   gxt + lr0 * D, D, scr, lane,
                   A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
       }
@@ -1736,14 +1877,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       }
     }
     // ---- dynamics trunk (dX only); tail (grad wrt [x|a]) K-split over the waves
-    EpiBwdL<RT> es{};
+    EpiBwdL<RT, NP> es{};
     {
-      EpiBwdL<RT> e = dyn_epi(fnl - 2, t, Y);
-      Res0Pre<RT, EpiBwdL<RT>> pp;
+      EpiBwdL<RT, NP> e = dyn_epi(fnl - 2, t, Y);
+      Res0Pre<RT, EpiBwdL<RT, NP>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
       PF_MARK(3);
-      res0_layer<RT>(whd, e.nt, X, LD, wid, lane, e, pp);
+      res0_layer<RT>(whd, e.nt, PM_XIN(X), PM_XLD, wid, lane, e, pp);
       if (fnl > 2) es = dyn_epi(fnl - 3, t, X);
     }
     __syncthreads();
@@ -1756,7 +1897,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PM_SWAP_XY();
       PF_MARK(4 + l);
     }
-    head_partial<RT>(twd, dyn_tail_kb, X, LD, PM_HP(), wid, lane);
+    if constexpr (PR != 0) head_partial_s<RT, NP, F16>(tsd, dyn_tail_kb, X, (unsigned)LDB, PM_HP(), wid, lane);
+    else head_partial<RT>(twd, dyn_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PF_MARK(12);
     // ---- phase B: tail result; state part -> gxn, action part -> policy head adjoint
@@ -1781,8 +1923,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
             go_mu = gu;
             go_ls = gu * stg[r * S + 1 + 2 * D + U + j];
           }
-          X[r * LD + j] = go_mu;
-          X[r * LD + U + j] = go_ls;
+          PM_XIN(X)[r * PM_XLD + j] = go_mu;
+          PM_XIN(X)[r * PM_XLD + U + j] = go_ls;
           gst[(size_t)j * (16 * RT) + r] = go_mu;
           gst[(size_t)(U + j) * (16 * RT) + r] = go_ls;
         }
@@ -1791,15 +1933,15 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       for (int i = tid; i < R * 16; i += PF_NT) {
         const int r = i >> 4, k = i & 15;
         if (k >= 2 * U) {
-          X[r * LD + k] = 0.f;
+          PM_XIN(X)[r * PM_XLD + k] = 0.f;
           gst[(size_t)k * (16 * RT) + r] = 0.f;
         }
       }
     }
     // ---- policy trunk: dX chain + G stash; tail (grad wrt x) K-split over the waves
     {
-      EpiBwdL<RT> e = pol_epi(pnl - 2, t, blk, Y);
-      Res0Pre<RT, EpiBwdL<RT>> pp;
+      EpiBwdL<RT, NP> e = pol_epi(pnl - 2, t, blk, Y);
+      Res0Pre<RT, EpiBwdL<RT, NP>> pp;
       res0_prefetch<RT>(pp, e, e.nt, wid);
       __syncthreads();
       PF_MARK(13);
@@ -1816,7 +1958,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
           A.agn[(size_t)t * B + row0 + r] = sqrtf(s2);
         }
       }
-      res0_layer<RT>(whp, e.nt, X, LD, wid, lane, e, pp);
+      res0_layer<RT>(whp, e.nt, PM_XIN(X), PM_XLD, wid, lane, e, pp);
       if (pnl > 2) es = pol_epi(pnl - 3, t, blk, X);
     }
     __syncthreads();
@@ -1829,7 +1971,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PM_SWAP_XY();
       PF_MARK(14 + l);
     }
-    head_partial<RT>(twp, pol_tail_kb, X, LD, PM_HP(), wid, lane);
+    if constexpr (PR != 0) head_partial_s<RT, NP, F16>(tsp, pol_tail_kb, X, (unsigned)LDB, PM_HP(), wid, lane);
+    else head_partial<RT>(twp, pol_tail_kb, X, LD, PM_HP(), wid, lane);
     __syncthreads();
     PF_MARK(22);
     // ---- dL/dx_t = gxn + policy tail (+ external state gradient); on the plain path the same

@@ -11,6 +11,30 @@ from . import _lib
 
 LOG_MAX_STD = math.log(5.0)   # reference models/densities.py:75
 
+# Arithmetic of the hidden-width GEMMs of the sweep kernels (include/pmbrl.h, PMBRL_PREC_*):
+# 'f32' exact fp32 MFMA, 'split' bf16 pieces on the bf16 matrix cores (fp32-equivalent forward sweep,
+# two-piece adjoint).  Module default, overridable per call and by the environment.
+_PRECISIONS = {'f32': _lib.PREC_F32, 'split': _lib.PREC_SPLIT, 'split_f16': _lib.PREC_SPLIT_F16}
+_default_precision = [None]
+
+
+def set_precision(name):
+    """Default arithmetic of plans created from now on: 'f32' or 'split'."""
+    assert name in _PRECISIONS, name
+    _default_precision[0] = name
+
+
+def get_precision():
+    import os
+    return _default_precision[0] or os.environ.get('PMBRL_PRECISION', 'split_f16')
+
+
+def safe_precision(name):
+    """The arithmetic to retry a failed rollout with before the failure is believed: the fp16 pieces of
+    'split_f16' overflow beyond +-65504 (a hidden activation that large is reported as a non-finite
+    step), the bf16 pieces of 'split' have fp32's range.  None: `name` has no such hazard."""
+    return 'split' if name == 'split_f16' else None
+
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
@@ -254,7 +278,7 @@ class Engine:
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
-                 force_generic=False, no_shaped=False, infer_ns=False):
+                 force_generic=False, no_shaped=False, infer_ns=False, precision=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -282,6 +306,7 @@ class Engine:
                 mlp.keep[i] = float(keep[i]) if i < len(keep) else 1.0
         cfg.reward = make_reward_struct(reward_spec, D, U)
         cfg.rows_per_wg_hint = rows_per_wg_hint
+        cfg.precision = _PRECISIONS[precision if precision is not None else get_precision()]
         self.cfg = cfg
         self.B, self.D, self.U, self.H = B, D, U, H
         self.n_pol_layers = len(pol_dims) - 1
@@ -295,7 +320,8 @@ class Engine:
         self.info = dict(rows_per_wg=info[0], n_wg=info[1], row_tiles=info[2],
                          lds_bytes=info[3], n_pol_params=info[4], n_dyn_params=info[5],
                          dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9],
-                         fast=info[10], stages=(info[11] >> 4, info[11] & 15), mm_grid=info[12])
+                         fast=info[10], stages=(info[11] >> 4, info[11] & 15), mm_grid=info[12],
+                         precision={_lib.PREC_SPLIT: 'split', _lib.PREC_SPLIT_F16: 'split_f16'}.get(info[13], 'f32'))
         self.n_pol_params = info[4]
         self.n_dyn_params = info[5]
         ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)

@@ -130,6 +130,25 @@ def synthetic_problem(name='cartpole_nomm', seed=0, P=None, S=None, H=None, data
     return d
 
 
+def shard_problem(d, rank, world):
+    """Rows [rank*B/world, (rank+1)*B/world) of problem d as one rank's problem (whole particle /
+    moment-matching groups per rank); shared inputs (weights, normalisation, the cyclic
+    moment-matching noise, which the kernels index with the global row) stay whole."""
+    B = d['x0'].shape[0]
+    assert B % world == 0
+    per = B // world
+    lo, hi = rank * per, (rank + 1) * per
+    G = int(d['mm_groups'])
+    assert G % world == 0 or G == 0, 'whole moment-matching groups per rank'
+    out = dict(d)
+    for k, v in d.items():
+        v = np.asarray(v) if not isinstance(v, (str, bool, int, float)) else v
+        if k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and getattr(v, 'ndim', 0) == 2 and v.shape[0] == B):
+            out[k] = v[lo:hi]
+    out['mm_groups'] = G // world
+    return out
+
+
 # ---------------------------------------------------------------------------
 def reward_spec_from_problem(d):
     return dict(kind=str(d['rew_kind']), expand=bool(d['rew_expand']),
@@ -171,7 +190,7 @@ def loss_weights(d, B_global):
 
 
 def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_global=None,
-                        row_offset=None, force_generic=False, no_shaped=False):
+                        row_offset=None, force_generic=False, no_shaped=False, precision=None):
     """Build an Engine + its device input tensors from a problem dict.
     shard=(rank, world): this rank's contiguous block of rows (whole mm groups) of ONE
     global batch described by d.  B_global/row_offset instead place the whole of d as a
@@ -199,7 +218,8 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    reward_spec_from_problem(d), mm_states=bool(d['mm_states']),
                    mm_rewards=bool(d['mm_rewards']), mm_groups=Gl, device=dev, B_global=Bg,
                    row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic,
-                   no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False)
+                   no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False,
+                   precision=precision)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
     args = dict(
         x0=T(d['x0'][lo:hi]), pol_flat=T(flat_params(d, 'pol')), dyn_flat=T(flat_params(d, 'dyn')),

@@ -100,10 +100,11 @@ def _reward_key(spec):
 
 def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
                mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
-               max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False):
+               max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None):
+    precision = precision or E.get_precision()
     key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
            tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
-           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns))
+           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision)
     eng = _ENGINES.get(key)
     if eng is None:
         if len(_ENGINES) > 16:
@@ -112,7 +113,7 @@ def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_stat
                        mm_states=mm_states, mm_rewards=mm_rewards, mm_groups=mm_groups,
                        device=device, B_global=B_global, row_offset=row_offset,
                        zmm_per_step=zmm_per_step, max_log_std_pol=max_log_std[0],
-                       max_log_std_dyn=max_log_std[1], infer_ns=infer_ns)
+                       max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision)
         _ENGINES[key] = eng
     return eng
 
@@ -122,7 +123,7 @@ class Bundle:
 
     def __init__(self, dynamics, policy, B, H, resample_state_noise, resample_action_noise,
                  mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=None, row_offset=0,
-                 infer_ns=False):
+                 infer_ns=False, precision=None):
         if not isinstance(policy, M.Policy) or not isinstance(dynamics, M.DynamicsModel):
             raise TypeError('rollout() needs prob_mbrl_amd.models.Policy / DynamicsModel')
         if len(policy.angle_dims) or len(dynamics.angle_dims):
@@ -209,7 +210,7 @@ class Bundle:
                                  self.dyn_keep, self.spec, mm_states, mm_rewards, mm_groups, dev,
                                  B_global=B_global, row_offset=row_offset,
                                  zmm_per_step=self.zmm_per_step, max_log_std=self.max_log_std,
-                                 infer_ns=infer_ns and (mm_states or mm_rewards))
+                                 infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision)
 
     def forward(self, x0, out=None):
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
@@ -282,15 +283,23 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     if callable(on_pol_eval):
         raise NotImplementedError('on_pol_eval needs a per-step Python hook; not offered')
     B = states.shape[0]
-    bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
-                    mm_states, mm_rewards, mm_groups, z_mm, z_rr,
-                    B_global=kwargs.pop('B_global', None), row_offset=kwargs.pop('row_offset', 0),
-                    infer_ns=bool(infer_noise_variables))
-    # a list that backward() appends the [H, B] matrix of ||dL/da_t|| to (prioritised replay)
-    bundle.agn_out = kwargs.pop('action_grad_norms_out', None)
-    x0 = states.to(device=bundle.device, dtype=torch.float32)
-    S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
-    n = bundle.engine.valid_steps()
+    B_global, row_offset = kwargs.pop('B_global', None), kwargs.pop('row_offset', 0)
+    agn_out = kwargs.pop('action_grad_norms_out', None)
+    precision = kwargs.pop('precision', None)
+    while True:
+        bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
+                        mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=B_global,
+                        row_offset=row_offset, infer_ns=bool(infer_noise_variables), precision=precision)
+        # a list that backward() appends the [H, B] matrix of ||dL/da_t|| to (prioritised replay)
+        bundle.agn_out = agn_out
+        x0 = states.to(device=bundle.device, dtype=torch.float32)
+        S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
+        n = bundle.engine.valid_steps()
+        retry = E.safe_precision(bundle.engine.info['precision']) if n < steps else None
+        if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None):
+            break          # (fresh noise was drawn: a retry would be a different rollout)
+        # a failure under fp16 pieces may be their range, not the rollout: decide on the bf16 path
+        precision = retry
     if n < steps:
         # utils/rollout.py:154-157: keep a truncated horizon if enough steps succeeded
         if n <= 5:

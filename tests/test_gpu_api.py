@@ -120,6 +120,42 @@ def test_rollout_truncated_horizon_matches_reference(monkeypatch):
         pm.utils.rollout(x0, dyn, pol, H, resample_state_noise=False, resample_action_noise=False)
 
 
+def test_fp16_range_failure_is_retried_on_bf16_pieces(capsys):
+    """'split_f16' (the default arithmetic) keeps the forward sweep's hidden activations as fp16 pieces:
+    beyond +-65504 they overflow and the step is reported as non-finite.  That must not look like a
+    failed rollout to the caller: rollout() and mc_pilco re-run on the bf16 pieces (fp32's range) before
+    believing a failure.  Policy rescaled so that its first hidden layer is ~1e6 x larger and the second
+    layer's weights 1e-6 x smaller: the same function in exact arithmetic, far outside fp16."""
+    import prob_mbrl_amd as pm
+    from prob_mbrl_amd import engine as E
+    assert E.get_precision() == 'split_f16'
+    d = dict(common.load('nomm_d4'))
+    d['pol_W0'] = d['pol_W0'] * np.float32(2.0**20)
+    d['pol_b0'] = d['pol_b0'] * np.float32(2.0**20)
+    d['pol_W1'] = d['pol_W1'] * np.float32(2.0**-20)       # exact rescaling (powers of two)
+    ref = common.load('nomm_d4')
+    dyn, pol = common.modules_from_fixture(d, 'nomm_d4', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    H = int(d['H'])
+    # the fp16 path alone fails ...
+    eng, args, _ = common.engine_from_fixture(d, DEV, precision='split_f16')
+    eng.forward(**args)
+    assert eng.valid_steps() < H
+    # ... the public entry points do not
+    states, actions, rewards = pm.utils.rollout(x0, dyn, pol, H, resample_state_noise=False,
+                                                resample_action_noise=False)
+    assert len(rewards) == H
+    assert common.rel(torch.stack(states).detach().cpu().numpy(), ref['ref64_states']) < 2e-5
+    opt = torch.optim.Adam(pol.parameters(), 1e-4)
+    seen = []
+    pm.algorithms.mc_pilco(x0, dyn, pol, H, opt, None, 6, on_iteration=lambda i, loss, *a: seen.append(float(loss)),
+                           frozen_noise=dict(z_mm=torch.zeros(H + x0.shape[0], 4), z_rr=torch.zeros(H + x0.shape[0], 1)))
+    out = capsys.readouterr().out
+    assert 'continuing with split' in out and 'RuntimeError' not in out
+    assert len(seen) >= 4 and all(np.isfinite(seen))
+    assert abs(seen[0] - float(ref['ref32_loss'])) <= 1e-4 * abs(float(ref['ref32_loss']))
+
+
 def test_mc_pilco_autograd_path_options():
     """CVaR + regulariser go through the autograd node; runs and moves the parameters."""
     import prob_mbrl_amd as pm

@@ -15,6 +15,29 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
 
 
+def _errors_vs_oracle(d, **kw):
+    from oracle import ref_torch as R
+    eng, S, A, Rw, loss, g, _ = _run(d, **kw)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(16)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
+                                            meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+    return eng, common.rel(S, torch.stack(S64).detach().numpy()), abs(loss - float(l64)) / abs(float(l64)), \
+        common.rel(g, g64.numpy())
+
+
+@pytest.mark.parametrize('prec', ['split', 'split_f16'])
+@pytest.mark.parametrize('config', ['cartpole_nomm', 'cartpole_mm'])
+def test_full_size_split_precision_matches_oracle(config, prec):
+    """C2 / C3 at full size on the split-operand matrix-core paths against the fp64 oracle, same
+    tolerances as the exact-fp32 path."""
+    d = _problem(config)
+    eng, e_s, e_l, e_g = _errors_vs_oracle(d, precision=prec)
+    assert eng.info['precision'] == prec and eng.info['fast'] == 1
+    print('%s %s: states %.2e loss %.2e grad %.2e' % (config, prec, e_s, e_l, e_g))
+    assert e_s < 2e-5 and e_l < 2e-5 and e_g < 1e-4
+
+
 def _run(d, lean=True, **kw):
     from prob_mbrl_amd import problem as PB
     eng, args, _ = PB.engine_from_problem(d, DEV, **kw)

@@ -98,9 +98,12 @@ def _wide(d):
     return max(d['pol_W0'].shape[0], d['dyn_W0'].shape[0]) > 256
 
 
-def _run(d, dev, hint=0, generic=False, n_valid=None):
-    eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint, force_generic=generic)
+def _run(d, dev, hint=0, generic=False, n_valid=None, precision=None):
+    eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint, force_generic=generic,
+                                              precision=precision)
     assert bool(eng.info['fast']) == (not generic and not _wide(d) and not bool(d.get('infer_ns', False)))
+    if precision in ('split', 'split_f16'):
+        assert eng.info['precision'] == precision      # the bf16 / fp16 matrix-core path really ran
     S, A, Rw = eng.forward(**args)
     if n_valid is not None:     # pretend the sweep failed at step n_valid (see test_truncated_horizon)
         eng.status[0] = n_valid
@@ -135,6 +138,30 @@ def test_rollout_parity(dev, name, generic):
     assert common.rel(g, d['ref64_grad']) < TOL_GRAD
     if 'ref32_grad' in d:
         assert common.rel(g, d['ref32_grad']) < TOL_GRAD + common.rel(d['ref32_grad'], d['ref64_grad'])
+
+
+_SPLIT_CASES = [n for n, g in _PARITY_CASES if not g]
+
+
+@pytest.mark.parametrize('prec', ['split', 'split_f16'])
+@pytest.mark.parametrize('name', _SPLIT_CASES)
+def test_rollout_parity_split_precision(dev, name, prec):
+    """PMBRL_PREC_SPLIT / _SPLIT_F16: the hidden-width GEMMs on the bf16 / fp16 matrix cores with split
+    operands (forward: three bf16 or two fp16 pieces = fp32-equivalent; adjoint: two bf16 pieces) against
+    the same fixtures and the same tolerances as the exact-fp32 path.  Reports the errors next to the
+    fp32 path's."""
+    d = common.load(name)
+    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev, precision=prec)
+    _, S0, A0, Rw0, loss0, g0, _, _ = _run(d, dev, precision='f32')
+    assert eng.valid_steps() == int(d['H'])
+    e_s, e_g = common.rel(S, d['ref64_states']), common.rel(g, d['ref64_grad'])
+    print('%s %s: states %.2e grad %.2e | f32: states %.2e grad %.2e' %
+          (name, prec, e_s, e_g, common.rel(S0, d['ref64_states']), common.rel(g0, d['ref64_grad'])))
+    assert e_s < TOL_TRAJ
+    assert common.rel(A, d['ref64_actions']) < TOL_TRAJ
+    assert common.rel(Rw.reshape(d['ref64_rewards'].shape), d['ref64_rewards']) < TOL_TRAJ
+    assert abs(loss - float(d['ref64_loss'])) <= TOL_TRAJ * abs(float(d['ref64_loss']))
+    assert e_g < TOL_GRAD
 
 
 @pytest.mark.parametrize('generic', [False, True], ids=['fast', 'generic'])

@@ -39,6 +39,9 @@ def main():
         a = buf.cpu().numpy().reshape(H, 32)
         print('== %s: cycles between marks, median over steps (slot: delta)' % name)
         slots = [s for s in range(32) if a[H // 2, s] != 0]
+        if not slots:
+            print('   (no stamps: this variant carries no cycle stamps)')
+            continue
         order = sorted(slots, key=lambda s: a[H // 2, s])
         prev = None
         tot = 0
