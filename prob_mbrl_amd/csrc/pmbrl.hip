@@ -1101,9 +1101,24 @@ static int fast_variant(int RT, const RolloutArgs& A) {
 }
 // split-bf16 precision (pmbrl_split.h): same variants and shape specialisation, PR = 1
 template <int RT, int CA, int CB, int PR>
-static void launch_split(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-  const int var = fast_variant(RT, A);
+static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t s, bool fwd) {
+  const int var = fast_variant(RT, A0);
   const dim3 g(p->nwg), b(PF_NT);
+  RolloutArgs A = A0;
+  // Register-resident first tiles (pmbrl_fast.h, resident_tile_s): the 16-row plain variants keep output
+  // tile `wave` of the sweep's first streamed layer in registers when a tile is exactly one stage pair and
+  // two pieces wide; the stream table then starts at tile 8 of that layer.
+  {
+    StreamDesc& sd = fwd ? A.sd_fwd : A.sd_bwd;
+    const int np = (fwd && PR != 2) ? 3 : 2;
+    if (RT == 1 && CA + CB == 7 && np == 2 && (var == PF_VAR_LEAN || var == PF_VAR_EXT) && sd.n >= 1 &&
+        sd.n_kb[0] == 7 * np && sd.n_ot[0] > 8) {
+      A.res_tiles = 8;
+      A.res_w = sd.wf[0];
+      sd.wf[0] += (size_t)8 * sd.n_kb[0] * 256;
+      sd.n_ot[0] -= 8;
+    }
+  }
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
   if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
       A.pol.nl == NLV && A.dyn.nl == NLV && hidden_tiles(A) == NTV) {                                        \

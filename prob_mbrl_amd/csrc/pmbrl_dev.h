@@ -84,6 +84,10 @@ struct RolloutArgs {
   int rows_per_wg, nwg, Rw;   // Rw = 16*RT = stash block width
   int LD;              // LDS leading dimension of the activation buffers (floats)
   int LDB;             // split precision: leading dimension of the bf16 piece planes (elements; 0 = fp32 path)
+  int res_tiles;       // split precision: the first res_tiles (0 or 8 = one per wave) output tiles of the sweep's FIRST
+                       // streamed layer keep their weights in registers for the launch; the stream table then
+                       // describes only the remaining tiles of that layer (res_w: the layer's full fragments)
+  const float* res_w;
   float mls_pol, mls_dyn;
   NetDev pol, dyn;
   const RewardDev* rew;

@@ -185,13 +185,15 @@ struct Cursor {
 
 // Compile-time shape of the weight stream (shape-specialised kernels: every streamed layer has
 // the same tile / k-block counts); zeros = read the lane table.
-template <int NOT_, int NKB_, int NS_>
+template <int NOT_, int NKB_, int NS_, int NOT0_ = NOT_>
 struct PfStream {
   static constexpr int NOT = NOT_, NKB = NKB_, NS = NS_;   // streamed tiles, padded k-blocks, layers
+  static constexpr int NOT0 = NOT0_;                       // streamed tiles of layer 0 (fewer when its first tiles
+                                                           // are register-resident, resident_tile_s)
 };
 typedef PfStream<0, 0, 0> PfStreamAny;
 #define SD_N(SC, sd) (SC::NS ? SC::NS : (sd).n)
-#define SD_NOT(SC, sd, l) (SC::NOT ? SC::NOT : pm_rl((sd).v, 4 * (l)))
+#define SD_NOT(SC, sd, l) (SC::NOT ? ((l) == 0 ? SC::NOT0 : SC::NOT) : pm_rl((sd).v, 4 * (l)))
 #define SD_NKB(SC, sd, l) (SC::NKB ? SC::NKB : pm_rl((sd).v, 4 * (l) + 1))
 #define SD_WF(sd, l) pm_rlp<const float>((sd).v, 4 * (l) + 2)
 template <class SC>
@@ -241,7 +243,7 @@ __device__ __forceinline__ void cur_init(const SdV& sd, Cursor& q, int wid) {
 }
 template <int CKB, class SC>
 __device__ __forceinline__ void cur_advance(const SdV& sd, Cursor& q, int wid) {
-  const int n_kb = SC::NKB ? SC::NKB : q.n_kb, n_ot = SC::NOT ? SC::NOT : q.n_ot;
+  const int n_kb = SC::NKB ? SC::NKB : q.n_kb, n_ot = SC::NOT ? (q.li == 0 ? SC::NOT0 : SC::NOT) : q.n_ot;
   q.c += CKB;
   q.wp += (size_t)CKB * 256;
   if (q.c >= n_kb) {
@@ -359,7 +361,7 @@ __device__ __forceinline__ void stream_layer(const SdV& sd, int li, Cursor& q, F
   // On entry the load cursor is one chunk ahead INSIDE layer li (every layer has >= 2 chunks per
   // tile), unless this wave owns no tile of it: the layer shape is already in SGPRs.
   if (!q.live || q.li != li) return;
-  const int n_ot = SC::NOT ? SC::NOT : q.n_ot;
+  const int n_ot = SC::NOT ? (li == 0 ? SC::NOT0 : SC::NOT) : q.n_ot;
   const int nch2 = (SC::NKB ? SC::NKB : q.n_kb) / (CA + CB);
   int pslot = 24;
   BPair<RT> b0;
@@ -417,9 +419,11 @@ template <int RT, int CA, int CB, int NP, bool F16, class SC, class Epi>
 __device__ __forceinline__ void stream_layer_s(const SdV& sd, int li, Cursor& q, FragS<CA * NP>& fa,
                                                FragS<CB * NP>& fb, const float* buf_in, unsigned ldb,
                                                int wid, int lane, Epi& epi, unsigned vo0, unsigned vo1,
-                                               long long* prof = nullptr) {
+                                               long long* prof = nullptr, int ot_base = 0) {
+  // (ot_base: the stream's tile 0 of this layer is output tile ot_base -- the tiles before it are
+  //  register-resident, see resident_tile_s)
   if (!q.live || q.li != li) return;
-  const int n_ot = SC::NOT ? SC::NOT : q.n_ot;
+  const int n_ot = SC::NOT ? (li == 0 ? SC::NOT0 : SC::NOT) : q.n_ot;
   const int nch2 = (SC::NKB ? SC::NKB : q.n_kb) / ((CA + CB) * NP);
   int pslot = 24;
   const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
@@ -432,7 +436,7 @@ __device__ __forceinline__ void stream_layer_s(const SdV& sd, int li, Cursor& q,
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
     typename Epi::Pre pre[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot, rt);
+    for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot + ot_base, rt);
     f32x4 acc[2][RT];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -463,11 +467,37 @@ __device__ __forceinline__ void stream_layer_s(const SdV& sd, int li, Cursor& q,
       pacc[rt] = acc[0][rt] + acc[1][rt];
       ppre[rt] = pre[rt];
     }
-    pot = ot;
+    pot = ot + ot_base;
   }
   if (pot >= 0) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) epi(pot, rt, pacc[rt], ppre[rt]);
+  }
+}
+
+// One output tile whose weights (NB K32 blocks x NP pieces) stay in REGISTERS for the whole launch: no
+// weight load, no wait -- the sweep kernels are bound by the weight stream L2 -> CU, and the split-precision
+// instantiations leave ~90 registers per lane unused, which is one tile per wave.
+template <int RT, int NB, int NP, bool F16, class Epi>
+__device__ __forceinline__ void resident_tile_s(const FragS<NB * NP>& w, const float* buf_in, unsigned ldb, int lane,
+                                                Epi& epi, int ot) {
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  typename Epi::Pre pre[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot, rt);
+  BQ<RT, NP> b0;
+  bq_load<RT, NP>(b0, lb, ldb, 0);
+  f32x4 acc[2][RT];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag_compute_s<RT, NB, NP, F16>(w, 0, 0, lb, ldb, acc, b0);
+  Epi::wait_all();      // the epilogue operands (adjoint: activation bits from L2); also lands the stream's next stage
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    epi.landed(pre[rt], rt);
+    epi(ot, rt, acc[0][rt] + acc[1][rt], pre[rt]);
   }
 }
 
@@ -1159,7 +1189,11 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
 // tile is K-split, that tile's partial / gather / epilogue around it
 #define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
   if constexpr (PR != 0) {                                                                              \
-    stream_layer_s<RT, CA, CB, NP, F16, SC>(sd, (SI), q, fa, fb, X, (unsigned)LDB, wid, lane, (ES), vo0, vo1, (PROF)); \
+    const int rb_ = (RESK && (SI) == 0) ? res_tiles : 0;                                                \
+    if constexpr (RESK) {                                                                               \
+      if (rb_) resident_tile_s<RT, CA + CB, NP, F16>(wres, X, (unsigned)LDB, lane, (ES), wid);         \
+    }                                                                                                   \
+    stream_layer_s<RT, CA, CB, NP, F16, SC>(sd, (SI), q, fa, fb, X, (unsigned)LDB, wid, lane, (ES), vo0, vo1, (PROF), rb_); \
   } else {                                                                                              \
     const int ks_ = SKS_KNOWN ? 1 : (SC::NOT ? 0 : pm_rl(sd.k, 4 * (SI)));                                                            \
     typename std::remove_reference<decltype(ES)>::type::Pre tpre_[RT];                                  \
@@ -1250,8 +1284,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   constexpr int NKBc = !SH::NT ? 0
                        : PR ? ((SH::NT + 1) / 2 + CA + CB - 1) / (CA + CB) * (CA + CB) * NP     // loads per tile
                             : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
+  // register-resident first tiles (resident_tile_s): compiled into the 16-row plain variants whose stage pair
+  // is a whole tile; the tile counts of the stream then differ between layers (read from the table)
+  constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
-                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0, SH::NT - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKBc / (PR ? NP : 1) * 32 + 16 : 0;
   const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
   const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);   // ... of whatever the hidden-layer epilogues write
@@ -1356,6 +1393,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   if (q.live) {
     frag_load<FA>(fa, q, vo0, vo1);
     cur_advance<FA, SC>(sd, q, wid);
+  }
+  // register-resident tile of this wave: output tile `wid` of the sweep's first streamed layer
+  // (shape-specialised instantiations: always on, the stream's tile counts are compile-time constants)
+  const int res_tiles = !RESK ? 0 : (SH::NT > 8 ? 8 : A.res_tiles);
+  FragS<RESK ? (CA + CB) * NP : 1> wres;
+  if constexpr (RESK) {
+    if (res_tiles) {
+      const float* wp = A.res_w + (size_t)wid * ((CA + CB) * NP) * 256 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < (CA + CB) * NP; ++i) wres.a[i] = ldg4(wp + (size_t)i * 256);
+    }
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = VAR == PF_VAR_MM && A.mm_mode == 1 && mm_states;
@@ -1600,8 +1648,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr bool SKS_KNOWN = SH::NT && pm_fast_ksplit(SH::NT, RT, PR);
   constexpr int NKB32c = ((SH::NT + 1) / 2 + CA + CB - 1) / (CA + CB) * (CA + CB);   // padded K32 blocks per tile
   constexpr int NKBc = !SH::NT ? 0 : PR ? NKB32c * NP : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
+  constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
-                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0> SC;
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0, SH::NT - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKB32c * 32 + 16 : 0;
   const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
   const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);
@@ -1720,6 +1769,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   if (q.live) {
     frag_load<FA>(fa, q, vo0, vo1);
     cur_advance<FA, SC>(sd, q, wid);
+  }
+  // register-resident tile of this wave: output tile `wid` of the sweep's first streamed layer
+  // (shape-specialised instantiations: always on, the stream's tile counts are compile-time constants)
+  const int res_tiles = !RESK ? 0 : (SH::NT > 8 ? 8 : A.res_tiles);
+  FragS<RESK ? (CA + CB) * NP : 1> wres;
+  if constexpr (RESK) {
+    if (res_tiles) {
+      const float* wp = A.res_w + (size_t)wid * ((CA + CB) * NP) * 256 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < (CA + CB) * NP; ++i) wres.a[i] = ldg4(wp + (size_t)i * 256);
+    }
   }
   __syncthreads();
 
