@@ -1,5 +1,6 @@
 // libpmbrl_hip.so -- C ABI (include/pmbrl.h) over the gfx950 kernels.
 // Host side: shape validation, tiling choice, workspace carve-up, launches.
+#define PM_MAIN_TU
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -9,8 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "pmbrl.h"
-#include "pmbrl_dev.h"
+#include "pmbrl_host.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
 #include "pmbrl_fast.h"
@@ -19,16 +19,11 @@
 #include "pmbrl_bnn.h"
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+int pm_fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-#define HIPCHK(expr)                                                               \
-  do {                                                                             \
-    hipError_t _e = (expr);                                                        \
-    if (_e != hipSuccess)                                                          \
-      return fail(-100 - (int)_e, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
+static int fail(int code, const std::string& msg) { return pm_fail(code, msg); }
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
 extern "C" int pmbrl_version(void) { return 2; }
@@ -357,49 +352,6 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A,
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-struct NetPlan {
-  int nl;
-  int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
-  float keep[PM_MAXL];
-  size_t w_off[PM_MAXL], b_off[PM_MAXL];   // offsets (floats) in the flat parameter vector
-  size_t n_params;
-  // workspace offsets (bytes)
-  size_t wf[PM_MAXL], wb[PM_MAXL], bias[PM_MAXL], abits[PM_MAXL];
-};
-
-struct pmbrl_plan {
-  pmbrl_config cfg;
-  int device;
-  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CA, CB;   // CA/CB: k-blocks per weight-stream stage
-  int prec, LDB;   // PMBRL_PREC_* in use; split precision: leading dimension of the bf16 piece planes
-  size_t lds_bytes;
-  NetPlan pol, dyn;
-  RewardDev* rew_d;
-  DwBlock* dw_blocks_d;
-  int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
-  int dw_wave_first[PM_DW_NW + 1];
-  // workspace offsets (bytes)
-  size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
-      off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, ws_bytes;
-  int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
-  // optional per-kernel timing (hipEvents on the caller's stream)
-  long long* prof_fwd;
-  long long* prof_bwd;
-  int timing;
-  hipEvent_t ev[PMBRL_TIMER_COUNT][2];
-  bool ev_set[PMBRL_TIMER_COUNT];
-};
-
-struct ScopedTimer {
-  pmbrl_plan* p; int slot; hipStream_t s;
-  ScopedTimer(pmbrl_plan* p_, int slot_, hipStream_t s_) : p(p_), slot(slot_), s(s_) {
-    if (p->timing) (void)hipEventRecord(p->ev[slot][0], s);
-  }
-  ~ScopedTimer() {
-    if (p->timing) { (void)hipEventRecord(p->ev[slot][1], s); p->ev_set[slot] = true; }
-  }
-};
-
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expect,
@@ -424,104 +376,6 @@ static int net_plan(const pmbrl_mlp& m, NetPlan& n, int in_expect, int out_expec
     off += n.dim[l + 1];
   }
   n.n_params = off;
-  return 0;
-}
-
-// the instantiated (row tiles, stage pair) combinations -- keep in sync with stages_for()
-#define PM_FAST_CASES                                                                  \
-  PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
-  PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
-// shape-specialised instantiations (pmbrl_fast.h: PfShape): RT, CA, CB, variant, D, U, LD, layers,
-// 16-wide tiles per hidden layer.
-// The shipped configurations: cart-pole (D=4) and double cart-pole (D=6) states, one action,
-// 2 x 200 hidden units; plain / per-step / in-kernel moment matching.
-#define PM_FAST_SHAPED_CASES                                  \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 4, 1, 216, 3, 13)      \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3, 13)       \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3, 13)      \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3, 13)      \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 5, 1, 216, 3, 13)       \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 6, 1, 216, 3, 13)       \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 5, 1, 216, 3, 13)        \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 6, 1, 216, 3, 13)        \
-  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
-  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)        \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 4, 1, 216, 3, 13)       \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 5, 1, 216, 3, 13)       \
-  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 6, 1, 216, 3, 13)
-
-// split-bf16 instantiations (pmbrl_split.h): stage pairs in K32 blocks
-#define PM_SPLIT_CASES PM_SPLIT_CASE(1, 4, 3) PM_SPLIT_CASE(1, 1, 1) PM_SPLIT_CASE(2, 4, 3) PM_SPLIT_CASE(2, 1, 1)
-// shape-specialised split instantiations; LDV: floats per row of an activation buffer = piece planes x 240 / 2
-// (three bf16 planes: 360, two fp16 planes: 240)
-#define PM_SPLIT_SHAPED_CASES(LDV)                             \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 4, 1, LDV, 3, 13)       \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_EXT, 4, 1, LDV, 3, 13)        \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
-  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)
-
-template <int RT, int CA, int CB, int PR>
-static int set_attr_split(size_t lds) {
-  const void* fns[] = {
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_EXT, PfShapeAny, PR>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_EXT, PfShapeAny, PR>),
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MM, PfShapeAny, PR>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM, PfShapeAny, PR>)};
-  for (const void* f : fns)
-    HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if constexpr (RT == 1) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MMG, PfShapeAny, PR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MMG, PfShapeAny, PR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                          \
-  if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
-    HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
-    HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
-  }
-  PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
-#undef PM_FAST_SHAPED
-  return 0;
-}
-
-template <int RT, int CA, int CB>
-static int set_attr_fast(size_t lds) {
-  const void* fns[] = {
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_LEAN>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_LEAN>),
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_EXT>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_EXT>),
-      reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MM>),
-      reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM>)};
-  for (const void* f : fns)
-    HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if constexpr (RT == 1) {     // the one-launch form of mm_mode 3 exists for 16-row workgroups
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MMG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MMG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                          \
-  if (RT == RTV && CA == CAV && CB == CBV) {                                                             \
-    HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
-    HIPCHK(hipFuncSetAttribute(                                                                          \
-        reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                          \
-  }
-  PM_FAST_SHAPED_CASES
-#undef PM_FAST_SHAPED
   return 0;
 }
 
@@ -852,17 +706,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       default: rc2 = set_attr<4>(p->lds_bytes); break;
     }
   } else if (p->prec) {
-#define PM_SPLIT_CASE(RTV, CAV, CBV)                                 \
-  if (p->RT == RTV && p->CA == CAV && p->CB == CBV)                  \
-    rc2 = p->prec == PMBRL_PREC_SPLIT_F16 ? set_attr_split<RTV, CAV, CBV, 2>(p->lds_bytes) \
-                                          : set_attr_split<RTV, CAV, CBV, 1>(p->lds_bytes);
-    PM_SPLIT_CASES
-#undef PM_SPLIT_CASE
+    rc2 = p->prec == PMBRL_PREC_SPLIT_F16 ? pm_fast_split2_set_attr(p) : pm_fast_split1_set_attr(p);
   } else {
-#define PM_FAST_CASE(RTV, CAV, CBV) \
-  if (p->RT == RTV && p->CA == CAV && p->CB == CBV) rc2 = set_attr_fast<RTV, CAV, CBV>(p->lds_bytes);
-    PM_FAST_CASES
-#undef PM_FAST_CASE
+    rc2 = pm_fast_f32_set_attr(p);
   }
   if (p->mm_mode == 2 || p->mm_mode == 3) {
     const int smem = (int)(pm_mm_kernel_doubles(c.D) * sizeof(double));
@@ -1084,130 +930,10 @@ template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
-// 16-wide tiles of the hidden layers if every hidden layer of both nets has the same width, else -1
-static int hidden_tiles(const RolloutArgs& A) {
-  const int nt = A.pol.nt[1];
-  for (int l = 1; l < A.pol.nl; ++l) if (A.pol.nt[l] != nt) return -1;
-  for (int l = 1; l < A.dyn.nl; ++l) if (A.dyn.nt[l] != nt) return -1;
-  return nt;
-}
-static int fast_variant(int RT, const RolloutArgs& A) {
-  // variant: see pmbrl_fast.h (PF_VAR_*)
-  const bool mm = A.mm_mode == 1 || A.mm_mode == 3;   // moment matching inside the sweep launches
-  const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
-                   (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
-  const bool mmg = RT == 1 && A.mm_mode == 3 && A.mm_grid;
-  return mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
-}
-// split-bf16 precision (pmbrl_split.h): same variants and shape specialisation, PR = 1
-template <int RT, int CA, int CB, int PR>
-static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t s, bool fwd) {
-  const int var = fast_variant(RT, A0);
-  const dim3 g(p->nwg), b(PF_NT);
-  RolloutArgs A = A0;
-  // Register-resident first tiles (pmbrl_fast.h, resident_tile_s): the 16-row plain variants keep output
-  // tile `wave` of the sweep's first streamed layer in registers when a tile is exactly one stage pair and
-  // two pieces wide; the stream table then starts at tile 8 of that layer.
-  {
-    StreamDesc& sd = fwd ? A.sd_fwd : A.sd_bwd;
-    const int np = (fwd && PR != 2) ? 3 : 2;
-    if (RT == 1 && CA + CB == 7 && np == 2 && (var == PF_VAR_LEAN || var == PF_VAR_EXT) && sd.n >= 1 &&
-        sd.n_kb[0] == 7 * np && sd.n_ot[0] > 8) {
-      A.res_tiles = 8;
-      A.res_w = sd.wf[0];
-      sd.wf[0] += (size_t)8 * sd.n_kb[0] * 256;
-      sd.n_ot[0] -= 8;
-    }
-  }
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
-  if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
-      A.pol.nl == NLV && A.dyn.nl == NLV && hidden_tiles(A) == NTV) {                                        \
-    if (fwd)                                                                                                \
-      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), g, b,    \
-                         p->lds_bytes, s, A);                                                               \
-    else                                                                                                    \
-      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), g, b,    \
-                         p->lds_bytes, s, A);                                                               \
-    return;                                                                                                 \
-  }
-  if (!(A.flags & PMBRL_FLAG_NO_SHAPED)) {
-    PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
-  }
-#undef PM_FAST_SHAPED
-#define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V, PfShapeAny, PR>), g, b, p->lds_bytes, s, A)
-  if constexpr (RT == 1) {
-    if (var == PF_VAR_MMG) {
-      if (fwd) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MMG);
-      else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MMG);
-      return;
-    }
-  }
-  if (fwd) {
-    if (var == PF_VAR_MM) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);
-    else if (var == PF_VAR_EXT) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_EXT);
-    else PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_LEAN);
-  } else {
-    if (var == PF_VAR_MM) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MM);
-    else if (var == PF_VAR_EXT) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_EXT);
-    else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_LEAN);
-  }
-#undef PM_LAUNCH_VAR
-}
-
-template <int RT, int CA, int CB>
-static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-  const int var = fast_variant(RT, A);
-  const bool mm = var == PF_VAR_MM, ext = var == PF_VAR_EXT, mmg = var == PF_VAR_MMG;
-  const dim3 g(p->nwg), b(PF_NT);
-  // a shape-specialised instantiation if there is one for this plan
-#define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
-  if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
-      A.pol.nl == NLV && A.dyn.nl == NLV && hidden_tiles(A) == NTV) {                                                                \
-    if (fwd)                                                                                                \
-      hipLaunchKernelGGL((pm_rollout_fwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), g, b,       \
-                         p->lds_bytes, s, A);                                                               \
-    else                                                                                                    \
-      hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>>), g, b,       \
-                         p->lds_bytes, s, A);                                                               \
-    return;                                                                                                 \
-  }
-  if (!(A.flags & PMBRL_FLAG_NO_SHAPED)) {
-    PM_FAST_SHAPED_CASES
-  }
-#undef PM_FAST_SHAPED
-#define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V>), g, b, p->lds_bytes, s, A)
-  if constexpr (RT == 1) {
-    if (mmg) {
-      if (fwd) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MMG);
-      else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MMG);
-      return;
-    }
-  }
-  if (fwd) {
-    if (mm) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_MM);
-    else if (ext) PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_EXT);
-    else PM_LAUNCH_VAR(pm_rollout_fwd_fast, PF_VAR_LEAN);
-  } else {
-    if (mm) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_MM);
-    else if (ext) PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_EXT);
-    else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_LEAN);
-  }
-#undef PM_LAUNCH_VAR
-}
 static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-  if (p->prec) {
-#define PM_SPLIT_CASE(RTV, CAV, CBV)                                                       \
-  if (p->RT == RTV && p->CA == CAV && p->CB == CBV)                                        \
-    return p->prec == PMBRL_PREC_SPLIT_F16 ? launch_split<RTV, CAV, CBV, 2>(p, A, s, fwd)  \
-                                           : launch_split<RTV, CAV, CBV, 1>(p, A, s, fwd);
-    PM_SPLIT_CASES
-#undef PM_SPLIT_CASE
-    return;
-  }
-#define PM_FAST_CASE(RTV, CAV, CBV) \
-  if (p->RT == RTV && p->CA == CAV && p->CB == CBV) return launch_fast<RTV, CAV, CBV>(p, A, s, fwd);
-  PM_FAST_CASES
-#undef PM_FAST_CASE
+  if (p->prec == PMBRL_PREC_SPLIT_F16) return pm_fast_split2_launch(p, A, s, fwd);
+  if (p->prec) return pm_fast_split1_launch(p, A, s, fwd);
+  pm_fast_f32_launch(p, A, s, fwd);
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   if (p->fast) return launch_fast_rt(p, A, s, true);

@@ -119,6 +119,12 @@ struct RolloutArgs {
   long long* prof;              // debug: cycle stamps [H][32] of workgroup 0 (nullptr = off)
 };
 
+// kernel variants of the latency-optimised family (pmbrl_fast.h)
+#define PF_VAR_LEAN 0
+#define PF_VAR_EXT 1
+#define PF_VAR_MM 2
+#define PF_VAR_MMG 3   // mm_mode 3 as ONE launch: the workgroups meet at a device-wide barrier every step
+
 #define PM_MARK(slot)                                                        \
   do {                                                                        \
     if (A.prof && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + (slot)] = (long long)__builtin_readcyclecounter(); \

@@ -50,6 +50,7 @@ struct DwArgs {
   float* part;                           // [nsplit][n_params]
 };
 
+#ifdef PM_MAIN_TU   // the kernels below are compiled into pmbrl.hip only (pmbrl_host.h needs just the structs above)
 __device__ __forceinline__ void pm_dw_ld(f32x4& d, unsigned voff, const float* sbase) {
 #ifdef PM_EXP_DW_NOLOAD
   asm volatile("" : "=v"(d) : "v"(voff), "s"(sbase));
@@ -238,3 +239,4 @@ __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ pa
       if (c4 * 4 + r < n) grad[c4 * 4 + r] = t[r];
   }
 }
+#endif   // PM_MAIN_TU

@@ -790,6 +790,7 @@ struct EpiBwdL {
 // ---------------------------------------------------------------------------
 // rewards: not part of the sweep kernels
 // ---------------------------------------------------------------------------
+#ifdef PM_MAIN_TU   // non-template kernels: compiled into pmbrl.hip only
 // All rewards of a rollout in one fully parallel pass: thread = one (t, b) row-step.
 // r~ -> rt (if rewards are moment matched afterwards) or rewards; d r~/d x~ -> Jx; d r~/d a -> Ja;
 // non-finite states / rewards are reported through the status word like in the sweep.
@@ -896,6 +897,8 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
             pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false, A.grad_rewards + (size_t)t * A.B + r0, 1,
             gr_tilde + (size_t)t * A.B + r0, 1, mmscr_r, lane);
 }
+
+#endif   // PM_MAIN_TU
 
 // ---------------------------------------------------------------------------
 // LDS map of the fast kernels
@@ -1259,10 +1262,7 @@ struct PfShape {
 };
 typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
 
-#define PF_VAR_LEAN 0
-#define PF_VAR_EXT 1
-#define PF_VAR_MM 2
-#define PF_VAR_MMG 3   // mm_mode 3 as ONE launch: the workgroups meet at a device-wide barrier every step
+// (PF_VAR_* are defined in pmbrl_dev.h)
 #define PF_MARK(slot)                                                                              \
   do {                                                                                             \
     if (EXT && A.prof && wg == 0 && tid == 0)                                                      \

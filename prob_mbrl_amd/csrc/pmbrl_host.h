@@ -1,0 +1,123 @@
+// Host-side declarations shared by the translation units of libpmbrl_hip.so.  The library is built from
+// several .hip files so that the kernel families compile in parallel: pmbrl.hip (C ABI, plan, small kernels,
+// general kernel family), pmbrl_fast_f32.hip (latency-optimised sweeps, exact fp32 MFMA) and
+// pmbrl_fast_split.hip (the same on split bf16 / fp16 operands; compiled once per precision).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "pmbrl.h"
+#include "pmbrl_dev.h"
+#include "pmbrl_dw.h"
+
+int pm_fail(int code, const std::string& msg);
+#define HIPCHK(expr)                                                               \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return pm_fail(-100 - (int)_e, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct NetPlan {
+  int nl;
+  int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
+  float keep[PM_MAXL];
+  size_t w_off[PM_MAXL], b_off[PM_MAXL];   // offsets (floats) in the flat parameter vector
+  size_t n_params;
+  // workspace offsets (bytes)
+  size_t wf[PM_MAXL], wb[PM_MAXL], bias[PM_MAXL], abits[PM_MAXL];
+};
+
+struct pmbrl_plan {
+  pmbrl_config cfg;
+  int device;
+  int RT, rows_per_wg, nwg, LD, mm_mode, G, M, fast, CA, CB;   // CA/CB: k-blocks per weight-stream stage
+  int prec, LDB;   // PMBRL_PREC_* in use; split precision: leading dimension of the bf16 piece planes
+  size_t lds_bytes;
+  NetPlan pol, dyn;
+  RewardDev* rew_d;
+  DwBlock* dw_blocks_d;
+  int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  int dw_wave_first[PM_DW_NW + 1];
+  // workspace offsets (bytes)
+  size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
+      off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, ws_bytes;
+  int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
+  // optional per-kernel timing (hipEvents on the caller's stream)
+  long long* prof_fwd;
+  long long* prof_bwd;
+  int timing;
+  hipEvent_t ev[PMBRL_TIMER_COUNT][2];
+  bool ev_set[PMBRL_TIMER_COUNT];
+};
+
+struct ScopedTimer {
+  pmbrl_plan* p; int slot; hipStream_t s;
+  ScopedTimer(pmbrl_plan* p_, int slot_, hipStream_t s_) : p(p_), slot(slot_), s(s_) {
+    if (p->timing) (void)hipEventRecord(p->ev[slot][0], s);
+  }
+  ~ScopedTimer() {
+    if (p->timing) { (void)hipEventRecord(p->ev[slot][1], s); p->ev_set[slot] = true; }
+  }
+};
+
+// the instantiated (row tiles, stage pair) combinations -- keep in sync with stages_for()
+#define PM_FAST_CASES                                                                  \
+  PM_FAST_CASE(1, 8, 8) PM_FAST_CASE(1, 7, 6) PM_FAST_CASE(1, 4, 4) PM_FAST_CASE(1, 2, 2) \
+  PM_FAST_CASE(2, 4, 4) PM_FAST_CASE(2, 4, 3) PM_FAST_CASE(2, 2, 2) PM_FAST_CASE(4, 2, 2) PM_FAST_CASE(4, 1, 1)
+// shape-specialised instantiations (pmbrl_fast.h: PfShape): RT, CA, CB, variant, D, U, LD, layers,
+// 16-wide tiles per hidden layer.
+// The shipped configurations: cart-pole (D=4) and double cart-pole (D=6) states, one action,
+// 2 x 200 hidden units; plain / per-step / in-kernel moment matching.
+#define PM_FAST_SHAPED_CASES                                  \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 4, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 4, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 5, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_LEAN, 6, 1, 216, 3, 13)      \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 5, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_EXT, 6, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 5, 1, 216, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 6, 1, 216, 3, 13)        \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
+  PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 4, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 5, 1, 216, 3, 13)       \
+  PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 6, 1, 216, 3, 13)
+
+// split-bf16 instantiations (pmbrl_split.h): stage pairs in K32 blocks
+#define PM_SPLIT_CASES PM_SPLIT_CASE(1, 4, 3) PM_SPLIT_CASE(1, 1, 1) PM_SPLIT_CASE(2, 4, 3) PM_SPLIT_CASE(2, 1, 1)
+// shape-specialised split instantiations; LDV: floats per row of an activation buffer = piece planes x 240 / 2
+// (three bf16 planes: 360, two fp16 planes: 240)
+#define PM_SPLIT_SHAPED_CASES(LDV)                             \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 4, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_EXT, 4, 1, LDV, 3, 13)        \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)
+
+// 16-wide tiles of the hidden layers if every hidden layer of both nets has the same width, else -1
+static inline int hidden_tiles(const RolloutArgs& A) {
+  const int nt = A.pol.nt[1];
+  for (int l = 1; l < A.pol.nl; ++l) if (A.pol.nt[l] != nt) return -1;
+  for (int l = 1; l < A.dyn.nl; ++l) if (A.dyn.nt[l] != nt) return -1;
+  return nt;
+}
+static inline int fast_variant(int RT, const RolloutArgs& A) {
+  // variant: see pmbrl_fast.h (PF_VAR_*)
+  const bool mm = A.mm_mode == 1 || A.mm_mode == 3;   // moment matching inside the sweep launches
+  const bool ext = A.prof || A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
+                   (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
+  const bool mmg = RT == 1 && A.mm_mode == 3 && A.mm_grid;
+  return mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
+}
+
+// per-family entry points (defined in pmbrl_fast_f32.hip / pmbrl_fast_split.hip)
+int pm_fast_f32_set_attr(const pmbrl_plan* p);
+void pm_fast_f32_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);
+int pm_fast_split1_set_attr(const pmbrl_plan* p);     // PMBRL_PREC_SPLIT
+void pm_fast_split1_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);
+int pm_fast_split2_set_attr(const pmbrl_plan* p);     // PMBRL_PREC_SPLIT_F16
+void pm_fast_split2_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);

@@ -17,19 +17,27 @@ HIPCC = '/opt/rocm/bin/hipcc'
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
 def test_no_instruction_touches_in_flight_registers(tmp_path):
     csrc = os.path.join(ROOT, 'prob_mbrl_amd', 'csrc')
-    out = str(tmp_path / 'pmbrl.s')
-    subprocess.check_call([HIPCC, '-w', '--offload-arch=gfx950', '-O3', '-std=c++17',
-                           '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
-                           os.path.join(csrc, 'pmbrl.hip'), '-o', out], cwd=csrc)
+    # the translation units that hold inline-asm loads, compiled to ISA side by side
+    units = [('pmbrl.hip', []), ('pmbrl_fast_f32.hip', []), ('pmbrl_fast_split.hip', ['-DPM_SPLIT_PR=1']),
+             ('pmbrl_fast_split.hip', ['-DPM_SPLIT_PR=2'])]
+    procs = []
+    for k, (src, extra) in enumerate(units):
+        out = str(tmp_path / ('u%d.s' % k))
+        procs.append((out, subprocess.Popen([HIPCC, '-w', '--offload-arch=gfx950', '-O3', '-std=c++17',
+                                             '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only'] + extra +
+                                            [os.path.join(csrc, src), '-o', out], cwd=csrc)))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import check_inflight as CI
-    funcs = CI.parse_functions(out)
-    names = [n for n in funcs if 'fast' in n or 'pm_dw_kernel' in n]
-    assert len(names) >= 19, names          # 9 fwd + 9 bwd instantiations + the dW kernel
-    total_loads = 0
-    for n in names:
-        bad, nload, _ = CI.check_function(n, funcs[n])
-        assert bad == 0, '%s: %d in-flight register violations' % (n, bad)
-        total_loads += nload
+    names, total_loads = [], 0
+    for out, pr in procs:
+        assert pr.wait() == 0
+        funcs = CI.parse_functions(out)
+        for n in funcs:
+            if 'fast' in n or 'pm_dw_kernel' in n:
+                bad, nload, _ = CI.check_function(n, funcs[n])
+                assert bad == 0, '%s: %d in-flight register violations' % (n, bad)
+                total_loads += nload
+                names.append(n)
+    assert len(names) >= 19 + 16, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
     assert total_loads > 500
     shutil.rmtree(str(tmp_path), ignore_errors=True)
