@@ -183,13 +183,17 @@ def main():
     loss_buf = torch.zeros(1, device=dev)
     state = dict(step=0)
 
+    if world > 1:
+        from prob_mbrl_amd.distributed import grad_allreduce
+        allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI, on the compute stream
+
     def step():
         state['step'] += 1
         _, _, R = eng.forward(**args)
         eng.weighted_sum(R, gw, out=loss_buf)
         g, _, _ = eng.backward(gw)
         if world > 1:
-            dist.all_reduce(g)
+            allreduce(g)
         E.clip_adam(params, g, m, v, state['step'], 1e-4, max_norm=1.0)
 
     def sync():

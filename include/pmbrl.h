@@ -245,6 +245,24 @@ int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* grads_d,
                             double eps, double max_norm, float* norm_out_d,
                             const int32_t* status_d, int32_t expect);
 
+/* ---- gradient all-reduce over xGMI (RCCL) ---------------------------------- */
+/* The one collective of the sharded path: the sum of the flat policy gradient over the
+ * ranks, in place, issued on the caller's stream right behind pmbrl_rollout_bwd -- no host round
+ * trip, no second stream.  Rows are sharded by whole moment-matching groups, so nothing else crosses
+ * GPUs (algorithms/mc_pilco.py has no counterpart: the reference is single-process).
+ *   pmbrl_comm_unique_id: rank 0 obtains the 128-byte RCCL id and hands it to the other ranks by
+ *   whatever channel the launcher has (prob_mbrl_amd.distributed broadcasts it over
+ *   torch.distributed's store); pmbrl_comm_init: every rank, once; collective.
+ * librccl is loaded at run time (dlopen; the copy the process already has, else the system's), so
+ * the library has no link-time dependency on it and single-GPU users never load it. */
+#define PMBRL_COMM_ID_BYTES 128
+typedef struct pmbrl_comm pmbrl_comm;
+int pmbrl_comm_unique_id(void* id_out /* host, PMBRL_COMM_ID_BYTES */);
+int pmbrl_comm_init(const void* id /* host, PMBRL_COMM_ID_BYTES */, int32_t rank, int32_t nranks,
+                    int32_t device, pmbrl_comm** out);
+int pmbrl_allreduce_sum(pmbrl_comm* comm, void* stream, float* buf_d, int64_t n);
+void pmbrl_comm_destroy(pmbrl_comm* comm);
+
 /* Optional per-kernel timing for bench.py's roofline line: when enabled, the
  * library brackets its kernels with hipEvents on the caller's stream;
  * pmbrl_plan_read_timing waits for them and returns the last call's durations

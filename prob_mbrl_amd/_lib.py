@@ -79,6 +79,7 @@ EXPORTS = [
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
+    'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_destroy',
 ]
 
 _lib = None
@@ -150,6 +151,14 @@ def load():
     lib.pmbrl_plan_read_timing.argtypes = [vp, C.POINTER(C.c_float)]
     lib.pmbrl_plan_set_prof.restype = C.c_int
     lib.pmbrl_plan_set_prof.argtypes = [vp, vp, vp]
+    lib.pmbrl_comm_unique_id.restype = C.c_int
+    lib.pmbrl_comm_unique_id.argtypes = [vp]
+    lib.pmbrl_comm_init.restype = C.c_int
+    lib.pmbrl_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.pmbrl_allreduce_sum.restype = C.c_int
+    lib.pmbrl_allreduce_sum.argtypes = [vp, vp, vp, i64]
+    lib.pmbrl_comm_destroy.restype = None
+    lib.pmbrl_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -300,7 +300,8 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     on_rollout(i, states, actions, rewards, disc)
                 g, _, _ = eng.backward(gw)
                 if world > 1:
-                    dist.all_reduce(g, group=process_group)
+                    from .distributed import grad_allreduce
+                    grad_allreduce(process_group, dev)(g)     # RCCL on the compute stream (C ABI)
                 cache['step'] += 1
                 grp = cache['group']
                 E.clip_adam(bundle.pol_flat, g, cache['m'], cache['v'], cache['step'], grp['lr'],

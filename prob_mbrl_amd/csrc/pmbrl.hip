@@ -720,6 +720,16 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     }
   }
   if (rc2) { pmbrl_plan_destroy(p); return rc2; }
+  if (p->mm_grid) {
+    // the barrier-form sweep needs every workgroup resident at once: ask the runtime how many of THIS
+    // kernel (registers, LDS) fit a CU instead of assuming one
+    const int per_cu = p->prec == PMBRL_PREC_SPLIT_F16 ? pm_fast_split2_mmg_blocks_per_cu(p)
+                       : p->prec                        ? pm_fast_split1_mmg_blocks_per_cu(p)
+                                                        : pm_fast_f32_mmg_blocks_per_cu(p);
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    if (per_cu < 1 || p->nwg > cus) p->mm_grid = 0;     // (one per CU is all that is relied upon)
+  }
   *out = p;
   return 0;
 }
@@ -1460,6 +1470,81 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
   hipLaunchKernelGGL(pm_bnn_loss, dim3(1), dim3(64), 0, s, Fa, nfb);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// gradient all-reduce: RCCL through dlopen (no link-time dependency)
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct RcclId { char internal[PMBRL_COMM_ID_BYTES]; };          // = ncclUniqueId (rccl.h:43)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;      // ncclCommInitRank(comm*, nranks, id BY VALUE, rank)
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);      // the copy torch.distributed already loaded
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(-4, std::string("librccl not found: ") + dlerror());
+  RcclApi a;
+  a.lib = h;
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
+    return fail(-4, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
+  g_rccl = a;
+  return 0;
+}
+int rccl_fail(const char* what, int rc) {
+  return fail(-200 - rc, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+struct pmbrl_comm {
+  void* comm;
+  int rank, nranks, device;
+};
+extern "C" int pmbrl_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(-1, "null argument");
+  if (int rc = rccl_load()) return rc;
+  RcclId id;
+  if (int rc = g_rccl.GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+extern "C" int pmbrl_comm_init(const void* id_in, int32_t rank, int32_t nranks, int32_t device, pmbrl_comm** out) {
+  if (!id_in || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "bad argument");
+  if (int rc = rccl_load()) return rc;
+  HIPCHK(hipSetDevice(device));
+  RcclId id;
+  memcpy(&id, id_in, sizeof(id));
+  void* c = nullptr;
+  if (int rc = g_rccl.CommInitRank(&c, nranks, id, rank)) return rccl_fail("ncclCommInitRank", rc);
+  *out = new pmbrl_comm{c, rank, nranks, device};
+  return 0;
+}
+extern "C" int pmbrl_allreduce_sum(pmbrl_comm* comm, void* stream, float* buf_d, int64_t n) {
+  if (!comm || !buf_d || n < 0) return fail(-1, "bad argument");
+  // ncclFloat32 = 7, ncclSum = 0 (rccl.h: ncclDataType_t, ncclRedOp_t)
+  if (int rc = g_rccl.AllReduce(buf_d, buf_d, (size_t)n, 7, 0, comm->comm, (hipStream_t)stream))
+    return rccl_fail("ncclAllReduce", rc);
+  return 0;
+}
+extern "C" void pmbrl_comm_destroy(pmbrl_comm* comm) {
+  if (!comm) return;
+  if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
+  delete comm;
 }
 
 extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d, int64_t n,

@@ -90,3 +90,19 @@ void pm_fast_f32_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s
   PM_FAST_CASES
 #undef PM_FAST_CASE
 }
+
+template <int CA, int CB>
+static int mmg_occ_f32(size_t lds) {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, pm_rollout_fwd_fast<1, CA, CB, PF_VAR_MMG>, PF_NT, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pm_rollout_bwd_fast<1, CA, CB, PF_VAR_MMG>, PF_NT, lds) != hipSuccess) return 0;
+  return a < b ? a : b;
+}
+int pm_fast_f32_mmg_blocks_per_cu(const pmbrl_plan* p) {
+  if (p->RT != 1) return 0;
+#define PM_FAST_CASE(RTV, CAV, CBV) \
+  if (RTV == 1 && p->CA == CAV && p->CB == CBV) return mmg_occ_f32<CAV, CBV>(p->lds_bytes);
+  PM_FAST_CASES
+#undef PM_FAST_CASE
+  return 0;
+}

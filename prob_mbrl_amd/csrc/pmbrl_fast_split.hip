@@ -113,3 +113,19 @@ void PM_CAT(pm_fast_split, PM_SPLIT_PR, _launch)(const pmbrl_plan* p, const Roll
   PM_SPLIT_CASES
 #undef PM_SPLIT_CASE
 }
+
+template <int CA, int CB>
+static int mmg_occ_split(size_t lds) {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, pm_rollout_fwd_fast<1, CA, CB, PF_VAR_MMG, PfShapeAny, PM_SPLIT_PR>, PF_NT, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, pm_rollout_bwd_fast<1, CA, CB, PF_VAR_MMG, PfShapeAny, PM_SPLIT_PR>, PF_NT, lds) != hipSuccess) return 0;
+  return a < b ? a : b;
+}
+int PM_CAT(pm_fast_split, PM_SPLIT_PR, _mmg_blocks_per_cu)(const pmbrl_plan* p) {
+  if (p->RT != 1) return 0;
+#define PM_SPLIT_CASE(RTV, CAV, CBV) \
+  if (RTV == 1 && p->CA == CAV && p->CB == CBV) return mmg_occ_split<CAV, CBV>(p->lds_bytes);
+  PM_SPLIT_CASES
+#undef PM_SPLIT_CASE
+  return 0;
+}

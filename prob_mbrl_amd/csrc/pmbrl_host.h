@@ -115,6 +115,12 @@ static inline int fast_variant(int RT, const RolloutArgs& A) {
 }
 
 // per-family entry points (defined in pmbrl_fast_f32.hip / pmbrl_fast_split.hip)
+// *_mmg_blocks_per_cu: workgroups of the barrier-form sweep (PF_VAR_MMG) the runtime says can be resident
+// per CU with this plan's LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor, min over forward / adjoint;
+// 0 = no such instantiation): the one-launch form is selected only if every workgroup can be resident
+int pm_fast_f32_mmg_blocks_per_cu(const pmbrl_plan* p);
+int pm_fast_split1_mmg_blocks_per_cu(const pmbrl_plan* p);
+int pm_fast_split2_mmg_blocks_per_cu(const pmbrl_plan* p);
 int pm_fast_f32_set_attr(const pmbrl_plan* p);
 void pm_fast_f32_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);
 int pm_fast_split1_set_attr(const pmbrl_plan* p);     // PMBRL_PREC_SPLIT

@@ -426,3 +426,25 @@ def test_invalid_plans_fail_cleanly():
         eng.forward(**broken)
     S, A, R = eng.forward(**args)
     assert torch.isfinite(S).all() and eng.valid_steps() == eng.H
+
+
+def test_rccl_allreduce_through_the_c_abi(dev):
+    """pmbrl_comm_* / pmbrl_allreduce_sum: the RCCL communicator behind the C ABI, bootstrapped and
+    exercised with the one rank a single-GPU box has (the all-reduce of one rank is the identity; what
+    this pins is the dlopen of librccl, the symbol signatures and the call on torch's stream).  The
+    multi-rank run is the driver's scaling bench."""
+    import ctypes as C
+    from prob_mbrl_amd import _lib, engine as E
+    lib = _lib.load()
+    idbuf = C.create_string_buffer(128)
+    _lib.check(lib.pmbrl_comm_unique_id(idbuf), 'pmbrl_comm_unique_id')
+    assert any(idbuf.raw)
+    comm = C.c_void_p()
+    _lib.check(lib.pmbrl_comm_init(C.c_char_p(bytes(idbuf.raw)), 0, 1, 0, C.byref(comm)), 'pmbrl_comm_init')
+    g = torch.randn(41602, device=dev)
+    want = g.clone()
+    for _ in range(3):
+        _lib.check(lib.pmbrl_allreduce_sum(comm, E._stream(), E._ptr(g), g.numel()), 'pmbrl_allreduce_sum')
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    lib.pmbrl_comm_destroy(comm)

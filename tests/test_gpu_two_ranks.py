@@ -42,6 +42,19 @@ def test_bench_two_ranks_one_device():
     assert 'cpu_baseline' not in out
 
 
+def test_bench_two_ranks_strong_scaling():
+    """--scaling strong: the SAME 100 x 25 rows divided over the ranks (what BASELINE.json's metric at
+    N GPUs means); the JSON line says which it was."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--scaling', 'strong',
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['scaling'] == 'strong' and out['config']['global_rows'] == 2500 and out['config']['rows_per_gpu'] == 1250
+
+
 def _mcp_worker(rank, world, port, name, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
