@@ -22,6 +22,7 @@
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
 #include "pmbrl_split.h"
+#include "pmbrl_mm_w.h"
 
 // Streamed layers: ONE output tile per wave in flight, two accumulator chains per row tile
 // (even / odd k-blocks) to cover the 40-cycle dependent-MFMA latency, and a register stage
@@ -667,6 +668,7 @@ __device__ __forceinline__ void tail_gather(const float* tp, int* tcnt, int roun
 // of the SIMD is in ITS epilogue at the same time, so the MFMA pipe idles): they are kept to
 // a few dozen VALU instructions -- 32-bit offsets from uniform bases (the stash row block is
 // Rw = 16*RT, a compile-time constant), a multiply by the precomputed 1/keep.
+struct PmEmpty {};
 // NP = 0: the layer output goes to LDS as fp32 rows (leading dimension ld); NP > 0: as NP bf16 (F16: fp16)
 // piece planes (pmbrl_split.h; leading dimension ld in 16-bit elements)
 template <int RT, int NP = 0, bool F16 = false>
@@ -678,7 +680,9 @@ struct EpiFwdL {
   float* lds_out;
   float* stash;             // HBM block or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
-  int* ovf;                 // F16: LDS word set when an activation leaves fp16's range (nullptr otherwise)
+  // F16: LDS word set when an activation leaves fp16's range; an empty member otherwise (the fp32 kernels are
+  // at their scalar-register limit: not one more pointer in their epilogue descriptors)
+  [[no_unique_address]] typename std::conditional<F16, int*, PmEmpty>::type ovf;
   struct Pre {
     f32x4 b;
     unsigned mw;
@@ -1288,7 +1292,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // is a whole tile; the tile counts of the stream then differ between layers (read from the table)
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
-                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0, SH::NT - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
+                   (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKBc / (PR ? NP : 1) * 32 + 16 : 0;
   const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
   const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);   // ... of whatever the hidden-layer epilogues write
@@ -1429,18 +1434,22 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     const int dv = f == 0 ? d_nt : f == 1 ? d_b : f == 5 ? d_ik : f >= 6 ? 0 : (dhid ? (f == 2 ? d_m : d64) : 0);
     vdd = l < F.nl ? dv : 0;
   }
+  const auto ovf_init = [&] {
+    if constexpr (F16) return L.ovf;
+    else return PmEmpty{};
+  }();
   auto pol_epi = [&](int l, int t, size_t blk, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdp, 8 * l);
     return EpiFwdL<RT, NP, F16>{L.base + pm_rl(vdp, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdp, 8 * l + 2)),
                            pm_rlp<uint8_t>(vdp, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdp, 8 * l + 5), out,
                            pm_rlp<float>(vdp, 8 * l + 6) + blk * (size_t)nt * 16 * R, ELD, R, row0, nvalid, nt, lane,
-                           F16 ? L.ovf : nullptr};
+                           ovf_init};
   };
   auto dyn_epi = [&](int l, int t, float* out) {
     const int nt = SH::NT ? SH::NT : pm_rl(vdd, 8 * l);
     return EpiFwdL<RT, NP, F16>{L.base + pm_rl(vdd, 8 * l + 1), reinterpret_cast<const uint16_t*>(L.base + pm_rl(vdd, 8 * l + 2)),
                            pm_rlp<uint8_t>(vdd, 8 * l + 3) + (size_t)t * B * nt * 4, pm_rlf(vdd, 8 * l + 5), out,
-                           nullptr, ELD, R, row0, nvalid, nt, lane, F16 ? L.ovf : nullptr};
+                           nullptr, ELD, R, row0, nvalid, nt, lane, ovf_init};
   };
   const float* pol_head_bias = L.base + pm_rl(vdp, 8 * (P.nl - 1) + 1);
   const float* dyn_head_bias = L.base + pm_rl(vdd, 8 * (F.nl - 1) + 1);
@@ -1608,9 +1617,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        const bool ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, L.zs + lr0 * D, D, 0, 0, false,
-                                  xa + lr0 * D, D, scr, lane,
-                                  A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
+        bool ok;
+        if constexpr (SH::D >= 1 && SH::D <= 6) {
+          // compile-time width: Gram tile on the fp64 matrix core, d x d algebra in registers (pmbrl_mm_w.h)
+          ok = pm_mm_fwd_w<SH::D ? SH::D : 1>(xb + lr0 * D, D, A.M, L.zs + lr0 * D, D, xa + lr0 * D, D, lane,
+                                              A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
+        } else {
+          ok = pm_mm_fwd(xb + lr0 * D, D, A.M, D, L.zs + lr0 * D, D, 0, 0, false,
+                         xa + lr0 * D, D, scr, lane,
+                         A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
+        }
         if (!ok && lane == 0) atomicMin(A.status, t);
       }
       __syncthreads();
@@ -1650,7 +1666,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr int NKBc = !SH::NT ? 0 : PR ? NKB32c * NP : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
-                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0, SH::NT - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
+                   (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
+                   (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKB32c * 32 + 16 : 0;
   const int LDB = PR ? (LDBc ? LDBc : A.LDB) : 0;     // leading dimension of the piece planes (bf16 elements)
   const int ELD = PR ? LDB : (SH::LD ? SH::LD : A.LD);
@@ -1919,9 +1936,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        pm_mm_bwd(xrows + lr0 * xrows_ld, xrows_ld, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
-                  gxt + lr0 * D, D, scr, lane,
-                  A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
+        if constexpr (false) {
+          // (the register form of the adjoint, pm_mm_bwd_w, was measured slower than the LDS form with the
+          //  factor handed over from the forward sweep: 8.0 k vs 7.5 k cycles at d = 4 -- two Gram tiles and
+          //  ~320 dependent fp64 operations on one wave; kept for reference in pmbrl_mm_w.h)
+          pm_mm_bwd_w<SH::D ? SH::D : 1>(xrows + lr0 * xrows_ld, xrows_ld, A.M, L.zs + lr0 * D, D, gx + lr0 * D, D,
+                                         gxt + lr0 * D, D, lane);
+        } else {
+          pm_mm_bwd(xrows + lr0 * xrows_ld, xrows_ld, A.M, D, L.zs + lr0 * D, D, 0, 0, false, gx + lr0 * D, D,
+                    gxt + lr0 * D, D, scr, lane,
+                    A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D));
+        }
       }
     }
     PF_MARK(1);
