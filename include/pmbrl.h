@@ -43,6 +43,11 @@ extern "C" {
 #define PMBRL_FLAG_INFER_NS 4    /* utils/rollout.py:6-17 (mm_resample_infer_ns_) */
 #define PMBRL_FLAG_FORCE_GENERIC 16 /* do not use the latency-optimised kernel variants (tests) */
 #define PMBRL_FLAG_NO_SHAPED 32 /* do not use the shape-specialised instantiations (tests) */
+#define PMBRL_FLAG_POL_MASKS_PER_STEP 64  /* pol_mask_bits_d[l] is [H, B, ceil(h/16)]: a fresh dropout mask at every
+                                            step (utils/rollout.py:95-98 resample_policy=True -> models/modules.py:55-58) */
+#define PMBRL_FLAG_DYN_MASKS_PER_STEP 128 /* the same for the dynamics model (resample_model=True, utils/rollout.py:110-115
+                                            -> models/modules.py:134-139,155-157).  Either flag selects the general
+                                            kernel family (the latency-optimised one keeps the masks in LDS for the launch) */
 #define PMBRL_FLAG_ZMM_PER_STEP 8 /* z_mm/z_rr are [H, B_global, .] fresh draws per step
                                      (utils/rollout.py:58-59, z=None) instead of the cyclic
                                      PEGASUS buffer of utils/rollout.py:53-57 */

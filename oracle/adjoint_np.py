@@ -192,7 +192,10 @@ def forward(P):
     st = dict(states=[x], actions=[], rewards=[], pacts=[], pbits=[], dbits=[],
               Tp=[], Td=[], xt=[], rt=[], mmc_s=[], mmc_r=[])
     for t in range(H):
-        o, pacts, pbits = mlp_fwd(x, P.pW, P.pb, P.pmask, P.pkeep)
+        # [H, B, h] masks: a fresh draw per step (resample_policy / resample_model=True)
+        pmask = [m[t] if m.ndim == 3 else m for m in P.pmask]
+        dmask = [m[t] if m.ndim == 3 else m for m in P.dmask]
+        o, pacts, pbits = mlp_fwd(x, P.pW, P.pb, pmask, P.pkeep)
         U = o.shape[1] // 2
         mu, l = o[:, :U], o[:, U:]
         lc = -softplus(-l + LOG_MAX_STD) + LOG_MAX_STD
@@ -202,7 +205,7 @@ def forward(P):
         a = P.pscale * th + P.pbias
         Tp = P.pz[:B] * e * sigmoid(-l + LOG_MAX_STD)
         xin = (np.concatenate([x, a], 1) - P.mx) * P.iSx
-        o2, _, dbits = mlp_fwd(xin, P.dW, P.db, P.dmask, P.dkeep)
+        o2, _, dbits = mlp_fwd(xin, P.dW, P.db, dmask, P.dkeep)
         mu2, l2 = o2[:, :D], o2[:, D:]
         lc2 = -softplus(-l2 + LOG_MAX_STD) + LOG_MAX_STD + np.log(P.Sy)
         e2 = np.exp(lc2)

@@ -17,6 +17,7 @@ MAX_DIM = 64
 FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
 FLAG_FORCE_GENERIC = 16
 FLAG_NO_SHAPED = 32
+FLAG_POL_MASKS_PER_STEP, FLAG_DYN_MASKS_PER_STEP = 64, 128
 REWARD_EXP, REWARD_NEG = 0, 1
 PREC_F32, PREC_SPLIT, PREC_SPLIT_F16 = 0, 1, 2
 INFO_COUNT = 16

@@ -477,7 +477,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   const size_t lds_cap = 160 * 1024;
   // infer_noise_variables (utils/rollout.py:6-17, not a default anywhere) lives in the general
   // single-wave moment-matching routines only: general kernel family, mm_mode 1 or 2
-  p->fast = !(c.flags & (PMBRL_FLAG_FORCE_GENERIC | PMBRL_FLAG_INFER_NS)) &&
+  p->fast = !(c.flags & (PMBRL_FLAG_FORCE_GENERIC | PMBRL_FLAG_INFER_NS | PMBRL_FLAG_POL_MASKS_PER_STEP |
+                         PMBRL_FLAG_DYN_MASKS_PER_STEP)) &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   const int LD_generic = p->LD;

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     // ---- policy hidden layers
     for (int l = 0; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
-      EpiHiddenFwd e{P.bias[l], P.mask[l], P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+      const uint16_t* mk = P.mask[l] + ((A.flags & PMBRL_FLAG_POL_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
+      EpiHiddenFwd e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
                      A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
       gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
       __syncthreads();
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     // ---- dynamics hidden layers
     for (int l = 0; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
-      EpiHiddenFwd e{F.bias[l], F.mask[l], F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
+      const uint16_t* mk = F.mask[l] + ((A.flags & PMBRL_FLAG_DYN_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
+      EpiHiddenFwd e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
                      nullptr, LD, A.Rw, row0, nvalid, nt, lane};
       gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
       __syncthreads();

@@ -278,7 +278,8 @@ class Engine:
                  reward_spec, mm_states=False, mm_rewards=False, mm_groups=None,
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
-                 force_generic=False, no_shaped=False, infer_ns=False, precision=None):
+                 force_generic=False, no_shaped=False, infer_ns=False, precision=None,
+                 pol_masks_per_step=False, dyn_masks_per_step=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -292,6 +293,8 @@ class Engine:
                      (_lib.FLAG_MM_REWARDS if mm_rewards else 0) |
                      (_lib.FLAG_ZMM_PER_STEP if zmm_per_step else 0) |
                      (_lib.FLAG_INFER_NS if infer_ns else 0) |
+                     (_lib.FLAG_POL_MASKS_PER_STEP if pol_masks_per_step else 0) |
+                     (_lib.FLAG_DYN_MASKS_PER_STEP if dyn_masks_per_step else 0) |
                      (_lib.FLAG_FORCE_GENERIC if force_generic else 0) |
                      (_lib.FLAG_NO_SHAPED if no_shaped else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
@@ -311,6 +314,7 @@ class Engine:
         self.B, self.D, self.U, self.H = B, D, U, H
         self.n_pol_layers = len(pol_dims) - 1
         self.n_dyn_layers = len(dyn_dims) - 1
+        self.mask_rows = (H * B if pol_masks_per_step else B, H * B if dyn_masks_per_step else B)
         plan = C.c_void_p()
         _lib.check(self.lib.pmbrl_plan_create(C.byref(cfg), self.device.index or 0,
                                               C.byref(plan)), 'pmbrl_plan_create')
@@ -390,11 +394,12 @@ class Engine:
         inp.x0, inp.pol_params, inp.dyn_params = x0.data_ptr(), pol_flat.data_ptr(), dyn_flat.data_ptr()
         inp.mx, inp.iSx, inp.my, inp.Sy = mx.data_ptr(), iSx.data_ptr(), my.data_ptr(), Sy.data_ptr()
         inp.pol_scale, inp.pol_bias = pol_scale.data_ptr(), pol_bias.data_ptr()
+        # frozen masks: bit rows [>= B, nt]; per-step masks (FLAG_*_MASKS_PER_STEP): [H * B, nt]
         for i, b in enumerate(pol_mask_bits):
-            assert b.shape[0] >= self.B and b.is_contiguous()
+            assert b.shape[0] >= self.mask_rows[0] and b.is_contiguous()
             inp.pol_mask_bits[i] = b.data_ptr()
         for i, b in enumerate(dyn_mask_bits):
-            assert b.shape[0] >= self.B and b.is_contiguous()
+            assert b.shape[0] >= self.mask_rows[1] and b.is_contiguous()
             inp.dyn_mask_bits[i] = b.data_ptr()
         inp.z_pol, inp.z_dyn = z_pol.data_ptr(), z_dyn.data_ptr()
         inp.z_pol_step_stride, inp.z_dyn_step_stride = zps, zds

@@ -213,20 +213,30 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
         Bg, roff = B_global, row_offset
     Bl = hi - lo
     Gl = (G * Bl // B) if G > 0 else None
+    # [H, B, h] masks: a fresh dropout mask at every step (resample_policy / resample_model=True)
+    pol_ps = np.asarray(d['pol_mask0']).ndim == 3
+    dyn_ps = np.asarray(d['dyn_mask0']).ndim == 3
     eng = E.Engine(Bl, D, U, H, layer_dims(d, 'pol'), list(np.asarray(d['pol_keep'])),
                    layer_dims(d, 'dyn'), list(np.asarray(d['dyn_keep'])),
                    reward_spec_from_problem(d), mm_states=bool(d['mm_states']),
                    mm_rewards=bool(d['mm_rewards']), mm_groups=Gl, device=dev, B_global=Bg,
                    row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic,
                    no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False,
-                   precision=precision)
+                   precision=precision, pol_masks_per_step=pol_ps, dyn_masks_per_step=dyn_ps)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
+
+    def rows(m):
+        m = np.asarray(m)
+        if m.ndim == 3:      # per-step masks: [H, B, h] -> bit rows [H * B, nt]
+            return T(m[:, lo:hi]).reshape(-1, m.shape[-1]).contiguous()
+        return T(m[lo:hi])
+
     args = dict(
         x0=T(d['x0'][lo:hi]), pol_flat=T(flat_params(d, 'pol')), dyn_flat=T(flat_params(d, 'dyn')),
         mx=T(d['dyn_mx']), iSx=T(d['dyn_iSx']), my=T(d['dyn_my']), Sy=T(d['dyn_Sy']),
         pol_scale=T(d['pol_scale']), pol_bias=T(d['pol_bias']),
-        pol_mask_bits=[E.pack_mask(T(d['pol_mask%d' % i][lo:hi])) for i in range(npl - 1)],
-        dyn_mask_bits=[E.pack_mask(T(d['dyn_mask%d' % i][lo:hi])) for i in range(ndl - 1)],
+        pol_mask_bits=[E.pack_mask(rows(d['pol_mask%d' % i])) for i in range(npl - 1)],
+        dyn_mask_bits=[E.pack_mask(rows(d['dyn_mask%d' % i])) for i in range(ndl - 1)],
         z_pol=T(d['pol_z'][lo:hi]), z_dyn=T(d['dyn_z'][lo:hi]),
         z_mm=T(d['z_mm']) if 'z_mm' in d and bool(d['mm_states']) else None,
         z_rr=T(d['z_rr']) if 'z_rr' in d and bool(d['mm_rewards']) else None)

@@ -100,11 +100,12 @@ def _reward_key(spec):
 
 def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
                mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
-               max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None):
+               max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None,
+               masks_per_step=(False, False)):
     precision = precision or E.get_precision()
     key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
            tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
-           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision)
+           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision, tuple(masks_per_step))
     eng = _ENGINES.get(key)
     if eng is None:
         if len(_ENGINES) > 16:
@@ -113,7 +114,8 @@ def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_stat
                        mm_states=mm_states, mm_rewards=mm_rewards, mm_groups=mm_groups,
                        device=device, B_global=B_global, row_offset=row_offset,
                        zmm_per_step=zmm_per_step, max_log_std_pol=max_log_std[0],
-                       max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision)
+                       max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision,
+                       pol_masks_per_step=masks_per_step[0], dyn_masks_per_step=masks_per_step[1])
         _ENGINES[key] = eng
     return eng
 
@@ -123,7 +125,7 @@ class Bundle:
 
     def __init__(self, dynamics, policy, B, H, resample_state_noise, resample_action_noise,
                  mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=None, row_offset=0,
-                 infer_ns=False, precision=None):
+                 infer_ns=False, precision=None, resample_policy=False, resample_model=False):
         if not isinstance(policy, M.Policy) or not isinstance(dynamics, M.DynamicsModel):
             raise TypeError('rollout() needs prob_mbrl_amd.models.Policy / DynamicsModel')
         if len(policy.angle_dims) or len(dynamics.angle_dims):
@@ -162,16 +164,32 @@ class Bundle:
         self.dyn_keep = [dr.keep_prob() if dr is not None else 1.0 for dr in ddrop]
         # masks (frozen unless resampled by the caller through .resample())
         self.pol_bits, self.dyn_bits = [], []
+
+        def step_masks(dr, w):
+            """A fresh mask per time step (resample=True in the module's forward: models/modules.py:55-58 for
+            Bernoulli dropout -- drawn and not stored --, :134-139,155-157 for concrete dropout in eval mode --
+            new uniform noise, a hard sample of its concrete probabilities, stored), bit-packed [H * B, nt]."""
+            ms = torch.stack([dr.forward_mask(B, w, resample=True) for _ in range(H)])
+            return E.pack_mask(ms.reshape(H * B, w).float().contiguous())
+
         for i, dr in enumerate(pdrop):
             w = self.pol_dims[i + 1]
             key = (id(policy), 'p', i)
-            self.pol_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else
-                                 _masked(key, dr, B, w))
+            if dr is not None and resample_policy:
+                self.pol_bits.append(step_masks(dr, w))
+            elif dr is None and resample_policy:
+                self.pol_bits.append(E.pack_mask(torch.ones(H * B, w, device=dev)))
+            else:
+                self.pol_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else _masked(key, dr, B, w))
         for i, dr in enumerate(ddrop):
             w = self.dyn_dims[i + 1]
             key = (id(dynamics), 'd', i)
-            self.dyn_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else
-                                 _masked(key, dr, B, w))
+            if dr is not None and resample_model:
+                self.dyn_bits.append(step_masks(dr, w))
+            elif dr is None and resample_model:
+                self.dyn_bits.append(E.pack_mask(torch.ones(H * B, w, device=dev)))
+            else:
+                self.dyn_bits.append(_MASKS.ones(key, B, w, dev) if dr is None else _masked(key, dr, B, w))
         # output noise: frozen buffer, or a fresh draw per step (models/densities.py:111-119)
         if resample_action_noise:
             self.z_pol = torch.randn(H, B, self.U, device=dev)
@@ -210,7 +228,8 @@ class Bundle:
                                  self.dyn_keep, self.spec, mm_states, mm_rewards, mm_groups, dev,
                                  B_global=B_global, row_offset=row_offset,
                                  zmm_per_step=self.zmm_per_step, max_log_std=self.max_log_std,
-                                 infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision)
+                                 infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision,
+                                 masks_per_step=(bool(resample_policy), bool(resample_model)))
 
     def forward(self, x0, out=None):
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
@@ -277,9 +296,6 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     given particles: returns [states (steps+1 x [B,D]), actions (steps x [B,U]),
     rewards (steps x [B,1])], connected to policy.parameters() (and to `states`) for autograd.
     Same arguments as the reference (utils/rollout.py:62-79)."""
-    if resample_model or resample_policy:
-        raise NotImplementedError('per-step mask resampling (resample_model / resample_policy) '
-                                  'is not offered on the device path')
     if callable(on_pol_eval):
         raise NotImplementedError('on_pol_eval needs a per-step Python hook; not offered')
     B = states.shape[0]
@@ -289,14 +305,16 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     while True:
         bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
                         mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=B_global,
-                        row_offset=row_offset, infer_ns=bool(infer_noise_variables), precision=precision)
+                        row_offset=row_offset, infer_ns=bool(infer_noise_variables), precision=precision,
+                        resample_policy=bool(resample_policy), resample_model=bool(resample_model))
         # a list that backward() appends the [H, B] matrix of ||dL/da_t|| to (prioritised replay)
         bundle.agn_out = agn_out
         x0 = states.to(device=bundle.device, dtype=torch.float32)
         S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
         n = bundle.engine.valid_steps()
         retry = E.safe_precision(bundle.engine.info['precision']) if n < steps else None
-        if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None):
+        if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None) \
+                or resample_model or resample_policy:
             break          # (fresh noise was drawn: a retry would be a different rollout)
         # a failure under fp16 pieces may be their range, not the rollout: decide on the bf16 path
         precision = retry

@@ -16,7 +16,44 @@ def _flat_grad(pol):
     return torch.cat([t.grad.reshape(-1) for l in lins for t in (l.weight, l.bias)]).cpu().numpy()
 
 
-@pytest.mark.parametrize('name', common.fixture_names('iter'))
+def test_rollout_resamples_masks_every_step(monkeypatch):
+    """rollout(resample_model=True, resample_policy=True): new dropout masks at every step
+    (utils/rollout.py:95-98,110-115).  Fixture from the reference's own rollout, whose draws were
+    recorded; here they are handed out by the dropout modules' mask source in the same order."""
+    import prob_mbrl_amd as pm
+    d = common.load('stepmask_d4')
+    H = int(d['H'])
+    frozen = dict(d)
+    for k in ('pol_mask0', 'pol_mask1', 'dyn_mask0', 'dyn_mask1'):
+        frozen[k] = d[k][0]
+    dyn, pol = common.modules_from_fixture(frozen, 'stepmask_d4', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    queues = {id(pol.model.drop0): list(d['pol_mask0']), id(pol.model.drop1): list(d['pol_mask1']),
+              id(dyn.model.drop0): list(d['dyn_mask0']), id(dyn.model.drop1): list(d['dyn_mask1'])}
+
+    def fake(self, B, width, resample=False, seed=None):
+        assert resample
+        return torch.tensor(queues[id(self)].pop(0), device=DEV)
+
+    monkeypatch.setattr(pm.models.BDropout, 'forward_mask', fake)
+    monkeypatch.setattr(pm.models.CDropout, 'forward_mask', fake)
+    states, actions, rewards = pm.utils.rollout(x0, dyn, pol, H, resample_model=True, resample_policy=True,
+                                                resample_state_noise=False, resample_action_noise=False)
+    assert all(len(q) == 0 for q in queues.values())
+    gamma = [float(g) for g in d['gamma']]
+    loss = (-torch.stack([r * gamma[i] for i, r in enumerate(rewards)]).sum(0)).mean()
+    pol.zero_grad()
+    loss.backward()
+    assert common.rel(torch.stack(states).detach().cpu().numpy(), d['ref64_states']) < 2e-5
+    assert abs(float(loss) - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+    assert common.rel(_flat_grad(pol), d['ref64_grad']) < 1e-4
+    monkeypatch.undo()
+    # and with the modules' own draws: runs, finite, different masks at different steps
+    s2, _, _ = pm.utils.rollout(x0, dyn, pol, H, resample_model=True, resample_policy=True)
+    assert torch.isfinite(torch.stack(s2)).all()
+
+
+@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if not n.startswith('stepmask')])
 def test_rollout_autograd_matches_reference(name):
     """utils.rollout + the reference's loss + loss.backward() (algorithms/mc_pilco.py:134-197)."""
     import prob_mbrl_amd as pm

@@ -101,7 +101,8 @@ def _wide(d):
 def _run(d, dev, hint=0, generic=False, n_valid=None, precision=None):
     eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint, force_generic=generic,
                                               precision=precision)
-    assert bool(eng.info['fast']) == (not generic and not _wide(d) and not bool(d.get('infer_ns', False)))
+    assert bool(eng.info['fast']) == (not generic and not _wide(d) and not bool(d.get('infer_ns', False))
+                                      and np.asarray(d['pol_mask0']).ndim == 2)
     if precision in ('split', 'split_f16'):
         assert eng.info['precision'] == precision      # the bf16 / fp16 matrix-core path really ran
     S, A, Rw = eng.forward(**args)
@@ -117,8 +118,9 @@ def _run(d, dev, hint=0, generic=False, n_valid=None, precision=None):
 
 
 # (the C5 shape and infer_noise_variables exist in the general family only)
+# (the C5 shape, infer_noise_variables and per-step dropout masks exist in the general family only)
 _PARITY_CASES = [(n, g) for n in common.fixture_names('iter') for g in (False, True)
-                 if g or not (n.startswith('c5_') or 'infer_ns' in n)]
+                 if g or not (n.startswith(('c5_', 'stepmask')) or 'infer_ns' in n)]
 
 
 @pytest.mark.parametrize('name,generic', _PARITY_CASES,

@@ -533,6 +533,72 @@ def make_trunc_case(name, D=4, U=1, hid=(32, 32), B=30, H=12, fail_step=8, seed=
     return d
 
 
+def make_resample_case(name, D=4, U=1, hid=(32, 32), B=24, H=8, seed=27):
+    """resample_model=True and resample_policy=True (utils/rollout.py:95-98,110-115): every step draws new
+    dropout masks -- Bernoulli(p) for the policy (models/modules.py:55-58), a hard sample of the concrete
+    probabilities from fresh uniform noise for the dynamics in eval mode (models/modules.py:134-139,
+    102-118).  The masks the reference drew are recorded from its torch.bernoulli calls, in call order
+    (per step: policy drop0, drop1, dynamics drop0, drop1), and stored as [H, B, h]."""
+    print('[resample] %s' % name)
+    rew = _cartpole()
+    dyn, pol = build(D, U, list(hid), list(hid), rew, 10.0, seed)
+    dyn.eval()
+    pol.train()
+    torch.manual_seed(seed + 1000)
+    x0 = 0.1 * torch.randn(B, D)
+    gamma = [1.0 / H] * H
+    with torch.no_grad():
+        utils.rollout(x0, dyn, pol, 1, resample_state_noise=False, resample_action_noise=False)
+    torch.manual_seed(seed + 5)
+    pol.model.fc_nonlin.z.data = torch.randn_like(pol.model.fc_nonlin.z)
+    d = capture_inputs(dyn, pol, x0, H, gamma, False, False, None, None, None, True, False, rew)
+    rec = []
+    orig = torch.bernoulli
+
+    def bern(p, *a, **k):
+        out = orig(p, *a, **k)
+        rec.append(out.detach().clone())
+        return out
+
+    def run(dt, replay=None):
+        pol.zero_grad()
+        dyn.zero_grad()
+        it = iter(replay) if replay is not None else None
+        torch.bernoulli = (lambda p, *a, **k: next(it).to(p.dtype)) if it is not None else bern
+        try:
+            states, actions, rewards = utils.rollout(
+                x0.to(dt), dyn, pol, H, resample_model=True, resample_policy=True,
+                resample_state_noise=False, resample_action_noise=False)
+        finally:
+            torch.bernoulli = orig
+        disc = torch.stack([r * gamma[i] for i, r in enumerate(rewards)])
+        loss = (-disc.sum(0)).mean()
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in pol.parameters()])
+        return dict(states=torch.stack(states).detach().numpy(), actions=torch.stack(actions).detach().numpy(),
+                    rewards=torch.stack(rewards).detach().numpy(), loss=float(loss), grad=g.detach().numpy().copy())
+
+    torch.manual_seed(seed + 9)
+    r32 = run(torch.float32)
+    masks = list(rec)
+    assert len(masks) == 4 * H, len(masks)
+    for k, (pre, i) in enumerate((('pol', 0), ('pol', 1), ('dyn', 0), ('dyn', 1))):
+        m = torch.stack([masks[4 * t + k] for t in range(H)])
+        assert m.shape == (H, B, hid[i]) and bool(((m == 0) | (m == 1)).all())
+        d['%s_mask%d' % (pre, i)] = m.double().numpy()
+    dyn.double()
+    pol.double()
+    rew.double()
+    r64 = run(torch.float64, replay=masks)
+    for k, v in r32.items():
+        d['ref32_' + k] = np.asarray(v, dtype=np.float32)
+    for k, v in r64.items():
+        d['ref64_' + k] = np.asarray(v, dtype=np.float64)
+    print('   loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' % (
+        r32['loss'], r64['loss'], np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])))
+    return d
+
+
 def make_standalone_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, seed=11):
     """Stand-alone Policy.forward / DynamicsModel.forward of the reference (models/core.py:221-248,
     265-303) on B rows with the stored masks and noise (resample=False, resample_noise=False),
@@ -945,6 +1011,7 @@ CASES = {
     'mmg_h40': lambda: make_case('mmg_h40', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 40,
                                  mm=True, mm_groups=4, seed=18, P=4),
     'trunc_mm': lambda: make_trunc_case('trunc_mm'),
+    'stepmask_d4': lambda: make_resample_case('stepmask_d4'),
     'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
     'standalone_fwd_u4': lambda: make_standalone_case('standalone_fwd_u4', 8, 4, [48, 24, 40], [24, 24],
                                                       lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
