@@ -115,11 +115,19 @@ typedef struct pmbrl_config {
   int32_t mm_groups;
   float max_log_std_pol; /* models/densities.py:75: log(max_noise_std) */
   float max_log_std_dyn;
-  pmbrl_mlp pol; /* dims[0] = D, dims[n] = 2U */
-  pmbrl_mlp dyn; /* dims[0] = D+U, dims[n] = 2D */
+  pmbrl_mlp pol; /* dims[0] = D + n_pol_angle, dims[n] = 2U */
+  pmbrl_mlp dyn; /* dims[0] = D + U + n_dyn_angle, dims[n] = 2D */
   pmbrl_reward reward;
   int32_t rows_per_wg_hint; /* 0 = choose automatically */
   int32_t precision;        /* PMBRL_PREC_*: arithmetic of the hidden-width GEMMs of the sweeps */
+  /* angle_dims of Policy (models/core.py:233-234) and of the dynamics Regressor (models/core.py:173-174):
+   * the network sees utils/angles.py:39-42's [other dims in order | sin(angles) | cos(angles)] of the
+   * state (policy) or of [state | action] (dynamics; angle dims must be state dims).  mx / iSx of the
+   * rollout arguments then have dyn.dims[0] entries, in that feature order. */
+  int32_t n_pol_angle;
+  int32_t pol_angle_dims[PMBRL_MAX_ANGLE];
+  int32_t n_dyn_angle;
+  int32_t dyn_angle_dims[PMBRL_MAX_ANGLE];
 } pmbrl_config;
 
 typedef struct pmbrl_plan pmbrl_plan;
@@ -160,7 +168,7 @@ typedef struct pmbrl_inputs {
   const float* x0_d;          /* [B, D] */
   const float* pol_params_d;  /* flat, torch parameter order: W0[out,in], b0, W1, b1, ... */
   const float* dyn_params_d;  /* same for the dynamics MLP */
-  const float* mx_d;          /* [D+U]  models/core.py:141-145 */
+  const float* mx_d;          /* [dyn.dims[0]] (= D+U without angle dims)  models/core.py:141-145 */
   const float* iSx_d;         /* [D+U] */
   const float* my_d;          /* [D] */
   const float* Sy_d;          /* [D] */

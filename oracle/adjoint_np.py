@@ -66,7 +66,9 @@ class Problem:
         self.dz = f('dyn_z')
         self.mx, self.iSx, self.my, self.Sy = (f('dyn_mx'), f('dyn_iSx'),
                                                f('dyn_my'), f('dyn_Sy'))
-        assert len(d['pol_angle_dims']) == 0 and len(d['dyn_angle_dims']) == 0
+        # angle_dims of Policy / the dynamics Regressor (models/core.py:233-234,173-174)
+        self.pol_adims = [int(a) for a in np.asarray(d['pol_angle_dims'])]
+        self.dyn_adims = [int(a) for a in np.asarray(d['dyn_angle_dims'])]
         self.rew_kind = str(d['rew_kind'])
         self.rew_expand = bool(d['rew_expand'])
         self.rew_adims = [int(a) for a in np.asarray(d['rew_angle_dims'])]
@@ -103,6 +105,19 @@ class Problem:
 # ---------------------------------------------------------------------------
 # moment matching (utils/rollout.py:20-29) and its adjoint
 # ---------------------------------------------------------------------------
+def expand_bwd(g, x, adims):
+    """Adjoint of expand_angles: g over [others | sin | cos] -> gradient over x."""
+    adims = list(adims)
+    if not adims:
+        return g
+    od = [i for i in range(x.shape[-1]) if i not in adims]
+    no, na = len(od), len(adims)
+    gx = np.zeros_like(x)
+    gx[:, od] = g[:, :no]
+    gx[:, adims] = g[:, no:no + na] * np.cos(x[:, adims]) - g[:, no + na:] * np.sin(x[:, adims])
+    return gx
+
+
 def mm_forward(s, z, infer_ns=False):
     """s, z: [M, d].  Returns out and the cache (delta, L, zhat)."""
     M, d = s.shape
@@ -195,7 +210,8 @@ def forward(P):
         # [H, B, h] masks: a fresh draw per step (resample_policy / resample_model=True)
         pmask = [m[t] if m.ndim == 3 else m for m in P.pmask]
         dmask = [m[t] if m.ndim == 3 else m for m in P.dmask]
-        o, pacts, pbits = mlp_fwd(x, P.pW, P.pb, pmask, P.pkeep)
+        xp = expand_angles(x, P.pol_adims)[0] if P.pol_adims else x
+        o, pacts, pbits = mlp_fwd(xp, P.pW, P.pb, pmask, P.pkeep)
         U = o.shape[1] // 2
         mu, l = o[:, :U], o[:, U:]
         lc = -softplus(-l + LOG_MAX_STD) + LOG_MAX_STD
@@ -204,7 +220,10 @@ def forward(P):
         th = np.tanh(u)
         a = P.pscale * th + P.pbias
         Tp = P.pz[:B] * e * sigmoid(-l + LOG_MAX_STD)
-        xin = (np.concatenate([x, a], 1) - P.mx) * P.iSx
+        xa = np.concatenate([x, a], 1)
+        if P.dyn_adims:
+            xa = expand_angles(xa, P.dyn_adims)[0]
+        xin = (xa - P.mx) * P.iSx
         o2, _, dbits = mlp_fwd(xin, P.dW, P.db, dmask, P.dkeep)
         mu2, l2 = o2[:, :D], o2[:, D:]
         lc2 = -softplus(-l2 + LOG_MAX_STD) + LOG_MAX_STD + np.log(P.Sy)
@@ -293,7 +312,7 @@ def backward(P, st, gr_all=None):
             if P.dkeep[i] != 1.0:
                 gp = gp / P.dkeep[i]
             gh = _mm(gp, P.dW[i], 'dx')
-        gxa = gh * P.iSx
+        gxa = expand_bwd(gh * P.iSx, np.concatenate([x, a], 1), P.dyn_adims)
         gx = gxt + gxa[:, :D]
         ga = ga + gxa[:, D:]
         # policy head
@@ -313,7 +332,7 @@ def backward(P, st, gr_all=None):
             gW[i] += _mm(gp.T, st['pacts'][t][i], 'dw')
             gb[i] += gp.sum(0)
             gh = _mm(gp, P.pW[i], 'dx')
-        gx = gx + gh
+        gx = gx + expand_bwd(gh, x, P.pol_adims)
         Gst.append(Gs)
     flat = np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)])
                            for w, b in zip(gW, gb)])

@@ -56,7 +56,9 @@ class Config(C.Structure):
                 ('row_offset', C.c_int32), ('flags', C.c_int32),
                 ('mm_groups', C.c_int32), ('max_log_std_pol', C.c_float),
                 ('max_log_std_dyn', C.c_float), ('pol', MLP), ('dyn', MLP),
-                ('reward', Reward), ('rows_per_wg_hint', C.c_int32), ('precision', C.c_int32)]
+                ('reward', Reward), ('rows_per_wg_hint', C.c_int32), ('precision', C.c_int32),
+                ('n_pol_angle', C.c_int32), ('pol_angle_dims', C.c_int32 * MAX_ANGLE),
+                ('n_dyn_angle', C.c_int32), ('dyn_angle_dims', C.c_int32 * MAX_ANGLE)]
 
 
 class Inputs(C.Structure):

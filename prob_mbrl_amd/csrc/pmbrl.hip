@@ -462,8 +462,13 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->cfg = c;
   if (p->cfg.B_global <= 0) p->cfg.B_global = c.B;
   p->device = device;
-  int rc = net_plan(c.pol, p->pol, c.D, 2 * c.U, "policy");
-  if (rc == 0) rc = net_plan(c.dyn, p->dyn, c.D + c.U, 2 * c.D, "dynamics");
+  if (c.n_pol_angle < 0 || c.n_pol_angle > PMBRL_MAX_ANGLE || c.n_dyn_angle < 0 || c.n_dyn_angle > PMBRL_MAX_ANGLE) {
+    delete p;
+    return fail(-2, "n_pol_angle / n_dyn_angle out of range");
+  }
+  const bool angles = c.n_pol_angle > 0 || c.n_dyn_angle > 0;
+  int rc = net_plan(c.pol, p->pol, c.D + c.n_pol_angle, 2 * c.U, "policy");
+  if (rc == 0) rc = net_plan(c.dyn, p->dyn, c.D + c.U + c.n_dyn_angle, 2 * c.D, "dynamics");
   if (rc) { delete p; return rc; }
 
   // LDS leading dimension: widest activation (any layer of either net), +8 so that
@@ -478,7 +483,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // infer_noise_variables (utils/rollout.py:6-17, not a default anywhere) lives in the general
   // single-wave moment-matching routines only: general kernel family, mm_mode 1 or 2
   p->fast = !(c.flags & (PMBRL_FLAG_FORCE_GENERIC | PMBRL_FLAG_INFER_NS | PMBRL_FLAG_POL_MASKS_PER_STEP |
-                         PMBRL_FLAG_DYN_MASKS_PER_STEP)) &&
+                         PMBRL_FLAG_DYN_MASKS_PER_STEP)) && !angles &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   const int LD_generic = p->LD;
@@ -650,6 +655,38 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
   }
+  // angle_dims feature maps (utils/angles.py:29-42: others in order, then sin, then cos)
+  if (angles) {
+    AngleDev a;
+    memset(&a, 0, sizeof(a));
+    auto build = [&](FeatMap& m, int width, int n_ang, const int32_t* dims, int max_dim) -> bool {
+      for (int d = 0; d < PMBRL_MAX_DIM; ++d) m.f_copy[d] = m.f_sin[d] = m.f_cos[d] = -1;
+      for (int j = 0; j < n_ang; ++j) {
+        if (dims[j] < 0 || dims[j] >= max_dim) return false;
+        for (int i = 0; i < j; ++i)
+          if (dims[i] == dims[j]) return false;
+      }
+      int no = 0;
+      for (int i = 0; i < width; ++i) {
+        bool isang = false;
+        for (int j = 0; j < n_ang; ++j) isang |= (dims[j] == i);
+        if (!isang) { m.src[no] = i; m.mode[no] = 0; m.f_copy[i] = no; ++no; }
+      }
+      for (int j = 0; j < n_ang; ++j) {
+        m.src[no + j] = dims[j]; m.mode[no + j] = 1; m.f_sin[dims[j]] = no + j;
+        m.src[no + n_ang + j] = dims[j]; m.mode[no + n_ang + j] = 2; m.f_cos[dims[j]] = no + n_ang + j;
+      }
+      m.n_feat = no + 2 * n_ang;
+      return m.n_feat <= PMBRL_MAX_DIM;
+    };
+    if (!build(a.pol, c.D, c.n_pol_angle, c.pol_angle_dims, c.D) ||
+        !build(a.dyn, c.D + c.U, c.n_dyn_angle, c.dyn_angle_dims, c.D)) {
+      pmbrl_plan_destroy(p);
+      return fail(-2, "angle dims must be distinct state dims (0 <= d < D)");
+    }
+    HIPCHK(hipMalloc(&p->ang_d, sizeof(AngleDev)));
+    HIPCHK(hipMemcpy(p->ang_d, &a, sizeof(AngleDev), hipMemcpyHostToDevice));
+  }
   {
     std::vector<DwBlock> blocks;
     p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first);
@@ -771,6 +808,7 @@ extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
     for (int i = 0; i < PMBRL_TIMER_COUNT; ++i)
       for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
   if (p->rew_d) (void)hipFree(p->rew_d);
+  if (p->ang_d) (void)hipFree(p->ang_d);
   if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
   delete p;
 }
@@ -845,6 +883,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   fill_net(p->pol, ws, in->pol_mask_bits_d, A.pol);
   fill_net(p->dyn, ws, in->dyn_mask_bits_d, A.dyn);
   A.rew = p->rew_d;
+  A.ang = p->ang_d;
   A.x0 = in->x0_d; A.mx = in->mx_d; A.iSx = in->iSx_d; A.my = in->my_d; A.Sy = in->Sy_d;
   A.pscale = in->pol_scale_d; A.pbias = in->pol_bias_d;
   A.zpol = in->z_pol_d; A.zdyn = in->z_dyn_d; A.zmm = in->z_mm_d; A.zrr = in->z_rr_d;

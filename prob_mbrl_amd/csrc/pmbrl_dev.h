@@ -61,6 +61,23 @@ struct RewardDev {
   int d_copy[PMBRL_MAX_DIM], d_sin[PMBRL_MAX_DIM], d_cos[PMBRL_MAX_DIM];
 };
 
+// Network-input feature maps for angle_dims (utils/angles.py:39-42): feature k of a network's input is
+// v[src[k]] | sin(v[..]) | cos(v[..]) for mode[k] = 0 | 1 | 2, v = state (policy) or [state | action]
+// (dynamics); entry s of v feeds feature f_copy[s] (or -1) and, as an angle, f_sin[s] / f_cos[s].
+struct FeatMap {
+  int n_feat;
+  int src[PMBRL_MAX_DIM], mode[PMBRL_MAX_DIM];
+  int f_copy[PMBRL_MAX_DIM], f_sin[PMBRL_MAX_DIM], f_cos[PMBRL_MAX_DIM];
+};
+struct AngleDev {
+  FeatMap pol, dyn;
+};
+__device__ __forceinline__ float pm_feat(const FeatMap* m, int k, const float* v) {
+  const float s = v[m->src[k]];
+  const int md = m->mode[k];
+  return md == 0 ? s : md == 1 ? sinf(s) : cosf(s);
+}
+
 // weight stream of the fast kernels: the hidden->hidden layers in processing order
 struct StreamDesc {
   int n;
@@ -91,6 +108,7 @@ struct RolloutArgs {
   float mls_pol, mls_dyn;
   NetDev pol, dyn;
   const RewardDev* rew;
+  const AngleDev* ang;   // angle_dims of the policy / the dynamics model (general family only); nullptr: none
   const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn, *zmm, *zrr;
   float *states, *actions, *rewards;
   float* actT[PM_MAXL];   // policy layer inputs, feature-major blocks [H][nwg][nt*16][Rw]

@@ -234,6 +234,9 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
 
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
+  // angle_dims of the policy / the dynamics model (models/core.py:233-234,173-174)
+  const FeatMap* pmap = A.ang ? &A.ang->pol : nullptr;
+  const FeatMap* dmap = A.ang ? &A.ang->dyn : nullptr;
 
   for (int t = A.t0; t < A.t1; ++t) {
     const size_t blk = (size_t)t * A.nwg + wg;
@@ -246,7 +249,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       float* st = A.actT[0] + blk * (size_t)K16 * A.Rw;
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int k = i / R, r = i - k * R;
-        const float v = (k < D) ? xa[r * D + k] : 0.f;
+        float v = 0.f;
+        if (pmap) {
+          if (k < pmap->n_feat) v = pm_feat(pmap, k, xa + r * D);
+        } else if (k < D) {
+          v = xa[r * D + k];
+        }
         X[r * LD + k] = v;
         st[(size_t)k * A.Rw + r] = v;
       }
@@ -274,10 +282,17 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int r = i / K16, k = i - r * K16;
         float v = 0.f;
-        if (k < D) {
-          v = (xa[r * D + k] - A.mx[k]) * A.iSx[k];
-        } else if (k < D + U) {
-          const int j = k - D;
+        int src = k;
+        bool live = k < D + U;
+        if (dmap) {
+          live = k < dmap->n_feat;
+          src = live ? dmap->src[k] : 0;
+        }
+        if (live && src < D) {
+          const float s = dmap ? pm_feat(dmap, k, xa + r * D) : xa[r * D + k];
+          v = (s - A.mx[k]) * A.iSx[k];
+        } else if (live) {
+          const int j = src - D;
           const float mu = Y[r * LD + j];
           const float ls = Y[r * LD + U + j];
           const float z = (r < nvalid) ? A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j] : 0.f;
@@ -411,6 +426,8 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
   const NetDev& F = A.dyn;
   const bool mms = (A.flags & PMBRL_FLAG_MM_STATES) != 0;
   const bool mmr = (A.flags & PMBRL_FLAG_MM_REWARDS) != 0;
+  const FeatMap* pmap = A.ang ? &A.ang->pol : nullptr;
+  const FeatMap* dmap = A.ang ? &A.ang->dyn : nullptr;
   // truncated horizon (utils/rollout.py:154-157): only the steps the forward sweep completed
   const int T1 = A.nvalid ? min(A.t1, *A.nvalid) : A.t1;
 
@@ -531,15 +548,30 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
       const int K16 = P.nt[P.nl] * 16;
       float* gst = A.gT[P.nl - 1] + blk * (size_t)K16 * A.Rw;
       const int W = max(K16, D + U);
+      const float* xcur = A.states + (size_t)t * B * D;   // x_t (the angles the input features were taken at)
       for (int i = tid; i < R * W; i += PM_NT) {
         const int r = i / W, k = i - r * W;
         if (k < D) {
-          gxt[r * D + k] += Y[r * LD + k] * A.iSx[k];     // dL/dx_t via identity + dynamics input
+          // dL/dx_t via identity + dynamics input
+          if (!dmap) {
+            gxt[r * D + k] += Y[r * LD + k] * A.iSx[k];
+          } else if (r < nvalid) {
+            float g = 0.f;
+            const int fc = dmap->f_copy[k], fs = dmap->f_sin[k];
+            if (fc >= 0) g = Y[r * LD + fc] * A.iSx[fc];
+            if (fs >= 0) {
+              const int fo = dmap->f_cos[k];
+              const float th = xcur[(size_t)(row0 + r) * D + k];
+              g += Y[r * LD + fs] * A.iSx[fs] * cosf(th) - Y[r * LD + fo] * A.iSx[fo] * sinf(th);
+            }
+            gxt[r * D + k] += g;
+          }
         } else if (k < D + U) {
           const int j = k - D;
+          const int fa = dmap ? dmap->f_copy[k] : k;     // where action j sits in the dynamics input
           float go_mu = 0.f, go_ls = 0.f;
           if (r < nvalid) {
-            float ga = L.gad[r * 16 + j] + Y[r * LD + k] * A.iSx[k];
+            float ga = L.gad[r * 16 + j] + Y[r * LD + fa] * A.iSx[fa];
             if (A.grad_actions) ga += A.grad_actions[((size_t)t * B + row0 + r) * U + j];
             L.gad[r * 16 + j] = ga;   // total dL/da_t (for the priority hook below)
             const float sc = A.pscale[j];
@@ -584,7 +616,17 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
     // ---- phase C: dL/dx_t
     for (int i = tid; i < R * D; i += PM_NT) {
       const int r = i / D, d = i - r * D;
-      float v = gxt[i] + Y[r * LD + d];
+      float v = gxt[i];
+      if (!pmap) {
+        v += Y[r * LD + d];
+      } else if (r < nvalid) {
+        const int fc = pmap->f_copy[d], fs = pmap->f_sin[d];
+        if (fc >= 0) v += Y[r * LD + fc];
+        if (fs >= 0) {
+          const float th = A.states[((size_t)t * B + row0 + r) * D + d];
+          v += Y[r * LD + fs] * cosf(th) - Y[r * LD + pmap->f_cos[d]] * sinf(th);
+        }
+      }
       if (A.grad_states && r < nvalid) v += A.grad_states[((size_t)t * B + row0 + r) * D + d];
       gx[i] = v;
     }

@@ -279,7 +279,7 @@ class Engine:
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
                  force_generic=False, no_shaped=False, infer_ns=False, precision=None,
-                 pol_masks_per_step=False, dyn_masks_per_step=False):
+                 pol_masks_per_step=False, dyn_masks_per_step=False, pol_angle_dims=(), dyn_angle_dims=()):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -310,6 +310,16 @@ class Engine:
         cfg.reward = make_reward_struct(reward_spec, D, U)
         cfg.rows_per_wg_hint = rows_per_wg_hint
         cfg.precision = _PRECISIONS[precision if precision is not None else get_precision()]
+        # angle_dims of the policy / the dynamics model (models/core.py:233-234,173-174)
+        pol_angle_dims, dyn_angle_dims = [int(a) for a in pol_angle_dims], [int(a) for a in dyn_angle_dims]
+        if len(pol_angle_dims) > _lib.MAX_ANGLE or len(dyn_angle_dims) > _lib.MAX_ANGLE:
+            raise ValueError('at most %d angle dims per network' % _lib.MAX_ANGLE)
+        cfg.n_pol_angle, cfg.n_dyn_angle = len(pol_angle_dims), len(dyn_angle_dims)
+        for i, a in enumerate(pol_angle_dims):
+            cfg.pol_angle_dims[i] = a
+        for i, a in enumerate(dyn_angle_dims):
+            cfg.dyn_angle_dims[i] = a
+        self.n_dyn_in = D + U + len(dyn_angle_dims)
         self.cfg = cfg
         self.B, self.D, self.U, self.H = B, D, U, H
         self.n_pol_layers = len(pol_dims) - 1
@@ -364,7 +374,7 @@ class Engine:
         x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias, z_pol, z_dyn = t
         assert x0.shape == (self.B, self.D), x0.shape
         assert pol_flat.numel() == self.n_pol_params and dyn_flat.numel() == self.n_dyn_params
-        assert mx.numel() == self.D + self.U and my.numel() == self.D
+        assert mx.numel() == self.n_dyn_in and iSx.numel() == self.n_dyn_in and my.numel() == self.D
         zps = zds = 0
         if z_pol.dim() == 3:
             assert z_pol.shape == (self.H, self.B, self.U)

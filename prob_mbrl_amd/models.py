@@ -421,7 +421,8 @@ class Regressor(_Loadable):
 
     def set_dataset(self, X, Y, N_ensemble=-1, p=0.5):
         if len(self.angle_dims):
-            raise NotImplementedError('angle_dims inside the dynamics model is not offered yet')
+            from .utils import to_complex
+            X = to_complex(X, self.angle_dims)
         self.X.data = X
         self.Y.data = Y
         self.mx.data = self.X.mean(0, keepdim=True)

@@ -222,7 +222,9 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    mm_rewards=bool(d['mm_rewards']), mm_groups=Gl, device=dev, B_global=Bg,
                    row_offset=roff, rows_per_wg_hint=rows_per_wg_hint, force_generic=force_generic,
                    no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False,
-                   precision=precision, pol_masks_per_step=pol_ps, dyn_masks_per_step=dyn_ps)
+                   precision=precision, pol_masks_per_step=pol_ps, dyn_masks_per_step=dyn_ps,
+                   pol_angle_dims=[int(a) for a in np.asarray(d.get('pol_angle_dims', []))],
+                   dyn_angle_dims=[int(a) for a in np.asarray(d.get('dyn_angle_dims', []))])
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
 
     def rows(m):

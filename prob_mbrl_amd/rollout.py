@@ -101,11 +101,12 @@ def _reward_key(spec):
 def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
                mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
                max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None,
-               masks_per_step=(False, False)):
+               masks_per_step=(False, False), angle_dims=((), ())):
     precision = precision or E.get_precision()
     key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
            tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
-           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision, tuple(masks_per_step))
+           B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision, tuple(masks_per_step),
+           tuple(angle_dims[0]), tuple(angle_dims[1]))
     eng = _ENGINES.get(key)
     if eng is None:
         if len(_ENGINES) > 16:
@@ -115,7 +116,8 @@ def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_stat
                        device=device, B_global=B_global, row_offset=row_offset,
                        zmm_per_step=zmm_per_step, max_log_std_pol=max_log_std[0],
                        max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision,
-                       pol_masks_per_step=masks_per_step[0], dyn_masks_per_step=masks_per_step[1])
+                       pol_masks_per_step=masks_per_step[0], dyn_masks_per_step=masks_per_step[1],
+                       pol_angle_dims=angle_dims[0], dyn_angle_dims=angle_dims[1])
         _ENGINES[key] = eng
     return eng
 
@@ -128,9 +130,6 @@ class Bundle:
                  infer_ns=False, precision=None, resample_policy=False, resample_model=False):
         if not isinstance(policy, M.Policy) or not isinstance(dynamics, M.DynamicsModel):
             raise TypeError('rollout() needs prob_mbrl_amd.models.Policy / DynamicsModel')
-        if len(policy.angle_dims) or len(dynamics.angle_dims):
-            raise NotImplementedError('angle_dims inside Policy / DynamicsModel is not offered yet '
-                                      '(the examples feed the expanded state)')
         if dynamics.reward_func is None or not hasattr(dynamics.reward_func, 'spec'):
             raise NotImplementedError('DynamicsModel.reward_func must be a prob_mbrl_amd.rewards '
                                       'module (learned rewards are not offered)')
@@ -151,11 +150,17 @@ class Bundle:
         self.device = dev
         self.pol_dims = [plin[0].in_features] + [l.out_features for l in plin]
         self.dyn_dims = [dlin[0].in_features] + [l.out_features for l in dlin]
-        self.D = self.pol_dims[0]
+        # angle_dims (models/core.py:233-234,173-174): the networks see [others | sin | cos] of their input
+        self.angle_dims = (tuple(int(a) for a in policy.angle_dims.tolist()),
+                           tuple(int(a) for a in dynamics.angle_dims.tolist()))
+        self.D = self.pol_dims[0] - len(self.angle_dims[0])
         self.U = self.pol_dims[-1] // 2
-        if self.dyn_dims[0] != self.D + self.U or self.dyn_dims[-1] != 2 * self.D:
-            raise NotImplementedError('dynamics must map [x|u] (%d) to 2*|x| outputs; a learned '
-                                      'reward head is not offered' % (self.D + self.U))
+        n_dyn_in = self.D + self.U + len(self.angle_dims[1])
+        if self.dyn_dims[0] != n_dyn_in or self.dyn_dims[-1] != 2 * self.D:
+            raise NotImplementedError('dynamics must map [x|u] (%d inputs with its angle_dims) to 2*|x| outputs; '
+                                      'a learned reward head is not offered' % n_dyn_in)
+        if any(a >= self.D for a in self.angle_dims[1]):
+            raise NotImplementedError('angle_dims of the dynamics model must be state dimensions')
         self.B, self.H = B, H
         if getattr(dynamics.reward_func, 'bind_action_dim', None):
             dynamics.reward_func.bind_action_dim(self.U)
@@ -203,7 +208,7 @@ class Bundle:
             self.z_dyn = ddens.frozen_noise(B, False)
         self.max_log_std = (_scalar_of(pdens, 'max_log_std'), _scalar_of(ddens, 'max_log_std'))
         f = lambda t, n: t.detach().reshape(-1).float().expand(n).contiguous()  # noqa: E731
-        self.mx, self.iSx = f(dynamics.mx, self.D + self.U), f(dynamics.iSx, self.D + self.U)
+        self.mx, self.iSx = f(dynamics.mx, n_dyn_in), f(dynamics.iSx, n_dyn_in)
         self.my, self.Sy = f(dynamics.my, self.D), f(dynamics.Sy, self.D)
         self.scale, self.bias = f(policy.scale, self.U), f(policy.bias, self.U)
         # moment matching noise
@@ -229,7 +234,8 @@ class Bundle:
                                  B_global=B_global, row_offset=row_offset,
                                  zmm_per_step=self.zmm_per_step, max_log_std=self.max_log_std,
                                  infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision,
-                                 masks_per_step=(bool(resample_policy), bool(resample_model)))
+                                 masks_per_step=(bool(resample_policy), bool(resample_model)),
+                                 angle_dims=self.angle_dims)
 
     def forward(self, x0, out=None):
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,

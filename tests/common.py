@@ -50,7 +50,9 @@ def modules_from_fixture(d, name, device='cuda:0'):
     npl, ndl = int(d['pol_n_layers']), int(d['dyn_n_layers'])
     pol_hid = [d['pol_W%d' % i].shape[0] for i in range(npl - 1)]
     dyn_hid = [d['dyn_W%d' % i].shape[0] for i in range(ndl - 1)]
-    if name.startswith('dcp'):
+    pad = [int(a) for a in np.asarray(d['pol_angle_dims'])]
+    dad = [int(a) for a in np.asarray(d['dyn_angle_dims'])]
+    if name.startswith('dcp') or name.startswith('angles_dcp'):
         rew = pm.rewards.DoubleCartpoleReward(pole1_length=torch.tensor(0.6),
                                               pole2_length=torch.tensor(0.6))
     elif name.startswith('pend'):
@@ -65,16 +67,16 @@ def modules_from_fixture(d, name, device='cuda:0'):
     else:
         rew = pm.rewards.CartpoleReward(pole_length=torch.tensor(0.5))
     dyn = pm.models.DynamicsModel(
-        pm.models.mlp(D + U, 2 * D, dyn_hid,
+        pm.models.mlp(D + U + len(dad), 2 * D, dyn_hid,
                       dropout_layers=[pm.models.CDropout(0.1 * np.ones(h)) for h in dyn_hid],
                       nonlin=torch.nn.ReLU),
-        reward_func=rew, output_density=pm.models.DiagGaussianDensity(D)).float()
+        reward_func=rew, output_density=pm.models.DiagGaussianDensity(D), angle_dims=dad).float()
     maxU = np.asarray(d['pol_scale'], dtype=np.float32)
     pol = pm.models.Policy(
-        pm.models.mlp(D, 2 * U, pol_hid,
+        pm.models.mlp(D + len(pad), 2 * U, pol_hid,
                       dropout_layers=[pm.models.BDropout(0.1) for _ in pol_hid],
                       nonlin=torch.nn.ReLU,
-                      output_nonlin=partial(pm.models.DiagGaussianDensity, U)), maxU, -maxU).float()
+                      output_nonlin=partial(pm.models.DiagGaussianDensity, U)), maxU, -maxU, angle_dims=pad).float()
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
     with torch.no_grad():
         for pre, mod, n in (('pol', pol.model, npl), ('dyn', dyn.model, ndl)):

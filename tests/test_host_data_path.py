@@ -119,3 +119,24 @@ def test_apply_controller_loop():
         Env(), lambda x, t=None: np.array([[1.0, 2.0]]), 20, callback=lambda *a: seen.append(a))
     assert len(states) == 5 and dones[-1] and costs[0] == 3.0 and len(seen) == 5
     assert np.array_equal(states[3], np.full(3, 3.0)) and actions[0].shape == (2,)
+
+
+def test_set_dataset_normalises_the_expanded_input():
+    """models/core.py:136-146: with angle_dims the normalisation statistics are those of
+    to_complex(X) = [others | sin | cos] (utils/angles.py:39-42), which is what the rollout's dynamics
+    input is built from (fixtures angles_*)."""
+    import prob_mbrl_amd as pm
+    d = common.load('angles_dcp_mmg')
+    D, U = d['x0'].shape[1], d['pol_z'].shape[1]
+    ad = [int(a) for a in d['dyn_angle_dims']]
+    dyn = pm.models.DynamicsModel(pm.models.mlp(D + U + len(ad), 2 * D, [8]), angle_dims=ad,
+                                  output_density=pm.models.DiagGaussianDensity(D))
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(50, D + U, generator=g), torch.randn(50, D, generator=g)
+    dyn.set_dataset(X, Y)
+    others = [i for i in range(D + U) if i not in ad]
+    Xe = torch.cat([X[:, others], X[:, ad].sin(), X[:, ad].cos()], -1)
+    assert dyn.X.shape == (50, D + U + len(ad))
+    assert torch.allclose(dyn.mx, Xe.mean(0, keepdim=True))
+    assert torch.allclose(dyn.iSx, (4.0 * Xe.std(0, keepdim=True)).reciprocal())
+    assert d['dyn_mx'].shape[0] == D + U + len(ad)

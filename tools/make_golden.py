@@ -138,21 +138,22 @@ def reward_spec(rew, D):
 # model construction exactly as examples/deep_pilco_mm.py:117-151
 # ---------------------------------------------------------------------------
 def build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_drop=0.1, dyn_drop=0.1,
-          n_data=300, y_scale=0.01):
+          n_data=300, y_scale=0.01, pol_angle_dims=(), dyn_angle_dims=()):
     torch.manual_seed(seed)
     np.random.seed(seed)
+    pol_angle_dims, dyn_angle_dims = list(pol_angle_dims or ()), list(dyn_angle_dims or ())
     dyn_model = models.mlp(
-        D + U, 2 * D, dyn_hid,
+        D + U + len(dyn_angle_dims), 2 * D, dyn_hid,
         dropout_layers=[
             models.modules.CDropout(dyn_drop * np.ones(hid))
             if dyn_drop > 0 else None for hid in dyn_hid
         ],
         nonlin=torch.nn.ReLU)
-    dyn = models.DynamicsModel(dyn_model, reward_func=rew,
+    dyn = models.DynamicsModel(dyn_model, reward_func=rew, angle_dims=dyn_angle_dims,
                                output_density=models.DiagGaussianDensity(D)).float()
     from functools import partial
     pol_model = models.mlp(
-        D, 2 * U, pol_hid,
+        D + len(pol_angle_dims), 2 * U, pol_hid,
         dropout_layers=[
             models.modules.BDropout(pol_drop) if pol_drop > 0 else None
             for hid in pol_hid
@@ -160,7 +161,7 @@ def build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_drop=0.1, dyn_drop=0.1,
         nonlin=torch.nn.ReLU,
         output_nonlin=partial(models.DiagGaussianDensity, U))
     maxU_t = np.asarray(maxU, dtype=np.float32).reshape(-1)
-    pol = models.Policy(pol_model, maxU_t, -maxU_t).float()
+    pol = models.Policy(pol_model, maxU_t, -maxU_t, angle_dims=pol_angle_dims).float()
     # synthetic dataset -> normalisation buffers (models/core.py:134-152)
     X = torch.randn(n_data, D + U)
     Y = y_scale * torch.randn(n_data, D)
@@ -274,12 +275,33 @@ def ref_iteration(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
     return out
 
 
+def _patch_build_odims():
+    """The reference's utils/angles.py:29-36 (build_odims_) only defines `odims` when `dims` is NOT a tensor,
+    and Policy / Regressor always hand it their registered `angle_dims` buffer (models/core.py:131,200): the
+    in-module angle_dims path raises UnboundLocalError as shipped.  The angle fixtures are generated with that
+    one function replaced by what it evidently means (the complement of dims, in order); everything else --
+    to_complex_, Policy.forward, Regressor.forward / set_dataset, utils.rollout -- runs as the reference has it."""
+    import prob_mbrl.utils.angles as ang
+
+    def build_odims_(x, dims):
+        if not isinstance(dims, torch.Tensor):
+            dims = torch.tensor(dims)
+        dims = dims.long().to(getattr(x, 'device', 'cpu'))
+        odims = torch.tensor([i for i in range(x.shape[-1]) if i not in dims.tolist()]).long().to(dims.device)
+        return odims, dims
+
+    ang.build_odims_ = build_odims_
+
+
 def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
               mm_groups=None, discount=None, seed=0, infer_ns=False,
               maximize=True, x0_scale=0.1, P=None, weight_seed=None, pol_angle_dims=None,
               dyn_angle_dims=None):
     rew = rew_fn()
-    dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed)
+    if pol_angle_dims or dyn_angle_dims:
+        _patch_build_odims()
+    dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_angle_dims=pol_angle_dims,
+                     dyn_angle_dims=dyn_angle_dims)
     if weight_seed is not None:
         # wide networks: the weights come from a seed (oracle.ref_torch.seeded_weights) so that the
         # fixture does not have to carry megabytes of them
@@ -1010,6 +1032,15 @@ CASES = {
                                       mm=True, seed=17),
     'mmg_h40': lambda: make_case('mmg_h40', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 40,
                                  mm=True, mm_groups=4, seed=18, P=4),
+    # angle_dims inside Policy / DynamicsModel (models/core.py:233-234,173-174): raw state in the rollout,
+    # [others | sin | cos] in front of the networks; x0 spread over +-1 rad so that sin / cos are not linear
+    'angles_d4': lambda: make_case('angles_d4', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 40, 12, seed=24, P=8,
+                                   x0_scale=1.0, pol_angle_dims=[2], dyn_angle_dims=[2]),
+    'angles_dcp_mmg': lambda: make_case('angles_dcp_mmg', 6, 1, [40, 40], [24, 24], _dcartpole, 20.0, 36, 8,
+                                        mm=True, mm_groups=3, seed=25, P=3, x0_scale=0.7,
+                                        pol_angle_dims=[2, 4], dyn_angle_dims=[4]),
+    'angles_full200': lambda: make_case('angles_full200', 4, 1, [200, 200], [200, 200], _cartpole, 10.0, 50, 10,
+                                        seed=26, x0_scale=0.5, pol_angle_dims=[2], dyn_angle_dims=[]),
     'trunc_mm': lambda: make_trunc_case('trunc_mm'),
     'stepmask_d4': lambda: make_resample_case('stepmask_d4'),
     'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
