@@ -493,7 +493,15 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // split-bf16 precision: offered by the fast family for workgroups of up to 32 rows
   const bool want_split = (c.precision == PMBRL_PREC_SPLIT || c.precision == PMBRL_PREC_SPLIT_F16) && p->fast &&
                           !getenv("PMBRL_FORCE_F32");
-  auto prec_for = [&](int RT) { return (want_split && RT <= 2) ? c.precision : 0; };
+  // (64-row workgroups: two fp16 piece planes fit the LDS next to everything else, three bf16 planes do not)
+  // 64-row workgroups on split operands: two fp16 piece planes fit the LDS (three bf16 planes do not), and
+  // only the shape-specialised instance keeps its inline-asm loads clear of register-allocator copies
+  // (tools/check_inflight.py; the generic 64-row split instances fail that lint and are not compiled):
+  // the double cart-pole shape with in-kernel moment matching (PM_SPLIT_SHAPED_RT4), fp32 otherwise
+  bool rt4_split = c.precision == PMBRL_PREC_SPLIT_F16 && mm && c.D == 6 && c.U == 1 && p->pol.nl == 3 &&
+                   p->dyn.nl == 3 && p->pol.nt[1] == 13 && p->pol.nt[2] == 13 && p->dyn.nt[1] == 13 &&
+                   p->dyn.nt[2] == 13 && !(c.flags & PMBRL_FLAG_NO_SHAPED);
+  auto prec_for = [&](int RT) { return (want_split && (RT <= 2 || rt4_split)) ? c.precision : 0; };
   // (kdiv: 16-wide k-blocks per stage unit -- 1 on the fp32 path, 2 = one K32 block on the split path)
   auto stream_work = [&](int m, int kdiv) {
     long w = 0;
@@ -534,9 +542,12 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   };
   auto lds_need = [&](int RT, int mmd) {
     p->LD = ld_for(RT);
-    if (p->fast)
+    if (p->fast) {
+      // in-kernel moment matching: one wave per whole group of the workgroup
+      const int mw = (mmd && p->M <= 16 * RT) ? std::min(PF_NW, std::max(1, 16 * RT / p->M)) : PF_NW;
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
-                                p->dyn.nl, mmd, prec_for(RT)) * sizeof(float);
+                                p->dyn.nl, mmd, prec_for(RT), mw) * sizeof(float);
+    }
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
   };
   p->G = 1;
@@ -547,6 +558,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     if (c.B % p->G) { delete p; return fail(-2, "B must be divisible by mm_groups"); }
     p->M = c.B / p->G;
     if (p->M < 2) { delete p; return fail(-2, "moment matching needs >= 2 rows per group"); }
+    if (rt4_split && p->fast && lds_need(4, c.D) > lds_cap) rt4_split = false;   // 64-row workgroups: fp32 then
     // in-kernel if a whole number of groups fits a workgroup's row tiles and LDS
     p->mm_mode = 2;
     for (int RT : {1, 2, 4}) {
@@ -560,6 +572,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     }
   }
   if (p->mm_mode != 1) {
+    rt4_split = false;
     int RT = 1;
     if (c.rows_per_wg_hint >= 64) RT = 4;
     else if (c.rows_per_wg_hint >= 32) RT = 2;

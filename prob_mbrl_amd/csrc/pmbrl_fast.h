@@ -669,6 +669,19 @@ __device__ __forceinline__ void tail_gather(const float* tp, int* tcnt, int roun
 // a few dozen VALU instructions -- 32-bit offsets from uniform bases (the stash row block is
 // Rw = 16*RT, a compile-time constant), a multiply by the precomputed 1/keep.
 struct PmEmpty {};
+// 64-row workgroups park the heads' partial tiles (fp32 sums) in whichever activation buffer is idle
+// (pm_fast_hp_alias).  On the piece planes that leaves arbitrary 16-bit patterns -- infinities and NaNs among
+// them -- in the K-padding columns the layer epilogues never write; the next GEMM multiplies those by zero
+// weights, and 0 x inf is not 0 (forward: the NaN pre-activations then vanish in the ReLU and silently zero
+// the row's hidden units).  The epilogue of a layer's LAST tile therefore clears the padding of its rows.
+template <int RT, int NP, bool F16>
+__device__ __forceinline__ void pm_zero_k_padding(float* lds_out, unsigned ldb, unsigned lrow, unsigned f0, int ot, int nt) {
+  if constexpr (RT >= 4) {
+    if (ot == nt - 1)
+      for (unsigned c = f0 + 16; c + 16 <= ldb; c += 16)
+        pm_store_planes<NP, 16 * RT, F16>(lds_out, ldb, lrow, c, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
 // NP = 0: the layer output goes to LDS as fp32 rows (leading dimension ld); NP > 0: as NP bf16 (F16: fp16)
 // piece planes (pmbrl_split.h; leading dimension ld in 16-bit elements)
 template <int RT, int NP = 0, bool F16 = false>
@@ -715,8 +728,12 @@ struct EpiFwdL {
       h[r] = a ? v * inv_keep : 0.f;
       act |= (a ? 1u : 0u) << r;
     }
-    if constexpr (NP > 0) pm_store_planes<NP, 16 * RT, F16>(lds_out, (unsigned)ld, lrow, f0, h);
-    else *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    if constexpr (NP > 0) {
+      pm_store_planes<NP, 16 * RT, F16>(lds_out, (unsigned)ld, lrow, f0, h);
+      pm_zero_k_padding<RT, NP, F16>(lds_out, (unsigned)ld, lrow, f0, ot, nt);
+    } else {
+      *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    }
     if constexpr (F16) {
       // fp16 pieces: a value beyond the format's range would turn into inf - inf = NaN inside the next
       // layer and vanish in its ReLU; report it instead (h >= 0 here; the sampling phase of this step
@@ -778,8 +795,12 @@ struct EpiBwdL {
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = ((nib >> r) & 1u) ? acc[r] * inv_keep : 0.f;
-    if constexpr (NP > 0) pm_store_planes<NP, 16 * RT>(lds_out, (unsigned)ld, lrow, f0, h);
-    else *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    if constexpr (NP > 0) {
+      pm_store_planes<NP, 16 * RT>(lds_out, (unsigned)ld, lrow, f0, h);
+      pm_zero_k_padding<RT, NP, false>(lds_out, (unsigned)ld, lrow, f0, ot, nt);
+    } else {
+      *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
+    }
 #ifndef PM_EXP_NOSTASH
     if (stash) {
       PM_GLOBAL float* sp = (PM_GLOBAL float*)(stash + (unsigned)ot * (16u * RW));   // uniform
@@ -933,7 +954,8 @@ __host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
 #define PM_XIN_LD 24             // = 8 (mod 16): conflict-free ds_read_b128 of the MFMA B operand
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
-                                                     int dnl, int mm_d, int prec = 0) {
+                                                     int dnl, int mm_d, int prec = 0, int mm_waves = PF_NW) {
+  // (mm_waves: waves that do in-kernel moment matching at once = whole groups per workgroup, at most PF_NW)
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
   if (!pm_fast_hp_alias(R, LD, RT)) n += (size_t)PF_NW * RT * 256;
   for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
@@ -951,7 +973,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
     const size_t tw = tf > tb ? tf : tb;
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
-  n += 2 * (size_t)PF_NW * pm_mm_scratch_doubles(mm_d);
+  n += 2 * (size_t)mm_waves * pm_mm_scratch_doubles(mm_d);
   return n;
 }
 

@@ -1,6 +1,8 @@
 // Latency-optimised sweep kernels on split bf16 / fp16 operands (pmbrl_split.h): instantiations, attribute
 // setup and launch dispatch.  Compiled once per precision: -DPM_SPLIT_PR=1 (three bf16 pieces forward) and
 // -DPM_SPLIT_PR=2 (two fp16 pieces forward); the adjoint uses two bf16 pieces in both.
+#include <cstdio>
+#include <cstdlib>
 #include "pmbrl_host.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
@@ -12,6 +14,7 @@
 
 template <int RT, int CA, int CB, int PR>
 static int set_attr_split(size_t lds) {
+  if constexpr (RT < 4) {   // (64-row workgroups: the shape-specialised instances below only)
   const void* fns[] = {
       reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
       reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_LEAN, PfShapeAny, PR>),
@@ -21,6 +24,7 @@ static int set_attr_split(size_t lds) {
       reinterpret_cast<const void*>(&pm_rollout_bwd_fast<RT, CA, CB, PF_VAR_MM, PfShapeAny, PR>)};
   for (const void* f : fns)
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   if constexpr (RT == 1) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<RT, CA, CB, PF_VAR_MMG, PfShapeAny, PR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -76,6 +80,11 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
     PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
   }
 #undef PM_FAST_SHAPED
+  if constexpr (RT >= 4) {
+    // unreachable: pmbrl_plan_create selects 64-row split workgroups for the specialised shape only
+    fprintf(stderr, "pmbrl: no 64-row split-precision instance for this shape\n");
+    abort();
+  } else {
 #define PM_LAUNCH_VAR(K, V) hipLaunchKernelGGL((K<RT, CA, CB, V, PfShapeAny, PR>), g, b, p->lds_bytes, s, A)
   if constexpr (RT == 1) {
     if (var == PF_VAR_MMG) {
@@ -94,6 +103,7 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
     else PM_LAUNCH_VAR(pm_rollout_bwd_fast, PF_VAR_LEAN);
   }
 #undef PM_LAUNCH_VAR
+  }
 }
 
 

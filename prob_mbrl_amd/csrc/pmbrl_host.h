@@ -88,7 +88,15 @@ struct ScopedTimer {
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 6, 1, 216, 3, 13)
 
 // split-bf16 instantiations (pmbrl_split.h): stage pairs in K32 blocks
-#define PM_SPLIT_CASES PM_SPLIT_CASE(1, 4, 3) PM_SPLIT_CASE(1, 1, 1) PM_SPLIT_CASE(2, 4, 3) PM_SPLIT_CASE(2, 1, 1)
+// (64-row workgroups exist with two fp16 piece planes only: PM_SPLIT_PR == 2)
+#define PM_SPLIT_CASES_12 PM_SPLIT_CASE(1, 4, 3) PM_SPLIT_CASE(1, 1, 1) PM_SPLIT_CASE(2, 4, 3) PM_SPLIT_CASE(2, 1, 1)
+#if defined(PM_SPLIT_PR) && PM_SPLIT_PR == 2
+#define PM_SPLIT_CASES PM_SPLIT_CASES_12 PM_SPLIT_CASE(4, 4, 3)
+#define PM_SPLIT_SHAPED_RT4(LDV) PM_FAST_SHAPED(4, 4, 3, PF_VAR_MM, 6, 1, LDV, 3, 13)
+#else
+#define PM_SPLIT_CASES PM_SPLIT_CASES_12
+#define PM_SPLIT_SHAPED_RT4(LDV)
+#endif
 // shape-specialised split instantiations; LDV: floats per row of an activation buffer = piece planes x 240 / 2
 // (three bf16 planes: 360, two fp16 planes: 240)
 #define PM_SPLIT_SHAPED_CASES(LDV)                             \
@@ -97,7 +105,8 @@ struct ScopedTimer {
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
-  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)         \
+  PM_SPLIT_SHAPED_RT4(LDV)
 
 // 16-wide tiles of the hidden layers if every hidden layer of both nets has the same width, else -1
 static inline int hidden_tiles(const RolloutArgs& A) {

@@ -141,21 +141,37 @@ template <int RT, int NB, int NP, bool F16, class FR>
 __device__ __forceinline__ void frag_compute_s(const FR& f, int kb0, int kb0_next, const unsigned short* lane_base,
                                                unsigned ldb, f32x4 (&acc)[2][RT], BQ<RT, NP>& b0) {
   typedef PmPairs<NP> PP;
-  BQ<RT, NP> b[2];
-  b[0] = b0;
+  if constexpr (RT >= 4) {
+    // 64-row workgroups: registers are the constraint (four row tiles of B operands and accumulators per
+    // wave) -- one set of B operands, read right before its 4 * N MFMAs (the SIMD's other wave covers the
+    // LDS latency), and the four row tiles as the independent accumulator chains
+    (void)kb0_next;
 #pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    const int cur = blk & 1, nxt = cur ^ 1;
-    bq_load<RT, NP>(b[nxt], lane_base, ldb, blk + 1 < NB ? kb0 + blk + 1 : kb0_next);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int blk = 0; blk < NB; ++blk) {
+      bq_load<RT, NP>(b0, lane_base, ldb, kb0 + blk);
 #pragma unroll
-    for (int q = 0; q < PP::N; ++q)
+      for (int q = 0; q < PP::N; ++q)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[q & 1][rt] = pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b[cur].v[PP::A[q]][rt], acc[q & 1][rt]);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int rt = 0; rt < RT; ++rt)
+          acc[0][rt] = pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b0.v[PP::A[q]][rt], acc[0][rt]);
+    }
+  } else {
+    BQ<RT, NP> b[2];
+    b[0] = b0;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int cur = blk & 1, nxt = cur ^ 1;
+      bq_load<RT, NP>(b[nxt], lane_base, ldb, blk + 1 < NB ? kb0 + blk + 1 : kb0_next);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[q & 1][rt] = pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b[cur].v[PP::A[q]][rt], acc[q & 1][rt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    b0 = b[NB & 1];
   }
-  b0 = b[NB & 1];
 }
 
 // Narrow head / tail on the piece planes: K32 block `wid` of the single output tile per wave (<= 8
