@@ -486,7 +486,10 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
                          PMBRL_FLAG_DYN_MASKS_PER_STEP)) && !angles &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
-  const int LD_generic = p->LD;
+  // general family on split operands (pmbrl_gsplit.h): two fp16 pieces forward / two bf16 pieces in the adjoint;
+  // an activation buffer row is then LD 16-bit elements per piece plane, LD = 16 (mod 32)
+  const bool gsplit = !p->fast && c.precision == PMBRL_PREC_SPLIT_F16 && !getenv("PMBRL_FORCE_F32");
+  const int LD_generic = gsplit ? (maxnt * 16 + 31) / 32 * 32 + 16 : p->LD;
   // stage sizes (k-blocks) of the weight stream: every streamed layer is padded to a whole number
   // of stage PAIRS (CA + CB k-blocks); pick, among the instantiated pairs, the one that pads least
   struct StagePair { int ca, cb; };
@@ -501,7 +504,10 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   bool rt4_split = c.precision == PMBRL_PREC_SPLIT_F16 && mm && c.D == 6 && c.U == 1 && p->pol.nl == 3 &&
                    p->dyn.nl == 3 && p->pol.nt[1] == 13 && p->pol.nt[2] == 13 && p->dyn.nt[1] == 13 &&
                    p->dyn.nt[2] == 13 && !(c.flags & PMBRL_FLAG_NO_SHAPED);
-  auto prec_for = [&](int RT) { return (want_split && (RT <= 2 || rt4_split)) ? c.precision : 0; };
+  auto prec_for = [&](int RT) {
+    if (!p->fast) return gsplit ? (int)PMBRL_PREC_SPLIT_F16 : 0;
+    return (want_split && (RT <= 2 || rt4_split)) ? (int)c.precision : 0;
+  };
   // (kdiv: 16-wide k-blocks per stage unit -- 1 on the fp32 path, 2 = one K32 block on the split path)
   auto stream_work = [&](int m, int kdiv) {
     long w = 0;
@@ -528,6 +534,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // split path: elements per row of a bf16 piece plane = padded K + 16 (conflict-free ds_read_b128)
   auto ldb_for = [&](int RT) {
     if (!prec_for(RT)) return 0;
+    if (!p->fast) return LD_generic;
     const StagePair sp = stages_for(RT);
     const int m = sp.ca + sp.cb;
     return ((maxnt + 1) / 2 + m - 1) / m * m * 32 + 16;
@@ -750,7 +757,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->ws_bytes = off;
   }
   int rc2 = 0;
-  if (!p->fast) {
+  if (!p->fast && p->prec) {
+    rc2 = pm_general_split_set_attr(p);
+  } else if (!p->fast) {
     switch (p->RT) {
       case 1: rc2 = set_attr<1>(p->lds_bytes); break;
       case 2: rc2 = set_attr<2>(p->lds_bytes); break;
@@ -968,9 +977,17 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   return 0;
 }
 
-static void pack_jobs(const NetPlan& n, char* ws, const float* params, int pair_kb, PackArgs& P, int prec = 0) {
+static void pack_jobs(const NetPlan& n, char* ws, const float* params, int pair_kb, PackArgs& P, int prec = 0,
+                      bool general = false) {
   for (int l = 0; l < n.nl; ++l) {
     const int O = n.dim[l + 1], K = n.dim[l];
+    if (general && prec) {
+      // general family on split operands: every layer as two piece planes of whole K32 blocks
+      P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wf[l]), O, K, 0, 1, 0, 2, 1};
+      P.job[P.n++] = PackJob{params + n.w_off[l], reinterpret_cast<float*>(ws + n.wb[l]), O, K, 1, 1, 0, 2, 0};
+      P.job[P.n++] = PackJob{params + n.b_off[l], reinterpret_cast<float*>(ws + n.bias[l]), O, K, 0, 1, 1, 0, 0};
+      continue;
+    }
     // hidden->hidden layers feed the streamed GEMMs of the fast kernels: k-blocks padded to CA+CB
     const int mult = (pair_kb >= 1 && l >= 1 && l <= n.nl - 2) ? pair_kb : 1;
     // split precision: bf16 pieces for every product with K = a hidden width -- forward: hidden->hidden layers
@@ -1000,6 +1017,7 @@ static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   if (p->fast) return launch_fast_rt(p, A, s, true);
+  if (p->prec) return pm_general_split_launch(p, A, s, true);
   switch (p->RT) {
     case 1: launch_fwd<1>(p, A, s); break;
     case 2: launch_fwd<2>(p, A, s); break;
@@ -1008,6 +1026,7 @@ static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t
 }
 static void launch_bwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   if (p->fast) return launch_fast_rt(p, A, s, false);
+  if (p->prec) return pm_general_split_launch(p, A, s, false);
   switch (p->RT) {
     case 1: launch_bwd<1>(p, A, s); break;
     case 2: launch_bwd<2>(p, A, s); break;
@@ -1033,8 +1052,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
     PackArgs PK;
     PK.n = 0;
-    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec);
-    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec);
+    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
+    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
     PK.status = status_d;
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   }

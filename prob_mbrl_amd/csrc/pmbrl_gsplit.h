@@ -1,0 +1,173 @@
+// Split-operand matrix-core GEMMs for the GENERAL kernel family (pmbrl_rollout.h): wide networks (the
+// 3 x 512 stress shape), three-layer nets, angle_dims, per-step masks -- everything the latency-optimised
+// sweeps (pmbrl_fast.h) do not cover.  Same arithmetic as there (pmbrl_split.h): every fp32 operand is two
+// 16-bit pieces, a product is the three piece products of combined order < 2 on v_mfma_f32_16x16x32_{f16,bf16}
+// with fp32 accumulation -- two fp16 pieces (22 bits) in the forward sweep, two bf16 pieces in the adjoint.
+//
+// What changes against the fp32 form of this family:
+//   * an activation buffer [R][LD] floats is read as two piece planes [2][R][LDB] of 16-bit elements with
+//     LDB = LD (same bytes), LDB = 16 (mod 32): conflict-free ds_read_b128 B operands;
+//   * weights [tile][K32 block][piece][lane][8 x 16 bit] (pm_pack_all, planes = 2): the same 4 bytes per
+//     weight as fp32, one global_load_dwordx4 per (tile, block, piece) and lane;
+//   * per K = 32 three MFMAs of 16 cycles instead of eight fp32 MFMAs of 32: the hidden-width GEMMs stop being
+//     bound by the matrix core (0.55 of the fp32 peak at 3 x 512) and become bound by the weight stream L2 -> CU;
+//   * narrow GEMMs (heads, first-layer adjoints) still leave fp32 rows in the output buffer, which the
+//     elementwise phases read as before; those phases write network inputs as piece planes.
+// Loads are plain compiler-scheduled loads here (no inline-asm stream): this family is throughput-bound.
+#pragma once
+#include "pmbrl_split.h"
+
+#define PM_GS_CK 2   // K32 blocks per chunk (two chunks in flight)
+
+// scalar store of one value into the piece planes (the elementwise phases' network inputs)
+template <int R, bool F16>
+__device__ __forceinline__ void pm_put_planes(float* buf, unsigned ldb, unsigned row, unsigned col, float v) {
+  unsigned short* pb = reinterpret_cast<unsigned short*>(buf);
+  if constexpr (F16) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    pb[row * ldb + col] = __builtin_bit_cast(unsigned short, h);
+    pb[(R + row) * ldb + col] = __builtin_bit_cast(unsigned short, l);
+  } else {
+    const unsigned a = pm_pk_bf16(v, 0.f) & 0xffffu;
+    const unsigned b = pm_pk_bf16(v - pm_bf_lo(a), 0.f) & 0xffffu;
+    pb[row * ldb + col] = (unsigned short)a;
+    pb[(R + row) * ldb + col] = (unsigned short)b;
+  }
+}
+
+// K32 blocks of a layer input of `nt` 16-wide tiles
+__host__ __device__ inline int pm_kb32(int nt) { return (nt + 1) / 2; }
+
+template <int NT>
+struct GsFrag {
+  f32x4 a[NT][PM_GS_CK][2];
+};
+
+// NT output tiles (ot0, ot0 + PM_NW, ...) x RT row tiles per wave; absent tiles of the last group are computed
+// as duplicates of the group's first tile and dropped.
+template <int RT, int NT, bool F16, class Epi>
+__device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf, int n_kb, int ot0, int n_ot,
+                                                   const float* buf_in, unsigned ldb, int lane, Epi& epi) {
+  typedef PmPairs<2> PP;
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  f32x4 acc[NT][RT];
+  const float* wp[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int ot = ot0 + k * PM_NW;
+    wp[k] = wf + ((size_t)(ot < n_ot ? ot : ot0) * n_kb) * 512 + lane * 4;   // 2 pieces x 256 floats per block
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  GsFrag<NT> f0, f1;
+  auto load = [&](GsFrag<NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_GS_CK; ++c) {
+      const int kb = kb0 + c < n_kb ? kb0 + c : 0;   // past the end: a harmless re-load of block 0
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) f.a[k][c][p] = ldg4(wp[k] + ((size_t)kb * 2 + p) * 256);
+    }
+  };
+  auto compute = [&](const GsFrag<NT>& f, int kb0) {
+#pragma unroll
+    for (int c = 0; c < PM_GS_CK; ++c) {
+      if (kb0 + c < n_kb) {
+        BQ<RT, 2> b;
+        bq_load<RT, 2>(b, lb, ldb, kb0 + c);
+#pragma unroll
+        for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+          for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[k][rt] = pm_mfma_bf<F16>(f.a[k][c][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt]);
+      }
+    }
+  };
+  load(f0, 0);
+  for (int kb0 = 0; kb0 < n_kb; kb0 += 2 * PM_GS_CK) {
+    load(f1, kb0 + PM_GS_CK);
+    compute(f0, kb0);
+    load(f0, kb0 + 2 * PM_GS_CK);
+    compute(f1, kb0 + PM_GS_CK);
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (ot0 + k * PM_NW < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt]);
+    }
+  }
+}
+
+template <int RT, bool F16, class Epi>
+__device__ __forceinline__ void gemm_tiles_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* buf_in,
+                                             unsigned ldb, int wid, int lane, Epi& epi) {
+  constexpr int NT = 2;
+  for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
+    gemm_tiles_group_s<RT, NT, F16>(wf, n_kb, ot0, n_ot, buf_in, ldb, lane, epi);
+}
+
+// K-split GEMM for narrow outputs (see gemm_ksplit): every wave reduces its slice of K32 blocks for all
+// output tiles; partial tiles in the layout gemm_ksplit_combine() reads.
+template <int RT, bool F16>
+__device__ __forceinline__ void gemm_ksplit_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* buf_in,
+                                              unsigned ldb, int wid, int lane, float* part, float* alias, int ld) {
+  typedef PmPairs<2> PP;
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  const int per = (n_kb + PM_NW - 1) / PM_NW;
+  const int k_lo = wid * per;
+  const int k_hi = min(n_kb, k_lo + per);
+  f32x4 acc[PM_KS_NT][RT];
+#pragma unroll
+  for (int k = 0; k < PM_KS_NT; ++k)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = k_lo; kb < k_hi; ++kb) {
+    f32x4 a[PM_KS_NT][2];
+#pragma unroll
+    for (int k = 0; k < PM_KS_NT; ++k)
+      if (k < n_ot) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a[k][p] = ldg4(wf + (((size_t)k * n_kb + kb) * 2 + p) * 256 + lane * 4);
+      }
+    BQ<RT, 2> b;
+    bq_load<RT, 2>(b, lb, ldb, kb);
+#pragma unroll
+    for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+      for (int k = 0; k < PM_KS_NT; ++k)
+        if (k < n_ot) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[k][rt] = pm_mfma_bf<F16>(a[k][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt]);
+        }
+  }
+#pragma unroll
+  for (int k = 0; k < PM_KS_NT; ++k)
+    if (k < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        *reinterpret_cast<f32x4*>(pm_part_at(part, alias, ld, (((wid * PM_KS_NT + k) * RT + rt) * 64 + lane) * 4)) =
+            acc[k][rt];
+    }
+}
+
+// head / tail layer on the piece planes; fp32 rows (with bias) in lds_out[row][0 .. n_ot*16), leading
+// dimension ld floats.  Contains barriers: called by all threads.
+template <int RT, bool F16>
+__device__ __forceinline__ void gemm_narrow_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* bias,
+                                              const float* buf_in, unsigned ldb, float* lds_out, int ld, float* part,
+                                              int wid, int lane, int tid) {
+  if (n_ot <= PM_KS_NT) {
+    gemm_ksplit_s<RT, F16>(wf, n_ot, n_kb, buf_in, ldb, wid, lane, part, lds_out, ld);
+    __syncthreads();
+    gemm_ksplit_combine<RT>(part, n_ot, bias, lds_out, ld, tid, lds_out);
+  } else {
+    EpiPlain e{bias, lds_out, ld, lane};
+    gemm_tiles_s<RT, F16>(wf, n_ot, n_kb, buf_in, ldb, wid, lane, e);
+  }
+  __syncthreads();
+}

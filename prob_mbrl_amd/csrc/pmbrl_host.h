@@ -131,6 +131,9 @@ static inline int fast_variant(int RT, const RolloutArgs& A) {
 int pm_fast_f32_mmg_blocks_per_cu(const pmbrl_plan* p);
 int pm_fast_split1_mmg_blocks_per_cu(const pmbrl_plan* p);
 int pm_fast_split2_mmg_blocks_per_cu(const pmbrl_plan* p);
+// general family on split operands (pmbrl_general_split.hip)
+int pm_general_split_set_attr(const pmbrl_plan* p);
+void pm_general_split_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);
 int pm_fast_f32_set_attr(const pmbrl_plan* p);
 void pm_fast_f32_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd);
 int pm_fast_split1_set_attr(const pmbrl_plan* p);     // PMBRL_PREC_SPLIT

@@ -7,12 +7,16 @@
 #pragma once
 #include "pmbrl_dev.h"
 #include "pmbrl_mm.h"
+#include "pmbrl_gsplit.h"
 
 // ---------------------------------------------------------------------------
 // epilogues
 // ---------------------------------------------------------------------------
 // hidden layer, forward:  h = relu(acc + b) * mask / keep     (models/modules.py:46-61,120-160)
-struct EpiHiddenFwd {
+// NP = 0: fp32 rows out (leading dimension ld floats); NP = 2: two piece planes (pmbrl_gsplit.h; ld in 16-bit
+// elements, R rows per plane; F16: fp16 pieces with range check into *ovf)
+template <int NP = 0, bool F16 = false, int R = 0>
+struct EpiHiddenFwdT {
   const float* bias;
   const uint16_t* mask;   // [B][nt]
   uint16_t* abits;        // [B][nt] slice of step t
@@ -20,6 +24,7 @@ struct EpiHiddenFwd {
   float* lds_out;
   float* stash;           // feature-major block [nt*16][Rw] or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
+  int* ovf;
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
     const int g = lane >> 4;
     const int lrow = rt * 16 + (lane & 15);
@@ -38,7 +43,17 @@ struct EpiHiddenFwd {
       h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
       act |= (a ? 1u : 0u) << r;
     }
-    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if constexpr (NP > 0) {
+      pm_store_planes<NP, R, F16>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0, h);
+      // the K padding up to the next K32 block (the buffer held fp32 rows / partial tiles before: any bits)
+      if (ot == nt - 1 && (nt & 1))
+        pm_store_planes<NP, R, F16>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0 + 16u, f32x4{0.f, 0.f, 0.f, 0.f});
+      if constexpr (F16) {
+        if (fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3])) > 65504.f) *ovf = 1;
+      }
+    } else {
+      *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    }
     if (stash) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
@@ -51,7 +66,8 @@ struct EpiHiddenFwd {
 };
 
 // hidden layer, backward: g_pre = active ? acc / keep : 0
-struct EpiHiddenBwd {
+template <int NP = 0, int R = 0>
+struct EpiHiddenBwdT {
   const uint16_t* abits;  // [B][nt] slice of step t
   float keep;
   float* lds_out;
@@ -68,7 +84,13 @@ struct EpiHiddenBwd {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
-    *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    if constexpr (NP > 0) {
+      pm_store_planes<NP, R, false>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0, h);
+      if (ot == nt - 1 && (nt & 1))
+        pm_store_planes<NP, R, false>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0 + 16u, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
+      *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
+    }
     if (stash) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
@@ -206,10 +228,13 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
 // ===========================================================================
 // forward
 // ===========================================================================
-template <int RT>
+// PR = 0: exact fp32 MFMA; PR = 2: split operands (pmbrl_gsplit.h) -- two fp16 pieces
+template <int RT, int PR = 0>
 __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
+  constexpr bool SP = PR != 0;
+  const unsigned LDB = (unsigned)A.LD;   // split: elements per row of a piece plane (= floats per row)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
@@ -219,6 +244,9 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT);
   float* xa = L.xa;   // current state x_t
   float* xb = L.xb;   // pre-moment-matching next state
+  // PR = 2: set when an activation leaves fp16's range (the action-gradient rows are idle in the forward sweep)
+  int* const p_ovf = reinterpret_cast<int*>(L.gad);
+  if (SP && tid == 0) *p_ovf = 0;
 
   // initial state (states[t0] is x0 for t0 == 0, the previous launch's output otherwise)
   {
@@ -246,8 +274,9 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     // ---- policy input (no normalisation in Policy.forward, models/core.py:221-248)
     {
       const int K16 = P.nt[0] * 16;
+      const int KW = SP ? pm_kb32(P.nt[0]) * 32 : K16;   // split: whole K32 blocks of the piece planes
       float* st = A.actT[0] + blk * (size_t)K16 * A.Rw;
-      for (int i = tid; i < R * K16; i += PM_NT) {
+      for (int i = tid; i < R * KW; i += PM_NT) {
         const int k = i / R, r = i - k * R;
         float v = 0.f;
         if (pmap) {
@@ -255,8 +284,9 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         } else if (k < D) {
           v = xa[r * D + k];
         }
-        X[r * LD + k] = v;
-        st[(size_t)k * A.Rw + r] = v;
+        if constexpr (SP) pm_put_planes<R, true>(X, LDB, r, k, v);
+        else X[r * LD + k] = v;
+        if (k < K16) st[(size_t)k * A.Rw + r] = v;
       }
     }
     __syncthreads();
@@ -265,20 +295,26 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     for (int l = 0; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
       const uint16_t* mk = P.mask[l] + ((A.flags & PMBRL_FLAG_POL_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
-      EpiHiddenFwd e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
-                     A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
+      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+                                        A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane,
+                                        p_ovf};
+      if constexpr (SP) gemm_tiles_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
+      else gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(2 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // ---- policy head -> Y[r][0..2U)
-    gemm_narrow<RT>(P.wf[P.nl - 1], P.nt[P.nl], P.nt[P.nl - 1], P.bias[P.nl - 1], X, Y, LD, L.part,
-                    wid, lane, tid);
+    if constexpr (SP)
+      gemm_narrow_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), P.bias[P.nl - 1], X, LDB, Y, LD,
+                              L.part, wid, lane, tid);
+    else
+      gemm_narrow<RT>(P.wf[P.nl - 1], P.nt[P.nl], P.nt[P.nl - 1], P.bias[P.nl - 1], X, Y, LD, L.part,
+                      wid, lane, tid);
     PM_MARK(10);
     // ---- squash + dynamics input (models/densities.py:87-121, models/core.py:243,169-177)
     {
-      const int K16 = F.nt[0] * 16;
+      const int K16 = SP ? pm_kb32(F.nt[0]) * 32 : F.nt[0] * 16;
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int r = i / K16, k = i - r * K16;
         float v = 0.f;
@@ -308,7 +344,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           }
           v = (a - A.mx[k]) * A.iSx[k];
         }
-        X[r * LD + k] = v;
+        if constexpr (SP) pm_put_planes<R, true>(X, LDB, r, k, v);
+        else X[r * LD + k] = v;
       }
     }
     __syncthreads();
@@ -317,16 +354,21 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     for (int l = 0; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
       const uint16_t* mk = F.mask[l] + ((A.flags & PMBRL_FLAG_DYN_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
-      EpiHiddenFwd e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
-                     nullptr, LD, A.Rw, row0, nvalid, nt, lane};
-      gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
+      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
+                                        nullptr, LD, A.Rw, row0, nvalid, nt, lane, p_ovf};
+      if constexpr (SP) gemm_tiles_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
+      else gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(12 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // ---- dynamics head -> Y[r][0..2D)
-    gemm_narrow<RT>(F.wf[F.nl - 1], F.nt[F.nl], F.nt[F.nl - 1], F.bias[F.nl - 1], X, Y, LD, L.part,
-                    wid, lane, tid);
+    if constexpr (SP)
+      gemm_narrow_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), F.bias[F.nl - 1], X, LDB, Y, LD,
+                              L.part, wid, lane, tid);
+    else
+      gemm_narrow<RT>(F.wf[F.nl - 1], F.nt[F.nl], F.nt[F.nl - 1], F.bias[F.nl - 1], X, Y, LD, L.part,
+                      wid, lane, tid);
     PM_MARK(20);
     // ---- sample next state (models/densities.py:97-121 with scaling_params, core.py:298)
     for (int i = tid; i < R * D; i += PM_NT) {
@@ -355,6 +397,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         rv = reward_row(A.rew, xb + r * D, D, L.av + r * U, U, nullptr);
         bool ok = isfinite(rv);
         for (int d = 0; d < D; ++d) ok = ok && isfinite(xb[r * D + d]);
+        if (SP && *p_ovf) ok = false;   // an activation left fp16's range in this step (or earlier): the host retries in fp32
         if (!ok) atomicMin(A.status, t);
         const size_t o = (size_t)t * B + row0 + r;
         if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[o] = rv;
@@ -409,10 +452,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
 // backward sweep.  Produces the G stash consumed by the
 // dW GEMM; policy dW/db are NOT accumulated here.
 // ===========================================================================
-template <int RT>
-__global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) {
+// (PR = 2: two bf16 pieces -- the adjoint is linear in the incoming gradient, profiles/r02_split_precision_study.txt)
+template <int RT, int PR = 0>
+__global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
+  constexpr bool SP = PR != 0;
+  const unsigned LDB = (unsigned)A.LD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
@@ -517,7 +563,7 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
     PM_MARK(2);
     // ---- dynamics head adjoint input: [gxt*Sy | gxt*Td | 0] -> X
     {
-      const int K16 = F.nt[F.nl] * 16;
+      const int K16 = SP ? pm_kb32(F.nt[F.nl]) * 32 : F.nt[F.nl] * 16;
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int r = i / K16, k = i - r * K16;
         float v = 0.f;
@@ -525,7 +571,8 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
           if (k < D) v = gxt[r * D + k] * A.Sy[k];
           else if (k < 2 * D) v = gxt[r * D + k - D] * A.Td[((size_t)t * B + row0 + r) * D + k - D];
         }
-        X[r * LD + k] = v;
+        if constexpr (SP) pm_put_planes<R, false>(X, LDB, r, k, v);
+        else X[r * LD + k] = v;
       }
     }
     __syncthreads();
@@ -533,21 +580,26 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
     // ---- dynamics trunk, dX only (weights frozen: no dV)
     for (int l = F.nl - 1; l >= 1; --l) {
       const int nt = F.nt[l];
-      EpiHiddenBwd e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw,
-                     row0, nvalid, nt, lane};
-      gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
+      EpiHiddenBwdT<SP ? 2 : 0, R> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw,
+                                    row0, nvalid, nt, lane};
+      if constexpr (SP) gemm_tiles_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
+      else gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(4 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
     // grad wrt normalised dynamics input [x | a] -> Y[r][0..D+U)
-    gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    if constexpr (SP)
+      gemm_narrow_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);
+    else
+      gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
     PM_MARK(12);
     // ---- phase B: split into state / action parts; policy head adjoint -> X
     {
       const int K16 = P.nt[P.nl] * 16;
+      const int KP = SP ? pm_kb32(P.nt[P.nl]) * 32 : K16;   // split: the head-gradient tile is whole K32 blocks wide
       float* gst = A.gT[P.nl - 1] + blk * (size_t)K16 * A.Rw;
-      const int W = max(K16, D + U);
+      const int W = max(KP, D + U);
       const float* xcur = A.states + (size_t)t * B * D;   // x_t (the angles the input features were taken at)
       for (int i = tid; i < R * W; i += PM_NT) {
         const int r = i / W, k = i - r * W;
@@ -580,15 +632,21 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
             go_mu = gu;
             go_ls = gu * A.Tp[((size_t)t * B + row0 + r) * U + j];
           }
-          X[r * LD + j] = go_mu;
-          X[r * LD + U + j] = go_ls;
+          if constexpr (SP) {
+            pm_put_planes<R, false>(X, LDB, r, j, go_mu);
+            pm_put_planes<R, false>(X, LDB, r, U + j, go_ls);
+          } else {
+            X[r * LD + j] = go_mu;
+            X[r * LD + U + j] = go_ls;
+          }
           gst[(size_t)j * A.Rw + r] = go_mu;
           gst[(size_t)(U + j) * A.Rw + r] = go_ls;
         }
         // zero the K-padding of the head-gradient tile (columns 2U..K16)
-        if (k >= 2 * U && k < K16) {
-          X[r * LD + k] = 0.f;
-          gst[(size_t)k * A.Rw + r] = 0.f;
+        if (k >= 2 * U && k < KP) {
+          if constexpr (SP) pm_put_planes<R, false>(X, LDB, r, k, 0.f);
+          else X[r * LD + k] = 0.f;
+          if (k < K16) gst[(size_t)k * A.Rw + r] = 0.f;
         }
       }
     }
@@ -604,14 +662,18 @@ __global__ __launch_bounds__(PM_NT, 2) void pm_rollout_bwd(const RolloutArgs A) 
     // ---- policy trunk: dX chain + G stash
     for (int l = P.nl - 1; l >= 1; --l) {
       const int nt = P.nt[l];
-      EpiHiddenBwd e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
-                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
+      EpiHiddenBwdT<SP ? 2 : 0, R> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
+                                    A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
+      if constexpr (SP) gemm_tiles_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
+      else gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(14 + l);
       float* tmp = X; X = Y; Y = tmp;
     }
-    gemm_narrow<RT>(P.wb[0], P.nt[0], P.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
+    if constexpr (SP)
+      gemm_narrow_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);
+    else
+      gemm_narrow<RT>(P.wb[0], P.nt[0], P.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
     PM_MARK(22);
     // ---- phase C: dL/dx_t
     for (int i = tid; i < R * D; i += PM_NT) {
