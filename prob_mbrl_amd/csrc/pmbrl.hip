@@ -392,7 +392,7 @@ static int set_attr(size_t lds) {
 // blocks, dealt to the four SIMDs (waves w and w+4 share SIMD w) by decreasing size so that
 // every SIMD issues the same number of MFMAs.  Returns the number of blocks; `blocks` comes back
 // sorted by wave, wave w owning [wave_first[w], wave_first[w+1]).
-static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, int* wave_first) {
+static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, int* wave_first, int tn_max = PM_DW_TN) {
   blocks.clear();
   auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
     const int parts = (n + maxsz - 1) / maxsz;
@@ -406,7 +406,7 @@ static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, 
   for (int l = 0; l < nl; ++l) {
     std::vector<std::pair<int, int>> os, is;
     split(nt[l + 1], PM_DW_TM, os);
-    split(nt[l], PM_DW_TN, is);
+    split(nt[l], tn_max, is);
     for (auto& o : os)
       for (auto& i : is) {
         DwBlock b;
@@ -421,10 +421,10 @@ static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, 
   }
   const int n_blocks = (int)blocks.size();
   // cost of a block = MFMAs per chunk in the shape class it runs in (see pm_dw_kernel)
-  auto cost = [](const DwBlock& b) {
+  auto cost = [tn_max](const DwBlock& b) {
     const int ni = b.n_ot <= 1 ? 1 : (b.n_ot <= 3 ? 3 : 4);
     const int nj = b.n_it <= 1 ? 1 : (b.n_it <= 4 ? 4 : (b.n_it <= 6 ? 6 : 7));
-    return ni * nj;
+    return ni * (tn_max <= 4 && nj > 1 ? 4 : nj);
   };
   std::stable_sort(blocks.begin(), blocks.end(),
                    [&](const DwBlock& a, const DwBlock& b) { return cost(a) > cost(b); });
@@ -709,10 +709,15 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   }
   {
     std::vector<DwBlock> blocks;
-    p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first);
+    // split-operand form of the dW GEMM (pmbrl_dw.h, pm_dw_kernel_s): where the fp32 form is bound by the matrix
+    // core -- 32- / 64-row workgroups and the general family's wide networks; the 16-row sweeps' dW is HBM-bound
+    p->dw_split = p->prec != 0 && (p->RT >= 2 || !p->fast) && !getenv("PMBRL_DW_F32");
+    if (getenv("PMBRL_DW_SPLIT") && p->prec != 0) p->dw_split = 1;
+    p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first, p->dw_split ? PM_DW_TN_S : PM_DW_TN);
     p->dw_n_chunks = c.H * p->nwg * p->RT;
     int nsplit = std::min(256, p->dw_n_chunks);   // one 8-wave workgroup per CU
     p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
+    if (p->dw_split) p->dw_chunks_per_split = (p->dw_chunks_per_split + 1) & ~1;   // whole chunk pairs
     p->dw_nsplit = (p->dw_n_chunks + p->dw_chunks_per_split - 1) / p->dw_chunks_per_split;
     HIPCHK(hipMalloc(&p->dw_blocks_d, blocks.size() * sizeof(DwBlock)));
     HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock),
@@ -1209,9 +1214,11 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   W.part = reinterpret_cast<float*>(ws + p->off_part);
   W.nvalid = status_d;
   W.chunks_per_step = p->nwg * p->RT;
+  W.split_prec = p->dw_split;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW, s);
-    hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+    if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+    else hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
   }
   const int n = (int)p->pol.n_params;
   {

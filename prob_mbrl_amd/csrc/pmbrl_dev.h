@@ -410,6 +410,19 @@ struct EpiPlain {
     if (bias) acc += ldg4(bias + f0);
     *reinterpret_cast<f32x4*>(lds_out + (rt * 16 + (lane & 15)) * ld + f0) = acc;
   }
+  // (operands fetched at the start of a tile group: see EpiHiddenFwdT::pre)
+  struct Pre {
+    f32x4 b;
+  };
+  __device__ __forceinline__ Pre pre(int ot, int) const {
+    Pre p;
+    p.b = bias ? ldg4(bias + ot * 16 + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    return p;
+  }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
+    const int f0 = ot * 16 + 4 * (lane >> 4);
+    *reinterpret_cast<f32x4*>(lds_out + (rt * 16 + (lane & 15)) * ld + f0) = acc + pr.b;
+  }
 };
 
 // head / tail layer: picks K-split or tile-split by width.  Contains barriers:

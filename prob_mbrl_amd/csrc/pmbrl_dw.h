@@ -24,12 +24,14 @@
 // queue (vmcnt(0)) before every chunk, i.e. one exposed HBM round trip per chunk.
 #pragma once
 #include "pmbrl_dev.h"
+#include "pmbrl_split.h"
 
 #define PM_DW_NW 8
 #define PM_DW_NT (PM_DW_NW * 64)
 #define PM_DW_TM 4
 #define PM_DW_TN 7
 #define PM_DW_MAXBLK 256
+#define PM_DW_TN_S 4   // split-operand form: blocks of at most 4 x 4 tiles (see pm_dw_block_s)
 
 struct DwBlock {      // one wave block
   int16_t layer, ot0, it0, n_ot, n_it, pad;
@@ -48,6 +50,7 @@ struct DwArgs {
   const DwBlock* blocks;                 // sorted by wave
   int wave_first[PM_DW_NW + 1];          // wave w owns blocks [wave_first[w], wave_first[w+1])
   float* part;                           // [nsplit][n_params]
+  int split_prec;                        // 1: two bf16 pieces per operand on the bf16 matrix core (pm_dw_kernel_s)
 };
 
 #ifdef PM_MAIN_TU   // the kernels below are compiled into pmbrl.hip only (pmbrl_host.h needs just the structs above)
@@ -197,6 +200,180 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
     if (blk.n_ot <= 1) pm_dw_dispatch_j<1>(A, blk, c_lo, c_hi, part, lane);
     else if (blk.n_ot <= 3) pm_dw_dispatch_j<3>(A, blk, c_lo, c_hi, part, lane);
     else pm_dw_dispatch_j<4>(A, blk, c_lo, c_hi, part, lane);
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// The same GEMM on split operands: every stashed fp32 value becomes two bf16 pieces in registers
+// (round, residual, round: 16 bits of significand -- the adjoint's precision class,
+// profiles/r02_split_precision_study.txt) and a product is three v_mfma_f32_16x16x32_bf16 per 32 row-steps
+// instead of eight fp32 MFMAs of twice the issue time.  K = 32 row-steps = two consecutive 16-row chunks
+// (c even, c + 1): lane (c16, g) supplies rows 8(g&1)..+7 of chunk c + (g>>1).  One raw operand set is in
+// flight while the previous one, already split into pieces, feeds the MFMAs; blocks are at most 4 x 4 tiles
+// (64 accumulator + 64 piece + 64 raw registers).  Used where the fp32 form is bound by the matrix core
+// (32- and 64-row workgroups, wide networks); the 16-row form is bound by HBM and stays fp32.
+template <int NI, int NJ>
+__device__ __forceinline__ void pm_dw_block_s(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
+                                              float* part, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int l = blk.layer;
+  const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
+  const float* gbase = A.gT[l];
+  const float* abase = A.actT[l];
+  const size_t gblk = (size_t)Fo16 * A.Rw, ablk = (size_t)Fi16 * A.Rw;
+  // bytes from chunk c (even) to chunk c + 1: the next 16 rows of the same block, or (16-row blocks) the next block
+  const unsigned gd = A.RT >= 2 ? 64u : (unsigned)(gblk * 4), ad = A.RT >= 2 ? 64u : (unsigned)(ablk * 4);
+  unsigned goff[NI], aoff[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int ot = blk.ot0 + (i < blk.n_ot ? i : blk.n_ot - 1);
+    goff[i] = (unsigned)(((ot * 16 + c16) * A.Rw + 8 * (g & 1)) * 4) + (unsigned)(g >> 1) * gd;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int it = blk.it0 + (j < blk.n_it ? j : blk.n_it - 1);
+    aoff[j] = (unsigned)(((it * 16 + c16) * A.Rw + 8 * (g & 1)) * 4) + (unsigned)(g >> 1) * ad;
+  }
+  f32x4 acc[NI][NJ];
+  float bsum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    bsum[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = blk.it0 == 0;
+  f32x4 gr[NI][2], ar[NJ][2];     // raw fp32 rows, in flight
+  f32x4 gp[NI][2], ap[NJ][2];     // pieces: [.][0] = 8 high bf16, [.][1] = 8 low bf16
+  auto load = [&](int c) {
+    const int cc = c < c_hi ? c : c_lo;         // past the end: harmless re-load of the first pair
+    const int b = cc / A.RT, rt = cc - b * A.RT;
+    const float* gq = gbase + (size_t)b * gblk + rt * 16;
+    const float* aq = abase + (size_t)b * ablk + rt * 16;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(gr[i][0]) : "v"(goff[i]), "s"(gq));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(gr[i][1]) : "v"(goff[i]), "s"(gq));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[j][0]) : "v"(aoff[j]), "s"(aq));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(ar[j][1]) : "v"(aoff[j]), "s"(aq));
+    }
+  };
+  // 8 fp32 -> 8 high + 8 low bf16; rows of an absent second chunk (odd tail) contribute zeros
+  auto split8 = [&](const f32x4 (&r)[2], f32x4 (&p)[2], bool live) {
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = live ? r[e >> 1][2 * (e & 1)] : 0.f, b = live ? r[e >> 1][2 * (e & 1) + 1] : 0.f;
+      hi[e] = pm_pk_bf16(a, b);
+      lo[e] = pm_pk_bf16(a - pm_bf_lo(hi[e]), b - pm_bf_hi(hi[e]));
+    }
+    p[0] = __builtin_bit_cast(f32x4, (uint4){hi[0], hi[1], hi[2], hi[3]});
+    p[1] = __builtin_bit_cast(f32x4, (uint4){lo[0], lo[1], lo[2], lo[3]});
+  };
+  load(c_lo);
+  for (int c = c_lo; c < c_hi; c += 2) {
+    asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      asm volatile("" : "+v"(gr[i][0]));
+      asm volatile("" : "+v"(gr[i][1]));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      asm volatile("" : "+v"(ar[j][0]));
+      asm volatile("" : "+v"(ar[j][1]));
+    }
+    const bool live = g < 2 || c + 1 < c_hi;
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const f32x4 t = gr[i][0] + gr[i][1];
+        bsum[i] += live ? (t[0] + t[1]) + (t[2] + t[3]) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) split8(gr[i], gp[i], live);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) split8(ar[j], ap[j], live);
+    load(c + 2);
+    // smallest contributions first: lo x hi, hi x lo, hi x hi
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = pm_mfma_bf<false>(gp[i][1], ap[j][0], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = pm_mfma_bf<false>(gp[i][0], ap[j][1], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = pm_mfma_bf<false>(gp[i][0], ap[j][0], acc[i][j]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)");   // drain the look-ahead loads before the registers are reused
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    asm volatile("" : "+v"(gr[i][0]));
+    asm volatile("" : "+v"(gr[i][1]));
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    asm volatile("" : "+v"(ar[j][0]));
+    asm volatile("" : "+v"(ar[j][1]));
+  }
+  const int O = A.dim[l + 1], K = A.dim[l];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (i < blk.n_ot) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (j < blk.n_it) {
+          const int k = (blk.it0 + j) * 16 + c16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = (blk.ot0 + i) * 16 + 4 * g + r;
+            if (o < O && k < K) part[A.w_off[l] + (size_t)o * K + k] = acc[i][j][r];
+          }
+        }
+      if (do_bias) {
+        float s = bsum[i];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const int o = (blk.ot0 + i) * 16 + c16;
+        if (g == 0 && o < O) part[A.b_off[l] + o] = s;
+      }
+    }
+}
+
+template <int NI>
+__device__ __forceinline__ void pm_dw_dispatch_js(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
+                                                  float* part, int lane) {
+  if (blk.n_it <= 1) pm_dw_block_s<NI, 1>(A, blk, c_lo, c_hi, part, lane);
+  else pm_dw_block_s<NI, PM_DW_TN_S>(A, blk, c_lo, c_hi, part, lane);
+}
+
+// (chunks_per_split is even: a chunk pair never straddles two splits)
+__global__ __launch_bounds__(PM_DW_NT, 1) void pm_dw_kernel_s(const DwArgs A) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int c_lo = split * A.chunks_per_split;
+  int n_chunks = A.n_chunks;
+  if (A.nvalid)
+    n_chunks = (int)min((long long)n_chunks,
+                        (long long)max(0, __builtin_amdgcn_readfirstlane(*A.nvalid)) * A.chunks_per_step);
+  const int c_hi = min(n_chunks, c_lo + A.chunks_per_split);
+  if (c_lo >= c_hi) return;
+  float* part = A.part + (size_t)split * A.part_stride;
+  for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
+    const DwBlock blk = A.blocks[bi];
+    if (blk.n_ot <= 1) pm_dw_dispatch_js<1>(A, blk, c_lo, c_hi, part, lane);
+    else if (blk.n_ot <= 3) pm_dw_dispatch_js<3>(A, blk, c_lo, c_hi, part, lane);
+    else pm_dw_dispatch_js<4>(A, blk, c_lo, c_hi, part, lane);
   }
 }
 

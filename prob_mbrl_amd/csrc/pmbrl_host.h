@@ -37,6 +37,7 @@ struct pmbrl_plan {
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
+  int dw_split;        // dW GEMM on split bf16 operands (pm_dw_kernel_s)
   AngleDev* ang_d;
   DwBlock* dw_blocks_d;
   int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;

@@ -25,15 +25,29 @@ struct EpiHiddenFwdT {
   float* stash;           // feature-major block [nt*16][Rw] or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
   int* ovf;
-  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+  // the epilogue's operands from HBM / L2 (bias, dropout bits): fetched by the split-operand GEMMs when a tile
+  // group STARTS, so that the round trip hides behind the group's MFMAs
+  struct Pre {
+    f32x4 b;
+    unsigned mw;
+  };
+  __device__ __forceinline__ Pre pre(int ot, int rt) const {
+    const int g = lane >> 4;
+    const int lrow = rt * 16 + (lane & 15);
+    Pre p;
+    p.b = ldg4(bias + ot * 16 + 4 * g);
+    p.mw = 0;
+    if (lrow < nvalid) p.mw = mask[(size_t)(row0 + lrow) * nt + ot];
+    return p;
+  }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) { (*this)(ot, rt, acc, pre(ot, rt)); }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     const int g = lane >> 4;
     const int lrow = rt * 16 + (lane & 15);
     const int f0 = ot * 16 + 4 * g;
-    const f32x4 b = ldg4(bias + f0);
+    const f32x4 b = pr.b;
     const bool valid = lrow < nvalid;
-    unsigned mw = 0;
-    if (valid) mw = mask[(size_t)(row0 + lrow) * nt + ot];
-    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    const unsigned nib = (pr.mw >> (4 * g)) & 0xFu;
     f32x4 h;
     unsigned act = 0;
 #pragma unroll
@@ -73,13 +87,22 @@ struct EpiHiddenBwdT {
   float* lds_out;
   float* stash;           // gT block or nullptr
   int ld, Rw, row0, nvalid, nt, lane;
-  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
+  struct Pre {
+    unsigned mw;
+  };
+  __device__ __forceinline__ Pre pre(int ot, int rt) const {
+    const int lrow = rt * 16 + (lane & 15);
+    Pre p;
+    p.mw = 0;
+    if (lrow < nvalid) p.mw = abits[(size_t)(row0 + lrow) * nt + ot];
+    return p;
+  }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) { (*this)(ot, rt, acc, pre(ot, rt)); }
+  __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     const int g = lane >> 4;
     const int lrow = rt * 16 + (lane & 15);
     const int f0 = ot * 16 + 4 * g;
-    unsigned mw = 0;
-    if (lrow < nvalid) mw = abits[(size_t)(row0 + lrow) * nt + ot];
-    const unsigned nib = (mw >> (4 * g)) & 0xFu;
+    const unsigned nib = (pr.mw >> (4 * g)) & 0xFu;
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
