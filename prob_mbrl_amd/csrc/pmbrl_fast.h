@@ -1910,6 +1910,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // Same phase pattern as the forward sweep: descriptors and the epilogue's activation bits
   // (HBM / L2 reads) are issued before the barrier that opens a phase.
   bool pa_done = false;   // the previous step's last phase already ran this step's phase A
+  // in-kernel moment matching: the pre-mm rows and the noise rows of step t - 1 are fetched during step t
+  // (one value per thread: R * D <= PF_NT) -- their HBM round trip used to open the step's first phase
+  // (not at four row tiles per wave: those instances are out of registers and the two values live across
+  //  the step cost more in spills than the round trip -- C4 adjoint 2.00 -> 2.06 ms when tried)
+  constexpr bool MMPF = VAR == PF_VAR_MM && RT <= 2 && (16 * RT) * (SH::D ? SH::D : 64) <= PF_NT;
+  float mmx_cur = 0.f, mmz_cur = 0.f;
+  bool mm_have = false;
   for (int t = T1 - 1; t >= T0; --t) {
     const size_t blk = (size_t)t * A.nwg + wg;
     int xsel = 0;           // X = bufA + xsel*R*LD (bufB directly follows bufA)
@@ -1940,11 +1947,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       const float* xsrc = A.xt + (size_t)t * B * D;
       float* const xrows = PM_XIN(Y);
       const int xrows_ld = PM_XLD;
-      for (int i = tid; i < R * D; i += PF_NT) {
-        const int r = i / D, d = i - r * D;
-        xrows[r * xrows_ld + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
-      }
-      {
+      if (MMPF && mm_have) {
+        if (tid < R * D) {
+          const int r = tid / D, d = tid - r * D;
+          xrows[r * xrows_ld + d] = mmx_cur;
+          if (r < nvalid) L.zs[tid] = mmz_cur;
+        }
+      } else {
+        for (int i = tid; i < R * D; i += PF_NT) {
+          const int r = i / D, d = i - r * D;
+          xrows[r * xrows_ld + d] = (r < nvalid) ? xsrc[(size_t)(row0 + r) * D + d] : 0.f;
+        }
         const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
         const int z0 = pm_zrow0(t, A.row_off + row0, A.flags);
         for (int i = tid; i < nvalid * D; i += PF_NT) {
@@ -1952,13 +1965,38 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
           L.zs[i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
         }
       }
-      __syncthreads();
+      if constexpr (MMPF) {
+        // step t - 1's rows: in flight until the next iteration
+        mm_have = t > T0;
+        mmx_cur = mmz_cur = 0.f;
+        if (mm_have && tid < R * D) {
+          const int r = tid / D, d = tid - r * D;
+          if (r < nvalid) {
+            mmx_cur = A.xt[((size_t)(t - 1) * B + row0 + r) * D + d];
+            const float* zb1 = pm_zbase(A.zmm, D, t - 1, A.Bg, A.flags);
+            mmz_cur = zb1[(size_t)pm_zidx(pm_zrow0(t - 1, A.row_off + row0, A.flags), r, A.Bg) * D + d];
+          }
+        }
+      }
       const int gpw = rows_per_wg / A.M;
+      // this wave's group: statistics and factor of the forward sweep into the scratch, in flight with the rows
+      constexpr bool MML = SH::D >= 1 && SH::D <= 6;
+      if (MML && wid < gpw && wid * A.M < nvalid) {
+        const double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + wid * A.M) / A.M) * pm_mm_fac_doubles(D);
+        double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
+        for (int e = lane; e < (int)pm_mm_fac_doubles(D); e += 64) scr[e] = fac[e];
+      }
+      __syncthreads();
       for (int gi = wid; gi < gpw; gi += PF_NW) {
         const int lr0 = gi * A.M;
         if (lr0 >= nvalid) break;
         double* scr = L.mm + (size_t)wid * pm_mm_scratch_doubles(D);
-        if constexpr (false) {
+        if constexpr (MML) {
+          pm_mm_bwd_l<SH::D ? SH::D : 1>(xrows + lr0 * xrows_ld, xrows_ld, A.M, L.zs + lr0 * D, D, gx + lr0 * D, D,
+                                         gxt + lr0 * D, D, scr, lane,
+                                         A.mmfac + ((size_t)t * A.mmfac_groups + (row0 + lr0) / A.M) * pm_mm_fac_doubles(D),
+                                         gi == wid && gi < PF_NW);
+        } else if constexpr (false) {
           // (the register form of the adjoint, pm_mm_bwd_w, was measured slower than the LDS form with the
           //  factor handed over from the forward sweep: 8.0 k vs 7.5 k cycles at d = 4 -- two Gram tiles and
           //  ~320 dependent fp64 operations on one wave; kept for reference in pmbrl_mm_w.h)

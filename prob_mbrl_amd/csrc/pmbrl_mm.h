@@ -308,6 +308,126 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
 }
 
 
+// The adjoint with a compile-time width (the shape-specialised sweep kernels) and the factor already in the
+// scratch (the caller copies pm_mm_fac_doubles values there while the group's rows are still on their way from
+// HBM: that load is a full memory round trip and used to open this routine).  Same mathematics and summation
+// order as pm_mm_bwd; what changes is where the serial part runs: the d lanes that do the two triangular
+// solves keep L, 1 / diag(L) and their own row / column in REGISTERS -- the LDS form pays an LDS round trip
+// for every one of the d (d + 1) / 2 dependent steps of a solve.
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_l(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                            const float* g, int g_ld, float* gout, int gout_ld, double* scr,
+                                            int lane, const double* fac, bool fac_in_scr) {
+  constexpr int d = DD;
+  const MMScratch q = pm_mm_carve(scr, d);
+  if (!fac_in_scr) {
+    for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) scr[e] = fac[e];
+    pm_wave_sync();
+  }
+  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
+  {
+    constexpr int e2 = DD <= 1 ? 1 : DD <= 2 ? 2 : DD <= 4 ? 4 : 8;
+    constexpr int P = 64 / e2;
+    const int part = lane % P, j = lane / P;
+    double a = 0.0;
+    if (j < d)
+      for (int r = part; r < M; r += P) a += (double)g[r * g_ld + j];
+    a = pm_seg_sum(a, P);
+    if (j < d && part == 0) q.mbar[j] = a;
+  }
+  {
+    constexpr int e2 = DD * DD <= 1 ? 1 : DD * DD <= 4 ? 4 : DD * DD <= 16 ? 16 : DD * DD <= 32 ? 32 : 64;
+    constexpr int P = 64 / e2;
+    const int part = lane % P, e = lane / P;
+    const int i = e / d, j = e - i * d;
+    const bool live = e < d * d && j <= i;
+    double acc = 0.0;
+    if (live) {
+      const double zm = q.zmean[j], zs = q.zistd[j];
+      for (int r = part; r < M; r += P) acc += (double)g[r * g_ld + i] * (((double)z[r * z_ld + j] - zm) * zs);
+    }
+    acc = pm_seg_sum(acc, P);
+    if (e < d * d && part == 0) q.P[e] = live ? acc : 0.0;
+  }
+  pm_wave_sync();
+  // L and 1 / diag(L) in registers (every lane: the loads are broadcasts, issued back to back)
+  double Lr[DD][DD], idg[DD];
+#pragma unroll
+  for (int i = 0; i < DD; ++i) {
+    idg[i] = q.invd[i];
+#pragma unroll
+    for (int j = 0; j <= i; ++j) Lr[i][j] = q.Lm[i * d + j];
+  }
+  // Phi = tril(L^T Lbar), diagonal halved: lane i builds ROW i, solves x L = phi_i in registers -> row i of X
+  if (lane < d) {
+    const int i = lane;
+    double lb[DD][DD];   // Lbar rows c >= i are needed: read the whole lower triangle (broadcast reads)
+#pragma unroll
+    for (int c = 0; c < DD; ++c)
+#pragma unroll
+      for (int j = 0; j <= c; ++j) lb[c][j] = q.P[c * d + j];
+    // column i of L below the diagonal (i = lane: selected by comparison, zero above): L[c][i], c >= i
+    double lci[DD];
+#pragma unroll
+    for (int c = 0; c < DD; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int ii = 0; ii <= c; ++ii) v = (ii == i) ? Lr[c][ii] : v;
+      lci[c] = v;
+    }
+    double x[DD];
+#pragma unroll
+    for (int j = 0; j < DD; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = j; c < DD; ++c) acc += lci[c] * lb[c][j];   // (terms with c < i are exact zeros)
+      if (j == i) acc *= 0.5;
+      x[j] = (j <= i) ? acc : 0.0;
+    }
+#pragma unroll
+    for (int j = DD - 1; j >= 0; --j) {
+      double a = x[j];
+#pragma unroll
+      for (int c = j + 1; c < DD; ++c) a -= x[c] * Lr[c][j];
+      x[j] = a * idg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < DD; ++j) q.Sb[i * d + j] = x[j];
+  }
+  pm_wave_sync();
+  // Sbar = L^-T X: lane j solves L^T y = x_j (COLUMN j of X) in registers
+  if (lane < d) {
+    const int j = lane;
+    double y[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) y[i] = q.Sb[i * d + j];
+#pragma unroll
+    for (int i = DD - 1; i >= 0; --i) {
+      double a = y[i];
+#pragma unroll
+      for (int c = i + 1; c < DD; ++c) a -= Lr[c][i] * y[c];
+      y[i] = a * idg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DD; ++i) q.Sb[i * d + j] = y[i];
+  }
+  pm_wave_sync();
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) * inv_m1;
+  }
+  pm_wave_sync();
+  for (int e = lane; e < M * d; e += 64) {
+    const int r = e / d, j = e - r * d;
+    double acc = q.mbar[j] * inv_m;
+#pragma unroll
+    for (int c = 0; c < DD; ++c) acc += ((double)s[r * s_ld + c] - q.mean[c]) * q.P[c * d + j];
+    gout[r * gout_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
+}
+
+
 // ===========================================================================
 // Compile-time-d variants (2d+1 <= 16) for the stand-alone moment-matching kernels (groups
 // larger than a workgroup's rows: the reference examples' default, one group over all
