@@ -8,6 +8,8 @@ import torch
 
 from tests import common
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _load():
     return np.load(os.path.join(common.GOLDEN, 'experience_host.npz'), allow_pickle=False)
@@ -140,3 +142,15 @@ def test_set_dataset_normalises_the_expanded_input():
     assert torch.allclose(dyn.mx, Xe.mean(0, keepdim=True))
     assert torch.allclose(dyn.iSx, (4.0 * Xe.std(0, keepdim=True)).reciprocal())
     assert d['dyn_mx'].shape[0] == D + U + len(ad)
+
+
+def test_prob_mbrl_import_alias():
+    """compat/prob_mbrl: reference scripts' `from prob_mbrl import utils, models, algorithms` without an edit."""
+    import subprocess
+    import sys
+    code = ('import sys; sys.path[:0] = [%r, %r]; '
+            'from prob_mbrl import utils, models, algorithms; import prob_mbrl.models as m; '
+            'import prob_mbrl_amd.models as a; assert m is a and hasattr(utils, "rollout") and '
+            'hasattr(algorithms, "mc_pilco") and hasattr(models, "DynamicsModel")'
+            % (os.path.join(ROOT, 'compat'), ROOT))
+    assert subprocess.run([sys.executable, '-c', code]).returncode == 0
