@@ -48,6 +48,10 @@ extern "C" {
 #define PMBRL_FLAG_DYN_MASKS_PER_STEP 128 /* the same for the dynamics model (resample_model=True, utils/rollout.py:110-115
                                             -> models/modules.py:134-139,155-157).  Either flag selects the general
                                             kernel family (the latency-optimised one keeps the masks in LDS for the launch) */
+#define PMBRL_FLAG_GMM_EXACT_NOISE_GRAD 256 /* mixture head: differentiate the noise term with the step's own noise
+                                   * (default: with the LAST step's, as the reference's autograd does -- its
+                                   * sampler swaps the storage of a saved tensor, models/densities.py:229-231) */
+#define PMBRL_MAX_COMP 8          /* mixture components of the dynamics head */
 #define PMBRL_FLAG_ZMM_PER_STEP 8 /* z_mm/z_rr are [H, B_global, .] fresh draws per step
                                      (utils/rollout.py:58-59, z=None) instead of the cyclic
                                      PEGASUS buffer of utils/rollout.py:53-57 */
@@ -128,6 +132,12 @@ typedef struct pmbrl_config {
   int32_t pol_angle_dims[PMBRL_MAX_ANGLE];
   int32_t n_dyn_angle;
   int32_t dyn_angle_dims[PMBRL_MAX_ANGLE];
+  /* GaussianMixtureDensity dynamics head (models/densities.py:151-259; examples/deep_pilco_mm.py:117-121):
+   * n components, dyn.dims[n_layers] = (2D + 1) n + 1 = [n D means | n D log-stds | n logits | log-temperature],
+   * means / log-stds indexed [d * n + c].  0 or 1: the DiagGaussianDensity head (dyn.dims[n_layers] = 2D).
+   * Needs z_pi_d and u_cat_d, and z_dyn_d as a per-step draw (z_dyn_step_stride = B * D: the reference redraws
+   * the Gaussian noise of this head at every step). */
+  int32_t dyn_components;
 } pmbrl_config;
 
 typedef struct pmbrl_plan pmbrl_plan;
@@ -183,6 +193,11 @@ typedef struct pmbrl_inputs {
   int64_t z_dyn_step_stride;
   const float* z_mm_d;        /* [>= B_global, D] or NULL  algorithms/mc_pilco.py:57-62 */
   const float* z_rr_d;        /* [>= B_global, 1] or NULL */
+  /* mixture head only (NULL otherwise) */
+  const float* z_pi_d;        /* [B, n] frozen Gumbel noise (models/densities.py:166-167,213-216) */
+  const float* u_cat_d;       /* [H, B] uniforms in [0, 1): the component of (t, b) is drawn by inverse CDF over the
+                                 tempered softmax (the reference draws it from torch's generator at every step,
+                                 models/densities.py:221-222) */
 } pmbrl_inputs;
 
 /* utils/rollout.py:62-163 (rollout) fused over all H steps, including

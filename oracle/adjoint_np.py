@@ -66,6 +66,7 @@ class Problem:
         self.dz = f('dyn_z')
         self.mx, self.iSx, self.my, self.Sy = (f('dyn_mx'), f('dyn_iSx'),
                                                f('dyn_my'), f('dyn_Sy'))
+        assert 'dyn_gmm_n' not in d or int(d['dyn_gmm_n']) <= 1, 'mixture head: torch oracle only'
         # angle_dims of Policy / the dynamics Regressor (models/core.py:233-234,173-174)
         self.pol_adims = [int(a) for a in np.asarray(d['pol_angle_dims'])]
         self.dyn_adims = [int(a) for a in np.asarray(d['dyn_angle_dims'])]

@@ -16,6 +16,6 @@ of include/pmbrl.h; there is no CPU or eager-torch fallback.
 """
 from . import models, rewards, utils, algorithms, envs  # noqa: F401
 from .models import (BDropout, BSequential, CDropout, DiagGaussianDensity, DynamicsModel,  # noqa: F401
-                     Policy, Regressor, mlp)
+                     GaussianMixtureDensity, Policy, Regressor, mlp)
 
 __all__ = ['models', 'rewards', 'utils', 'algorithms', 'envs']

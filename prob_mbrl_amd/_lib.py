@@ -18,6 +18,8 @@ FLAG_MM_STATES, FLAG_MM_REWARDS, FLAG_INFER_NS, FLAG_ZMM_PER_STEP = 1, 2, 4, 8
 FLAG_FORCE_GENERIC = 16
 FLAG_NO_SHAPED = 32
 FLAG_POL_MASKS_PER_STEP, FLAG_DYN_MASKS_PER_STEP = 64, 128
+FLAG_GMM_EXACT_NOISE_GRAD = 256
+MAX_COMP = 8
 REWARD_EXP, REWARD_NEG = 0, 1
 PREC_F32, PREC_SPLIT, PREC_SPLIT_F16 = 0, 1, 2
 INFO_COUNT = 16
@@ -58,7 +60,8 @@ class Config(C.Structure):
                 ('max_log_std_dyn', C.c_float), ('pol', MLP), ('dyn', MLP),
                 ('reward', Reward), ('rows_per_wg_hint', C.c_int32), ('precision', C.c_int32),
                 ('n_pol_angle', C.c_int32), ('pol_angle_dims', C.c_int32 * MAX_ANGLE),
-                ('n_dyn_angle', C.c_int32), ('dyn_angle_dims', C.c_int32 * MAX_ANGLE)]
+                ('n_dyn_angle', C.c_int32), ('dyn_angle_dims', C.c_int32 * MAX_ANGLE),
+                ('dyn_components', C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -70,7 +73,8 @@ class Inputs(C.Structure):
                 ('dyn_mask_bits', C.c_void_p * MAX_LAYERS),
                 ('z_pol', C.c_void_p), ('z_dyn', C.c_void_p),
                 ('z_pol_step_stride', C.c_int64), ('z_dyn_step_stride', C.c_int64),
-                ('z_mm', C.c_void_p), ('z_rr', C.c_void_p)]
+                ('z_mm', C.c_void_p), ('z_rr', C.c_void_p),
+                ('z_pi', C.c_void_p), ('u_cat', C.c_void_p)]
 
 
 EXPORTS = [

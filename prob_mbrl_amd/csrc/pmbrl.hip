@@ -26,7 +26,7 @@ int pm_fail(int code, const std::string& msg) {
 static int fail(int code, const std::string& msg) { return pm_fail(code, msg); }
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
-extern "C" int pmbrl_version(void) { return 2; }
+extern "C" int pmbrl_version(void) { return 3; }
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -468,7 +468,15 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   }
   const bool angles = c.n_pol_angle > 0 || c.n_dyn_angle > 0;
   int rc = net_plan(c.pol, p->pol, c.D + c.n_pol_angle, 2 * c.U, "policy");
-  if (rc == 0) rc = net_plan(c.dyn, p->dyn, c.D + c.U + c.n_dyn_angle, 2 * c.D, "dynamics");
+  const bool gmm = c.dyn_components > 1;
+  if (c.dyn_components < 0 || c.dyn_components > PMBRL_MAX_COMP) {
+    delete p;
+    return fail(-2, "dyn_components out of range (<= PMBRL_MAX_COMP)");
+  }
+  // (mixture head: n D means, n D log-stds, n logits, one log-temperature -- examples/deep_pilco_mm.py:117-121)
+  if (rc == 0)
+    rc = net_plan(c.dyn, p->dyn, c.D + c.U + c.n_dyn_angle, gmm ? (2 * c.D + 1) * c.dyn_components + 1 : 2 * c.D,
+                  "dynamics");
   if (rc) { delete p; return rc; }
 
   // LDS leading dimension: widest activation (any layer of either net), +8 so that
@@ -483,7 +491,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // infer_noise_variables (utils/rollout.py:6-17, not a default anywhere) lives in the general
   // single-wave moment-matching routines only: general kernel family, mm_mode 1 or 2
   p->fast = !(c.flags & (PMBRL_FLAG_FORCE_GENERIC | PMBRL_FLAG_INFER_NS | PMBRL_FLAG_POL_MASKS_PER_STEP |
-                         PMBRL_FLAG_DYN_MASKS_PER_STEP)) && !angles &&
+                         PMBRL_FLAG_DYN_MASKS_PER_STEP)) && !angles && !gmm &&
             pm_fast_net_ok(p->pol.dim, p->pol.nt, p->pol.nl) &&
             pm_fast_net_ok(p->dyn.dim, p->dyn.nt, p->dyn.nl);
   // general family on split operands (pmbrl_gsplit.h): two fp16 pieces forward / two bf16 pieces in the adjoint;
@@ -749,6 +757,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     }
     p->off_Tp = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_Td = take((size_t)c.H * c.B * c.D * sizeof(float));
+    p->off_gmm_c = take(gmm ? (size_t)c.H * c.B * (c.dyn_components + 1) * c.D * sizeof(float) : 0);
+    p->off_gmm_k = take(gmm ? (size_t)c.H * c.B * sizeof(int) : 0);
     p->off_xt = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_rt = take((size_t)c.H * c.B * sizeof(float));
     p->off_mmfac = take(p->mm_mode == 1 ? (size_t)c.H * (c.B / p->M) * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
@@ -925,6 +935,21 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   }
   A.Tp = reinterpret_cast<float*>(ws + p->off_Tp);
   A.Td = reinterpret_cast<float*>(ws + p->off_Td);
+  A.gmm_n = p->cfg.dyn_components > 1 ? p->cfg.dyn_components : 0;
+  A.zpi = A.ucat = A.zdyn_grad = nullptr;
+  A.gmm_k = nullptr;
+  A.gmm_c = nullptr;
+  if (A.gmm_n) {
+    if (!in->z_pi_d || !in->u_cat_d) return fail(-1, "mixture head: z_pi_d and u_cat_d are required");
+    if (in->z_dyn_step_stride == 0) return fail(-1, "mixture head: z_dyn_d must be a per-step draw [H, B, D]");
+    A.zpi = in->z_pi_d;
+    A.ucat = in->u_cat_d;
+    // the reference's autograd differentiates the noise term with the LAST step's noise at every step
+    if (!(p->cfg.flags & PMBRL_FLAG_GMM_EXACT_NOISE_GRAD))
+      A.zdyn_grad = in->z_dyn_d + (size_t)(p->cfg.H - 1) * in->z_dyn_step_stride;
+    A.gmm_c = reinterpret_cast<float*>(ws + p->off_gmm_c);
+    A.gmm_k = reinterpret_cast<int*>(ws + p->off_gmm_k);
+  }
   A.xt = reinterpret_cast<float*>(ws + p->off_xt);
   A.rt = reinterpret_cast<float*>(ws + p->off_rt);
   A.mmfac = reinterpret_cast<double*>(ws + p->off_mmfac);

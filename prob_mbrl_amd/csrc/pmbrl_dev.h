@@ -109,6 +109,14 @@ struct RolloutArgs {
   NetDev pol, dyn;
   const RewardDev* rew;
   const AngleDev* ang;   // angle_dims of the policy / the dynamics model (general family only); nullptr: none
+  // GaussianMixtureDensity dynamics head (general family only): components (0: diagonal Gaussian head), frozen
+  // Gumbel noise [B][n], uniforms [H][B], the Gaussian noise rows the derivative of the noise term uses (the last
+  // step's: the reference's autograd; nullptr: each step's own), and the stashes the adjoint consumes:
+  // component drawn [H][B], coefficients of dL/d(logits, log-temperature) [H][B][n + 1][D]
+  int gmm_n;
+  const float *zpi, *ucat, *zdyn_grad;
+  int* gmm_k;
+  float* gmm_c;
   const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn, *zmm, *zrr;
   float *states, *actions, *rewards;
   float* actT[PM_MAXL];   // policy layer inputs, feature-major blocks [H][nwg][nt*16][Rw]

@@ -44,7 +44,7 @@ struct pmbrl_plan {
   int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
-      off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, ws_bytes;
+      off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, off_gmm_c, off_gmm_k, ws_bytes;
   int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;

@@ -394,6 +394,72 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
                       wid, lane, tid);
     PM_MARK(20);
     // ---- sample next state (models/densities.py:97-121 with scaling_params, core.py:298)
+    if (A.gmm_n > 1) {
+      // GaussianMixtureDensity head (models/densities.py:173-233): head row = [n D means | n D log-stds | n logits |
+      // log-temperature]; straight-through one-hot component over the tempered Gumbel-softmax.  Every (row, d)
+      // thread redoes the row's softmax (n <= 8) and leaves what the adjoint needs: Td (d/d log-std of the drawn
+      // component) and the coefficients of dL/d(logits, log-temperature) -- both linear in dL/dx~_d.
+      const int n = A.gmm_n, nD = n * D;
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, d = i - r * D;
+        const float* o = Y + r * LD;
+        const bool valid = r < nvalid;
+        const size_t row = (size_t)t * B + row0 + r;
+        const float lt = o[2 * nD + n];
+        const float temp = 0.1f + softplusf(lt);
+        float lg[PMBRL_MAX_COMP], ks[PMBRL_MAX_COMP], sm[PMBRL_MAX_COMP];
+        float mxl = -3.0e38f;
+        for (int c = 0; c < n; ++c) { lg[c] = o[2 * nD + c] / temp; mxl = fmaxf(mxl, lg[c]); }
+        float se = 0.f;
+        for (int c = 0; c < n; ++c) se += expf(lg[c] - mxl);
+        const float lse = mxl + logf(se);
+        float mxy = -3.0e38f;
+        for (int c = 0; c < n; ++c) {
+          sm[c] = expf(lg[c] - lse);
+          ks[c] = ((lg[c] - lse) + (valid ? A.zpi[(size_t)(row0 + r) * n + c] : 0.f)) / 0.1f;
+          mxy = fmaxf(mxy, ks[c]);
+        }
+        float sy = 0.f;
+        for (int c = 0; c < n; ++c) { ks[c] = expf(ks[c] - mxy); sy += ks[c]; }
+        for (int c = 0; c < n; ++c) ks[c] /= sy;
+        // component: inverse CDF of the row's uniform
+        const float u = valid ? A.ucat[row] : 0.f;
+        int kc = 0;
+        float cum = ks[0];
+        while (kc < n - 1 && u >= cum) { ++kc; cum += ks[kc]; }
+        const float Sy = A.Sy[d], lSy = logf(Sy), myd = A.my[d];
+        const float z = valid ? A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d] : 0.f;
+        const float zg = (valid && A.zdyn_grad) ? A.zdyn_grad[(size_t)(row0 + r) * D + d] : z;
+        const float lsr_k = o[nD + d * n + kc];
+        const float E = expf(-softplusf(-lsr_k + A.mls_dyn) + A.mls_dyn + lSy);
+        const float xn = xa[i] + ((o[d * n + kc] * Sy + myd) + z * E);
+        xb[i] = xn;
+        if (valid) {
+          const size_t oo = row * D + d;
+          A.Td[oo] = zg * E * sigmoidf(-lsr_k + A.mls_dyn);
+          if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[oo] = xn;
+          else A.states[oo + (size_t)B * D] = xn;
+          // gk_c = g_d A_c,  A_c = mean_c + zg E lsc_c;  k_soft = softmax(y / 0.1);  y = log_softmax(logit) + z_pi
+          float Ac[PMBRL_MAX_COMP], abar = 0.f;
+          for (int c = 0; c < n; ++c) {
+            const float lsc = -softplusf(-o[nD + d * n + c] + A.mls_dyn) + A.mls_dyn + lSy;
+            Ac[c] = (o[d * n + c] * Sy + myd) + zg * E * lsc;
+            abar += ks[c] * Ac[c];
+          }
+          float scy = 0.f;
+          for (int c = 0; c < n; ++c) { Ac[c] = 10.f * ks[c] * (Ac[c] - abar); scy += Ac[c]; }
+          float ct = 0.f;
+          float* cp = A.gmm_c + row * (size_t)(n + 1) * D + d;
+          for (int c = 0; c < n; ++c) {
+            const float cl = Ac[c] - sm[c] * scy;          // d/d logit_c
+            cp[(size_t)c * D] = cl / temp;                 // d/d logit_pi_c (raw head output)
+            ct -= cl * o[2 * nD + c];
+          }
+          cp[(size_t)n * D] = ct * sigmoidf(lt) / (temp * temp);   // d/d log-temperature
+          if (d == 0) A.gmm_k[row] = kc;
+        }
+      }
+    } else
     for (int i = tid; i < R * D; i += PM_NT) {
       const int r = i / D, d = i - r * D;
       const float mu = Y[r * LD + d];
@@ -590,7 +656,19 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int r = i / K16, k = i - r * K16;
         float v = 0.f;
-        if (r < nvalid) {
+        if (r < nvalid && A.gmm_n > 1) {
+          // mixture head: only the drawn component's mean / log-std see the state gradient; logits and
+          // log-temperature through the coefficients the forward sweep left
+          const int n = A.gmm_n, nD = n * D;
+          const size_t row = (size_t)t * B + row0 + r;
+          if (k < 2 * nD) {
+            const int kk = k < nD ? k : k - nD, dd = kk / n, c = kk - dd * n;
+            if (c == A.gmm_k[row]) v = gxt[r * D + dd] * (k < nD ? A.Sy[dd] : A.Td[row * D + dd]);
+          } else if (k <= 2 * nD + n) {
+            const float* cp = A.gmm_c + (row * (size_t)(n + 1) + (k - 2 * nD)) * D;
+            for (int dd = 0; dd < D; ++dd) v = fmaf(gxt[r * D + dd], cp[dd], v);
+          }
+        } else if (r < nvalid) {
           if (k < D) v = gxt[r * D + k] * A.Sy[k];
           else if (k < 2 * D) v = gxt[r * D + k - D] * A.Td[((size_t)t * B + row0 + r) * D + k - D];
         }

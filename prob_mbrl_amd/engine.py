@@ -279,7 +279,8 @@ class Engine:
                  device=None, B_global=None, row_offset=0, rows_per_wg_hint=0,
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
                  force_generic=False, no_shaped=False, infer_ns=False, precision=None,
-                 pol_masks_per_step=False, dyn_masks_per_step=False, pol_angle_dims=(), dyn_angle_dims=()):
+                 pol_masks_per_step=False, dyn_masks_per_step=False, pol_angle_dims=(), dyn_angle_dims=(),
+                 dyn_components=0, gmm_exact_noise_grad=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -295,6 +296,7 @@ class Engine:
                      (_lib.FLAG_INFER_NS if infer_ns else 0) |
                      (_lib.FLAG_POL_MASKS_PER_STEP if pol_masks_per_step else 0) |
                      (_lib.FLAG_DYN_MASKS_PER_STEP if dyn_masks_per_step else 0) |
+                     (_lib.FLAG_GMM_EXACT_NOISE_GRAD if gmm_exact_noise_grad else 0) |
                      (_lib.FLAG_FORCE_GENERIC if force_generic else 0) |
                      (_lib.FLAG_NO_SHAPED if no_shaped else 0))
         cfg.mm_groups = int(mm_groups) if mm_groups else 0
@@ -320,6 +322,9 @@ class Engine:
         for i, a in enumerate(dyn_angle_dims):
             cfg.dyn_angle_dims[i] = a
         self.n_dyn_in = D + U + len(dyn_angle_dims)
+        # GaussianMixtureDensity dynamics head (models/densities.py:151-259): components (0 / 1: diagonal Gaussian)
+        self.n_comp = int(dyn_components) if dyn_components and int(dyn_components) > 1 else 0
+        cfg.dyn_components = self.n_comp
         self.cfg = cfg
         self.B, self.D, self.U, self.H = B, D, U, H
         self.n_pol_layers = len(pol_dims) - 1
@@ -365,7 +370,7 @@ class Engine:
 
     # ------------------------------------------------------------------
     def forward(self, x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias,
-                pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None, out=None):
+                pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None, out=None, z_pi=None, u_cat=None):
         """z_pol / z_dyn: [B,.] (frozen, the same at every step) or [H,B,.] (a fresh
         draw per step).  out: optional (states, actions, rewards) tensors to fill."""
         dev = self.device
@@ -415,8 +420,13 @@ class Engine:
         inp.z_pol_step_stride, inp.z_dyn_step_stride = zps, zds
         inp.z_mm = z_mm.data_ptr() if z_mm is not None else None
         inp.z_rr = z_rr.data_ptr() if z_rr is not None else None
+        if self.n_comp:   # mixture head: frozen Gumbel noise [B, n], uniforms of the component draws [H, B]
+            z_pi, u_cat = _f32c(z_pi, dev), _f32c(u_cat, dev)
+            assert z_pi.shape == (self.B, self.n_comp) and u_cat.shape == (self.H, self.B)
+            assert z_dyn.dim() == 3, 'mixture head: z_dyn is a per-step draw [H, B, D]'
+            inp.z_pi, inp.u_cat = z_pi.data_ptr(), u_cat.data_ptr()
         self._inputs = inp
-        self._keep = (t, z_mm, z_rr, list(pol_mask_bits), list(dyn_mask_bits))
+        self._keep = (t, z_mm, z_rr, list(pol_mask_bits), list(dyn_mask_bits), z_pi, u_cat)
         # `out`: the caller's tensors receive this rollout's trajectory and are what backward() reads;
         # they are NOT adopted as the engine's own buffers (engines are shared between callers by
         # shape: a later rollout must not write into tensors an earlier one handed out)

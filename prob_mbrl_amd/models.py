@@ -227,6 +227,63 @@ class DiagGaussianDensity(StochasticModule):
         return self.__class__.__name__ + '(output_dims=%d)' % self.output_dims
 
 
+class GaussianMixtureDensity(StochasticModule):
+    """Mixture-of-diagonal-Gaussians head (models/densities.py:151-259; examples/deep_pilco_mm.py:117-121): the
+    network emits [n D means | n D log-stds | n component logits | 1 log-temperature] (width (2 D + 1) n + 1); a
+    sample picks ONE component -- straight-through one-hot over the tempered Gumbel-softmax of the logits -- and
+    adds that component's Gaussian noise.  Offered as the dynamics model's `output_density` inside rollouts (the
+    sampling phase of the general kernel family and its adjoint: csrc/pmbrl_rollout.h); `log_prob` is the mixture
+    log-likelihood (torch ops, for callers that evaluate it themselves).
+
+    Random draws, as the reference makes them: `z_pi` (Gumbel noise, [B, n]) is frozen until `resample()` / a
+    shape change / resample_noise=True; the Gaussian noise is redrawn at EVERY step whatever resample_noise says
+    (the reference compares `mean[:-1].shape` with `z_pi.shape`, :228-231) and so is the component index
+    (`Categorical(k_soft).sample()`, :221-222).  On the device both per-step draws are explicit inputs of the
+    rollout: `z_normal` [H, B, D] and uniforms [H, B] for an inverse-CDF draw."""
+
+    def __init__(self, output_dims, n_components, max_noise_std=5.0):
+        super().__init__()
+        self.n_components = int(n_components)
+        self.output_dims = output_dims
+        self.register_buffer('z_normal', torch.ones([1, 1]))
+        self.register_buffer('z_pi', torch.ones([1, 1]))
+        self.register_buffer('max_log_std', torch.tensor(max_noise_std).log())
+        # True: differentiate the noise term with each step's own noise; False (default) reproduces the
+        # reference's gradient, whose autograd ends up using the LAST step's noise at every step (see
+        # oracle/ref_torch.py:gmm_sample)
+        self.exact_noise_grad = False
+
+    def resample(self, seed=None):
+        if seed is not None:
+            torch.manual_seed(int(seed))
+        u = torch.rand_like(self.z_pi)
+        self.z_pi.data = -(-u.log()).log()
+        self.z_normal.data = torch.randn_like(self.z_normal)
+
+    def frozen_gumbel(self, B, resample_noise):
+        """z_pi [B, n] with the reference's refresh rule (models/densities.py:213-216)."""
+        n = self.n_components
+        if tuple(self.z_pi.shape) != (B, n) or resample_noise:
+            u = torch.rand(B, n, device=self.z_pi.device, dtype=self.z_pi.dtype)
+            self.z_pi.data = -(-u.log()).log()
+        return self.z_pi
+
+    def log_prob(self, z, mean, log_std, logit_pi):
+        """models/densities.py:235-252: log sum_c pi_c N(z; mean_c, diag(std_c^2)), mean / log_std [B, D, n]."""
+        D = int(self.output_dims)
+        deltas = mean - z.unsqueeze(-1)
+        log_norm = -D * 0.5 * math.log(2 * math.pi) - log_std.sum(-2)
+        dists = -0.5 * ((deltas * (-log_std).exp())**2).sum(-2)
+        log_probs = torch.log_softmax(logit_pi, -1) + log_norm + dists
+        return torch.logsumexp(log_probs, dim=-1, keepdim=True)
+
+    def forward(self, x, **kwargs):
+        raise NotImplementedError('stand-alone density forward is not part of the accelerated path')
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(output_dims=%d, n_components=%d)' % (self.output_dims, self.n_components)
+
+
 # ---------------------------------------------------------------------------
 # containers
 # ---------------------------------------------------------------------------

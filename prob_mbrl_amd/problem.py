@@ -224,7 +224,8 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    no_shaped=no_shaped, infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False,
                    precision=precision, pol_masks_per_step=pol_ps, dyn_masks_per_step=dyn_ps,
                    pol_angle_dims=[int(a) for a in np.asarray(d.get('pol_angle_dims', []))],
-                   dyn_angle_dims=[int(a) for a in np.asarray(d.get('dyn_angle_dims', []))])
+                   dyn_angle_dims=[int(a) for a in np.asarray(d.get('dyn_angle_dims', []))],
+                   dyn_components=int(d['dyn_gmm_n']) if 'dyn_gmm_n' in d else 0)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
 
     def rows(m):
@@ -239,7 +240,11 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
         pol_scale=T(d['pol_scale']), pol_bias=T(d['pol_bias']),
         pol_mask_bits=[E.pack_mask(rows(d['pol_mask%d' % i])) for i in range(npl - 1)],
         dyn_mask_bits=[E.pack_mask(rows(d['dyn_mask%d' % i])) for i in range(ndl - 1)],
-        z_pol=T(d['pol_z'][lo:hi]), z_dyn=T(d['dyn_z'][lo:hi]),
+        z_pol=T(d['pol_z'][lo:hi]),
+        z_dyn=T(np.asarray(d['dyn_z'])[:, lo:hi] if np.asarray(d['dyn_z']).ndim == 3 else d['dyn_z'][lo:hi]),
         z_mm=T(d['z_mm']) if 'z_mm' in d and bool(d['mm_states']) else None,
         z_rr=T(d['z_rr']) if 'z_rr' in d and bool(d['mm_rewards']) else None)
+    if 'dyn_gmm_n' in d and int(d['dyn_gmm_n']) > 1:
+        # mixture head: frozen Gumbel noise and the uniforms of the per-step component draws ('dyn_ucat' [H, B])
+        args.update(z_pi=T(np.asarray(d['dyn_zpi'])[lo:hi]), u_cat=T(np.asarray(d['dyn_ucat'])[:, lo:hi]))
     return eng, args, (lo, hi)

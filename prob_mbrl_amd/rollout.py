@@ -101,12 +101,12 @@ def _reward_key(spec):
 def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
                mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
                max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None,
-               masks_per_step=(False, False), angle_dims=((), ())):
+               masks_per_step=(False, False), angle_dims=((), ()), gmm=(0, False)):
     precision = precision or E.get_precision()
     key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
            tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
            B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision, tuple(masks_per_step),
-           tuple(angle_dims[0]), tuple(angle_dims[1]))
+           tuple(angle_dims[0]), tuple(angle_dims[1]), tuple(gmm))
     eng = _ENGINES.get(key)
     if eng is None:
         if len(_ENGINES) > 16:
@@ -117,7 +117,8 @@ def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_stat
                        zmm_per_step=zmm_per_step, max_log_std_pol=max_log_std[0],
                        max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision,
                        pol_masks_per_step=masks_per_step[0], dyn_masks_per_step=masks_per_step[1],
-                       pol_angle_dims=angle_dims[0], dyn_angle_dims=angle_dims[1])
+                       pol_angle_dims=angle_dims[0], dyn_angle_dims=angle_dims[1],
+                       dyn_components=gmm[0], gmm_exact_noise_grad=gmm[1])
         _ENGINES[key] = eng
     return eng
 
@@ -136,10 +137,11 @@ class Bundle:
         plin, pdrop, pdens = policy.model.layer_spec()
         dlin, ddrop, ddens_inner = dynamics.model.layer_spec()
         ddens = dynamics.output_density
-        if not isinstance(pdens, M.DiagGaussianDensity) or not isinstance(ddens, M.DiagGaussianDensity) \
-                or ddens_inner is not None:
-            raise NotImplementedError('policy needs a DiagGaussianDensity output_nonlin and the '
-                                      'dynamics a DiagGaussianDensity output_density')
+        self.gmm = isinstance(ddens, M.GaussianMixtureDensity)
+        if not isinstance(pdens, M.DiagGaussianDensity) or ddens_inner is not None or \
+                not (isinstance(ddens, M.DiagGaussianDensity) or self.gmm):
+            raise NotImplementedError('policy needs a DiagGaussianDensity output_nonlin and the dynamics a '
+                                      'DiagGaussianDensity or GaussianMixtureDensity output_density')
         self.pol_flat, self.pol_params = flat_parameters(plin, policy.model)
         self.dyn_flat, _ = flat_parameters(dlin, dynamics.model)
         dev = self.pol_flat.device
@@ -156,7 +158,9 @@ class Bundle:
         self.D = self.pol_dims[0] - len(self.angle_dims[0])
         self.U = self.pol_dims[-1] // 2
         n_dyn_in = self.D + self.U + len(self.angle_dims[1])
-        if self.dyn_dims[0] != n_dyn_in or self.dyn_dims[-1] != 2 * self.D:
+        self.n_comp = ddens.n_components if self.gmm else 0
+        n_dyn_out = (2 * self.D + 1) * self.n_comp + 1 if self.gmm else 2 * self.D
+        if self.dyn_dims[0] != n_dyn_in or self.dyn_dims[-1] != n_dyn_out:
             raise NotImplementedError('dynamics must map [x|u] (%d inputs with its angle_dims) to 2*|x| outputs; '
                                       'a learned reward head is not offered' % n_dyn_in)
         if any(a >= self.D for a in self.angle_dims[1]):
@@ -201,7 +205,19 @@ class Bundle:
             pdens.z.data = self.z_pol[-1]
         else:
             self.z_pol = pdens.frozen_noise(B, False)
-        if resample_state_noise:
+        self.z_pi = self.u_cat = None
+        if self.gmm:
+            # mixture head (models/densities.py:213-231): frozen Gumbel noise; a component draw and new Gaussian
+            # noise at every step, whatever resample_state_noise says (the reference's own behaviour)
+            self.z_pi = ddens.frozen_gumbel(B, resample_state_noise)
+            forced = getattr(ddens, '_forced_draws', None)      # tests: replay recorded draws
+            if forced is not None:
+                self.z_dyn, self.u_cat = (f.to(device=dev, dtype=torch.float32).contiguous() for f in forced)
+            else:
+                self.z_dyn = torch.randn(H, B, self.D, device=dev)
+                self.u_cat = torch.rand(H, B, device=dev)
+            ddens.z_normal.data = self.z_dyn[-1]
+        elif resample_state_noise:
             self.z_dyn = torch.randn(H, B, self.D, device=dev)
             ddens.z.data = self.z_dyn[-1]
         else:
@@ -235,12 +251,14 @@ class Bundle:
                                  zmm_per_step=self.zmm_per_step, max_log_std=self.max_log_std,
                                  infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision,
                                  masks_per_step=(bool(resample_policy), bool(resample_model)),
-                                 angle_dims=self.angle_dims)
+                                 angle_dims=self.angle_dims,
+                                 gmm=(self.n_comp, bool(getattr(ddens, 'exact_noise_grad', False))))
 
     def forward(self, x0, out=None):
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
                                    self.Sy, self.scale, self.bias, self.pol_bits, self.dyn_bits,
-                                   self.z_pol, self.z_dyn, self.z_mm, self.z_rr, out=out)
+                                   self.z_pol, self.z_dyn, self.z_mm, self.z_rr, out=out, z_pi=self.z_pi,
+                                   u_cat=self.u_cat)
 
 
 class RolloutFunction(torch.autograd.Function):
@@ -320,7 +338,7 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
         n = bundle.engine.valid_steps()
         retry = E.safe_precision(bundle.engine.info['precision']) if n < steps else None
         if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None) \
-                or resample_model or resample_policy:
+                or resample_model or resample_policy or bundle.gmm:
             break          # (fresh noise was drawn: a retry would be a different rollout)
         # a failure under fp16 pieces may be their range, not the rollout: decide on the bf16 path
         precision = retry

@@ -25,7 +25,30 @@ def fixture_names(kind=None):
 
 def load(name):
     from oracle import ref_torch
-    return ref_torch.load_fixture(os.path.join(GOLDEN, name + '.npz'))
+    d = ref_torch.load_fixture(os.path.join(GOLDEN, name + '.npz'))
+    if 'dyn_gmm_n' in d and int(d['dyn_gmm_n']) > 1 and 'dyn_ucat' not in d:
+        d = dict(d)
+        d['dyn_ucat'] = gmm_uniforms(d)
+    return d
+
+
+def gmm_uniforms(d):
+    """Mixture head: the reference draws the component of every (step, row) from torch's generator and the fixture
+    records the INDEX; the device draws by inverse CDF from a uniform.  The uniforms that reproduce the recorded
+    indices: midpoints of the drawn component's CDF interval, the softmax taken from the fp64 oracle run."""
+    import torch
+    from oracle import ref_torch as R
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    dyn['k_soft_out'] = []
+    R.iteration(x0, pol, dyn, spec, meta['H'], gamma, meta['maximize'], meta['mm_states'], meta['mm_rewards'],
+                meta['mm_groups'], z_mm, z_rr, meta['infer_ns'])
+    ks = torch.stack(dyn['k_soft_out'][:meta['H']]).numpy()          # [H, B, n]
+    kidx = np.asarray(d['dyn_kidx'])
+    cdf = np.cumsum(ks, -1)
+    hi = np.take_along_axis(cdf, kidx[..., None], -1)[..., 0]
+    lo = hi - np.take_along_axis(ks, kidx[..., None], -1)[..., 0]
+    assert np.all(hi - lo > 1e-4), 'a drawn component has (almost) no probability: midpoint not robust'
+    return np.clip(0.5 * (lo + hi), 0.0, 1.0 - 1e-7).astype(np.float32)
 
 
 from prob_mbrl_amd.problem import engine_from_problem as engine_from_fixture  # noqa: E402,F401
@@ -52,7 +75,7 @@ def modules_from_fixture(d, name, device='cuda:0'):
     dyn_hid = [d['dyn_W%d' % i].shape[0] for i in range(ndl - 1)]
     pad = [int(a) for a in np.asarray(d['pol_angle_dims'])]
     dad = [int(a) for a in np.asarray(d['dyn_angle_dims'])]
-    if name.startswith('dcp') or name.startswith('angles_dcp'):
+    if name.startswith(('dcp', 'angles_dcp', 'gmm_d6')):
         rew = pm.rewards.DoubleCartpoleReward(pole1_length=torch.tensor(0.6),
                                               pole2_length=torch.tensor(0.6))
     elif name.startswith('pend'):
@@ -66,11 +89,14 @@ def modules_from_fixture(d, name, device='cuda:0'):
                                              torch.tensor(np.asarray(d['rew_R'], dtype=np.float32)))
     else:
         rew = pm.rewards.CartpoleReward(pole_length=torch.tensor(0.5))
+    n_comp = int(d['dyn_gmm_n']) if 'dyn_gmm_n' in d else 0
     dyn = pm.models.DynamicsModel(
-        pm.models.mlp(D + U + len(dad), 2 * D, dyn_hid,
+        pm.models.mlp(D + U + len(dad), (2 * D + 1) * n_comp + 1 if n_comp > 1 else 2 * D, dyn_hid,
                       dropout_layers=[pm.models.CDropout(0.1 * np.ones(h)) for h in dyn_hid],
                       nonlin=torch.nn.ReLU),
-        reward_func=rew, output_density=pm.models.DiagGaussianDensity(D), angle_dims=dad).float()
+        reward_func=rew, angle_dims=dad,
+        output_density=(pm.models.GaussianMixtureDensity(D, n_comp) if n_comp > 1
+                        else pm.models.DiagGaussianDensity(D))).float()
     maxU = np.asarray(d['pol_scale'], dtype=np.float32)
     pol = pm.models.Policy(
         pm.models.mlp(D + len(pad), 2 * U, pol_hid,
@@ -91,7 +117,11 @@ def modules_from_fixture(d, name, device='cuda:0'):
             dr.noise.data = torch.rand(B, dyn_hid[i])
             dr.concrete_noise = T(d['dyn_mask%d' % i])
         pol.model.fc_nonlin.z.data = T(d['pol_z'])
-        dyn.output_density.z.data = T(d['dyn_z'])
+        if n_comp > 1:    # mixture head: frozen Gumbel noise; the per-step draws are replayed (rollout.Bundle)
+            dyn.output_density.z_pi.data = T(d['dyn_zpi'])
+            dyn.output_density._forced_draws = (T(d['dyn_z']), T(d['dyn_ucat']))
+        else:
+            dyn.output_density.z.data = T(d['dyn_z'])
         for k in ('mx', 'iSx', 'my', 'Sy'):
             getattr(dyn, k).data = T(d['dyn_' + k]).reshape(1, -1)
         dyn.Sx.data = dyn.iSx.reciprocal()

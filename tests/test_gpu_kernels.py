@@ -120,7 +120,7 @@ def _run(d, dev, hint=0, generic=False, n_valid=None, precision=None):
 # (the C5 shape, infer_noise_variables, per-step dropout masks and angle_dims inside the networks exist in the
 # general family only)
 _PARITY_CASES = [(n, g) for n in common.fixture_names('iter') for g in (False, True)
-                 if g or not (n.startswith(('c5_', 'stepmask', 'angles_')) or 'infer_ns' in n)]
+                 if g or not (n.startswith(('c5_', 'stepmask', 'angles_', 'gmm_')) or 'infer_ns' in n)]
 
 
 @pytest.mark.parametrize('name,generic', _PARITY_CASES,

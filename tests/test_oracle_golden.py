@@ -41,7 +41,7 @@ def test_torch_oracle_matches_reference_fp64(name):
     assert common.rel(g.numpy(), d['ref64_grad']) < 1e-6
 
 
-@pytest.mark.parametrize('name', common.fixture_names('iter'))
+@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if not n.startswith('gmm_')])
 def test_explicit_adjoint_matches_reference_fp64(name):
     """The autograd-free forward/adjoint the HIP kernels implement."""
     d = common.load(name)

@@ -230,7 +230,10 @@ def capture_inputs(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
             d['dyn_mask%d' % i] = np.ones((x0.shape[0], lin[i].out_features))
             scales.append(1.0)
     d['dyn_keep'] = np.array(scales)
-    d['dyn_z'] = f(dyn.output_density.z)
+    if hasattr(dyn.output_density, 'z'):
+        d['dyn_z'] = f(dyn.output_density.z)
+    else:   # GaussianMixtureDensity: make_gmm_case fills in the per-step draws
+        d['dyn_z'] = np.zeros((x0.shape[0], D))
     for k in ['mx', 'iSx', 'my', 'Sy']:
         d['dyn_' + k] = f(getattr(dyn, k)).reshape(-1)
     d['dyn_angle_dims'] = dyn.angle_dims.numpy().astype(np.int64)
@@ -552,6 +555,115 @@ def make_trunc_case(name, D=4, U=1, hid=(32, 32), B=30, H=12, fail_step=8, seed=
     print('   valid steps %d of %d, loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' % (
         fail_step, H, r32['loss'], r64['loss'],
         np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])))
+    return d
+
+
+def make_gmm_case(name, D=4, U=1, hid=(32, 32), n_comp=3, B=30, H=10, seed=31, mm_groups=None, rew_fn=None):
+    """Dynamics model with a GaussianMixtureDensity head (models/densities.py:151-259; examples/deep_pilco_mm.py:
+    117-121: output width (2D + 1) n + 1).  Its sampler draws the component index from torch's generator at
+    every step (Categorical(k_soft).sample(), :221-222) and -- because it compares mean[:-1].shape with
+    z_pi.shape (:228-231) -- new Gaussian noise at every step whatever resample_noise says; only the Gumbel noise
+    z_pi stays frozen.  Both per-step draws are recorded in call order and replayed for the fp64 run."""
+    print('[gmm] %s' % name)
+    rew = (rew_fn or _cartpole)()
+    mm = mm_groups is not None
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dynE = (2 * D + 1) * n_comp + 1
+    dyn_model = models.mlp(D + U, dynE, list(hid),
+                           dropout_layers=[models.modules.CDropout(0.1 * np.ones(h)) for h in hid],
+                           nonlin=torch.nn.ReLU)
+    dyn = models.DynamicsModel(dyn_model, reward_func=rew,
+                               output_density=models.GaussianMixtureDensity(D, n_comp)).float()
+    from functools import partial
+    pol_model = models.mlp(D, 2 * U, list(hid), dropout_layers=[models.modules.BDropout(0.1) for h in hid],
+                           nonlin=torch.nn.ReLU, output_nonlin=partial(models.DiagGaussianDensity, U))
+    maxU_t = np.asarray(10.0, dtype=np.float32).reshape(-1)
+    pol = models.Policy(pol_model, maxU_t, -maxU_t).float()
+    dyn.set_dataset(torch.randn(300, D + U), 0.01 * torch.randn(300, D))
+    # a head that actually mixes: spread the component logits and the means
+    last = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)][-1]
+    with torch.no_grad():
+        last.bias.add_(0.5 * torch.randn_like(last.bias))
+    dyn.eval()
+    pol.train()
+    torch.manual_seed(seed + 1000)
+    x0 = 0.1 * torch.randn(B, D)
+    gamma = [1.0 / H] * H
+    with torch.no_grad():   # sizes the noise buffers (z_pi is drawn here and then frozen)
+        utils.rollout(x0, dyn, pol, 1, resample_state_noise=False, resample_action_noise=False)
+    seed_t = torch.tensor([seed + 77])
+    dyn.model.resample(seed=seed_t)
+    pol.resample(seed=seed_t)
+    torch.manual_seed(seed + 5)
+    pol.model.fc_nonlin.z.data = torch.randn_like(pol.model.fc_nonlin.z)
+    z_mm = torch.randn(H + B, D) if mm else None
+    z_rr = torch.randn(H + B, 1) if mm else None
+    d = capture_inputs(dyn, pol, x0, H, gamma, mm, mm, mm_groups, z_mm, z_rr, True, False, rew)
+    d['dyn_zpi'] = dyn.output_density.z_pi.detach().double().numpy()
+    d['dyn_gmm_n'] = n_comp
+    rec_k, rec_z = [], []
+    Cat = torch.distributions.Categorical
+    orig_sample, orig_randn = Cat.sample, torch.randn
+
+    def run(dt, replay=None):
+        pol.zero_grad()
+        dyn.zero_grad()
+        it_k = iter(replay[0]) if replay else None
+        it_z = iter(replay[1]) if replay else None
+
+        def sample(self, *a, **k):
+            if it_k is not None:
+                return next(it_k)
+            out = orig_sample(self, *a, **k)
+            rec_k.append(out.detach().clone())
+            return out
+
+        def randn(*a, **k):
+            if it_z is not None:
+                return next(it_z)
+            out = orig_randn(*a, **k)
+            rec_z.append(out.detach().clone())
+            return out
+
+        Cat.sample, torch.randn = sample, randn
+        try:
+            states, actions, rewards = utils.rollout(
+                x0.to(dt), dyn, pol, H, resample_state_noise=False, resample_action_noise=False, mm_states=mm,
+                mm_rewards=mm, mm_groups=mm_groups, z_mm=None if z_mm is None else z_mm.to(dt),
+                z_rr=None if z_rr is None else z_rr.to(dt))
+        finally:
+            Cat.sample, torch.randn = orig_sample, orig_randn
+        disc = torch.stack([r * gamma[i] for i, r in enumerate(rewards)])
+        loss = (-disc.sum(0)).mean()
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in pol.parameters()])
+        return dict(states=torch.stack(states).detach().numpy(), actions=torch.stack(actions).detach().numpy(),
+                    rewards=torch.stack(rewards).detach().numpy(), loss=float(loss), grad=g.detach().numpy().copy())
+
+    torch.manual_seed(seed + 9)
+    r32 = run(torch.float32)
+    # per step three torch.randn calls: utils/rollout.py:96-97 (z1, z2: unused without moment matching), then the
+    # density's z_normal
+    per = 1 if mm else 3
+    assert len(rec_k) == H and len(rec_z) == per * H, (len(rec_k), len(rec_z))
+    zn = rec_z[per - 1::per]
+    assert all(z.shape == (B, D) for z in zn)
+    assert torch.equal(dyn.output_density.z_pi.double(), torch.tensor(d['dyn_zpi'])), 'z_pi was redrawn'
+    d['dyn_kidx'] = torch.stack(rec_k).numpy().astype(np.int64)          # [H, B]
+    d['dyn_z'] = torch.stack(zn).double().numpy()                        # [H, B, D]
+    assert d['dyn_z'].shape == (H, B, D) and d['dyn_kidx'].shape == (H, B)
+    print('   components drawn: %s' % np.bincount(d['dyn_kidx'].reshape(-1), minlength=n_comp))
+    dyn.double()
+    pol.double()
+    rew.double()
+    r64 = run(torch.float64, replay=(list(rec_k), list(rec_z)))
+    for k, v in r32.items():
+        d['ref32_' + k] = np.asarray(v, dtype=np.float32)
+    for k, v in r64.items():
+        d['ref64_' + k] = np.asarray(v, dtype=np.float64)
+    gerr = np.linalg.norm(r32['grad'] - r64['grad']) / np.linalg.norm(r64['grad'])
+    print('%-22s B=%d H=%d loss32=%.7f loss64=%.7f |g32-g64|/|g64|=%.2e' % (name, B, H, r32['loss'], r64['loss'], gerr))
     return d
 
 
@@ -1041,6 +1153,9 @@ CASES = {
                                         pol_angle_dims=[2, 4], dyn_angle_dims=[4]),
     'angles_full200': lambda: make_case('angles_full200', 4, 1, [200, 200], [200, 200], _cartpole, 10.0, 50, 10,
                                         seed=26, x0_scale=0.5, pol_angle_dims=[2], dyn_angle_dims=[]),
+    'gmm_d4': lambda: make_gmm_case('gmm_d4'),
+    'gmm_d6_mmg': lambda: make_gmm_case('gmm_d6_mmg', D=6, hid=(40, 24), n_comp=2, B=36, H=8, seed=33, mm_groups=3,
+                                        rew_fn=_dcartpole),
     'trunc_mm': lambda: make_trunc_case('trunc_mm'),
     'stepmask_d4': lambda: make_resample_case('stepmask_d4'),
     'standalone_fwd': lambda: make_standalone_case('standalone_fwd', 4, 1, [32, 32], [32, 32], _cartpole, 10.0, 37),
