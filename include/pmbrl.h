@@ -377,7 +377,12 @@ typedef struct {
   int32_t loss_kind;                     /* 0: Gaussian negative log-likelihood (losses.py:16-37);
                                           * 1: mean squared error of the mean head against the targets
                                           *    (the critic fit of examples/deep_pilco_no_mm_with_value.py:40-44;
-                                          *    the log-std half of the head is ignored) */
+                                          *    the log-std half of the head is ignored);
+                                          * 2: negative log-likelihood of a mixture of diagonal Gaussians
+                                          *    (losses.py:40-64 over models/densities.py:173-207,
+                                          *    return_samples=False): net.dims[n_layers] =
+                                          *    (2 n_out + 1) n_components + 1, see pmbrl_config.dyn_components */
+  int32_t n_components;                  /* loss_kind 2 only */
 } pmbrl_bnn_config;
 typedef struct pmbrl_bnn_plan pmbrl_bnn_plan;
 

@@ -14,8 +14,8 @@ the call surface of mcgillmrl/prob_mbrl:
 The arithmetic runs in hand-written HIP kernels (prob_mbrl_amd/csrc) behind the C ABI
 of include/pmbrl.h; there is no CPU or eager-torch fallback.
 """
-from . import models, rewards, utils, algorithms, envs  # noqa: F401
+from . import models, rewards, utils, algorithms, envs, losses  # noqa: F401
 from .models import (BDropout, BSequential, CDropout, DiagGaussianDensity, DynamicsModel,  # noqa: F401
                      GaussianMixtureDensity, Policy, Regressor, mlp)
 
-__all__ = ['models', 'rewards', 'utils', 'algorithms', 'envs']
+__all__ = ['models', 'rewards', 'utils', 'algorithms', 'envs', 'losses']

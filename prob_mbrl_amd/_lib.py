@@ -40,7 +40,8 @@ class MlpCall(C.Structure):
 class BnnConfig(C.Structure):
     _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('net', MLP), ('max_log_std', C.c_float),
                 ('temperature', C.c_float * MAX_LAYERS), ('reg_scale', C.c_float * MAX_LAYERS),
-                ('drop_reg', C.c_float * MAX_LAYERS), ('reg_weight', C.c_float), ('loss_kind', C.c_int32)]
+                ('drop_reg', C.c_float * MAX_LAYERS), ('reg_weight', C.c_float), ('loss_kind', C.c_int32),
+                ('n_components', C.c_int32)]
 
 
 class Reward(C.Structure):

@@ -1412,7 +1412,12 @@ extern "C" int pmbrl_bnn_plan_create(const pmbrl_bnn_config* cfg, int device, pm
   const pmbrl_mlp& m = cfg->net;
   if (m.n_layers < 2 || m.n_layers > PM_MAXL) return fail(-2, "bnn: 2..8 layers");
   if (cfg->M < 1 || cfg->N < 1) return fail(-2, "bnn: M, N must be >= 1");
-  if (m.dims[m.n_layers] % 2) return fail(-2, "bnn: the output layer must be 2 x n_out wide");
+  if (cfg->loss_kind == 2) {
+    const int n = cfg->n_components;
+    if (n < 2 || n > PMBRL_MAX_COMP) return fail(-2, "bnn: mixture loss needs 2..PMBRL_MAX_COMP components");
+    if ((m.dims[m.n_layers] - 1) % n || ((m.dims[m.n_layers] - 1) / n - 1) % 2 || (m.dims[m.n_layers] - 1) / n < 3)
+      return fail(-2, "bnn: mixture head must be (2 n_out + 1) n_components + 1 wide");
+  } else if (m.dims[m.n_layers] % 2) return fail(-2, "bnn: the output layer must be 2 x n_out wide");
   pmbrl_bnn_plan* p = new pmbrl_bnn_plan();
   p->cfg = *cfg;
   p->device = device;
@@ -1504,6 +1509,11 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
   BnnArgs A;
   memset(&A, 0, sizeof(A));
   A.M = p->cfg.M; A.nl = p->nl; A.LD = p->LD; A.n_out = p->dim[p->nl] / 2; A.nwg = p->nwg;
+  A.gmm_n = 0;
+  if (p->cfg.loss_kind == 2) {
+    A.gmm_n = p->cfg.n_components;
+    A.n_out = ((p->dim[p->nl] - 1) / A.gmm_n - 1) / 2;
+  }
   A.n_in = p->dim[0]; A.sum_h = p->sum_h;
   for (int i = 0; i <= p->nl; ++i) { A.dim[i] = p->dim[i]; A.nt[i] = p->nt[i]; }
   for (int l = 0; l < p->nl; ++l) {

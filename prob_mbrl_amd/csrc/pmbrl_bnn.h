@@ -30,6 +30,7 @@ struct BnnArgs {
   const int* idx;                  // [M] minibatch rows
   float mls, inv_M;
   int mse;                         // loss: mean squared error of the mean head instead of the Gaussian NLL
+  int gmm_n;                       // > 1: mixture-of-Gaussians NLL, head = [n D means | n D log-stds | n logits | log-T]
   const float* row_w;              // [M] per-row weight of the log-likelihood (importance sampling) or nullptr
   float* row_lp;                   // [M] out: per-row log-likelihood (unweighted) or nullptr
   float* actT[PM_MAXL];            // stash: input of layer l   [wg][nt[l]*16][16]
@@ -145,6 +146,83 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
   }
   gemm_narrow<1>(A.wf[nl - 1], A.nt[nl], A.nt[nl - 1], A.bias[nl - 1], H + (size_t)(nl - 1) * R * LD, G1, LD, part,
                  wid, lane, tid);
+  // ---- mixture negative log-likelihood (losses.py:40-64; head parametrisation models/densities.py:173-207):
+  //      ll = logsumexp_c [log_softmax(logit / T)_c - sum_d lsc_dc - D/2 log 2 pi - 1/2 sum_d t_dc^2]
+  if (A.gmm_n > 1) {
+    const int n = A.gmm_n, D = A.n_out, nD = n * D, W16 = A.nt[nl] * 16;
+    float* gst = A.gT[nl - 1] + (size_t)wg * W16 * 16;
+    __shared__ float s_resp[16][PMBRL_MAX_COMP], s_sm[16][PMBRL_MAX_COMP], s_temp[16], s_ll[16];
+    // responsibilities: one thread per row (n <= 8, D <= 64: a few hundred flops)
+    if (tid < R) {
+      const int r = tid;
+      float ll = 0.f;
+      if (r < nvalid) {
+        const float* o = G1 + r * LD;
+        const float* y = A.Y + (size_t)A.idx[row0 + r] * D;
+        const float temp = 0.1f + softplusf(o[2 * nD + n]);
+        float lg[PMBRL_MAX_COMP], lp[PMBRL_MAX_COMP], mx = -3.0e38f;
+        for (int c = 0; c < n; ++c) { lg[c] = o[2 * nD + c] / temp; mx = fmaxf(mx, lg[c]); }
+        float se = 0.f;
+        for (int c = 0; c < n; ++c) se += expf(lg[c] - mx);
+        const float lse = mx + logf(se);
+        float mxp = -3.0e38f;
+        for (int c = 0; c < n; ++c) {
+          float sls = 0.f, sq = 0.f;
+          for (int d = 0; d < D; ++d) {
+            const float lsc = -softplusf(-o[nD + d * n + c] + A.mls) + A.mls;
+            const float t = (o[d * n + c] - y[d]) * expf(-lsc);
+            sls += lsc;
+            sq = fmaf(t, t, sq);
+          }
+          lp[c] = (lg[c] - lse) + (-(float)D * 0.9189385332046727f - sls) - 0.5f * sq;
+          s_sm[r][c] = expf(lg[c] - lse);
+          mxp = fmaxf(mxp, lp[c]);
+        }
+        float sp = 0.f;
+        for (int c = 0; c < n; ++c) sp += expf(lp[c] - mxp);
+        ll = mxp + logf(sp);
+        for (int c = 0; c < n; ++c) s_resp[r][c] = expf(lp[c] - ll);
+        s_temp[r] = temp;
+      }
+      s_ll[r] = ll;
+    }
+    __syncthreads();
+    float lsum = 0.f;
+    for (int i = tid; i < R * W16; i += PM_NT) {
+      const int r = i / W16, j = i - r * W16;
+      float gval = 0.f;
+      if (r < nvalid && j <= 2 * nD + n) {
+        const float* o = G1 + r * LD;
+        const float rw = (A.row_w ? A.row_w[row0 + r] : 1.f) * A.inv_M;
+        if (j < 2 * nD) {
+          const int jj = j < nD ? j : j - nD, d = jj / n, c = jj - d * n;
+          const float ls = o[nD + jj];
+          const float lsc = -softplusf(-ls + A.mls) + A.mls;
+          const float sd = expf(-lsc);
+          const float t = (o[jj] - A.Y[(size_t)A.idx[row0 + r] * D + d]) * sd;
+          gval = j < nD ? rw * s_resp[r][c] * t * sd : rw * s_resp[r][c] * (1.f - t * t) * sigmoidf(A.mls - ls);
+        } else if (j < 2 * nD + n) {
+          const int c = j - 2 * nD;
+          gval = -rw * (s_resp[r][c] - s_sm[r][c]) / s_temp[r];
+        } else {
+          float a = 0.f;
+          for (int c = 0; c < n; ++c) a += (s_resp[r][c] - s_sm[r][c]) * o[2 * nD + c];
+          gval = rw * a * sigmoidf(o[2 * nD + n]) / (s_temp[r] * s_temp[r]);
+        }
+        if (j == 0) lsum -= (A.row_w ? A.row_w[row0 + r] : 1.f) * s_ll[r];
+      }
+      G0[r * LD + j] = gval;
+      gst[(size_t)j * 16 + r] = gval;
+    }
+    red[tid] = lsum;
+    __syncthreads();
+    for (int o = PM_NT / 2; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) A.part_loss[wg] = red[0];
+    if (A.row_lp && tid < nvalid) A.row_lp[row0 + tid] = s_ll[tid];
+  } else
   // ---- Gaussian negative log-likelihood and its gradient wrt the head outputs
   {
     const int n = A.n_out;

@@ -184,7 +184,7 @@ class BnnStep:
     W0, b0, [logit_p0], W1, b1, [logit_p1], ..., W_L, b_L."""
 
     def __init__(self, dims, temperature, reg_scale, drop_reg, M, N, reg_weight=1.0,
-                 max_log_std=LOG_MAX_STD, device=None, loss_kind='nll'):
+                 max_log_std=LOG_MAX_STD, device=None, loss_kind='nll', n_components=0):
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else 'cuda:0')
         cfg = _lib.BnnConfig()
@@ -199,7 +199,9 @@ class BnnStep:
             cfg.drop_reg[l] = float(drop_reg[l])
         cfg.max_log_std = float(max_log_std)
         cfg.reg_weight = float(reg_weight)
-        cfg.loss_kind = {'nll': 0, 'mse': 1}[loss_kind]
+        # 'gmm': mixture-of-Gaussians NLL (losses.py:40-64), head (2 n_out + 1) n_components + 1 wide
+        cfg.loss_kind = {'nll': 0, 'mse': 1, 'gmm': 2}[loss_kind]
+        cfg.n_components = int(n_components) if loss_kind == 'gmm' else 0
         self.M, self.N, self.dims = int(M), int(N), list(dims)
         self.drop_widths = [dims[l + 1] for l in range(nl - 1) if cfg.temperature[l] > 0]
         self.sum_h = sum(self.drop_widths)

@@ -268,6 +268,28 @@ class GaussianMixtureDensity(StochasticModule):
             self.z_pi.data = -(-u.log()).log()
         return self.z_pi
 
+    def from_head(self, x, my=None, Sy=None, return_samples=False, resample_noise=True, sampling_temperature=0.1):
+        """models/densities.py:173-233 on the raw head rows x [B, (2 D + 1) n + 1]: (mean, log_std, logit_pi) with
+        mean / log_std [B, D, n], or samples [B, D]."""
+        D, n = int(self.output_dims), self.n_components
+        nD = D * n
+        mean, log_std, extras = x[:, :nD], x[:, nD:2 * nD], x[:, 2 * nD:]
+        logit_pi, log_temperature = extras[:, :n], extras[:, n:]
+        log_std = -torch.nn.functional.softplus(-log_std + self.max_log_std) + self.max_log_std
+        mean, log_std = mean.reshape(-1, D, n), log_std.reshape(-1, D, n)
+        logit_pi = logit_pi / (1e-1 + torch.nn.functional.softplus(log_temperature))
+        if my is not None and Sy is not None:
+            log_std = log_std + Sy.reshape(1, D, 1).log()
+            mean = mean * Sy.reshape(1, D, 1) + my.reshape(1, D, 1)
+        if not return_samples:
+            return mean, log_std, logit_pi
+        z1 = self.frozen_gumbel(x.shape[0], resample_noise)
+        k_soft = ((torch.log_softmax(logit_pi, -1) + z1) / sampling_temperature).softmax(-1)
+        k_idx = torch.distributions.Categorical(k_soft).sample().view(-1, 1)
+        k = torch.zeros_like(k_soft).scatter(1, k_idx, 1)[:, None, :]
+        self.z_normal.data = torch.randn(x.shape[0], D, device=x.device, dtype=x.dtype)   # (:228-231: every call)
+        return (mean * k).sum(-1) + self.z_normal * (log_std * k).sum(-1).exp()
+
     def log_prob(self, z, mean, log_std, logit_pi):
         """models/densities.py:235-252: log sum_c pi_c N(z; mean_c, diag(std_c^2)), mean / log_std [B, D, n]."""
         D = int(self.output_dims)
@@ -338,7 +360,8 @@ class BSequential(nn.Sequential):
         B = x.shape[0]
         dims = [linears[0].in_features] + [l.out_features for l in linears]
         flat, _ = flat_parameters(linears, self)
-        plain = density is None
+        mixture = isinstance(density, GaussianMixtureDensity)
+        plain = density is None or mixture
         if plain:
             # a network without an output density (the critic of
             # examples/deep_pilco_no_mm_with_value.py:269-278; models/core.py:185-186:
@@ -358,6 +381,12 @@ class BSequential(nn.Sequential):
                 m = dr.forward_mask(B, lin.out_features, resample=resample, seed=seed)
                 keep.append(dr.keep_prob())
                 bits.append(E.pack_mask(m.to(device=x.device, dtype=torch.float32)))
+        if mixture:
+            # the network on the device (raw head rows), the few head formulas of the mixture with torch ops on
+            # those rows (stand-alone evaluation is not the hot path; rollouts and training are fused kernels)
+            o = E.mlp_forward(x, flat, dims, keep, bits, None, in_shift, in_iscale, None, None, want=('mean',))['mean']
+            return density.from_head(o, out_shift, out_scale, return_samples=return_samples,
+                                     resample_noise=resample_noise)
         if plain:
             return E.mlp_forward(x, flat, dims, keep, bits, None, in_shift, in_iscale, out_scale,
                                  out_shift, want=('mean',))['mean']

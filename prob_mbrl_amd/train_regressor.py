@@ -78,6 +78,15 @@ def _is_diag_gaussian_ll(fn):
     return isinstance(getattr(fn, '__self__', None), DiagGaussianDensity) and fn.__name__ == 'log_prob'
 
 
+def _is_mixture_ll(fn):
+    """losses.gaussian_mixture_log_likelihood, or the bound GaussianMixtureDensity.log_prob (same formula,
+    losses.py:40-64 / models/densities.py:235-252)."""
+    if getattr(fn, '__name__', '') == 'gaussian_mixture_log_likelihood':
+        return True
+    from .models import GaussianMixtureDensity
+    return isinstance(getattr(fn, '__self__', None), GaussianMixtureDensity) and fn.__name__ == 'log_prob'
+
+
 def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=None, log_likelihood=None,
                     reg_weight=1.0, pbar_class=None, summary_writer=None, summary_scope='',
                     decoupled_reg=False, prioritized_sampling=False, priority_eps=1e-3, priority_alpha=0.6,
@@ -86,8 +95,15 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
     plain torch.optim.Adam; decoupled_reg (the regulariser's gradient applied by a separate plain
     SGD step, :133-147) and prioritized_sampling (minibatches from a per-model SumTree with
     importance weights, priorities from the rows' log-likelihoods, :88-131)."""
-    if not _is_diag_gaussian_ll(log_likelihood):
-        raise NotImplementedError('only the diagonal-Gaussian log-likelihood is offered on the device path')
+    from .models import GaussianMixtureDensity
+    mixture = isinstance(getattr(model, 'output_density', None), GaussianMixtureDensity)
+    if mixture:
+        if not _is_mixture_ll(log_likelihood):
+            raise NotImplementedError('a GaussianMixtureDensity head is trained with '
+                                      'losses.gaussian_mixture_log_likelihood (pass it as log_likelihood)')
+    elif not _is_diag_gaussian_ll(log_likelihood):
+        raise NotImplementedError('the diagonal-Gaussian and the Gaussian-mixture log-likelihoods are offered on '
+                                  'the device path')
     model.train()
     dev = model.mx.device
     if dev.type != 'cuda':
@@ -169,7 +185,9 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
         st = steps.get(M)
         if st is None:
             st = steps[M] = E.BnnStep(dims, temps, rscale, dreg, M, N, reg_weight,
-                                      max_log_std=float(density.max_log_std), device=dev)
+                                      max_log_std=float(density.max_log_std), device=dev,
+                                      loss_kind='gmm' if mixture else 'nll',
+                                      n_components=density.n_components if mixture else 0)
         idx = device_indices(idx_np)
         if _replay is not None:     # tests: the reference's recorded draws of this step
             f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).reshape(-1)  # noqa: E731

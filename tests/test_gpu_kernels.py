@@ -329,8 +329,9 @@ def test_bnn_training_matches_reference(name):
     rs = [float(d['reg_scale%d' % l]) for l in range(nl - 1)]
     dr = [float(d['drop_reg%d' % l]) for l in range(nl - 1)]
     M, N = int(d['M']), int(d['N'])
+    n_comp = int(d['n_components']) if 'n_components' in d else 0      # > 1: mixture-of-Gaussians head + NLL
     step = E.BnnStep(dims, temps, rs, dr, M, N, float(d['reg_weight']), max_log_std=float(d['max_log_std']),
-                     device=dev)
+                     device=dev, loss_kind='gmm' if n_comp > 1 else 'nll', n_components=n_comp)
     assert step.n_params == flat.numel()
     Xn, Yn = T(d['Xn']), T(d['Yn'])
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)

@@ -768,19 +768,27 @@ def make_standalone_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, seed=11)
     return d
 
 
-def make_bnn_case(name, D, U, dyn_hid, N, M, iters, lr, seed=21, reg_weight=1.0):
+def make_bnn_case(name, D, U, dyn_hid, N, M, iters, lr, seed=21, reg_weight=1.0, n_comp=0):
     """BNN maximum-likelihood training of the dynamics model: the body of utils.train_regressor
     (utils/train_regressor.py:58-165) run for a few iterations with Adam, with the random draws
     of the concrete-dropout layers (uniform noise and Bernoulli samples) recorded."""
     print('[bnn] %s' % name)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    from prob_mbrl.losses import gaussian_log_likelihood
-    dyn_model = models.mlp(D + U, 2 * D, dyn_hid,
+    from prob_mbrl.losses import gaussian_log_likelihood, gaussian_mixture_log_likelihood
+    # n_comp > 1: GaussianMixtureDensity head and the mixture log-likelihood (examples/deep_pilco_mm.py:117-121,
+    # losses.py:40-64)
+    dyn_model = models.mlp(D + U, (2 * D + 1) * n_comp + 1 if n_comp > 1 else 2 * D, dyn_hid,
                            dropout_layers=[models.modules.CDropout(0.25 * np.ones(h)) for h in dyn_hid],
                            nonlin=torch.nn.ReLU)
     dyn = models.DynamicsModel(dyn_model, reward_func=None,
-                               output_density=models.DiagGaussianDensity(D)).float()
+                               output_density=(models.GaussianMixtureDensity(D, n_comp) if n_comp > 1
+                                               else models.DiagGaussianDensity(D))).float()
+    if n_comp > 1:
+        gaussian_log_likelihood = gaussian_mixture_log_likelihood
+        last = [m for m in dyn.model._modules.values() if isinstance(m, torch.nn.Linear)][-1]
+        with torch.no_grad():
+            last.bias.add_(0.5 * torch.randn_like(last.bias))
     Xd = torch.randn(N, D + U)
     Yd = 0.3 * torch.randn(N, D) + 0.5 * Xd[:, :D] * Xd[:, D:D + 1]
     dyn.set_dataset(Xd, Yd)
@@ -807,6 +815,8 @@ def make_bnn_case(name, D, U, dyn_hid, N, M, iters, lr, seed=21, reg_weight=1.0)
     d['Yn'] = f(Yn)
     d['N'], d['M'], d['iters'], d['lr'], d['reg_weight'] = N, M, iters, lr, reg_weight
     d['max_log_std'] = float(dyn.output_density.max_log_std)
+    if n_comp > 1:
+        d['n_components'] = n_comp
 
     rec = []
     orig_rand_like, orig_bern = torch.rand_like, torch.bernoulli
@@ -1163,6 +1173,7 @@ CASES = {
                                                       lambda: RendezvousReward(), [1.0, 2.0, 3.0, 4.0], 70, seed=5),
     'bnn_small': lambda: make_bnn_case('bnn_small', 4, 1, [32, 32], 60, 20, 3, 1e-3),
     'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
+    'bnn_gmm': lambda: make_bnn_case('bnn_gmm', 4, 1, [48, 48], 80, 30, 3, 1e-3, seed=6, n_comp=3),
     'experience_host': lambda: make_experience_case('experience_host'),
     'critic_fit': lambda: make_critic_case('critic_fit'),
     'bnnopt_decoupled': lambda: make_bnn_opts_case('bnnopt_decoupled', 'decoupled'),
