@@ -1106,19 +1106,22 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64),
                        pm_mm_kernel_doubles(p->cfg.D) * sizeof(double), s, Am, p->cfg.H - 1);   // x_H
   } else if (p->mm_mode != 2) {
-    launch_fwd_rt(p, A, s);
+    RolloutArgs As = A;
+    if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
+    launch_fwd_rt(p, As, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
-    RolloutArgs Am = A;
-    if (p->fast) Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // fast family: rewards are handled after the sweep
+    RolloutArgs Am = A, As = A;
+    Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // both families: rewards are handled after the sweep
+    if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }
     for (int t = 0; t < p->cfg.H; ++t) {
-      A.t0 = t; A.t1 = t + 1;
-      launch_fwd_rt(p, A, s);
+      As.t0 = t; As.t1 = t + 1;
+      launch_fwd_rt(p, As, s);
       hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t);
     }
   }
   }
-  if (p->fast) {
+  {
     // rewards (+ Jacobians) of all row-steps in one parallel pass, then their moment matching
     ScopedTimer tm(p, PMBRL_TIMER_REWARD, s);
     A.t0 = 0; A.t1 = p->cfg.H;
@@ -1163,12 +1166,14 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   if (status_d) HIPCHK(hipMemsetAsync(status_d + 1, 0, sizeof(int32_t), s));
   float* grt = reinterpret_cast<float*>(ws + p->off_grt);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
-  if (p->fast && mm_r) {
-    // fast family: adjoint of the reward moment matching for all (t, group) up front
+  if (!p->fast) { A.ext_reward = 1; }
+  if (mm_r) {
+    // adjoint of the reward moment matching for all (t, group) up front
     hipLaunchKernelGGL(pm_mm_rewards_bwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                        pm_mm_scratch_doubles(1) * sizeof(double), s, A, grt);
     A.grad_rewards = grt;
   }
+  if (!p->fast) A.flags &= ~PMBRL_FLAG_MM_REWARDS;   // (general sweeps: the reward side is done, see ext_reward)
   if (p->mm_mode == 3) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     if (grad_states_d) return fail(-3, "grad_states with moment-matching groups spanning workgroups: not offered");
@@ -1201,11 +1206,7 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
     HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
     RolloutArgs Am = A;
-    if (p->fast) {
-      Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
-    } else {
-      A.grad_rewards = grt;
-    }
+    Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
     A.gx_from_carry = 1;
     for (int t = p->cfg.H - 1; t >= 0; --t) {
       hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);

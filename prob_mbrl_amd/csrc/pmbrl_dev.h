@@ -115,6 +115,10 @@ struct RolloutArgs {
   // component drawn [H][B], coefficients of dL/d(logits, log-temperature) [H][B][n + 1][D]
   int gmm_n;
   const float *zpi, *ucat, *zdyn_grad;
+  // general family: rewards, their Jacobians (Jx, Ja) and their moment matching are computed for all row-steps
+  // after the forward sweep (pm_reward_all_kernel), as in the latency-optimised family; the sweeps only check the
+  // sampled states and consume the Jacobians
+  int ext_reward;
   int* gmm_k;
   float* gmm_c;
   const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn, *zmm, *zrr;

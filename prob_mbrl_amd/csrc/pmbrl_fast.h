@@ -909,7 +909,7 @@ __global__ void pm_mm_rewards_fwd_kernel(const RolloutArgs A) {
   const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
   const int r0 = gi * A.M;
   const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-                            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false,
+                            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0,
                             A.rewards + (size_t)t * A.B + r0, 1, mmscr_r, lane);
   if (!ok && lane == 0) atomicMin(A.status, t);
 }
@@ -919,7 +919,8 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
   const int r0 = gi * A.M;
   if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
   pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, false, A.grad_rewards + (size_t)t * A.B + r0, 1,
+            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0,
+            A.grad_rewards + (size_t)t * A.B + r0, 1,
             gr_tilde + (size_t)t * A.B + r0, 1, mmscr_r, lane);
 }
 

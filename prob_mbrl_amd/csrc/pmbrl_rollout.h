@@ -480,6 +480,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     __syncthreads();
     PM_MARK(21);
     // ---- reward on the sampled (pre-mm) next state; failure detection
+    if (A.ext_reward) {
+      // (the reward never feeds the state recursion: pm_reward_all_kernel evaluates it for all row-steps at once
+      //  after the sweep -- one thread per row here was 34 k cycles of a 243 k-cycle step at D = 32)
+      for (int i = tid; i < nvalid * D; i += PM_NT)
+        if (!isfinite(xb[i]) || (SP && *p_ovf)) atomicMin(A.status, t);
+    } else
     for (int r = tid; r < R; r += PM_NT) {
       float rv = 0.f;
       if (r < nvalid) {
@@ -637,6 +643,16 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     PM_MARK(1);
     // ---- reward adjoint: gxt += dr/dx~ * gr ; ga_direct -> X scratch column block
     //      (X[r][0..U) holds the direct action gradient until phase B)
+    if (A.ext_reward) {
+      // Jacobians of the reward from pm_reward_all_kernel: dL/dx~ += dL/dr~ J_x, direct action gradient dL/dr~ J_a
+      for (int i = tid; i < R * max(D, U); i += PM_NT) {
+        const int r = i / max(D, U), k = i - r * max(D, U);
+        const bool v = r < nvalid;
+        const size_t row = (size_t)t * B + row0 + r;
+        if (k < D && v) gxt[r * D + k] += L.gr[r] * A.Jx[row * D + k];
+        if (k < U) L.gad[r * 16 + k] = v ? L.gr[r] * A.Ja[row * U + k] : 0.f;
+      }
+    } else
     for (int r = tid; r < R; r += PM_NT) {
       float ga[16];
       float xrow[PMBRL_MAX_DIM], gxr[PMBRL_MAX_DIM];
