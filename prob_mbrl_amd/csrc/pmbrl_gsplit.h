@@ -13,11 +13,11 @@
 //     bound by the matrix core (0.55 of the fp32 peak at 3 x 512) and become bound by the weight stream L2 -> CU;
 //   * narrow GEMMs (heads, first-layer adjoints) still leave fp32 rows in the output buffer, which the
 //     elementwise phases read as before; those phases write network inputs as piece planes.
-// Loads are plain compiler-scheduled loads here (no inline-asm stream): this family is throughput-bound.
+// The weight loads of the tile GEMM are inline asm with explicit waits (see gemm_tiles_group_s).
 #pragma once
 #include "pmbrl_split.h"
 
-#define PM_GS_CK 2   // K32 blocks per chunk (two chunks in flight)
+#define PM_GS_CK 1   // K32 blocks per chunk (a ring of four chunks: three in flight while one feeds the MFMAs)
 
 // scalar store of one value into the piece planes (the elementwise phases' network inputs)
 template <int R, bool F16>
@@ -68,18 +68,39 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) pre[k][rt] = epi.pre(ot < n_ot ? ot : ot0, rt);
   }
-  GsFrag<NT> f0, f1;
+  // A ring of four one-block chunks: three (NT * 2 KB each = 12 KB per wave at NT = 2) in flight while one feeds
+  // the MFMAs.  At 3 x 512 the weights (6 MB a sweep) do not fit an XCD's L2 and a load takes ~2 k cycles to
+  // return: with one two-block chunk ahead (8 KB in flight) the K loop ran at one chunk per round trip,
+  // 32 B/clk/CU.  (Four TWO-block buffers were measured slower: 128 registers of landing space spill.)
+  // The loads are inline asm with explicit waits (the rules of pmbrl_fast.h's weight stream; checked by
+  // tools/check_inflight.py): left to the compiler, the wait in front of the first chunk of every loop iteration
+  // came out as vmcnt(1) -- everything issued so far -- and the ring never had more than its last chunk in flight.
+  GsFrag<NT> f0, f1, f2, f3;
+  constexpr int NLD = NT * PM_GS_CK * 2;   // loads per chunk
   auto load = [&](GsFrag<NT>& f, int kb0) {
 #pragma unroll
     for (int c = 0; c < PM_GS_CK; ++c) {
       const int kb = kb0 + c < n_kb ? kb0 + c : 0;   // past the end: a harmless re-load of block 0
 #pragma unroll
-      for (int k = 0; k < NT; ++k)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) f.a[k][c][p] = ldg4(wp[k] + ((size_t)kb * 2 + p) * 256);
+      for (int k = 0; k < NT; ++k) {
+        const float* q = wp[k] + (size_t)kb * 512;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(f.a[k][c][0]) : "v"(q));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"(f.a[k][c][1]) : "v"(q));
+      }
     }
   };
-  auto compute = [&](const GsFrag<NT>& f, int kb0) {
+  // chunk f has landed: at most the three younger chunks are still outstanding
+  auto wait = [&](GsFrag<NT>& f) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLD));
+#pragma unroll
+    for (int c = 0; c < PM_GS_CK; ++c)
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(f.a[k][c][p]));
+  };
+  auto compute = [&](GsFrag<NT>& f, int kb0) {
+    wait(f);
 #pragma unroll
     for (int c = 0; c < PM_GS_CK; ++c) {
       if (kb0 + c < n_kb) {
@@ -95,15 +116,32 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
       }
     }
   };
-  // (a ring of four chunk buffers -- three chunks in flight -- was measured slower: 24.8 vs 21.8 ms per forward
-  //  sweep at 3 x 512; the registers cost more in spills than the deeper queue gained)
+  constexpr int S = PM_GS_CK;
   load(f0, 0);
-  for (int kb0 = 0; kb0 < n_kb; kb0 += 2 * PM_GS_CK) {
-    load(f1, kb0 + PM_GS_CK);
+  load(f1, S);
+  load(f2, 2 * S);
+  for (int kb0 = 0; kb0 < n_kb; kb0 += 4 * S) {
+    load(f3, kb0 + 3 * S);
     compute(f0, kb0);
-    load(f0, kb0 + 2 * PM_GS_CK);
-    compute(f1, kb0 + PM_GS_CK);
+    load(f0, kb0 + 4 * S);
+    compute(f1, kb0 + S);
+    load(f1, kb0 + 5 * S);
+    compute(f2, kb0 + 2 * S);
+    load(f2, kb0 + 6 * S);
+    compute(f3, kb0 + 3 * S);
   }
+  // the look-ahead chunks (harmless re-loads past the end) land before their registers are reused
+  asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+  for (int c = 0; c < PM_GS_CK; ++c)
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        asm volatile("" : "+v"(f0.a[k][c][p]));
+        asm volatile("" : "+v"(f1.a[k][c][p]));
+        asm volatile("" : "+v"(f2.a[k][c][p]));
+      }
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     if (ot0 + k * PM_NW < n_ot) {

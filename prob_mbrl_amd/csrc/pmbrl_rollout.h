@@ -50,11 +50,15 @@ struct EpiHiddenFwdT {
     const unsigned nib = (pr.mw >> (4 * g)) & 0xFu;
     f32x4 h;
     unsigned act = 0;
+    // (fp32 form: the reference's division, x / p; split form: a multiply -- the product is not bit-exact anyway
+    //  and four IEEE divisions are a third of this epilogue's instructions)
+    const float ik = NP > 0 ? 1.f / keep : 1.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[r] + b[r];
       const bool a = ((nib >> r) & 1u) && (v > 0.f);
-      h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
+      if constexpr (NP > 0) h[r] = a ? v * ik : 0.f;
+      else h[r] = a ? (keep == 1.f ? v : v / keep) : 0.f;
       act |= (a ? 1u : 0u) << r;
     }
     if constexpr (NP > 0) {
@@ -68,14 +72,18 @@ struct EpiHiddenFwdT {
     } else {
       *reinterpret_cast<f32x4*>(lds_out + lrow * ld + f0) = h;
     }
+#ifndef PM_EXP_GS_NOSTASH
     if (stash) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+      for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(h[r], stash + (size_t)(f0 + r) * Rw + lrow);   // write-once stream: keep the weights in L2
     }
+#endif
+#ifndef PM_EXP_GS_NOABITS
     unsigned w16 = act << (4 * g);
     w16 |= __shfl_xor(w16, 16);
     w16 |= __shfl_xor(w16, 32);
     if (g == 0 && valid) abits[(size_t)(row0 + lrow) * nt + ot] = (uint16_t)w16;
+#endif
   }
 };
 
@@ -104,9 +112,12 @@ struct EpiHiddenBwdT {
     const int f0 = ot * 16 + 4 * g;
     const unsigned nib = (pr.mw >> (4 * g)) & 0xFu;
     f32x4 h;
+    const float ik = NP > 0 ? 1.f / keep : 1.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (NP > 0) h[r] = ((nib >> r) & 1u) ? acc[r] * ik : 0.f;
+      else h[r] = ((nib >> r) & 1u) ? (keep == 1.f ? acc[r] : acc[r] / keep) : 0.f;
+    }
     if constexpr (NP > 0) {
       pm_store_planes<NP, R, false>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0, h);
       if (ot == nt - 1 && (nt & 1))
@@ -116,7 +127,7 @@ struct EpiHiddenBwdT {
     }
     if (stash) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stash[(size_t)(f0 + r) * Rw + lrow] = h[r];
+      for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(h[r], stash + (size_t)(f0 + r) * Rw + lrow);   // write-once stream: keep the weights in L2
     }
   }
 };

@@ -19,7 +19,7 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
     csrc = os.path.join(ROOT, 'prob_mbrl_amd', 'csrc')
     # the translation units that hold inline-asm loads, compiled to ISA side by side
     units = [('pmbrl.hip', []), ('pmbrl_fast_f32.hip', []), ('pmbrl_fast_split.hip', ['-DPM_SPLIT_PR=1']),
-             ('pmbrl_fast_split.hip', ['-DPM_SPLIT_PR=2'])]
+             ('pmbrl_fast_split.hip', ['-DPM_SPLIT_PR=2']), ('pmbrl_general_split.hip', [])]
     procs = []
     for k, (src, extra) in enumerate(units):
         out = str(tmp_path / ('u%d.s' % k))
@@ -33,11 +33,13 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
         assert pr.wait() == 0
         funcs = CI.parse_functions(out)
         for n in funcs:
-            if 'fast' in n or 'pm_dw_kernel' in n:
+            # (the general family's split-operand instantiations -- template argument 2 -- stream their weights
+            #  with inline-asm loads too: pmbrl_gsplit.h)
+            if 'fast' in n or 'pm_dw_kernel' in n or ('pm_rollout_' in n and n.endswith('ELi2EEv11RolloutArgs')):
                 bad, nload, _ = CI.check_function(n, funcs[n])
                 assert bad == 0, '%s: %d in-flight register violations' % (n, bad)
                 total_loads += nload
                 names.append(n)
-    assert len(names) >= 19 + 16, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
+    assert len(names) >= 19 + 16 + 6, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
     assert total_loads > 500
     shutil.rmtree(str(tmp_path), ignore_errors=True)
