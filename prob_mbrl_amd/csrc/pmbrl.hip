@@ -190,6 +190,8 @@ struct PackJob {
 };
 struct PackArgs {
   int n;
+  int* wflag;       // fp16 pieces: set to `gen` when a weight is beyond +-65504 or not finite (nullptr: no check)
+  int gen;
   int* status;      // reset to "no failure" by the same launch (nullptr: leave alone)
   PackJob job[6 * PM_MAXL];
 };
@@ -224,6 +226,8 @@ __global__ void pm_pack_all(const PackArgs P) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (j.f16) {
+            if (p == 0 && P.wflag && (!(fabsf(v[2 * e]) <= 65504.f) || !(fabsf(v[2 * e + 1]) <= 65504.f)))
+              atomicMax(P.wflag, P.gen);
             w[e] = pm_pk_f16(v[2 * e], v[2 * e + 1]);
             const pm_f32x2 f = pm_unpk_f16(w[e]);
             v[2 * e] -= f[0];
@@ -682,6 +686,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     }
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&p->wflag_d, sizeof(int)));
+    HIPCHK(hipMemset(p->wflag_d, 0, sizeof(int)));
+    p->wgen = 0;
   }
   // angle_dims feature maps (utils/angles.py:29-42: others in order, then sin, then cos)
   if (angles) {
@@ -845,6 +852,7 @@ extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
     for (int i = 0; i < PMBRL_TIMER_COUNT; ++i)
       for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
   if (p->rew_d) (void)hipFree(p->rew_d);
+  if (p->wflag_d) (void)hipFree(p->wflag_d);
   if (p->ang_d) (void)hipFree(p->ang_d);
   if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
   delete p;
@@ -1081,12 +1089,23 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
     PackArgs PK;
+    PK.wflag = nullptr;
+    PK.gen = 0;
     PK.n = 0;
     pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
     pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
     PK.status = status_d;
+    if (p->wgen >= 0x7ffffff0) {   // (the flag only ever grows: start over)
+      HIPCHK(hipMemsetAsync(p->wflag_d, 0, sizeof(int), s));
+      p->wgen = 0;
+    }
+    ++p->wgen;
+    PK.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
+    PK.gen = p->wgen;
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
   }
+  A.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
+  A.wgen = p->wgen;
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   {
   ScopedTimer tm(p, PMBRL_TIMER_FWD, s);
@@ -1317,6 +1336,8 @@ extern "C" int pmbrl_mlp_forward(void* stream, const pmbrl_mlp_call* c, void* wo
   hipStream_t s = (hipStream_t)stream;
   char* ws = static_cast<char*>(workspace_d);
   PackArgs PK;
+  PK.wflag = nullptr;
+  PK.gen = 0;
   PK.n = 0;
   PK.status = nullptr;
   MlpArgs A;
@@ -1364,6 +1385,8 @@ extern "C" int pmbrl_mlp_grad_input(void* stream, const pmbrl_mlp_call* c, void*
   hipStream_t s = (hipStream_t)stream;
   char* ws = static_cast<char*>(workspace_d);
   PackArgs PK;
+  PK.wflag = nullptr;
+  PK.gen = 0;
   PK.n = 0;
   PK.status = nullptr;
   MlpBwdArgs Bw;
@@ -1505,6 +1528,8 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
   HIPCHK(hipSetDevice(p->device));
   char* ws = static_cast<char*>(workspace_d);
   PackArgs PK;
+  PK.wflag = nullptr;
+  PK.gen = 0;
   PK.n = 0;
   PK.status = nullptr;
   BnnArgs A;

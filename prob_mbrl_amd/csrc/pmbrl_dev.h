@@ -119,6 +119,9 @@ struct RolloutArgs {
   // after the forward sweep (pm_reward_all_kernel), as in the latency-optimised family; the sweeps only check the
   // sampled states and consume the Jacobians
   int ext_reward;
+  // fp16 weight pieces: *wflag == wgen if pm_pack_all saw a weight beyond fp16's range in this call's weights
+  const int* wflag;
+  int wgen;
   int* gmm_k;
   float* gmm_c;
   const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn, *zmm, *zrr;

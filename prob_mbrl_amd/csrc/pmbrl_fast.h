@@ -738,6 +738,7 @@ struct EpiFwdL {
       // fp16 pieces: a value beyond the format's range would turn into inf - inf = NaN inside the next
       // layer and vanish in its ReLU; report it instead (h >= 0 here; the sampling phase of this step
       // turns the flag into a failed step)
+      // (a WEIGHT beyond fp16's range is caught when the weights are packed: pm_pack_all, RolloutArgs::wflag)
       if (fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3])) > 65504.f) *ovf = 1;
     }
 #ifndef PM_EXP_NOSTASH
@@ -1424,6 +1425,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   }
   // register-resident tile of this wave: output tile `wid` of the sweep's first streamed layer
   // (shape-specialised instantiations: always on, the stream's tile counts are compile-time constants)
+  // fp16 pieces: a weight beyond +-65504 (or non-finite) was seen while packing this launch's weights
+  if (F16 && tid == 0 && A.wflag && *A.wflag == A.wgen) atomicMin(A.status, A.t0);
   const int res_tiles = !RESK ? 0 : (SH::NT > 8 ? 8 : A.res_tiles);
   FragS<RESK ? (CA + CB) * NP : 1> wres;
   if constexpr (RESK) {

@@ -37,6 +37,8 @@ struct pmbrl_plan {
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
+  int* wflag_d;        // weight-range flag of the fp16 packer (see RolloutArgs::wflag)
+  int wgen;            // generation of the last forward call
   int dw_split;        // dW GEMM on split bf16 operands (pm_dw_kernel_s)
   AngleDev* ang_d;
   DwBlock* dw_blocks_d;

@@ -67,6 +67,8 @@ struct EpiHiddenFwdT {
       if (ot == nt - 1 && (nt & 1))
         pm_store_planes<NP, R, F16>(lds_out, (unsigned)ld, (unsigned)lrow, (unsigned)f0 + 16u, f32x4{0.f, 0.f, 0.f, 0.f});
       if constexpr (F16) {
+        // an activation out of fp16's range (h >= 0 here); a WEIGHT out of range -- it would pack to inf, inf x 0 is
+        // NaN, and a NaN pre-activation vanishes in the ReLU -- is caught when the weights are packed (A.wflag)
         if (fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3])) > 65504.f) *ovf = 1;
       }
     } else {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   float* xb = L.xb;   // pre-moment-matching next state
   // PR = 2: set when an activation leaves fp16's range (the action-gradient rows are idle in the forward sweep)
   int* const p_ovf = reinterpret_cast<int*>(L.gad);
-  if (SP && tid == 0) *p_ovf = 0;
+  if (SP && tid == 0) *p_ovf = (A.wflag && *A.wflag == A.wgen) ? 1 : 0;   // (1: a weight did not fit fp16, pm_pack_all)
 
   // initial state (states[t0] is x0 for t0 == 0, the previous launch's output otherwise)
   {

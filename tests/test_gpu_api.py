@@ -193,6 +193,29 @@ def test_fp16_range_failure_is_retried_on_bf16_pieces(capsys):
     assert abs(seen[0] - float(ref['ref32_loss'])) <= 1e-4 * abs(float(ref['ref32_loss']))
 
 
+def test_fp16_range_failure_in_the_general_family_is_retried_in_fp32():
+    """The same hazard in the general kernel family (here: angle_dims inside the networks, which only that family
+    runs): its split form has fp16 pieces only, so the retry lands on exact fp32."""
+    import prob_mbrl_amd as pm
+    name = 'angles_d4'
+    d = dict(common.load(name))
+    d['pol_W0'] = d['pol_W0'] * np.float32(2.0**20)
+    d['pol_b0'] = d['pol_b0'] * np.float32(2.0**20)
+    d['pol_W1'] = d['pol_W1'] * np.float32(2.0**-20)
+    ref = common.load(name)
+    eng, args, _ = common.engine_from_fixture(d, DEV, precision='split_f16')
+    assert not eng.info['fast'] and eng.info['precision'] == 'split_f16'
+    eng.forward(**args)
+    assert eng.valid_steps() < int(d['H'])
+    eng, args, _ = common.engine_from_fixture(d, DEV, precision='split')      # bf16 pieces: not in this family
+    assert eng.info['precision'] == 'f32'
+    dyn, pol = common.modules_from_fixture(d, name, DEV)
+    states, actions, rewards = pm.utils.rollout(torch.tensor(d['x0'], device=DEV), dyn, pol, int(d['H']),
+                                                resample_state_noise=False, resample_action_noise=False)
+    assert len(rewards) == int(d['H'])
+    assert common.rel(torch.stack(states).detach().cpu().numpy(), ref['ref64_states']) < 2e-5
+
+
 def test_mc_pilco_autograd_path_options():
     """CVaR + regulariser go through the autograd node; runs and moves the parameters."""
     import prob_mbrl_amd as pm
