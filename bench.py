@@ -243,6 +243,7 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes);
         # only valid for the configuration they were collected on
         traffic, traffic_src = None, None
+        prec = eng.info['precision']
         try:
             src = 'profiles/r02_pmc_traffic_%s.json' % prec
             pmc = json.load(open(os.path.join(ROOT, src)))
@@ -251,7 +252,6 @@ def main():
                 traffic_src = src + ' (rocprofv3 --pmc passes of this command, not measured in this run)'
         except Exception:
             traffic = None
-        prec = eng.info['precision']
         # peak the dominant kernel is priced against: the dense MFMA peak of the instruction it issues --
         # exact fp32 MFMA, or fp16 / bf16 MFMA at THREE instructions per fp32-equivalent product (two-piece
         # split operands; the three-piece bf16 forward of 'split' issues six)
