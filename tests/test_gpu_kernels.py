@@ -142,6 +142,50 @@ def test_rollout_parity(dev, name, generic):
         assert common.rel(g, d['ref32_grad']) < TOL_GRAD + common.rel(d['ref32_grad'], d['ref64_grad'])
 
 
+@pytest.mark.parametrize('name', [n for n, g in _PARITY_CASES if g])
+def test_rollout_parity_general_family_fp32(dev, name):
+    """The general kernel family in exact fp32 (PMBRL_PREC_F32): test_rollout_parity above runs it in the default
+    arithmetic (split operands), this keeps the fp32 instantiations under the same fixtures and tolerances."""
+    d = common.load(name)
+    eng, S, A, Rw, loss, g, gx0, agn = _run(d, dev, generic=True, precision='f32')
+    assert eng.info['precision'] == 'f32' and eng.valid_steps() == int(d['H'])
+    assert common.rel(S, d['ref64_states']) < TOL_TRAJ
+    assert common.rel(A, d['ref64_actions']) < TOL_TRAJ
+    assert common.rel(Rw.reshape(d['ref64_rewards'].shape), d['ref64_rewards']) < TOL_TRAJ
+    assert abs(loss - float(d['ref64_loss'])) <= TOL_TRAJ * abs(float(d['ref64_loss']))
+    assert common.rel(g, d['ref64_grad']) < TOL_GRAD
+
+
+def test_mixture_head_exact_noise_gradient(dev):
+    """PMBRL_FLAG_GMM_EXACT_NOISE_GRAD: the noise term of the mixture head differentiated with each step's own
+    noise (the mathematically exact gradient) instead of the reference's last-step noise; against the torch oracle
+    in that mode."""
+    from oracle import ref_torch as R
+    d = common.load('gmm_d4')
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    dyn['exact_noise_grad'] = True
+    loss64, g64, _ = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, meta['maximize'], meta['mm_states'],
+                                 meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr, meta['infer_ns'])
+    assert common.rel(g64.numpy(), d['ref64_grad']) > 1e-2           # (it IS a different gradient)
+    from prob_mbrl_amd import problem as PB
+    import prob_mbrl_amd.engine as E
+    orig = E.Engine.__init__
+
+    def init(self, *a, **k):
+        k['gmm_exact_noise_grad'] = True
+        orig(self, *a, **k)
+    E.Engine.__init__ = init
+    try:
+        eng, args, _ = PB.engine_from_problem(d, dev)
+    finally:
+        E.Engine.__init__ = orig
+    S, A, Rw = eng.forward(**args)
+    gw = torch.tensor(common.loss_weights(d, d['x0'].shape[0]), device=dev)
+    g, _, _ = eng.backward(gw)
+    assert common.rel(S.cpu().numpy(), d['ref64_states']) < TOL_TRAJ
+    assert common.rel(g.cpu().numpy(), g64.numpy()) < TOL_GRAD
+
+
 _SPLIT_CASES = [n for n, g in _PARITY_CASES if not g]
 
 
