@@ -39,6 +39,8 @@ def parse(argv=None):
     ap.add_argument('--dyn_opt_iters', type=int, default=2000)
     ap.add_argument('--dyn_batch_size', type=int, default=100)
     ap.add_argument('--dyn_drop_rate', type=float, default=0.1)
+    ap.add_argument('--dyn_components', type=int, default=1,
+                    help='> 1: GaussianMixtureDensity dynamics head (examples/deep_pilco_mm.py:117-121)')
     ap.add_argument('--dyn_shape', type=lambda s: [int(v) for v in s.split(',')], default=[200, 200])
     ap.add_argument('--pol_lr', type=float, default=1e-3)
     ap.add_argument('--pol_clip', type=float, default=1.0)
@@ -73,11 +75,15 @@ def main(argv=None):
         args.discount_factor = ((1.0 / args.control_H)**(2.0 / args.control_H)
                                 if args.discount_factor == 'auto' else float(args.discount_factor))
 
+    if args.dyn_components > 1:     # mixture-of-Gaussians head: (2 D + 1) n + 1 outputs
+        density, dynE = models.GaussianMixtureDensity(D, args.dyn_components), (2 * D + 1) * args.dyn_components + 1
+    else:
+        density, dynE = models.DiagGaussianDensity(D), 2 * D
     dyn = models.DynamicsModel(
-        models.mlp(D + U, 2 * D, args.dyn_shape,
+        models.mlp(D + U, dynE, args.dyn_shape,
                    dropout_layers=[models.CDropout(args.dyn_drop_rate * np.ones(h)) if args.dyn_drop_rate > 0
                                    else None for h in args.dyn_shape], nonlin=torch.nn.ReLU),
-        reward_func=env.reward_func, output_density=models.DiagGaussianDensity(D)).float()
+        reward_func=env.reward_func, output_density=density).float()
     pol = models.Policy(
         models.mlp(D, 2 * U, args.pol_shape,
                    dropout_layers=[models.BDropout(args.pol_drop_rate) if args.pol_drop_rate > 0 else None
