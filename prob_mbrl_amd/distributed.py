@@ -109,6 +109,13 @@ def grad_allreduce(group=None, device=None):
                 if dist.get_rank(group) == 0:
                     print('prob_mbrl_amd: RCCL communicator through the C ABI unavailable (%s); '
                           'using torch.distributed.all_reduce' % e)
+            # every rank must take the same path: one that failed alone would leave the others in a collective
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                              device=device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         _COMMS[key] = comm
     comm = _COMMS[key]
     if comm is not None:
