@@ -20,6 +20,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- \
   python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --timing-steps 1 > /dev/null 2>$O/pw.err
 # 4. in-kernel cycle stamps, the other configurations, the neighbouring paths
 timeout 120 python $R/tools/phase_prof.py > $O/phase_prof.txt 2>/dev/null
+for c in cartpole_mm dcartpole_mm stress32; do timeout 120 python $R/tools/phase_prof.py $c > $O/phase_prof_$c.txt 2>/dev/null; done
 for c in cartpole_mm dcartpole_mm stress32; do
   timeout 300 python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null
 done
