@@ -524,6 +524,10 @@ struct Res0Pre {
 // epilogue operands of a resident layer: issued BEFORE the barrier that opens its phase
 template <int RT, class Epi>
 __device__ __forceinline__ void res0_prefetch(Res0Pre<RT, Epi>& pp, const Epi& epi, int n_ot, int wid) {
+  // (four row tiles per wave, LDS operands: fetched inside res0_layer instead -- eight Pre sets held across the
+  //  barrier and the MFMAs are 40 registers these instances spill, and every epilogue then waited for a scratch
+  //  reload: 12 k cycles for a K = 16 layer)
+  if constexpr (RT >= 4 && Epi::kLdsPre) return;
 #pragma unroll
   for (int i = 0; i < PM_L0T; ++i) {
     const int ot = wid + i * PF_NW;
@@ -558,8 +562,12 @@ __device__ __forceinline__ void res0_layer(const Res0<RT>& r, int n_ot, const fl
     const int ot = wid + i * PF_NW;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      epi.landed(pp.p[i][rt], rt);
-      if (ot < n_ot) epi(ot, rt, acc[i][rt], pp.p[i][rt]);
+      if constexpr (RT >= 4 && Epi::kLdsPre) {
+        if (ot < n_ot) epi(ot, rt, acc[i][rt], epi.pre(ot, rt));
+      } else {
+        epi.landed(pp.p[i][rt], rt);
+        if (ot < n_ot) epi(ot, rt, acc[i][rt], pp.p[i][rt]);
+      }
     }
   }
 }
@@ -673,15 +681,8 @@ struct PmEmpty {};
 // (pm_fast_hp_alias).  On the piece planes that leaves arbitrary 16-bit patterns -- infinities and NaNs among
 // them -- in the K-padding columns the layer epilogues never write; the next GEMM multiplies those by zero
 // weights, and 0 x inf is not 0 (forward: the NaN pre-activations then vanish in the ReLU and silently zero
-// the row's hidden units).  The epilogue of a layer's LAST tile therefore clears the padding of its rows.
-template <int RT, int NP, bool F16>
-__device__ __forceinline__ void pm_zero_k_padding(float* lds_out, unsigned ldb, unsigned lrow, unsigned f0, int ot, int nt) {
-  if constexpr (RT >= 4) {
-    if (ot == nt - 1)
-      for (unsigned c = f0 + 16; c + 16 <= ldb; c += 16)
-        pm_store_planes<NP, 16 * RT, F16>(lds_out, ldb, lrow, c, f32x4{0.f, 0.f, 0.f, 0.f});
-  }
-}
+// the row's hidden units).  The epilogue of a layer's LAST tile therefore clears the padding of its rows
+// (the `ot == nt - 1` branches below).
 // NP = 0: the layer output goes to LDS as fp32 rows (leading dimension ld); NP > 0: as NP bf16 (F16: fp16)
 // piece planes (pmbrl_split.h; leading dimension ld in 16-bit elements)
 template <int RT, int NP = 0, bool F16 = false>
@@ -712,6 +713,7 @@ struct EpiFwdL {
   }
   __device__ __forceinline__ void landed(Pre&, int) const {}   // LDS operands: the compiler tracks them
   static __device__ __forceinline__ void wait_all() {}
+  static constexpr bool kLdsPre = true;    // pre() reads LDS only: cheap enough to fetch right before the epilogue
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     constexpr unsigned RW = 16 * RT;
     const unsigned g = (unsigned)lane >> 4;
@@ -729,8 +731,17 @@ struct EpiFwdL {
       act |= (a ? 1u : 0u) << r;
     }
     if constexpr (NP > 0) {
-      pm_store_planes<NP, 16 * RT, F16>(lds_out, (unsigned)ld, lrow, f0, h);
-      pm_zero_k_padding<RT, NP, F16>(lds_out, (unsigned)ld, lrow, f0, ot, nt);
+      if constexpr (RT >= 4) {
+        // (one per-lane pointer, constant offsets per row tile / piece: pm_store_planes_q)
+        unsigned short* q = reinterpret_cast<unsigned short*>(lds_out) + ((unsigned)lane & 15u) * (unsigned)ld + f0;
+        asm volatile("" : "+v"(q));      // keep it ONE register: do not fold the buffer offset into the immediates
+        pm_store_planes_q<NP, 16 * RT, F16>(q, (unsigned)ld, rt, h);
+        if (ot == nt - 1)
+          for (unsigned c = 16; f0 + c + 16 <= (unsigned)ld; c += 16)
+            pm_store_planes_q<NP, 16 * RT, F16>(q + c, (unsigned)ld, rt, f32x4{0.f, 0.f, 0.f, 0.f});
+      } else {
+        pm_store_planes<NP, 16 * RT, F16>(lds_out, (unsigned)ld, lrow, f0, h);
+      }
     } else {
       *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
     }
@@ -787,6 +798,7 @@ struct EpiBwdL {
     if ((int)lrow >= nvalid) p.nib = 0;
   }
   static __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)"); }
+  static constexpr bool kLdsPre = false;   // pre() is an HBM / L2 load: issued ahead
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc, const Pre& pr) {
     constexpr unsigned RW = 16 * RT;
     const unsigned g = (unsigned)lane >> 4;
@@ -797,8 +809,16 @@ struct EpiBwdL {
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = ((nib >> r) & 1u) ? acc[r] * inv_keep : 0.f;
     if constexpr (NP > 0) {
-      pm_store_planes<NP, 16 * RT>(lds_out, (unsigned)ld, lrow, f0, h);
-      pm_zero_k_padding<RT, NP, false>(lds_out, (unsigned)ld, lrow, f0, ot, nt);
+      if constexpr (RT >= 4) {
+        unsigned short* q = reinterpret_cast<unsigned short*>(lds_out) + ((unsigned)lane & 15u) * (unsigned)ld + f0;
+        asm volatile("" : "+v"(q));
+        pm_store_planes_q<NP, 16 * RT, false>(q, (unsigned)ld, rt, h);
+        if (ot == nt - 1)
+          for (unsigned c = 16; f0 + c + 16 <= (unsigned)ld; c += 16)
+            pm_store_planes_q<NP, 16 * RT, false>(q + c, (unsigned)ld, rt, f32x4{0.f, 0.f, 0.f, 0.f});
+      } else {
+        pm_store_planes<NP, 16 * RT>(lds_out, (unsigned)ld, lrow, f0, h);
+      }
     } else {
       *reinterpret_cast<f32x4*>(lds_out + lrow * (unsigned)ld + f0) = h;
     }

@@ -99,6 +99,19 @@ __device__ __forceinline__ void pm_store_planes(float* buf, unsigned ldb, unsign
     *reinterpret_cast<pm_u32x2*>(pb + ((unsigned)(p * R) + lrow) * ldb + f0) = pc[p];
 }
 
+// the same from a per-lane pointer q = plane 0, row (lane & 15), column f0: row tile rt and piece p are then
+// CONSTANT offsets (p R + 16 rt) ldb -- at most 54 KB for 64 rows of 240 elements, inside the 16-bit immediate of a
+// ds_write.  With the buffer's own offset in the immediate instead (the compiler's choice for the form above) the
+// second plane of a 64-row buffer is out of the immediate's reach and every (row tile, piece) gets an address
+// register of its own: eight of them, spilled, and reloaded behind a vmcnt(0) in every epilogue.
+template <int NP, int R, bool F16 = false>
+__device__ __forceinline__ void pm_store_planes_q(unsigned short* q, unsigned ldb, int rt, f32x4 h) {
+  pm_u32x2 pc[NP];
+  pm_split4<NP, F16>(h, pc);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<pm_u32x2*>(q + ((unsigned)(p * R) + 16u * (unsigned)rt) * ldb) = pc[p];
+}
+
 // piece products kept, smallest contributions first
 template <int NP>
 struct PmPairs;
