@@ -152,6 +152,7 @@ enum {
   PMBRL_INFO_N_DYN_PARAMS = 5,
   PMBRL_INFO_DW_SPLITS = 6,
   PMBRL_INFO_PRECISION = 13, /* PMBRL_PREC_* actually in use */
+  PMBRL_INFO_DW_PIPE = 14,   /* launches the adjoint sweep is cut into so that the dW GEMM runs behind it (1: no) */
   PMBRL_INFO_COUNT = 16
 };
 

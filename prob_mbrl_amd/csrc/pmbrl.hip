@@ -738,6 +738,63 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock),
                      hipMemcpyHostToDevice));
   }
+  {
+    // dW GEMM behind the adjoint sweep.  The sweep is latency-bound and holds nwg CUs completely (its
+    // workgroups take a CU's whole register file); with fewer workgroups than CUs the rest of the chip idles
+    // for its duration, and the dW GEMM -- 12-17 % of an iteration -- used to start when the sweep had
+    // finished.  It needs only the deltas of the steps already swept: the sweep becomes pipe_K launches
+    // over descending step ranges (the state gradient is carried through HBM, as in the per-step launch
+    // modes) and the GEMM of range k runs next to the sweep of range k+1, on a second stream, in a grid that
+    // fits the idle CUs (workgroups go round-robin to the 8 XCDs, so per XCD: CUs/8 - ceil(nwg/8) are free)
+    // with workgroups that cannot share a CU with the sweep's.  Only the last, short range is exposed.
+    // Correctness never depends on the overlap: every dependency is a stream event.
+    p->pipe_K = 1;
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    const char* e = getenv("PMBRL_DW_PIPE");
+    const int n_free = cus >= 64 && cus % 8 == 0 ? 8 * (cus / 8 - (p->nwg + 7) / 8) : 0;
+    const bool single = p->mm_mode == 0 || p->mm_mode == 1;
+    // Worth it where a range of the sweep is long against a launch boundary (tail of the last step, launch
+    // gap, the next launch's prologue: 15 us at 16 rows per workgroup, 40 us at 64) -- measured: the double
+    // cart-pole shape (64-row workgroups, 30 us per step) gains 7 % of an iteration, the cart-pole shapes
+    // (6 / 13 us per step) lose 1-5 %.  Proxy for the step time: rows per workgroup x weights of both nets.
+    const bool explicit_ranges = e && e[0] >= '0' && e[0] <= '9';
+    const bool long_steps = (long long)p->RT * (long long)(p->pol.n_params + p->dyn.n_params) >= 256 * 1024 && c.H >= 16;
+    if (single && n_free >= cus / 8 && c.H >= 2 && !(e && !strcmp(e, "off")) && (long_steps || explicit_ranges)) {
+      std::vector<int> cnt;
+      if (explicit_ranges) {     // PMBRL_DW_PIPE=n0,n1,...: steps per range, highest steps first (tests, tuning)
+        int sum = 0;
+        for (const char* q = e; *q;) {
+          const int v = atoi(q);
+          if (v > 0) { cnt.push_back(v); sum += v; }
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+        if (sum != c.H || (int)cnt.size() > PM_PIPE_MAX) cnt.clear();
+      }
+      if (cnt.empty() && long_steps) {
+        // 40 / 30 / 20 / 10 % of the horizon: the exposed tail is the GEMM of the last tenth
+        const int a3 = std::max(2, c.H / 10), a2 = a3 + std::max(2, c.H / 5), a1 = a2 + std::max(2, (3 * c.H) / 10);
+        cnt = {c.H - a1, a1 - a2, a2 - a3, a3};
+      }
+      // lower step bound of every range (the last one ends at step 0; ranges emptied by the adjustment are dropped)
+      int K = 0, lo = c.H;
+      for (size_t k = 0; k < cnt.size() && lo > 0; ++k) {
+        lo = k + 1 == cnt.size() ? 0 : std::max(0, lo - cnt[k]);
+        // split-operand GEMM: a K = 32 chunk pair must not straddle two launches
+        if (p->dw_split && ((p->nwg * p->RT) & 1) && (lo & 1)) lo -= 1;
+        if (K > 0 && lo >= p->pipe_lo[K - 1]) continue;
+        p->pipe_lo[K++] = lo;
+      }
+      if (K >= 2 && p->pipe_lo[K - 1] == 0) {
+        p->pipe_K = K;
+        p->pipe_grid = n_free;                     // workgroups (= partial rows) of a GEMM launch next to the sweep
+        p->pipe_rows = std::max(n_free, cus);      // ... of the last launch, which has the chip to itself
+        HIPCHK(hipStreamCreateWithFlags(&p->pipe_stream, hipStreamNonBlocking));
+        for (int k = 0; k < p->pipe_K; ++k) HIPCHK(hipEventCreateWithFlags(&p->pipe_ev[k], hipEventDisableTiming));
+      }
+    }
+  }
   // workspace carve-up
   {
     size_t off = 0;
@@ -775,7 +832,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
     p->off_gsync = take(2 * 1024 * sizeof(unsigned));   // one flag per workgroup for the device-wide barriers (forward, backward)
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
-    p->off_part = take((size_t)p->dw_nsplit * ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
+    p->off_part = take((size_t)std::max(p->dw_nsplit, p->pipe_K > 1 ? p->pipe_rows : 0) *
+                       ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
   }
   int rc2 = 0;
@@ -855,6 +913,10 @@ extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
   if (p->wflag_d) (void)hipFree(p->wflag_d);
   if (p->ang_d) (void)hipFree(p->ang_d);
   if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
+  if (p->pipe_stream) {
+    (void)hipStreamDestroy(p->pipe_stream);
+    for (int k = 0; k < p->pipe_K; ++k) (void)hipEventDestroy(p->pipe_ev[k]);
+  }
   delete p;
 }
 
@@ -877,6 +939,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[11] = p->CA * 16 + p->CB;
   info[12] = p->mm_grid;
   info[PMBRL_INFO_PRECISION] = p->prec;
+  info[PMBRL_INFO_DW_PIPE] = p->pipe_K;
   return 0;
 }
 
@@ -1193,46 +1256,6 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     A.grad_rewards = grt;
   }
   if (!p->fast) A.flags &= ~PMBRL_FLAG_MM_REWARDS;   // (general sweeps: the reward side is done, see ext_reward)
-  if (p->mm_mode == 3) {
-    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
-    if (grad_states_d) return fail(-3, "grad_states with moment-matching groups spanning workgroups: not offered");
-    float* cbuf[2] = {A.gx_carry, reinterpret_cast<float*>(ws + p->off_gxc2)};
-    HIPCHK(hipMemsetAsync(cbuf[0], 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
-    A.gx_from_carry = 1;
-    int k = 0;
-    if (p->mm_grid) {
-      A.gsync += 1024;
-      HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
-      A.gx_carry_out = cbuf[1];
-      A.t0 = 0; A.t1 = p->cfg.H;
-      launch_bwd_rt(p, A, s);
-    } else
-    for (int t = p->cfg.H - 1; t >= 0; --t, k ^= 1) {
-      A.gx_carry = cbuf[k];           // dL/dx_{t+1}, all rows (read by every workgroup of the group)
-      A.gx_carry_out = cbuf[k ^ 1];   // dL/dx_t of this workgroup's rows
-      A.t0 = t; A.t1 = t + 1;
-      launch_bwd_rt(p, A, s);
-    }
-    A.gx_carry = cbuf[0];
-    A.gx_carry_out = nullptr;
-  } else if (p->mm_mode != 2) {
-    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
-    A.gx_from_carry = 0;
-    launch_bwd_rt(p, A, s);
-  } else {
-    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
-    if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
-    const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
-    HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
-    RolloutArgs Am = A;
-    Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
-    A.gx_from_carry = 1;
-    for (int t = p->cfg.H - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
-      A.t0 = t; A.t1 = t + 1;
-      launch_bwd_rt(p, A, s);
-    }
-  }
   // dW GEMM over the stashes + deterministic reduction
   DwArgs W;
   memset(&W, 0, sizeof(W));
@@ -1260,16 +1283,98 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   W.nvalid = status_d;
   W.chunks_per_step = p->nwg * p->RT;
   W.split_prec = p->dw_split;
+  const bool pipe = p->pipe_K > 1 && !p->prof_bwd;
+  auto launch_dw = [&](int k, hipStream_t st) {
+    DwArgs Wk = W;
+    const int cps = W.chunks_per_step;
+    Wk.pipe = 1;
+    Wk.pipe_k = k;
+    const bool last = k + 1 == p->pipe_K;
+    Wk.nsplit = last ? p->pipe_rows : p->pipe_grid;
+    Wk.rows_before = p->pipe_grid;
+    Wk.c_begin = p->pipe_lo[k] * cps;
+    Wk.c_end = (k ? p->pipe_lo[k - 1] : p->cfg.H) * cps;
+    Wk.chunks_per_split = (Wk.c_end - Wk.c_begin + Wk.nsplit - 1) / Wk.nsplit;
+    if (p->dw_split) Wk.chunks_per_split = (Wk.chunks_per_split + 1) & ~1;
+    if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
+    else hipLaunchKernelGGL(pm_dw_kernel, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
+  };
+  if (p->mm_mode == 3) {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
+    if (grad_states_d) return fail(-3, "grad_states with moment-matching groups spanning workgroups: not offered");
+    float* cbuf[2] = {A.gx_carry, reinterpret_cast<float*>(ws + p->off_gxc2)};
+    HIPCHK(hipMemsetAsync(cbuf[0], 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
+    A.gx_from_carry = 1;
+    int k = 0;
+    if (p->mm_grid) {
+      A.gsync += 1024;
+      HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
+      A.gx_carry_out = cbuf[1];
+      A.t0 = 0; A.t1 = p->cfg.H;
+      launch_bwd_rt(p, A, s);
+    } else
+    for (int t = p->cfg.H - 1; t >= 0; --t, k ^= 1) {
+      A.gx_carry = cbuf[k];           // dL/dx_{t+1}, all rows (read by every workgroup of the group)
+      A.gx_carry_out = cbuf[k ^ 1];   // dL/dx_t of this workgroup's rows
+      A.t0 = t; A.t1 = t + 1;
+      launch_bwd_rt(p, A, s);
+    }
+    A.gx_carry = cbuf[0];
+    A.gx_carry_out = nullptr;
+  } else if (p->mm_mode != 2 && pipe) {
+    // range k of the sweep on s; the dW GEMM of range k on the second stream behind it (the last one below, on s)
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
+    for (int k = 0; k < p->pipe_K; ++k) {
+      A.t0 = p->pipe_lo[k];
+      A.t1 = k ? p->pipe_lo[k - 1] : p->cfg.H;
+      A.gx_from_carry = k > 0;
+      launch_bwd_rt(p, A, s);
+      if (k + 1 < p->pipe_K) {
+        HIPCHK(hipEventRecord(p->pipe_ev[k], s));
+        HIPCHK(hipStreamWaitEvent(p->pipe_stream, p->pipe_ev[k], 0));
+        launch_dw(k, p->pipe_stream);
+      }
+    }
+    A.t0 = 0; A.t1 = p->cfg.H;
+  } else if (p->mm_mode != 2) {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
+    A.gx_from_carry = 0;
+    launch_bwd_rt(p, A, s);
+  } else {
+    ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
+    if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");
+    const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
+    HIPCHK(hipMemsetAsync(A.gx_carry, 0, (size_t)p->cfg.B * p->cfg.D * sizeof(float), s));
+    RolloutArgs Am = A;
+    Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
+    A.gx_from_carry = 1;
+    for (int t = p->cfg.H - 1; t >= 0; --t) {
+      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
+      A.t0 = t; A.t1 = t + 1;
+      launch_bwd_rt(p, A, s);
+    }
+  }
+  const bool piped = pipe && p->mm_mode != 2 && p->mm_mode != 3;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW, s);
-    if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+    if (piped) {
+      // the rows of the last range are added to what the second stream left: join it first
+      HIPCHK(hipEventRecord(p->pipe_ev[p->pipe_K - 1], p->pipe_stream));
+      HIPCHK(hipStreamWaitEvent(s, p->pipe_ev[p->pipe_K - 1], 0));
+      launch_dw(p->pipe_K - 1, s);
+    }
+    else if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
     else hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
   }
   const int n = (int)p->pol.n_params;
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
-    hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
-                       W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split);
+    if (piped)   // every partial row was written (pm_dw_range)
+      hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->pipe_rows, n,
+                         W.part_stride, grad_pol_flat_d, (const int*)nullptr, 0, 1);
+    else
+      hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
+                         W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split);
   }
   HIPCHK(hipGetLastError());
   return 0;

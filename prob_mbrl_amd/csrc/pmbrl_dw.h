@@ -51,6 +51,20 @@ struct DwArgs {
   int wave_first[PM_DW_NW + 1];          // wave w owns blocks [wave_first[w], wave_first[w+1])
   float* part;                           // [nsplit][n_params]
   int split_prec;                        // 1: two bf16 pieces per operand on the bf16 matrix core (pm_dw_kernel_s)
+  // Pipelined form (pmbrl.hip: "dW behind the adjoint sweep"): the adjoint sweep runs as K launches over
+  // descending step ranges and launch k of this GEMM covers the chunks of range k only, [c_begin, c_end),
+  // dealt to the same nsplit partial rows every time; the first launch that owns a valid step writes its
+  // row (zeros if the row got no chunk), the later ones add to it -- still one fixed order of additions.
+  int pipe;                              // 0: one launch over all chunks (fields below unused)
+  int pipe_k;                            // index of this launch, 0 = the highest steps
+  int c_begin, c_end;                    // chunk range of this launch (c_end = the previous launch's c_begin)
+  int rows_before;                       // partial rows the earlier launches own (the last launch has more)
+};
+
+struct DwRange {
+  int c_lo, c_hi;
+  bool add;        // the partial row already holds the sum of earlier launches
+  bool zero;       // no chunk for this row in the launch that defines the rows: write zeros
 };
 
 #ifdef PM_MAIN_TU   // the kernels below are compiled into pmbrl.hip only (pmbrl_host.h needs just the structs above)
@@ -62,9 +76,30 @@ __device__ __forceinline__ void pm_dw_ld(f32x4& d, unsigned voff, const float* s
 #endif
 }
 
+// chunk range and write mode of partial row `row` in this launch; false: nothing to do
+__device__ __forceinline__ bool pm_dw_range(const DwArgs& A, int row, DwRange& r) {
+  long long nv = 0x7fffffffll;      // valid steps of the forward sweep (the status word is INT_MAX when complete)
+  if (A.nvalid) nv = max(0, __builtin_amdgcn_readfirstlane(*A.nvalid));
+  const int n_chunks = A.nvalid ? (int)min((long long)A.n_chunks, nv * A.chunks_per_step) : A.n_chunks;
+  r.add = r.zero = false;
+  if (!A.pipe) {
+    r.c_lo = row * A.chunks_per_split;
+    r.c_hi = min(n_chunks, r.c_lo + A.chunks_per_split);
+    return r.c_lo < r.c_hi;                 // (pm_dw_reduce skips the rows without chunks)
+  }
+  const long long first_valid = max(nv, 1ll) * A.chunks_per_step;   // a launch below this bound defines the rows
+  r.add = A.pipe_k > 0 && (long long)A.c_end < first_valid && row < A.rows_before;
+  r.c_lo = A.c_begin + row * A.chunks_per_split;
+  r.c_hi = min(min(A.c_end, n_chunks), r.c_lo + A.chunks_per_split);
+  if (r.c_lo < r.c_hi) return true;
+  r.zero = !r.add && (long long)A.c_begin < first_valid;
+  return r.zero;
+}
+__device__ __forceinline__ void pm_dw_put(float* q, float v, bool add) { *q = add ? *q + v : v; }
+
 template <int NI, int NJ>
 __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
-                                            float* part, int lane) {
+                                            float* part, int lane, bool add) {
   const int g = lane >> 4, c16 = lane & 15;
   const int l = blk.layer;
   const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
@@ -159,7 +194,7 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int o = (blk.ot0 + i) * 16 + 4 * g + r;
-            if (o < O && k < K) part[A.w_off[l] + (size_t)o * K + k] = acc[i][j][r];
+            if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], add);
           }
         }
       if (do_bias) {
@@ -167,7 +202,7 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         const int o = (blk.ot0 + i) * 16 + c16;
-        if (g == 0 && o < O) part[A.b_off[l] + o] = s;
+        if (g == 0 && o < O) pm_dw_put(part + A.b_off[l] + o, s, add);
       }
     }
 }
@@ -176,30 +211,32 @@ __device__ __forceinline__ void pm_dw_block(const DwArgs& A, const DwBlock& blk,
 // class that holds it)
 template <int NI>
 __device__ __forceinline__ void pm_dw_dispatch_j(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
-                                                 float* part, int lane) {
-  if (blk.n_it <= 1) pm_dw_block<NI, 1>(A, blk, c_lo, c_hi, part, lane);
-  else if (blk.n_it <= 4) pm_dw_block<NI, 4>(A, blk, c_lo, c_hi, part, lane);
-  else if (blk.n_it <= 6) pm_dw_block<NI, 6>(A, blk, c_lo, c_hi, part, lane);
-  else pm_dw_block<NI, 7>(A, blk, c_lo, c_hi, part, lane);
+                                                 float* part, int lane, bool add) {
+  if (blk.n_it <= 1) pm_dw_block<NI, 1>(A, blk, c_lo, c_hi, part, lane, add);
+  else if (blk.n_it <= 4) pm_dw_block<NI, 4>(A, blk, c_lo, c_hi, part, lane, add);
+  else if (blk.n_it <= 6) pm_dw_block<NI, 6>(A, blk, c_lo, c_hi, part, lane, add);
+  else pm_dw_block<NI, 7>(A, blk, c_lo, c_hi, part, lane, add);
 }
 
+// (two waves per SIMD at up to 256 registers per lane: a workgroup takes a CU's whole register file, so a grid
+//  of n workgroups occupies n CUs and never shares one with the adjoint sweep's workgroups -- the pipelined
+//  form relies on that to stay out of the sweep's way)
 __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x;
-  const int c_lo = split * A.chunks_per_split;
-  int n_chunks = A.n_chunks;
-  if (A.nvalid)   // (the status word is INT_MAX after a complete sweep: 64-bit product)
-    n_chunks = (int)min((long long)n_chunks,
-                        (long long)max(0, __builtin_amdgcn_readfirstlane(*A.nvalid)) * A.chunks_per_step);
-  const int c_hi = min(n_chunks, c_lo + A.chunks_per_split);
-  if (c_lo >= c_hi) return;                // (pm_dw_reduce skips the splits without chunks)
-  float* part = A.part + (size_t)split * A.part_stride;
+  const int row = blockIdx.x;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  float* part = A.part + (size_t)row * A.part_stride;
+  if (R.zero) {
+    for (int i = tid; i < A.part_stride; i += PM_DW_NT) part[i] = 0.f;
+    return;
+  }
   for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
     const DwBlock blk = A.blocks[bi];
-    if (blk.n_ot <= 1) pm_dw_dispatch_j<1>(A, blk, c_lo, c_hi, part, lane);
-    else if (blk.n_ot <= 3) pm_dw_dispatch_j<3>(A, blk, c_lo, c_hi, part, lane);
-    else pm_dw_dispatch_j<4>(A, blk, c_lo, c_hi, part, lane);
+    if (blk.n_ot <= 1) pm_dw_dispatch_j<1>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
+    else if (blk.n_ot <= 3) pm_dw_dispatch_j<3>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
+    else pm_dw_dispatch_j<4>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
   }
 }
 
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_kernel(const DwArgs A) {
 // (32- and 64-row workgroups, wide networks); the 16-row form is bound by HBM and stays fp32.
 template <int NI, int NJ>
 __device__ __forceinline__ void pm_dw_block_s(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
-                                              float* part, int lane) {
+                                              float* part, int lane, bool add) {
   const int g = lane >> 4, c16 = lane & 15;
   const int l = blk.layer;
   const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
@@ -336,7 +373,7 @@ __device__ __forceinline__ void pm_dw_block_s(const DwArgs& A, const DwBlock& bl
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int o = (blk.ot0 + i) * 16 + 4 * g + r;
-            if (o < O && k < K) part[A.w_off[l] + (size_t)o * K + k] = acc[i][j][r];
+            if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], add);
           }
         }
       if (do_bias) {
@@ -344,36 +381,36 @@ __device__ __forceinline__ void pm_dw_block_s(const DwArgs& A, const DwBlock& bl
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         const int o = (blk.ot0 + i) * 16 + c16;
-        if (g == 0 && o < O) part[A.b_off[l] + o] = s;
+        if (g == 0 && o < O) pm_dw_put(part + A.b_off[l] + o, s, add);
       }
     }
 }
 
 template <int NI>
 __device__ __forceinline__ void pm_dw_dispatch_js(const DwArgs& A, const DwBlock& blk, int c_lo, int c_hi,
-                                                  float* part, int lane) {
-  if (blk.n_it <= 1) pm_dw_block_s<NI, 1>(A, blk, c_lo, c_hi, part, lane);
-  else pm_dw_block_s<NI, PM_DW_TN_S>(A, blk, c_lo, c_hi, part, lane);
+                                                  float* part, int lane, bool add) {
+  if (blk.n_it <= 1) pm_dw_block_s<NI, 1>(A, blk, c_lo, c_hi, part, lane, add);
+  else pm_dw_block_s<NI, PM_DW_TN_S>(A, blk, c_lo, c_hi, part, lane, add);
 }
 
-// (chunks_per_split is even: a chunk pair never straddles two splits)
+// (chunks_per_split and c_begin are even: a chunk pair never straddles two rows or two launches; up to 256
+//  registers per lane, i.e. one workgroup per CU -- a CU holds this kernel or the adjoint sweep, never both)
 __global__ __launch_bounds__(PM_DW_NT, 1) void pm_dw_kernel_s(const DwArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x;
-  const int c_lo = split * A.chunks_per_split;
-  int n_chunks = A.n_chunks;
-  if (A.nvalid)
-    n_chunks = (int)min((long long)n_chunks,
-                        (long long)max(0, __builtin_amdgcn_readfirstlane(*A.nvalid)) * A.chunks_per_step);
-  const int c_hi = min(n_chunks, c_lo + A.chunks_per_split);
-  if (c_lo >= c_hi) return;
-  float* part = A.part + (size_t)split * A.part_stride;
+  const int row = blockIdx.x;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  float* part = A.part + (size_t)row * A.part_stride;
+  if (R.zero) {
+    for (int i = tid; i < A.part_stride; i += PM_DW_NT) part[i] = 0.f;
+    return;
+  }
   for (int bi = A.wave_first[wid]; bi < A.wave_first[wid + 1]; ++bi) {
     const DwBlock blk = A.blocks[bi];
-    if (blk.n_ot <= 1) pm_dw_dispatch_js<1>(A, blk, c_lo, c_hi, part, lane);
-    else if (blk.n_ot <= 3) pm_dw_dispatch_js<3>(A, blk, c_lo, c_hi, part, lane);
-    else pm_dw_dispatch_js<4>(A, blk, c_lo, c_hi, part, lane);
+    if (blk.n_ot <= 1) pm_dw_dispatch_js<1>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
+    else if (blk.n_ot <= 3) pm_dw_dispatch_js<3>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
+    else pm_dw_dispatch_js<4>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
   }
 }
 

@@ -1743,7 +1743,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       const size_t o = (size_t)row0 * D + i;
       float v = 0.f;
       if (EXT && A.gx_from_carry) v = A.gx_carry[o];
-      else if (EXT && A.grad_states) v = A.grad_states[(size_t)T0 * B * D + o];
+      else if (EXT && A.grad_states) v = A.grad_states[(size_t)max(T1, 0) * B * D + o];   // (T1: the truncated horizon's end)
       if (EXT && A.gx_carry && !(MMG && mm_states)) (A.gx_carry_out ? A.gx_carry_out : A.gx_carry)[o] = v;
       if (T0 == 0 && A.grad_x0) A.grad_x0[o] = v;
     }

@@ -29,6 +29,7 @@ struct NetPlan {
   size_t wf[PM_MAXL], wb[PM_MAXL], bias[PM_MAXL], abits[PM_MAXL];
 };
 
+#define PM_PIPE_MAX 8
 struct pmbrl_plan {
   pmbrl_config cfg;
   int device;
@@ -43,6 +44,12 @@ struct pmbrl_plan {
   AngleDev* ang_d;
   DwBlock* dw_blocks_d;
   int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
+  // dW GEMM behind the adjoint sweep (pmbrl_rollout_bwd): the sweep as pipe_K launches over descending step
+  // ranges [pipe_lo[k], pipe_lo[k-1]); the GEMM of range k runs on pipe_stream, on the CUs the sweep leaves
+  // idle, while the sweep is in range k+1.  pipe_K <= 1: off.
+  int pipe_K, pipe_lo[PM_PIPE_MAX], pipe_rows, pipe_grid;
+  hipStream_t pipe_stream;
+  hipEvent_t pipe_ev[PM_PIPE_MAX];
   int dw_wave_first[PM_DW_NW + 1];
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
