@@ -13,7 +13,7 @@ def fixture_names(kind=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
     if kind == 'iter':
         return [n for n in names if not n.startswith(('mcp_', 'ext_', 'standalone_', 'bnn_', 'experience_', 'critic_', 'bnnopt_',
-                                                      'trunc_'))]
+                                                      'trunc_', 'draw_'))]
     if kind == 'bnn':
         return [n for n in names if n.startswith('bnn_')]
     if kind == 'standalone':

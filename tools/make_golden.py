@@ -733,6 +733,47 @@ def make_resample_case(name, D=4, U=1, hid=(32, 32), B=24, H=8, seed=27):
     return d
 
 
+def make_cdrop_case(name, B=12, h=40, seed=51):
+    """The dropout DRAWS themselves (models/modules.py:55-58 BDropout.update_noise; :95-118
+    CDropout.update_noise / update_concrete_noise): uniform noise from a seeded generator, the concrete
+    probabilities sigmoid((logit_p + log((u + 1e-7) / (1 - (u - 1e-7)))) / temp) handed to torch.bernoulli, the
+    hard sample that comes back -- per-unit rates, two temperatures, eval mode (what a rollout uses)."""
+    print('[cdrop] %s' % name)
+    from prob_mbrl.models import modules as M
+    d = dict(seed=np.int64(seed), B=np.int64(B), h=np.int64(h))
+    orig = torch.bernoulli
+    for k, (temp, lo, hi) in enumerate(((0.1, 0.05, 0.5), (0.5, 0.2, 0.8))):
+        rate = torch.linspace(lo, hi, h)
+        cd = M.CDropout(rate, temperature=temp)
+        cd.eval()
+        seen = []
+
+        def bern(p, *a, **kw):
+            out = orig(p, *a, **kw)
+            seen.append((p.detach().clone(), out.detach().clone()))
+            return out
+
+        torch.bernoulli = bern
+        try:
+            cd.update_noise(torch.empty(B, h), seed=seed + k)
+        finally:
+            torch.bernoulli = orig
+        assert len(seen) == 1
+        d['rate%d' % k] = rate.double().numpy()
+        d['temp%d' % k] = np.float64(temp)
+        d['logit_p%d' % k] = cd.logit_p.detach().double().numpy()
+        d['u%d' % k] = cd.noise.detach().double().numpy()
+        d['probs%d' % k] = seen[0][0].double().numpy()
+        d['hard%d' % k] = seen[0][1].numpy()
+        assert bool((cd.concrete_noise.detach() == seen[0][1]).all())
+        d['p_after%d' % k] = cd.p.detach().double().numpy()
+    bd = M.BDropout(torch.linspace(0.05, 0.6, h))
+    bd.update_noise(torch.empty(B, h), seed=seed + 7)
+    d['b_rate'] = torch.linspace(0.05, 0.6, h).double().numpy()
+    d['hardb'] = bd.noise.detach().numpy()
+    return d
+
+
 def make_standalone_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, seed=11):
     """Stand-alone Policy.forward / DynamicsModel.forward of the reference (models/core.py:221-248,
     265-303) on B rows with the stored masks and noise (resample=False, resample_noise=False),
@@ -1175,6 +1216,7 @@ CASES = {
     'bnn_full': lambda: make_bnn_case('bnn_full', 5, 1, [200, 200], 300, 100, 2, 1e-4, seed=4),
     'bnn_gmm': lambda: make_bnn_case('bnn_gmm', 4, 1, [48, 48], 80, 30, 3, 1e-3, seed=6, n_comp=3),
     'experience_host': lambda: make_experience_case('experience_host'),
+    'draw_dropout': lambda: make_cdrop_case('draw_dropout'),
     'critic_fit': lambda: make_critic_case('critic_fit'),
     'bnnopt_decoupled': lambda: make_bnn_opts_case('bnnopt_decoupled', 'decoupled'),
     'bnnopt_prioritized': lambda: make_bnn_opts_case('bnnopt_prioritized', 'prioritized'),
