@@ -153,6 +153,7 @@ enum {
   PMBRL_INFO_DW_SPLITS = 6,
   PMBRL_INFO_PRECISION = 13, /* PMBRL_PREC_* actually in use */
   PMBRL_INFO_DW_PIPE = 14,   /* launches the adjoint sweep is cut into so that the dW GEMM runs behind it (1: no) */
+  PMBRL_INFO_MM_PARTS = 15,  /* workgroups a moment-matching group is split over (in-kernel moment matching; 1: whole groups) */
   PMBRL_INFO_COUNT = 16
 };
 

@@ -559,13 +559,14 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     const int m = sp.ca + sp.cb;
     return (maxnt + m - 1) / m * m * 16 + 8;   // room for the zero K padding
   };
-  auto lds_need = [&](int RT, int mmd) {
+  auto lds_need = [&](int RT, int mmd, int parts = 1) {
     p->LD = ld_for(RT);
     if (p->fast) {
-      // in-kernel moment matching: one wave per whole group of the workgroup
-      const int mw = (mmd && p->M <= 16 * RT) ? std::min(PF_NW, std::max(1, 16 * RT / p->M)) : PF_NW;
+      // in-kernel moment matching: one wave per whole group of the workgroup (a group split over `parts`
+      // workgroups: wave 0, and the whole group's rows in LDS)
+      const int mw = parts > 1 ? 1 : (mmd && p->M <= 16 * RT) ? std::min(PF_NW, std::max(1, 16 * RT / p->M)) : PF_NW;
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
-                                p->dyn.nl, mmd, prec_for(RT), mw) * sizeof(float);
+                                p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? p->M : 0) * sizeof(float);
     }
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
   };
@@ -589,6 +590,29 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         break;
       }
     }
+    // A group of 33..64 rows in ONE 64-row workgroup is throughput-bound on its CU (52 tile epilogues and
+    // 52 x 21 MFMAs per layer: 67 k cycles per step at the double cart-pole shape) while most of the chip idles.
+    // Split over two workgroups of <= 32 rows a step is 26 k cycles of GEMMs; the halves exchange their
+    // rows through HBM and meet at a group-local flag barrier (pm_group_sync), and each factors the whole
+    // group redundantly (the d x d fp64 chain is serial anyway).  Needs every workgroup resident (checked
+    // here like the device-wide barrier form).  PMBRL_MM_PARTS=1 keeps one workgroup per group.
+    p->mm_parts = 1;
+    {
+      const char* e = getenv("PMBRL_MM_PARTS");
+      const int want = e ? atoi(e) : 2;
+      int cus = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      const bool big = (p->mm_mode == 1 && p->RT == 4) || (e && (p->mm_mode == 1 || p->mm_mode == 2));   // (PMBRL_MM_PARTS=n: wherever it can be done -- tests)
+      if (p->fast && want >= 2 && want <= 8 && big && p->M % want == 0 && p->M / want <= 32 && p->M <= 64 &&
+          (c.flags & PMBRL_FLAG_MM_STATES) && c.B / (p->M / want) <= std::min(cus, 1024) &&
+          lds_need(2, c.D, want) <= lds_cap) {
+        p->mm_mode = 1;
+        p->mm_parts = want;
+        p->RT = p->M / want <= 16 ? 1 : 2;
+        p->rows_per_wg = p->M / want;
+        if (lds_need(p->RT, c.D, want) > lds_cap) { p->mm_parts = 1; p->mm_mode = 2; }
+      }
+    }
   }
   if (p->mm_mode != 1) {
     rt4_split = false;
@@ -606,7 +630,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     while (RT > 1 && lds_need(RT, 0) > lds_cap) RT /= 2;
     p->RT = RT;
     p->rows_per_wg = 16 * RT;
-  } else if (c.rows_per_wg_hint > 0) {
+  } else if (c.rows_per_wg_hint > 0 && p->mm_parts <= 1) {
     // allow the caller to force fewer groups per workgroup
     const int want = std::max(p->M, (c.rows_per_wg_hint / p->M) * p->M);
     if (want <= 16 * p->RT) p->rows_per_wg = want;
@@ -618,7 +642,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       !getenv("PMBRL_MM_MODE2") && lds_need(p->RT, c.D) <= lds_cap &&
       (size_t)2 * 16 * p->RT * ld_for(p->RT) * sizeof(float) >= (size_t)8 * 256 * sizeof(double))
     p->mm_mode = 3;
-  p->lds_bytes = lds_need(p->RT, (p->mm_mode == 1 || p->mm_mode == 3) ? c.D : 0);   // also fixes p->LD for the chosen RT
+  p->lds_bytes = lds_need(p->RT, (p->mm_mode == 1 || p->mm_mode == 3) ? c.D : 0, p->mm_parts);   // also fixes p->LD for the chosen RT
   { const StagePair sp = stages_for(p->RT); p->CA = sp.ca; p->CB = sp.cb; }
   p->prec = prec_for(p->RT);
   p->LDB = ldb_for(p->RT);
@@ -753,7 +777,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     const char* e = getenv("PMBRL_DW_PIPE");
     const int n_free = cus >= 64 && cus % 8 == 0 ? 8 * (cus / 8 - (p->nwg + 7) / 8) : 0;
-    const bool single = p->mm_mode == 0 || p->mm_mode == 1;
+    const bool single = (p->mm_mode == 0 || p->mm_mode == 1) && p->mm_parts <= 1;   // (no second kernel next to flag barriers)
     // Worth it where a range of the sweep is long against a launch boundary (tail of the last step, launch
     // gap, the next launch's prologue: 15 us at 16 rows per workgroup, 40 us at 64) -- measured: the double
     // cart-pole shape (64-row workgroups, 30 us per step) gains 7 % of an iteration, the cart-pole shapes
@@ -940,6 +964,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[12] = p->mm_grid;
   info[PMBRL_INFO_PRECISION] = p->prec;
   info[PMBRL_INFO_DW_PIPE] = p->pipe_K;
+  info[PMBRL_INFO_MM_PARTS] = p->mm_parts;
   return 0;
 }
 
@@ -1029,6 +1054,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.Ja = reinterpret_cast<float*>(ws + p->off_Ja);
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
   A.mm_grid = p->mm_grid;
+  A.mm_parts = p->mm_parts;
   A.gsync = reinterpret_cast<unsigned*>(ws + p->off_gsync);
   A.gx_carry_out = nullptr;
   if (p->fast) {
@@ -1190,6 +1216,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   } else if (p->mm_mode != 2) {
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
+    if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     launch_fwd_rt(p, As, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
@@ -1339,7 +1366,14 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   } else if (p->mm_mode != 2) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     A.gx_from_carry = 0;
+    if (p->mm_parts > 1) {
+      // groups split over workgroups: their own flags, and two buffers for the rows of dL/dx they exchange
+      A.gsync += 1024;
+      HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
+      A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
+    }
     launch_bwd_rt(p, A, s);
+    A.gx_carry_out = nullptr;
   } else {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
     if (grad_states_d) return fail(-3, "grad_states with external moment matching: not offered");

@@ -138,6 +138,10 @@ struct RolloutArgs {
   // backward only
   const float *grad_rewards, *grad_states, *grad_actions;
   float* gx_carry_out;   // mm_mode 3: the carried gradient is written here (ping-pong with gx_carry)
+  // in-kernel moment matching with a group SPLIT over mm_parts workgroups (>= 2; rows_per_wg = M / mm_parts):
+  // the workgroups of a group exchange their rows through HBM and meet at a group-local flag barrier
+  // (pmbrl_fast.h, pm_group_sync); every one of them factors the whole group, each keeps its own rows
+  int mm_parts;
   // mm_mode 3 with every workgroup resident at once: ONE launch over the horizon, the workgroups
   // meet at a device-wide barrier (arrival counter gsync) where the per-step launches ended
   int mm_grid;

@@ -152,6 +152,34 @@ __device__ __forceinline__ bool pm_grid_barrier(unsigned* flags, unsigned k) {
   return ok;
 }
 
+// The same between the `parts` consecutive workgroups that share a moment-matching group (flags[first .. first
+// + parts)): a handful of flags to poll instead of every workgroup's -- the device-wide barrier costs ~11 us at
+// 250 workgroups, this one a memory round trip.  Needs the group's workgroups resident together (the host
+// checks that ALL are, as for the device-wide barrier); a wait that does not end poisons the group's flags.
+__device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int parts, unsigned k) {
+  bool ok = true;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_max(flags + blockIdx.x, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    const int w = first + ((int)threadIdx.x < parts ? (int)threadIdx.x : 0);
+    long long spins = 0;
+    for (;;) {
+      const bool here = __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
+      if (__all(here)) break;
+      if (++spins > (1ll << 21)) {
+        ok = false;
+        __hip_atomic_fetch_max(flags + w, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (__hip_atomic_load(flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) ok = false;
+  }
+  __syncthreads();
+  return ok;
+}
+
 struct SdV {
   int n, v;
   int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l
@@ -976,8 +1004,10 @@ __host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
 #define PM_XIN_LD 24             // = 8 (mod 16): conflict-free ds_read_b128 of the MFMA B operand
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
-                                                     int dnl, int mm_d, int prec = 0, int mm_waves = PF_NW) {
-  // (mm_waves: waves that do in-kernel moment matching at once = whole groups per workgroup, at most PF_NW)
+                                                     int dnl, int mm_d, int prec = 0, int mm_waves = PF_NW,
+                                                     int mm_group_rows = 0) {
+  // (mm_waves: waves that do in-kernel moment matching at once = whole groups per workgroup, at most PF_NW;
+  //  mm_group_rows: rows of a group split over workgroups -- four row blocks of the whole group behind L.mm)
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
   if (!pm_fast_hp_alias(R, LD, RT)) n += (size_t)PF_NW * RT * 256;
   for (int l = 0; l < pnl; ++l) n += (size_t)pnt[l + 1] * 16;
@@ -996,6 +1026,7 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
   n += 2 * (size_t)mm_waves * pm_mm_scratch_doubles(mm_d);
+  n += 4 * (size_t)mm_group_rows * mm_d;
   return n;
 }
 
@@ -1458,6 +1489,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = VAR == PF_VAR_MM && A.mm_mode == 1 && mm_states;
+  // ... with the group split over mm_parts workgroups: first workgroup / first row of the group, and the LDS
+  // blocks [M][D] of the whole group's rows (sampled rows, noise rows, result) behind wave 0's scratch
+  const bool mm_pair = mm_in && A.mm_parts > 1;
+  const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
+  const int mmp_g0 = mmp_first * (MM ? A.rows_per_wg : 0);
+  float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
   // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
@@ -1525,10 +1562,18 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         // this step's moment-matching noise rows -> LDS, a whole step before they are needed (the
         // statistics loops of pm_mm_* would otherwise chase them through HBM one at a time)
         const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+        if (mm_pair) {     // the whole group's noise rows
+          const int z0 = pm_zrow0(t, A.row_off + mmp_g0, A.flags);
+          for (int i = tid; i < A.M * D; i += PF_NT) {
+            const int r = i / D, d = i - r * D;
+            mmg[A.M * D + i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
+          }
+        } else {
         const int z0 = pm_zrow0(t, A.row_off + row0, A.flags);
         for (int i = tid; i < nvalid * D; i += PF_NT) {
           const int r = i / D, d = i - r * D;
           L.zs[i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
+        }
         }
       }
     }
@@ -1639,7 +1684,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           if (r < nvalid) {
             const size_t o = ((size_t)t * B + row0 + r) * D + d;
             A.Td[o] = z * e * (1.f - sg);
-            if (mm_gs) pm_st_dev(A.xt + o, xn);        // read by the other workgroups after the barrier
+            if (mm_gs || mm_pair) pm_st_dev(A.xt + o, xn);   // read by other workgroups after the barrier
             else if (mm_states) A.xt[o] = xn;
             else A.states[o + (size_t)B * D] = xn;
           }
@@ -1656,7 +1701,30 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
     // after the sweep (so is the moment matching of rewards).  Only the moment matching of
     // STATES is part of the recursion.
-    if (mm_in) {
+    if (mm_pair) {
+      // every workgroup of the group has its sampled rows of this step in A.xt once the group has met; each of
+      // them then matches the moments of the WHOLE group (redundantly: the d x d chain is serial anyway) and
+      // keeps its own rows
+      if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(t - T0 + 1)) && tid == 0) atomicMin(A.status, t);
+      const float* xg = A.xt + ((size_t)t * B + mmp_g0) * D;
+      for (int i = tid; i < A.M * D; i += PF_NT) mmg[i] = pm_ldc<true>(xg + i);
+      __syncthreads();
+      if (wid == 0) {
+        bool ok = false;
+        double* fac = wg == mmp_first ? A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D) : nullptr;
+        if constexpr (SH::D >= 1 && SH::D <= 6)
+          ok = pm_mm_fwd_w<SH::D ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D, lane, fac);
+        else
+          ok = pm_mm_fwd(mmg, D, A.M, D, mmg + A.M * D, D, 0, 0, false, mmg + 2 * A.M * D, D, L.mm, lane, fac);
+        if (!ok && lane == 0) atomicMin(A.status, t);
+      }
+      __syncthreads();
+      const float* res = mmg + 2 * A.M * D + (row0 - mmp_g0) * D;
+      for (int i = tid; i < nvalid * D; i += PF_NT) {
+        xa[i] = res[i];
+        A.states[((size_t)(t + 1) * B + row0) * D + i] = res[i];
+      }
+    } else if (mm_in) {
       __syncthreads();
       const int gpw = rows_per_wg / A.M;
       for (int gi = wid; gi < gpw; gi += PF_NW) {
@@ -1899,6 +1967,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     if (k < U) L.gad[r * 16 + k] = (r < nvalid) ? stg[r * S] * stg[r * S + 1 + D + k] : 0.f;
   };
   const bool mm_in = VAR == PF_VAR_MM && (A.mm_mode == 1 && mms);
+  // group split over mm_parts workgroups (see the forward sweep): LDS blocks [M][D] of the whole group's
+  // pre-mm rows, noise rows, incoming gradient and result behind wave 0's scratch
+  const bool mm_pair = mm_in && A.mm_parts > 1;
+  const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
+  const int mmp_g0 = mmp_first * rows_per_wg;
+  float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
@@ -1964,7 +2038,42 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PF_MARK(29);
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // restore the zero K padding
     }
-    if (mm_in) {
+    if (mm_pair) {
+      // dL/dx_{t+1} of the whole group is needed: own rows -> HBM (two buffers alternate: a partner may already
+      // write step t-1's rows while this workgroup still reads step t's), meet the group, then the adjoint of
+      // the moment matching of the WHOLE group on wave 0 of every workgroup of it; each keeps its own rows
+      float* carry = ((T1 - 1 - t) & 1) ? A.gx_carry_out : A.gx_carry;
+      __syncthreads();
+      for (int i = tid; i < nvalid * D; i += PF_NT) pm_st_dev(carry + (size_t)row0 * D + i, gx[i]);
+      // (the group's pre-mm rows, noise rows and the forward sweep's factor: on their way while the rows above go out)
+      {
+        const float* xsrc = A.xt + ((size_t)t * B + mmp_g0) * D;
+        const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+        const int z0 = pm_zrow0(t, A.row_off + mmp_g0, A.flags);
+        for (int i = tid; i < A.M * D; i += PF_NT) {
+          const int r = i / D, d = i - r * D;
+          mmg[i] = xsrc[i];
+          mmg[A.M * D + i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
+        }
+        const double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
+        if (SH::D >= 1 && SH::D <= 6 && wid == 0)
+          for (int e = lane; e < (int)pm_mm_fac_doubles(D); e += 64) L.mm[e] = fac[e];
+      }
+      if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(T1 - t)) && tid == 0 && A.status) atomicMax(A.status, 1);
+      for (int i = tid; i < A.M * D; i += PF_NT) mmg[2 * A.M * D + i] = pm_ldc<true>(carry + (size_t)mmp_g0 * D + i);
+      __syncthreads();
+      if (wid == 0) {
+        if constexpr (SH::D >= 1 && SH::D <= 6)
+          pm_mm_bwd_l<SH::D ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D, mmg + 3 * A.M * D, D,
+                                         L.mm, lane, nullptr, true);
+        else
+          pm_mm_bwd(mmg, D, A.M, D, mmg + A.M * D, D, 0, 0, false, mmg + 2 * A.M * D, D, mmg + 3 * A.M * D, D, L.mm, lane,
+                    A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D));
+      }
+      __syncthreads();
+      for (int i = tid; i < R * D; i += PF_NT)
+        gxt[i] = i < nvalid * D ? mmg[3 * A.M * D + (row0 - mmp_g0) * D + i] : 0.f;
+    } else if (mm_in) {
       // adjoint of the in-kernel moment matching of states (needs the pre-mm rows)
       // (scratch rows: the idle activation buffer, or -- split precision, where a stray fp32 row would
       //  land in the piece planes' zero padding -- the input tile, which is free until phase A)

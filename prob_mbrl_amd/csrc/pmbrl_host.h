@@ -55,6 +55,7 @@ struct pmbrl_plan {
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
       off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, off_gmm_c, off_gmm_k, ws_bytes;
   int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
+  int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -91,6 +92,7 @@ struct ScopedTimer {
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 5, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 6, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, 232, 3, 13)        \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 6, 1, 232, 3, 13)        \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MM, 4, 1, 216, 3, 13)        \
   PM_FAST_SHAPED(4, 1, 1, PF_VAR_MM, 6, 1, 232, 3, 13)        \
   PM_FAST_SHAPED(1, 7, 6, PF_VAR_MMG, 4, 1, 216, 3, 13)       \
@@ -115,6 +117,7 @@ struct ScopedTimer {
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
+  PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 6, 1, LDV, 3, 13)         \
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)         \
   PM_SPLIT_SHAPED_RT4(LDV)
 

@@ -1,0 +1,122 @@
+"""In-kernel moment matching with a group SPLIT over several workgroups (pmbrl.hip: mm_parts; pmbrl_fast.h:
+pm_group_sync): the workgroups of a group exchange their rows through HBM, meet at a group-local flag barrier
+and each factors the whole group.  On by default where a group needs a 64-row workgroup (the double cart-pole
+shape: two 25-row workgroups instead); forced here on the ordinary fixtures (PMBRL_MM_PARTS=n) and compared with
+whole groups per workgroup and with the fp64 reference numbers."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_TRAJ, TOL_GRAD = 2e-5, 1e-4
+
+
+@contextlib.contextmanager
+def parts(n):
+    old = os.environ.get('PMBRL_MM_PARTS')
+    os.environ['PMBRL_MM_PARTS'] = str(n)
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ['PMBRL_MM_PARTS']
+        else:
+            os.environ['PMBRL_MM_PARTS'] = old
+
+
+def run(d, n, precision=None, n_valid=None, no_shaped=False):
+    dev = torch.device(DEV)
+    with parts(n):
+        eng, args, _ = common.engine_from_fixture(d, dev, precision=precision, no_shaped=no_shaped)
+    S, A, Rw = eng.forward(**args)
+    nv = eng.valid_steps()
+    if n_valid is not None:
+        eng.status[0] = n_valid
+    gw = torch.tensor(common.loss_weights(d, d['x0'].shape[0]), device=dev)
+    g, gx0, agn = eng.backward(gw, want_x0=True, want_agn=True)
+    torch.cuda.synchronize()
+    return eng, nv, S.cpu().numpy(), Rw.cpu().numpy(), g.cpu().numpy().copy(), gx0.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize('precision', ['f32', 'split_f16'])
+@pytest.mark.parametrize('name,n', [('mmg_d4', 2), ('dcp_d6_mmg', 2), ('dcp_d6_mmg', 3), ('dcp_d6_mmg', 4),
+                                    ('full200_mmg', 5), ('angles_dcp_mmg', 2)])
+def test_split_groups_match_whole_groups(name, n, precision):
+    d = common.load(name)
+    e1, nv1, S1, R1, g1, x1 = run(d, 1, precision)
+    if not e1.info['fast']:
+        pytest.skip('general kernel family')
+    e2, nv2, S2, R2, g2, x2 = run(d, n, precision)
+    assert e1.info['mm_parts'] == 1
+    assert e2.info['mm_parts'] == n and e2.info['mm_mode'] == 1, e2.info
+    assert e2.info['n_wg'] == n * e1.info['n_wg'] or e1.info['rows_per_wg'] != d['x0'].shape[0] // int(d['mm_groups'])
+    assert nv1 == nv2 == int(d['H'])
+    # the same group statistics from the same rows: only the summation order inside the GEMMs' K-split differs
+    assert common.rel(S2, S1) < 5e-6 and common.rel(g2, g1) < 2e-5
+    assert common.rel(S2, d['ref64_states']) < TOL_TRAJ
+    assert common.rel(R2.reshape(d['ref64_rewards'].shape), d['ref64_rewards']) < TOL_TRAJ
+    assert common.rel(g2, d['ref64_grad']) < TOL_GRAD
+    assert common.rel(x2, x1) < 2e-5
+
+
+def test_split_groups_truncated_horizon():
+    """trunc_mm: one group of 30 rows, H = 12, valid horizon 8: two workgroups of 15 rows."""
+    d = common.load('trunc_mm')
+    n = int(d['fail_step'])
+    e1, _, S1, _, g1, x1 = run(d, 1, n_valid=n)
+    e2, _, S2, _, g2, x2 = run(d, 2, n_valid=n)
+    assert e2.info['mm_parts'] == 2 and e2.info['rows_per_wg'] == 15
+    assert common.rel(g2, g1) < 2e-5 and common.rel(g2, d['ref64_grad']) < TOL_GRAD
+    assert common.rel(S2[:n + 1], d['ref64_states']) < TOL_TRAJ
+
+
+def test_double_cartpole_shape_splits_its_groups_by_default():
+    from prob_mbrl_amd import problem as PB
+    assert 'PMBRL_MM_PARTS' not in os.environ
+    pr = PB.synthetic_problem('dcartpole_mm', seed=0, data_seed=0)
+    eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 25 and eng.info['n_wg'] == 200, eng.info
+    pr = PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0)
+    eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    assert eng.info['mm_parts'] == 1, eng.info
+
+
+def test_split_groups_replay_in_a_graph():
+    """The flag barriers count from zero in every launch (their flags are cleared by a memset node of the graph)."""
+    d = common.load('dcp_d6_mmg')
+
+    def go(use_graph):
+        with parts(2):
+            eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+        assert eng.info['mm_parts'] == 2
+        gw = torch.tensor(common.loss_weights(d, d['x0'].shape[0]), device=DEV)
+        out = []
+
+        def step():
+            eng.forward(**args)
+            return eng.backward(gw)[0]
+
+        if not use_graph:
+            for _ in range(3):
+                g = step()
+            return g.cpu().numpy().copy()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g = step()
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        return g.cpu().numpy().copy()
+
+    assert np.array_equal(go(False), go(True))
