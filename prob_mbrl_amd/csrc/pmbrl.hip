@@ -602,15 +602,21 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       const int want = e ? atoi(e) : 2;
       int cus = 0;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-      const bool big = (p->mm_mode == 1 && p->RT == 4) || (e && (p->mm_mode == 1 || p->mm_mode == 2));   // (PMBRL_MM_PARTS=n: wherever it can be done -- tests)
-      if (p->fast && want >= 2 && want <= 8 && big && p->M % want == 0 && p->M / want <= 32 && p->M <= 64 &&
-          (c.flags & PMBRL_FLAG_MM_STATES) && c.B / (p->M / want) <= std::min(cus, 1024) &&
-          lds_need(2, c.D, want) <= lds_cap) {
-        p->mm_mode = 1;
-        p->mm_parts = want;
-        p->RT = p->M / want <= 16 ? 1 : 2;
-        p->rows_per_wg = p->M / want;
-        if (lds_need(p->RT, c.D, want) > lds_cap) { p->mm_parts = 1; p->mm_mode = 2; }
+      // by default where a group needs more than 16 rows: 64-row workgroups (M = 33..64) are throughput-bound on
+      // their CU, and a 32-row workgroup (M = 17..32) still takes 30 k cycles per step against 24 k for two
+      // 16-row ones with the exchange (measured on the cart-pole shapes); PMBRL_MM_PARTS=n: wherever it can be
+      // done (tests)
+      const bool big = (p->mm_mode == 1 && p->RT >= 2) || (e && (p->mm_mode == 1 || p->mm_mode == 2));
+      const int rpw = (p->M + want - 1) / std::max(1, want);      // the last part takes what is left of the group
+      if (p->fast && want >= 2 && want <= 8 && big && p->M <= 64 && rpw <= 32 && (want - 1) * rpw < p->M &&
+          (c.flags & PMBRL_FLAG_MM_STATES) && p->G * want <= std::min(cus, 1024)) {
+        const int rt = rpw <= 16 ? 1 : 2;
+        if (lds_need(rt, c.D, want) <= lds_cap) {
+          p->mm_mode = 1;
+          p->mm_parts = want;
+          p->RT = rt;
+          p->rows_per_wg = rpw;
+        }
       }
     }
   }
@@ -647,7 +653,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->prec = prec_for(p->RT);
   p->LDB = ldb_for(p->RT);
   if (p->lds_bytes > lds_cap) { delete p; return fail(-3, "network too wide for the fused kernel's LDS budget"); }
-  p->nwg = (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
+  p->nwg = p->mm_parts > 1 ? p->G * p->mm_parts : (c.B + p->rows_per_wg - 1) / p->rows_per_wg;
   // groups spanning workgroups, every workgroup resident at once (one per CU always fits): the
   // per-step launches become one launch whose workgroups meet at a device-wide barrier per step
   p->mm_grid = 0;

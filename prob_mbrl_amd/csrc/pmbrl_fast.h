@@ -1382,8 +1382,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
   const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
-  const int row0 = wg * rows_per_wg;
-  const int nvalid = min(rows_per_wg, A.B - row0);
+  // (a group split over mm_parts workgroups: part p owns rows [p * rows_per_wg, ...) of its group, the last
+  //  part what is left of the group's M rows)
+  const int mmp_n = (VAR == PF_VAR_MM && A.mm_mode == 1) ? A.mm_parts : 1;
+  const int row0 = mmp_n > 1 ? (wg / mmp_n) * A.M + (wg % mmp_n) * rows_per_wg : wg * rows_per_wg;
+  const int nvalid = mmp_n > 1 ? min(rows_per_wg, A.M - (wg % mmp_n) * rows_per_wg) : min(rows_per_wg, A.B - row0);
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
@@ -1493,7 +1496,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // blocks [M][D] of the whole group's rows (sampled rows, noise rows, result) behind wave 0's scratch
   const bool mm_pair = mm_in && A.mm_parts > 1;
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
-  const int mmp_g0 = mmp_first * (MM ? A.rows_per_wg : 0);
+  const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
   float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
@@ -1799,8 +1802,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
   const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
-  const int row0 = wg * rows_per_wg;
-  const int nvalid = min(rows_per_wg, A.B - row0);
+  // (a group split over mm_parts workgroups: part p owns rows [p * rows_per_wg, ...) of its group, the last
+  //  part what is left of the group's M rows)
+  const int mmp_n = (VAR == PF_VAR_MM && A.mm_mode == 1) ? A.mm_parts : 1;
+  const int row0 = mmp_n > 1 ? (wg / mmp_n) * A.M + (wg % mmp_n) * rows_per_wg : wg * rows_per_wg;
+  const int nvalid = mmp_n > 1 ? min(rows_per_wg, A.M - (wg % mmp_n) * rows_per_wg) : min(rows_per_wg, A.B - row0);
   const int D = SH::D ? SH::D : A.D, U = SH::U ? SH::U : A.U, LD = SH::LD ? SH::LD : A.LD, B = A.B;
   const NetDev& P = A.pol;
   const NetDev& F = A.dyn;
@@ -1971,7 +1977,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // pre-mm rows, noise rows, incoming gradient and result behind wave 0's scratch
   const bool mm_pair = mm_in && A.mm_parts > 1;
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
-  const int mmp_g0 = mmp_first * rows_per_wg;
+  const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
   float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);

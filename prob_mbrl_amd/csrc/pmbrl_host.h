@@ -117,6 +117,7 @@ struct ScopedTimer {
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 5, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_LEAN, 6, 1, LDV, 3, 13)       \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
+  PM_FAST_SHAPED(1, 4, 3, PF_VAR_MM, 4, 1, LDV, 3, 13)         \
   PM_FAST_SHAPED(2, 4, 3, PF_VAR_MM, 6, 1, LDV, 3, 13)         \
   PM_FAST_SHAPED(1, 4, 3, PF_VAR_MMG, 5, 1, LDV, 3, 13)         \
   PM_SPLIT_SHAPED_RT4(LDV)
