@@ -573,6 +573,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->G = 1;
   p->M = c.B;
   p->mm_mode = 0;
+  p->mm_parts = 1;
   if (mm) {
     p->G = c.mm_groups > 0 ? c.mm_groups : 1;
     if (c.B % p->G) { delete p; return fail(-2, "B must be divisible by mm_groups"); }

@@ -168,7 +168,7 @@ __device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int pa
     for (;;) {
       const bool here = __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
       if (__all(here)) break;
-      if (++spins > (1ll << 21)) {
+      if (++spins > (1ll << 19)) {     // ~1 s: gives up once for the group, like pm_grid_barrier
         ok = false;
         __hip_atomic_fetch_max(flags + w, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;

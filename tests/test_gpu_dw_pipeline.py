@@ -20,15 +20,19 @@ TOL_GRAD = 1e-4
 
 @contextlib.contextmanager
 def pipe(spec):
-    old = os.environ.get('PMBRL_DW_PIPE')
-    os.environ['PMBRL_DW_PIPE'] = spec
+    # (whole moment-matching groups per workgroup: groups split over workgroups meet at flag barriers and do not
+    #  share the chip with a second kernel -- the plan leaves the pipeline off for them)
+    new = {'PMBRL_DW_PIPE': spec, 'PMBRL_MM_PARTS': '1'}
+    old = {k: os.environ.get(k) for k in new}
+    os.environ.update(new)
     try:
         yield
     finally:
-        if old is None:
-            del os.environ['PMBRL_DW_PIPE']
-        else:
-            os.environ['PMBRL_DW_PIPE'] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 def ranges(H, K):
@@ -171,5 +175,9 @@ def test_long_sweeps_are_pipelined_by_default():
     assert 'PMBRL_DW_PIPE' not in os.environ
     for name, want in (('dcartpole_mm', 4), ('cartpole_nomm', 1)):
         pr = PB.synthetic_problem(name, seed=0, data_seed=0)
-        eng = PB.engine_from_problem(pr, dev)[0]
+        os.environ['PMBRL_MM_PARTS'] = '1'       # (64-row workgroups: one per 50-row group)
+        try:
+            eng = PB.engine_from_problem(pr, dev)[0]
+        finally:
+            del os.environ['PMBRL_MM_PARTS']
         assert eng.info['dw_pipe'] == want, (name, eng.info)

@@ -5,6 +5,7 @@ launch), which the small fixtures never reach.  Checked against the oracle where
 seconds, and through size-independent properties everywhere: the specialised, the general and
 the EXT instantiations are the same arithmetic (bit-identical results), the gradient is linear in
 the loss weights, and rows are independent (a row permutation permutes the trajectories)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -68,7 +69,9 @@ def test_full_size_matches_oracle(config):
     from oracle import ref_torch as R
     d = _problem(config)
     eng, S, A, Rw, loss, g, _ = _run(d)
-    assert eng.info['fast'] == 1 and eng.info['rows_per_wg'] == (16 if config == 'cartpole_nomm' else 25)
+    # (cartpole_mm: every 25-row group split over two 16-row workgroups, 13 + 12 rows)
+    assert eng.info['fast'] == 1 and eng.info['rows_per_wg'] == (16 if config == 'cartpole_nomm' else 13)
+    assert eng.info['mm_parts'] == (1 if config == 'cartpole_nomm' else 2)
     x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
     torch.set_num_threads(8)
     l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
@@ -201,14 +204,22 @@ def test_c5_shape_matches_oracle():
     assert common.rel(S2, S) < 1e-6 and common.rel(g2, g) < 1e-5
 
 
-def test_c4_full_size_matches_oracle():
+@pytest.mark.parametrize('parts', [2, 1], ids=['split_groups', 'whole_groups'])
+def test_c4_full_size_matches_oracle(parts):
     """BASELINE.json configs[3], one GPU's share: D=6, 100 x 50 rows in 50-row moment-matching groups,
-    the real horizon H=60, against the fp64 oracle."""
+    the real horizon H=60, against the fp64 oracle -- with every group split over two 32-row workgroups (the
+    default at this size) and with one 64-row workgroup per group (what a plan with more than 128 groups uses)."""
     from oracle import ref_torch as R
     d = _problem('dcartpole_mm')
     assert int(d['H']) == 60 and d['x0'].shape == (5000, 6)
-    eng, S, A, Rw, loss, g, _ = _run(d)
-    assert eng.info['fast'] == 1 and eng.info['mm_mode'] == 1 and eng.info['rows_per_wg'] == 50
+    if parts == 1:
+        os.environ['PMBRL_MM_PARTS'] = '1'
+    try:
+        eng, S, A, Rw, loss, g, _ = _run(d)
+    finally:
+        os.environ.pop('PMBRL_MM_PARTS', None)
+    assert eng.info['fast'] == 1 and eng.info['mm_mode'] == 1 and eng.info['mm_parts'] == parts
+    assert eng.info['rows_per_wg'] == 50 // parts and eng.info['row_tiles'] == (2 if parts == 2 else 4)
     x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
     torch.set_num_threads(16)
     l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,

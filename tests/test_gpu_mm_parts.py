@@ -88,9 +88,14 @@ def test_double_cartpole_shape_splits_its_groups_by_default():
     pr = PB.synthetic_problem('dcartpole_mm', seed=0, data_seed=0)
     eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
     assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 25 and eng.info['n_wg'] == 200, eng.info
+    # 25-row groups: 13 + 12 rows in two 16-row workgroups instead of one 32-row workgroup
     pr = PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0)
     eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
-    assert eng.info['mm_parts'] == 1, eng.info
+    assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 13 and eng.info['n_wg'] == 200, eng.info
+    # more groups than half the CUs: whole groups per workgroup as before
+    pr = PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0, P=160)
+    eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    assert eng.info['mm_parts'] == 1 and eng.info['rows_per_wg'] == 25, eng.info
 
 
 def test_split_groups_replay_in_a_graph():
