@@ -600,19 +600,30 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->mm_parts = 1;
     {
       const char* e = getenv("PMBRL_MM_PARTS");
-      const int want = e ? atoi(e) : 2;
       int cus = 0;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-      // by default where a group needs more than 16 rows: 64-row workgroups (M = 33..64) are throughput-bound on
+      const int max_wg = std::min(cus, 1024);
+      // By default where a group needs more than 16 rows: 64-row workgroups (M = 33..64) are throughput-bound on
       // their CU, and a 32-row workgroup (M = 17..32) still takes 30 k cycles per step against 24 k for two
-      // 16-row ones with the exchange (measured on the cart-pole shapes); PMBRL_MM_PARTS=n: wherever it can be
-      // done (tests)
-      // ... and where a group of <= 64 rows fits no workgroup at all (LDS): the device-wide-barrier form would
-      // take over otherwise (D = 6, 2 x 256 hidden units, 50-row groups: 8.9 ms against 4.0 ms per iteration)
+      // 16-row ones with the exchange (measured on the cart-pole shapes, also with unshaped networks) -- and
+      // where a group fits no workgroup at all (more than 64 rows, or LDS): the device-wide-barrier form would
+      // take over otherwise (D = 6, 2 x 256 hidden units, 50-row groups: 8.9 ms against 4.0 ms per iteration).
+      // Groups of up to 128 rows (beyond 64 the one-wave routines walk the rows in strides).  The fewest parts
+      // that bring a part down to 16 rows while every workgroup stays resident, else to 32 rows.
+      // PMBRL_MM_PARTS=n: n parts wherever that can be done (tests); 1: whole groups.
       const bool big = (p->mm_mode == 1 && p->RT >= 2) || p->mm_mode == 2 || (e && p->mm_mode == 1);
-      const int rpw = (p->M + want - 1) / std::max(1, want);      // the last part takes what is left of the group
-      if (p->fast && want >= 2 && want <= 8 && big && p->M <= 64 && rpw <= 32 && (want - 1) * rpw < p->M &&
-          (c.flags & PMBRL_FLAG_MM_STATES) && p->G * want <= std::min(cus, 1024)) {
+      auto fits = [&](int parts, int max_rows) {
+        const int rpw = (p->M + parts - 1) / parts;      // the last part takes what is left of the group
+        return rpw <= max_rows && (parts - 1) * rpw < p->M && p->G * parts <= max_wg;
+      };
+      int want = 0;
+      if (e) want = atoi(e);
+      else {
+        for (int parts = 2; parts <= 8 && !want; ++parts) if (fits(parts, 16)) want = parts;
+        for (int parts = 2; parts <= 8 && !want; ++parts) if (fits(parts, 32)) want = parts;
+      }
+      if (p->fast && want >= 2 && want <= 8 && big && p->M <= 128 && fits(want, 32) && (c.flags & PMBRL_FLAG_MM_STATES)) {
+        const int rpw = (p->M + want - 1) / want;
         const int rt = rpw <= 16 ? 1 : 2;
         if (lds_need(rt, c.D, want) <= lds_cap) {
           p->mm_mode = 1;

@@ -1715,8 +1715,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       if (wid == 0) {
         bool ok = false;
         double* fac = wg == mmp_first ? A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D) : nullptr;
-        if constexpr (SH::D >= 1 && SH::D <= 6)
-          ok = pm_mm_fwd_w<SH::D ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D, lane, fac);
+        // (the compile-time-width routines keep one row per lane: groups of up to 64 rows)
+        if (SH::D >= 1 && SH::D <= 6 && A.M <= 64)
+          ok = pm_mm_fwd_w<(SH::D >= 1 && SH::D <= 6) ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D, lane, fac);
         else
           ok = pm_mm_fwd(mmg, D, A.M, D, mmg + A.M * D, D, 0, 0, false, mmg + 2 * A.M * D, D, L.mm, lane, fac);
         if (!ok && lane == 0) atomicMin(A.status, t);
@@ -2062,16 +2063,16 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
           mmg[A.M * D + i] = zb[(size_t)pm_zidx(z0, r, A.Bg) * D + d];
         }
         const double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
-        if (SH::D >= 1 && SH::D <= 6 && wid == 0)
+        if (SH::D >= 1 && SH::D <= 6 && A.M <= 64 && wid == 0)
           for (int e = lane; e < (int)pm_mm_fac_doubles(D); e += 64) L.mm[e] = fac[e];
       }
       if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(T1 - t)) && tid == 0 && A.status) atomicMax(A.status, 1);
       for (int i = tid; i < A.M * D; i += PF_NT) mmg[2 * A.M * D + i] = pm_ldc<true>(carry + (size_t)mmp_g0 * D + i);
       __syncthreads();
       if (wid == 0) {
-        if constexpr (SH::D >= 1 && SH::D <= 6)
-          pm_mm_bwd_l<SH::D ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D, mmg + 3 * A.M * D, D,
-                                         L.mm, lane, nullptr, true);
+        if (SH::D >= 1 && SH::D <= 6 && A.M <= 64)
+          pm_mm_bwd_l<(SH::D >= 1 && SH::D <= 6) ? SH::D : 1>(mmg, D, A.M, mmg + A.M * D, D, mmg + 2 * A.M * D, D,
+                                                                mmg + 3 * A.M * D, D, L.mm, lane, nullptr, true);
         else
           pm_mm_bwd(mmg, D, A.M, D, mmg + A.M * D, D, 0, 0, false, mmg + 2 * A.M * D, D, mmg + 3 * A.M * D, D, L.mm, lane,
                     A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D));

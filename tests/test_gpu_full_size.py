@@ -133,7 +133,24 @@ def test_groups_spanning_workgroups_match_oracle(groups):
     from oracle import ref_torch as R
     d = _problem('cartpole_mm', 12)
     d['mm_groups'] = np.asarray(groups)
+    # (100-row groups would by default be split over seven workgroups with a group-local barrier -- below; this
+    #  test is about the device-wide-barrier form, which serves the groups of more than 128 rows)
+    if groups:
+        eng7, S7, A7, Rw7, loss7, g7, _ = _run(d)
+        assert eng7.info['mm_mode'] == 1 and eng7.info['mm_parts'] == 7 and eng7.info['rows_per_wg'] == 15
+    os.environ['PMBRL_MM_PARTS'] = '1'
+    try:
+        _spanning_forms(d, groups, (S7, g7) if groups else None)
+    finally:
+        del os.environ['PMBRL_MM_PARTS']
+
+
+def _spanning_forms(d, groups, split):
+    import os
+    from oracle import ref_torch as R
     eng, S, A, Rw, loss, g, _ = _run(d)
+    if split is not None:
+        assert common.rel(split[0], S) < 5e-6 and common.rel(split[1], g) < 2e-5
     # every workgroup is resident at once here: ONE launch per sweep, a device-wide barrier per step
     assert eng.info['mm_mode'] == 3 and eng.info['rows_per_wg'] == 16 and eng.info['mm_grid'] == 1
     x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)

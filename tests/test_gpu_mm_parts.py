@@ -47,7 +47,8 @@ def run(d, n, precision=None, n_valid=None, no_shaped=False):
 @pytest.mark.parametrize('precision', ['f32', 'split_f16'])
 @pytest.mark.parametrize('name,n', [('mmg_d4', 2), ('mmg_d4', 3), ('mmg_d4', 4), ('dcp_d6_mmg', 2), ('dcp_d6_mmg', 3),
                                     ('dcp_d6_mmg', 4), ('full200_mmg', 2), ('full200_mmg', 3), ('full200_mmg', 5),
-                                    ('mmg_h40', 2), ('mm1_b100_h40', 4), ('angles_dcp_mmg', 2)])
+                                    ('mmg_h40', 2), ('mm1_b100_h40', 4), ('mm1_b100', 7), ('mmg_m80', 3), ('mmg_m80', 5),
+                                    ('angles_dcp_mmg', 2)])
 def test_split_groups_match_whole_groups(name, n, precision):
     d = common.load(name)
     e1, nv1, S1, R1, g1, x1 = run(d, 1, precision)
@@ -56,8 +57,7 @@ def test_split_groups_match_whole_groups(name, n, precision):
     e2, nv2, S2, R2, g2, x2 = run(d, n, precision)
     G = max(1, int(d['mm_groups']))
     M = d['x0'].shape[0] // G
-    if M > 64:
-        pytest.skip('group too large for one wave')
+    assert M <= 128      # (beyond 64 rows the one-wave routines walk the rows in strides)
     assert e1.info['mm_parts'] == 1
     # (unequal parts: the last workgroup of a group takes what is left of its M rows)
     assert e2.info['mm_parts'] == n and e2.info['mm_mode'] == 1 and e2.info['n_wg'] == n * G, e2.info
@@ -80,6 +80,17 @@ def test_split_groups_truncated_horizon():
     assert e2.info['mm_parts'] == 2 and e2.info['rows_per_wg'] == 15
     assert common.rel(g2, g1) < 2e-5 and common.rel(g2, d['ref64_grad']) < TOL_GRAD
     assert common.rel(S2[:n + 1], d['ref64_states']) < TOL_TRAJ
+
+
+def test_number_of_parts_chosen_by_the_plan():
+    """The fewest parts that bring a part down to 16 rows with every workgroup resident, else to 32 rows."""
+    assert 'PMBRL_MM_PARTS' not in os.environ
+    dev = torch.device(DEV)
+    for name, parts, rows in (('mm1_b100', 7, 15), ('mmg_m80', 5, 16), ('mmg_h40', 2, 13), ('dcp_d6_mmg', 1, 12),
+                              ('trunc_mm', 2, 15)):
+        d = common.load(name)
+        eng = common.engine_from_fixture(d, dev)[0]
+        assert (eng.info['mm_parts'], eng.info['rows_per_wg']) == (parts, rows), (name, eng.info)
 
 
 def test_double_cartpole_shape_splits_its_groups_by_default():
