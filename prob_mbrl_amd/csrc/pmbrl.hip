@@ -396,7 +396,8 @@ static int set_attr(size_t lds) {
 // blocks, dealt to the four SIMDs (waves w and w+4 share SIMD w) by decreasing size so that
 // every SIMD issues the same number of MFMAs.  Returns the number of blocks; `blocks` comes back
 // sorted by wave, wave w owning [wave_first[w], wave_first[w+1]).
-static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, int* wave_first, int tn_max = PM_DW_TN) {
+static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, int* wave_first, int tn_max = PM_DW_TN,
+                           const bool* skip = nullptr) {
   blocks.clear();
   auto split = [](int n, int maxsz, std::vector<std::pair<int, int>>& out) {
     const int parts = (n + maxsz - 1) / maxsz;
@@ -408,6 +409,7 @@ static int build_dw_blocks(int nl, const int* nt, std::vector<DwBlock>& blocks, 
     }
   };
   for (int l = 0; l < nl; ++l) {
+    if (skip && skip[l]) continue;      // a wide layer: pm_dw_wide_kernel
     std::vector<std::pair<int, int>> os, is;
     split(nt[l + 1], PM_DW_TM, os);
     split(nt[l], tn_max, is);
@@ -772,15 +774,33 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // core -- 32- / 64-row workgroups and the general family's wide networks; the 16-row sweeps' dW is HBM-bound
     p->dw_split = p->prec != 0 && (p->RT >= 2 || !p->fast) && !getenv("PMBRL_DW_F32");
     if (getenv("PMBRL_DW_SPLIT") && p->prec != 0) p->dw_split = 1;
-    p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first, p->dw_split ? PM_DW_TN_S : PM_DW_TN);
+    // wide layers of the split form go to the LDS-staged tile kernel (pmbrl_dw.h, pm_dw_wide_kernel)
+    bool wide[PM_MAXL] = {false};
+    std::vector<DwUnit> units;
+    if (p->dw_split && !getenv("PMBRL_DW_NO_WIDE"))
+      for (int l = 0; l < p->pol.nl; ++l)
+        if (p->pol.nt[l + 1] * 16 >= 2 * PM_DWW_TM && p->pol.nt[l] * 16 >= 2 * PM_DWW_TN) {
+          wide[l] = true;
+          for (int m0 = 0; m0 < p->pol.nt[l + 1] * 16; m0 += PM_DWW_TM)
+            for (int n0 = 0; n0 < p->pol.nt[l] * 16; n0 += PM_DWW_TN) units.push_back(DwUnit{(int16_t)l, (int16_t)m0, (int16_t)n0, 0});
+        }
+    p->n_dw_units = (int)units.size();
+    if (p->n_dw_units) {
+      HIPCHK(hipMalloc(&p->dw_units_d, units.size() * sizeof(DwUnit)));
+      HIPCHK(hipMemcpy(p->dw_units_d, units.data(), units.size() * sizeof(DwUnit), hipMemcpyHostToDevice));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_wide_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWW_LDS_BYTES));
+    }
+    p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first, p->dw_split ? PM_DW_TN_S : PM_DW_TN, wide);
     p->dw_n_chunks = c.H * p->nwg * p->RT;
     int nsplit = std::min(256, p->dw_n_chunks);   // one 8-wave workgroup per CU
     p->dw_chunks_per_split = (p->dw_n_chunks + nsplit - 1) / nsplit;
     if (p->dw_split) p->dw_chunks_per_split = (p->dw_chunks_per_split + 1) & ~1;   // whole chunk pairs
     p->dw_nsplit = (p->dw_n_chunks + p->dw_chunks_per_split - 1) / p->dw_chunks_per_split;
-    HIPCHK(hipMalloc(&p->dw_blocks_d, blocks.size() * sizeof(DwBlock)));
-    HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock),
-                     hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&p->dw_blocks_d, std::max<size_t>(1, blocks.size()) * sizeof(DwBlock)));
+    if (!blocks.empty())
+      HIPCHK(hipMemcpy(p->dw_blocks_d, blocks.data(), blocks.size() * sizeof(DwBlock),
+                       hipMemcpyHostToDevice));
   }
   {
     // dW GEMM behind the adjoint sweep.  The sweep is latency-bound and holds nwg CUs completely (its
@@ -957,6 +977,7 @@ extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
   if (p->wflag_d) (void)hipFree(p->wflag_d);
   if (p->ang_d) (void)hipFree(p->ang_d);
   if (p->dw_blocks_d) (void)hipFree(p->dw_blocks_d);
+  if (p->dw_units_d) (void)hipFree(p->dw_units_d);
   if (p->pipe_stream) {
     (void)hipStreamDestroy(p->pipe_stream);
     for (int k = 0; k < p->pipe_K; ++k) (void)hipEventDestroy(p->pipe_ev[k]);
@@ -1345,6 +1366,9 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     if (p->dw_split) Wk.chunks_per_split = (Wk.chunks_per_split + 1) & ~1;
     if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
     else hipLaunchKernelGGL(pm_dw_kernel, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
+    if (p->n_dw_units)
+      hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((Wk.nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, st, Wk,
+                         p->dw_units_d, p->n_dw_units);
   };
   if (p->mm_mode == 3) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
@@ -1417,8 +1441,13 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
       HIPCHK(hipStreamWaitEvent(s, p->pipe_ev[p->pipe_K - 1], 0));
       launch_dw(p->pipe_K - 1, s);
     }
-    else if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
-    else hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+    else {
+      if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+      else hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+      if (p->n_dw_units)
+        hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((p->dw_nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, s, W,
+                           p->dw_units_d, p->n_dw_units);
+    }
   }
   const int n = (int)p->pol.n_params;
   {

@@ -37,6 +37,16 @@ struct DwBlock {      // one wave block
   int16_t layer, ot0, it0, n_ot, n_it, pad;
 };
 
+// one 256 x 128 output tile of a wide layer (pm_dw_wide_kernel)
+struct DwUnit {
+  int16_t layer, m0, n0, pad;      // first output feature / first input feature of the tile
+};
+#define PM_DWW_TM 128
+#define PM_DWW_TN 128
+#define PM_DWW_LDK 40
+#define PM_DWW_STAGE ((PM_DWW_TM + PM_DWW_TN) * 2 * PM_DWW_LDK)      // 16-bit elements per stage
+#define PM_DWW_LDS_BYTES (2 * PM_DWW_STAGE * 2)
+
 struct DwArgs {
   int nl, nsplit, n_chunks, chunks_per_split;
   int RT, Rw, n_params;
@@ -411,6 +421,179 @@ __global__ __launch_bounds__(PM_DW_NT, 1) void pm_dw_kernel_s(const DwArgs A) {
     if (blk.n_ot <= 1) pm_dw_dispatch_js<1>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
     else if (blk.n_ot <= 3) pm_dw_dispatch_js<3>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
     else pm_dw_dispatch_js<4>(A, blk, R.c_lo, R.c_hi, part, lane, R.add);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Wide layers (both widths >= 128: the 512 x 512 layers of the stress shape).  The block kernels above give every
+// wave its own 4 x 4-tile block and let it fetch and split its operands itself: at 32 x 32 tiles per layer every
+// stash tile is fetched and converted by eight waves, with one memory round trip exposed per chunk pair (15 ms
+// for 1.8 TFLOP).  Here a workgroup owns a 128 x 128 output tile of ONE layer over its row-step range; per K = 32
+// row-steps the two operand tiles are fetched once (registers, a step ahead), split once into two bf16 pieces
+// and staged in LDS ([piece][feature][32 + 8 bf16]: 80-byte rows, conflict-free b128 reads), double-buffered,
+// one barrier per step; every wave accumulates 2 x 4 tiles.  116 registers and 80 KB of LDS: two workgroups per
+// CU, one in its MFMAs while the other converts and stages.  Same partial-row scheme as the block kernels
+// (row = split of the row-step range).  Measured at the stress shape: 15.3 -> 7.7 ms for the whole dW step
+// (6.5 ms this kernel: 52 GB from L2 at the ~31 B/clk a CU pulls -- that, not the matrix pipe, is its bound;
+// 256 x 128 tiles with one workgroup per CU: 6.9 ms, phases serialised).
+__global__ __launch_bounds__(PM_DW_NT, 4) void pm_dw_wide_kernel(const DwArgs A, const DwUnit* __restrict__ units,
+                                                                  int n_units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short dww_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroups go round-robin to the 8 XCDs (each with its own L2): the tiles of one row-step range share their
+  // operands -- a 256-feature delta tile is read by every input tile of its layer -- so all tiles of a range are
+  // dealt to ONE XCD, next to each other in its dispatch order (XCD x works on the ranges x, x + 8, ...).  Dealt
+  // to eight XCDs they fetched eight copies: 40 GB through HBM instead of 13 at the 3 x 512 stress shape.
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int row = (jx / n_units) * 8 + xcd, unit = jx % n_units;
+  if (row >= A.nsplit) return;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  const DwUnit U = units[unit];
+  const int l = U.layer;
+  const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
+  const int O = A.dim[l + 1], K = A.dim[l];
+  float* part = A.part + (size_t)row * A.part_stride;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int wm = wid & 3, wn = wid >> 2;      // 32 output features (2 tiles) x 64 input features (4 tiles) per wave
+  if (R.zero) {
+    for (int e = tid; e < PM_DWW_TM * PM_DWW_TN; e += PM_DW_NT) {
+      const int o = U.m0 + e / PM_DWW_TN, k = U.n0 + e % PM_DWW_TN;
+      if (o < O && k < K) part[A.w_off[l] + (size_t)o * K + k] = 0.f;
+    }
+    if (U.n0 == 0)
+      for (int e = tid; e < PM_DWW_TM; e += PM_DW_NT)
+        if (U.m0 + e < O) part[A.b_off[l] + U.m0 + e] = 0.f;
+    return;
+  }
+  const float* gbase = A.gT[l];
+  const float* abase = A.actT[l];
+  const size_t gblk = (size_t)Fo16 * A.Rw, ablk = (size_t)Fi16 * A.Rw;
+  // staging: thread -> (feature f = idx >> 3, k quad kq = idx & 7), idx = tid + 512 j
+  f32x4 ra0[2], rb0[2];
+  float bs[2] = {0.f, 0.f};
+  auto fetch = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], int c) {
+    const bool second = c + 1 < R.c_hi;      // (16-row blocks: rows 16..31 of the step are the next chunk)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + PM_DW_NT * j, f = U.m0 + (idx >> 3), kq = idx & 7;
+      const float* p;
+      bool live = f < Fo16;
+      if (A.RT >= 2) {
+        const int b = c / A.RT, rt = c - b * A.RT;
+        p = gbase + (size_t)b * gblk + (size_t)f * A.Rw + rt * 16 + kq * 4;
+      } else {
+        p = gbase + (size_t)(c + (kq >> 2)) * gblk + (size_t)f * 16 + (kq & 3) * 4;
+        live = live && (kq < 4 || second);
+      }
+      ra[j] = live ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + PM_DW_NT * j, f = U.n0 + (idx >> 3), kq = idx & 7;
+      const float* p;
+      bool live = f < Fi16;
+      if (A.RT >= 2) {
+        const int b = c / A.RT, rt = c - b * A.RT;
+        p = abase + (size_t)b * ablk + (size_t)f * A.Rw + rt * 16 + kq * 4;
+      } else {
+        p = abase + (size_t)(c + (kq >> 2)) * ablk + (size_t)f * 16 + (kq & 3) * 4;
+        live = live && (kq < 4 || second);
+      }
+      rb[j] = live ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // fp32 x 4 -> 4 high + 4 low bf16, written to the two piece planes of `plane` (feature row f, k quad kq)
+  auto put = [&](unsigned short* plane, int nfeat, int f, int kq, const f32x4& v) {
+    const unsigned h0 = pm_pk_bf16(v[0], v[1]), h1 = pm_pk_bf16(v[2], v[3]);
+    const unsigned l0 = pm_pk_bf16(v[0] - pm_bf_lo(h0), v[1] - pm_bf_hi(h0));
+    const unsigned l1 = pm_pk_bf16(v[2] - pm_bf_lo(h1), v[3] - pm_bf_hi(h1));
+    unsigned short* q = plane + f * PM_DWW_LDK + kq * 4;
+    *reinterpret_cast<uint2*>(q) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(q + nfeat * PM_DWW_LDK) = uint2{l0, l1};
+  };
+  auto stage = [&](const f32x4 (&ra)[2], const f32x4 (&rb)[2], int st) {
+    unsigned short* sa = dww_lds + st * PM_DWW_STAGE;
+    unsigned short* sb = sa + 2 * PM_DWW_TM * PM_DWW_LDK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + PM_DW_NT * j;
+      put(sa, PM_DWW_TM, idx >> 3, idx & 7, ra[j]);
+      bs[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + PM_DW_NT * j;
+      put(sb, PM_DWW_TN, idx >> 3, idx & 7, rb[j]);
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfmas = [&](int st) {
+    const unsigned short* sa = dww_lds + st * PM_DWW_STAGE;
+    const unsigned short* sb = sa + 2 * PM_DWW_TM * PM_DWW_LDK;
+    f32x4 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* q = sa + (wm * 32 + i * 16 + c16) * PM_DWW_LDK + g * 8;
+      ah[i] = *reinterpret_cast<const f32x4*>(q);
+      al[i] = *reinterpret_cast<const f32x4*>(q + PM_DWW_TM * PM_DWW_LDK);
+    }
+    // one B fragment pair at a time (registers); per accumulator the smallest contributions first:
+    // lo x hi, hi x lo, hi x hi
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned short* q = sb + (wn * 64 + j * 16 + c16) * PM_DWW_LDK + g * 8;
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(q);
+      const f32x4 bl = *reinterpret_cast<const f32x4*>(q + PM_DWW_TN * PM_DWW_LDK);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = pm_mfma_bf<false>(al[i], bh, acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = pm_mfma_bf<false>(ah[i], bl, acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = pm_mfma_bf<false>(ah[i], bh, acc[i][j]);
+    }
+  };
+  // step c from LDS stage st; the registers receive step c + 2 meanwhile (the CU's other workgroup covers what of
+  // that round trip the MFMAs of one step do not)
+  fetch(ra0, rb0, R.c_lo);
+  stage(ra0, rb0, 0);
+  __syncthreads();
+  int st = 0;
+  for (int c = R.c_lo; c < R.c_hi; c += 2, st ^= 1) {
+    const bool more = c + 2 < R.c_hi;
+    if (more) fetch(ra0, rb0, c + 2);
+    mfmas(st);
+    if (more) stage(ra0, rb0, st ^ 1);
+    __syncthreads();
+  }
+  // partial tile: lane holds dW[o = m0 + 32 wm + 16 i + 4 g + r][k = n0 + 64 wn + 16 j + c16]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = U.n0 + wn * 64 + j * 16 + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = U.m0 + wm * 32 + i * 16 + 4 * g + r;
+        if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], R.add);
+      }
+    }
+  if (U.n0 == 0) {
+    // bias gradient: the eight threads that staged one delta feature hold its partial row sums
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v = bs[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const int idx = tid + PM_DW_NT * j, o = U.m0 + (idx >> 3);
+      if ((idx & 7) == 0 && o < O) pm_dw_put(part + A.b_off[l] + o, v, R.add);
+    }
   }
 }
 

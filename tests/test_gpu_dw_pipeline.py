@@ -181,3 +181,28 @@ def test_long_sweeps_are_pipelined_by_default():
         finally:
             del os.environ['PMBRL_MM_PARTS']
         assert eng.info['dw_pipe'] == want, (name, eng.info)
+
+
+@pytest.mark.parametrize('spec', ['off', '9,7,4'])
+@pytest.mark.parametrize('n_valid', [None, 13, 7, 0])
+def test_wide_layer_gemm_matches_block_gemm(spec, n_valid):
+    """The 512 x 512 layers of the stress shape go through pm_dw_wide_kernel (LDS-staged 128 x 128 tiles); the
+    block kernel (PMBRL_DW_NO_WIDE) is the reference here -- complete and truncated horizons, one launch and
+    the pipelined launches (where the later ranges ADD to the partial rows)."""
+    d = common.load('c5_small')
+    H = int(d['H'])
+    assert H == 20
+    os.environ['PMBRL_DW_NO_WIDE'] = '1'
+    try:
+        e0, g0, x0, a0 = run(d, 'off', True, n_valid=n_valid)
+    finally:
+        del os.environ['PMBRL_DW_NO_WIDE']
+    e1, g1, x1, a1 = run(d, spec, True, n_valid=n_valid)
+    assert e1.info['dw_pipe'] == (1 if spec == 'off' else 3)
+    assert np.all(np.isfinite(g1))
+    if n_valid == 0:
+        assert np.all(g1 == 0.0) and np.all(g0 == 0.0)
+    else:
+        assert common.rel(g1, g0) < 2e-6
+    if n_valid is None:
+        assert common.rel(g1, d['ref64_grad']) < TOL_GRAD
