@@ -777,9 +777,13 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // wide layers of the split form go to the LDS-staged tile kernel (pmbrl_dw.h, pm_dw_wide_kernel)
     bool wide[PM_MAXL] = {false};
     std::vector<DwUnit> units;
-    if (p->dw_split && !getenv("PMBRL_DW_NO_WIDE"))
+    // (layers of at least 128 x 128 on the split-precision plans: also the 200 x 200 layer of the cart-pole shapes,
+    //  whose block-kernel GEMM re-read its stash 1.5 x -- C2 0.116 -> 0.102 ms, C4 0.50 -> 0.38 ms; the exact-fp32
+    //  plans keep the fp32 block kernel for every layer)
+    const int wide_min = getenv("PMBRL_DW_WIDE_MIN") ? atoi(getenv("PMBRL_DW_WIDE_MIN")) : 128;
+    if (p->prec != 0 && !getenv("PMBRL_DW_NO_WIDE"))
       for (int l = 0; l < p->pol.nl; ++l)
-        if (p->pol.nt[l + 1] * 16 >= 2 * PM_DWW_TM && p->pol.nt[l] * 16 >= 2 * PM_DWW_TN) {
+        if (p->pol.nt[l + 1] * 16 >= wide_min && p->pol.nt[l] * 16 >= wide_min) {
           wide[l] = true;
           for (int m0 = 0; m0 < p->pol.nt[l + 1] * 16; m0 += PM_DWW_TM)
             for (int n0 = 0; n0 < p->pol.nt[l] * 16; n0 += PM_DWW_TN) units.push_back(DwUnit{(int16_t)l, (int16_t)m0, (int16_t)n0, 0});
