@@ -781,9 +781,18 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     //  whose block-kernel GEMM re-read its stash 1.5 x -- C2 0.116 -> 0.102 ms, C4 0.50 -> 0.38 ms; the exact-fp32
     //  plans keep the fp32 block kernel for every layer)
     const int wide_min = getenv("PMBRL_DW_WIDE_MIN") ? atoi(getenv("PMBRL_DW_WIDE_MIN")) : 128;
+    p->dw_layer13 = -1;
     if (p->prec != 0 && !getenv("PMBRL_DW_NO_WIDE"))
       for (int l = 0; l < p->pol.nl; ++l)
         if (p->pol.nt[l + 1] * 16 >= wide_min && p->pol.nt[l] * 16 >= wide_min) {
+          if (p->dw_layer13 < 0 && p->pol.nt[l + 1] <= PM_DWL_NT && p->pol.nt[l] <= PM_DWL_NT && !getenv("PMBRL_DW_NO_LAYER13")) {
+            // a whole layer of up to 13 x 13 tiles per workgroup
+            wide[l] = true;
+            p->dw_layer13 = l;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_layer_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWL_LDS_BYTES));
+            continue;
+          }
           wide[l] = true;
           for (int m0 = 0; m0 < p->pol.nt[l + 1] * 16; m0 += PM_DWW_TM)
             for (int n0 = 0; n0 < p->pol.nt[l] * 16; n0 += PM_DWW_TN) units.push_back(DwUnit{(int16_t)l, (int16_t)m0, (int16_t)n0, 0});
@@ -1373,6 +1382,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     if (p->n_dw_units)
       hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((Wk.nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, st, Wk,
                          p->dw_units_d, p->n_dw_units);
+    if (p->dw_layer13 >= 0)
+      hipLaunchKernelGGL(pm_dw_layer_kernel, dim3(Wk.nsplit), dim3(PM_DW_NT), PM_DWL_LDS_BYTES, st, Wk, p->dw_layer13);
   };
   if (p->mm_mode == 3) {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);
@@ -1451,6 +1462,8 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
       if (p->n_dw_units)
         hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((p->dw_nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, s, W,
                            p->dw_units_d, p->n_dw_units);
+      if (p->dw_layer13 >= 0)
+        hipLaunchKernelGGL(pm_dw_layer_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), PM_DWL_LDS_BYTES, s, W, p->dw_layer13);
     }
   }
   const int n = (int)p->pol.n_params;

@@ -597,6 +597,149 @@ __global__ __launch_bounds__(PM_DW_NT, 4) void pm_dw_wide_kernel(const DwArgs A,
   }
 }
 
+// A WHOLE layer of up to 13 x 13 tiles (the 200 x 200 layer of the shipped shapes) per workgroup: at that width
+// the 128 x 128 tiles above leave a workgroup a dozen steps of one exposed memory round trip each, in two rounds
+// over the chip (65 us for 173 MB at the cart-pole shape).  One workgroup per row-step range and CU instead:
+// 53 KB per step in flight per CU, every stash byte fetched once, wave w accumulates tile rows w and w + 8.
+#define PM_DWL_NT 13
+#define PM_DWL_F (PM_DWL_NT * 16)
+#define PM_DWL_STAGE (2 * PM_DWL_F * 2 * PM_DWW_LDK)
+#define PM_DWL_LDS_BYTES (2 * PM_DWL_STAGE * 2)
+#define PM_DWL_Q ((PM_DWL_F * 8 + PM_DW_NT - 1) / PM_DW_NT)      // float4 quads per thread and operand: 4
+__global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_layer_kernel(const DwArgs A, int l) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short dww_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  const int Fo16 = A.nt[l + 1] * 16, Fi16 = A.nt[l] * 16;
+  const int O = A.dim[l + 1], K = A.dim[l];
+  float* part = A.part + (size_t)row * A.part_stride;
+  const int g = lane >> 4, c16 = lane & 15;
+  if (R.zero) {
+    for (int e = tid; e < O * K; e += PM_DW_NT) part[A.w_off[l] + e] = 0.f;
+    for (int e = tid; e < O; e += PM_DW_NT) part[A.b_off[l] + e] = 0.f;
+    return;
+  }
+  const float* gbase = A.gT[l];
+  const float* abase = A.actT[l];
+  const size_t gblk = (size_t)Fo16 * A.Rw, ablk = (size_t)Fi16 * A.Rw;
+  f32x4 ra[PM_DWL_Q], rb[PM_DWL_Q];
+  float bs[PM_DWL_Q];
+#pragma unroll
+  for (int j = 0; j < PM_DWL_Q; ++j) bs[j] = 0.f;
+  auto fetch1 = [&](f32x4& dst, const float* base, size_t blk, int F16, int idx, int c, bool second) {
+    const int f = idx >> 3, kq = idx & 7;
+    const float* p;
+    bool live = f < F16;
+    if (A.RT >= 2) {
+      const int b = c / A.RT, rt = c - b * A.RT;
+      p = base + (size_t)b * blk + (size_t)f * A.Rw + rt * 16 + kq * 4;
+    } else {
+      p = base + (size_t)(c + (kq >> 2)) * blk + (size_t)f * 16 + (kq & 3) * 4;
+      live = live && (kq < 4 || second);
+    }
+    dst = live ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto fetch = [&](int c) {
+    const bool second = c + 1 < R.c_hi;
+#pragma unroll
+    for (int j = 0; j < PM_DWL_Q; ++j) {
+      const int idx = tid + PM_DW_NT * j;      // (idx >= 13 * 16 * 8: feature >= 208 >= F16 -> zeros, never staged)
+      fetch1(ra[j], gbase, gblk, Fo16, idx, c, second);
+      fetch1(rb[j], abase, ablk, Fi16, idx, c, second);
+    }
+  };
+  auto put = [&](unsigned short* plane, int f, int kq, const f32x4& v) {
+    const unsigned h0 = pm_pk_bf16(v[0], v[1]), h1 = pm_pk_bf16(v[2], v[3]);
+    const unsigned l0 = pm_pk_bf16(v[0] - pm_bf_lo(h0), v[1] - pm_bf_hi(h0));
+    const unsigned l1 = pm_pk_bf16(v[2] - pm_bf_lo(h1), v[3] - pm_bf_hi(h1));
+    unsigned short* q = plane + f * PM_DWW_LDK + kq * 4;
+    *reinterpret_cast<uint2*>(q) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(q + PM_DWL_F * PM_DWW_LDK) = uint2{l0, l1};
+  };
+  auto stage = [&](int st) {
+    unsigned short* sa = dww_lds + st * PM_DWL_STAGE;
+    unsigned short* sb = sa + 2 * PM_DWL_F * PM_DWW_LDK;
+#pragma unroll
+    for (int j = 0; j < PM_DWL_Q; ++j) {
+      const int idx = tid + PM_DW_NT * j;
+      if (idx < PM_DWL_F * 8) {
+        put(sa, idx >> 3, idx & 7, ra[j]);
+        put(sb, idx >> 3, idx & 7, rb[j]);
+        bs[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+      }
+    }
+  };
+  f32x4 acc[2][PM_DWL_NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < PM_DWL_NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool two = wid + 8 < PM_DWL_NT;      // this wave owns tile rows wid and (waves 0..4) wid + 8
+  auto mfmas = [&](int st) {
+    const unsigned short* sa = dww_lds + st * PM_DWL_STAGE;
+    const unsigned short* sb = sa + 2 * PM_DWL_F * PM_DWW_LDK;
+    f32x4 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tr = (i == 0 || two) ? wid + 8 * i : wid;
+      const unsigned short* q = sa + (tr * 16 + c16) * PM_DWW_LDK + g * 8;
+      ah[i] = *reinterpret_cast<const f32x4*>(q);
+      al[i] = *reinterpret_cast<const f32x4*>(q + PM_DWL_F * PM_DWW_LDK);
+    }
+#pragma unroll
+    for (int j = 0; j < PM_DWL_NT; ++j) {
+      const unsigned short* q = sb + (j * 16 + c16) * PM_DWW_LDK + g * 8;
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(q);
+      const f32x4 bl = *reinterpret_cast<const f32x4*>(q + PM_DWL_F * PM_DWW_LDK);
+      // per accumulator the smallest contributions first: lo x hi, hi x lo, hi x hi
+      acc[0][j] = pm_mfma_bf<false>(al[0], bh, acc[0][j]);
+      if (two) acc[1][j] = pm_mfma_bf<false>(al[1], bh, acc[1][j]);
+      acc[0][j] = pm_mfma_bf<false>(ah[0], bl, acc[0][j]);
+      if (two) acc[1][j] = pm_mfma_bf<false>(ah[1], bl, acc[1][j]);
+      acc[0][j] = pm_mfma_bf<false>(ah[0], bh, acc[0][j]);
+      if (two) acc[1][j] = pm_mfma_bf<false>(ah[1], bh, acc[1][j]);
+    }
+  };
+  fetch(R.c_lo);
+  stage(0);
+  __syncthreads();
+  int st = 0;
+  for (int c = R.c_lo; c < R.c_hi; c += 2, st ^= 1) {
+    const bool more = c + 2 < R.c_hi;
+    if (more) fetch(c + 2);
+    mfmas(st);
+    if (more) stage(st ^ 1);
+    __syncthreads();
+  }
+  // lane holds dW[o = 16 (wid + 8 i) + 4 g + r][k = 16 j + c16]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i == 0 || two) {
+#pragma unroll
+      for (int j = 0; j < PM_DWL_NT; ++j) {
+        const int k = j * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (wid + 8 * i) * 16 + 4 * g + r;
+          if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], R.add);
+        }
+      }
+    }
+  // bias gradient: the eight threads that staged one delta feature hold its partial row sums
+#pragma unroll
+  for (int j = 0; j < PM_DWL_Q; ++j) {
+    float v = bs[j];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    const int idx = tid + PM_DW_NT * j, o = idx >> 3;
+    if ((idx & 7) == 0 && o < O) pm_dw_put(part + A.b_off[l] + o, v, R.add);
+  }
+}
+
 // grad[i] = sum_s part[s][i] in fixed order.  A workgroup = 64 float4 columns x 8 slices of the
 // split range: every wave reads whole 1 KiB rows, a thread keeps 8 independent loads in flight.
 __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
