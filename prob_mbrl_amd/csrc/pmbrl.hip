@@ -730,6 +730,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     } else {
       for (int i = 0; i < c.D; ++i) { r.phi_src[i] = i; r.phi_mode[i] = 0; r.d_copy[i] = i; }
     }
+    if ((size_t)256 * (c.D | 1) * sizeof(float) > 64 * 1024)      // (rows of a block staged in LDS)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reward_all_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (c.D | 1) * (int)sizeof(float)));
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&p->wflag_d, sizeof(int)));
@@ -1289,7 +1292,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     ScopedTimer tm(p, PMBRL_TIMER_REWARD, s);
     A.t0 = 0; A.t1 = p->cfg.H;
     const long long n = (long long)p->cfg.H * p->cfg.B;
-    hipLaunchKernelGGL(pm_reward_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(pm_reward_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                       (size_t)256 * (p->cfg.D | 1) * sizeof(float), s, A);
     if (mm_r)
       hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                          pm_mm_scratch_doubles(1) * sizeof(double), s, A);

@@ -868,15 +868,29 @@ struct EpiBwdL {
 // All rewards of a rollout in one fully parallel pass: thread = one (t, b) row-step.
 // r~ -> rt (if rewards are moment matched afterwards) or rewards; d r~/d x~ -> Jx; d r~/d a -> Ja;
 // non-finite states / rewards are reported through the status word like in the sweep.
+// The 256 state rows of a block go through LDS (row stride D | 1): a thread walks ITS row, so straight from HBM
+// every load and every Jacobian store of a wave touched 64 cache lines (1.7 ms at D = 32, 1.6 M row-steps).  The
+// Jacobian row overwrites the state row in place and leaves the same way.
 __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A) {
+  extern __shared__ float rw_rows[];
   const long long n = (long long)A.H * A.B;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int t = (int)(i / A.B);
+  const long long i0 = (long long)blockIdx.x * blockDim.x;
+  const long long i = i0 + threadIdx.x;
   const int D = A.D, U = A.U;
+  const int ld = D | 1;
+  const int nrow = (int)min((long long)blockDim.x, n - i0);
+  {
+    const float* src = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i0 * D : A.states + ((size_t)i0 + A.B) * D;
+    for (int e = threadIdx.x; e < nrow * D; e += blockDim.x) {
+      const int r = e / D, d = e - r * D;
+      rw_rows[r * ld + d] = src[e];
+    }
+  }
+  __syncthreads();
+  if (i < n) {
+  const int t = (int)(i / A.B);
   const RewardDev* __restrict__ rw = A.rew;
-  const float* xs = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i * D
-                                                     : A.states + ((size_t)i + A.B) * D;
+  float* xs = rw_rows + threadIdx.x * ld;
   const float* as = A.actions + (size_t)i * U;
   // No per-thread array is indexed at run time (that would live in scratch): the feature map is
   // walked in gather form, x / a come from their (L1-resident) rows, only the k <= 8 tip
@@ -941,7 +955,7 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
       const float th = xs[d];
       g += gphi(js) * cosf(th) - gphi(rw->d_cos[d]) * sinf(th);
     }
-    A.Jx[(size_t)i * D + d] = g;
+    xs[d] = g;      // (x_d has been read: only dimension d's own sine / cosine terms use it)
   }
   for (int q = 0; q < U; ++q) {
     float s = 0.f;
@@ -950,6 +964,12 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[i] = rv;
   else A.rewards[i] = rv;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nrow * D; e += blockDim.x) {
+    const int r = e / D, d = e - r * D;
+    A.Jx[(size_t)i0 * D + e] = rw_rows[r * ld + d];
+  }
 }
 
 // moment matching of the rewards for all (t, group) at once (one wave each), and its adjoint
