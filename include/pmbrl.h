@@ -138,6 +138,17 @@ typedef struct pmbrl_config {
    * Needs z_pi_d and u_cat_d, and z_dyn_d as a per-step draw (z_dyn_step_stride = B * D: the reference redraws
    * the Gaussian noise of this head at every step). */
   int32_t dyn_components;
+  /* Moment-matching groups whose rows are spread over several ranks (e.g. mm_groups=None of
+   * examples/deep_pilco_mm.py:31 on a sharded run: ONE Gaussian over the particles of all GPUs, utils/rollout.py:20-29).
+   * mm_span_rows: rows of one group over all ranks (0: groups are local to this device, the fields above say it
+   * all); mm_span_offset: position of this rank's B / mm_groups rows inside each group -- the cyclic noise row of
+   * local row i of group g is then (t + g * mm_span_rows + mm_span_offset + i) mod B_global, row_offset is not used
+   * by the moment matching.  Per step the ranks exchange the groups' sufficient statistics (fp64; forward: one
+   * in-place sum of ranks x groups x (D^2 + 3 D + 1) values, adjoint: groups x (D^2 + D)) through the
+   * collective attached with pmbrl_plan_set_comm / pmbrl_plan_set_collective; the sweeps then run as one launch
+   * per step.  Not offered together with PMBRL_FLAG_INFER_NS or grad_states. */
+  int32_t mm_span_rows, mm_span_offset;
+  int32_t mm_span_ranks, mm_span_rank; /* ranks a group is spread over and this rank's index among them */
 } pmbrl_config;
 
 typedef struct pmbrl_plan pmbrl_plan;
@@ -292,6 +303,16 @@ int pmbrl_comm_init(const void* id /* host, PMBRL_COMM_ID_BYTES */, int32_t rank
                     int32_t device, pmbrl_comm** out);
 int pmbrl_allreduce_sum(pmbrl_comm* comm, void* stream, float* buf_d, int64_t n);
 void pmbrl_comm_destroy(pmbrl_comm* comm);
+
+/* In-place fp64 sum over the ranks of buf_d[0..n) on `stream`: the per-step statistics exchange of
+ * moment-matching groups that span ranks (pmbrl_config.mm_span_rows).  pmbrl_plan_set_comm: RCCL through the
+ * communicator above (no host round trip; capturable).  pmbrl_plan_set_collective: any other transport --
+ * fn(ctx, stream, buf_d, n) must return 0 once the sum is ORDERED on `stream` (it may block the host); e.g. a
+ * host-staged torch.distributed / MPI all-reduce, which is how the two-process tests run on one device.
+ * The plan keeps the pointer, not the communicator: destroy the plan first. */
+typedef int (*pmbrl_collective_fn)(void* ctx, void* stream, double* buf_d, int64_t n);
+int pmbrl_plan_set_comm(pmbrl_plan* plan, pmbrl_comm* comm);
+int pmbrl_plan_set_collective(pmbrl_plan* plan, pmbrl_collective_fn fn, void* ctx);
 
 /* Optional per-kernel timing for bench.py's roofline line: when enabled, the
  * library brackets its kernels with hipEvents on the caller's stream;

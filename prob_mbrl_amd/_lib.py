@@ -62,7 +62,13 @@ class Config(C.Structure):
                 ('reward', Reward), ('rows_per_wg_hint', C.c_int32), ('precision', C.c_int32),
                 ('n_pol_angle', C.c_int32), ('pol_angle_dims', C.c_int32 * MAX_ANGLE),
                 ('n_dyn_angle', C.c_int32), ('dyn_angle_dims', C.c_int32 * MAX_ANGLE),
-                ('dyn_components', C.c_int32)]
+                ('dyn_components', C.c_int32),
+                ('mm_span_rows', C.c_int32), ('mm_span_offset', C.c_int32),
+                ('mm_span_ranks', C.c_int32), ('mm_span_rank', C.c_int32)]
+
+
+# int fn(void* ctx, void* stream, double* buf_d, int64_t n): pmbrl_plan_set_collective
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class Inputs(C.Structure):
@@ -88,6 +94,7 @@ EXPORTS = [
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
     'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_destroy',
+    'pmbrl_plan_set_comm', 'pmbrl_plan_set_collective',
 ]
 
 _lib = None
@@ -167,6 +174,10 @@ def load():
     lib.pmbrl_allreduce_sum.argtypes = [vp, vp, vp, i64]
     lib.pmbrl_comm_destroy.restype = None
     lib.pmbrl_comm_destroy.argtypes = [vp]
+    lib.pmbrl_plan_set_comm.restype = C.c_int
+    lib.pmbrl_plan_set_comm.argtypes = [vp, vp]
+    lib.pmbrl_plan_set_collective.restype = C.c_int
+    lib.pmbrl_plan_set_collective.argtypes = [vp, COLLECTIVE_FN, vp]
     _lib = lib
     return lib
 

@@ -119,15 +119,20 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     D = init_states.shape[-1]
     N_particles = init_states.shape[0]
     world, rank = 1, 0
+    mm_span = None      # one moment-matching group over the particles of all ranks (sharded runs, mm_groups=None)
     if process_group is not None:
         import torch.distributed as dist
         world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         if world > 1 and (mm_states or mm_rewards) and mm_groups is None:
-            # one Gaussian over ALL particles (the examples' default) would need the per-step
-            # sufficient statistics summed over the ranks; fitting one Gaussian per rank
-            # instead would silently be different mathematics
-            raise NotImplementedError('moment matching over one global group (mm_groups=None) is not offered on '
-                                      'sharded runs: pass mm_groups (whole groups per rank)')
+            # one Gaussian over ALL particles (the examples' default): the per-step sufficient statistics are
+            # summed over the ranks (pmbrl_config.mm_span_rows) -- fitting one Gaussian per rank
+            # instead would silently be different mathematics.  Needs the same particle count on every rank.
+            cnt = torch.tensor([N_particles, -N_particles], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=process_group)
+            if int(cnt[0]) != -int(cnt[1]):
+                raise ValueError('moment matching over one global group on a sharded run needs the same number of '
+                                 'particles on every rank')
+            mm_span = (N_particles * world, rank * N_particles, world, rank)
     Bg = N_particles * world
     z_mm = torch.randn(H + Bg, D, device=dev)
     z_rr = torch.randn(H + Bg, 1, device=dev)
@@ -147,6 +152,10 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
             value_func.resample(seed=seed)
         z_mm.normal_()
         z_rr.normal_()
+        if mm_span is not None:
+            # one group over all ranks: one cyclic noise buffer, as one process would hold it
+            dist.broadcast(z_mm, dist.get_global_rank(process_group, 0), group=process_group)
+            dist.broadcast(z_rr, dist.get_global_rank(process_group, 0), group=process_group)
 
     resample()
     x0 = init_states
@@ -230,7 +239,8 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                                mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
                                z_rr if pegasus else None,
                                B_global=Bg if world > 1 else None,
-                               row_offset=rank * N_particles if world > 1 else 0, precision=prec['name'])
+                               row_offset=rank * N_particles if world > 1 else 0, precision=prec['name'],
+                               mm_span=mm_span, process_group=process_group if mm_span else None)
             cache = None if need_autograd else _adam_flat_state(opt, bundle.pol_params,
                                                                 bundle.pol_flat)
             if cache is None:

@@ -13,6 +13,7 @@
 #include "pmbrl_host.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
+#include "pmbrl_mmx.h"
 #include "pmbrl_fast.h"
 #include "pmbrl_dw.h"
 #include "pmbrl_mlp.h"
@@ -26,7 +27,7 @@ int pm_fail(int code, const std::string& msg) {
 static int fail(int code, const std::string& msg) { return pm_fail(code, msg); }
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
-extern "C" int pmbrl_version(void) { return 3; }
+extern "C" int pmbrl_version(void) { return 4; }
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -582,9 +583,27 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->M = c.B / p->G;
     if (p->M < 2) { delete p; return fail(-2, "moment matching needs >= 2 rows per group"); }
     if (rt4_split && p->fast && lds_need(4, c.D) > lds_cap) rt4_split = false;   // 64-row workgroups: fp32 then
+    // groups spread over ranks: the statistics cross devices between the two halves of the moment matching, so it
+    // stays outside the sweep kernels (mm_mode 2: one sweep launch per step)
+    p->span = c.mm_span_rows > 0;
+    if (p->span) {
+      if (c.mm_span_ranks < 1 || c.mm_span_rank < 0 || c.mm_span_rank >= c.mm_span_ranks) {
+        delete p; return fail(-2, "mm_span_ranks / mm_span_rank out of range");
+      }
+      if (c.mm_span_offset < 0 || c.mm_span_offset + p->M > c.mm_span_rows) {
+        delete p; return fail(-2, "mm_span_offset + rows per group on this rank exceeds mm_span_rows");
+      }
+      if ((long long)p->G * c.mm_span_rows > p->cfg.B_global) {
+        delete p; return fail(-2, "mm_groups x mm_span_rows exceeds B_global");
+      }
+      if (c.flags & PMBRL_FLAG_INFER_NS) {
+        delete p; return fail(-3, "infer_noise_variables with moment-matching groups spread over ranks: not offered");
+      }
+    }
     // in-kernel if a whole number of groups fits a workgroup's row tiles and LDS
     p->mm_mode = 2;
     for (int RT : {1, 2, 4}) {
+      if (p->span) break;
       const int R = 16 * RT;
       if (p->M <= R && lds_need(RT, c.D) <= lds_cap) {
         p->mm_mode = 1;
@@ -613,7 +632,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // Groups of up to 128 rows (beyond 64 the one-wave routines walk the rows in strides).  The fewest parts
       // that bring a part down to 16 rows while every workgroup stays resident, else to 32 rows.
       // PMBRL_MM_PARTS=n: n parts wherever that can be done (tests); 1: whole groups.
-      const bool big = (p->mm_mode == 1 && p->RT >= 2) || p->mm_mode == 2 || (e && p->mm_mode == 1);
+      const bool big = !p->span && ((p->mm_mode == 1 && p->RT >= 2) || p->mm_mode == 2 || (e && p->mm_mode == 1));
       auto fits = [&](int parts, int max_rows) {
         const int rpw = (p->M + parts - 1) / parts;      // the last part takes what is left of the group
         return rpw <= max_rows && (parts - 1) * rpw < p->M && p->G * parts <= max_wg;
@@ -660,7 +679,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // groups that span workgroups: the fast family does the state moment matching in the prologue of
   // its per-step launches (mm_mode 3) when it has a compile-time-width instance and the partial
   // Gram tiles fit the activation buffers; otherwise separate kernels per step (mm_mode 2)
-  if (p->mm_mode == 2 && p->fast && (c.flags & PMBRL_FLAG_MM_STATES) && c.D >= 4 && c.D <= 6 &&
+  if (p->mm_mode == 2 && !p->span && p->fast && (c.flags & PMBRL_FLAG_MM_STATES) && c.D >= 4 && c.D <= 6 &&
       !getenv("PMBRL_MM_MODE2") && lds_need(p->RT, c.D) <= lds_cap &&
       (size_t)2 * 16 * p->RT * ld_for(p->RT) * sizeof(float) >= (size_t)8 * 256 * sizeof(double))
     p->mm_mode = 3;
@@ -912,6 +931,14 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
     p->off_gsync = take(2 * 1024 * sizeof(unsigned));   // one flag per workgroup for the device-wide barriers (forward, backward)
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
+    {
+      // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
+      // rewards of all steps), the factors the adjoint reuses
+      const size_t n_s = (size_t)p->G * pm_mmx_slot_doubles(c.D), n_r = (size_t)c.H * p->G * pm_mmx_slot_doubles(1);
+      p->off_mmx_buf = take(p->span ? (size_t)c.mm_span_ranks * std::max(n_s, n_r) * sizeof(double) : 0);
+      p->off_mmx_fac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
+      p->off_mmx_rfac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(1) * sizeof(double) : 0);
+    }
     p->off_part = take((size_t)std::max(p->dw_nsplit, p->pipe_K > 1 ? p->pipe_rows : 0) *
                        ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
@@ -1218,6 +1245,23 @@ static void launch_bwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t
   }
 }
 
+// groups spread over ranks (pmbrl_mmx.h): the in-place fp64 sum of the statistics buffer over the ranks
+static int mmx_exchange(pmbrl_plan* p, hipStream_t s, double* buf, size_t n) {
+  if (!p->coll) return fail(-3, "moment-matching groups spread over ranks: attach a collective first (pmbrl_plan_set_comm / pmbrl_plan_set_collective)");
+  if (int rc = p->coll(p->coll_ctx, (void*)s, buf, (int64_t)n)) return fail(-4, "statistics all-reduce failed (" + std::to_string(rc) + ")");
+  return 0;
+}
+static MmxArgs mmx_args(const pmbrl_plan* p, char* ws, bool rewards) {
+  MmxArgs X;
+  X.nranks = p->cfg.mm_span_ranks;
+  X.rank = p->cfg.mm_span_rank;
+  X.span_rows = p->cfg.mm_span_rows;
+  X.span_off = p->cfg.mm_span_offset;
+  X.buf = reinterpret_cast<double*>(ws + p->off_mmx_buf);
+  X.fac = reinterpret_cast<double*>(ws + (rewards ? p->off_mmx_rfac : p->off_mmx_fac));
+  return X;
+}
+
 extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
                                  float* states_d, float* actions_d, float* rewards_d,
                                  int32_t* status_d) {
@@ -1283,7 +1327,17 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     for (int t = 0; t < p->cfg.H; ++t) {
       As.t0 = t; As.t1 = t + 1;
       launch_fwd_rt(p, As, s);
-      hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t);
+      if (!p->span) {
+        hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t);
+      } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
+        // groups spread over ranks: own statistics -> sum over the ranks -> factor + own rows
+        MmxArgs X = mmx_args(p, ws, false);
+        X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
+        const size_t scr = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+        hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G, X.nranks), dim3(64), scr, s, Am, X, t);
+        if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * p->G * pm_mmx_slot_doubles(p->cfg.D))) return rc;
+        hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t);
+      }
     }
   }
   }
@@ -1294,7 +1348,15 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     const long long n = (long long)p->cfg.H * p->cfg.B;
     hipLaunchKernelGGL(pm_reward_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
                        (size_t)256 * (p->cfg.D | 1) * sizeof(float), s, A);
-    if (mm_r)
+    if (mm_r && p->span) {
+      // the rewards of all steps: one exchange for the whole horizon
+      const MmxArgs X = mmx_args(p, ws, true);
+      const size_t scr = pm_mm_scratch_doubles(1) * sizeof(double);
+      const int n_items = p->cfg.H * p->G;
+      hipLaunchKernelGGL(pm_mmx_stats_kernel<1>, dim3(n_items, X.nranks), dim3(64), scr, s, A, X, 0);
+      if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * n_items * pm_mmx_slot_doubles(1))) return rc;
+      hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0);
+    } else if (mm_r)
       hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                          pm_mm_scratch_doubles(1) * sizeof(double), s, A);
   }
@@ -1334,7 +1396,15 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   float* grt = reinterpret_cast<float*>(ws + p->off_grt);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   if (!p->fast) { A.ext_reward = 1; }
-  if (mm_r) {
+  if (mm_r && p->span) {
+    const MmxArgs X = mmx_args(p, ws, true);
+    const size_t scr = pm_mm_scratch_doubles(1) * sizeof(double);
+    const int n_items = p->cfg.H * p->G;
+    hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0);
+    if (int rc = mmx_exchange(p, s, X.buf, (size_t)n_items * pm_mmx_bwd_doubles(1))) return rc;
+    hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0, grt);
+    A.grad_rewards = grt;
+  } else if (mm_r) {
     // adjoint of the reward moment matching for all (t, group) up front
     hipLaunchKernelGGL(pm_mm_rewards_bwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                        pm_mm_scratch_doubles(1) * sizeof(double), s, A, grt);
@@ -1446,7 +1516,16 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
     A.gx_from_carry = 1;
     for (int t = p->cfg.H - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
+      if (!p->span) {
+        hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
+      } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
+        MmxArgs X = mmx_args(p, ws, false);
+        X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
+        const size_t scr = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
+        hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t);
+        if (int rc = mmx_exchange(p, s, X.buf, (size_t)p->G * pm_mmx_bwd_doubles(p->cfg.D))) return rc;
+        hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t, (float*)nullptr);
+      }
       A.t0 = t; A.t1 = t + 1;
       launch_bwd_rt(p, A, s);
     }
@@ -1894,6 +1973,23 @@ extern "C" void pmbrl_comm_destroy(pmbrl_comm* comm) {
   if (!comm) return;
   if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
   delete comm;
+}
+
+static int pm_coll_rccl(void* ctx, void* stream, double* buf_d, int64_t n) {
+  pmbrl_comm* comm = static_cast<pmbrl_comm*>(ctx);
+  return g_rccl.AllReduce(buf_d, buf_d, (size_t)n, 8 /* ncclDouble */, 0 /* ncclSum */, comm->comm, (hipStream_t)stream);
+}
+extern "C" int pmbrl_plan_set_comm(pmbrl_plan* plan, pmbrl_comm* comm) {
+  if (!plan || !comm) return fail(-1, "null argument");
+  plan->coll = pm_coll_rccl;
+  plan->coll_ctx = comm;
+  return 0;
+}
+extern "C" int pmbrl_plan_set_collective(pmbrl_plan* plan, pmbrl_collective_fn fn, void* ctx) {
+  if (!plan) return fail(-1, "null argument");
+  plan->coll = fn;
+  plan->coll_ctx = ctx;
+  return 0;
 }
 
 extern "C" int pmbrl_weighted_sum(void* stream, const float* a_d, const float* w_d, int64_t n,

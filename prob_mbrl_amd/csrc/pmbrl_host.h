@@ -58,6 +58,12 @@ struct pmbrl_plan {
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
       off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, off_gmm_c, off_gmm_k, ws_bytes;
   int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
+  // moment-matching groups spread over ranks (pmbrl_config.mm_span_rows; mm_mode 2 with the statistics exchanged
+  // through `coll` between the two halves of the external moment matching, pmbrl_mmx.h)
+  int span;
+  size_t off_mmx_buf, off_mmx_fac, off_mmx_rfac;
+  int (*coll)(void* ctx, void* stream, double* buf_d, int64_t n);
+  void* coll_ctx;
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;

@@ -72,6 +72,39 @@ __device__ __forceinline__ double pm_seg_sum(double v, int P) {
   return v;
 }
 
+// In-place Cholesky factor of the covariance in q.Lm (lower triangle), 1 / diag(L) into q.invd.
+// Returns false (wave-uniform) on a non-positive pivot.
+__device__ __forceinline__ bool pm_mm_chol(int d, const MMScratch& q, int lane) {
+  // The reference factors in fp32 and raises (-> RuntimeError, utils/rollout.py:154-157)
+  // when a pivot is lost to rounding; reproduce that contract: a pivot that has shed
+  // more than fp32 precision relative to its diagonal entry counts as non-positive.
+  for (int j = lane; j < d; j += 64) q.mbar[j] = q.Lm[j * d + j];
+  pm_wave_sync();
+  bool ok = true;
+  for (int k = 0; k < d; ++k) {
+    double piv = q.Lm[k * d + k];
+    if (!(piv > 6e-8 * q.mbar[k])) {
+      ok = false;
+      piv = 1.0;
+    }
+    const double rs = pm_rsqrt(piv);
+    const double lkk = piv * rs;
+    pm_wave_sync();   // everyone has read the pivot before lane 0 overwrites it
+    for (int i = k + 1 + lane; i < d; i += 64) q.Lm[i * d + k] *= rs;
+    if (lane == 0) {
+      q.Lm[k * d + k] = lkk;
+      q.invd[k] = rs;
+    }
+    pm_wave_sync();
+    for (int e = lane; e < d * d; e += 64) {
+      const int i = e / d, j = e - i * d;
+      if (j > k && j <= i) q.Lm[e] -= q.Lm[i * d + k] * q.Lm[j * d + k];
+    }
+    pm_wave_sync();
+  }
+  return ok;
+}
+
 // means, z standardisation, covariance and its Cholesky factor.  Returns false
 // (wave-uniform) on a non-positive pivot.
 __device__ __forceinline__ bool pm_mm_factor(const float* s, int s_ld, int M, int d, const float* z,
@@ -123,34 +156,7 @@ __device__ __forceinline__ bool pm_mm_factor(const float* s, int s_ld, int M, in
     }
   }
   pm_wave_sync();
-  // The reference factors in fp32 and raises (-> RuntimeError, utils/rollout.py:154-157)
-  // when a pivot is lost to rounding; reproduce that contract: a pivot that has shed
-  // more than fp32 precision relative to its diagonal entry counts as non-positive.
-  for (int j = lane; j < d; j += 64) q.mbar[j] = q.Lm[j * d + j];
-  pm_wave_sync();
-  bool ok = true;
-  for (int k = 0; k < d; ++k) {
-    double piv = q.Lm[k * d + k];
-    if (!(piv > 6e-8 * q.mbar[k])) {
-      ok = false;
-      piv = 1.0;
-    }
-    const double rs = pm_rsqrt(piv);
-    const double lkk = piv * rs;
-    pm_wave_sync();   // everyone has read the pivot before lane 0 overwrites it
-    for (int i = k + 1 + lane; i < d; i += 64) q.Lm[i * d + k] *= rs;
-    if (lane == 0) {
-      q.Lm[k * d + k] = lkk;
-      q.invd[k] = rs;
-    }
-    pm_wave_sync();
-    for (int e = lane; e < d * d; e += 64) {
-      const int i = e / d, j = e - i * d;
-      if (j > k && j <= i) q.Lm[e] -= q.Lm[i * d + k] * q.Lm[j * d + k];
-    }
-    pm_wave_sync();
-  }
-  return ok;
+  return pm_mm_chol(d, q, lane);
 }
 
 __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
@@ -182,6 +188,57 @@ __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d
   }
   pm_wave_sync();
   return ok;
+}
+
+// The adjoint behind the sums over the rows: (q.mbar = sum_r g, q.P = Lbar = tril(g^T zhat), the factor in q)
+// -> gout = dL/d s for the M_rows rows at s; inv_m / inv_m1 = 1 / M and 1 / (M - 1) of the WHOLE group (the rows
+// at s may be a part of it: groups spanning devices, pm_mmx_*).
+__device__ __forceinline__ void pm_mm_bwd_finish(const float* s, int s_ld, int M, int d, double inv_m, double inv_m1,
+                                                 float* gout, int gout_ld, const MMScratch& q, int lane) {
+  // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    double acc = 0.0;
+    if (j <= i) {
+      for (int c = i; c < d; ++c) acc += q.Lm[c * d + i] * q.P[c * d + j];
+      if (i == j) acc *= 0.5;
+    }
+    q.Sb[e] = acc;
+  }
+  pm_wave_sync();
+  // X = Phi L^-1  (row i of X solves x L = phi_i), in place in q.Sb
+  for (int i = lane; i < d; i += 64) {
+    for (int j = d - 1; j >= 0; --j) {
+      double a = q.Sb[i * d + j];
+      for (int c = j + 1; c < d; ++c) a -= q.Sb[i * d + c] * q.Lm[c * d + j];
+      q.Sb[i * d + j] = a * q.invd[j];
+    }
+  }
+  pm_wave_sync();
+  // Sbar = L^-T X  (column j solves L^T y = x_j), in place
+  for (int j = lane; j < d; j += 64) {
+    for (int i = d - 1; i >= 0; --i) {
+      double a = q.Sb[i * d + j];
+      for (int c = i + 1; c < d; ++c) a -= q.Lm[c * d + i] * q.Sb[c * d + j];
+      q.Sb[i * d + j] = a * q.invd[i];
+    }
+  }
+  pm_wave_sync();
+  // symmetrise into q.P:  P = (Sbar + Sbar^T) / (M-1)   (= 2 * sym(Sbar) / (M-1))
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) * inv_m1;
+  }
+  pm_wave_sync();
+  // sbar[r][j] = sum_c Delta[r][c] P[c][j] + mbar[j]/M      (mean_r of the first term is 0)
+  for (int e = lane; e < M * d; e += 64) {
+    const int r = e / d, j = e - r * d;
+    double acc = q.mbar[j] * inv_m;
+    for (int c = 0; c < d; ++c) acc += ((double)s[r * s_ld + c] - q.mean[c]) * q.P[c * d + j];
+    // all reads of g happened before the first pm_wave_sync above: in-place is safe
+    gout[r * gout_ld + j] = (float)acc;
+  }
+  pm_wave_sync();
 }
 
 // g: upstream dL/d out [M][d]; gout: dL/d s [M][d] (may alias g).
@@ -261,50 +318,7 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
     }
     pm_wave_sync();
   }
-  // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
-  for (int e = lane; e < d * d; e += 64) {
-    const int i = e / d, j = e - i * d;
-    double acc = 0.0;
-    if (j <= i) {
-      for (int c = i; c < d; ++c) acc += q.Lm[c * d + i] * q.P[c * d + j];
-      if (i == j) acc *= 0.5;
-    }
-    q.Sb[e] = acc;
-  }
-  pm_wave_sync();
-  // X = Phi L^-1  (row i of X solves x L = phi_i), in place in q.Sb
-  for (int i = lane; i < d; i += 64) {
-    for (int j = d - 1; j >= 0; --j) {
-      double a = q.Sb[i * d + j];
-      for (int c = j + 1; c < d; ++c) a -= q.Sb[i * d + c] * q.Lm[c * d + j];
-      q.Sb[i * d + j] = a * q.invd[j];
-    }
-  }
-  pm_wave_sync();
-  // Sbar = L^-T X  (column j solves L^T y = x_j), in place
-  for (int j = lane; j < d; j += 64) {
-    for (int i = d - 1; i >= 0; --i) {
-      double a = q.Sb[i * d + j];
-      for (int c = i + 1; c < d; ++c) a -= q.Lm[c * d + i] * q.Sb[c * d + j];
-      q.Sb[i * d + j] = a * q.invd[i];
-    }
-  }
-  pm_wave_sync();
-  // symmetrise into q.P:  P = (Sbar + Sbar^T) / (M-1)   (= 2 * sym(Sbar) / (M-1))
-  for (int e = lane; e < d * d; e += 64) {
-    const int i = e / d, j = e - i * d;
-    q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) * inv_m1;
-  }
-  pm_wave_sync();
-  // sbar[r][j] = sum_c Delta[r][c] P[c][j] + mbar[j]/M      (mean_r of the first term is 0)
-  for (int e = lane; e < M * d; e += 64) {
-    const int r = e / d, j = e - r * d;
-    double acc = q.mbar[j] * inv_m;
-    for (int c = 0; c < d; ++c) acc += ((double)s[r * s_ld + c] - q.mean[c]) * q.P[c * d + j];
-    // all reads of g happened before the first pm_wave_sync above: in-place is safe
-    gout[r * gout_ld + j] = (float)acc;
-  }
-  pm_wave_sync();
+  pm_mm_bwd_finish(s, s_ld, M, d, inv_m, inv_m1, gout, gout_ld, q, lane);
 }
 
 

@@ -1,0 +1,271 @@
+// Moment matching of a group whose rows are spread over several devices (the reference is
+// single-process: this is utils/rollout.py:20-29 over the rows of ALL ranks, e.g. mm_groups=None of
+// examples/deep_pilco_mm.py:31 on a sharded run).
+//
+// Per step and group every rank
+//   1. leaves the statistics of its own rows in ITS slot of a [ranks][groups][slot] fp64 buffer and zeros in
+//      the other slots (pm_mmx_stats): row count, mean, centred second moments, sum z, sum z^2;
+//   2. the buffer is summed over the ranks in place (one small all-reduce on the compute stream: with disjoint
+//      slots that is an all-gather, so every rank then combines the SAME numbers in the SAME order);
+//   3. combines the slots in rank order with the pairwise update of the centred moments (no raw second moments:
+//      a 1 x 1 reward "covariance" of nearly equal rewards would cancel to noise), factors the covariance
+//      exactly as the single-device routine does (pm_mm_chol) and maps its own rows (pm_mmx_apply).
+// The adjoint needs two sums over all rows of the group -- mbar = sum_r g_r and Lbar = tril(g^T zhat) -- which
+// are plain sums (pm_mmx_bwd_sums, one all-reduce), then the single-device tail (pm_mm_bwd_finish) on its own
+// rows with the group's 1 / M.  One wavefront per group; everything in fp64 like pmbrl_mm.h.
+#pragma once
+#include "pmbrl_mm.h"
+
+__host__ __device__ inline size_t pm_mmx_slot_doubles(int d) { return (size_t)d * d + 3 * d + 1; }
+__host__ __device__ inline size_t pm_mmx_bwd_doubles(int d) { return (size_t)d * d + d; }
+
+// slot: [n | mean (d) | M2 (d*d, lower triangle used) | sum z (d) | sum z^2 (d)]
+__device__ __forceinline__ void pm_mmx_stats(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
+                                             int zrow0, int Bg, double* slot, double* scr, int lane) {
+  double* mean = scr;   // d doubles of scratch
+  const double inv_m = 1.0 / (double)M;
+  {
+    const int e2 = pm_pow2ceil(d);
+    const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
+    const int part = lane % P;
+    for (int base = 0; base < d; base += per) {
+      const int j = base + lane / P;
+      double m = 0.0, zm = 0.0, zz = 0.0;
+      if (j < d)
+        for (int i = part; i < M; i += P) {
+          m += (double)s[(size_t)i * s_ld + j];
+          const double zv = (double)z[(size_t)pm_zidx(zrow0, i, Bg) * z_ld + j];
+          zm += zv;
+          zz += zv * zv;
+        }
+      m = pm_seg_sum(m, P);
+      zm = pm_seg_sum(zm, P);
+      zz = pm_seg_sum(zz, P);
+      if (j < d && part == 0) {
+        mean[j] = m * inv_m;
+        slot[1 + j] = m * inv_m;
+        slot[1 + d + d * d + j] = zm;
+        slot[1 + 2 * d + d * d + j] = zz;
+      }
+    }
+    if (lane == 0) slot[0] = (double)M;
+  }
+  pm_wave_sync();
+  {
+    const int e2 = pm_pow2ceil(d * d);
+    const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
+    const int part = lane % P;
+    for (int base = 0; base < d * d; base += per) {
+      const int e = base + lane / P;
+      const int i = e / d, j = e - i * d;
+      double acc = 0.0;
+      const bool live = e < d * d && j <= i;
+      if (live) {
+        const double mi = mean[i], mj = mean[j];
+        for (int r = part; r < M; r += P)
+          acc += ((double)s[(size_t)r * s_ld + i] - mi) * ((double)s[(size_t)r * s_ld + j] - mj);
+      }
+      acc = pm_seg_sum(acc, P);
+      if (e < d * d && part == 0) slot[1 + d + e] = live ? acc : 0.0;
+    }
+  }
+  pm_wave_sync();
+}
+
+// slots of all ranks (summed buffer, `stride` doubles from one rank's slot to the next) -> means, z
+// standardisation, covariance and its factor in q.  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool pm_mmx_factor(const double* slots, size_t stride, int nranks, int d,
+                                              const MMScratch& q, int lane) {
+  double Mtot = 0.0;
+  for (int w = 0; w < nranks; ++w) Mtot += slots[w * stride];
+  const double inv_m = 1.0 / Mtot, inv_m1 = 1.0 / (Mtot - 1.0);
+  for (int j = lane; j < d; j += 64) {
+    double m = 0.0, zm = 0.0, zz = 0.0;
+    for (int w = 0; w < nranks; ++w) {
+      const double* sl = slots + w * stride;
+      m += sl[0] * sl[1 + j];
+      zm += sl[1 + d + d * d + j];
+      zz += sl[1 + 2 * d + d * d + j];
+    }
+    m *= inv_m;
+    zm *= inv_m;
+    q.mean[j] = m;
+    q.zmean[j] = zm;
+    q.zistd[j] = pm_rsqrt((zz - Mtot * zm * zm) * inv_m1);
+  }
+  pm_wave_sync();
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e - i * d;
+    double acc = 0.0;
+    if (j <= i) {
+      const double mi = q.mean[i], mj = q.mean[j];
+      for (int w = 0; w < nranks; ++w) {
+        const double* sl = slots + w * stride;
+        acc += sl[1 + d + e] + sl[0] * (sl[1 + i] - mi) * (sl[1 + j] - mj);
+      }
+      acc = acc * inv_m1 + (i == j ? 1e-12 : 0.0);
+    }
+    q.Lm[e] = acc;
+  }
+  pm_wave_sync();
+  return pm_mm_chol(d, q, lane);
+}
+
+// out rows = mean + zhat L^T for this rank's M rows of the group (pm_mm_fwd's last loop)
+__device__ __forceinline__ void pm_mmx_apply(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
+                                             float* out, int out_ld, const MMScratch& q, int lane) {
+  for (int e = lane; e < M * d; e += 64) {
+    const int r = e / d, j = e - r * d;
+    double acc = q.mean[j];
+    const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
+    for (int c = 0; c <= j; ++c)
+      acc += ((double)z[zr + c] - q.zmean[c]) * q.zistd[c] * q.Lm[j * d + c];
+    out[(size_t)r * out_ld + j] = (float)acc;
+  }
+}
+
+// this rank's part of mbar = sum_r g_r (d) and Lbar = tril(g^T zhat) (d*d) -> sums[d + d*d]
+__device__ __forceinline__ void pm_mmx_bwd_sums(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
+                                                const float* g, int g_ld, const MMScratch& q, double* sums,
+                                                int lane) {
+  {
+    const int e2 = pm_pow2ceil(d);
+    const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
+    const int part = lane % P;
+    for (int base = 0; base < d; base += per) {
+      const int j = base + lane / P;
+      double a = 0.0;
+      if (j < d)
+        for (int r = part; r < M; r += P) a += (double)g[(size_t)r * g_ld + j];
+      a = pm_seg_sum(a, P);
+      if (j < d && part == 0) sums[j] = a;
+    }
+  }
+  {
+    const int e2 = pm_pow2ceil(d * d);
+    const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
+    const int part = lane % P;
+    for (int base = 0; base < d * d; base += per) {
+      const int e = base + lane / P;
+      const int i = e / d, j = e - i * d;
+      double acc = 0.0;
+      const bool live = e < d * d && j <= i;
+      if (live) {
+        const double zm = q.zmean[j], zs = q.zistd[j];
+        for (int r = part; r < M; r += P)
+          acc += (double)g[(size_t)r * g_ld + i] *
+                 (((double)z[(size_t)pm_zidx(zrow0, r, Bg) * z_ld + j] - zm) * zs);
+      }
+      acc = pm_seg_sum(acc, P);
+      if (e < d * d && part == 0) sums[d + e] = live ? acc : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernels.  One wavefront per (rank slot, group[, step]); the caller's rows of group gi are rows
+// [gi * A.M, (gi + 1) * A.M) of this device; their global row (the cyclic noise index of utils/rollout.py:53-59)
+// is gi * span_rows + span_off + i.
+// ---------------------------------------------------------------------------
+struct MmxArgs {
+  int nranks, rank;
+  int span_rows, span_off;   // rows of a group over all ranks; this rank's first row inside each group
+  double* buf;               // forward [nranks][n_items][slot]; backward [n_items][d + d*d]
+  double* fac;               // [n_items][pm_mm_fac_doubles(d)]: the factor, forward -> adjoint
+};
+
+// what == 0: the states sampled by step t (A.xt -> A.states[t+1], d = D, items = groups);
+// what == 1: the rewards of all steps (A.rt -> A.rewards, d = 1, items = (step, group))
+template <int WHAT>
+struct MmxItem {
+  int d, t, gi, item, n_items, zrow0;
+  const float *src, *z;
+  float* out;
+  __device__ MmxItem(const RolloutArgs& A, const MmxArgs& X, int t_arg, int bid) {
+    if (WHAT == 0) {
+      d = A.D; t = t_arg; gi = bid; item = bid; n_items = A.G;
+      src = A.xt + ((size_t)t * A.B + (size_t)gi * A.M) * A.D;
+      out = A.states + ((size_t)(t + 1) * A.B + (size_t)gi * A.M) * A.D;
+      z = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
+    } else {
+      d = 1; t = bid / A.G; gi = bid - t * A.G; item = bid; n_items = A.H * A.G;
+      src = A.rt + (size_t)t * A.B + (size_t)gi * A.M;
+      out = A.rewards + (size_t)t * A.B + (size_t)gi * A.M;
+      z = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
+    }
+    zrow0 = pm_zrow0(t, gi * X.span_rows + X.span_off, A.flags);
+  }
+};
+
+template <int WHAT>
+__global__ __launch_bounds__(64) void pm_mmx_stats_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+  extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
+  const int lane = threadIdx.x;
+  const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
+  const size_t ss = pm_mmx_slot_doubles(I.d);
+  const int w = blockIdx.y;
+  double* slot = X.buf + ((size_t)w * I.n_items + I.item) * ss;
+  if (w != X.rank) {
+    for (int e = lane; e < (int)ss; e += 64) slot[e] = 0.0;
+    return;
+  }
+  pm_mmx_stats(I.src, I.d, A.M, I.d, I.z, I.d, I.zrow0, A.Bg, slot, mmx_scr, lane);
+}
+
+template <int WHAT>
+__global__ __launch_bounds__(64) void pm_mmx_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+  extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
+  const int lane = threadIdx.x;
+  const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
+  const size_t ss = pm_mmx_slot_doubles(I.d);
+  const MMScratch q = pm_mm_carve(mmx_scr, I.d);
+  const bool ok = pm_mmx_factor(X.buf + (size_t)I.item * ss, (size_t)I.n_items * ss, X.nranks, I.d, q, lane);
+  double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
+  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) fac[e] = mmx_scr[e];
+  pm_mmx_apply(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, I.out, I.d, q, lane);
+  if (!ok && lane == 0) atomicMin(A.status, I.t);
+}
+
+// adjoint, first half: g = dL/d(moment-matched rows) of this rank -> its part of the two sums.
+// WHAT == 0: g = A.gx_carry (dL/dx_{t+1}); WHAT == 1: g = A.grad_rewards.
+template <int WHAT>
+__global__ __launch_bounds__(64) void pm_mmx_bwd_sums_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+  extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
+  const int lane = threadIdx.x;
+  const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
+  double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
+  if (A.nvalid && I.t >= *A.nvalid) {   // a step the forward sweep did not complete: nothing to add (the
+    for (int e = lane; e < (int)pm_mmx_bwd_doubles(I.d); e += 64) sums[e] = 0.0;   // collective still runs)
+    return;
+  }
+  const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
+  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
+  pm_wave_sync();
+  const MMScratch q = pm_mm_carve(mmx_scr, I.d);
+  const float* g = WHAT == 0 ? A.gx_carry + (size_t)I.gi * A.M * A.D
+                             : A.grad_rewards + (size_t)I.t * A.B + (size_t)I.gi * A.M;
+  pm_mmx_bwd_sums(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, g, I.d, q, sums, lane);
+}
+
+// adjoint, second half: the summed (mbar, Lbar) -> dL/d(rows before moment matching) for this rank's rows.
+// WHAT == 0: in place in A.gx_carry; WHAT == 1: A.grad_rewards -> gr_tilde.
+template <int WHAT>
+__global__ __launch_bounds__(64) void pm_mmx_bwd_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg,
+                                                              float* gr_tilde) {
+  extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
+  const int lane = threadIdx.x;
+  const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
+  if (A.nvalid && I.t >= *A.nvalid) return;
+  const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
+  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
+  const MMScratch q = pm_mm_carve(mmx_scr, I.d);
+  const double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
+  pm_wave_sync();
+  for (int e = lane; e < I.d; e += 64) q.mbar[e] = sums[e];
+  for (int e = lane; e < I.d * I.d; e += 64) q.P[e] = sums[I.d + e];
+  pm_wave_sync();
+  const double Mtot = (double)X.span_rows;
+  float* gout = WHAT == 0 ? A.gx_carry + (size_t)I.gi * A.M * A.D
+                          : gr_tilde + (size_t)I.t * A.B + (size_t)I.gi * A.M;
+  pm_mm_bwd_finish(I.src, I.d, A.M, I.d, 1.0 / Mtot, 1.0 / (Mtot - 1.0), gout, I.d, q, lane);
+}

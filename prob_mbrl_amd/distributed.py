@@ -91,14 +91,13 @@ class GradComm:
 _COMMS = {}
 
 
-def grad_allreduce(group=None, device=None):
-    """The in-place sum all-reduce of the flat gradient for this process group: through the C ABI on
-    the compute stream when the group runs on RCCL (backend nccl), through torch.distributed
-    otherwise (gloo: CPU tests and the one-device debugging mode of bench.py) or when RCCL cannot be
-    initialised here (reported once)."""
+def get_comm(group=None, device=None):
+    """The RCCL communicator behind the C ABI for this process group (one per group and device, created on first
+    use; collective), or None when the group does not run on RCCL (gloo: CPU tests and the one-device debugging
+    mode of bench.py) or RCCL cannot be initialised here (reported once)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return lambda t: t
+        return None
     key = (id(group), str(device))
     if key not in _COMMS:
         comm = None
@@ -117,7 +116,18 @@ def grad_allreduce(group=None, device=None):
                 comm.close()
                 comm = None
         _COMMS[key] = comm
-    comm = _COMMS[key]
+    return _COMMS[key]
+
+
+def grad_allreduce(group=None, device=None):
+    """The in-place sum all-reduce of the flat gradient for this process group: through the C ABI on
+    the compute stream when the group runs on RCCL (backend nccl), through torch.distributed
+    otherwise (gloo: CPU tests and the one-device debugging mode of bench.py) or when RCCL cannot be
+    initialised here (reported once)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return lambda t: t
+    comm = get_comm(group, device)
     if comm is not None:
         return comm.allreduce_
     return lambda t: allreduce_sum_(t, group)

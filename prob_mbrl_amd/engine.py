@@ -282,7 +282,7 @@ class Engine:
                  max_log_std_pol=LOG_MAX_STD, max_log_std_dyn=LOG_MAX_STD, zmm_per_step=False,
                  force_generic=False, no_shaped=False, infer_ns=False, precision=None,
                  pol_masks_per_step=False, dyn_masks_per_step=False, pol_angle_dims=(), dyn_angle_dims=(),
-                 dyn_components=0, gmm_exact_noise_grad=False):
+                 dyn_components=0, gmm_exact_noise_grad=False, mm_span=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('prob_mbrl_amd needs a HIP device (no CPU fallback)')
@@ -327,6 +327,12 @@ class Engine:
         # GaussianMixtureDensity dynamics head (models/densities.py:151-259): components (0 / 1: diagonal Gaussian)
         self.n_comp = int(dyn_components) if dyn_components and int(dyn_components) > 1 else 0
         cfg.dyn_components = self.n_comp
+        # moment-matching groups spread over ranks: (rows of a group over all ranks, this rank's first row in
+        # each group, ranks, this rank) -- pmbrl_config.mm_span_*; needs attach_collective() before forward()
+        self.mm_span = tuple(int(v) for v in mm_span) if mm_span else None
+        if self.mm_span:
+            cfg.mm_span_rows, cfg.mm_span_offset, cfg.mm_span_ranks, cfg.mm_span_rank = self.mm_span
+        self._coll = None
         self.cfg = cfg
         self.B, self.D, self.U, self.H = B, D, U, H
         self.n_pol_layers = len(pol_dims) - 1
@@ -370,6 +376,49 @@ class Engine:
                 self.plan = None
         except Exception:
             pass
+
+    def attach_collective(self, group):
+        """The statistics exchange of moment-matching groups spread over the ranks of `group` (pmbrl_config.
+        mm_span_rows): RCCL through the C ABI on the compute stream when the group runs on it (pmbrl_plan_set_comm),
+        otherwise a host-staged torch.distributed all-reduce handed to the library as a callback
+        (pmbrl_plan_set_collective: gloo groups -- the CPU-transport tests with both ranks on one device)."""
+        if self._coll is not None and self._coll[0] is group:
+            return
+        ws = self.workspace
+        if callable(group):
+            # a transport of the caller's: group(view) sums the fp64 device tensor `view` over the ranks in place
+            # (tests: ranks as threads of one process)
+            on_device, custom = False, group
+        else:
+            import torch.distributed as dist
+            from .distributed import get_comm
+            comm = get_comm(group, self.device)
+            if comm is not None:
+                _lib.check(self.lib.pmbrl_plan_set_comm(self.plan, comm.comm), 'pmbrl_plan_set_comm')
+                self._coll = (group, comm)
+                return
+            on_device, custom = dist.get_backend(group) == 'nccl', None
+
+        def allreduce(ctx, stream, buf, n):
+            try:
+                off = int(buf) - ws.data_ptr()
+                view = ws[off:off + 8 * n].view(torch.float64)
+                if custom is not None:
+                    custom(view)
+                elif on_device:
+                    dist.all_reduce(view, group=group)
+                else:
+                    host = view.cpu()          # (orders behind the kernels queued on the current stream)
+                    dist.all_reduce(host, group=group)
+                    view.copy_(host)
+                return 0
+            except Exception:   # noqa: BLE001 -- must not unwind through the C caller
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = _lib.COLLECTIVE_FN(allreduce)
+        _lib.check(self.lib.pmbrl_plan_set_collective(self.plan, fn, None), 'pmbrl_plan_set_collective')
+        self._coll = (group, fn)      # keeps the callback alive as long as the plan may call it
 
     # ------------------------------------------------------------------
     def forward(self, x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias,

@@ -101,12 +101,12 @@ def _reward_key(spec):
 def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_states, mm_rewards,
                mm_groups, device, B_global=None, row_offset=0, zmm_per_step=False,
                max_log_std=(E.LOG_MAX_STD, E.LOG_MAX_STD), infer_ns=False, precision=None,
-               masks_per_step=(False, False), angle_dims=((), ()), gmm=(0, False)):
+               masks_per_step=(False, False), angle_dims=((), ()), gmm=(0, False), mm_span=None):
     precision = precision or E.get_precision()
     key = (str(device), B, D, U, H, tuple(pol_dims), tuple(pol_keep), tuple(dyn_dims),
            tuple(dyn_keep), _reward_key(spec), bool(mm_states), bool(mm_rewards), mm_groups,
            B_global, row_offset, zmm_per_step, max_log_std, bool(infer_ns), precision, tuple(masks_per_step),
-           tuple(angle_dims[0]), tuple(angle_dims[1]), tuple(gmm))
+           tuple(angle_dims[0]), tuple(angle_dims[1]), tuple(gmm), tuple(mm_span) if mm_span else None)
     eng = _ENGINES.get(key)
     if eng is None:
         if len(_ENGINES) > 16:
@@ -118,7 +118,7 @@ def get_engine(B, D, U, H, pol_dims, pol_keep, dyn_dims, dyn_keep, spec, mm_stat
                        max_log_std_dyn=max_log_std[1], infer_ns=infer_ns, precision=precision,
                        pol_masks_per_step=masks_per_step[0], dyn_masks_per_step=masks_per_step[1],
                        pol_angle_dims=angle_dims[0], dyn_angle_dims=angle_dims[1],
-                       dyn_components=gmm[0], gmm_exact_noise_grad=gmm[1])
+                       dyn_components=gmm[0], gmm_exact_noise_grad=gmm[1], mm_span=mm_span)
         _ENGINES[key] = eng
     return eng
 
@@ -128,7 +128,8 @@ class Bundle:
 
     def __init__(self, dynamics, policy, B, H, resample_state_noise, resample_action_noise,
                  mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=None, row_offset=0,
-                 infer_ns=False, precision=None, resample_policy=False, resample_model=False):
+                 infer_ns=False, precision=None, resample_policy=False, resample_model=False,
+                 mm_span=None, process_group=None):
         if not isinstance(policy, M.Policy) or not isinstance(dynamics, M.DynamicsModel):
             raise TypeError('rollout() needs prob_mbrl_amd.models.Policy / DynamicsModel')
         if dynamics.reward_func is None or not hasattr(dynamics.reward_func, 'spec'):
@@ -252,7 +253,13 @@ class Bundle:
                                  infer_ns=infer_ns and (mm_states or mm_rewards), precision=precision,
                                  masks_per_step=(bool(resample_policy), bool(resample_model)),
                                  angle_dims=self.angle_dims,
-                                 gmm=(self.n_comp, bool(getattr(ddens, 'exact_noise_grad', False))))
+                                 gmm=(self.n_comp, bool(getattr(ddens, 'exact_noise_grad', False))),
+                                 mm_span=mm_span if (mm_states or mm_rewards) else None)
+        if mm_span and (mm_states or mm_rewards):
+            # groups spread over the ranks of process_group: their per-step statistics cross devices
+            if process_group is None:
+                raise ValueError('mm_span needs the process_group whose ranks share the groups')
+            self.engine.attach_collective(process_group)
 
     def forward(self, x0, out=None):
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
@@ -326,11 +333,15 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     B_global, row_offset = kwargs.pop('B_global', None), kwargs.pop('row_offset', 0)
     agn_out = kwargs.pop('action_grad_norms_out', None)
     precision = kwargs.pop('precision', None)
+    # moment-matching groups spread over the ranks of process_group (not in the reference, which is single-process):
+    # mm_span = (rows of a group over all ranks, this rank's first row inside each group, ranks, this rank)
+    mm_span, process_group = kwargs.pop('mm_span', None), kwargs.pop('process_group', None)
     while True:
         bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
                         mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=B_global,
                         row_offset=row_offset, infer_ns=bool(infer_noise_variables), precision=precision,
-                        resample_policy=bool(resample_policy), resample_model=bool(resample_model))
+                        resample_policy=bool(resample_policy), resample_model=bool(resample_model),
+                        mm_span=mm_span, process_group=process_group)
         # a list that backward() appends the [H, B] matrix of ||dL/da_t|| to (prioritised replay)
         bundle.agn_out = agn_out
         x0 = states.to(device=bundle.device, dtype=torch.float32)

@@ -76,7 +76,10 @@ def _mcp_worker(rank, world, port, name, out):
             torch.tensor(d['x0'], device='cuda:0'), dyn, pol, int(d['H']), opt, None,
             int(d['mcp_n_iters']), maximize=True, clip_grad=float(d['mcp_clip']),
             on_iteration=lambda i, loss, *a: losses.append(float(loss)),
-            frozen_noise=dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1)),
+            frozen_noise=(dict(z_mm=torch.tensor(d['z_mm']), z_rr=torch.tensor(d['z_rr'])) if bool(d['mm_states'])
+                          else dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1))),
+            mm_states=bool(d['mm_states']), mm_rewards=bool(d['mm_rewards']),
+            discount=None if np.allclose(d['gamma'], d['gamma'][0]) else float(d['gamma'][1] / d['gamma'][0]),
             process_group=dist.group.WORLD)
         lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
         final = torch.cat([t.detach().reshape(-1) for l in lins for t in (l.weight, l.bias)])
@@ -105,3 +108,30 @@ def test_mc_pilco_two_ranks_match_reference():
         assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
         assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
     assert np.array_equal(res[0][2], res[1][2])      # replicas stay bit-identical
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_mc_pilco_one_global_moment_matching_group_over_ranks(world):
+    """mm_groups=None on a sharded run (the examples' default, examples/deep_pilco_mm.py:31): ONE Gaussian over the
+    particles of all ranks at every step -- the ranks exchange the group's fp64 statistics per step, forward and in
+    the adjoint (pmbrl_config.mm_span_rows).  The fixture is the REAL reference's single-process
+    mc_pilco with moment-matched states and rewards over its 30 rows; here 15 + 15 and 10 + 10 + 10 rows on
+    separate processes reproduce its losses and final parameters on every rank."""
+    import torch.multiprocessing as mp
+    name = 'mcp_mm1'
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mcp_worker, args=(r, world, port, name, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = common.load(name)
+    for rank, losses, final in res:
+        assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
+        assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+    for r in res[1:]:
+        assert np.array_equal(res[0][2], r[2])      # replicas stay bit-identical
