@@ -1,0 +1,154 @@
+"""GPU (-m gpu): moment-matching groups spread over several ranks (pmbrl_config.mm_span_*), the ranks
+as THREADS of one process: every rank holds a slice of every group, the per-step statistics cross the ranks through
+pmbrl_plan_set_collective (here a barrier and a sum over the ranks' device buffers).  What the ranks compute
+together must be what one process computes on all rows: the fixtures are runs of the real reference
+(tools/make_golden.py) with its fp64 trajectory and policy gradient.  The multi-process form of the same path
+(torch.distributed transport, mc_pilco) is in tests/test_gpu_two_ranks.py."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+class ThreadSum:
+    """In-place sum over the ranks (threads) of a device tensor, same result on every rank."""
+
+    def __init__(self, world):
+        self.world, self.bar, self.views, self.total = world, threading.Barrier(world, timeout=30), [None] * world, None
+
+    def rank(self, r):
+        def allreduce(view):
+            torch.cuda.synchronize()
+            self.views[r] = view
+            self.bar.wait()
+            if r == 0:
+                tot = self.views[0].clone()
+                for v in self.views[1:]:
+                    tot += v
+                torch.cuda.synchronize()
+                self.total = tot
+            self.bar.wait()
+            view.copy_(self.total)
+            torch.cuda.synchronize()
+            self.bar.wait()
+        return allreduce
+
+
+def _rows(B, G, parts, r):
+    """Global rows of rank r: slice [off_r, off_r + parts[r]) of every group of M = B / G rows."""
+    M = B // G
+    off = sum(parts[:r])
+    return np.concatenate([np.arange(g * M + off, g * M + off + parts[r]) for g in range(G)]), off
+
+
+def _run(name, parts, precision=None, fail_at=None):
+    from prob_mbrl_amd import rollout as RO
+    d0 = common.load(name)
+    B = d0['x0'].shape[0]
+    G = max(int(d0['mm_groups']), 1)
+    M, H, W = B // G, int(d0['H']), len(parts)
+    assert sum(parts) == M
+    ts = ThreadSum(W)
+    res, err = [None] * W, []
+
+    def worker(r):
+        try:
+            rows, off = _rows(B, G, parts, r)
+            d = dict(d0)
+            for k in list(d):
+                if k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and not k.endswith(('_shape', '_bits'))):
+                    d[k] = d[k][rows]
+            dyn, pol = common.modules_from_fixture(d, name, DEV)
+            x0 = torch.tensor(d['x0'], device=DEV)
+            # (the engine interface mc_pilco's fused path uses, not loss.backward(): autograd runs the device nodes
+            #  of every thread's graph on ONE worker thread per device, so two thread-ranks would wait for each
+            #  other inside it; ranks that are processes have an autograd engine each)
+            bundle = RO.Bundle(dyn, pol, len(rows), H, False, False, True, True, G if G > 1 else None,
+                               torch.tensor(d['z_mm'], device=DEV), torch.tensor(d['z_rr'], device=DEV),
+                               B_global=B, precision=precision, mm_span=(M, off, W, r), process_group=ts.rank(r))
+            eng = bundle.engine
+            S, A, R = bundle.forward(x0)
+            n = min(eng.valid_steps(), H)
+            if fail_at is not None:
+                # a failure at step fail_at as the forward sweep reports it: status word, poisoned tail
+                assert n == H
+                n = fail_at
+                eng.status[0] = n
+                S[n + 1:], A[n:], R[n:] = float('nan'), float('nan'), float('nan')
+            gw = torch.tensor(common.loss_weights(d, B)[:, :len(rows)], device=DEV)
+            loss = float((R[:n, :, 0] * gw[:n]).sum())
+            g, _, _ = eng.backward(gw)
+            res[r] = (rows, S[:n + 1].cpu().numpy(), R[:n].cpu().numpy(), loss, g.double().cpu().numpy())
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+            ts.bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=90)
+    if err:
+        raise err[0]
+    n = res[0][1].shape[0]
+    assert all(x[1].shape[0] == n for x in res)        # every rank kept the same horizon
+    S = np.zeros((n, B, d0['x0'].shape[1]))
+    for rows, s, _, _, _ in res:
+        S[:, rows] = s
+    return d0, S, sum(x[3] for x in res), sum(x[4] for x in res)
+
+
+@pytest.mark.parametrize('name,parts', [
+    ('mm1_d5', (12, 12)),              # one group of 24 rows over two ranks
+    ('mm1_b100_h40', (40, 35, 25)),    # the H = 40 regime SURVEY 7 flags, unequal slices over three ranks
+    ('mmg_d4', (6, 4)),                # four groups, each spread over two ranks
+    ('mmg_h40', (15, 10)),
+    ('dcp_d6_mmg', (5, 4, 3)),         # D = 6, three groups over three ranks
+    ('full200_mmg', (13, 12)),         # the 200-wide cart-pole networks (latency-optimised kernel family)
+])
+def test_groups_spread_over_ranks_match_the_reference(name, parts):
+    d, S, loss, grad = _run(name, parts)
+    assert S.shape == d['ref64_states'].shape
+    assert common.rel(S, d['ref64_states']) < 2e-5
+    assert abs(loss - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+    assert common.rel(grad, d['ref64_grad']) < 1e-4
+
+
+def test_groups_spread_over_ranks_in_exact_fp32():
+    d, S, loss, grad = _run('mmg_d4', (5, 5), precision='f32')
+    assert common.rel(S, d['ref64_states']) < 2e-5
+    assert common.rel(grad, d['ref64_grad']) < 1e-4
+
+
+def test_truncated_horizon_with_groups_spread_over_ranks():
+    """utils/rollout.py:154-157 (a failure after more than 5 steps: the first n steps are kept): the adjoint's
+    statistics exchange covers the completed steps only, every rank still issues every collective."""
+    d0 = common.load('trunc_mm')
+    d, S, loss, grad = _run('trunc_mm', (16, 14), fail_at=int(d0['fail_step']))
+    assert S.shape == d['ref64_states'].shape
+    assert common.rel(S, d['ref64_states']) < 2e-5
+    assert abs(loss - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+    assert np.all(np.isfinite(grad)) and common.rel(grad, d['ref64_grad']) < 1e-4
+
+
+def test_span_needs_a_collective_and_rejects_bad_slices():
+    import prob_mbrl_amd as pm
+    d = common.load('mmg_d4')
+    rows, off = _rows(40, 4, (6, 4), 0)
+    for k in list(d):
+        if k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and not k.endswith(('_shape', '_bits'))):
+            d[k] = d[k][rows]
+    dyn, pol = common.modules_from_fixture(d, 'mmg_d4', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    kw = dict(resample_state_noise=False, resample_action_noise=False, mm_states=True, mm_rewards=True, mm_groups=4,
+              z_mm=torch.tensor(d['z_mm'], device=DEV), z_rr=torch.tensor(d['z_rr'], device=DEV), B_global=40)
+    with pytest.raises(ValueError):
+        pm.utils.rollout(x0, dyn, pol, 4, mm_span=(10, 0, 2, 0), **kw)               # no process_group
+    with pytest.raises(pm._lib.PmbrlError):
+        pm.utils.rollout(x0, dyn, pol, 4, mm_span=(10, 5, 2, 1), process_group=lambda v: None, **kw)   # 5 + 6 > 10
