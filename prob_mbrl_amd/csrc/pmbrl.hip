@@ -1333,10 +1333,11 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
         // groups spread over ranks: own statistics -> sum over the ranks -> factor + own rows
         MmxArgs X = mmx_args(p, ws, false);
         X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
-        const size_t scr = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
-        hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G, X.nranks), dim3(64), scr, s, Am, X, t);
+        const int nw = pm_mmx_waves(p->M, p->cfg.D);
+        const size_t scr = pm_mmx_lds_doubles(p->cfg.D, nw) * sizeof(double);
+        hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G, X.nranks), dim3(64 * nw), scr, s, Am, X, t);
         if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * p->G * pm_mmx_slot_doubles(p->cfg.D))) return rc;
-        hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t);
+        hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t);
       }
     }
   }
@@ -1351,11 +1352,12 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     if (mm_r && p->span) {
       // the rewards of all steps: one exchange for the whole horizon
       const MmxArgs X = mmx_args(p, ws, true);
-      const size_t scr = pm_mm_scratch_doubles(1) * sizeof(double);
+      const int nw = std::min(4, pm_mmx_waves(p->M, 1));   // (H x G workgroups: fewer waves each)
+      const size_t scr = pm_mmx_lds_doubles(1, nw) * sizeof(double);
       const int n_items = p->cfg.H * p->G;
-      hipLaunchKernelGGL(pm_mmx_stats_kernel<1>, dim3(n_items, X.nranks), dim3(64), scr, s, A, X, 0);
+      hipLaunchKernelGGL(pm_mmx_stats_kernel<1>, dim3(n_items, X.nranks), dim3(64 * nw), scr, s, A, X, 0);
       if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * n_items * pm_mmx_slot_doubles(1))) return rc;
-      hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0);
+      hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64 * nw), scr, s, A, X, 0);
     } else if (mm_r)
       hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                          pm_mm_scratch_doubles(1) * sizeof(double), s, A);
@@ -1398,11 +1400,12 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
   if (!p->fast) { A.ext_reward = 1; }
   if (mm_r && p->span) {
     const MmxArgs X = mmx_args(p, ws, true);
-    const size_t scr = pm_mm_scratch_doubles(1) * sizeof(double);
+    const int nw = std::min(4, pm_mmx_waves(p->M, 1));
+    const size_t scr = pm_mmx_lds_doubles(1, nw) * sizeof(double);
     const int n_items = p->cfg.H * p->G;
-    hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0);
+    hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<1>, dim3(n_items), dim3(64 * nw), scr, s, A, X, 0);
     if (int rc = mmx_exchange(p, s, X.buf, (size_t)n_items * pm_mmx_bwd_doubles(1))) return rc;
-    hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<1>, dim3(n_items), dim3(64), scr, s, A, X, 0, grt);
+    hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<1>, dim3(n_items), dim3(64 * nw), scr, s, A, X, 0, grt);
     A.grad_rewards = grt;
   } else if (mm_r) {
     // adjoint of the reward moment matching for all (t, group) up front
@@ -1521,10 +1524,11 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
       } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
         MmxArgs X = mmx_args(p, ws, false);
         X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
-        const size_t scr = pm_mm_scratch_doubles(p->cfg.D) * sizeof(double);
-        hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t);
+        const int nw = pm_mmx_waves(p->M, p->cfg.D);
+        const size_t scr = pm_mmx_lds_doubles(p->cfg.D, nw) * sizeof(double);
+        hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t);
         if (int rc = mmx_exchange(p, s, X.buf, (size_t)p->G * pm_mmx_bwd_doubles(p->cfg.D))) return rc;
-        hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<0>, dim3(p->G), dim3(64), scr, s, Am, X, t, (float*)nullptr);
+        hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t, (float*)nullptr);
       }
       A.t0 = t; A.t1 = t + 1;
       launch_bwd_rt(p, A, s);

@@ -191,10 +191,11 @@ __device__ __forceinline__ bool pm_mm_fwd(const float* s, int s_ld, int M, int d
 }
 
 // The adjoint behind the sums over the rows: (q.mbar = sum_r g, q.P = Lbar = tril(g^T zhat), the factor in q)
-// -> gout = dL/d s for the M_rows rows at s; inv_m / inv_m1 = 1 / M and 1 / (M - 1) of the WHOLE group (the rows
-// at s may be a part of it: groups spanning devices, pm_mmx_*).
-__device__ __forceinline__ void pm_mm_bwd_finish(const float* s, int s_ld, int M, int d, double inv_m, double inv_m1,
-                                                 float* gout, int gout_ld, const MMScratch& q, int lane) {
+// -> gout = dL/d s for the M rows at s; inv_m / inv_m1 = 1 / M and 1 / (M - 1) of the WHOLE group (the rows
+// at s may be a part of it: groups spread over devices, pmbrl_mmx.h);
+// first the serial part on ONE wave (pm_mm_bwd_solve: q.P <- the symmetric matrix of the row formula), then the
+// rows (pm_mm_bwd_rows: any number of threads, thread `tid` of `nthreads`).
+__device__ __forceinline__ void pm_mm_bwd_solve(int d, double inv_m1, const MMScratch& q, int lane) {
   // Phi = tril(L^T Lbar), diagonal halved -> q.Sb
   for (int e = lane; e < d * d; e += 64) {
     const int i = e / d, j = e - i * d;
@@ -230,14 +231,22 @@ __device__ __forceinline__ void pm_mm_bwd_finish(const float* s, int s_ld, int M
     q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) * inv_m1;
   }
   pm_wave_sync();
+}
+__device__ __forceinline__ void pm_mm_bwd_rows(const float* s, int s_ld, int M, int d, double inv_m, float* gout,
+                                               int gout_ld, const MMScratch& q, int tid, int nthreads) {
   // sbar[r][j] = sum_c Delta[r][c] P[c][j] + mbar[j]/M      (mean_r of the first term is 0)
-  for (int e = lane; e < M * d; e += 64) {
+  for (int e = tid; e < M * d; e += nthreads) {
     const int r = e / d, j = e - r * d;
     double acc = q.mbar[j] * inv_m;
     for (int c = 0; c < d; ++c) acc += ((double)s[r * s_ld + c] - q.mean[c]) * q.P[c * d + j];
     // all reads of g happened before the first pm_wave_sync above: in-place is safe
     gout[r * gout_ld + j] = (float)acc;
   }
+}
+__device__ __forceinline__ void pm_mm_bwd_finish(const float* s, int s_ld, int M, int d, double inv_m, double inv_m1,
+                                                 float* gout, int gout_ld, const MMScratch& q, int lane) {
+  pm_mm_bwd_solve(d, inv_m1, q, lane);
+  pm_mm_bwd_rows(s, s_ld, M, d, inv_m, gout, gout_ld, q, lane, 64);
   pm_wave_sync();
 }
 

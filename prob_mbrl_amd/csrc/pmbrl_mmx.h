@@ -11,28 +11,43 @@
 //      a 1 x 1 reward "covariance" of nearly equal rewards would cancel to noise), factors the covariance
 //      exactly as the single-device routine does (pm_mm_chol) and maps its own rows (pm_mmx_apply).
 // The adjoint needs two sums over all rows of the group -- mbar = sum_r g_r and Lbar = tril(g^T zhat) -- which
-// are plain sums (pm_mmx_bwd_sums, one all-reduce), then the single-device tail (pm_mm_bwd_finish) on its own
-// rows with the group's 1 / M.  One wavefront per group; everything in fp64 like pmbrl_mm.h.
+// are plain sums (pm_mmx_bwd_sums, one all-reduce), then the single-device tail (pm_mm_bwd_solve / _rows) on its own
+// rows with the group's 1 / M.  One workgroup per group -- the sums over the rows split over its waves, the d x d
+// chain on wave 0; everything in fp64 like pmbrl_mm.h.
 #pragma once
 #include "pmbrl_mm.h"
 
 __host__ __device__ inline size_t pm_mmx_slot_doubles(int d) { return (size_t)d * d + 3 * d + 1; }
 __host__ __device__ inline size_t pm_mmx_bwd_doubles(int d) { return (size_t)d * d + d; }
 
+// Waves per group: the sums over a rank's rows are split over the waves of one workgroup (rows wid * P + part,
+// stride nw * P), the waves' partial sums meet in LDS and wave 0 adds them in wave order (deterministic).
+// `part` holds nw x pm_mmx_part_doubles(d) doubles.
+__host__ __device__ inline size_t pm_mmx_part_doubles(int d) { return (size_t)d * d + 3 * d; }
+__host__ inline int pm_mmx_waves(int M, int d) {
+  int nw = (M + 63) / 64;
+  const int cap = (int)(4096 / pm_mmx_part_doubles(d));   // <= 32 KB of partial sums (with the scratch: < 64 KB of LDS)
+  if (nw > cap) nw = cap;
+  if (nw > 16) nw = 16;
+  return nw < 1 ? 1 : nw;
+}
+
 // slot: [n | mean (d) | M2 (d*d, lower triangle used) | sum z (d) | sum z^2 (d)]
+// (all waves of the workgroup call this; scr: d doubles, part: see above)
 __device__ __forceinline__ void pm_mmx_stats(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
-                                             int zrow0, int Bg, double* slot, double* scr, int lane) {
+                                             int zrow0, int Bg, double* slot, double* scr, double* part, int nw,
+                                             int wid, int lane) {
   double* mean = scr;   // d doubles of scratch
   const double inv_m = 1.0 / (double)M;
   {
     const int e2 = pm_pow2ceil(d);
     const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
-    const int part = lane % P;
+    const int pt = lane % P;
     for (int base = 0; base < d; base += per) {
       const int j = base + lane / P;
       double m = 0.0, zm = 0.0, zz = 0.0;
       if (j < d)
-        for (int i = part; i < M; i += P) {
+        for (int i = wid * P + pt; i < M; i += nw * P) {
           m += (double)s[(size_t)i * s_ld + j];
           const double zv = (double)z[(size_t)pm_zidx(zrow0, i, Bg) * z_ld + j];
           zm += zv;
@@ -41,20 +56,36 @@ __device__ __forceinline__ void pm_mmx_stats(const float* s, int s_ld, int M, in
       m = pm_seg_sum(m, P);
       zm = pm_seg_sum(zm, P);
       zz = pm_seg_sum(zz, P);
-      if (j < d && part == 0) {
-        mean[j] = m * inv_m;
-        slot[1 + j] = m * inv_m;
-        slot[1 + d + d * d + j] = zm;
-        slot[1 + 2 * d + d * d + j] = zz;
+      if (j < d && pt == 0) {
+        double* pw = part + (size_t)wid * 3 * d;
+        pw[j] = m;
+        pw[d + j] = zm;
+        pw[2 * d + j] = zz;
       }
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+    for (int j = lane; j < d; j += 64) {
+      double m = 0.0, zm = 0.0, zz = 0.0;
+      for (int w = 0; w < nw; ++w) {
+        const double* pw = part + (size_t)w * 3 * d;
+        m += pw[j];
+        zm += pw[d + j];
+        zz += pw[2 * d + j];
+      }
+      mean[j] = m * inv_m;
+      slot[1 + j] = m * inv_m;
+      slot[1 + d + d * d + j] = zm;
+      slot[1 + 2 * d + d * d + j] = zz;
     }
     if (lane == 0) slot[0] = (double)M;
   }
-  pm_wave_sync();
+  __syncthreads();
   {
     const int e2 = pm_pow2ceil(d * d);
     const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
-    const int part = lane % P;
+    const int pt = lane % P;
     for (int base = 0; base < d * d; base += per) {
       const int e = base + lane / P;
       const int i = e / d, j = e - i * d;
@@ -62,14 +93,20 @@ __device__ __forceinline__ void pm_mmx_stats(const float* s, int s_ld, int M, in
       const bool live = e < d * d && j <= i;
       if (live) {
         const double mi = mean[i], mj = mean[j];
-        for (int r = part; r < M; r += P)
+        for (int r = wid * P + pt; r < M; r += nw * P)
           acc += ((double)s[(size_t)r * s_ld + i] - mi) * ((double)s[(size_t)r * s_ld + j] - mj);
       }
       acc = pm_seg_sum(acc, P);
-      if (e < d * d && part == 0) slot[1 + d + e] = live ? acc : 0.0;
+      if (e < d * d && pt == 0) part[(size_t)wid * d * d + e] = live ? acc : 0.0;
     }
   }
-  pm_wave_sync();
+  __syncthreads();
+  if (wid == 0)
+    for (int e = lane; e < d * d; e += 64) {
+      double acc = 0.0;
+      for (int w = 0; w < nw; ++w) acc += part[(size_t)w * d * d + e];
+      slot[1 + d + e] = acc;
+    }
 }
 
 // slots of all ranks (summed buffer, `stride` doubles from one rank's slot to the next) -> means, z
@@ -111,10 +148,10 @@ __device__ __forceinline__ bool pm_mmx_factor(const double* slots, size_t stride
   return pm_mm_chol(d, q, lane);
 }
 
-// out rows = mean + zhat L^T for this rank's M rows of the group (pm_mm_fwd's last loop)
+// out rows = mean + zhat L^T for this rank's M rows of the group (pm_mm_fwd's last loop), thread tid of nthreads
 __device__ __forceinline__ void pm_mmx_apply(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
-                                             float* out, int out_ld, const MMScratch& q, int lane) {
-  for (int e = lane; e < M * d; e += 64) {
+                                             float* out, int out_ld, const MMScratch& q, int tid, int nthreads) {
+  for (int e = tid; e < M * d; e += nthreads) {
     const int r = e / d, j = e - r * d;
     double acc = q.mean[j];
     const size_t zr = (size_t)pm_zidx(zrow0, r, Bg) * z_ld;
@@ -125,26 +162,28 @@ __device__ __forceinline__ void pm_mmx_apply(int M, int d, const float* z, int z
 }
 
 // this rank's part of mbar = sum_r g_r (d) and Lbar = tril(g^T zhat) (d*d) -> sums[d + d*d]
+// (all waves of the workgroup; part: nw x (d + d*d) doubles)
 __device__ __forceinline__ void pm_mmx_bwd_sums(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
                                                 const float* g, int g_ld, const MMScratch& q, double* sums,
-                                                int lane) {
+                                                double* part, int nw, int wid, int lane) {
+  double* pw = part + (size_t)wid * (d + d * d);
   {
     const int e2 = pm_pow2ceil(d);
     const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
-    const int part = lane % P;
+    const int pt = lane % P;
     for (int base = 0; base < d; base += per) {
       const int j = base + lane / P;
       double a = 0.0;
       if (j < d)
-        for (int r = part; r < M; r += P) a += (double)g[(size_t)r * g_ld + j];
+        for (int r = wid * P + pt; r < M; r += nw * P) a += (double)g[(size_t)r * g_ld + j];
       a = pm_seg_sum(a, P);
-      if (j < d && part == 0) sums[j] = a;
+      if (j < d && pt == 0) pw[j] = a;
     }
   }
   {
     const int e2 = pm_pow2ceil(d * d);
     const int P = e2 >= 64 ? 1 : 64 / e2, per = 64 / P;
-    const int part = lane % P;
+    const int pt = lane % P;
     for (int base = 0; base < d * d; base += per) {
       const int e = base + lane / P;
       const int i = e / d, j = e - i * d;
@@ -152,18 +191,25 @@ __device__ __forceinline__ void pm_mmx_bwd_sums(int M, int d, const float* z, in
       const bool live = e < d * d && j <= i;
       if (live) {
         const double zm = q.zmean[j], zs = q.zistd[j];
-        for (int r = part; r < M; r += P)
+        for (int r = wid * P + pt; r < M; r += nw * P)
           acc += (double)g[(size_t)r * g_ld + i] *
                  (((double)z[(size_t)pm_zidx(zrow0, r, Bg) * z_ld + j] - zm) * zs);
       }
       acc = pm_seg_sum(acc, P);
-      if (e < d * d && part == 0) sums[d + e] = live ? acc : 0.0;
+      if (e < d * d && pt == 0) pw[d + e] = live ? acc : 0.0;
     }
   }
+  __syncthreads();
+  if (wid == 0)
+    for (int e = lane; e < d + d * d; e += 64) {
+      double acc = 0.0;
+      for (int w = 0; w < nw; ++w) acc += part[(size_t)w * (d + d * d) + e];
+      sums[e] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
-// kernels.  One wavefront per (rank slot, group[, step]); the caller's rows of group gi are rows
+// kernels.  One workgroup per (rank slot, group[, step]); the caller's rows of group gi are rows
 // [gi * A.M, (gi + 1) * A.M) of this device; their global row (the cyclic noise index of utils/rollout.py:53-59)
 // is gi * span_rows + span_off + i.
 // ---------------------------------------------------------------------------
@@ -197,75 +243,89 @@ struct MmxItem {
   }
 };
 
+// LDS of the kernels: the one-wave scratch of pmbrl_mm.h, then the waves' partial sums
+__host__ __device__ inline size_t pm_mmx_lds_doubles(int d, int nw) {
+  return pm_mm_scratch_doubles(d) + (size_t)nw * pm_mmx_part_doubles(d);
+}
+
 template <int WHAT>
-__global__ __launch_bounds__(64) void pm_mmx_stats_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+__global__ __launch_bounds__(1024) void pm_mmx_stats_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
   extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
   const size_t ss = pm_mmx_slot_doubles(I.d);
   const int w = blockIdx.y;
   double* slot = X.buf + ((size_t)w * I.n_items + I.item) * ss;
   if (w != X.rank) {
-    for (int e = lane; e < (int)ss; e += 64) slot[e] = 0.0;
+    for (int e = threadIdx.x; e < (int)ss; e += blockDim.x) slot[e] = 0.0;
     return;
   }
-  pm_mmx_stats(I.src, I.d, A.M, I.d, I.z, I.d, I.zrow0, A.Bg, slot, mmx_scr, lane);
+  pm_mmx_stats(I.src, I.d, A.M, I.d, I.z, I.d, I.zrow0, A.Bg, slot, mmx_scr, mmx_scr + pm_mm_scratch_doubles(I.d),
+               nw, wid, lane);
 }
 
 template <int WHAT>
-__global__ __launch_bounds__(64) void pm_mmx_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+__global__ __launch_bounds__(1024) void pm_mmx_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
   extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
   const size_t ss = pm_mmx_slot_doubles(I.d);
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
-  const bool ok = pm_mmx_factor(X.buf + (size_t)I.item * ss, (size_t)I.n_items * ss, X.nranks, I.d, q, lane);
-  double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
-  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) fac[e] = mmx_scr[e];
-  pm_mmx_apply(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, I.out, I.d, q, lane);
-  if (!ok && lane == 0) atomicMin(A.status, I.t);
+  if (wid == 0) {
+    const bool ok = pm_mmx_factor(X.buf + (size_t)I.item * ss, (size_t)I.n_items * ss, X.nranks, I.d, q, lane);
+    double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
+    for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) fac[e] = mmx_scr[e];
+    if (!ok && lane == 0) atomicMin(A.status, I.t);
+  }
+  __syncthreads();
+  pm_mmx_apply(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, I.out, I.d, q, threadIdx.x, blockDim.x);
 }
 
 // adjoint, first half: g = dL/d(moment-matched rows) of this rank -> its part of the two sums.
 // WHAT == 0: g = A.gx_carry (dL/dx_{t+1}); WHAT == 1: g = A.grad_rewards.
 template <int WHAT>
-__global__ __launch_bounds__(64) void pm_mmx_bwd_sums_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
+__global__ __launch_bounds__(1024) void pm_mmx_bwd_sums_kernel(const RolloutArgs A, const MmxArgs X, int t_arg) {
   extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
   double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
   if (A.nvalid && I.t >= *A.nvalid) {   // a step the forward sweep did not complete: nothing to add (the
-    for (int e = lane; e < (int)pm_mmx_bwd_doubles(I.d); e += 64) sums[e] = 0.0;   // collective still runs)
+    for (int e = threadIdx.x; e < (int)pm_mmx_bwd_doubles(I.d); e += blockDim.x) sums[e] = 0.0;   // collective still runs)
     return;
   }
   const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
-  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
-  pm_wave_sync();
+  for (int e = threadIdx.x; e < (int)pm_mm_fac_doubles(I.d); e += blockDim.x) mmx_scr[e] = fac[e];
+  __syncthreads();
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
   const float* g = WHAT == 0 ? A.gx_carry + (size_t)I.gi * A.M * A.D
                              : A.grad_rewards + (size_t)I.t * A.B + (size_t)I.gi * A.M;
-  pm_mmx_bwd_sums(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, g, I.d, q, sums, lane);
+  pm_mmx_bwd_sums(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, g, I.d, q, sums, mmx_scr + pm_mm_scratch_doubles(I.d), nw, wid,
+                  lane);
 }
 
 // adjoint, second half: the summed (mbar, Lbar) -> dL/d(rows before moment matching) for this rank's rows.
 // WHAT == 0: in place in A.gx_carry; WHAT == 1: A.grad_rewards -> gr_tilde.
 template <int WHAT>
-__global__ __launch_bounds__(64) void pm_mmx_bwd_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg,
-                                                              float* gr_tilde) {
+__global__ __launch_bounds__(1024) void pm_mmx_bwd_apply_kernel(const RolloutArgs A, const MmxArgs X, int t_arg,
+                                                                float* gr_tilde) {
   extern __shared__ __attribute__((aligned(16))) double mmx_scr[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
   if (A.nvalid && I.t >= *A.nvalid) return;
-  const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
-  for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
-  const double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
-  pm_wave_sync();
-  for (int e = lane; e < I.d; e += 64) q.mbar[e] = sums[e];
-  for (int e = lane; e < I.d * I.d; e += 64) q.P[e] = sums[I.d + e];
-  pm_wave_sync();
   const double Mtot = (double)X.span_rows;
+  if (wid == 0) {
+    const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
+    for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
+    const double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
+    pm_wave_sync();
+    for (int e = lane; e < I.d; e += 64) q.mbar[e] = sums[e];
+    for (int e = lane; e < I.d * I.d; e += 64) q.P[e] = sums[I.d + e];
+    pm_wave_sync();
+    pm_mm_bwd_solve(I.d, 1.0 / (Mtot - 1.0), q, lane);
+  }
+  __syncthreads();
   float* gout = WHAT == 0 ? A.gx_carry + (size_t)I.gi * A.M * A.D
                           : gr_tilde + (size_t)I.t * A.B + (size_t)I.gi * A.M;
-  pm_mm_bwd_finish(I.src, I.d, A.M, I.d, 1.0 / Mtot, 1.0 / (Mtot - 1.0), gout, I.d, q, lane);
+  pm_mm_bwd_rows(I.src, I.d, A.M, I.d, 1.0 / Mtot, gout, I.d, q, threadIdx.x, blockDim.x);
 }

@@ -190,7 +190,7 @@ def loss_weights(d, B_global):
 
 
 def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_global=None,
-                        row_offset=None, force_generic=False, no_shaped=False, precision=None):
+                        row_offset=None, force_generic=False, no_shaped=False, precision=None, mm_span=None):
     """Build an Engine + its device input tensors from a problem dict.
     shard=(rank, world): this rank's contiguous block of rows (whole mm groups) of ONE
     global batch described by d.  B_global/row_offset instead place the whole of d as a
@@ -225,7 +225,7 @@ def engine_from_problem(d, device='cuda:0', rows_per_wg_hint=0, shard=None, B_gl
                    precision=precision, pol_masks_per_step=pol_ps, dyn_masks_per_step=dyn_ps,
                    pol_angle_dims=[int(a) for a in np.asarray(d.get('pol_angle_dims', []))],
                    dyn_angle_dims=[int(a) for a in np.asarray(d.get('dyn_angle_dims', []))],
-                   dyn_components=int(d['dyn_gmm_n']) if 'dyn_gmm_n' in d else 0)
+                   dyn_components=int(d['dyn_gmm_n']) if 'dyn_gmm_n' in d else 0, mm_span=mm_span)
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
 
     def rows(m):
