@@ -43,6 +43,9 @@ def parse():
                     help='arithmetic of the hidden-width GEMMs (default: the library default)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='N > 1: per-GPU rows fixed (weak) or the global 100 x 25 rows divided over the GPUs (strong)')
+    ap.add_argument('--mm-global', action='store_true',
+                    help='moment-matching configs: ONE group over the rows of all ranks (mm_groups=None, the '
+                         "reference examples' default) -- per-step statistics exchange between the ranks; weak scaling only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
@@ -173,8 +176,23 @@ def main():
     B = d['x0'].shape[0]
     H = int(d['H'])
     Bg = B * world
+    mm_span = None
+    if a.mm_global:
+        assert bool(d['mm_states']) and a.scaling == 'weak', '--mm-global: a moment-matching config, weak scaling'
+        d = dict(d)
+        d['mm_groups'] = 0
+        if world > 1:
+            mm_span = (Bg, rank * B, world, rank)
+    if world > 1 and bool(d['mm_states']) and a.scaling == 'weak':
+        # one cyclic noise buffer over the GLOBAL rows (utils/rollout.py:53-59), the same on every rank
+        d = dict(d)
+        gen = np.random.default_rng(12345)
+        d['z_mm'] = gen.standard_normal((H + Bg, d['x0'].shape[1])).astype(np.float32)
+        d['z_rr'] = gen.standard_normal((H + Bg, 1)).astype(np.float32)
     eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=a.rows_per_wg, B_global=Bg,
-                                          row_offset=rank * B, precision=a.precision)
+                                          row_offset=rank * B, precision=a.precision, mm_span=mm_span)
+    if mm_span:
+        eng.attach_collective(dist.group.WORLD)
     gw = torch.tensor(PB.loss_weights(d, Bg)[:, :B].copy(), device=dev)
     params = args['pol_flat'].clone()
     args['pol_flat'] = params
@@ -284,6 +302,7 @@ def main():
                         precision=prec, rows_per_wg=eng.info['rows_per_wg'], workgroups=eng.info['n_wg'],
                         cu_occupancy='%d of %d CUs hold a workgroup' % (min(eng.info['n_wg'], N_CUS), N_CUS),
                         mm_mode=eng.info['mm_mode'], mm_grid=eng.info.get('mm_grid', 0),
+                        **({'mm_groups': 'one group over the rows of all ranks'} if a.mm_global else {}),
                         adjoint_sweep_launches=eng.info.get('dw_pipe', 1), **({'debug_one_device': True} if a.one_device else {})),
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,

@@ -55,6 +55,18 @@ def test_bench_two_ranks_strong_scaling():
     assert out['scaling'] == 'strong' and out['config']['global_rows'] == 2500 and out['config']['rows_per_gpu'] == 1250
 
 
+def test_bench_two_ranks_one_global_moment_matching_group():
+    """--mm-global: one moment-matching group over the rows of both ranks, statistics exchanged every step."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', 'cartpole_mm',
+           '--mm-global', '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['config']['mm_mode'] == 2 and out['config']['global_rows'] == 5000 and out['value'] > 0
+
+
 def _mcp_worker(rank, world, port, name, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
