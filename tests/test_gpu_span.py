@@ -111,6 +111,8 @@ def _run(name, parts, precision=None, fail_at=None):
     ('mmg_h40', (15, 10)),
     ('dcp_d6_mmg', (5, 4, 3)),         # D = 6, three groups over three ranks
     ('full200_mmg', (13, 12)),         # the 200-wide cart-pole networks (latency-optimised kernel family)
+    ('angles_dcp_mmg', (6, 6)),        # angle_dims inside Policy / DynamicsModel
+    ('mmg_m80', (30, 50)),             # 80-row groups: two waves of a workgroup share a rank's rows
 ])
 def test_groups_spread_over_ranks_match_the_reference(name, parts):
     d, S, loss, grad = _run(name, parts)
