@@ -146,7 +146,7 @@ typedef struct pmbrl_config {
    * by the moment matching.  Per step the ranks exchange the groups' sufficient statistics (fp64; forward: one
    * in-place sum of ranks x groups x (D^2 + 3 D + 1) values, adjoint: groups x (D^2 + D)) through the
    * collective attached with pmbrl_plan_set_comm / pmbrl_plan_set_collective; the sweeps then run as one launch
-   * per step.  Not offered together with PMBRL_FLAG_INFER_NS or grad_states. */
+   * per step.  Not offered together with grad_states. */
   int32_t mm_span_rows, mm_span_offset;
   int32_t mm_span_ranks, mm_span_rank; /* ranks a group is spread over and this rank's index among them */
 } pmbrl_config;

@@ -596,9 +596,6 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       if ((long long)p->G * c.mm_span_rows > p->cfg.B_global) {
         delete p; return fail(-2, "mm_groups x mm_span_rows exceeds B_global");
       }
-      if (c.flags & PMBRL_FLAG_INFER_NS) {
-        delete p; return fail(-3, "infer_noise_variables with moment-matching groups spread over ranks: not offered");
-      }
     }
     // in-kernel if a whole number of groups fits a workgroup's row tiles and LDS
     p->mm_mode = 2;

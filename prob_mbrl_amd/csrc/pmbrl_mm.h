@@ -250,6 +250,20 @@ __device__ __forceinline__ void pm_mm_bwd_finish(const float* s, int s_ld, int M
   pm_wave_sync();
 }
 
+// infer_noise_variables: q.Sb = A = g^T Delta (full d x d) -> q.P = Lbar = tril(A L^-T): row i of A L^-T by forward
+// substitution (x L^T = A_i)
+__device__ __forceinline__ void pm_mm_infer_lbar(int d, const MMScratch& q, int lane) {
+  for (int i = lane; i < d; i += 64) {
+    for (int j = 0; j < d; ++j) {
+      double a = q.Sb[i * d + j];
+      for (int c = 0; c < j; ++c) a -= q.P[i * d + c] * q.Lm[j * d + c];
+      q.P[i * d + j] = a * q.invd[j];       // full row first (x_c for c < j feeds x_j) ...
+    }
+    for (int j = i + 1; j < d; ++j) q.P[i * d + j] = 0.0;   // ... then keep the lower triangle
+  }
+  pm_wave_sync();
+}
+
 // g: upstream dL/d out [M][d]; gout: dL/d s [M][d] (may alias g).
 __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d, const float* z, int z_ld,
                                  int zrow0, int Bg, bool infer_ns, const float* g, int g_ld,
@@ -317,15 +331,7 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
       }
     }
     pm_wave_sync();
-    for (int i = lane; i < d; i += 64) {
-      for (int j = 0; j < d; ++j) {
-        double a = q.Sb[i * d + j];
-        for (int c = 0; c < j; ++c) a -= q.P[i * d + c] * q.Lm[j * d + c];
-        q.P[i * d + j] = a * q.invd[j];       // full row first (x_c for c < j feeds x_j) ...
-      }
-      for (int j = i + 1; j < d; ++j) q.P[i * d + j] = 0.0;   // ... then keep the lower triangle
-    }
-    pm_wave_sync();
+    pm_mm_infer_lbar(d, q, lane);
   }
   pm_mm_bwd_finish(s, s_ld, M, d, inv_m, inv_m1, gout, gout_ld, q, lane);
 }

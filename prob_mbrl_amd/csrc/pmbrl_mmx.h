@@ -148,9 +148,18 @@ __device__ __forceinline__ bool pm_mmx_factor(const double* slots, size_t stride
   return pm_mm_chol(d, q, lane);
 }
 
-// out rows = mean + zhat L^T for this rank's M rows of the group (pm_mm_fwd's last loop), thread tid of nthreads
+// out rows = mean + zhat L^T for this rank's M rows of the group (pm_mm_fwd's last loop), thread tid of nthreads;
+// infer_noise_variables (utils/rollout.py:6-17): zhat = Delta L^-T, the rows come back as they are (s, s_ld)
 __device__ __forceinline__ void pm_mmx_apply(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
-                                             float* out, int out_ld, const MMScratch& q, int tid, int nthreads) {
+                                             float* out, int out_ld, const MMScratch& q, int tid, int nthreads,
+                                             const float* s = nullptr, int s_ld = 0) {
+  if (s) {
+    for (int e = tid; e < M * d; e += nthreads) {
+      const int r = e / d, j = e - r * d;
+      out[(size_t)r * out_ld + j] = s[(size_t)r * s_ld + j];
+    }
+    return;
+  }
   for (int e = tid; e < M * d; e += nthreads) {
     const int r = e / d, j = e - r * d;
     double acc = q.mean[j];
@@ -165,7 +174,9 @@ __device__ __forceinline__ void pm_mmx_apply(int M, int d, const float* z, int z
 // (all waves of the workgroup; part: nw x (d + d*d) doubles)
 __device__ __forceinline__ void pm_mmx_bwd_sums(int M, int d, const float* z, int z_ld, int zrow0, int Bg,
                                                 const float* g, int g_ld, const MMScratch& q, double* sums,
-                                                double* part, int nw, int wid, int lane) {
+                                                double* part, int nw, int wid, int lane,
+                                                const float* s_inf = nullptr, int s_ld = 0) {
+  // s_inf (infer_noise_variables): the second sum is A = g^T Delta (full d x d, Delta = s - the GROUP's mean)
   double* pw = part + (size_t)wid * (d + d * d);
   {
     const int e2 = pm_pow2ceil(d);
@@ -188,8 +199,12 @@ __device__ __forceinline__ void pm_mmx_bwd_sums(int M, int d, const float* z, in
       const int e = base + lane / P;
       const int i = e / d, j = e - i * d;
       double acc = 0.0;
-      const bool live = e < d * d && j <= i;
-      if (live) {
+      const bool live = e < d * d && (j <= i || s_inf);
+      if (live && s_inf) {
+        const double mj = q.mean[j];
+        for (int r = wid * P + pt; r < M; r += nw * P)
+          acc += (double)g[(size_t)r * g_ld + i] * ((double)s_inf[(size_t)r * s_ld + j] - mj);
+      } else if (live) {
         const double zm = q.zmean[j], zs = q.zistd[j];
         for (int r = wid * P + pt; r < M; r += nw * P)
           acc += (double)g[(size_t)r * g_ld + i] *
@@ -278,7 +293,8 @@ __global__ __launch_bounds__(1024) void pm_mmx_apply_kernel(const RolloutArgs A,
     if (!ok && lane == 0) atomicMin(A.status, I.t);
   }
   __syncthreads();
-  pm_mmx_apply(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, I.out, I.d, q, threadIdx.x, blockDim.x);
+  const bool ins = (A.flags & PMBRL_FLAG_INFER_NS) != 0;
+  pm_mmx_apply(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, I.out, I.d, q, threadIdx.x, blockDim.x, ins ? I.src : nullptr, I.d);
 }
 
 // adjoint, first half: g = dL/d(moment-matched rows) of this rank -> its part of the two sums.
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(1024) void pm_mmx_bwd_sums_kernel(const RolloutArgs
   const float* g = WHAT == 0 ? A.gx_carry + (size_t)I.gi * A.M * A.D
                              : A.grad_rewards + (size_t)I.t * A.B + (size_t)I.gi * A.M;
   pm_mmx_bwd_sums(A.M, I.d, I.z, I.d, I.zrow0, A.Bg, g, I.d, q, sums, mmx_scr + pm_mm_scratch_doubles(I.d), nw, wid,
-                  lane);
+                  lane, (A.flags & PMBRL_FLAG_INFER_NS) ? I.src : nullptr, I.d);
 }
 
 // adjoint, second half: the summed (mbar, Lbar) -> dL/d(rows before moment matching) for this rank's rows.
@@ -320,7 +336,13 @@ __global__ __launch_bounds__(1024) void pm_mmx_bwd_apply_kernel(const RolloutArg
     const double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
     pm_wave_sync();
     for (int e = lane; e < I.d; e += 64) q.mbar[e] = sums[e];
-    for (int e = lane; e < I.d * I.d; e += 64) q.P[e] = sums[I.d + e];
+    if (A.flags & PMBRL_FLAG_INFER_NS) {
+      for (int e = lane; e < I.d * I.d; e += 64) q.Sb[e] = sums[I.d + e];   // A = g^T Delta over all ranks
+      pm_wave_sync();
+      pm_mm_infer_lbar(I.d, q, lane);
+    } else {
+      for (int e = lane; e < I.d * I.d; e += 64) q.P[e] = sums[I.d + e];
+    }
     pm_wave_sync();
     pm_mm_bwd_solve(I.d, 1.0 / (Mtot - 1.0), q, lane);
   }

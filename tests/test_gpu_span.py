@@ -71,7 +71,8 @@ def _run(name, parts, precision=None, fail_at=None):
             #  other inside it; ranks that are processes have an autograd engine each)
             bundle = RO.Bundle(dyn, pol, len(rows), H, False, False, True, True, G if G > 1 else None,
                                torch.tensor(d['z_mm'], device=DEV), torch.tensor(d['z_rr'], device=DEV),
-                               B_global=B, precision=precision, mm_span=(M, off, W, r), process_group=ts.rank(r))
+                               B_global=B, precision=precision, mm_span=(M, off, W, r), process_group=ts.rank(r),
+                               infer_ns=bool(d['infer_ns']) if 'infer_ns' in d else False)
             eng = bundle.engine
             S, A, R = bundle.forward(x0)
             n = min(eng.valid_steps(), H)
@@ -113,6 +114,7 @@ def _run(name, parts, precision=None, fail_at=None):
     ('full200_mmg', (13, 12)),         # the 200-wide cart-pole networks (latency-optimised kernel family)
     ('angles_dcp_mmg', (6, 6)),        # angle_dims inside Policy / DynamicsModel
     ('mmg_m80', (30, 50)),             # 80-row groups: two waves of a workgroup share a rank's rows
+    ('mmg_infer_ns', (5, 3)),          # infer_noise_variables (utils/rollout.py:6-17): zhat = Delta L^-T
 ])
 def test_groups_spread_over_ranks_match_the_reference(name, parts):
     d, S, loss, grad = _run(name, parts)
