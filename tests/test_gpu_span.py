@@ -156,3 +156,50 @@ def test_span_needs_a_collective_and_rejects_bad_slices():
         pm.utils.rollout(x0, dyn, pol, 4, mm_span=(10, 0, 2, 0), **kw)               # no process_group
     with pytest.raises(pm._lib.PmbrlError):
         pm.utils.rollout(x0, dyn, pol, 4, mm_span=(10, 5, 2, 1), process_group=lambda v: None, **kw)   # 5 + 6 > 10
+
+
+def test_span_form_over_an_rccl_communicator_and_inside_a_graph():
+    """pmbrl_plan_set_comm: the statistics exchange as ncclAllReduce (fp64, in place) on the compute stream, with the
+    one rank a single-GPU box has (the sum over one rank is the identity: what this pins is the call itself --
+    datatype, stream, buffer -- between the two halves of the moment matching, 2 H + 2 times per iteration), eager
+    and recorded into a hipGraph; the result is what the in-kernel moment matching of the same rows gives."""
+    import ctypes as C
+    from prob_mbrl_amd import _lib, engine as E
+    name = 'full200_mmg'
+    d = dict(common.load(name))
+    B, G = d['x0'].shape[0], int(d['mm_groups'])
+    lib = _lib.load()
+    idbuf = C.create_string_buffer(128)
+    _lib.check(lib.pmbrl_comm_unique_id(idbuf), 'pmbrl_comm_unique_id')
+    comm = C.c_void_p()
+    _lib.check(lib.pmbrl_comm_init(C.c_char_p(bytes(idbuf.raw)), 0, 1, 0, C.byref(comm)), 'pmbrl_comm_init')
+    gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+    eng0, args0, _ = common.engine_from_fixture(d, torch.device(DEV))
+    S0, _, R0 = eng0.forward(**args0)
+    g0 = eng0.backward(gw)[0].clone()
+    eng, args, _ = common.engine_from_fixture(d, torch.device(DEV), mm_span=(B // G, 0, 1, 0))
+    assert eng.info['mm_mode'] == 2
+    _lib.check(lib.pmbrl_plan_set_comm(eng.plan, comm), 'pmbrl_plan_set_comm')
+    S, _, R = eng.forward(**args)
+    g = eng.backward(gw)[0].clone()
+    assert eng.valid_steps() == eng.H
+    assert common.rel(S.cpu().numpy(), S0.cpu().numpy()) < 1e-6 and common.rel(R.cpu().numpy(), R0.cpu().numpy()) < 1e-6
+    assert common.rel(g.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+    assert common.rel(S.cpu().numpy(), d['ref64_states']) < 2e-5 and common.rel(g.cpu().numpy(), d['ref64_grad']) < 1e-4
+    # the same launches and collectives recorded into one graph
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.forward(**args)
+        eng.backward(gw)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.forward(**args)
+        eng.backward(gw)
+    eng.grad_flat.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grad_flat, g)
+    del eng
+    lib.pmbrl_comm_destroy(comm)

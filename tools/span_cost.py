@@ -3,7 +3,9 @@ the transport: the cartpole_mm shape with ONE group over all 2500 rows (mm_group
  (a) as one process runs it (moment matching inside the sweeps / behind a device-wide barrier), and
  (b) in the form a sharded run uses (pmbrl_config.mm_span_*: one sweep launch per step, statistics kernel ->
      collective -> factor-and-apply kernel, forward and adjoint) with a collective that does nothing (one rank).
-(b) - (a) is the launch structure's price; a real run adds 2 H + 2 small all-reduces per iteration on top.
+(b) - (a) is the launch structure's price; (c) the same with the statistics going through ncclAllReduce on a
+one-rank RCCL communicator (the launches of the real transport, none of its link latency), (d) recorded into a
+hipGraph and replayed.
     python tools/span_cost.py [config] [iterations]"""
 import sys
 import time
@@ -19,9 +21,21 @@ dev = torch.device('cuda:0')
 d = dict(PB.synthetic_problem(name, seed=0, data_seed=0))
 d['mm_groups'] = 0
 B, H = d['x0'].shape[0], int(d['H'])
-for label, span in (('one process', None), ('span form, 1 rank, no transport', (B, 0, 1, 0))):
+import ctypes as C  # noqa: E402
+from prob_mbrl_amd import _lib  # noqa: E402
+lib = _lib.load()
+idbuf = C.create_string_buffer(128)
+_lib.check(lib.pmbrl_comm_unique_id(idbuf), 'pmbrl_comm_unique_id')
+comm = C.c_void_p()
+_lib.check(lib.pmbrl_comm_init(C.c_char_p(bytes(idbuf.raw)), 0, 1, 0, C.byref(comm)), 'pmbrl_comm_init')
+for label, span in (('one process', None), ('span form, 1 rank, no transport', (B, 0, 1, 0)),
+                    ('span form, 1 rank, RCCL all-reduce', (B, 0, 1, 0)),
+                    ('span form, 1 rank, RCCL, hipGraph', (B, 0, 1, 0))):
     eng, args, _ = PB.engine_from_problem(d, dev, mm_span=span)
-    if span:
+    if span and 'RCCL' in label:
+        # the real transport with the one rank this box has: 2 H + 2 ncclAllReduce launches per iteration
+        _lib.check(lib.pmbrl_plan_set_comm(eng.plan, comm), 'pmbrl_plan_set_comm')
+    elif span:
         eng.attach_collective(lambda view: None)
     gw = torch.tensor(PB.loss_weights(d, B).copy(), device=dev)
 
@@ -29,6 +43,14 @@ for label, span in (('one process', None), ('span form, 1 rank, no transport', (
         eng.forward(**args)
         eng.backward(gw)
     for _ in range(3):
+        step()
+    if 'hipGraph' in label:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.forward(**args)
+            eng.backward(gw)
+        step = graph.replay       # noqa: F811
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
