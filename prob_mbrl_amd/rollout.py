@@ -349,8 +349,9 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
         n = bundle.engine.valid_steps()
         retry = E.safe_precision(bundle.engine.info['precision']) if n < steps else None
         if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None) \
-                or resample_model or resample_policy or bundle.gmm:
-            break          # (fresh noise was drawn: a retry would be a different rollout)
+                or resample_model or resample_policy or bundle.gmm or mm_span:
+            break          # (fresh noise was drawn: a retry would be a different rollout; groups spread over ranks:
+            #                 a rank retrying alone would leave the others inside a collective)
         # a failure under fp16 pieces may be their range, not the rollout: decide on the bf16 path
         precision = retry
     if n < steps:
