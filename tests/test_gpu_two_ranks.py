@@ -147,3 +147,59 @@ def test_mc_pilco_one_global_moment_matching_group_over_ranks(world):
         assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
     for r in res[1:]:
         assert np.array_equal(res[0][2], r[2])      # replicas stay bit-identical
+
+
+def _rollout_worker(rank, world, port, name, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import prob_mbrl_amd as pm
+        d = dict(common.load(name))
+        B, H = d['x0'].shape[0], int(d['H'])
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        for k in list(d):
+            if k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and not k.endswith(('_shape', '_bits'))):
+                d[k] = d[k][lo:hi]
+        dyn, pol = common.modules_from_fixture(d, name, 'cuda:0')
+        x0 = torch.tensor(d['x0'], device='cuda:0')
+        S, A, R = pm.utils.rollout(
+            x0, dyn, pol, H, resample_state_noise=False, resample_action_noise=False, mm_states=True, mm_rewards=True,
+            z_mm=torch.tensor(d['z_mm'], device='cuda:0'), z_rr=torch.tensor(d['z_rr'], device='cuda:0'),
+            B_global=B, mm_span=(B, lo, world, rank), process_group=dist.group.WORLD)
+        gamma = [float(g) for g in d['gamma']]
+        loss = (-torch.stack([r * gamma[i] for i, r in enumerate(R)]).sum(0)).sum() / B
+        pol.zero_grad()
+        loss.backward()          # the adjoint's statistics exchange runs on autograd's device thread
+        lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
+        g = torch.cat([t.grad.reshape(-1) for l in lins for t in (l.weight, l.bias)]).double().cpu()
+        tot = torch.cat([loss.detach().double().cpu().reshape(1), g])
+        dist.all_reduce(tot)
+        out.put((rank, lo, hi, torch.stack(S).detach().cpu().numpy(), float(tot[0]), tot[1:].numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rollout_autograd_with_one_group_over_two_processes():
+    """utils.rollout(..., mm_span=, process_group=) + loss.backward() on two processes, one moment-matching group of
+    100 rows over both at H = 40: the reference's fp64 trajectory, loss and policy gradient (sum over the ranks)."""
+    import torch.multiprocessing as mp
+    name = 'mm1_b100_h40'
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rollout_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = common.load(name)
+    S = np.zeros(d['ref64_states'].shape)
+    for rank, lo, hi, s, loss, g in res:
+        S[:, lo:hi] = s
+        assert abs(loss - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
+        assert common.rel(g, d['ref64_grad']) < 1e-4
+    assert common.rel(S, d['ref64_states']) < 2e-5
