@@ -160,7 +160,11 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     resample()
     x0 = init_states
     n_opt_steps = policy_update_counter[policy]
-    need_autograd = ((cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0) or reg_weight > 0
+    cvar = cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0
+    # sharded runs: CVaR is a row mask on dL/dr once the returns of ALL ranks are known, the regulariser touches only
+    # the (replicated) parameters -- both fit the fused path; one process keeps the reference's own
+    # sequence of autograd operations for them
+    need_autograd = (((cvar or reg_weight > 0) and world == 1)
                      or value_func is not None or prioritized_replay or bool(rollout_kwargs))
     replay = None
     if prioritized_replay:      # algorithms/mc_pilco.py:80-84
@@ -293,6 +297,22 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 if n_valid < min_steps:
                     raise RuntimeError('rollout failed at step %d' % n_valid)
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
+                if cvar:
+                    # algorithms/mc_pilco.py:146-154 over the rows of all ranks: the returns are gathered in rank (=
+                    # row) order, the quantile is the one process' quantile, every rank keeps its own rows' mask
+                    gcol = torch.tensor(gamma_full[:n_valid], dtype=torch.float32, device=dev)
+                    ret = sign * (R[:n_valid, :, 0] * gcol[:, None]).sum(0)
+                    parts = [None] * world
+                    dist.all_gather_object(parts, ret.cpu().numpy(), group=process_group)
+                    rd = np.concatenate(parts)
+                    if cvar_eps > 0:
+                        q = np.quantile(rd, cvar_eps)
+                        sel, n_sel = ret < float(q), int((rd < q).sum())
+                    else:
+                        q = np.quantile(rd, -cvar_eps)
+                        sel, n_sel = ret > float(q), int((rd > q).sum())
+                    gfull = torch.tensor(gamma_full, dtype=torch.float64) * (sign / max(n_sel, 1))
+                    gw = (gfull.float().to(dev)[:, None] * sel.float()[None, :]).contiguous()
                 loss = eng.weighted_sum(R, gw)[0]
                 if world > 1:
                     loss = loss.reshape(1).clone()
@@ -312,6 +332,14 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 if world > 1:
                     from .distributed import grad_allreduce
                     grad_allreduce(process_group, dev)(g)     # RCCL on the compute stream (C ABI)
+                if reg_weight > 0:
+                    # algorithms/mc_pilco.py:193-194: a function of the parameters alone, the same on every rank
+                    policy.zero_grad()
+                    regl = policy.regularization_loss()
+                    regl.backward()
+                    g.add_(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                      for p in bundle.pol_params]), alpha=float(reg_weight))
+                    loss = loss + reg_weight * regl.detach()
                 cache['step'] += 1
                 grp = cache['group']
                 E.clip_adam(bundle.pol_flat, g, cache['m'], cache['v'], cache['step'], grp['lr'],
@@ -401,7 +429,8 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
                         rollout_kwargs, process_group, world, value_func=None, replay=None):
     """The reference loop body on top of the single-node autograd rollout."""
     if world > 1:
-        raise NotImplementedError('sharded runs use the fused path (plain Adam, no CVaR/regulariser)')
+        raise NotImplementedError('sharded runs use the fused path (plain Adam; no value function, prioritised '
+                                  'replay or rollout_kwargs)')
     policy.zero_grad()
     opt.zero_grad()
     weighted = replay is not None and replay['idxs'] is not None

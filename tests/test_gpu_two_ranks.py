@@ -92,6 +92,8 @@ def _mcp_worker(rank, world, port, name, out):
                           else dict(z_mm=torch.zeros(1, 4), z_rr=torch.zeros(1, 1))),
             mm_states=bool(d['mm_states']), mm_rewards=bool(d['mm_rewards']),
             discount=None if np.allclose(d['gamma'], d['gamma'][0]) else float(d['gamma'][1] / d['gamma'][0]),
+            cvar_eps=float(d['mcp_cvar_eps']) if 'mcp_cvar_eps' in d else 0.0,
+            reg_weight=float(d['mcp_reg_weight']) if 'mcp_reg_weight' in d else 0.0,
             process_group=dist.group.WORLD)
         lins = [m for m in pol.model._modules.values() if isinstance(m, torch.nn.Linear)]
         final = torch.cat([t.detach().reshape(-1) for l in lins for t in (l.weight, l.bias)])
@@ -111,7 +113,7 @@ def test_mc_pilco_two_ranks_match_reference():
     procs = [ctx.Process(target=_mcp_worker, args=(r, 2, port, name, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=300) for _ in range(2)]
+    res = [out.get(timeout=120) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -137,7 +139,7 @@ def test_mc_pilco_one_global_moment_matching_group_over_ranks(world):
     procs = [ctx.Process(target=_mcp_worker, args=(r, world, port, name, out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=300) for _ in range(world)]
+    res = [out.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -192,7 +194,7 @@ def test_rollout_autograd_with_one_group_over_two_processes():
     procs = [ctx.Process(target=_rollout_worker, args=(r, 2, port, name, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=300) for _ in range(2)]
+    res = [out.get(timeout=120) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -203,3 +205,26 @@ def test_rollout_autograd_with_one_group_over_two_processes():
         assert abs(loss - float(d['ref64_loss'])) <= 2e-5 * abs(float(d['ref64_loss']))
         assert common.rel(g, d['ref64_grad']) < 1e-4
     assert common.rel(S, d['ref64_states']) < 2e-5
+
+
+@pytest.mark.parametrize('name', ['mcp_cvar', 'mcp_reg', 'mcp_cvar_neg_reg'])
+def test_mc_pilco_two_ranks_cvar_and_regulariser(name):
+    """CVaR (algorithms/mc_pilco.py:146-154: the quantile over the returns of ALL ranks' rows, gathered in row
+    order) and the policy regulariser (:193-194) on a sharded run: the real reference's single-process losses and
+    final parameters on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mcp_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = common.load(name)
+    for rank, losses, final in res:
+        assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
+        assert np.allclose(final, d['ref32_mcp_final'], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(res[0][2], res[1][2])
