@@ -932,7 +932,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
       // rewards of all steps), the factors the adjoint reuses
       const size_t n_s = (size_t)p->G * pm_mmx_slot_doubles(c.D), n_r = (size_t)c.H * p->G * pm_mmx_slot_doubles(1);
-      p->off_mmx_buf = take(p->span ? (size_t)c.mm_span_ranks * std::max(n_s, n_r) * sizeof(double) : 0);
+      p->off_mmx_buf = take(p->span ? (size_t)c.mm_span_ranks * std::max(n_s * PM_MMX_NB, n_r) * sizeof(double) : 0);
       p->off_mmx_fac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
       p->off_mmx_rfac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(1) * sizeof(double) : 0);
     }
@@ -1256,6 +1256,7 @@ static MmxArgs mmx_args(const pmbrl_plan* p, char* ws, bool rewards) {
   X.span_off = p->cfg.mm_span_offset;
   X.buf = reinterpret_cast<double*>(ws + p->off_mmx_buf);
   X.fac = reinterpret_cast<double*>(ws + (rewards ? p->off_mmx_rfac : p->off_mmx_fac));
+  X.nb = rewards ? 1 : pm_mmx_blocks(p->M);   // (rewards: H x G workgroups already)
   return X;
 }
 
@@ -1330,10 +1331,10 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
         // groups spread over ranks: own statistics -> sum over the ranks -> factor + own rows
         MmxArgs X = mmx_args(p, ws, false);
         X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
-        const int nw = pm_mmx_waves(p->M, p->cfg.D);
+        const int nw = pm_mmx_waves(p->M, p->cfg.D), nws = pm_mmx_waves((p->M + X.nb - 1) / X.nb, p->cfg.D);
         const size_t scr = pm_mmx_lds_doubles(p->cfg.D, nw) * sizeof(double);
-        hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G, X.nranks), dim3(64 * nw), scr, s, Am, X, t);
-        if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * p->G * pm_mmx_slot_doubles(p->cfg.D))) return rc;
+        hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G * X.nb, X.nranks), dim3(64 * nws), scr, s, Am, X, t);
+        if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * X.nb * p->G * pm_mmx_slot_doubles(p->cfg.D))) return rc;
         hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t);
       }
     }
@@ -1521,10 +1522,10 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
       } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
         MmxArgs X = mmx_args(p, ws, false);
         X.fac += (size_t)t * p->G * pm_mm_fac_doubles(p->cfg.D);
-        const int nw = pm_mmx_waves(p->M, p->cfg.D);
+        const int nw = pm_mmx_waves(p->M, p->cfg.D), nws = pm_mmx_waves((p->M + X.nb - 1) / X.nb, p->cfg.D);
         const size_t scr = pm_mmx_lds_doubles(p->cfg.D, nw) * sizeof(double);
-        hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t);
-        if (int rc = mmx_exchange(p, s, X.buf, (size_t)p->G * pm_mmx_bwd_doubles(p->cfg.D))) return rc;
+        hipLaunchKernelGGL(pm_mmx_bwd_sums_kernel<0>, dim3(p->G * X.nb), dim3(64 * nws), scr, s, Am, X, t);
+        if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nb * p->G * pm_mmx_bwd_doubles(p->cfg.D))) return rc;
         hipLaunchKernelGGL(pm_mmx_bwd_apply_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t, (float*)nullptr);
       }
       A.t0 = t; A.t1 = t + 1;

@@ -203,3 +203,48 @@ def test_span_form_over_an_rccl_communicator_and_inside_a_graph():
     assert torch.equal(eng.grad_flat, g)
     del eng
     lib.pmbrl_comm_destroy(comm)
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_sums_spread_over_workgroups_match_one_process(world):
+    """Slices of more than 256 rows: the sums over a rank's rows are spread over several workgroups (a slot per
+    workgroup forward, parts added in order in the adjoint).  The cart-pole shape with ONE group over all 2500 rows,
+    as one process runs it (moment matching behind the device-wide barrier) and in the span form on 1 and 2 ranks."""
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0))
+    d['mm_groups'] = 0
+    d['H'] = 12
+    B = d['x0'].shape[0]
+    dev = torch.device(DEV)
+    gw_all = torch.tensor(PB.loss_weights(d, B)[:12].copy(), device=DEV)
+    eng0, args0, _ = PB.engine_from_problem(d, dev)
+    S0, _, R0 = eng0.forward(**args0)
+    g0 = eng0.backward(gw_all)[0].double().cpu().numpy()
+    S0, R0 = S0.cpu().numpy(), R0.cpu().numpy()
+    assert eng0.valid_steps() == 12
+    ts = ThreadSum(world)
+    res, err = [None] * world, []
+
+    def worker(r):
+        try:
+            lo, hi = r * B // world, (r + 1) * B // world
+            eng, args, _ = PB.engine_from_problem(d, dev, shard=(r, world), mm_span=(B, lo, world, r))
+            assert eng.info['mm_mode'] == 2
+            eng.attach_collective(ts.rank(r))
+            S, _, R = eng.forward(**args)
+            g = eng.backward(gw_all[:, lo:hi].contiguous())[0]
+            res[r] = (lo, hi, S.cpu().numpy(), R.cpu().numpy(), g.double().cpu().numpy())
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+            ts.bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=90)
+    if err:
+        raise err[0]
+    for lo, hi, S, R, _ in res:
+        assert common.rel(S, S0[:, lo:hi]) < 1e-5 and common.rel(R, R0[:, lo:hi]) < 1e-5
+    assert common.rel(sum(x[4] for x in res), g0) < 1e-4

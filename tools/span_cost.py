@@ -7,12 +7,13 @@ the transport: the cartpole_mm shape with ONE group over all 2500 rows (mm_group
 one-rank RCCL communicator (the launches of the real transport, none of its link latency), (d) recorded into a
 hipGraph and replayed.
     python tools/span_cost.py [config] [iterations]"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prob_mbrl_amd import problem as PB  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'cartpole_mm'
