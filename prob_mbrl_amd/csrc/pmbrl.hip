@@ -1248,6 +1248,11 @@ static int mmx_exchange(pmbrl_plan* p, hipStream_t s, double* buf, size_t n) {
   if (int rc = p->coll(p->coll_ctx, (void*)s, buf, (int64_t)n)) return fail(-4, "statistics all-reduce failed (" + std::to_string(rc) + ")");
   return 0;
 }
+// dynamic LDS of pm_mmx_apply_kernel: room for the slots of every (rank, workgroup) if that fits (pmbrl_mmx.h)
+static size_t mmx_apply_lds(int d, const MmxArgs& X, size_t other) {
+  const size_t want = pm_mmx_apply_lds_doubles(d, X.nranks * X.nb) * sizeof(double);
+  return want <= PM_MMX_LDS_MAX ? std::max(want, other) : other;
+}
 static MmxArgs mmx_args(const pmbrl_plan* p, char* ws, bool rewards) {
   MmxArgs X;
   X.nranks = p->cfg.mm_span_ranks;
@@ -1335,7 +1340,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
         const size_t scr = pm_mmx_lds_doubles(p->cfg.D, nw) * sizeof(double);
         hipLaunchKernelGGL(pm_mmx_stats_kernel<0>, dim3(p->G * X.nb, X.nranks), dim3(64 * nws), scr, s, Am, X, t);
         if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * X.nb * p->G * pm_mmx_slot_doubles(p->cfg.D))) return rc;
-        hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64 * nw), scr, s, Am, X, t);
+        hipLaunchKernelGGL(pm_mmx_apply_kernel<0>, dim3(p->G), dim3(64 * nw), mmx_apply_lds(p->cfg.D, X, scr), s, Am, X, t);
       }
     }
   }
@@ -1355,7 +1360,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
       const int n_items = p->cfg.H * p->G;
       hipLaunchKernelGGL(pm_mmx_stats_kernel<1>, dim3(n_items, X.nranks), dim3(64 * nw), scr, s, A, X, 0);
       if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * n_items * pm_mmx_slot_doubles(1))) return rc;
-      hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64 * nw), scr, s, A, X, 0);
+      hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64 * nw), mmx_apply_lds(1, X, scr), s, A, X, 0);
     } else if (mm_r)
       hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
                          pm_mm_scratch_doubles(1) * sizeof(double), s, A);

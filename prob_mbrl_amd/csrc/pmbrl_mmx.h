@@ -319,6 +319,12 @@ struct MmxItem {
   }
 };
 
+// LDS of the forward's second half: the scratch, then the slots of every (rank, workgroup) of one item -- if that
+// fits PM_MMX_LDS_MAX (else the combination reads them from memory)
+#define PM_MMX_LDS_MAX (60 * 1024)
+__host__ __device__ inline size_t pm_mmx_apply_lds_doubles(int d, int nslots) {
+  return pm_mm_scratch_doubles(d) + (size_t)nslots * pm_mmx_slot_doubles(d);
+}
 // LDS of the kernels: the one-wave scratch of pmbrl_mm.h, then the waves' partial sums
 __host__ __device__ inline size_t pm_mmx_lds_doubles(int d, int nw) {
   return pm_mm_scratch_doubles(d) + (size_t)nw * pm_mmx_part_doubles(d);
@@ -349,8 +355,21 @@ __global__ __launch_bounds__(1024) void pm_mmx_apply_kernel(const RolloutArgs A,
   const MmxItem<WHAT> I(A, X, t_arg, blockIdx.x);
   const size_t ss = pm_mmx_slot_doubles(I.d);
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
+  // the slots of every (rank, workgroup) in one round trip to memory, all threads; wave 0 combines them from LDS
+  // (read one after the other from HBM the combination of 16 slots cost 8 us)
+  const int nslots = X.nranks * X.nb;
+  double* sl = mmx_scr + pm_mm_scratch_doubles(I.d);
+  const bool staged = pm_mmx_apply_lds_doubles(I.d, nslots) * sizeof(double) <= PM_MMX_LDS_MAX;
+  if (staged) {
+    for (int e = threadIdx.x; e < nslots * (int)ss; e += blockDim.x) {
+      const int k = e / (int)ss, o = e - k * (int)ss;
+      sl[e] = X.buf[((size_t)k * I.n_items + I.item) * ss + o];
+    }
+    __syncthreads();
+  }
   if (wid == 0) {
-    const bool ok = pm_mmx_factor(X.buf + (size_t)I.item * ss, (size_t)I.n_items * ss, X.nranks * X.nb, I.d, q, lane);
+    const bool ok = staged ? pm_mmx_factor(sl, ss, nslots, I.d, q, lane)
+                           : pm_mmx_factor(X.buf + (size_t)I.item * ss, (size_t)I.n_items * ss, nslots, I.d, q, lane);
     double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
     for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) fac[e] = mmx_scr[e];
     if (!ok && lane == 0) atomicMin(A.status, I.t);
@@ -398,15 +417,21 @@ __global__ __launch_bounds__(1024) void pm_mmx_bwd_apply_kernel(const RolloutArg
   if (A.nvalid && I.t >= *A.nvalid) return;
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
   const double Mtot = (double)X.span_rows;
+  // the nb parts of the two sums in one round trip to memory (all threads), added in order by wave 0
+  const int nbd = (int)pm_mmx_bwd_doubles(I.d);
+  double* pl = mmx_scr + pm_mm_scratch_doubles(I.d);
+  for (int e = threadIdx.x; e < X.nb * nbd; e += blockDim.x) {
+    const int b = e / nbd, o = e - b * nbd;
+    pl[e] = X.buf[((size_t)b * I.n_items + I.item) * nbd + o];
+  }
+  __syncthreads();
   if (wid == 0) {
     const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
     for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
-    const double* sums = X.buf + (size_t)I.item * pm_mmx_bwd_doubles(I.d);
     pm_wave_sync();
-    const size_t bstride = (size_t)I.n_items * pm_mmx_bwd_doubles(I.d);   // the nb parts, added in order
     auto total = [&](int e) {
       double t = 0.0;
-      for (int b = 0; b < X.nb; ++b) t += sums[(size_t)b * bstride + e];
+      for (int b = 0; b < X.nb; ++b) t += pl[b * nbd + e];
       return t;
     };
     for (int e = lane; e < I.d; e += 64) q.mbar[e] = total(e);
