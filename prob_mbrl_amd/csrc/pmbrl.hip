@@ -695,6 +695,24 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         p->nwg <= 1024)
       p->mm_grid = 1;
   }
+  // More workgroups than CUs under ONE launch cannot meet at a barrier: the sweeps would run one launch per step with
+  // the whole group's moment matching redone in the prologue of EVERY workgroup (one group of 5000 rows: 9.7 ms per
+  // forward + adjoint, 10 000 rows: 23.4 ms).  The form built for groups spread over ranks does better there --
+  // statistics over 16 workgroups, one factorisation, rows by all threads (pmbrl_mmx.h): 4.3 / 6.4 ms -- so such a
+  // plan is the span form with ONE rank, whose exchange is the identity (profiles/r02n_span_cost.txt).
+  // PMBRL_MM_PERSTEP keeps the per-step prologue form (tests).
+  int cus_now = 0;
+  (void)hipDeviceGetAttribute(&cus_now, hipDeviceAttributeMultiprocessorCount, p->device);
+  if (p->mm_mode == 3 && !p->mm_grid && !p->span && p->M >= 2048 && cus_now > 0 && p->nwg > cus_now &&
+      !(c.flags & PMBRL_FLAG_INFER_NS) && !getenv("PMBRL_MM_PERSTEP") && !getenv("PMBRL_MM_NO_SPAN1")) {
+    p->span = 1;
+    p->cfg.mm_span_rows = p->M;
+    p->cfg.mm_span_offset = p->cfg.row_offset;   // (the groups are local: only the noise row needs the shard's offset)
+    p->cfg.mm_span_ranks = 1;
+    p->cfg.mm_span_rank = 0;
+    p->mm_mode = 2;
+    p->lds_bytes = lds_need(p->RT, 0, 1);
+  }
 
   HIPCHK(hipSetDevice(device));
   // reward constants
@@ -932,7 +950,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
       // rewards of all steps), the factors the adjoint reuses
       const size_t n_s = (size_t)p->G * pm_mmx_slot_doubles(c.D), n_r = (size_t)c.H * p->G * pm_mmx_slot_doubles(1);
-      p->off_mmx_buf = take(p->span ? (size_t)c.mm_span_ranks * std::max(n_s * PM_MMX_NB, n_r) * sizeof(double) : 0);
+      p->off_mmx_buf = take(p->span ? (size_t)p->cfg.mm_span_ranks * std::max(n_s * PM_MMX_NB, n_r) * sizeof(double) : 0);
       p->off_mmx_fac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
       p->off_mmx_rfac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(1) * sizeof(double) : 0);
     }
@@ -1244,6 +1262,7 @@ static void launch_bwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t
 
 // groups spread over ranks (pmbrl_mmx.h): the in-place fp64 sum of the statistics buffer over the ranks
 static int mmx_exchange(pmbrl_plan* p, hipStream_t s, double* buf, size_t n) {
+  if (p->cfg.mm_span_ranks == 1 && !p->coll) return 0;   // one rank: the sum over the ranks is the identity
   if (!p->coll) return fail(-3, "moment-matching groups spread over ranks: attach a collective first (pmbrl_plan_set_comm / pmbrl_plan_set_collective)");
   if (int rc = p->coll(p->coll_ctx, (void*)s, buf, (int64_t)n)) return fail(-4, "statistics all-reduce failed (" + std::to_string(rc) + ")");
   return 0;

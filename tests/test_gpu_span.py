@@ -248,3 +248,28 @@ def test_sums_spread_over_workgroups_match_one_process(world):
     for lo, hi, S, R, _ in res:
         assert common.rel(S, S0[:, lo:hi]) < 1e-5 and common.rel(R, R0[:, lo:hi]) < 1e-5
     assert common.rel(sum(x[4] for x in res), g0) < 1e-4
+
+
+def test_one_process_group_beyond_the_cu_count_takes_the_one_rank_span_form(monkeypatch):
+    """One group of 5000 rows: 313 workgroups cannot meet at a barrier under one launch, and the plan runs the
+    span form with one rank (identity exchange, nothing to attach) instead of redoing the whole group's moment matching
+    in the prologue of every workgroup of every step's launch.  Same trajectory and gradient as that per-step form."""
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0, P=200, H=8))
+    d['mm_groups'] = 0
+    B = d['x0'].shape[0]
+    dev = torch.device(DEV)
+    gw = torch.tensor(PB.loss_weights(d, B).copy(), device=DEV)
+    monkeypatch.setenv('PMBRL_MM_PERSTEP', '1')
+    eng0, args0, _ = PB.engine_from_problem(d, dev)
+    assert eng0.info['mm_mode'] == 3 and eng0.info['mm_grid'] == 0
+    S0, _, R0 = eng0.forward(**args0)
+    g0 = eng0.backward(gw)[0].clone()
+    monkeypatch.delenv('PMBRL_MM_PERSTEP')
+    eng, args, _ = PB.engine_from_problem(d, dev)
+    assert eng.info['mm_mode'] == 2
+    S, _, R = eng.forward(**args)
+    g = eng.backward(gw)[0]
+    assert eng.valid_steps() == 8
+    assert common.rel(S.cpu().numpy(), S0.cpu().numpy()) < 1e-5 and common.rel(R.cpu().numpy(), R0.cpu().numpy()) < 1e-5
+    assert common.rel(g.cpu().numpy(), g0.cpu().numpy()) < 1e-4

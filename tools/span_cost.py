@@ -19,7 +19,8 @@ from prob_mbrl_amd import problem as PB  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else 'cartpole_mm'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device('cuda:0')
-d = dict(PB.synthetic_problem(name, seed=0, data_seed=0))
+# optional third argument: particles P (rows = P x 25): the size of the one group
+d = dict(PB.synthetic_problem(name, seed=0, data_seed=0, P=int(sys.argv[3]) if len(sys.argv) > 3 else None))
 d['mm_groups'] = 0
 B, H = d['x0'].shape[0], int(d['H'])
 import ctypes as C  # noqa: E402
