@@ -302,6 +302,9 @@ int pmbrl_comm_unique_id(void* id_out /* host, PMBRL_COMM_ID_BYTES */);
 int pmbrl_comm_init(const void* id /* host, PMBRL_COMM_ID_BYTES */, int32_t rank, int32_t nranks,
                     int32_t device, pmbrl_comm** out);
 int pmbrl_allreduce_sum(pmbrl_comm* comm, void* stream, float* buf_d, int64_t n);
+/* the number of ranks the COMMUNICATOR reports (ncclCommCount) -- what bench.py prints as rccl_ranks, so that a
+ * scaling record proves RCCL saw N ranks rather than echoing WORLD_SIZE */
+int pmbrl_comm_count(pmbrl_comm* comm, int32_t* nranks_out);
 void pmbrl_comm_destroy(pmbrl_comm* comm);
 
 /* In-place fp64 sum over the ranks of buf_d[0..n) on `stream`: the per-step statistics exchange of

@@ -93,7 +93,7 @@ EXPORTS = [
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
-    'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_destroy',
+    'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_count', 'pmbrl_comm_destroy',
     'pmbrl_plan_set_comm', 'pmbrl_plan_set_collective',
 ]
 
@@ -172,6 +172,8 @@ def load():
     lib.pmbrl_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.pmbrl_allreduce_sum.restype = C.c_int
     lib.pmbrl_allreduce_sum.argtypes = [vp, vp, vp, i64]
+    lib.pmbrl_comm_count.restype = C.c_int
+    lib.pmbrl_comm_count.argtypes = [vp, C.POINTER(i32)]
     lib.pmbrl_comm_destroy.restype = None
     lib.pmbrl_comm_destroy.argtypes = [vp]
     lib.pmbrl_plan_set_comm.restype = C.c_int

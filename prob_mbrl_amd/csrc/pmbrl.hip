@@ -264,8 +264,11 @@ __global__ void pm_pack_all(const PackArgs P) {
 // waves per group, rows in HBM; every wave takes a slice of the rows (pmbrl_mm.h, multi-wave
 // forms).  Widths without a compile-time instantiation run the general code on wave 0.
 #define PM_MM_NW 16
+// (widths beyond the compile-time instances -- D > 6 -- run the one-wave routine: one wave's scratch; sixteen
+//  of them would be 446 KB at D = 32)
+__host__ __device__ inline int pm_mm_kernel_scratch_waves(int D) { return D <= 6 ? PM_MM_NW : 1; }
 __host__ __device__ inline size_t pm_mm_kernel_doubles(int D) {
-  return (size_t)PM_MM_NW * pm_mm_scratch_doubles(D) + (size_t)PM_MM_NW * 256;
+  return (size_t)pm_mm_kernel_scratch_waves(D) * pm_mm_scratch_doubles(D) + (size_t)PM_MM_NW * 256;
 }
 #define PM_MM_MW_SWITCH(D, CALL, ELSE) \
   switch (D) {                         \
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A,
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
   const int gi = blockIdx.x, lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
+  double* part = mmscr + (size_t)pm_mm_kernel_scratch_waves(A.D) * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
   const bool ins = (A.flags & PMBRL_FLAG_INFER_NS) != 0;
   const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A,
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
   const int gi = blockIdx.x, lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* part = mmscr + (size_t)PM_MM_NW * pm_mm_scratch_doubles(A.D);
+  double* part = mmscr + (size_t)pm_mm_kernel_scratch_waves(A.D) * pm_mm_scratch_doubles(A.D);
   const int r0 = gi * A.M;
   if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
   const bool ins = (A.flags & PMBRL_FLAG_INFER_NS) != 0;
@@ -974,11 +977,16 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   }
   if (p->mm_mode == 2 || p->mm_mode == 3) {
     const int smem = (int)(pm_mm_kernel_doubles(c.D) * sizeof(double));
+    if (smem > (int)lds_cap) { pmbrl_plan_destroy(p); return fail(-3, "moment-matching scratch exceeds the LDS"); }
     if (smem > 64 * 1024) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_fwd_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_bwd_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mm_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        (void)hipGetLastError();
+        pmbrl_plan_destroy(p);
+        return fail(-3, "hipFuncSetAttribute(moment-matching kernels) failed");
+      }
     }
   }
   if (rc2) { pmbrl_plan_destroy(p); return rc2; }
@@ -1938,6 +1946,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, RcclId, int) = nullptr;      // ncclCommInitRank(comm*, nranks, id BY VALUE, rank)
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;                       // ncclCommCount(comm, int* count)
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1955,6 +1964,7 @@ int rccl_load() {
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
     return fail(-4, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
@@ -1993,6 +2003,14 @@ extern "C" int pmbrl_allreduce_sum(pmbrl_comm* comm, void* stream, float* buf_d,
   // ncclFloat32 = 7, ncclSum = 0 (rccl.h: ncclDataType_t, ncclRedOp_t)
   if (int rc = g_rccl.AllReduce(buf_d, buf_d, (size_t)n, 7, 0, comm->comm, (hipStream_t)stream))
     return rccl_fail("ncclAllReduce", rc);
+  return 0;
+}
+extern "C" int pmbrl_comm_count(pmbrl_comm* comm, int32_t* nranks_out) {
+  if (!comm || !nranks_out) return fail(-1, "null argument");
+  if (!g_rccl.CommCount) return fail(-4, "librccl lacks ncclCommCount");
+  int n = 0;
+  if (int rc = g_rccl.CommCount(comm->comm, &n)) return rccl_fail("ncclCommCount", rc);
+  *nranks_out = n;
   return 0;
 }
 extern "C" void pmbrl_comm_destroy(pmbrl_comm* comm) {

@@ -417,23 +417,22 @@ __global__ __launch_bounds__(1024) void pm_mmx_bwd_apply_kernel(const RolloutArg
   if (A.nvalid && I.t >= *A.nvalid) return;
   const MMScratch q = pm_mm_carve(mmx_scr, I.d);
   const double Mtot = (double)X.span_rows;
-  // the nb parts of the two sums in one round trip to memory (all threads), added in order by wave 0
+  // the nb parts of the two sums: every thread adds the parts of its entries in part order (nb independent loads
+  // in flight, one round trip to memory) and leaves the totals in LDS -- d*d + d doubles, which fit the partial-sum
+  // area of any launch (>= one wave's d*d + 3d), whatever nb is
   const int nbd = (int)pm_mmx_bwd_doubles(I.d);
   double* pl = mmx_scr + pm_mm_scratch_doubles(I.d);
-  for (int e = threadIdx.x; e < X.nb * nbd; e += blockDim.x) {
-    const int b = e / nbd, o = e - b * nbd;
-    pl[e] = X.buf[((size_t)b * I.n_items + I.item) * nbd + o];
+  for (int e = threadIdx.x; e < nbd; e += blockDim.x) {
+    double t = 0.0;
+    for (int b = 0; b < X.nb; ++b) t += X.buf[((size_t)b * I.n_items + I.item) * nbd + e];
+    pl[e] = t;
   }
   __syncthreads();
   if (wid == 0) {
     const double* fac = X.fac + (size_t)I.item * pm_mm_fac_doubles(I.d);
     for (int e = lane; e < (int)pm_mm_fac_doubles(I.d); e += 64) mmx_scr[e] = fac[e];
     pm_wave_sync();
-    auto total = [&](int e) {
-      double t = 0.0;
-      for (int b = 0; b < X.nb; ++b) t += pl[b * nbd + e];
-      return t;
-    };
+    auto total = [&](int e) { return pl[e]; };
     for (int e = lane; e < I.d; e += 64) q.mbar[e] = total(e);
     if (A.flags & PMBRL_FLAG_INFER_NS) {
       for (int e = lane; e < I.d * I.d; e += 64) q.Sb[e] = total(I.d + e);   // A = g^T Delta over all ranks

@@ -320,7 +320,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         } else if (k < D) {
           v = xa[r * D + k];
         }
-        if constexpr (SP) pm_put_planes<R, true>(X, LDB, r, k, v);
+        if constexpr (SP) {
+          // an INPUT out of fp16's range would become inf, inf x 0-weight NaN, and vanish in the ReLU: reported like an
+          // activation out of range (the host re-runs in fp32)
+          if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
+          pm_put_planes<R, true>(X, LDB, r, k, v);
+        }
         else X[r * LD + k] = v;
         if (k < K16) st[(size_t)k * A.Rw + r] = v;
       }
@@ -380,7 +385,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           }
           v = (a - A.mx[k]) * A.iSx[k];
         }
-        if constexpr (SP) pm_put_planes<R, true>(X, LDB, r, k, v);
+        if constexpr (SP) {
+          // an INPUT out of fp16's range would become inf, inf x 0-weight NaN, and vanish in the ReLU: reported like an
+          // activation out of range (the host re-runs in fp32)
+          if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
+          pm_put_planes<R, true>(X, LDB, r, k, v);
+        }
         else X[r * LD + k] = v;
       }
     }

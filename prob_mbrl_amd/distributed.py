@@ -76,6 +76,12 @@ class GradComm:
                                                 C.c_void_p(t.data_ptr()), t.numel()), 'pmbrl_allreduce_sum')
         return t
 
+    def count(self):
+        """Ranks as the RCCL communicator itself reports them (ncclCommCount)."""
+        n = C.c_int32(0)
+        _lib.check(self.lib.pmbrl_comm_count(self.comm, C.byref(n)), 'pmbrl_comm_count')
+        return int(n.value)
+
     def close(self):
         if self.comm:
             self.lib.pmbrl_comm_destroy(self.comm)

@@ -24,6 +24,15 @@ CONFIGS = {
     # configs[4]: MFMA stress, per-GPU share of 2048 x 64 over 8 GPUs
     'stress32': dict(D=32, U=8, pol_hid=[512, 512, 512], dyn_hid=[512, 512, 512], P=256, S=64,
                      H=100, mm=False, reward='generic', maxU=1.0),
+    # configs[4] as BASELINE.md's table has it: moment matching with mm_groups = particles (64-row groups, a 32 x 32
+    # covariance per group and step)
+    # (z_orth: see synthetic_problem -- i.i.d. moment-matching noise makes this row's 100-step rollout ill-conditioned
+    #  beyond what the reference's own fp32 Cholesky survives)
+    'stress32_mm': dict(D=32, U=8, pol_hid=[512, 512, 512], dyn_hid=[512, 512, 512], P=256, S=64,
+                        H=100, mm=True, reward='generic', maxU=1.0, z_orth=True),
+    # a 16-wide state with narrow networks: moment matching / span-form tests beyond the cart-pole widths
+    'mid16_mm': dict(D=16, U=2, pol_hid=[64, 64], dyn_hid=[64, 64], P=4, S=576, H=4,
+                     mm=True, reward='generic', maxU=1.0),
     # a small wide-network case for the parity tests of the general kernel family (hidden layers wide
     # enough that the K-split partial tiles live in the output buffer's free columns)
     'wide_small': dict(D=12, U=3, pol_hid=[272, 256], dyn_hid=[256, 288, 256], P=10, S=4, H=6,
@@ -86,8 +95,8 @@ def synthetic_problem(name='cartpole_nomm', seed=0, P=None, S=None, H=None, data
             d['%s_W%d' % (pre, i)] = W
             d['%s_b%d' % (pre, i)] = b
     # normalisation from a synthetic dataset X ~ N(0,1), Y ~ 0.01 N(0,1) (models/core.py:134-149)
-    X = rng.standard_normal((300, D + U))
-    Y = 0.01 * rng.standard_normal((300, D))
+    X = cfg.get('x_scale', 1.0) * rng.standard_normal((300, D + U))
+    Y = cfg.get('y_scale', 0.01) * rng.standard_normal((300, D))
     rew_rng = np.random.default_rng([seed, 12345])
     if data_seed is not None:   # per-rank particles / masks / noise; weights stay shared
         rng = np.random.default_rng([seed, data_seed])
@@ -127,6 +136,22 @@ def synthetic_problem(name='cartpole_nomm', seed=0, P=None, S=None, H=None, data
     d['infer_ns'] = False
     d['z_mm'] = rng.standard_normal((Hn + B, D)).astype(np.float32)
     d['z_rr'] = rng.standard_normal((Hn + B, 1)).astype(np.float32)
+    if cfg.get('z_orth'):
+        # Orthogonalised moment-matching noise: rows periodic in the group size M, any M consecutive rows have zero
+        # column means and the identity as sample covariance -- so mm_resample_'s m + z L^T reproduces the fitted
+        # covariance exactly.  (With i.i.d. rows the cyclic index of utils/rollout.py:53-59 hands a group nearly the
+        # SAME z block at consecutive steps; its sample correlation matrix C, eigenvalues (1 +- sqrt(D / M))^2, is
+        # then applied again and again -- cov <- L C L^T -- and at D = 32, M = 64 the covariance's condition number
+        # passes 1e14 within 50 steps: the reference's fp32 Cholesky raises after about 20, a fp64 one on fp32 states
+        # after about 45.  A designed z keeps the H = 100 rollout of the C5 row well-conditioned; the arithmetic the
+        # kernels do is the same.)
+        M = Sn
+        assert D + 1 < M
+        A = np.concatenate([np.ones((M, 1)), rng.standard_normal((M, D + 1))], 1)
+        Q = np.linalg.qr(A)[0][:, 1:] * math.sqrt(M - 1.0)
+        reps = (Hn + B + M - 1) // M
+        d['z_mm'] = np.tile(Q[:, :D], (reps, 1))[:Hn + B].astype(np.float32)
+        d['z_rr'] = np.tile(Q[:, D:D + 1], (reps, 1))[:Hn + B].astype(np.float32)
     return d
 
 

@@ -245,3 +245,182 @@ def test_c4_full_size_matches_oracle(parts):
     assert common.rel(Rw.reshape(60, 5000), torch.stack(R64).detach().numpy().reshape(60, 5000)) < 2e-5
     assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
     assert common.rel(g, g64.numpy()) < 1e-4
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[4] (C5) at its per-GPU size: 256 particles x 64 samples = 16 384 rows, H = 100, with and
+# without the moment matching BASELINE.md's table gives it (mm_groups = particles: 64-row groups, 32 x 32 covariances)
+# ---------------------------------------------------------------------------
+def _sub_rows(d, n):
+    """The first n rows of problem d as a problem of its own (shared inputs stay whole)."""
+    B = d['x0'].shape[0]
+    e = dict(d)
+    for k in list(e):
+        v = np.asarray(e[k]) if not isinstance(e[k], (str, bool, int, float)) else None
+        if v is not None and (k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and v.ndim == 2 and v.shape[0] == B)):
+            e[k] = v[:n]
+    if int(d['mm_groups']):
+        e['mm_groups'] = np.asarray(int(d['mm_groups']) * n // B)
+    return e
+
+
+def _oracle_on_first_rows(d, n, threads=16):
+    """fp64 oracle on the first n rows (whole moment-matching groups) of the global batch d: the cyclic noise of
+    utils/rollout.py:53-59 indexed with the GLOBAL batch size, the loss a mean over the global batch."""
+    from oracle import ref_torch as R
+    B = d['x0'].shape[0]
+    e = _sub_rows(d, n)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(e, torch.float64)
+    torch.set_num_threads(threads)
+    orig = R.get_z_rnd
+    R.get_z_rnd = lambda z, i, m: z[torch.arange(i, i + m) % B]
+    try:
+        l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
+                                                meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+    finally:
+        R.get_z_rnd = orig
+    return torch.stack(S64).detach().numpy(), float(l64) * n / B, g64.numpy() * (n / B)
+
+
+def test_c5_mm_shape_matches_oracle():
+    """C5 WITH moment matching (D = 32: a 32 x 32 covariance per 64-row group and step) at 8 particles x 64 samples,
+    the real horizon H = 100, against the fp64 oracle (utils/rollout.py:20-29 over the 3 x 512 networks)."""
+    from oracle import ref_torch as R
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem('stress32_mm', seed=0, data_seed=0, P=8, S=64))
+    assert int(d['H']) == 100 and d['x0'].shape == (512, 32) and int(d['mm_groups']) == 8
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    assert eng.info['fast'] == 0 and eng.info['mm_mode'] in (1, 2)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(16)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True, 8, z_mm, z_rr)
+    e_s, e_g = common.rel(S, torch.stack(S64).detach().numpy()), common.rel(g, g64.numpy())
+    print('C5 mm 512 rows: states %.2e loss %.2e grad %.2e' % (e_s, abs(loss - float(l64)) / abs(float(l64)), e_g))
+    assert e_s < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert e_g < 1e-4
+
+
+def _c5_full(config):
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem(config, seed=0, data_seed=0))
+    assert int(d['H']) == 100 and d['x0'].shape == (16384, 32)
+    return d
+
+
+def _masked(gw, n):
+    m = torch.zeros_like(gw)
+    m[:, :n] = gw[:, :n]
+    return m
+
+
+def test_c5_full_size_parity_and_properties():
+    """C5 at its per-GPU size (16 384 rows x H = 100, no moment matching: the configuration bench.py --config
+    stress32 times).  Rows are independent, so (a) the first 512 rows' trajectories and the gradient of the loss
+    restricted to them are the fp64 oracle's on those rows; (b) reversing the row order reverses the trajectories
+    bit for bit; (c) 16- and 32-row workgroups agree; (d) the gradient is linear in the loss weights."""
+    d = _c5_full('stress32')
+    eng, S, A, Rw, loss, g, gw = _run(d)
+    assert eng.info['fast'] == 0 and eng.info['rows_per_wg'] == 32
+    S64, l64, g64 = _oracle_on_first_rows(d, 512)
+    g_sub = eng.backward(_masked(gw, 512))[0].cpu().numpy().copy()
+    e_s, e_g = common.rel(S[:, :512], S64), common.rel(g_sub, g64)
+    print('C5 16384 rows, first 512 vs oracle: states %.2e grad %.2e' % (e_s, e_g))
+    assert e_s < 2e-5 and e_g < 1e-4
+    # (d) linearity: the rest of the rows' gradient adds up to the whole
+    g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
+    assert common.rel(g_sub + g_rest, g) < 2e-6
+    # (c) 16-row workgroups
+    eng16, S16, _, _, _, g16, _ = _run(d, rows_per_wg_hint=16)
+    assert eng16.info['rows_per_wg'] == 16
+    assert common.rel(S16, S) < 1e-6 and common.rel(g16, g) < 1e-5
+    del eng16
+    # (b) row reversal
+    B = d['x0'].shape[0]
+    e = dict(d)
+    for k in list(e):
+        v = np.asarray(e[k]) if not isinstance(e[k], (str, bool, int, float)) else None
+        if v is not None and (k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and v.ndim == 2 and v.shape[0] == B)):
+            e[k] = v[::-1].copy()
+    _, Sr, Ar, _, _, gr, _ = _run(e)
+    assert np.array_equal(S[:, ::-1], Sr) and np.array_equal(A[:, ::-1], Ar)
+    assert common.rel(gr, g) < 2e-6
+
+
+def test_c5_mm_full_size_parity_and_properties():
+    """C5 with mm_groups = 256 at its per-GPU size (16 384 rows x H = 100: bench.py --config stress32_mm).  Groups
+    are independent, so (a) the first 8 groups' trajectories and the gradient of the loss restricted to them are the
+    fp64 oracle's on those 512 rows (noise rows taken with the global row index, as the kernels and the reference
+    do); (b) the same 8 groups run as a shard of the global batch give the same bits; (c) the gradient is linear
+    in the loss weights."""
+    from prob_mbrl_amd import problem as PB
+    d = _c5_full('stress32_mm')
+    eng, S, A, Rw, loss, g, gw = _run(d)
+    assert eng.info['fast'] == 0 and int(d['mm_groups']) == 256
+    S64, l64, g64 = _oracle_on_first_rows(d, 512)
+    g_sub = eng.backward(_masked(gw, 512))[0].cpu().numpy().copy()
+    e_s, e_g = common.rel(S[:, :512], S64), common.rel(g_sub, g64)
+    print('C5 mm 16384 rows, first 8 groups vs oracle: states %.2e grad %.2e' % (e_s, e_g))
+    assert e_s < 2e-5 and e_g < 1e-4
+    g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
+    assert common.rel(g_sub + g_rest, g) < 2e-6
+    # (b) the first 8 groups as a shard of the 16 384-row global batch
+    sh, args, _ = PB.engine_from_problem(_sub_rows(d, 512), DEV, B_global=16384, row_offset=0)
+    Ss, As_, Rs = sh.forward(**args)
+    gs = sh.backward(gw[:, :512].contiguous())[0].cpu().numpy()
+    assert sh.valid_steps() == 100
+    assert np.array_equal(Ss.cpu().numpy(), S[:, :512]) and np.array_equal(As_.cpu().numpy(), A[:, :512])
+    assert common.rel(gs, g_sub) < 2e-6
+
+
+def test_device_detects_a_mid_horizon_failure_and_continues_on_the_truncated_horizon():
+    """A failure the DEVICE finds (no status word written by the test): one state dimension, decoupled from the
+    networks and the reward, drifts by 5e37 per step and overflows fp32 while step 6 computes x_7; the state moment
+    matching of step 6 sees a non-finite covariance -- the condition under which the reference's Cholesky raises
+    (utils/rollout.py:116-127) -- and the caller keeps the 6 completed steps (:154-157; more than 5).  The kept
+    trajectory, the loss and the gradient are the fp64 oracle's run to 6 steps.  (WHICH step overflows depends on
+    the arithmetic: the reference's own fp32 run would overflow the SUM of a group's 25 values of 5e37 in its mean
+    two steps in; the device takes its moments in fp64, so its first non-finite value is x_7 itself.  What is pinned
+    here is the device's detection and the continuation after it, against the oracle in fp64.)"""
+    from oracle import ref_torch as R
+    d = dict(common.load('mmg_h40'))
+    H, B = int(d['H']), d['x0'].shape[0]
+    k = 3
+    for key in ('pol_W0', 'dyn_W0'):
+        W = np.asarray(d[key]).copy()
+        W[:, k] = 0.0
+        d[key] = W
+    C = np.asarray(d['rew_C']).copy()
+    assert bool(d['rew_expand'])
+    # columns of the expanded state [others (0, 1, 3) | sin | cos]: the decoupled dimension 3 is column 2
+    C[:, 2] = 0.0
+    d['rew_C'] = C
+    my = np.asarray(d['dyn_my'], dtype=np.float32).copy()
+    my[k] = 5e37
+    d['dyn_my'] = my
+    # the general family on fp16 pieces cannot hold a normalised input of 1e37: it says so at the first step that sees
+    # one (rollout() / mc_pilco then re-run in fp32, tests/test_gpu_api.py) instead of rolling on with a NaN that
+    # vanishes in the ReLU
+    eng, args, _ = common.engine_from_fixture(d, DEV, force_generic=True, precision='split_f16')
+    eng.forward(**args)
+    assert eng.valid_steps() <= 1
+    for generic, prec in ((False, None), (True, 'f32')):
+        eng, args, _ = common.engine_from_fixture(d, DEV, force_generic=generic, precision=prec)
+        S, A, Rw = eng.forward(**args)
+        n = eng.valid_steps()
+        assert n == 6, n                                # found by the device, at step 6 of 40
+        gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+        loss = float((Rw[:n].reshape(n, B) * gw[:n]).sum())
+        g, _, _ = eng.backward(gw)
+        g = g.cpu().numpy()
+        assert np.all(np.isfinite(g))
+        x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+        l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, H, gamma, True, True, True, meta['mm_groups'],
+                                                z_mm, z_rr, n_steps=n)
+        S64 = torch.stack(S64).detach().numpy()
+        keep = [j for j in range(S64.shape[-1]) if j != k]
+        Sd = S[:n + 1].cpu().numpy()
+        assert common.rel(Sd[..., keep], S64[..., keep]) < 2e-5
+        assert common.rel(Sd[..., k], S64[..., k]) < 1e-6
+        assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+        assert common.rel(g, g64.numpy()) < 1e-4

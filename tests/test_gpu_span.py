@@ -115,6 +115,8 @@ def _run(name, parts, precision=None, fail_at=None):
     ('angles_dcp_mmg', (6, 6)),        # angle_dims inside Policy / DynamicsModel
     ('mmg_m80', (30, 50)),             # 80-row groups: two waves of a workgroup share a rank's rows
     ('mmg_infer_ns', (5, 3)),          # infer_noise_variables (utils/rollout.py:6-17): zhat = Delta L^-T
+    ('c5_mm_d12', (20, 12)),           # D = 12: 12 x 12 statistics cross the ranks
+    ('c5_mm_d32', (40, 24)),           # D = 32, 64-row groups (BASELINE.md's C5 widths)
 ])
 def test_groups_spread_over_ranks_match_the_reference(name, parts):
     d, S, loss, grad = _run(name, parts)
@@ -273,3 +275,54 @@ def test_one_process_group_beyond_the_cu_count_takes_the_one_rank_span_form(monk
     assert eng.valid_steps() == 8
     assert common.rel(S.cpu().numpy(), S0.cpu().numpy()) < 1e-5 and common.rel(R.cpu().numpy(), R0.cpu().numpy()) < 1e-5
     assert common.rel(g.cpu().numpy(), g0.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize('D,rows,world', [(16, 2304, 1), (16, 2304, 2), (32, 640, 1)])
+def test_wide_state_sums_spread_over_workgroups(D, rows, world):
+    """The span form at D >= 16 with enough rows per rank that the sums are spread over several workgroups (nb > 1):
+    the adjoint's second half adds nb parts of d*d + d doubles each (staged behind the scratch, they
+    overran the launch's LDS at D = 16 with >= 2048 rows, D = 32 with >= 512 rows).  One group over all rows,
+    against the fp64 oracle and against the one-workgroup-per-group kernels (mm_mode 2 without span)."""
+    from oracle import ref_torch as R
+    from prob_mbrl_amd import problem as PB
+    d = dict(PB.synthetic_problem('mid16_mm', seed=3, data_seed=0, P=4, S=rows // 4, H=4))
+    if D == 32:
+        d = dict(PB.synthetic_problem('stress32_mm', seed=3, data_seed=0, P=4, S=rows // 4, H=3))
+    d['mm_groups'] = 0
+    B, H = d['x0'].shape[0], int(d['H'])
+    assert B == rows and d['x0'].shape[1] == D
+    dev = torch.device(DEV)
+    gw_all = torch.tensor(PB.loss_weights(d, B).copy(), device=DEV)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(16)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, H, gamma, True, True, True, None, z_mm, z_rr)
+    S64 = torch.stack(S64).detach().numpy()
+    ts = ThreadSum(world)
+    res, err = [None] * world, []
+
+    def worker(r):
+        try:
+            lo, hi = r * B // world, (r + 1) * B // world
+            eng, args, _ = PB.engine_from_problem(d, dev, shard=(r, world), mm_span=(B, lo, world, r))
+            assert eng.info['mm_mode'] == 2
+            eng.attach_collective(ts.rank(r))
+            S, _, Rw = eng.forward(**args)
+            assert eng.valid_steps() == H
+            g = eng.backward(gw_all[:, lo:hi].contiguous())[0]
+            res[r] = (lo, hi, S.cpu().numpy(), g.double().cpu().numpy())
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+            ts.bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    if err:
+        raise err[0]
+    for lo, hi, S, _ in res:
+        assert common.rel(S, S64[:, lo:hi]) < 2e-5
+    g = sum(x[3] for x in res)
+    print('span D=%d rows=%d world=%d: grad %.2e' % (D, rows, world, common.rel(g, g64.numpy())))
+    assert common.rel(g, g64.numpy()) < 1e-4

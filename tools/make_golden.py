@@ -1190,6 +1190,16 @@ CASES = {
     # SURVEY C5 shape (D=32, U=8, 3 x 512 both nets): general kernel family, 32-tile layers
     'c5_small': lambda: make_case('c5_small', 32, 8, [512, 512, 512], [512, 512, 512],
                                   lambda: _generic_reward(32, 8), [1.0] * 8, 16, 20, seed=19, weight_seed=190),
+    # moment matching beyond D = 6 (the cart-pole widths): 12 x 12 and 32 x 32 covariances, 32- / 64-row groups.
+    # BASELINE.md's C5 row is D = 32 with mm_groups = particles (64 rows per group): c5_mm_d32 has its widths with
+    # narrow networks, c5_mm_small the 3 x 512 networks themselves (weights from a seed)
+    'c5_mm_d12': lambda: make_case('c5_mm_d12', 12, 3, [48, 48], [48, 48], lambda: _generic_reward(12, 3),
+                                   [1.0, 2.0, 0.5], 96, 10, mm=True, mm_groups=3, seed=41, P=3),
+    'c5_mm_d32': lambda: make_case('c5_mm_d32', 32, 8, [64, 64, 64], [64, 64, 64], lambda: _generic_reward(32, 8),
+                                   [1.0] * 8, 128, 12, mm=True, mm_groups=2, seed=42, P=2),
+    'c5_mm_small': lambda: make_case('c5_mm_small', 32, 8, [512, 512, 512], [512, 512, 512],
+                                     lambda: _generic_reward(32, 8), [1.0] * 8, 128, 10, mm=True, mm_groups=2,
+                                     seed=43, P=2, weight_seed=430),
     # moment matching at the examples' horizon (the regime SURVEY 7 flags as ill-conditioned)
     'mm1_b100_h40': lambda: make_case('mm1_b100_h40', 5, 1, [32, 32], [32, 32], _cartpole, 10.0, 100, 40,
                                       mm=True, seed=17),
