@@ -9,8 +9,12 @@ synthetic Cartpole-shaped problem (BASELINE.json configs[1]: |x|=4, |u|=1,
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU
 (torch.distributed, backend nccl = RCCL); the only collective is the gradient
 all-reduce.  --scaling weak (default): every rank owns its own 2500 rows of a
-global batch of N*2500; --scaling strong: the 100 x 25 = 2500 rows of BASELINE.json's
-metric are divided over the N ranks (whole particle groups per rank).
+global batch of N*2500 (`value`); --scaling strong: the 100 x 25 = 2500 rows of BASELINE.json's
+metric are divided over the N ranks (whole particle groups per rank, as evenly as they
+divide).  For N > 1 BOTH curves are timed in the one invocation: `value` is the chosen one, the
+other is reported next to it (`strong: {...}` / `weak: {...}`), and `rccl_ranks` is the rank
+count the RCCL communicator itself reports.  For N = 1 the exact-fp32 path is timed on the same
+problem next to the default arithmetic (`f32: {...}`).
 
 Prints ONE JSON line (rank 0).
 """
@@ -47,6 +51,8 @@ def parse():
                     help='moment-matching configs: ONE group over the rows of all ranks (mm_groups=None, the '
                          "reference examples' default) -- per-step statistics exchange between the ranks; weak scaling only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-twin', action='store_true', help='N = 1: skip the exact-fp32 leg')
+    ap.add_argument('--no-second-curve', action='store_true', help='N > 1: skip the other scaling curve')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
     # debugging aids for the N>1 control flow on a box with ONE GPU (tests/test_gpu_api.py):
@@ -142,114 +148,98 @@ def cpu_baseline(d, budget_s=24.0):
                 one_thread=dict(value=B / one, ms_per_step=one * 1e3))   # the reference's default (examples/deep_pilco_mm.py:21,65)
 
 
-def main():
-    a = parse()
-    from prob_mbrl_amd import problem as PB
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.cpu_only:
-        d = PB.synthetic_problem(a.config, seed=0, data_seed=0)
-        print(json.dumps(cpu_baseline(d)))
-        return
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if a.one_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
-    dev = torch.device('cuda:%d' % local_rank)
-    torch.cuda.set_device(dev)
-
-    from prob_mbrl_amd import engine as E
-    if a.scaling == 'strong' and world > 1:
-        # the SAME global problem for every N: its particle groups are dealt to the ranks
-        cfg = PB.CONFIGS[a.config]
-        assert cfg['P'] % world == 0, 'strong scaling: the particle count must divide by the GPU count'
-        dg = PB.synthetic_problem(a.config, seed=0, data_seed=0)
-        d = PB.shard_problem(dg, rank, world)
-    else:
-        d = PB.synthetic_problem(a.config, seed=0, data_seed=rank)
+def shard_rows(d, lo, hi):
+    """Rows [lo, hi) (whole moment-matching groups) of the global problem d as one rank's problem."""
     B = d['x0'].shape[0]
-    H = int(d['H'])
-    Bg = B * world
-    mm_span = None
-    if a.mm_global:
-        assert bool(d['mm_states']) and a.scaling == 'weak', '--mm-global: a moment-matching config, weak scaling'
-        d = dict(d)
-        d['mm_groups'] = 0
-        if world > 1:
-            mm_span = (Bg, rank * B, world, rank)
-    if world > 1 and bool(d['mm_states']) and a.scaling == 'weak':
-        # one cyclic noise buffer over the GLOBAL rows (utils/rollout.py:53-59), the same on every rank
-        d = dict(d)
-        gen = np.random.default_rng(12345)
-        d['z_mm'] = gen.standard_normal((H + Bg, d['x0'].shape[1])).astype(np.float32)
-        d['z_rr'] = gen.standard_normal((H + Bg, 1)).astype(np.float32)
-    eng, args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=a.rows_per_wg, B_global=Bg,
-                                          row_offset=rank * B, precision=a.precision, mm_span=mm_span)
-    if mm_span:
-        eng.attach_collective(dist.group.WORLD)
-    gw = torch.tensor(PB.loss_weights(d, Bg)[:, :B].copy(), device=dev)
-    params = args['pol_flat'].clone()
-    args['pol_flat'] = params
-    m = torch.zeros_like(params)
-    v = torch.zeros_like(params)
-    loss_buf = torch.zeros(1, device=dev)
-    state = dict(step=0)
+    G = int(d['mm_groups'])
+    out = dict(d)
+    for k, v in d.items():
+        if isinstance(v, (str, bool, int, float)):
+            continue
+        v = np.asarray(v)
+        if k in ('x0', 'pol_z', 'dyn_z') or ('_mask' in k and v.ndim == 2 and v.shape[0] == B):
+            out[k] = v[lo:hi]
+    out['mm_groups'] = (hi - lo) // (B // G) if G else 0
+    return out
 
-    if world > 1:
-        from prob_mbrl_amd.distributed import grad_allreduce
-        allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI, on the compute stream
 
-    def step():
-        state['step'] += 1
-        _, _, R = eng.forward(**args)
-        eng.weighted_sum(R, gw, out=loss_buf)
-        g, _, _ = eng.backward(gw)
-        if world > 1:
-            allreduce(g)
-        E.clip_adam(params, g, m, v, state['step'], 1e-4, max_norm=1.0)
+class Leg:
+    """One timed configuration: an engine, its resident inputs and the optimiser state."""
 
-    def sync():
+    def __init__(self, a, d, dev, Bg, row_offset, precision, mm_span, world, allreduce):
+        from prob_mbrl_amd import engine as E
+        from prob_mbrl_amd import problem as PB
+        self.E, self.world, self.allreduce = E, world, allreduce
+        self.d, self.B, self.Bg, self.H = d, d['x0'].shape[0], Bg, int(d['H'])
+        self.eng, self.args, _ = PB.engine_from_problem(d, dev, rows_per_wg_hint=a.rows_per_wg, B_global=Bg,
+                                                        row_offset=row_offset, precision=precision, mm_span=mm_span)
+        if mm_span:
+            import torch.distributed as dist
+            self.eng.attach_collective(dist.group.WORLD)
+        self.gw = torch.tensor(PB.loss_weights(d, Bg)[:, :self.B].copy(), device=dev)
+        self.params = self.args['pol_flat'].clone()
+        self.args['pol_flat'] = self.params
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.loss_buf = torch.zeros(1, device=dev)
+        self.n = 0
+
+    def step(self):
+        self.n += 1
+        _, _, R = self.eng.forward(**self.args)
+        self.eng.weighted_sum(R, self.gw, out=self.loss_buf)
+        g, _, _ = self.eng.backward(self.gw)
+        if self.world > 1:
+            self.allreduce(g)
+        self.E.clip_adam(self.params, g, self.m, self.v, self.n, 1e-4, max_norm=1.0)
+
+    def sync(self):
         torch.cuda.synchronize()
-        if world > 1:
+        if self.world > 1:
+            import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert eng.valid_steps() == H, 'numerical failure inside the benchmark rollout'
-    assert bool(torch.isfinite(params).all()) and bool(torch.isfinite(loss_buf).all())
+    def timed(self, steps, warmup, dev):
+        """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize; max over ranks."""
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert self.eng.valid_steps() == self.H, 'numerical failure inside the benchmark rollout'
+        assert bool(torch.isfinite(self.params).all()) and bool(torch.isfinite(self.loss_buf).all())
+        return dt
 
-    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region.
-    # Every rank runs these steps (step() contains the gradient all-reduce); rank 0 reports its own.
-    eng.set_timing(True)
-    acc = {}
-    for _ in range(a.timing_steps):
-        step()
-        for k, ms in eng.read_timing().items():
-            if ms >= 0:
-                acc.setdefault(k, []).append(ms)
-    eng.set_timing(False)
-    timings = {k: float(np.mean(vv)) for k, vv in acc.items()}
-    sync()
+    def kernel_ms(self, n):
+        """Per-kernel durations (HIP events on the launch stream), outside the timed region.  Every rank runs these
+        steps (step() contains the gradient all-reduce)."""
+        self.eng.set_timing(True)
+        acc = {}
+        for _ in range(n):
+            self.step()
+            for k, ms in self.eng.read_timing().items():
+                if ms >= 0:
+                    acc.setdefault(k, []).append(ms)
+        self.eng.set_timing(False)
+        self.sync()
+        return {k: float(np.mean(vv)) for k, vv in acc.items()}
 
-    if rank == 0:
-        flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
+    def roofline(self, timings):
+        """The dominant kernel against the dense MFMA peak of the instruction it issues: exact fp32 MFMA, or fp16 / bf16
+        MFMA at THREE instructions per fp32-equivalent product (two-piece split operands; the three-piece bf16
+        forward of 'split' issues six)."""
+        from prob_mbrl_amd import problem as PB
+        eng, d, B, H = self.eng, self.d, self.B, self.H
+        _, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
         # algorithmic flops per launch of each kernel (one launch covers B rows x H steps)
         kflops = dict(fwd=2.0 * H * B * (Pm + Fm), bwd=2.0 * H * B * (Pm + Fm), dw=2.0 * H * B * Pm)
         dom = max(kflops, key=lambda k: timings.get(k, 0.0))
@@ -261,22 +251,7 @@ def main():
         kname = {'fwd': 'pm_rollout_fwd', 'bwd': 'pm_rollout_bwd', 'dw': 'pm_dw_kernel'}[dom]
         if eng.info.get('fast') and dom != 'dw':
             kname += '_fast'
-        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes);
-        # only valid for the configuration they were collected on
-        traffic, traffic_src = None, None
         prec = eng.info['precision']
-        try:
-            src = 'profiles/r02_pmc_traffic_%s.json' % prec
-            pmc = json.load(open(os.path.join(ROOT, src)))
-            if a.config == 'cartpole_nomm' and world == 1 and kname in pmc['kernels']:
-                traffic = pmc['kernels'][kname]['hbm_bytes_per_launch']
-                traffic_src = src + ' (rocprofv3 --pmc passes of this command, not measured in this run)'
-        except Exception:
-            traffic = None
-        # peak the dominant kernel is priced against: the dense MFMA peak of the instruction it issues --
-        # exact fp32 MFMA, or fp16 / bf16 MFMA at THREE instructions per fp32-equivalent product (two-piece
-        # split operands; the three-piece bf16 forward of 'split' issues six)
         mfma_per_product = {('f32', 'fwd'): 1, ('f32', 'bwd'): 1, ('split', 'fwd'): 6, ('split', 'bwd'): 3,
                             ('split_f16', 'fwd'): 3, ('split_f16', 'bwd'): 3}.get((prec, dom), 1)
         if prec == 'f32' or dom == 'dw':
@@ -285,12 +260,137 @@ def main():
             peak = PEAK_F16_MFMA_TFLOPS / mfma_per_product
             peak_note = ('v_mfma_f32_16x16x32_%s dense peak (2500 TFLOP/s) / %d MFMAs per fp32-equivalent product' %
                          ('f16' if (prec == 'split_f16' and dom == 'fwd') else 'bf16', mfma_per_product))
+        n_wg = eng.info['n_wg']
+        # what binds the sweep: the latency-optimised family is one sequential chain of H steps per workgroup (DESIGN.md
+        # 4) -- the matrix pipe is not the limiter at any size it serves; the general family (wide networks, >= 2
+        # workgroups per CU) is priced as MFMA-bound
+        latency = bool(eng.info.get('fast')) and dom != 'dw'
+        r = dict(bound='latency' if latency else 'mfma', kernel=kname, achieved=achieved, peak=peak, unit='TFLOP/s',
+                 frac=achieved / peak, peak_is=peak_note, frac_of_f32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
+                 binding=('latency: H sequential steps per workgroup, %d of %d CUs occupied; weight stream L2->CU '
+                          'inside a step' % (min(n_wg, N_CUS), N_CUS)) if latency else
+                         'matrix pipe / weight fetch L2->CU: %d workgroups over %d CUs' % (n_wg, N_CUS),
+                 flops_per_launch=kflops[dom], avg_launch_ms=timings[dom])
+        return r, kname
+
+
+def pmc_traffic(config, prec, kname, world):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
+    Counters cannot be read from inside a run: the figure is the committed measurement of THIS command on this
+    configuration, and the line says so."""
+    if world != 1:
+        return None, None
+    for src in ('profiles/r03_pmc_traffic_%s_%s.json' % (config, prec), 'profiles/r03_pmc_traffic_%s.json' % prec):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, src)))
+            if pmc.get('config', 'cartpole_nomm') == config and kname in pmc['kernels']:
+                return pmc['kernels'][kname]['hbm_bytes_per_launch'], src
+        except Exception:
+            continue
+    return None, None
+
+
+def main():
+    a = parse()
+    from prob_mbrl_amd import problem as PB
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.cpu_only:
+        d = PB.synthetic_problem(a.config, seed=0, data_seed=0)
+        print(json.dumps(cpu_baseline(d)))
+        return
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.one_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    dev = torch.device('cuda:%d' % local_rank)
+    torch.cuda.set_device(dev)
+
+    allreduce, rccl_ranks = None, None
+    if world > 1:
+        from prob_mbrl_amd.distributed import get_comm, grad_allreduce
+        allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI, on the compute stream
+        comm = get_comm(None, dev)
+        rccl_ranks = comm.count() if comm is not None else None   # as the communicator reports it (ncclCommCount)
+
+    def make_leg(scaling, precision):
+        """weak: every rank brings its own rows of a global batch of N x rows; strong: the rows of BASELINE.json's
+        metric (one global problem, the same for every N) dealt to the ranks in whole moment-matching groups, as evenly
+        as they divide."""
+        mm_span = None
+        if scaling == 'strong' and world > 1:
+            from prob_mbrl_amd.distributed import shard_bounds
+            dg = PB.synthetic_problem(a.config, seed=0, data_seed=0)
+            Bg = dg['x0'].shape[0]
+            lo, hi = shard_bounds(Bg, int(dg['mm_groups']) or None, world, rank)
+            return Leg(a, shard_rows(dg, lo, hi), dev, Bg, lo, precision, None, world, allreduce)
+        d = PB.synthetic_problem(a.config, seed=0, data_seed=rank)
+        B, H = d['x0'].shape[0], int(d['H'])
+        Bg = B * world
+        if a.mm_global:
+            assert bool(d['mm_states']) and scaling == 'weak', '--mm-global: a moment-matching config, weak scaling'
+            d = dict(d)
+            d['mm_groups'] = 0
+            if world > 1:
+                mm_span = (Bg, rank * B, world, rank)
+        if world > 1 and bool(d['mm_states']):
+            # one cyclic noise buffer over the GLOBAL rows (utils/rollout.py:53-59), the same on every rank
+            d = dict(d)
+            dz = PB.synthetic_problem(a.config, seed=0, data_seed=0, P=PB.CONFIGS[a.config]['P'] * world)
+            d['z_mm'], d['z_rr'] = dz['z_mm'], dz['z_rr']
+        return Leg(a, d, dev, Bg, rank * B, precision, mm_span, world, allreduce)
+
+    primary = a.scaling if world > 1 else 'weak'
+    leg = make_leg(primary, a.precision)
+    dt = leg.timed(a.steps, a.warmup, dev)
+    timings = leg.kernel_ms(a.timing_steps)
+    eng, d, B, Bg, H = leg.eng, leg.d, leg.B, leg.Bg, leg.H
+    prec = eng.info['precision']
+
+    extra = {}
+    if world > 1 and not a.no_second_curve and not a.mm_global:
+        # the other scaling curve in the same invocation, timed the same way
+        other = 'strong' if primary == 'weak' else 'weak'
+        leg2 = make_leg(other, a.precision)
+        dt2 = leg2.timed(a.steps, a.warmup, dev)
+        rows = torch.tensor([leg2.B], device=dev, dtype=torch.int64)
+        lst = [torch.zeros_like(rows) for _ in range(world)]
+        dist.all_gather(lst, rows)
+        extra[other] = dict(value=leg2.Bg * a.steps / dt2, unit='rollouts/s', ms_per_step=dt2 / a.steps * 1e3,
+                            global_rows=leg2.Bg, rows_per_gpu=[int(x.item()) for x in lst], steps=a.steps,
+                            warmup=a.warmup, workgroups_rank0=leg2.eng.info['n_wg'],
+                            rows_per_wg=leg2.eng.info['rows_per_wg'])
+        del leg2
+    if world == 1 and prec != 'f32' and not a.no_f32_twin:
+        # the exact-fp32 MFMA path on the same problem in the same invocation (the reference's arithmetic)
+        leg3 = make_leg('weak', 'f32')
+        dt3 = leg3.timed(a.steps, a.warmup, dev)
+        t3 = leg3.kernel_ms(a.timing_steps)
+        r3, _ = leg3.roofline(t3)
+        extra['f32'] = dict(value=leg3.Bg * a.steps / dt3, unit='rollouts/s', ms_per_step=dt3 / a.steps * 1e3,
+                            steps=a.steps, warmup=a.warmup, dtype='f32 (v_mfma_f32_16x16x4_f32)',
+                            kernel_ms={k: round(vv, 4) for k, vv in t3.items()}, roofline=r3)
+        del leg3
+
+    if rank == 0:
+        flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
+        roof, kname = leg.roofline(timings)
+        traffic, traffic_src = pmc_traffic(a.config, prec, kname, world)
+        roof.update(traffic=traffic, traffic_measured_in_run=False, traffic_source=traffic_src)
         dtype = {'f32': 'f32', 'split': 'f32 via split bf16 MFMA (3 pieces fwd / 2 adjoint), fp32 accumulate',
                  'split_f16': 'f32 via split fp16 (fwd, 2 pieces) / bf16 (adjoint, 2 pieces) MFMA, fp32 accumulate'}[prec]
         out = dict(
             metric='particle_rollouts_per_sec', value=Bg * a.steps / dt, unit='rollouts/s',
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-            higher_is_better=True, scaling=a.scaling if world > 1 else 'weak', vs_baseline=None, dtype=dtype,
+            higher_is_better=True, scaling=primary, vs_baseline=None, dtype=dtype,
             data='synthetic',
             config=dict(workload='%s: D=%d U=%d pol=%s dyn=%s rows/GPU=%d (%s) H=%d mm=%s; full '
                                  'iteration = rollout fwd + loss + adjoint + dW + %sclip + Adam' %
@@ -307,16 +407,12 @@ def main():
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
-            roofline=dict(bound='mfma', kernel=kname,
-                          achieved=achieved, peak=peak, unit='TFLOP/s',
-                          frac=achieved / peak, traffic=traffic,
-                          traffic_source=traffic_src,
-                          peak_is=peak_note, frac_of_f32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
-                          # what binds this kernel at this size is not the matrix pipe: per-workgroup latency
-                          # of H sequential steps on %d of 256 CUs, and the weight stream L2 -> CU
-                          binding='latency: H sequential steps per workgroup, %d of %d CUs occupied; '
-                                  'weight stream L2->CU inside a step' % (min(eng.info['n_wg'], N_CUS), N_CUS),
-                          flops_per_launch=kflops[dom], avg_launch_ms=timings[dom]))
+            roofline=roof)
+        if world > 1:
+            out['rccl_ranks'] = rccl_ranks
+            out['collective'] = ('RCCL ncclAllReduce through the C ABI on the compute stream' if rccl_ranks else
+                                 'torch.distributed all_reduce (backend %s)' % a.dist_backend)
+        out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(d)
         print(json.dumps(out))

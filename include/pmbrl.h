@@ -279,7 +279,9 @@ int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d,
  * otherwise parameters, moments and counter are left untouched.  This is the
  * reference's "RuntimeError -> skip the optimiser step" (algorithms/
  * mc_pilco.py:122-131) without a host round trip per iteration: the host may
- * read the status word one iteration late. */
+ * read the status word one iteration late.  status_d is the two-word status of
+ * pmbrl_rollout_fwd / _bwd: the step is also skipped when status_d[1] != 0 (the adjoint
+ * sweep reported a failure of its own -- a barrier between workgroups timed out). */
 int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* grads_d,
                             float* exp_avg_d, float* exp_avg_sq_d, int64_t n,
                             int64_t* step_d, double lr, double beta1, double beta2,

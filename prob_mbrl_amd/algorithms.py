@@ -239,12 +239,11 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
         rk = dict(rollout_kwargs)
         queued = False
         try:
+            dist_kw = dict(B_global=Bg if world > 1 else None, row_offset=rank * N_particles if world > 1 else 0,
+                           mm_span=mm_span, process_group=process_group if mm_span else None)
             bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus,
                                mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
-                               z_rr if pegasus else None,
-                               B_global=Bg if world > 1 else None,
-                               row_offset=rank * N_particles if world > 1 else 0, precision=prec['name'],
-                               mm_span=mm_span, process_group=process_group if mm_span else None)
+                               z_rr if pegasus else None, precision=prec['name'], **dist_kw)
             cache = None if need_autograd else _adam_flat_state(opt, bundle.pol_params,
                                                                 bundle.pol_flat)
             if cache is None:
@@ -272,28 +271,31 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 queued = True
             else:
                 eng = bundle.engine
+                def agreed_steps(e):
+                    """Valid steps of the sweep just run -- on a sharded run the MIN over the ranks: every rank must take
+                    the same branch and the same horizon, a failure anywhere truncates (or fails) the rollout
+                    everywhere, like one process would."""
+                    n = e.valid_steps()           # the one host sync of the iteration
+                    if world > 1:
+                        import torch.distributed as dist
+                        nv = torch.tensor([n], dtype=torch.int32, device=dev)
+                        dist.all_reduce(nv, op=dist.ReduceOp.MIN, group=process_group)
+                        if int(nv[0]) < n:
+                            e.status[0:1].copy_(nv)           # what the adjoint sweep and the loss read
+                            n = int(nv[0])
+                    return n
                 S, A, R = bundle.forward(x0_)
-                n_valid = eng.valid_steps()       # the one host sync of the iteration
-                if n_valid < H and prec['name'] is None and world == 1 and \
-                        E.safe_precision(eng.info['precision']) is not None:
-                    # fp16 pieces: their range may be what failed -- decide on the bf16 path
+                n_valid = agreed_steps(eng)
+                if n_valid < H and prec['name'] is None and E.safe_precision(eng.info['precision']) is not None:
+                    # fp16 pieces: their range may be what failed -- decide on the bf16 / fp32 path.  (n_valid is the
+                    # ranks' minimum, so all of them switch together and stay switched.)
                     prec['name'] = E.safe_precision(eng.info['precision'])
                     bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus, mm_states,
                                        mm_rewards, mm_groups, z_mm if pegasus else None, z_rr if pegasus else None,
-                                       precision=prec['name'])
+                                       precision=prec['name'], **dist_kw)
                     eng = bundle.engine
                     S, A, R = bundle.forward(x0_)
-                    n_valid = eng.valid_steps()
-                if world > 1:
-                    # every rank must take the same branch and the same horizon: a failure anywhere
-                    # truncates (or fails) the rollout everywhere, like one process would
-                    import torch.distributed as dist
-                    nv = torch.tensor([n_valid], dtype=torch.int32, device=dev)
-                    dist.all_reduce(nv, op=dist.ReduceOp.MIN, group=process_group)
-                    n_all = int(nv[0])
-                    if n_all < n_valid:
-                        eng.status[0:1].copy_(nv)         # what the adjoint sweep and the loss read
-                        n_valid = n_all
+                    n_valid = agreed_steps(eng)
                 if n_valid < min_steps:
                     raise RuntimeError('rollout failed at step %d' % n_valid)
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
@@ -329,6 +331,17 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 if callable(on_rollout):
                     on_rollout(i, states, actions, rewards, disc)
                 g, _, _ = eng.backward(gw)
+                if eng.info.get('mm_grid') or eng.info.get('mm_parts', 1) > 1:
+                    # sweeps whose workgroups meet at barriers: a barrier that timed out (workgroups not co-resident
+                    # after all -- another process on the device) leaves a garbage gradient and says so in status[1]
+                    bad = eng.sweep_failed()
+                    if world > 1:
+                        import torch.distributed as dist
+                        fl = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+                        dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=process_group)
+                        bad = bool(int(fl[0]))
+                    if bad:
+                        raise RuntimeError('adjoint sweep: a barrier between workgroups timed out')
                 if world > 1:
                     from .distributed import grad_allreduce
                     grad_allreduce(process_group, dev)(g)     # RCCL on the compute stream (C ABI)

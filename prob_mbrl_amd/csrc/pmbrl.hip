@@ -14,6 +14,7 @@
 #include "pmbrl_mm.h"
 #include "pmbrl_rollout.h"
 #include "pmbrl_mmx.h"
+#include "pmbrl_mm_wide.h"
 #include "pmbrl_fast.h"
 #include "pmbrl_dw.h"
 #include "pmbrl_mlp.h"
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(256) void pm_gradnorm_kernel(const float* __restric
                                                           long long* __restrict__ step) {
   __shared__ double sm[256];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int go = (!status || *status >= expect) ? 1 : 0;
+    // status[0]: steps the forward sweep completed; status[1]: set by the adjoint sweep when one of its barriers
+    // timed out (pmbrl_rollout_bwd) -- the gradient is garbage then, and the step is skipped like a failed rollout
+    const int go = (!status || (status[0] >= expect && status[1] == 0)) ? 1 : 0;
     g_adam_go = go;
     if (go && step) step[0] += 1;
   }
@@ -355,6 +358,31 @@ __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_bwd_kernel(RolloutArgs A,
   } else {
     for (int i = threadIdx.x; i < A.M; i += PM_MM_NW * 64) gdst[i] = gsrc[i];
   }
+}
+
+// wide states (6 < D <= 32), rows of a group staged in LDS (pmbrl_mm_wide.h); the forward leaves the factor block of
+// (step, group) in fac_all for the adjoint
+__global__ __launch_bounds__(PM_MMW_NT) void pm_mmw_fwd_kernel(RolloutArgs A, int t, double* fac_all) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr[];
+  const int gi = blockIdx.x, r0 = gi * A.M;
+  const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
+  const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
+  const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
+  float* out = A.states + ((size_t)(t + 1) * A.B + r0) * A.D;
+  double* fac = fac_all + ((size_t)t * gridDim.x + gi) * pm_mmw_fac_doubles(A.D);
+  const bool ok = pm_mmw_fwd(s, A.M, A.D, zmm, zrow0, A.Bg, out, fac, mmscr);
+  if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
+}
+__global__ __launch_bounds__(PM_MMW_NT) void pm_mmw_bwd_kernel(RolloutArgs A, int t, const double* fac_all) {
+  extern __shared__ __attribute__((aligned(16))) double mmscr[];
+  const int gi = blockIdx.x, r0 = gi * A.M;
+  if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
+  const int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags);
+  const float* zmm = pm_zbase(A.zmm, A.D, t, A.Bg, A.flags);
+  const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
+  float* g = A.gx_carry + (size_t)r0 * A.D;
+  const double* fac = fac_all + ((size_t)t * gridDim.x + gi) * pm_mmw_fac_doubles(A.D);
+  pm_mmw_bwd(s, A.M, A.D, zmm, zrow0, A.Bg, g, g, fac, mmscr);
 }
 
 // ---------------------------------------------------------------------------
@@ -717,6 +745,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->lds_bytes = lds_need(p->RT, 0, 1);
   }
 
+  // wide states between per-step launches: the LDS-staged multi-wave kernels (PMBRL_MM_NO_WIDE: the one-wave routines)
+  p->mm_wide = p->mm_mode == 2 && !p->span && (c.flags & PMBRL_FLAG_MM_STATES) && pm_mmw_ok(p->M, c.D, c.flags) &&
+               !getenv("PMBRL_MM_NO_WIDE");
   HIPCHK(hipSetDevice(device));
   // reward constants
   {
@@ -942,7 +973,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_gmm_k = take(gmm ? (size_t)c.H * c.B * sizeof(int) : 0);
     p->off_xt = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_rt = take((size_t)c.H * c.B * sizeof(float));
-    p->off_mmfac = take(p->mm_mode == 1 ? (size_t)c.H * (c.B / p->M) * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
+    p->off_mmfac = take(p->mm_mode == 1 ? (size_t)c.H * (c.B / p->M) * pm_mm_fac_doubles(c.D) * sizeof(double)
+                        : p->mm_wide    ? (size_t)c.H * p->G * pm_mmw_fac_doubles(c.D) * sizeof(double)
+                                        : 0);
     p->off_Jx = take((size_t)c.H * c.B * c.D * sizeof(float));
     p->off_Ja = take((size_t)c.H * c.B * c.U * sizeof(float));
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
@@ -974,6 +1007,18 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     rc2 = p->prec == PMBRL_PREC_SPLIT_F16 ? pm_fast_split2_set_attr(p) : pm_fast_split1_set_attr(p);
   } else {
     rc2 = pm_fast_f32_set_attr(p);
+  }
+  if (p->mm_wide) {
+    const int smem = (int)pm_mmw_lds_bytes(p->M, c.D, true);
+    if (smem > 64 * 1024 &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mmw_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             smem) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_mmw_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             smem) != hipSuccess)) {
+      (void)hipGetLastError();
+      pmbrl_plan_destroy(p);
+      return fail(-3, "hipFuncSetAttribute(wide moment-matching kernels) failed");
+    }
   }
   if (p->mm_mode == 2 || p->mm_mode == 3) {
     const int smem = (int)(pm_mm_kernel_doubles(c.D) * sizeof(double));
@@ -1357,7 +1402,10 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     for (int t = 0; t < p->cfg.H; ++t) {
       As.t0 = t; As.t1 = t + 1;
       launch_fwd_rt(p, As, s);
-      if (!p->span) {
+      if (p->mm_wide) {
+        hipLaunchKernelGGL(pm_mmw_fwd_kernel, dim3(p->G), dim3(PM_MMW_NT), pm_mmw_lds_bytes(p->M, p->cfg.D, false), s, Am, t,
+                           reinterpret_cast<double*>(ws + p->off_mmfac));
+      } else if (!p->span) {
         hipLaunchKernelGGL(pm_mm_fwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t);
       } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
         // groups spread over ranks: own statistics -> sum over the ranks -> factor + own rows
@@ -1549,7 +1597,10 @@ extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, c
     Am.flags &= ~PMBRL_FLAG_MM_REWARDS;   // rewards already handled above
     A.gx_from_carry = 1;
     for (int t = p->cfg.H - 1; t >= 0; --t) {
-      if (!p->span) {
+      if (p->mm_wide) {
+        hipLaunchKernelGGL(pm_mmw_bwd_kernel, dim3(p->G), dim3(PM_MMW_NT), pm_mmw_lds_bytes(p->M, p->cfg.D, true), s, Am, t,
+                           reinterpret_cast<const double*>(ws + p->off_mmfac));
+      } else if (!p->span) {
         hipLaunchKernelGGL(pm_mm_bwd_kernel, dim3(p->G), dim3(PM_MM_NW * 64), smem, s, Am, t, grt);
       } else if (p->cfg.flags & PMBRL_FLAG_MM_STATES) {
         MmxArgs X = mmx_args(p, ws, false);

@@ -60,13 +60,21 @@ class GradComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         idbuf = C.create_string_buffer(128)
+        box = [None]
         if self.rank == 0:
-            _lib.check(self.lib.pmbrl_comm_unique_id(idbuf), 'pmbrl_comm_unique_id')
-        box = [bytes(idbuf.raw)]
+            # rank 0 ALWAYS takes part in the broadcast below: the id, or the reason it has none -- raising before it
+            # would leave the other ranks waiting in the broadcast while rank 0 moves on to a different collective
+            try:
+                _lib.check(self.lib.pmbrl_comm_unique_id(idbuf), 'pmbrl_comm_unique_id')
+                box = [bytes(idbuf.raw)]
+            except Exception as e:      # noqa: BLE001
+                box = ['error: %s' % e]
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                        group=group)
         self.comm = C.c_void_p()
+        if not isinstance(box[0], bytes):
+            raise RuntimeError('rank 0 could not create the RCCL id (%s)' % box[0])
         _lib.check(self.lib.pmbrl_comm_init(C.c_char_p(box[0]), self.rank, self.world, dev.index or 0,
                                             C.byref(self.comm)), 'pmbrl_comm_init')
 

@@ -420,6 +420,25 @@ class Engine:
         _lib.check(self.lib.pmbrl_plan_set_collective(self.plan, fn, None), 'pmbrl_plan_set_collective')
         self._coll = (group, fn)      # keeps the callback alive as long as the plan may call it
 
+    def any_rank(self, flag):
+        """True on every rank if `flag` is set on any rank of the group attached with attach_collective (collective:
+        every rank calls it).  Lets the ranks that share moment-matching groups take the same decision -- e.g. re-run a
+        rollout on a wider-range arithmetic after ONE of them left fp16's range."""
+        assert self._coll is not None, 'attach_collective() first'
+        group = self._coll[0]
+        v = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=self.device)
+        if callable(group):
+            group(v)
+        else:
+            import torch.distributed as dist
+            if dist.get_backend(group) == 'nccl':
+                dist.all_reduce(v, group=group)
+            else:
+                host = v.cpu()
+                dist.all_reduce(host, group=group)
+                v = host
+        return float(v[0]) > 0.0
+
     # ------------------------------------------------------------------
     def forward(self, x0, pol_flat, dyn_flat, mx, iSx, my, Sy, pol_scale, pol_bias,
                 pol_mask_bits, dyn_mask_bits, z_pol, z_dyn, z_mm=None, z_rr=None, out=None, z_pi=None, u_cat=None):

@@ -209,3 +209,37 @@ class LinearFeatureReward(AnalyticReward):
                     tip_target=self.c.detach().cpu().numpy().astype(np.float64), norm=1.0,
                     w=float(self.weight), Q=self.Q.detach().cpu().numpy().astype(np.float64),
                     R=self.R.detach().cpu().numpy().astype(np.float64))
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped reward modules
+# ---------------------------------------------------------------------------
+# class name of the reference module (envs/<env>/env.py) -> (class here, names of its length parameters)
+_BY_NAME = {
+    'CartpoleReward': (CartpoleReward, ('pole_length',)),
+    'PendulumReward': (PendulumReward, ('pole_length',)),
+    'DoubleCartpoleReward': (DoubleCartpoleReward, ('pole1_length', 'pole2_length')),
+    'CartAcrobotReward': (CartAcrobotReward, ('pole1_length', 'pole2_length')),
+    'RendezvousReward': (RendezvousReward, ()),
+}
+
+
+def from_module(obj):
+    """The analytic reward of this build for a REFERENCE-shaped reward module -- what `env.reward_func` is in the
+    reference's examples (examples/deep_pilco_mm.py:94-99,135): a torch module named after its environment holding
+    the constants of its closed form as parameters (envs/cartpole/env.py:27-40: Q, R, target, pole_length; likewise
+    pendulum, double_cartpole, cart_acrobot, rendezvous).  The constants are read from the module (not assumed), so
+    non-default lengths / weights / targets carry over.  Returns `obj` itself if it already is one of ours, None if
+    it is not a module this build recognises (the caller then treats it as a learned / unknown reward)."""
+    if obj is None or isinstance(obj, AnalyticReward):
+        return obj
+    hit = _BY_NAME.get(type(obj).__name__)
+    if hit is None or not all(hasattr(obj, a) for a in ('Q', 'R') + hit[1]):
+        return None
+    cls, lengths = hit
+    kw = {a: getattr(obj, a).detach().clone() for a in lengths}
+    kw.update(Q=obj.Q.detach().clone(), R=obj.R.detach().clone())
+    if hasattr(obj, 'target') and cls is not RendezvousReward:
+        kw['target'] = obj.target.detach().clone()
+    out = cls(**kw)
+    return out.to(obj.Q.device)

@@ -347,11 +347,15 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
         x0 = states.to(device=bundle.device, dtype=torch.float32)
         S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
         n = bundle.engine.valid_steps()
-        retry = E.safe_precision(bundle.engine.info['precision']) if n < steps else None
+        failed = n < steps
+        if mm_span and E.safe_precision(bundle.engine.info['precision']) is not None:
+            # groups spread over ranks: a rank retrying alone would leave the others inside a collective -- the ranks
+            # agree (every one of them makes this call), and retry together if any of them failed
+            failed = bundle.engine.any_rank(failed)
+        retry = E.safe_precision(bundle.engine.info['precision']) if failed else None
         if retry is None or resample_state_noise or resample_action_noise or (mm_states and z_mm is None) \
-                or resample_model or resample_policy or bundle.gmm or mm_span:
-            break          # (fresh noise was drawn: a retry would be a different rollout; groups spread over ranks:
-            #                 a rank retrying alone would leave the others inside a collective)
+                or resample_model or resample_policy or bundle.gmm:
+            break          # (fresh noise was drawn: a retry would be a different rollout)
         # a failure under fp16 pieces may be their range, not the rollout: decide on the bf16 path
         precision = retry
     if n < steps:

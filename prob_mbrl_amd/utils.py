@@ -19,6 +19,15 @@ def to_complex(x, dims):
     return torch.cat([x[..., others], x[..., dims].sin(), x[..., dims].cos()], -1)
 
 
+def load_csv(s):
+    """utils/core.py:193-197: "200,200" -> [200, 200] (None if it does not parse) -- the argparse type of the
+    examples' --dyn_shape / --pol_shape / --timesteps_to_sample."""
+    try:
+        return [int(d) for d in s.split(',')]
+    except Exception:
+        return None
+
+
 def train_regressor(*args, **kwargs):
     """utils/train_regressor.py:58-165 (see prob_mbrl_amd/train_regressor.py)."""
     from .train_regressor import train_regressor as _tr

@@ -103,6 +103,21 @@ def modules_from_fixture(d, name, device='cuda:0'):
                       dropout_layers=[pm.models.BDropout(0.1) for _ in pol_hid],
                       nonlin=torch.nn.ReLU,
                       output_nonlin=partial(pm.models.DiagGaussianDensity, U)), maxU, -maxU, angle_dims=pad).float()
+    fill_modules(dyn, pol, d)
+    dyn = dyn.to(dev)
+    pol = pol.to(dev)
+    dyn.eval()
+    return dyn, pol
+
+
+def fill_modules(dyn, pol, d):
+    """Copy the fixture's weights, normalisation, frozen masks and noise into reference-shaped modules (on the CPU,
+    before they are moved to the device)."""
+    import prob_mbrl_amd as pm
+    B, D = d['x0'].shape
+    npl, ndl = int(d['pol_n_layers']), int(d['dyn_n_layers'])
+    dyn_hid = [d['dyn_W%d' % i].shape[0] for i in range(ndl - 1)]
+    n_comp = int(d['dyn_gmm_n']) if 'dyn_gmm_n' in d else 0
     T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))  # noqa: E731
     with torch.no_grad():
         for pre, mod, n in (('pol', pol.model, npl), ('dyn', dyn.model, ndl)):
@@ -125,7 +140,3 @@ def modules_from_fixture(d, name, device='cuda:0'):
         for k in ('mx', 'iSx', 'my', 'Sy'):
             getattr(dyn, k).data = T(d['dyn_' + k]).reshape(1, -1)
         dyn.Sx.data = dyn.iSx.reciprocal()
-    dyn = dyn.to(dev)
-    pol = pol.to(dev)
-    dyn.eval()
-    return dyn, pol

@@ -40,6 +40,23 @@ def test_bench_two_ranks_one_device():
     assert out['n_gpus'] == 2 and out['config']['global_rows'] == 2 * out['config']['rows_per_gpu']
     assert out['scaling'] == 'weak' and out['value'] > 0 and out['config']['debug_one_device']
     assert 'cpu_baseline' not in out
+    # both curves in one line: the strong one is BASELINE.json's 100 x 25 rows divided over the ranks
+    st = out['strong']
+    assert st['global_rows'] == 2500 and st['rows_per_gpu'] == [1250, 1250] and st['value'] > 0
+    assert 'rccl_ranks' in out and out['rccl_ranks'] is None      # gloo here: no RCCL communicator to ask
+
+
+def test_bench_three_ranks_uneven_strong_split():
+    """100 moment-matching groups over 3 ranks: 34 / 33 / 33 whole groups (strong curve), 3 x 2500 rows (weak)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '1', '--config', 'cartpole_mm',
+           '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['scaling'] == 'weak' and out['config']['global_rows'] == 7500
+    assert out['strong']['rows_per_gpu'] == [850, 825, 825] and out['strong']['global_rows'] == 2500
 
 
 def test_bench_two_ranks_strong_scaling():
@@ -53,6 +70,7 @@ def test_bench_two_ranks_strong_scaling():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert out['scaling'] == 'strong' and out['config']['global_rows'] == 2500 and out['config']['rows_per_gpu'] == 1250
+    assert out['weak']['global_rows'] == 5000 and out['weak']['value'] > 0
 
 
 def test_bench_two_ranks_one_global_moment_matching_group():
