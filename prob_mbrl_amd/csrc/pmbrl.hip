@@ -370,7 +370,8 @@ __global__ __launch_bounds__(PM_MMW_NT) void pm_mmw_fwd_kernel(RolloutArgs A, in
   const float* s = A.xt + ((size_t)t * A.B + r0) * A.D;
   float* out = A.states + ((size_t)(t + 1) * A.B + r0) * A.D;
   double* fac = fac_all + ((size_t)t * gridDim.x + gi) * pm_mmw_fac_doubles(A.D);
-  const bool ok = pm_mmw_fwd(s, A.M, A.D, zmm, zrow0, A.Bg, out, fac, mmscr);
+  const bool ok = pm_mmw_fwd(s, A.M, A.D, zmm, zrow0, A.Bg, out, fac, mmscr,
+                             (A.prof && gi == 0) ? A.prof + (size_t)t * 32 : nullptr);
   if (!ok && threadIdx.x == 0) atomicMin(A.status, t);
 }
 __global__ __launch_bounds__(PM_MMW_NT) void pm_mmw_bwd_kernel(RolloutArgs A, int t, const double* fac_all) {
