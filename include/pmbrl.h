@@ -186,6 +186,22 @@ int pmbrl_plan_info(const pmbrl_plan* plan, int32_t* info /* [PMBRL_INFO_COUNT] 
 int pmbrl_pack_mask(void* stream, const float* mask_d, int32_t B, int32_t h,
                     int32_t src_ld, uint16_t* bits_d);
 
+/* Dropout masks drawn ON THE DEVICE, as the bit rows the sweeps read (same layout as pmbrl_pack_mask): one launch
+ * for all `rows` = H x B rows of a rollout that resamples its masks at every step (utils/rollout.py:95-98,110-115:
+ * resample_policy / resample_model) or of a resample() between iterations (algorithms/mc_pilco.py:99-105, pegasus=False).
+ *   kind 0  BDropout.update_noise (models/modules.py:40-44):   bit = u < keep[j]
+ *   kind 1  CDropout in eval mode (models/modules.py:95-118):  probs = sigmoid((logit_p[j] + log((u + 1e-7) /
+ *           (1 - (u - 1e-7)))) / temp),  bit = v < probs      (the hard sample of torch.bernoulli(probs))
+ * u, v: 24-bit uniforms of Philox4x32-10 keyed by `seed`, counter (row, unit, stream, offset) -- a draw is a
+ * function of (seed, offset, row, unit) only; advance `offset` between draws under one seed.  param_d: `param_len`
+ * (1 or h) keep probabilities / logits.  u_d / v_d non-NULL: uniforms [rows][h] to use instead (replaying recorded
+ * draws).  aux_*: for rows [aux_row0, aux_row0 + aux_rows) the float uniforms / hard samples / probabilities are
+ * written too ([aux_rows][h] each, any may be NULL) -- a module keeps its last draw as state. */
+int pmbrl_draw_masks(void* stream, int32_t kind, uint64_t seed, uint64_t offset, const float* param_d,
+                     int32_t param_len, float temp, int32_t rows, int32_t h, const float* u_d, const float* v_d,
+                     uint16_t* bits_d, int32_t aux_row0, int32_t aux_rows, float* u_out_d, float* hard_out_d,
+                     float* probs_out_d);
+
 /* Network + noise inputs shared by forward and backward. */
 typedef struct pmbrl_inputs {
   const float* x0_d;          /* [B, D] */

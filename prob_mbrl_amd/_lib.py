@@ -87,7 +87,7 @@ class Inputs(C.Structure):
 EXPORTS = [
     'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
-    'pmbrl_pack_mask', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
+    'pmbrl_pack_mask', 'pmbrl_draw_masks', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
     'pmbrl_weighted_sum', 'pmbrl_weighted_sum_steps', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
@@ -172,6 +172,8 @@ def load():
     lib.pmbrl_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.pmbrl_allreduce_sum.restype = C.c_int
     lib.pmbrl_allreduce_sum.argtypes = [vp, vp, vp, i64]
+    lib.pmbrl_draw_masks.restype = C.c_int
+    lib.pmbrl_draw_masks.argtypes = [vp, i32, C.c_uint64, C.c_uint64, vp, i32, C.c_float, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.pmbrl_comm_count.restype = C.c_int
     lib.pmbrl_comm_count.argtypes = [vp, C.POINTER(i32)]
     lib.pmbrl_comm_destroy.restype = None

@@ -72,6 +72,85 @@ __global__ void pm_pack_mask_kernel(const float* __restrict__ m, int B, int h, i
 }
 __global__ void pm_set_int(int* p, int v) { *p = v; }
 
+// ---------------------------------------------------------------------------
+// Dropout masks drawn on the device (pmbrl_draw_masks): bit rows straight from a counter-based generator.
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the caller's seed; counter = (row, 16-unit tile, quad + 4 * stream,
+// offset): a draw depends on (seed, offset, row, unit) alone, not on the launch shape.  Stream 0: the uniform noise u;
+// stream 1: the uniform the hard Bernoulli sample is thresholded with.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pm_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                          unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct DrawArgs {
+  int kind;              // 0: Bernoulli(keep) -- BDropout.update_noise, models/modules.py:40-44;  1: concrete -- :95-118
+  unsigned long long seed, offset;
+  const float* param;    // kind 0: keep probability; kind 1: logit_p  (param_len 1 or h)
+  int param_len;
+  float temp;
+  int rows, h;
+  const float *u_in, *v_in;     // [rows][h] uniforms to use instead of the generator's (nullptr: generate)
+  uint16_t* bits;        // [rows][ceil(h/16)]
+  int aux_row0, aux_rows;       // rows whose float values are also written (a module keeps its LAST draw as state)
+  float *u_out, *hard_out, *probs_out;   // [aux_rows][h] each, or nullptr
+};
+__global__ __launch_bounds__(256) void pm_draw_masks_kernel(const DrawArgs A) {
+  const int nt = (A.h + 15) / 16;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)A.rows * nt) return;
+  const int r = (int)(i / nt), t = (int)(i - (long long)r * nt);
+  const unsigned k0 = (unsigned)A.seed, k1 = (unsigned)(A.seed >> 32);
+  const unsigned o0 = (unsigned)A.offset, o1 = (unsigned)(A.offset >> 32);
+  unsigned w = 0;
+  const bool aux = r >= A.aux_row0 && r < A.aux_row0 + A.aux_rows;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned ru[4], rv[4];
+    if (!A.u_in) pm_philox((unsigned)r, (unsigned)t, (unsigned)q ^ (o1 << 3), o0, k0, k1, ru);
+    if (A.kind == 1 && !A.v_in) pm_philox((unsigned)r, (unsigned)t, (unsigned)(4 + q) ^ (o1 << 3), o0, k0, k1, rv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = t * 16 + q * 4 + e;
+      if (f >= A.h) continue;
+      const size_t idx = (size_t)r * A.h + f;
+      // 24-bit uniforms in [0, 1) (what torch.rand gives a float tensor)
+      const float u = A.u_in ? A.u_in[idx] : (float)(ru[e] >> 8) * (1.0f / 16777216.0f);
+      const float pr = A.param[A.param_len > 1 ? f : 0];
+      float probs;
+      bool bit;
+      if (A.kind == 0) {
+        probs = pr;
+        bit = u < pr;                                    // torch.bernoulli(p): 1 with probability p
+      } else {
+        // models/modules.py:102-114: probs = sigmoid((logit_p + log((u + 1e-7) / (1 - (u - 1e-7)))) / temp)
+        const float cp = pr + logf((u + 1e-7f) / (1.f - (u - 1e-7f)));
+        probs = 1.f / (1.f + expf(-cp / A.temp));
+        const float v = A.v_in ? A.v_in[idx] : (float)(rv[e] >> 8) * (1.0f / 16777216.0f);
+        bit = v < probs;
+      }
+      if (bit) w |= 1u << (q * 4 + e);
+      if (aux) {
+        const size_t o = (size_t)(r - A.aux_row0) * A.h + f;
+        if (A.u_out) A.u_out[o] = u;
+        if (A.hard_out) A.hard_out[o] = bit ? 1.f : 0.f;
+        if (A.probs_out) A.probs_out[o] = probs;
+      }
+    }
+  }
+  A.bits[i] = (uint16_t)w;
+}
+
 // Small reductions: per-block partial sums in a per-device scratch, finished in FIXED order
 // (bit-reproducible).  The scratch is shared by all calls on a device: calls are expected to
 // be stream-ordered (one optimisation loop per device), like the rest of a plan's work.
@@ -1128,6 +1207,24 @@ extern "C" int pmbrl_pack_mask(void* stream, const float* mask_d, int32_t B, int
   const int n = B * nt;
   hipLaunchKernelGGL(pm_pack_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      mask_d, B, h, src_ld, bits_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmbrl_draw_masks(void* stream, int32_t kind, uint64_t seed, uint64_t offset, const float* param_d,
+                                int32_t param_len, float temp, int32_t rows, int32_t h, const float* u_d, const float* v_d,
+                                uint16_t* bits_d, int32_t aux_row0, int32_t aux_rows, float* u_out_d, float* hard_out_d,
+                                float* probs_out_d) {
+  if (!param_d || !bits_d || rows < 1 || h < 1 || (kind != 0 && kind != 1) || (param_len != 1 && param_len != h) ||
+      aux_row0 < 0 || aux_rows < 0 || aux_row0 + aux_rows > rows)
+    return fail(-1, "bad argument");
+  if (kind == 1 && !(temp > 0.f)) return fail(-1, "concrete dropout needs a positive temperature");
+  DrawArgs A;
+  A.kind = kind; A.seed = seed; A.offset = offset; A.param = param_d; A.param_len = param_len; A.temp = temp;
+  A.rows = rows; A.h = h; A.u_in = u_d; A.v_in = v_d; A.bits = bits_d;
+  A.aux_row0 = aux_row0; A.aux_rows = aux_rows; A.u_out = u_out_d; A.hard_out = hard_out_d; A.probs_out = probs_out_d;
+  const long long n = (long long)rows * ((h + 15) / 16);
+  hipLaunchKernelGGL(pm_draw_masks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
   HIPCHK(hipGetLastError());
   return 0;
 }

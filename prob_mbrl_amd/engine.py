@@ -65,6 +65,27 @@ def pack_mask(mask):
     return bits
 
 
+def draw_masks(kind, seed, offset, param, temp, rows, h, u=None, v=None, aux=None, want=('u', 'hard')):
+    """Dropout masks drawn on the device as bit rows [rows, ceil(h/16)] (pmbrl_draw_masks).  kind: 'bernoulli'
+    (param = keep probabilities) or 'concrete' (param = logit_p, eval-mode hard sample).  aux = (row0, n): also
+    return the float uniforms / hard samples / probabilities of those rows (dict with the names in `want`)."""
+    lib = _lib.load()
+    param = param.detach().reshape(-1).float().contiguous()
+    assert param.is_cuda and param.numel() in (1, h)
+    dev = param.device
+    bits = torch.empty((rows, (h + 15) // 16), dtype=torch.int16, device=dev)
+    a0, an = aux if aux is not None else (0, 0)
+    outs = {k: (torch.empty((an, h), dtype=torch.float32, device=dev) if (an and k in want) else None)
+            for k in ('u', 'hard', 'probs')}
+    for t in (u, v):
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (rows, h))
+    _lib.check(lib.pmbrl_draw_masks(_stream(), 0 if kind == 'bernoulli' else 1, int(seed) & (2**64 - 1),
+                                    int(offset) & (2**64 - 1), _ptr(param), param.numel(), float(temp), rows, h,
+                                    _ptr(u), _ptr(v), _ptr(bits), a0, an, _ptr(outs['u']), _ptr(outs['hard']),
+                                    _ptr(outs['probs'])), 'pmbrl_draw_masks')
+    return bits, outs
+
+
 class _MlpCall:
     """Marshalled arguments of one stand-alone network evaluation (kept alive for the backward)."""
 

@@ -97,6 +97,16 @@ class BDropout(StochasticModule):
             return torch.bernoulli(self.p.expand(B, width).to(self.noise.device))
         return self.noise[:B]
 
+    def step_mask_bits(self, H, B, width):
+        """Bit rows [H * B, ceil(width/16)] of H fresh masks -- what a rollout with resample=True at every step
+        applies (models/modules.py:55-58: drawn, not stored) -- from ONE device launch (pmbrl_draw_masks) instead of
+        H x (rand, compare, pack) eager launches.  The counter-based generator is keyed from torch's CPU generator,
+        so torch.manual_seed makes the draw reproducible; it is not the draw torch.bernoulli would have made."""
+        from . import engine as E
+        seed = int(torch.randint(0, 2**62, (1,)))
+        bits, _ = E.draw_masks('bernoulli', seed, 0, (1 - self.rate).to(self.noise.device), 0.0, H * B, width)
+        return bits
+
     def forward(self, x, resample=True, mask_dims=2, seed=None, **kwargs):
         raise NotImplementedError(
             'a dropout layer is not evaluated on its own on the device path; call the network '
@@ -171,6 +181,25 @@ class CDropout(BDropout):
         if self.training or resampled:
             self.update_concrete_noise(noise)
         return self.concrete_noise.detach()[:B]
+
+    def step_mask_bits(self, H, B, width):
+        """H fresh eval-mode masks as bit rows, one device launch (see BDropout.step_mask_bits): new uniform noise and
+        a hard sample of its concrete probabilities per step (models/modules.py:134-139,155-157).  Like the reference,
+        the module is left holding the LAST step's noise and sample."""
+        if self.training:
+            raise NotImplementedError('training-mode (relaxed) concrete dropout is not on the rollout path; call '
+                                      'dynamics.eval() like mc_pilco does')
+        from . import engine as E
+        seed = int(torch.randint(0, 2**62, (1,)))
+        lp = self.logit_p.detach()
+        if lp.numel() not in (1, width):
+            raise ValueError('logit_p has %d entries for a layer of width %d' % (lp.numel(), width))
+        bits, aux = E.draw_masks('concrete', seed, 0, lp, float(self.temp), H * B, width, aux=((H - 1) * B, B))
+        self.noise.data = aux['u']
+        self.concrete_noise = aux['hard']
+        self._mask_gen = getattr(self, '_mask_gen', 0) + 1
+        self.p = self.logit_p.sigmoid()
+        return bits
 
     def hard_mask(self, B, width):
         if self.training:

@@ -178,9 +178,9 @@ class Bundle:
         def step_masks(dr, w):
             """A fresh mask per time step (resample=True in the module's forward: models/modules.py:55-58 for
             Bernoulli dropout -- drawn and not stored --, :134-139,155-157 for concrete dropout in eval mode --
-            new uniform noise, a hard sample of its concrete probabilities, stored), bit-packed [H * B, nt]."""
-            ms = torch.stack([dr.forward_mask(B, w, resample=True) for _ in range(H)])
-            return E.pack_mask(ms.reshape(H * B, w).float().contiguous())
+            new uniform noise, a hard sample of its concrete probabilities, stored), bit rows [H * B, nt] drawn by
+            one device launch (pmbrl_draw_masks)."""
+            return dr.step_mask_bits(H, B, w)
 
         for i, dr in enumerate(pdrop):
             w = self.pol_dims[i + 1]

@@ -31,12 +31,14 @@ def test_rollout_resamples_masks_every_step(monkeypatch):
     queues = {id(pol.model.drop0): list(d['pol_mask0']), id(pol.model.drop1): list(d['pol_mask1']),
               id(dyn.model.drop0): list(d['dyn_mask0']), id(dyn.model.drop1): list(d['dyn_mask1'])}
 
-    def fake(self, B, width, resample=False, seed=None):
-        assert resample
-        return torch.tensor(queues[id(self)].pop(0), device=DEV)
+    def fake(self, H_, B, width):
+        # the recorded draws of all H steps, packed the way the device draw (pmbrl_draw_masks) hands them over
+        from prob_mbrl_amd import engine as E
+        ms = torch.stack([torch.tensor(queues[id(self)].pop(0), device=DEV) for _ in range(H_)])
+        return E.pack_mask(ms.reshape(H_ * B, width).float().contiguous())
 
-    monkeypatch.setattr(pm.models.BDropout, 'forward_mask', fake)
-    monkeypatch.setattr(pm.models.CDropout, 'forward_mask', fake)
+    monkeypatch.setattr(pm.models.BDropout, 'step_mask_bits', fake)
+    monkeypatch.setattr(pm.models.CDropout, 'step_mask_bits', fake)
     states, actions, rewards = pm.utils.rollout(x0, dyn, pol, H, resample_model=True, resample_policy=True,
                                                 resample_state_noise=False, resample_action_noise=False)
     assert all(len(q) == 0 for q in queues.values())

@@ -495,3 +495,95 @@ def test_rccl_allreduce_through_the_c_abi(dev):
     torch.cuda.synchronize()
     assert torch.equal(g, want)
     lib.pmbrl_comm_destroy(comm)
+
+
+# ---------------------------------------------------------------------------
+# dropout masks drawn on the device (pmbrl_draw_masks)
+# ---------------------------------------------------------------------------
+def _unpack(bits, h):
+    b = bits.cpu().numpy().view(np.uint16)
+    out = np.unpackbits(b.view(np.uint8).reshape(b.shape[0], -1), axis=1, bitorder='little')
+    return out[:, :h]
+
+
+def test_draw_masks_formula_on_the_references_recorded_uniforms(dev):
+    """Fixture draw_dropout: the reference's own CDropout.update_noise / BDropout.update_noise calls (uniforms u, the
+    probabilities it handed to torch.bernoulli, the hard samples it kept).  With its u the kernel must form the same
+    probabilities (models/modules.py:102-114), and with threshold uniforms on the recorded side of them, the same bits."""
+    import os
+    from prob_mbrl_amd import engine as E
+    d = np.load(os.path.join(common.GOLDEN, 'draw_dropout.npz'))
+    B, h = int(d['B']), int(d['h'])
+    for k in range(2):
+        u = torch.tensor(d['u%d' % k], device=dev).contiguous()
+        probs, hard = d['probs%d' % k].astype(np.float64), d['hard%d' % k].astype(bool)
+        v = torch.tensor(np.where(hard, 0.5 * probs, 0.5 * (1.0 + probs)).astype(np.float32), device=dev)
+        bits, aux = E.draw_masks('concrete', 0, 0, torch.tensor(d['logit_p%d' % k], device=dev), float(d['temp%d' % k]),
+                                 B, h, u=u, v=v, aux=(0, B), want=('u', 'hard', 'probs'))
+        assert np.allclose(aux['probs'].cpu().numpy(), probs, rtol=2e-5, atol=1e-7)
+        assert np.array_equal(_unpack(bits, h).astype(bool), hard)
+        assert np.array_equal(aux['hard'].cpu().numpy().astype(bool), hard) and torch.equal(aux['u'], u)
+    keep = 1.0 - d['b_rate'].astype(np.float64)
+    hb = d['hardb'].astype(bool)
+    u = torch.tensor(np.where(hb, 0.5 * keep, 0.5 * (1.0 + keep)).astype(np.float32), device=dev).expand(B, h).contiguous()
+    bits, _ = E.draw_masks('bernoulli', 0, 0, torch.tensor(keep.astype(np.float32), device=dev), 0.0, B, h, u=u)
+    assert np.array_equal(_unpack(bits, h).astype(bool), hb)
+
+
+def test_draw_masks_distribution_and_reproducibility(dev):
+    """The generator's own draws: per-unit frequencies against the probabilities (Bernoulli: keep; concrete: the mean
+    of torch's own draw of the same formula), 4 sigma; no correlation between neighbouring units or rows; a draw is
+    a function of (seed, offset) -- same again, different with another offset, independent of how many rows are asked."""
+    from prob_mbrl_amd import engine as E
+    rows, h = 8192, 200
+    keep = torch.tensor([0.9], device=dev)
+    b0, _ = E.draw_masks('bernoulli', 1234, 0, keep, 0.0, rows, h)
+    b1, _ = E.draw_masks('bernoulli', 1234, 0, keep, 0.0, rows, h)
+    b2, _ = E.draw_masks('bernoulli', 1234, 1, keep, 0.0, rows, h)
+    b3, _ = E.draw_masks('bernoulli', 1234, 0, keep, 0.0, 100, h)
+    assert torch.equal(b0, b1) and not torch.equal(b0, b2) and torch.equal(b0[:100], b3)
+    m = _unpack(b0, h).astype(np.float64)
+    sig = np.sqrt(0.9 * 0.1 / rows)
+    assert np.all(np.abs(m.mean(0) - 0.9) < 4.5 * sig) and abs(m.mean() - 0.9) < 4 * sig / np.sqrt(h)
+    c = m - m.mean(0)
+    assert abs((c[:, :-1] * c[:, 1:]).mean()) < 4 * 0.09 / np.sqrt(rows * (h - 1))      # neighbouring units
+    assert abs((c[:-1] * c[1:]).mean()) < 4 * 0.09 / np.sqrt((rows - 1) * h)             # neighbouring rows
+    # concrete dropout: per-unit logits, temperature 0.1
+    g = torch.Generator().manual_seed(5)
+    logit = (torch.randn(h, generator=g) * 1.5 + 1.0).to(dev)
+    bits, aux = E.draw_masks('concrete', 77, 3, logit, 0.1, rows, h, aux=(0, rows), want=('u', 'hard', 'probs'))
+    hard = _unpack(bits, h).astype(np.float64)
+    assert np.array_equal(hard, aux['hard'].cpu().numpy())
+    u = aux['u']
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 4 / np.sqrt(12.0 * rows * h)
+    probs_t = (((logit + ((u + 1e-7) / (1 - (u - 1e-7))).log()) / 0.1).sigmoid())
+    assert torch.allclose(aux['probs'], probs_t, rtol=2e-5, atol=1e-7)
+    p_unit = probs_t.double().mean(0).cpu().numpy()
+    sd = np.sqrt(np.maximum(p_unit * (1 - p_unit), 1e-4) / rows)
+    assert np.all(np.abs(hard.mean(0) - p_unit) < 5 * sd)
+    # ... and torch's own draw of the same thing has the same per-unit frequencies
+    ut = torch.rand(rows, h, device=dev)
+    ht = torch.bernoulli(((logit + ((ut + 1e-7) / (1 - (ut - 1e-7))).log()) / 0.1).sigmoid()).double().mean(0).cpu().numpy()
+    assert np.all(np.abs(hard.mean(0) - ht) < 7 * sd)
+
+
+def test_rollout_with_per_step_masks_uses_the_device_draw(dev):
+    """utils.rollout(resample_model=True, resample_policy=True): one pmbrl_draw_masks launch per dropout layer; masks
+    differ from step to step, the run is reproducible under torch.manual_seed, and the concrete-dropout modules are
+    left holding the last step's noise and hard sample (models/modules.py:134-139,155-157)."""
+    import prob_mbrl_amd as pm
+    d = common.load('nomm_d4')
+    dyn, pol = common.modules_from_fixture(d, 'nomm_d4', 'cuda:0')
+    x0 = torch.tensor(d['x0'], device=dev)
+    H, B = int(d['H']), x0.shape[0]
+    kw = dict(resample_model=True, resample_policy=True, resample_state_noise=False, resample_action_noise=False)
+    torch.manual_seed(11)
+    S1, _, _ = pm.utils.rollout(x0, dyn, pol, H, **kw)
+    n1, c1 = dyn.model.drop0.noise.clone(), dyn.model.drop0.concrete_noise.clone()
+    torch.manual_seed(11)
+    S2, _, _ = pm.utils.rollout(x0, dyn, pol, H, **kw)
+    S3, _, _ = pm.utils.rollout(x0, dyn, pol, H, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(S1, S2)) and not torch.equal(S1[-1], S3[-1])
+    assert torch.isfinite(torch.stack(S3)).all()
+    assert n1.shape == (B, dyn.model.drop0.logit_p.numel()) and set(np.unique(c1.cpu().numpy())) <= {0.0, 1.0}
+    assert torch.equal(n1, dyn.model.drop0.noise) is False       # (the third rollout drew new noise)
