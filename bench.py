@@ -52,6 +52,8 @@ def parse():
                          "reference examples' default) -- per-step statistics exchange between the ranks; weak scaling only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-twin', action='store_true', help='N = 1: skip the exact-fp32 leg')
+    ap.add_argument('--no-fused-tail', action='store_true',
+                    help='N = 1: separate loss / dW-reduce / norm / Adam launches (what N > 1 runs around its all-reduce)')
     ap.add_argument('--no-second-curve', action='store_true', help='N > 1: skip the other scaling curve')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
@@ -183,9 +185,22 @@ class Leg:
         self.v = torch.zeros_like(self.params)
         self.loss_buf = torch.zeros(1, device=dev)
         self.n = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        # one process: the iteration is two library calls (the loss reduction is queued by the forward call, clip + Adam
+        # by the backward call: pmbrl_plan_set_loss, pmbrl_rollout_bwd_adam); with a gradient all-reduce between the dW
+        # reduction and the optimiser (N > 1) the separate calls
+        self.fused = world == 1 and not a.no_fused_tail
+        if self.fused:
+            self.eng.set_loss(self.gw, self.loss_buf)
+            self.adam = dict(params=self.params, exp_avg=self.m, exp_avg_sq=self.v, step=self.step_dev, lr=1e-4,
+                             betas=(0.9, 0.999), eps=1e-8, max_norm=1.0)
 
     def step(self):
         self.n += 1
+        if self.fused:
+            self.eng.forward(**self.args)
+            self.eng.backward(self.gw, adam=self.adam)
+            return
         _, _, R = self.eng.forward(**self.args)
         self.eng.weighted_sum(R, self.gw, out=self.loss_buf)
         g, _, _ = self.eng.backward(self.gw)
@@ -217,6 +232,8 @@ class Leg:
             dt = float(tt.item())
         assert self.eng.valid_steps() == self.H, 'numerical failure inside the benchmark rollout'
         assert bool(torch.isfinite(self.params).all()) and bool(torch.isfinite(self.loss_buf).all())
+        if self.fused:      # every optimiser step was taken (the device-side counter says so)
+            assert int(self.step_dev.item()) == self.n, (int(self.step_dev.item()), self.n)
         return dt
 
     def kernel_ms(self, n):

@@ -304,6 +304,30 @@ int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* grads_d,
                             double eps, double max_norm, float* norm_out_d,
                             const int32_t* status_d, int32_t expect);
 
+/* ---- fused iteration tail (one process; with a gradient all-reduce in between use the separate calls) -------------
+ * pmbrl_plan_set_loss: dL/dr weights [H][B] (device, resident; algorithms/mc_pilco.py:134-144: +-gamma_t / B) -- every
+ * pmbrl_rollout_fwd on the plan then also leaves sum_{t < valid, b} w r in *loss_out_d (the reduction of
+ * pmbrl_weighted_sum_steps, queued by the forward call itself); NULL switches it off.
+ * pmbrl_rollout_bwd_adam: pmbrl_rollout_bwd followed by clip_grad_norm_ + Adam.step as pmbrl_clip_adam_guarded defines
+ * them (taken on the device only if the rollout completed `expect_steps` steps and the adjoint reported no failure), in
+ * one call: the whole tail of an iteration is queued without returning to the host language.  status_d: int32[2],
+ * required. */
+typedef struct pmbrl_adam {
+  float* params_d;        /* flat policy parameters (the vector pmbrl_inputs::pol_params_d points at) */
+  float* exp_avg_d;
+  float* exp_avg_sq_d;
+  int64_t* step_d;        /* device-side step counter, advanced when the step is taken */
+  double lr, beta1, beta2, eps, max_norm;   /* max_norm <= 0: no clipping */
+  float* norm_out_d;      /* optional: the gradient norm before clipping */
+  int32_t expect_steps;   /* the step is taken if the rollout completed at least this many steps (0: H) */
+} pmbrl_adam;
+int pmbrl_plan_set_loss(pmbrl_plan* plan, const float* loss_weights_d, float* loss_out_d);
+int pmbrl_rollout_bwd_adam(pmbrl_plan* plan, void* stream, void* workspace_d, const pmbrl_inputs* in,
+                           const float* states_d, const float* actions_d, const float* rewards_d,
+                           const float* grad_rewards_d, const float* grad_states_d, const float* grad_actions_d,
+                           float* grad_pol_flat_d, float* grad_x0_d, float* action_grad_norms_d, int32_t* status_d,
+                           const pmbrl_adam* opt);
+
 /* ---- gradient all-reduce over xGMI (RCCL) ---------------------------------- */
 /* The one collective of the sharded path: the sum of the flat policy gradient over the
  * ranks, in place, issued on the caller's stream right behind pmbrl_rollout_bwd -- no host round

@@ -87,7 +87,8 @@ class Inputs(C.Structure):
 EXPORTS = [
     'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
-    'pmbrl_pack_mask', 'pmbrl_draw_masks', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd',
+    'pmbrl_pack_mask', 'pmbrl_draw_masks', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd', 'pmbrl_rollout_bwd_adam',
+    'pmbrl_plan_set_loss',
     'pmbrl_weighted_sum', 'pmbrl_weighted_sum_steps', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
@@ -96,6 +97,13 @@ EXPORTS = [
     'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_count', 'pmbrl_comm_destroy',
     'pmbrl_plan_set_comm', 'pmbrl_plan_set_collective',
 ]
+
+class Adam(C.Structure):
+    """pmbrl_adam (include/pmbrl.h): the optimiser state pmbrl_rollout_bwd_adam updates."""
+    _fields_ = [('params_d', C.c_void_p), ('exp_avg_d', C.c_void_p), ('exp_avg_sq_d', C.c_void_p),
+                ('step_d', C.c_void_p), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('eps', C.c_double), ('max_norm', C.c_double), ('norm_out_d', C.c_void_p), ('expect_steps', C.c_int32)]
+
 
 _lib = None
 
@@ -172,6 +180,10 @@ def load():
     lib.pmbrl_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.pmbrl_allreduce_sum.restype = C.c_int
     lib.pmbrl_allreduce_sum.argtypes = [vp, vp, vp, i64]
+    lib.pmbrl_plan_set_loss.restype = C.c_int
+    lib.pmbrl_plan_set_loss.argtypes = [vp, vp, vp]
+    lib.pmbrl_rollout_bwd_adam.restype = C.c_int
+    lib.pmbrl_rollout_bwd_adam.argtypes = [vp, vp, vp, C.POINTER(Inputs)] + [vp] * 10 + [C.POINTER(Adam)]
     lib.pmbrl_draw_masks.restype = C.c_int
     lib.pmbrl_draw_masks.argtypes = [vp, i32, C.c_uint64, C.c_uint64, vp, i32, C.c_float, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.pmbrl_comm_count.restype = C.c_int

@@ -263,10 +263,12 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 pipe['ev'][k].record()
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
                 loss = eng.weighted_sum(R, gw)[0]
-                g, _, _ = eng.backward(gw)
                 grp = cache['group']
-                E.clip_adam_guarded(bundle.pol_flat, g, cache['m'], cache['v'], pipe['step_dev'], grp['lr'],
-                                    eng.status, min_steps, grp['betas'], grp['eps'], max_norm=clip_grad)
+                # adjoint sweep, dW GEMM, then reduction + global norm + clip + Adam as one launch, taken on the device
+                # only if the rollout completed (pmbrl_rollout_bwd_adam)
+                eng.backward(gw, adam=dict(params=bundle.pol_flat, exp_avg=cache['m'], exp_avg_sq=cache['v'],
+                                           step=pipe['step_dev'], lr=grp['lr'], betas=grp['betas'], eps=grp['eps'],
+                                           max_norm=clip_grad, expect=min_steps))
                 pending = (i, pipe['ev'][k], pipe['snap'][k], loss, S, A, R)
                 queued = True
             else:

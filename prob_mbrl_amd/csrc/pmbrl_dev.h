@@ -469,3 +469,15 @@ __device__ __forceinline__ float softplusf(float x) {
   return x > 20.f ? x : log1pf(expf(x));
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// block-wide sum in a fixed order (sm: blockDim.x doubles of LDS); contains barriers
+__device__ __forceinline__ double pm_block_sum(double s, double* sm) {
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  return sm[0];
+}
+

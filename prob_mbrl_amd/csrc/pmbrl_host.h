@@ -57,6 +57,9 @@ struct pmbrl_plan {
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
       off_gxc, off_gxc2, off_gsync, off_grt, off_Jx, off_Ja, off_gmm_c, off_gmm_k, ws_bytes;
+  const float* loss_w;   // pmbrl_plan_set_loss: dL/dr [H][B]; the forward call also leaves the loss in *loss_out
+  float* loss_out;
+
   int mm_grid;   // mm_mode 3 as one launch per sweep with a device-wide barrier per step
   // moment-matching groups spread over ranks (pmbrl_config.mm_span_rows; mm_mode 2 with the statistics exchanged
   // through `coll` between the two halves of the external moment matching, pmbrl_mmx.h)

@@ -543,8 +543,21 @@ class Engine:
         moment-matching group spanning workgroups timed out)?"""
         return int(self.status[1].item()) != 0
 
+    def set_loss(self, weights, out=None):
+        """dL/dr weights [H, B] kept resident: every forward() then also leaves sum_{t < valid, b} w r in the returned
+        one-element tensor (pmbrl_plan_set_loss: the reduction is queued by the forward call).  None switches it off."""
+        if weights is None:
+            _lib.check(self.lib.pmbrl_plan_set_loss(self.plan, None, None), 'pmbrl_plan_set_loss')
+            self._loss = None
+            return None
+        w = _f32c(weights.reshape(self.H, self.B), self.device)
+        out = out if out is not None else torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pmbrl_plan_set_loss(self.plan, _ptr(w), _ptr(out)), 'pmbrl_plan_set_loss')
+        self._loss = (w, out)      # keeps both alive as long as the plan may use them
+        return out
+
     def backward(self, grad_rewards, grad_states=None, grad_actions=None, want_x0=False,
-                 want_agn=False):
+                 want_agn=False, adam=None):
         assert self._inputs is not None, 'forward() first'
         dev = self.device
         gr = _f32c(grad_rewards.reshape(self.H, self.B), dev)
@@ -559,6 +572,24 @@ class Engine:
         S, A, R = self._traj
         # the status word makes the adjoint cover exactly the steps the forward sweep completed
         # (truncated horizon, utils/rollout.py:154-157), decided on the device
+        if adam is not None:
+            # the optimiser step in the same call (pmbrl_rollout_bwd_adam): adam = dict(params, exp_avg, exp_avg_sq,
+            # step (device int64), lr, betas, eps, max_norm, [norm_out], [expect])
+            for k in ('params', 'exp_avg', 'exp_avg_sq'):
+                t = adam[k]
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.n_pol_params
+            assert adam['step'].is_cuda and adam['step'].dtype == torch.int64
+            o = _lib.Adam(adam['params'].data_ptr(), adam['exp_avg'].data_ptr(), adam['exp_avg_sq'].data_ptr(),
+                          adam['step'].data_ptr(), float(adam['lr']), float(adam['betas'][0]), float(adam['betas'][1]),
+                          float(adam['eps']), float(adam.get('max_norm') or 0.0),
+                          adam['norm_out'].data_ptr() if adam.get('norm_out') is not None else None,
+                          int(adam.get('expect') or 0))
+            _lib.check(self.lib.pmbrl_rollout_bwd_adam(self.plan, _stream(), self._ws_ptr,
+                                                       C.byref(self._inputs), _ptr(S), _ptr(A), _ptr(R), _ptr(gr),
+                                                       _ptr(gs), _ptr(ga), _ptr(self.grad_flat), _ptr(gx0),
+                                                       _ptr(agn), _ptr(self.status), C.byref(o)),
+                       'pmbrl_rollout_bwd_adam')
+            return self.grad_flat, gx0, agn
         _lib.check(self.lib.pmbrl_rollout_bwd(self.plan, _stream(), self._ws_ptr,
                                               C.byref(self._inputs), _ptr(S), _ptr(A), _ptr(R), _ptr(gr),
                                               _ptr(gs), _ptr(ga), _ptr(self.grad_flat), _ptr(gx0),

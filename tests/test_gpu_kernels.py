@@ -587,3 +587,57 @@ def test_rollout_with_per_step_masks_uses_the_device_draw(dev):
     assert torch.isfinite(torch.stack(S3)).all()
     assert n1.shape == (B, dyn.model.drop0.logit_p.numel()) and set(np.unique(c1.cpu().numpy())) <= {0.0, 1.0}
     assert torch.equal(n1, dyn.model.drop0.noise) is False       # (the third rollout drew new noise)
+
+
+# ---------------------------------------------------------------------------
+# fused iteration tail (pmbrl_plan_set_loss, pmbrl_rollout_bwd_adam)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('name,generic', [('nomm_d4', False), ('mmg_d4', False), ('full200_nomm', False), ('nomm_d5', True)])
+def test_fused_tail_matches_the_separate_launches(dev, name, generic):
+    """The iteration tail queued by two calls (pmbrl_plan_set_loss: the loss behind the forward call;
+    pmbrl_rollout_bwd_adam: adjoint, dW, clip and the device-guarded Adam) against the separate calls (weighted_sum,
+    backward, clip_adam): the same loss and clipped gradient, parameters and moments to rounding, over three iterations;
+    a rollout marked as failed leaves parameters, moments and the step counter alone."""
+    from prob_mbrl_amd import engine as E
+    d = common.load(name)
+    B = d['x0'].shape[0]
+    gw = torch.tensor(common.loss_weights(d, B), device=dev)
+
+    def run(fused):
+        eng, args, _ = common.engine_from_fixture(d, dev, force_generic=generic)
+        p = args['pol_flat'].clone()
+        args['pol_flat'] = p
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        step = torch.zeros(1, dtype=torch.int64, device=dev)
+        norm = torch.zeros(1, device=dev)
+        out = []
+        loss_buf = eng.set_loss(gw) if fused else torch.zeros(1, device=dev)
+        for it in range(1, 4):
+            _, _, R = eng.forward(**args)
+            if fused:
+                g, _, _ = eng.backward(gw, adam=dict(params=p, exp_avg=m, exp_avg_sq=v, step=step, lr=1e-3,
+                                                     betas=(0.9, 0.999), eps=1e-8, max_norm=0.05, norm_out=norm))
+            else:
+                eng.weighted_sum(R, gw, out=loss_buf)
+                g, _, _ = eng.backward(gw)
+                E.clip_adam(p, g, m, v, it, 1e-3, max_norm=0.05, norm_out=norm)
+            out.append((float(loss_buf), float(norm), g.clone(), p.clone(), m.clone(), v.clone()))
+        return eng, args, (p, m, v, step), out
+
+    _, _, _, ref = run(False)
+    eng, args, (p, m, v, step), got = run(True)
+    assert int(step.item()) == 3
+    for a, b in zip(ref, got):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-4 * a[1]
+        # (the guarded form takes its bias corrections from the device-side step counter -- device pow() against the
+        #  host's, equal to rounding -- so from the second iteration on the parameters differ in the last bits)
+        for x, y in zip(a[2:], b[2:]):
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-5 * float(x.abs().max()))
+    assert torch.equal(ref[0][2], got[0][2])    # first iteration, same parameters: the same kernels, the same bits
+    # a failed rollout: the status word says step 3 of H failed -> nothing moves
+    eng.forward(**args)
+    eng.status[0] = 3
+    before = (p.clone(), m.clone(), v.clone())
+    eng.backward(gw, adam=dict(params=p, exp_avg=m, exp_avg_sq=v, step=step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                               max_norm=0.05))
+    assert int(step.item()) == 3 and all(torch.equal(x, y) for x, y in zip(before, (p, m, v)))
