@@ -150,7 +150,8 @@ def test_prob_mbrl_import_alias():
     import sys
     code = ('import sys; sys.path[:0] = [%r, %r]; '
             'from prob_mbrl import utils, models, algorithms; import prob_mbrl.models as m; '
-            'import prob_mbrl_amd.models as a; assert m is a and hasattr(utils, "rollout") and '
+            'import prob_mbrl_amd.models as a; assert m.DynamicsModel is a.DynamicsModel and '
+            'm.modules.CDropout is a.CDropout and hasattr(utils, "rollout") and '
             'hasattr(algorithms, "mc_pilco") and hasattr(models, "DynamicsModel")'
             % (os.path.join(ROOT, 'compat'), ROOT))
     assert subprocess.run([sys.executable, '-c', code]).returncode == 0
