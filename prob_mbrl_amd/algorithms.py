@@ -102,8 +102,6 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     `frozen_noise` -- dict(z_mm=..., z_rr=...) to inject captured PEGASUS noise (tests);
     `progress` -- print the reference's tqdm-style line every 50 iterations."""
     global policy_update_counter, x0_tree, episode_counter
-    if (value_func is not None or prioritized_replay) and process_group is not None:
-        raise NotImplementedError('value_func / prioritized_replay run on the single-process path')
     if prioritized_replay and x0_tree is None:
         from .experience import SumTree
         x0_tree = SumTree(2**20)
@@ -169,7 +167,8 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     replay = None
     if prioritized_replay:      # algorithms/mc_pilco.py:80-84
         replay = dict(idxs=None, weights=None, beta=init_priority_beta, eps=priority_eps,
-                      alpha=priority_alpha, tree=x0_tree, N=N_particles)
+                      alpha=priority_alpha, tree=x0_tree, N=N_particles, world=world, rank=rank,
+                      group=process_group)
     gamma_full = [float(disc(i)) for i in range(H)]
     sign = -1.0 if maximize else 1.0
 
@@ -250,7 +249,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 loss, states, actions, rewards = _autograd_iteration(
                     x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups, z_mm,
                     z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i, rk,
-                    process_group, world, value_func, replay)
+                    process_group, world, value_func, replay, dist_kw)
             elif pipelined:
                 eng = bundle.engine
                 if pipe['step_dev'] is None:
@@ -306,9 +305,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     # row) order, the quantile is the one process' quantile, every rank keeps its own rows' mask
                     gcol = torch.tensor(gamma_full[:n_valid], dtype=torch.float32, device=dev)
                     ret = sign * (R[:n_valid, :, 0] * gcol[:, None]).sum(0)
-                    parts = [None] * world
-                    dist.all_gather_object(parts, ret.cpu().numpy(), group=process_group)
-                    rd = np.concatenate(parts)
+                    rd = _gather_rows(ret, process_group, world).cpu().numpy()
                     if cvar_eps > 0:
                         q = np.quantile(rd, cvar_eps)
                         sel, n_sel = ret < float(q), int((rd < q).sum())
@@ -386,10 +383,17 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                             x0_tree.append(x, x0_tree.max_p)
                             x0_tree.renormalize()
                     episode_counter = exp.n_episodes()
-                xs, replay['idxs'], w = x0_tree.sample(n_draw, beta=replay['beta'])
+                # sharded run: every rank holds the same tree and draws the same GLOBAL sample (numpy's generator:
+                # seed it alike on every rank, as one process would be seeded once), then keeps its slice of the
+                # start states and importance weights; the priorities of the whole sample are updated on every
+                # rank from the gathered norms (_update_priorities), so the replicas of the tree stay identical
+                xs, replay['idxs'], w = x0_tree.sample(n_draw * world, beta=replay['beta'])
                 # (sic) max, not min: beta never drops below 1 (mc_pilco.py:240-241)
                 replay['beta'] = max(1.0, replay['beta'] + priority_beta_increase)
-                x0 = torch.stack([torch.as_tensor(x) for x in xs]).to(dev, torch.float32)
+                lo_r, hi_r = rank * n_draw, (rank + 1) * n_draw
+                x0 = torch.stack([torch.as_tensor(x) for x in xs[lo_r:hi_r]]).to(dev, torch.float32)
+                # (the reference multiplies the [B, 1] returns with the [B] weights -- a [B, B] product, mc_pilco.py:156-158:
+                #  every row meets the weights of ALL sampled states, so a rank keeps the whole weight vector)
                 replay['weights'] = torch.as_tensor(np.stack(w)).to(dev, torch.float32)
             else:
                 x0 = exp.sample_states(n_draw, timestep=step_idx_to_sample).to(dev, torch.float32)
@@ -407,6 +411,19 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     policy.eval()
     dynamics.eval()
     policy_update_counter[policy] = n_opt_steps
+
+
+def _gather_rows(t, group, world):
+    """The rows of every rank's `t` ([n, ...], the same n on every rank) in rank order, on every rank -- a tensor
+    collective (no pickling, no host round trip beyond what the backend needs)."""
+    import torch.distributed as dist
+    parts = [torch.empty_like(t) for _ in range(world)]
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather(parts, t.contiguous(), group=group)
+        return torch.cat(parts, 0)
+    host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]     # (gloo groups: the CPU-transport tests)
+    dist.all_gather(host, t.detach().cpu().contiguous(), group=group)
+    return torch.cat(host, 0).to(t.device)
 
 
 _GW_CACHE = {}
@@ -430,8 +447,11 @@ def _update_priorities(replay, m_norms, mm_groups):
     particles (mc_pilco.py:163-182; the reference collects the same norms with tensor hooks on
     actions[t], here they are an output of the adjoint sweep)."""
     tree, idxs = replay['tree'], replay['idxs']
+    world = replay.get('world', 1)
+    if world > 1:      # [H, B_local] -> [H, B_global] in rank (= row) order
+        m_norms = _gather_rows(m_norms.t().contiguous(), replay['group'], world).t()
     if mm_groups is not None:
-        m_norms = m_norms.reshape(-1, mm_groups, int(replay['N'] / mm_groups)).mean(-1)
+        m_norms = m_norms.reshape(-1, mm_groups * world, int(replay['N'] / mm_groups)).mean(-1)
     scores = m_norms.mean(0).detach().cpu().numpy() / tree.counts[idxs - tree.max_size + 1]
     priorities = (scores + replay['eps'])**replay['alpha']
     for idx, p in zip(idxs, priorities):
@@ -441,11 +461,15 @@ def _update_priorities(replay, m_norms, mm_groups):
 
 def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups,
                         z_mm, z_rr, maximize, clip_grad, cvar_eps, reg_weight, disc, on_rollout, i,
-                        rollout_kwargs, process_group, world, value_func=None, replay=None):
-    """The reference loop body on top of the single-node autograd rollout."""
+                        rollout_kwargs, process_group, world, value_func=None, replay=None, dist_kw=None):
+    """The reference loop body on top of the autograd rollout.  On a sharded run (world > 1) this rank's rows are a
+    slice of one global batch: the loss is the mean over the GLOBAL batch (CVaR: over the rows its global quantile
+    keeps), the flat gradient is summed over the ranks before the clip, the regulariser -- a function of the
+    replicated parameters -- counts once."""
+    dkw = {}
     if world > 1:
-        raise NotImplementedError('sharded runs use the fused path (plain Adam; no value function, prioritised '
-                                  'replay or rollout_kwargs)')
+        import torch.distributed as dist
+        dkw = {k: v for k, v in (dist_kw or {}).items() if v is not None}
     policy.zero_grad()
     opt.zero_grad()
     weighted = replay is not None and replay['idxs'] is not None
@@ -454,7 +478,7 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
         x0_, dynamics, policy, H, resample_state_noise=not pegasus,
         resample_action_noise=not pegasus, mm_states=mm_states, mm_rewards=mm_rewards,
         z_mm=z_mm if pegasus else None, z_rr=z_rr if pegasus else None, mm_groups=mm_groups,
-        action_grad_norms_out=norms_out, **rollout_kwargs)
+        action_grad_norms_out=norms_out, **dkw, **rollout_kwargs)
     if callable(on_rollout):
         on_rollout(i, states, actions, rewards, disc)
     discounted = torch.stack([r * disc(t) for t, r in enumerate(rewards)])
@@ -464,22 +488,42 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
         Vend = value_func(states[-1], resample=False, return_samples=True)
         discounted = torch.cat([discounted, disc(H) * Vend.unsqueeze(0)], 0)
     returns = -discounted.sum(0) if maximize else discounted.sum(0)
+    n_global = returns.shape[0] * world
     if cvar_eps > -1.0 and cvar_eps < 1.0 and cvar_eps != 0:
         rd = returns.detach()
+        rd_all = (_gather_rows(rd, process_group, world) if world > 1 else rd).cpu().numpy()
         if cvar_eps > 0:
-            q = np.quantile(rd.cpu().numpy(), cvar_eps)
-            returns = returns[rd < q]
+            q = np.quantile(rd_all, cvar_eps)
+            returns, n_global = returns[rd < q], int((rd_all < q).sum())
         else:
-            q = np.quantile(rd.cpu().numpy(), -cvar_eps)
-            returns = returns[rd > q]
+            q = np.quantile(rd_all, -cvar_eps)
+            returns, n_global = returns[rd > q], int((rd_all > q).sum())
     if weighted:
         # importance-sampling weights, broadcast exactly as the reference does ([B,1] * [n],
         # mc_pilco.py:156-158)
         returns = returns * replay['weights']
-    loss = returns.mean()
-    if reg_weight > 0:
-        loss = loss + reg_weight * policy.regularization_loss()
-    loss.backward()
+    if world == 1:
+        loss = returns.mean()
+        if reg_weight > 0:
+            loss = loss + reg_weight * policy.regularization_loss()
+        loss.backward()
+    else:
+        if weighted and returns.dim() == 2:
+            n_global = n_global * returns.shape[1]     # (the reference's [B, 1] * [B] broadcast: a mean over [B, B])
+        loss = returns.sum() / max(n_global, 1)
+        if reg_weight > 0:
+            loss = loss + (reg_weight / world) * policy.regularization_loss()
+        loss.backward()
+        from .distributed import grad_allreduce
+        params = [p for p in policy.parameters() if p.requires_grad]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        tot = torch.cat([flat, loss.detach().reshape(1)])
+        grad_allreduce(process_group, tot.device)(tot)
+        off = 0
+        for p in params:
+            p.grad = tot[off:off + p.numel()].reshape(p.shape).clone()
+            off += p.numel()
+        loss = tot[-1]
     if weighted:
         _update_priorities(replay, norms_out[0][:len(actions)], mm_groups)
     if clip_grad is not None:
