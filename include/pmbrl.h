@@ -151,6 +151,24 @@ typedef struct pmbrl_config {
   int32_t mm_span_ranks, mm_span_rank; /* ranks a group is spread over and this rank's index among them */
 } pmbrl_config;
 
+/* Environment switches read by pmbrl_plan_create (and by nothing else in the library).  They select between code paths
+ * that compute the same results -- the tests use them to hold a non-default path against the default one, the profiles to
+ * time alternatives -- and are not needed for normal use: what they override is chosen from the configuration.
+ *   PMBRL_FORCE_F32=1       exact-fp32 MFMA sweeps whatever pmbrl_config.precision says
+ *   PMBRL_MM_PARTS=n        moment-matching groups split over n workgroups where that can be done (1: whole groups)
+ *   PMBRL_MM_MODE2=1        groups that span workgroups: separate moment-matching kernels between per-step launches
+ *                           instead of the in-sweep form (mm_mode 3)
+ *   PMBRL_MM_PERSTEP=1      mm_mode 3 as one launch per step instead of one launch with a device-wide barrier per step
+ *   PMBRL_MM_NO_SPAN1=1     a group beyond the CU count keeps the per-step prologue form instead of the one-rank span form
+ *   PMBRL_MM_NO_WIDE=1      states wider than 6: the one-wave moment-matching routines instead of the LDS-staged
+ *                           multi-wave kernels (pmbrl_mm_wide.h)
+ *   PMBRL_DW_F32=1          dW GEMM on fp32 MFMA on a split-precision plan;  PMBRL_DW_SPLIT=1: the opposite
+ *   PMBRL_DW_NO_WIDE=1      no LDS-staged tile kernel for layers >= PMBRL_DW_WIDE_MIN (default 128) wide
+ *   PMBRL_DW_NO_LAYER13=1   no whole-layer-per-workgroup kernel for a <= 13 x 13-tile layer
+ *   PMBRL_DW_PIPE=off | n0,n1,...   dW GEMM behind the adjoint sweep on a second stream: never / these step ranges
+ * Read by the Python layer: PMBRL_PRECISION (default arithmetic: f32 | split | split_f16), PMBRL_LIB_PATH (the shared
+ * library to load), PMBRL_TORCH_ALLREDUCE=1 (gradient all-reduce through torch.distributed instead of the C ABI). */
+
 typedef struct pmbrl_plan pmbrl_plan;
 
 /* plan->info indices for pmbrl_plan_info */
