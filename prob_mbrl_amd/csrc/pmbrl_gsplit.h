@@ -151,9 +151,67 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
   }
 }
 
+// Layers with K <= 64 (n_kb <= 2 K32 blocks): the first layers (state / [state | action] -> hidden) and the adjoints
+// of the heads (2D / 2U -> hidden).  The ring above is built for long K loops: at n_kb = 1 it issues seven chunk loads
+// per tile group of which one is used and drains them all before the epilogue -- two exposed memory round trips per
+// group, two groups per wave, 14-21 k cycles for a layer whose MFMAs take 0.4 k (profiles/r03a_phase_prof_stress32_mm.txt:
+// 21 + 18 k forward, 14 + 17 k adjoint of a 435 k-cycle step at the C5 shape).  Here a wave takes FOUR tiles at once:
+// every weight fragment and every epilogue operand of the group is requested up front, one round trip, then the MFMAs
+// and the epilogues.
+template <int RT, int NT, bool F16, class Epi>
+__device__ __forceinline__ void gemm_tiles_group_small_s(const float* __restrict__ wf, int n_kb, int ot0, int n_ot,
+                                                         const float* buf_in, unsigned ldb, int lane, Epi& epi) {
+  typedef PmPairs<2> PP;
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  f32x4 acc[NT][RT];
+  f32x4 a[NT][2][2];
+  typename Epi::Pre pre[NT][RT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int ot = ot0 + k * PM_NW < n_ot ? ot0 + k * PM_NW : ot0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kb = c < n_kb ? c : 0;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a[k][c][p] = ldg4(wf + (((size_t)ot * n_kb + kb) * 2 + p) * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pre[k][rt] = epi.pre(ot, rt);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c < n_kb) {
+      BQ<RT, 2> b;
+      bq_load<RT, 2>(b, lb, ldb, c);
+#pragma unroll
+      for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[k][rt] = pm_mfma_bf<F16>(a[k][c][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (ot0 + k * PM_NW < n_ot) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt], pre[k][rt]);
+    }
+  }
+}
+
 template <int RT, bool F16, class Epi>
 __device__ __forceinline__ void gemm_tiles_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* buf_in,
                                              unsigned ldb, int wid, int lane, Epi& epi) {
+  if (n_kb <= 2) {
+    constexpr int NTS = RT <= 2 ? 4 : 2;
+    for (int ot0 = wid; ot0 < n_ot; ot0 += NTS * PM_NW)
+      gemm_tiles_group_small_s<RT, NTS, F16>(wf, n_kb, ot0, n_ot, buf_in, ldb, lane, epi);
+    return;
+  }
   constexpr int NT = 2;
   for (int ot0 = wid; ot0 < n_ot; ot0 += NT * PM_NW)
     gemm_tiles_group_s<RT, NT, F16>(wf, n_kb, ot0, n_ot, buf_in, ldb, lane, epi);

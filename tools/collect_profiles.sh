@@ -12,17 +12,17 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py > $O/bench_cartpole_nomm.json 2>$O/bench.err
 # 2. kernel trace + stats of the same command (shorter run, no CPU leg)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- \
-  python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2>$O/kt.err
+  python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-twin > $O/bench_under_rocprof.json 2>$O/kt.err
 # 3. HBM traffic counters, one pass each
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- \
-  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --timing-steps 1 > /dev/null 2>$O/pf.err
+  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-twin --timing-steps 1 > /dev/null 2>$O/pf.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- \
-  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --timing-steps 1 > /dev/null 2>$O/pw.err
+  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-twin --timing-steps 1 > /dev/null 2>$O/pw.err
 # 4. in-kernel cycle stamps, the other configurations, the neighbouring paths
 timeout 120 python $R/tools/phase_prof.py > $O/phase_prof.txt 2>/dev/null
-for c in cartpole_mm dcartpole_mm stress32; do timeout 120 python $R/tools/phase_prof.py $c > $O/phase_prof_$c.txt 2>/dev/null; done
-for c in cartpole_mm dcartpole_mm stress32; do
-  timeout 300 python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null
+for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do timeout 120 python $R/tools/phase_prof.py $c > $O/phase_prof_$c.txt 2>/dev/null; done
+for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
+  timeout 300 python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-f32-twin > $O/bench_$c.json 2>/dev/null
 done
 timeout 300 python $R/tools/bench_bnn.py > $O/bench_bnn.json 2>/dev/null
 timeout 300 python $R/tools/mcp_speed.py > $O/mcp_speed.txt 2>/dev/null
