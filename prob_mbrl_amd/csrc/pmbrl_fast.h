@@ -1729,9 +1729,11 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       // them then matches the moments of the WHOLE group (redundantly: the d x d chain is serial anyway) and
       // keeps its own rows
       if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(t - T0 + 1)) && tid == 0) atomicMin(A.status, t);
+      PF_MARK(28);
       const float* xg = A.xt + ((size_t)t * B + mmp_g0) * D;
       for (int i = tid; i < A.M * D; i += PF_NT) mmg[i] = pm_ldc<true>(xg + i);
       __syncthreads();
+      PF_MARK(29);
       if (wid == 0) {
         bool ok = false;
         double* fac = wg == mmp_first ? A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D) : nullptr;
@@ -1743,6 +1745,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         if (!ok && lane == 0) atomicMin(A.status, t);
       }
       __syncthreads();
+      PF_MARK(30);
       const float* res = mmg + 2 * A.M * D + (row0 - mmp_g0) * D;
       for (int i = tid; i < nvalid * D; i += PF_NT) {
         xa[i] = res[i];
