@@ -673,7 +673,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
                                 p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? p->M : 0) * sizeof(float);
     }
-    return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd) * sizeof(float);
+    return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd, p->inplace != 0) * sizeof(float);
   };
   p->G = 1;
   p->M = c.B;
@@ -768,6 +768,23 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       if (!p->fast && RT == 1 && (c.B + 31) / 32 >= 512) RT = 2;
     }
     while (RT > 1 && lds_need(RT, 0) > lds_cap) RT /= 2;
+    // General family on split operands: 64-row workgroups with IN-PLACE layers (one activation buffer, pmbrl_gsplit.h:
+    // gemm_layer_inplace_s) where two buffers of 64 rows do not fit the LDS.  Built to stream a 512 x 512 layer's weights
+    // once per 64 rows instead of once per 32; measured at the C5 shape (profiles/r03b_inplace_*): a hidden layer's K loop
+    // does become MFMA-bound (25 k cycles per 64 rows), but with every wave's epilogues behind one barrier they no
+    // longer overlap another wave's MFMAs (+36 k), and the stash stores of a policy layer, issued back to back, cost
+    // 26 k cycles more -- 46.7 ms per iteration against 45.3 ms for the two-buffer 32-row form.  So it is taken only
+    // on request (rows_per_wg_hint >= 64): widths <= 512, every narrow width (2U, 2D, D + U) <= 64, no mixture head,
+    // no angle features.
+    if (gsplit && !angles && !gmm && maxnt <= 32 && 2 * c.D <= PM_IP_NOFF && 2 * c.U <= PM_IP_NOFF &&
+        c.D + c.U <= PM_IP_NOFF && RT < 4) {
+      const bool want = c.rows_per_wg_hint >= 64;
+      if (want) {
+        p->inplace = 1;
+        if (lds_need(4, 0) <= lds_cap) RT = 4;
+        else p->inplace = 0;
+      }
+    }
     p->RT = RT;
     p->rows_per_wg = 16 * RT;
   } else if (c.rows_per_wg_hint > 0 && p->mm_parts <= 1) {

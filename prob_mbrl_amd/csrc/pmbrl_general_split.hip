@@ -13,6 +13,13 @@ static int set_attr_gs(size_t lds) {
   return 0;
 }
 int pm_general_split_set_attr(const pmbrl_plan* p) {
+  if (p->inplace) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<4, 2, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    return 0;
+  }
   switch (p->RT) {
     case 1: return set_attr_gs<1>(p->lds_bytes);
     case 2: return set_attr_gs<2>(p->lds_bytes);
@@ -25,6 +32,11 @@ static void launch_gs(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, 
   else hipLaunchKernelGGL((pm_rollout_bwd<RT, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 void pm_general_split_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  if (p->inplace) {
+    if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, true>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, true>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    return;
+  }
   switch (p->RT) {
     case 1: launch_gs<1>(p, A, s, fwd); break;
     case 2: launch_gs<2>(p, A, s, fwd); break;

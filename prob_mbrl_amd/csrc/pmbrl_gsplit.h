@@ -217,6 +217,103 @@ __device__ __forceinline__ void gemm_tiles_s(const float* __restrict__ wf, int n
     gemm_tiles_group_s<RT, NT, F16>(wf, n_kb, ot0, n_ot, buf_in, ldb, lane, epi);
 }
 
+// ---------------------------------------------------------------------------
+// IN-PLACE layers: the output overwrites the input buffer.  A wave keeps ALL its output tiles (NT tiles x RT row
+// tiles) in accumulators over the whole K loop, the workgroup meets once every wave has read the input, and only
+// then do the epilogues write.  One activation buffer instead of two is what lets a workgroup hold 64 rows of a
+// 512-wide layer in LDS (135 KB) -- and 64 rows per weight fetch is what the wide sweeps are bound by: at 32 rows a
+// 512 x 512 layer streams its 1 MB of weight pieces at the ~30 B/clk a CU pulls from L2 and the matrix pipe idles
+// two thirds of the time.
+// Contains a barrier: called by all waves, also those without a tile.
+// ---------------------------------------------------------------------------
+template <int RT, int NT, bool F16, class Epi>
+__device__ __forceinline__ void gemm_tiles_inplace_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* buf,
+                                                     unsigned ldb, int wid, int lane, Epi& epi) {
+  typedef PmPairs<2> PP;
+  const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
+  const int ot0 = wid;
+  f32x4 acc[NT][RT];
+  const float* wp[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int ot = ot0 + k * PM_NW;
+    wp[k] = wf + ((size_t)(ot < n_ot ? ot : (ot0 < n_ot ? ot0 : 0)) * n_kb) * 512 + lane * 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  typename Epi::Pre pre[NT][RT];
+  if (ot0 < n_ot) {
+    GsFrag<NT> f0, f1;
+    constexpr int NLD = NT * 2;   // loads per one-block chunk
+    auto load = [&](GsFrag<NT>& f, int kb0) {
+      const int kb = kb0 < n_kb ? kb0 : 0;   // past the end: a harmless re-load of block 0
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const float* q = wp[k] + (size_t)kb * 512;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(f.a[k][0][0]) : "v"(q));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"(f.a[k][0][1]) : "v"(q));
+      }
+    };
+    auto compute = [&](GsFrag<NT>& f, int kb0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD));      // this chunk has landed: the younger one may be out
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(f.a[k][0][p]));
+      if (kb0 < n_kb) {
+        BQ<RT, 2> b;
+        bq_load<RT, 2>(b, lb, ldb, kb0);
+#pragma unroll
+        for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+          for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt]);
+      }
+    };
+    // two one-block chunks (NT x 2 KB each): one feeds the MFMAs while the other is in flight
+    load(f0, 0);
+    for (int kb0 = 0; kb0 < n_kb; kb0 += 2) {
+      load(f1, kb0 + 1);
+      compute(f0, kb0);
+      load(f0, kb0 + 2);
+      compute(f1, kb0 + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(f0.a[k][0][p]));
+    // the epilogues' HBM / L2 operands (bias, dropout / activity bits): requested now, in flight across the barrier
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const int ot = ot0 + k * PM_NW < n_ot ? ot0 + k * PM_NW : ot0;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) pre[k][rt] = epi.pre(ot, rt);
+    }
+  }
+  __syncthreads();          // every wave has read its last operand: the buffer may be overwritten
+  if (ot0 < n_ot) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      if (ot0 + k * PM_NW < n_ot) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt], pre[k][rt]);
+      }
+    }
+  }
+}
+
+// a layer of up to 4 * PM_NW output tiles in place: four tiles per wave, or one where the layer is narrow
+template <int RT, bool F16, class Epi>
+__device__ __forceinline__ void gemm_layer_inplace_s(const float* __restrict__ wf, int n_ot, int n_kb, const float* buf,
+                                                     unsigned ldb, int wid, int lane, Epi& epi) {
+  if (n_ot <= PM_NW) gemm_tiles_inplace_s<RT, 1, F16>(wf, n_ot, n_kb, buf, ldb, wid, lane, epi);
+  else if (n_ot <= 2 * PM_NW) gemm_tiles_inplace_s<RT, 2, F16>(wf, n_ot, n_kb, buf, ldb, wid, lane, epi);
+  else gemm_tiles_inplace_s<RT, 4, F16>(wf, n_ot, n_kb, buf, ldb, wid, lane, epi);
+}
+
 // K-split GEMM for narrow outputs (see gemm_ksplit): every wave reduces its slice of K32 blocks for all
 // output tiles; partial tiles in the layout gemm_ksplit_combine() reads.
 template <int RT, bool F16>

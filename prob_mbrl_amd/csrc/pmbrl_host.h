@@ -67,6 +67,7 @@ struct pmbrl_plan {
   size_t off_mmx_buf, off_mmx_fac, off_mmx_rfac;
   int (*coll)(void* ctx, void* stream, double* buf_d, int64_t n);
   void* coll_ctx;
+  int inplace;   // general family on split operands: 64-row workgroups with in-place layers (pm_rollout_fwd<4, 2, true>)
   int mm_wide;   // mm_mode 2 through the LDS-staged kernels for 6 < D <= 32 (pmbrl_mm_wide.h)
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
   // optional per-kernel timing (hipEvents on the caller's stream)

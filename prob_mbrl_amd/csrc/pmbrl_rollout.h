@@ -231,21 +231,23 @@ struct LdsMap {
   float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr, *part;
   double* mm;
 };
-__host__ __device__ inline size_t pm_lds_floats(int R, int LD, int D, int U, int RT, int mm_d) {
-  size_t n = 2 * (size_t)R * LD;          // bufA, bufB
+// ip: in-place layers (gemm_layer_inplace_s) -- ONE activation buffer, narrow GEMM outputs at column PM_IP_NOFF of it
+#define PM_IP_NOFF 64
+__host__ __device__ inline size_t pm_lds_floats(int R, int LD, int D, int U, int RT, int mm_d, bool ip = false) {
+  size_t n = (ip ? 1 : 2) * (size_t)R * LD;          // bufA, bufB
   n += 2 * (size_t)R * D;                 // xa, xb
   n += (size_t)R * U;                     // av
   n += (size_t)R * 16;                    // gad (action gradient, U <= 16)
   n += 2 * (size_t)R;                     // rr, gr
-  if (!pm_part_alias_ok(R, LD, RT)) n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials (else: in the output buffer)
+  if (!ip && !pm_part_alias_ok(R, LD, RT)) n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials (else: in the output buffer)
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);  // per-wave fp64 scratch
   return n;
 }
-__device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, int RT) {
+__device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, int RT, bool ip = false) {
   LdsMap m;
   m.bufA = base;
-  m.bufB = m.bufA + (size_t)R * LD;
+  m.bufB = ip ? m.bufA : m.bufA + (size_t)R * LD;
   m.xa = m.bufB + (size_t)R * LD;
   m.xb = m.xa + (size_t)R * D;
   m.av = m.xb + (size_t)R * D;
@@ -254,7 +256,7 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
   m.gr = m.rr + R;
   m.part = m.gr + R;
   size_t n = (size_t)(m.part - base);
-  if (pm_part_alias_ok(R, LD, RT)) m.part = nullptr;
+  if (ip || pm_part_alias_ok(R, LD, RT)) m.part = nullptr;
   else n += (size_t)PM_NW * PM_KS_NT * RT * 256;
   n = (n + 3) & ~(size_t)3;
   m.mm = reinterpret_cast<double*>(base + n);
@@ -265,7 +267,8 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
 // forward
 // ===========================================================================
 // PR = 0: exact fp32 MFMA; PR = 2: split operands (pmbrl_gsplit.h) -- two fp16 pieces
-template <int RT, int PR = 0>
+// IP: in-place layers (PR = 2 only; widths <= 512, narrow widths <= PM_IP_NOFF, no mixture head)
+template <int RT, int PR = 0, bool IP = false>
 __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   const int row0 = wg * A.rows_per_wg;
   const int nvalid = min(A.rows_per_wg, A.B - row0);
   const int D = A.D, U = A.U, LD = A.LD, B = A.B;
-  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT);
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP);
   float* xa = L.xa;   // current state x_t
   float* xb = L.xb;   // pre-moment-matching next state
   // PR = 2: set when an activation leaves fp16's range (the action-gradient rows are idle in the forward sweep)
@@ -336,17 +339,24 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     for (int l = 0; l < P.nl - 1; ++l) {
       const int nt = P.nt[l + 1];
       const uint16_t* mk = P.mask[l] + ((A.flags & PMBRL_FLAG_POL_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
-      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], Y,
+      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], IP ? X : Y,
                                         A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane,
                                         p_ovf};
-      if constexpr (SP) gemm_tiles_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
+      if constexpr (IP) gemm_layer_inplace_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
+      else if constexpr (SP) gemm_tiles_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(2 + l);
-      float* tmp = X; X = Y; Y = tmp;
+      if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
     // ---- policy head -> Y[r][0..2U)
-    if constexpr (SP)
+    if constexpr (IP) {
+      // fp32 rows at column PM_IP_NOFF of the one buffer: clear of the 64 plane columns the next phase writes
+      Y = X + PM_IP_NOFF;
+      EpiPlain e{P.bias[P.nl - 1], Y, LD, lane};
+      gemm_layer_inplace_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
+      __syncthreads();
+    } else if constexpr (SP)
       gemm_narrow_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), P.bias[P.nl - 1], X, LDB, Y, LD,
                               L.part, wid, lane, tid);
     else
@@ -400,16 +410,22 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     for (int l = 0; l < F.nl - 1; ++l) {
       const int nt = F.nt[l + 1];
       const uint16_t* mk = F.mask[l] + ((A.flags & PMBRL_FLAG_DYN_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
-      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], Y,
+      EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], IP ? X : Y,
                                         nullptr, LD, A.Rw, row0, nvalid, nt, lane, p_ovf};
-      if constexpr (SP) gemm_tiles_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
+      if constexpr (IP) gemm_layer_inplace_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
+      else if constexpr (SP) gemm_tiles_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(12 + l);
-      float* tmp = X; X = Y; Y = tmp;
+      if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
     // ---- dynamics head -> Y[r][0..2D)
-    if constexpr (SP)
+    if constexpr (IP) {
+      Y = X + PM_IP_NOFF;
+      EpiPlain e{F.bias[F.nl - 1], Y, LD, lane};
+      gemm_layer_inplace_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
+      __syncthreads();
+    } else if constexpr (SP)
       gemm_narrow_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), F.bias[F.nl - 1], X, LDB, Y, LD,
                               L.part, wid, lane, tid);
     else
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
 // dW GEMM; policy dW/db are NOT accumulated here.
 // ===========================================================================
 // (PR = 2: two bf16 pieces -- the adjoint is linear in the incoming gradient, profiles/r02_split_precision_study.txt)
-template <int RT, int PR = 0>
+template <int RT, int PR = 0, bool IP = false>
 __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
   const int row0 = wg * A.rows_per_wg;
   const int nvalid = min(A.rows_per_wg, A.B - row0);
   const int D = A.D, U = A.U, LD = A.LD, B = A.B;
-  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT);
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP);
   float* gx = L.xa;    // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;   // dL/dx~ (pre-mm next state)
   const NetDev& P = A.pol;
@@ -720,16 +736,22 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     // ---- dynamics trunk, dX only (weights frozen: no dV)
     for (int l = F.nl - 1; l >= 1; --l) {
       const int nt = F.nt[l];
-      EpiHiddenBwdT<SP ? 2 : 0, R> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], Y, nullptr, LD, A.Rw,
+      EpiHiddenBwdT<SP ? 2 : 0, R> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], IP ? X : Y, nullptr, LD, A.Rw,
                                     row0, nvalid, nt, lane};
-      if constexpr (SP) gemm_tiles_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
+      if constexpr (IP) gemm_layer_inplace_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
+      else if constexpr (SP) gemm_tiles_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(4 + l);
-      float* tmp = X; X = Y; Y = tmp;
+      if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
     // grad wrt normalised dynamics input [x | a] -> Y[r][0..D+U)
-    if constexpr (SP)
+    if constexpr (IP) {
+      Y = X + PM_IP_NOFF;
+      EpiPlain e{nullptr, Y, LD, lane};
+      gemm_layer_inplace_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
+      __syncthreads();
+    } else if constexpr (SP)
       gemm_narrow_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);
     else
       gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
@@ -802,15 +824,21 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     // ---- policy trunk: dX chain + G stash
     for (int l = P.nl - 1; l >= 1; --l) {
       const int nt = P.nt[l];
-      EpiHiddenBwdT<SP ? 2 : 0, R> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], Y,
+      EpiHiddenBwdT<SP ? 2 : 0, R> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], IP ? X : Y,
                                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      if constexpr (SP) gemm_tiles_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
+      if constexpr (IP) gemm_layer_inplace_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
+      else if constexpr (SP) gemm_tiles_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
       __syncthreads();
       PM_MARK(14 + l);
-      float* tmp = X; X = Y; Y = tmp;
+      if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
-    if constexpr (SP)
+    if constexpr (IP) {
+      Y = X + PM_IP_NOFF;
+      EpiPlain e{nullptr, Y, LD, lane};
+      gemm_layer_inplace_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
+      __syncthreads();
+    } else if constexpr (SP)
       gemm_narrow_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);
     else
       gemm_narrow<RT>(P.wb[0], P.nt[0], P.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);

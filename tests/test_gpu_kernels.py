@@ -641,3 +641,24 @@ def test_fused_tail_matches_the_separate_launches(dev, name, generic):
     eng.backward(gw, adam=dict(params=p, exp_avg=m, exp_avg_sq=v, step=step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                                max_norm=0.05))
     assert int(step.item()) == 3 and all(torch.equal(x, y) for x, y in zip(before, (p, m, v)))
+
+
+@pytest.mark.parametrize('name', ['c5_small', 'c5_mm_small'])
+def test_in_place_layers_at_64_rows_per_workgroup(dev, name):
+    """General family on split operands with rows_per_wg_hint = 64 at 3 x 512: ONE activation buffer, every layer
+    written in place after the workgroup has read it (pmbrl_gsplit.h: gemm_layer_inplace_s; the two-buffer form does
+    not fit 64 rows in LDS).  Same fixtures from the reference, same tolerances, and agreement with the 16-row form."""
+    d = common.load(name)
+    B = d['x0'].shape[0]
+    gw = torch.tensor(common.loss_weights(d, B), device=dev)
+    out = []
+    for hint in (0, 64):
+        eng, args, _ = common.engine_from_fixture(d, dev, rows_per_wg_hint=hint, force_generic=True)
+        S, A, Rw = eng.forward(**args)
+        g = eng.backward(gw)[0].cpu().numpy().copy()
+        assert eng.valid_steps() == int(d['H'])
+        out.append((eng.info['rows_per_wg'], eng.info['lds_bytes'], S.cpu().numpy(), g))
+    assert out[0][0] == 16 and out[1][0] == 64 and out[1][1] < 160 * 1024
+    for _, _, S, g in out:
+        assert common.rel(S, d['ref64_states']) < TOL_TRAJ and common.rel(g, d['ref64_grad']) < TOL_GRAD
+    assert common.rel(out[1][2], out[0][2]) < 1e-6 and common.rel(out[1][3], out[0][3]) < 1e-5
