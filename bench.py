@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--timing-steps', type=int, default=10)
     # debugging aids for the N>1 control flow on a box with ONE GPU (tests/test_gpu_api.py):
     # every rank on cuda:0, collectives over gloo.  Never used for a reported number.
+    ap.add_argument('--transport', default='rccl', choices=['rccl', 'p2p'],
+                    help='N > 1: gradient all-reduce / statistics exchange through RCCL (default) or the one-shot '
+                         'peer-to-peer transport of pmbrl_p2p.hip (PMBRL_P2P=1; ranks on one node)')
     ap.add_argument('--dist-backend', default='nccl')
     ap.add_argument('--one-device', action='store_true')
     return ap.parse_args()
@@ -332,6 +335,8 @@ def main():
     torch.cuda.set_device(dev)
 
     allreduce, rccl_ranks = None, None
+    if a.transport == 'p2p':
+        os.environ['PMBRL_P2P'] = '1'
     if world > 1:
         from prob_mbrl_amd.distributed import get_comm, grad_allreduce
         allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI, on the compute stream
@@ -427,7 +432,9 @@ def main():
             roofline=roof)
         if world > 1:
             out['rccl_ranks'] = rccl_ranks
-            out['collective'] = ('RCCL ncclAllReduce through the C ABI on the compute stream' if rccl_ranks else
+            out['collective'] = ('one-shot peer-to-peer all-reduce (pmbrl_p2p.hip, IPC-mapped slots) on the compute stream'
+                                 if a.transport == 'p2p' else
+                                 'RCCL ncclAllReduce through the C ABI on the compute stream' if rccl_ranks else
                                  'torch.distributed all_reduce (backend %s)' % a.dist_backend)
         out.update(extra)
         if world == 1 and not a.no_cpu_baseline:

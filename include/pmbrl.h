@@ -377,6 +377,28 @@ typedef int (*pmbrl_collective_fn)(void* ctx, void* stream, double* buf_d, int64
 int pmbrl_plan_set_comm(pmbrl_plan* plan, pmbrl_comm* comm);
 int pmbrl_plan_set_collective(pmbrl_plan* plan, pmbrl_collective_fn fn, void* ctx);
 
+/* ---- one-shot peer-to-peer all-reduce for latency-bound messages (pmbrl_p2p.hip) -------------------------------
+ * The per-step statistics of moment-matching groups spread over ranks (a few KB, 2 H + 2 times per iteration) and the
+ * flat policy gradient (163 KiB) are latency-, not bandwidth-bound: a ring pays 2 (N - 1) hops.  Here every rank writes
+ * its contribution into a slot of every peer's buffer (stores through IPC-mapped pointers: xGMI between GPUs), raises
+ * a flag per peer, waits for its own N flags and adds the N slots in rank order -- one hop, the same bits on every rank,
+ * one kernel per rank on the caller's stream.  Setup: every rank creates its object (one uncached device allocation
+ * sized for messages of up to max_bytes), exports a 64-byte handle (hipIpcGetMemHandle), the launcher carries the
+ * handles to all ranks by any channel, every rank opens every peer's.  Ranks may be processes on different GPUs of
+ * one node, or on ONE GPU (how the tests run it).  Waits are bounded: pmbrl_p2p_error reports a peer that never
+ * arrived.  pmbrl_plan_set_p2p attaches it as the statistics exchange of a plan (like pmbrl_plan_set_comm). */
+#define PMBRL_P2P_HANDLE_BYTES 64
+#define PMBRL_P2P_MAX_RANKS 16
+typedef struct pmbrl_p2p pmbrl_p2p;
+int pmbrl_p2p_create(int32_t rank, int32_t nranks, int32_t device, int64_t max_bytes, pmbrl_p2p** out);
+int pmbrl_p2p_handle(pmbrl_p2p* p, void* handle_out /* host, PMBRL_P2P_HANDLE_BYTES */);
+int pmbrl_p2p_open(pmbrl_p2p* p, int32_t peer, const void* handle /* host, PMBRL_P2P_HANDLE_BYTES */);
+int pmbrl_p2p_allreduce_f32(pmbrl_p2p* p, void* stream, float* buf_d, int64_t n);    /* in place */
+int pmbrl_p2p_allreduce_f64(pmbrl_p2p* p, void* stream, double* buf_d, int64_t n);
+int pmbrl_plan_set_p2p(pmbrl_plan* plan, pmbrl_p2p* p);
+int pmbrl_p2p_error(pmbrl_p2p* p, int32_t* err_out);   /* host sync; 1: a wait timed out since the last call */
+void pmbrl_p2p_destroy(pmbrl_p2p* p);
+
 /* Optional per-kernel timing for bench.py's roofline line: when enabled, the
  * library brackets its kernels with hipEvents on the caller's stream;
  * pmbrl_plan_read_timing waits for them and returns the last call's durations

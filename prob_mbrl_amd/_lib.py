@@ -96,6 +96,8 @@ EXPORTS = [
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
     'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_count', 'pmbrl_comm_destroy',
     'pmbrl_plan_set_comm', 'pmbrl_plan_set_collective',
+    'pmbrl_p2p_create', 'pmbrl_p2p_handle', 'pmbrl_p2p_open', 'pmbrl_p2p_allreduce_f32', 'pmbrl_p2p_allreduce_f64',
+    'pmbrl_plan_set_p2p', 'pmbrl_p2p_error', 'pmbrl_p2p_destroy',
 ]
 
 class Adam(C.Structure):
@@ -192,6 +194,21 @@ def load():
     lib.pmbrl_comm_destroy.argtypes = [vp]
     lib.pmbrl_plan_set_comm.restype = C.c_int
     lib.pmbrl_plan_set_comm.argtypes = [vp, vp]
+    lib.pmbrl_p2p_create.restype = C.c_int
+    lib.pmbrl_p2p_create.argtypes = [i32, i32, i32, i64, C.POINTER(vp)]
+    lib.pmbrl_p2p_handle.restype = C.c_int
+    lib.pmbrl_p2p_handle.argtypes = [vp, vp]
+    lib.pmbrl_p2p_open.restype = C.c_int
+    lib.pmbrl_p2p_open.argtypes = [vp, i32, vp]
+    for fn in (lib.pmbrl_p2p_allreduce_f32, lib.pmbrl_p2p_allreduce_f64):
+        fn.restype = C.c_int
+        fn.argtypes = [vp, vp, vp, i64]
+    lib.pmbrl_plan_set_p2p.restype = C.c_int
+    lib.pmbrl_plan_set_p2p.argtypes = [vp, vp]
+    lib.pmbrl_p2p_error.restype = C.c_int
+    lib.pmbrl_p2p_error.argtypes = [vp, C.POINTER(i32)]
+    lib.pmbrl_p2p_destroy.restype = None
+    lib.pmbrl_p2p_destroy.argtypes = [vp]
     lib.pmbrl_plan_set_collective.restype = C.c_int
     lib.pmbrl_plan_set_collective.argtypes = [vp, COLLECTIVE_FN, vp]
     _lib = lib

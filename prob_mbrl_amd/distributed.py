@@ -102,6 +102,54 @@ class GradComm:
             pass
 
 
+class P2PComm:
+    """One-shot peer-to-peer all-reduce behind the C ABI (pmbrl_p2p_*, csrc/pmbrl_p2p.hip) for the latency-bound
+    messages of a sharded run: every rank writes into IPC-mapped slots of every peer and sums in rank order, one kernel
+    per rank on the compute stream.  The 64-byte IPC handles travel through the torch.distributed group the caller
+    already has (bootstrap only).  Ranks of one node: on different GPUs, or several on one GPU."""
+
+    def __init__(self, group=None, device=None, max_bytes=1 << 20):
+        import torch.distributed as dist
+        self.lib = _lib.load()
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.device = dev
+        self.p2p = C.c_void_p()
+        _lib.check(self.lib.pmbrl_p2p_create(self.rank, self.world, dev.index or 0, int(max_bytes), C.byref(self.p2p)),
+                   'pmbrl_p2p_create')
+        hb = C.create_string_buffer(64)
+        _lib.check(self.lib.pmbrl_p2p_handle(self.p2p, hb), 'pmbrl_p2p_handle')
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(hb.raw), group=group)
+        for q, h in enumerate(handles):
+            if q != self.rank:
+                _lib.check(self.lib.pmbrl_p2p_open(self.p2p, q, C.c_char_p(h)), 'pmbrl_p2p_open')
+        dist.barrier(group=group)      # every rank has mapped every peer before the first store
+
+    def allreduce_(self, t):
+        """In-place sum over the ranks of a contiguous fp32 / fp64 device tensor (same bits on every rank)."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        fn = self.lib.pmbrl_p2p_allreduce_f32 if t.dtype == torch.float32 else self.lib.pmbrl_p2p_allreduce_f64
+        _lib.check(fn(self.p2p, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(t.data_ptr()), t.numel()),
+                   'pmbrl_p2p_allreduce')
+        return t
+
+    def __call__(self, view):          # a transport for Engine.attach_collective (groups spread over ranks)
+        return self.allreduce_(view)
+
+    def failed(self):
+        """Host sync: did a wait time out (a peer never arrived) since the last call?"""
+        e = C.c_int32(0)
+        _lib.check(self.lib.pmbrl_p2p_error(self.p2p, C.byref(e)), 'pmbrl_p2p_error')
+        return bool(e.value)
+
+    def close(self):
+        if self.p2p:
+            self.lib.pmbrl_p2p_destroy(self.p2p)
+            self.p2p = C.c_void_p()
+
+
 _COMMS = {}
 
 
@@ -133,6 +181,23 @@ def get_comm(group=None, device=None):
     return _COMMS[key]
 
 
+_P2PS = {}
+
+
+def get_p2p(group=None, device=None, max_bytes=4 << 20):
+    """The one-shot peer-to-peer transport for this process group (created on first use; collective).  Chosen with
+    PMBRL_P2P=1 for the latency-bound messages of a sharded run (the flat gradient up to max_bytes, the per-step
+    statistics of groups spread over ranks); all ranks must sit on one node."""
+    key = (id(group), str(device))
+    if key not in _P2PS:
+        _P2PS[key] = P2PComm(group, device, max_bytes=max_bytes)
+    return _P2PS[key]
+
+
+def p2p_wanted():
+    return bool(os.environ.get('PMBRL_P2P'))
+
+
 def grad_allreduce(group=None, device=None):
     """The in-place sum all-reduce of the flat gradient for this process group: through the C ABI on
     the compute stream when the group runs on RCCL (backend nccl), through torch.distributed
@@ -141,6 +206,15 @@ def grad_allreduce(group=None, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return lambda t: t
+    if p2p_wanted():
+        p2p = get_p2p(group, device)
+        fallback = get_comm(group, device)
+
+        def allreduce(t):      # (messages beyond the slots: the ring, which is bandwidth-bound territory anyway)
+            if t.numel() * t.element_size() <= (4 << 20):
+                return p2p.allreduce_(t)
+            return fallback.allreduce_(t) if fallback is not None else allreduce_sum_(t, group)
+        return allreduce
     comm = get_comm(group, device)
     if comm is not None:
         return comm.allreduce_

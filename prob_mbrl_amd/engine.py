@@ -406,13 +406,25 @@ class Engine:
         if self._coll is not None and self._coll[0] is group:
             return
         ws = self.workspace
+        from .distributed import P2PComm
+        if isinstance(group, P2PComm):
+            # one-shot peer-to-peer transport (pmbrl_p2p.hip): attached inside the library, one kernel per exchange on
+            # the compute stream, nothing of the host language in the per-step loop
+            _lib.check(self.lib.pmbrl_plan_set_p2p(self.plan, group.p2p), 'pmbrl_plan_set_p2p')
+            self._coll = (group, group)
+            return
         if callable(group):
             # a transport of the caller's: group(view) sums the fp64 device tensor `view` over the ranks in place
             # (tests: ranks as threads of one process)
             on_device, custom = False, group
         else:
             import torch.distributed as dist
-            from .distributed import get_comm
+            from .distributed import get_comm, get_p2p, p2p_wanted
+            if p2p_wanted():         # PMBRL_P2P=1: the one-shot peer-to-peer transport for the per-step statistics
+                p2p = get_p2p(group, self.device)
+                _lib.check(self.lib.pmbrl_plan_set_p2p(self.plan, p2p.p2p), 'pmbrl_plan_set_p2p')
+                self._coll = (group, p2p)
+                return
             comm = get_comm(group, self.device)
             if comm is not None:
                 _lib.check(self.lib.pmbrl_plan_set_comm(self.plan, comm.comm), 'pmbrl_plan_set_comm')

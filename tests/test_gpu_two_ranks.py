@@ -334,3 +334,16 @@ def test_mc_pilco_two_ranks_value_bootstrap_and_prioritised_replay(name):
         for r in res:
             assert np.array_equal(r[5][1], d['replay_final_counts'])
             assert np.allclose(r[5][2], d['replay_final_leaves'], rtol=1e-3)
+
+
+def test_bench_two_ranks_p2p_transport_one_device():
+    """bench.py --transport p2p with both ranks on one device: the gradient all-reduce of every iteration really runs on
+    the device between two processes (IPC-mapped slots), which RCCL cannot do on a one-GPU box."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--transport', 'p2p',
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device', '--no-second-curve']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and 'peer-to-peer' in out['collective']
