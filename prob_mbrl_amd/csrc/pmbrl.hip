@@ -671,7 +671,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // workgroups: wave 0, and the whole group's rows in LDS)
       const int mw = parts > 1 ? 1 : (mmd && p->M <= 16 * RT) ? std::min(PF_NW, std::max(1, 16 * RT / p->M)) : PF_NW;
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
-                                p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? p->M : 0) * sizeof(float);
+                                p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? p->M : 0, parts > 1 ? c.H : 0) * sizeof(float);
     }
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd, p->inplace != 0) * sizeof(float);
   };
@@ -1069,6 +1069,12 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_gxc = take((size_t)c.B * c.D * sizeof(float));
     p->off_gxc2 = take((size_t)c.B * c.D * sizeof(float));
     p->off_gsync = take(2 * 1024 * sizeof(unsigned));   // one flag per workgroup for the device-wide barriers (forward, backward)
+    // groups split over workgroups: the granules of their statistics exchange (pm_xch_sum; PMBRL_MM_XCH=0: rows + flags)
+    p->xch_bytes = 0;
+    if (p->mm_parts > 1 && !(getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0)) {
+      p->xch_bytes = (size_t)p->nwg * PM_XCH_WG_WORDS(2) * sizeof(unsigned long long);
+      p->off_xch = take(p->xch_bytes);
+    }
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     {
       // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
@@ -1263,6 +1269,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   memset(&A, 0, sizeof(A));
   A.B = c.B; A.D = c.D; A.U = c.U; A.H = c.H;
   A.Bg = c.B_global; A.row_off = c.row_offset; A.flags = c.flags;
+  // split groups without the statistics exchange (PMBRL_MM_XCH=0): only the generic instances carry the rows + flags form
+  if (p->mm_parts > 1 && !p->xch_bytes) A.flags |= PMBRL_FLAG_NO_SHAPED;
   A.G = p->G; A.M = p->M; A.mm_mode = p->mm_mode;
   A.t0 = 0; A.t1 = c.H;
   A.rows_per_wg = p->rows_per_wg; A.nwg = p->nwg; A.Rw = 16 * p->RT; A.LD = p->LD; A.LDB = p->LDB;
@@ -1314,6 +1322,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.mm_grid = p->mm_grid;
   A.mm_parts = p->mm_parts;
   A.gsync = reinterpret_cast<unsigned*>(ws + p->off_gsync);
+  A.xch = p->xch_bytes ? reinterpret_cast<unsigned long long*>(ws + p->off_xch) : nullptr;
   A.gx_carry_out = nullptr;
   if (p->fast) {
     // weight streams (hidden->hidden layers) and LDS offsets: same walk as pm_fast_carve
@@ -1499,6 +1508,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
     if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
+    if (p->mm_parts > 1 && As.xch) HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));      // ... or the granules' tags
     launch_fwd_rt(p, As, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
@@ -1705,6 +1715,7 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       // groups split over workgroups: their own flags, and two buffers for the rows of dL/dx they exchange
       A.gsync += 1024;
       HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
+      if (A.xch) HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }
     launch_bwd_rt(p, A, s);

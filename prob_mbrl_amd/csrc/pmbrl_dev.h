@@ -146,6 +146,7 @@ struct RolloutArgs {
   // meet at a device-wide barrier (arrival counter gsync) where the per-step launches ended
   int mm_grid;
   unsigned* gsync;
+  unsigned long long* xch;      // split groups: granules of the statistics exchange (pmbrl_fast.h, pm_xch_sum); nullptr = rows + flags
   float *grad_x0, *agn, *gx_carry;   // gx_carry [B][D]: dL/dx_{t+1} between launches (mm_mode 2)
   int gx_from_carry;
   long long zpol_ss, zdyn_ss;   // per-step strides of z_pol / z_dyn (0 = frozen)

@@ -180,6 +180,70 @@ __device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int pa
   return ok;
 }
 
+// Statistics of a moment-matching group that is split over `parts` workgroups: every part computes the sums over its
+// OWN rows (relative to a reference point all parts share), and wave 0 of each adds up the parts' sums -- NV doubles
+// per lane, element-wise, in part order (so every part ends with the same bits).  The doubles travel as data-tagged
+// 8-byte granules {tag = k, 32 bits of the value} written by one device-scope store each and polled by the reader:
+// no flag, no barrier, no row exchange (cdna_hip_programming.md, Guideline 16, form R2).  xb: [nwg][2][NV][2][64]
+// granules, zeroed before every launch (tag 0 = nothing yet); the two sets alternate between steps -- a part
+// writes its step k + 2 only after it read everybody's k + 1, which was written after that part had read this k.
+// A wait that does not end (a partner that is not resident -- the host checks that all are) gives up after ~1 s.
+#define PM_XCH_WG_WORDS(NV) (2 * (NV) * 2 * 64)
+// publish this part's NV doubles per lane for step k (nothing is waited for: the stores are on their way)
+template <int NV>
+__device__ __forceinline__ void pm_xch_put(unsigned long long* xb, int first, int me, unsigned k, const double (&v)[NV],
+                                           int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  const unsigned long long tag = (unsigned long long)k << 32;
+  gu64* mine = (gu64*)xb + (size_t)(first + me) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+    __hip_atomic_store(mine + (2 * i) * 64, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + (2 * i + 1) * 64, tag | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// v <- the sum over all parts, in part order (v holds this part's own contribution on entry)
+template <int NV>
+__device__ __forceinline__ bool pm_xch_get(const unsigned long long* xb, int first, int parts, int me, unsigned k,
+                                           double (&v)[NV], int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  double tot[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+  bool ok = true;
+  for (int q = 0; q < parts; ++q) {
+    if (q == me) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) tot[i] += v[i];
+      continue;
+    }
+    const gu64* theirs = (const gu64*)xb + (size_t)(first + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+    unsigned long long g[2 * NV];
+    for (int spins = 0;;) {
+      bool here = true;
+#pragma unroll
+      for (int i = 0; i < 2 * NV; ++i) {
+        g[i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        here = here && (g[i] >> 32) == (unsigned long long)k;
+      }
+      if (__all(here)) break;
+      if (++spins > (1 << 19)) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) break;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      tot[i] += __longlong_as_double((long long)(((g[2 * i] & 0xffffffffull) << 32) | (g[2 * i + 1] & 0xffffffffull)));
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = tot[i];
+  return ok;
+}
+
 struct SdV {
   int n, v;
   int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l
@@ -1025,7 +1089,7 @@ __host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
                                                      int dnl, int mm_d, int prec = 0, int mm_waves = PF_NW,
-                                                     int mm_group_rows = 0) {
+                                                     int mm_group_rows = 0, int mm_steps = 0) {
   // (mm_waves: waves that do in-kernel moment matching at once = whole groups per workgroup, at most PF_NW;
   //  mm_group_rows: rows of a group split over workgroups -- four row blocks of the whole group behind L.mm)
   size_t n = 2 * (size_t)R * LD + 2 * (size_t)R * D + (size_t)R * U + (size_t)R * 16 + 2 * (size_t)R;
@@ -1046,7 +1110,8 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
   n += 2 * (size_t)mm_waves * pm_mm_scratch_doubles(mm_d);
-  n += 4 * (size_t)mm_group_rows * mm_d;
+  // (+ statistics exchange: the reference point, the z standardisation [zm | zi] of every step of the launch)
+  n += 4 * (size_t)mm_group_rows * mm_d + (mm_group_rows ? 8 + 2 * (size_t)mm_steps * 2 * mm_d : 0);
   return n;
 }
 
@@ -1515,9 +1580,40 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // ... with the group split over mm_parts workgroups: first workgroup / first row of the group, and the LDS
   // blocks [M][D] of the whole group's rows (sampled rows, noise rows, result) behind wave 0's scratch
   const bool mm_pair = mm_in && A.mm_parts > 1;
+  // ... exchanging sums instead of rows (pm_xch_sum) where the one-wave routines of compile-time width apply
+  // (the instances of compile-time width take no other form of a split group: the host launches the generic
+  //  instance when the exchange is switched off)
+  constexpr bool XW = SH::D >= 1 && SH::D <= 6;
+  const bool mm_xch = mm_pair && XW && (A.xch != nullptr);
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
   const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
   float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
+  // (statistics exchange: the first reference point is the group's first row, which every part can read)
+  if (mm_xch && tid < D) mmg[4 * A.M * D + tid] = ((T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D)[(size_t)mmp_g0 * D + tid];
+  // ... and the standardisation of the group's noise rows, mean and 1 / std per column, for every step of the launch
+  // (the noise is an input: nothing of it waits for the recursion)
+  double* const mmzt = reinterpret_cast<double*>(mmg + 4 * A.M * D + 8);      // [T1 - T0][zm (D) | zi (D)]
+  if (mm_xch) {
+    const double dM = (double)A.M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(A.M - 1);
+    for (int tz = T0 + wid; tz < T1; tz += PF_NW) {
+      const float* zb = pm_zbase(A.zmm, D, tz, A.Bg, A.flags);
+      const int z0 = pm_zrow0(tz, A.row_off + mmp_g0, A.flags);
+      for (int j = 0; j < D; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = lane; r < A.M; r += 64) {
+          const double zv = (double)zb[(size_t)pm_zidx(z0, r, A.Bg) * D + j];
+          s1 += zv;
+          s2 += zv * zv;
+        }
+        const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
+        const double zm = sm * inv_m;
+        if (lane == 0) {
+          mmzt[(size_t)(tz - T0) * 2 * D + j] = zm;
+          mmzt[(size_t)(tz - T0) * 2 * D + D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
+        }
+      }
+    }
+  }
   // Phase pattern: everything a phase needs that does NOT depend on the previous phase's LDS
   // output (epilogue descriptors = scalar loads from the kernel arguments, epilogue operands)
   // is issued BEFORE the barrier that opens the phase, so those latencies overlap the barrier
@@ -1707,7 +1803,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
           if (r < nvalid) {
             const size_t o = ((size_t)t * B + row0 + r) * D + d;
             A.Td[o] = z * e * (1.f - sg);
-            if (mm_gs || mm_pair) pm_st_dev(A.xt + o, xn);   // read by other workgroups after the barrier
+            if (mm_gs || (mm_pair && !mm_xch)) pm_st_dev(A.xt + o, xn);   // read by other workgroups after the barrier
             else if (mm_states) A.xt[o] = xn;
             else A.states[o + (size_t)B * D] = xn;
           }
@@ -1724,7 +1820,79 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
     // the state recursion, and is computed for all (t, b) at once by pm_reward_all_kernel
     // after the sweep (so is the moment matching of rewards).  Only the moment matching of
     // STATES is part of the recursion.
-    if (mm_pair) {
+    if (mm_xch) {
+      // group split over workgroups, compile-time width: wave 0 sums the Gram tile over ITS rows (the other parts'
+      // places hold the reference point: they add nothing), adds the other parts' sums (pm_xch_sum) and goes on as
+      // if it had seen the whole group -- no row exchange, no flag barrier, the same bits in every part
+      constexpr int DDc = (SH::D >= 1 && SH::D <= 6) ? SH::D : 1;
+      float* const mmc = mmg + 4 * A.M * D;      // the reference point
+      __syncthreads();                            // this step's sampled rows (xb) are complete
+      PF_MARK(28);
+      if (wid == 0) {
+        const int me = wg - mmp_first, off = row0 - mmp_g0;
+        const unsigned k = (unsigned)(t - T0 + 1);
+        const double refl = (double)mmc[(lane & 15) < D ? (lane & 15) : 0];
+        // sums over this part's rows, relative to the reference point every part uses
+        pm_f64x4 G = pm_mm_gram_lds<DDc, 1, 4 * RT>(xb, xb, nvalid, lane, refl);
+        double v[2] = {G[0], G[1]};
+        PF_MARK(29);
+        pm_xch_put<2>(A.xch, mmp_first, me, k, v, lane);
+        // while they travel: the z standardisation of the whole group (prologue)
+        MMW<DDc> q;
+        {
+          const double* zt = mmzt + (size_t)(t - T0) * 2 * D;
+#pragma unroll
+          for (int j = 0; j < DDc; ++j) {
+            q.zm[j] = zt[j];
+            q.zi[j] = zt[DDc + j];
+          }
+        }
+        const bool xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
+        PF_MARK(31);
+        G[0] = v[0];
+        G[1] = v[1];
+        const bool ok = pm_mmw_factor<DDc, false>(G, A.M, q) && xok;
+        if (!ok && lane == 0) atomicMin(A.status, t);
+        double mean[DDc];
+#pragma unroll
+        for (int j = 0; j < DDc; ++j) mean[j] = q.mean[j] + pm_rl64(refl, j);
+        // this part's rows of the result; the next step's reference point; the factor for the adjoint sweep
+        if (lane < nvalid) {
+          const float* zr = mmg + A.M * D + (off + lane) * D;
+          double zh[DDc];
+#pragma unroll
+          for (int c = 0; c < DDc; ++c) zh[c] = ((double)zr[c] - q.zm[c]) * q.zi[c];
+          float* so = A.states + ((size_t)(t + 1) * B + row0 + lane) * D;
+#pragma unroll
+          for (int j = 0; j < DDc; ++j) {
+            double acc = mean[j];
+#pragma unroll
+            for (int c = 0; c <= j; ++c) acc += zh[c] * q.L[j][c];
+            xa[lane * D + j] = (float)acc;
+            so[j] = (float)acc;
+          }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int j = 0; j < DDc; ++j) mmc[j] = (float)mean[j];
+          if (me == 0) {
+            // [mean | zmean | zistd | (mbar) | invd | L row-major, lower triangle]
+            double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
+#pragma unroll
+            for (int j = 0; j < DDc; ++j) {
+              fac[j] = mean[j];
+              fac[DDc + j] = q.zm[j];
+              fac[2 * DDc + j] = q.zi[j];
+              fac[4 * DDc + j] = q.invd[j];
+#pragma unroll
+              for (int c = 0; c <= j; ++c) fac[5 * DDc + j * DDc + c] = q.L[j][c];
+            }
+          }
+        }
+      }
+      PF_MARK(30);
+      // (no barrier: the next step's first phase opens with one)
+    } else if (!XW && mm_pair) {
       // every workgroup of the group has its sampled rows of this step in A.xt once the group has met; each of
       // them then matches the moments of the WHOLE group (redundantly: the d x d chain is serial anyway) and
       // keeps its own rows
@@ -2000,9 +2168,23 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   // group split over mm_parts workgroups (see the forward sweep): LDS blocks [M][D] of the whole group's
   // pre-mm rows, noise rows, incoming gradient and result behind wave 0's scratch
   const bool mm_pair = mm_in && A.mm_parts > 1;
+  // ... exchanging sums instead of rows (pm_xch_sum) where the one-wave routines of compile-time width apply
+  // (the instances of compile-time width take no other form of a split group: the host launches the generic
+  //  instance when the exchange is switched off)
+  constexpr bool XW = SH::D >= 1 && SH::D <= 6;
+  const bool mm_xch = mm_pair && XW && (A.xch != nullptr);
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
   const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
   float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
+  if (mm_xch) {
+    // statistics exchange: this part's noise rows of the first step swept (the later ones are staged a step ahead)
+    const float* zb = pm_zbase(A.zmm, D, T1 - 1, A.Bg, A.flags);
+    const int z0 = pm_zrow0(T1 - 1, A.row_off + mmp_g0, A.flags);
+    for (int e = tid; e < nvalid * D; e += PF_NT) {
+      const int r = e / D, d = e - r * D;
+      mmg[A.M * D + e] = zb[(size_t)pm_zidx(z0, row0 - mmp_g0 + r, A.Bg) * D + d];
+    }
+  }
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
@@ -2068,7 +2250,92 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       PF_MARK(29);
       for (int i = tid; i < 2 * R * LD; i += PF_NT) L.bufA[i] = 0.f;   // restore the zero K padding
     }
-    if (mm_pair) {
+    if (mm_xch) {
+      // statistics exchange (see the forward sweep): wave 0 sums g^T [z | 1] over this part's rows, adds the other
+      // parts' sums, and finishes the adjoint of the whole group's moment matching with the forward sweep's factor
+      // for its own rows.  What comes from HBM (the factor, this part's pre-mm rows, the NEXT step's noise rows) is
+      // requested before the sums and lands behind the exchange.
+      constexpr int DDc = (SH::D >= 1 && SH::D <= 6) ? SH::D : 1;
+      constexpr int XPL = (16 * RT * DDc + 63) / 64;      // values of this part's rows per lane
+      float* const xst = mmg;                 // this part's pre-mm rows [nvalid][D]
+      float* const zst = mmg + A.M * D;       // this part's noise rows of step t [nvalid][D] (staged one step ahead)
+      const int off = row0 - mmp_g0;
+      __syncthreads();          // dL/dx_{t+1} of this part's rows (gx) is complete
+      PF_MARK(28);
+      if (wid == 0) {
+        const int me = wg - mmp_first;
+        const unsigned k = (unsigned)(T1 - t);
+        pm_f64x4 H = pm_mm_gram_h_lds<DDc, 4 * RT>(gx, zst, nvalid, lane, 0.0, 1.0);     // raw z: standardised below
+        double v[2] = {H[0], H[1]};
+        PF_MARK(30);
+        pm_xch_put<2>(A.xch, mmp_first, me, k, v, lane);
+        // behind the exchange: the factor, the pre-mm rows, the next step's noise rows (nothing of this is held in
+        // registers across a phase: the instances with two row tiles per wave would spill it and wait at once)
+        const MMScratch q = pm_mm_carve(L.mm, DDc);
+        const double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
+        const double f0 = fac[lane < (int)pm_mm_fac_doubles(D) ? lane : 0];
+        const double f1 = fac[lane + 64 < (int)pm_mm_fac_doubles(D) ? lane + 64 : 0];
+        const float* xsrc = A.xt + ((size_t)t * B + row0) * D;
+        float xsv[XPL], znv[XPL];
+#pragma unroll
+        for (int u = 0; u < XPL; ++u) xsv[u] = xsrc[lane + 64 * u < nvalid * D ? lane + 64 * u : 0];
+        {
+          const int tn = t > T0 ? t - 1 : t;
+          const float* zb = pm_zbase(A.zmm, D, tn, A.Bg, A.flags);
+          const int z0 = pm_zrow0(tn, A.row_off + mmp_g0, A.flags);
+#pragma unroll
+          for (int u = 0; u < XPL; ++u) {
+            const int e = lane + 64 * u < nvalid * D ? lane + 64 * u : 0, r = e / D, d = e - r * D;
+            znv[u] = zb[(size_t)pm_zidx(z0, off + r, A.Bg) * D + d];
+          }
+        }
+        const bool xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
+        PF_MARK(31);
+        if (!xok && lane == 0 && A.status) atomicMax(A.status, 1);
+        if (lane < (int)pm_mm_fac_doubles(D)) L.mm[lane] = f0;
+        if (lane + 64 < (int)pm_mm_fac_doubles(D)) L.mm[lane + 64] = f1;
+#pragma unroll
+        for (int u = 0; u < XPL; ++u)
+          if (lane + 64 * u < nvalid * D) {
+            xst[lane + 64 * u] = xsv[u];
+            zst[lane + 64 * u] = znv[u];      // (this step's noise rows were read by the sums above)
+          }
+        pm_wave_sync();
+        // Lbar = tril((g^T z - mbar zm^T) diag(zi)), mbar = g^T 1
+        {
+          const int gq = lane >> 4, c = lane & 15, cc = c < DDc ? c : 0;
+          double mb[DDc];
+#pragma unroll
+          for (int i = 0; i < DDc; ++i) mb[i] = pm_rl64(v[i >> 2], ((i & 3) << 4) | DDc);
+          const double zmc = q.zmean[cc], zsc = q.zistd[cc];
+#pragma unroll
+          for (int r = 0; r < (DDc + 3) / 4; ++r) {
+            const int i = gq + 4 * r;
+            double mi = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (4 * r + u < DDc) mi = (gq == u) ? mb[4 * r + u] : mi;
+            if (i < DDc && c < DDc) q.P[i * DDc + c] = (c <= i) ? (v[r] - zmc * mi) * zsc : 0.0;
+          }
+          if (lane < DDc) q.mbar[lane] = pm_sel(mb, lane);
+        }
+        pm_wave_sync();
+        pm_mm_bwd_l_tail<DDc>(q, lane, A.M);
+        const double inv_m = 1.0 / (double)A.M;
+        for (int e = lane; e < R * D; e += 64) {
+          const int r = e / D, j = e - r * D;
+          double acc = 0.0;
+          if (e < nvalid * D) {
+            acc = q.mbar[j] * inv_m;
+#pragma unroll
+            for (int c = 0; c < DDc; ++c) acc += ((double)xst[r * D + c] - q.mean[c]) * q.P[c * DDc + j];
+          }
+          gxt[e] = (float)acc;
+        }
+      }
+      PF_MARK(29);
+      // (the barrier that opens phase A follows)
+    } else if (!XW && mm_pair) {
       // dL/dx_{t+1} of the whole group is needed: own rows -> HBM (two buffers alternate: a partner may already
       // write step t-1's rows while this workgroup still reads step t's), meet the group, then the adjoint of
       // the moment matching of the WHOLE group on wave 0 of every workgroup of it; each keeps its own rows

@@ -13,6 +13,8 @@
 // away from it.  Rows may live in LDS or in HBM (generic pointers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+typedef double pm_f64x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t pm_mm_scratch_doubles(int d) {
   return d > 0 ? (size_t)3 * d * d + 5 * d : 0;
@@ -343,42 +345,99 @@ __device__ __forceinline__ void pm_mm_bwd(const float* s, int s_ld, int M, int d
 // order as pm_mm_bwd; what changes is where the serial part runs: the d lanes that do the two triangular
 // solves keep L, 1 / diag(L) and their own row / column in REGISTERS -- the LDS form pays an LDS round trip
 // for every one of the d (d + 1) / 2 dependent steps of a solve.
-template <int DD>
-__device__ __forceinline__ void pm_mm_bwd_l(const float* s, int s_ld, int M, const float* z, int z_ld,
-                                            const float* g, int g_ld, float* gout, int gout_ld, double* scr,
-                                            int lane, const double* fac, bool fac_in_scr) {
-  constexpr int d = DD;
-  const MMScratch q = pm_mm_carve(scr, d);
-  if (!fac_in_scr) {
-    for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) scr[e] = fac[e];
-    pm_wave_sync();
-  }
-  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
-  {
-    constexpr int e2 = DD <= 1 ? 1 : DD <= 2 ? 2 : DD <= 4 ? 4 : 8;
-    constexpr int P = 64 / e2;
-    const int part = lane % P, j = lane / P;
-    double a = 0.0;
-    if (j < d)
-      for (int r = part; r < M; r += P) a += (double)g[r * g_ld + j];
-    a = pm_seg_sum(a, P);
-    if (j < d && part == 0) q.mbar[j] = a;
-  }
-  {
-    constexpr int e2 = DD * DD <= 1 ? 1 : DD * DD <= 4 ? 4 : DD * DD <= 16 ? 16 : DD * DD <= 32 ? 32 : 64;
-    constexpr int P = 64 / e2;
-    const int part = lane % P, e = lane / P;
-    const int i = e / d, j = e - i * d;
-    const bool live = e < d * d && j <= i;
-    double acc = 0.0;
-    if (live) {
-      const double zm = q.zmean[j], zs = q.zistd[j];
-      for (int r = part; r < M; r += P) acc += (double)g[r * g_ld + i] * (((double)z[r * z_ld + j] - zm) * zs);
+// Gram tiles of a group whose rows sit in LDS, row-major with row length DD (what the split-group paths of the
+// latency-optimised sweeps stage: pmbrl_fast.h).  Branch-free operands, all of a pass's LDS reads issued before
+// its MFMAs -- the general routine above (cyclic noise rows, device-scope loads, row ranges) compiles to a load
+// and a wait inside a divergent branch per MFMA: 2.2 k cycles for 25 rows, 4.4 k for 50.
+//   pm_mm_gram_lds:   X^T X for X = [s - ref | 1 | z]          (ref: in lane l the reference point's column l & 15)
+//   pm_mm_gram_h_lds: g^T [zhat | 1], zhat = (z - zm) zi       (zm / zi: in lane l those of column l & 15)
+// (one wave alone on its SIMD issues an instruction every 4-5 cycles: what these routines cost is their instruction
+//  count -- operands are formed with per-lane constant multipliers instead of selects the compiler turns into branches)
+// MODE 0: X = [s - ref | 1 | z];  1: [s - ref | 1 | 0] (the sums several workgroups add up);  2: [0 | 1 | z]
+// Row quads q0, q0 + qs, ... (rows 4 q + lane / 16): eight waves take two quads each of a 64-row group.
+template <int DD, int MODE = 0, int UB = 8>
+__device__ __forceinline__ pm_f64x4 pm_mm_gram_lds(const float* s, const float* z, int M, int lane, double ref,
+                                                   int q0 = 0, int qs = 1) {
+  static_assert(2 * DD + 1 <= 16, "the Gram tile holds 2d+1 columns");
+  const int g = lane >> 4, c = lane & 15;
+  const bool is_s = MODE != 2 && c < DD, is_z = MODE != 1 && c > DD && c <= 2 * DD;
+  const float* base = (is_z ? z + (c - DD - 1) : s + (c < DD ? c : 0)) + g * DD;
+  // x = (v - sub) * mul + one: data columns mul = 1, the column of ones mul = 0 / one = 1, unused columns 0 / 0
+  double mul = (is_s || is_z) ? 1.0 : 0.0, one = c == DD ? 1.0 : 0.0, sub = is_s ? ref : 0.0;
+  asm volatile("" : "+v"(mul), "+v"(one), "+v"(sub));
+  pm_f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
+  for (int qb = q0; 4 * qb < M; qb += UB * qs) {
+    float v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = qb + u * qs;
+      v[u] = base[(4 * q + g < M ? 4 * q : 0) * DD];
     }
-    acc = pm_seg_sum(acc, P);
-    if (e < d * d && part == 0) q.P[e] = live ? acc : 0.0;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) asm volatile("" : "+v"(v[u]));     // the reads stay here, together
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = qb + u * qs;
+      double x = __builtin_fma((double)v[u] - sub, mul, one);
+      x = 4 * q + g < M ? x : 0.0;
+      asm volatile("" : "+v"(x));
+      if (4 * q < M) {      // (uniform) two accumulator chains
+        if (u & 1) G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G1, 0, 0, 0);
+        else G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G0, 0, 0, 0);
+      }
+    }
   }
-  pm_wave_sync();
+  return G0 + G1;
+}
+template <int DD, int UB = 8>
+__device__ __forceinline__ pm_f64x4 pm_mm_gram_h_lds(const float* g_rows, const float* z, int M, int lane, double zm,
+                                                     double zi, int q0 = 0, int qs = 1) {
+  const int gq = lane >> 4, c = lane & 15;
+  const int cc = c < DD ? c : 0;
+  const float* gb = g_rows + gq * DD + cc;
+  const float* zb = z + gq * DD + cc;
+  // a = g * am; b = (z - zm) * bm + one
+  double am = c < DD ? 1.0 : 0.0, bm = c < DD ? zi : 0.0, one = c == DD ? 1.0 : 0.0;
+  asm volatile("" : "+v"(am), "+v"(bm), "+v"(one));
+  pm_f64x4 H0 = {0.0, 0.0, 0.0, 0.0}, H1 = {0.0, 0.0, 0.0, 0.0};
+  for (int qb = q0; 4 * qb < M; qb += UB * qs) {
+    float gv[UB], zv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = qb + u * qs;
+      const int o = (4 * q + gq < M ? 4 * q : 0) * DD;
+      gv[u] = gb[o];
+      zv[u] = zb[o];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) asm volatile("" : "+v"(gv[u]), "+v"(zv[u]));
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = qb + u * qs;
+      double a = (double)gv[u] * am;
+      double b = __builtin_fma((double)zv[u] - zm, bm, one);
+      a = 4 * q + gq < M ? a : 0.0;
+      b = 4 * q + gq < M ? b : 0.0;
+      asm volatile("" : "+v"(a), "+v"(b));
+      if (4 * q < M) {
+        if (u & 1) H1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H1, 0, 0, 0);
+        else H0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H0, 0, 0, 0);
+      }
+    }
+  }
+  return H0 + H1;
+}
+
+// xf (a group split over workgroups): xf(H) delivers the sums over g as a tile g^T [zhat | 1] (pm_mm_gram_h_lds over
+// the parts' rows, summed by the caller: pmbrl_fast.h); g is not read here then
+struct PmNoXch {
+  __device__ __forceinline__ bool operator()(pm_f64x4&) const { return true; }
+};
+// the d x d part of the adjoint: q.P = Lbar (lower triangle), q.Lm / q.invd the factor  ->  q.P = (Sbar + Sbar^T) / (M - 1)
+template <int DD>
+__device__ __forceinline__ void pm_mm_bwd_l_tail(const MMScratch& q, int lane, int M) {
+  constexpr int d = DD;
+  const double inv_m1 = 1.0 / (double)(M - 1);
   // L and 1 / diag(L) in registers (every lane: the loads are broadcasts, issued back to back)
   double Lr[DD][DD], idg[DD];
 #pragma unroll
@@ -446,6 +505,56 @@ __device__ __forceinline__ void pm_mm_bwd_l(const float* s, int s_ld, int M, con
     q.P[e] = (q.Sb[i * d + j] + q.Sb[j * d + i]) * inv_m1;
   }
   pm_wave_sync();
+}
+template <int DD, class XF = PmNoXch>
+__device__ __forceinline__ void pm_mm_bwd_l(const float* s, int s_ld, int M, const float* z, int z_ld,
+                                            const float* g, int g_ld, float* gout, int gout_ld, double* scr,
+                                            int lane, const double* fac, bool fac_in_scr, XF xf = XF{}) {
+  constexpr int d = DD;
+  const MMScratch q = pm_mm_carve(scr, d);
+  if (!fac_in_scr) {
+    for (int e = lane; e < (int)pm_mm_fac_doubles(d); e += 64) scr[e] = fac[e];
+    pm_wave_sync();
+  }
+  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
+  if constexpr (!std::is_same<XF, PmNoXch>::value) {
+    const int gq = lane >> 4, c = lane & 15;
+    pm_f64x4 H = {0.0, 0.0, 0.0, 0.0};
+    (void)xf(H);
+#pragma unroll
+    for (int r = 0; r < (DD + 3) / 4; ++r) {
+      const int i = gq + 4 * r;
+      if (i < DD && c < DD) q.P[i * d + c] = c <= i ? H[r] : 0.0;
+      if (i < DD && c == DD) q.mbar[i] = H[r];
+    }
+  } else {
+  {
+    constexpr int e2 = DD <= 1 ? 1 : DD <= 2 ? 2 : DD <= 4 ? 4 : 8;
+    constexpr int P = 64 / e2;
+    const int part = lane % P, j = lane / P;
+    double a = 0.0;
+    if (j < d)
+      for (int r = part; r < M; r += P) a += (double)g[r * g_ld + j];
+    a = pm_seg_sum(a, P);
+    if (j < d && part == 0) q.mbar[j] = a;
+  }
+  {
+    constexpr int e2 = DD * DD <= 1 ? 1 : DD * DD <= 4 ? 4 : DD * DD <= 16 ? 16 : DD * DD <= 32 ? 32 : 64;
+    constexpr int P = 64 / e2;
+    const int part = lane % P, e = lane / P;
+    const int i = e / d, j = e - i * d;
+    const bool live = e < d * d && j <= i;
+    double acc = 0.0;
+    if (live) {
+      const double zm = q.zmean[j], zs = q.zistd[j];
+      for (int r = part; r < M; r += P) acc += (double)g[r * g_ld + i] * (((double)z[r * z_ld + j] - zm) * zs);
+    }
+    acc = pm_seg_sum(acc, P);
+    if (e < d * d && part == 0) q.P[e] = live ? acc : 0.0;
+  }
+  }
+  pm_wave_sync();
+  pm_mm_bwd_l_tail<DD>(q, lane, M);
   for (int e = lane; e < M * d; e += 64) {
     const int r = e / d, j = e - r * d;
     double acc = q.mbar[j] * inv_m;
@@ -471,7 +580,6 @@ __device__ __forceinline__ void pm_mm_bwd_l(const float* s, int s_ld, int M, con
 // covariance (sum s s^T - M m m^T) loses nothing that matters.
 // (Not used inside the sweep kernels: there the extra registers cost the other phases more than
 // the shorter phase gains -- DESIGN.md section 6.)
-typedef double pm_f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double pm_rl64(double v, int src_lane) {   // src_lane: wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -502,12 +610,13 @@ __device__ __forceinline__ float pm_ldc(const float* p) {
 template <int DD, bool COH = false>
 __device__ __forceinline__ pm_f64x4 pm_mm_gram_rows(const float* s, int s_ld, const float* z, int z_ld,
                                                     int zrow0, int Bg, int r_lo, int r_hi, int lane,
-                                                    double* ref_out = nullptr) {
+                                                    double* ref_out = nullptr, const double* ref_in = nullptr) {
+  // (ref_in: lane c < DD holds the reference point's column c instead -- sums that several workgroups add up)
   static_assert(2 * DD + 1 <= 16, "the Gram tile holds 2d+1 columns");
   const int g = lane >> 4, c = lane & 15;
   const int cs = c < DD ? c : 0;
   const int cz = (c > DD && c <= 2 * DD) ? c - DD - 1 : 0;
-  const double ref = (double)pm_ldc<COH>(s + cs);
+  const double ref = ref_in ? *ref_in : (double)pm_ldc<COH>(s + cs);
   if (ref_out) *ref_out = ref;     // lane j < DD: the group's first row, column j
   pm_f64x4 G = {0.0, 0.0, 0.0, 0.0};
   if (r_hi <= r_lo) return G;

@@ -25,17 +25,24 @@ struct MMW {
 
 // means (relative to the reference row), z standardisation, covariance, Cholesky factor from the Gram tile of
 // X = [s - ref | 1 | z].  Returns false on a lost pivot (same rule as pm_mm_factor).
+// the z standardisation alone (the columns of z in the tile)
 template <int DD>
-__device__ __forceinline__ bool pm_mmw_factor(const pm_f64x4& G, int M, MMW<DD>& q) {
+__device__ __forceinline__ void pm_mmw_zstats(const pm_f64x4& G, int M, MMW<DD>& q) {
   const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
-  double A[DD][DD];
 #pragma unroll
   for (int j = 0; j < DD; ++j) {
-    q.mean[j] = PM_G(G, DD, j) * inv_m;
     q.zm[j] = PM_G(G, DD, DD + 1 + j) * inv_m;
     const double szz = PM_G(G, DD + 1 + j, DD + 1 + j);
     q.zi[j] = pm_rsqrt((szz - dM * q.zm[j] * q.zm[j]) * inv_m1);
   }
+}
+template <int DD, bool ZS = true>      // ZS = false: q.zm / q.zi are already there
+__device__ __forceinline__ bool pm_mmw_factor(const pm_f64x4& G, int M, MMW<DD>& q) {
+  const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
+  double A[DD][DD];
+  if constexpr (ZS) pm_mmw_zstats<DD>(G, M, q);
+#pragma unroll
+  for (int j = 0; j < DD; ++j) q.mean[j] = PM_G(G, DD, j) * inv_m;
 #pragma unroll
   for (int i = 0; i < DD; ++i)
 #pragma unroll
@@ -69,13 +76,35 @@ __device__ __forceinline__ bool pm_mmw_factor(const pm_f64x4& G, int M, MMW<DD>&
 // forward: out = m + zhat L^T for the group's M rows (lane r = row r); s, z, out in LDS
 // fac_out (optional): the statistics and the factor in the layout of pm_mm_fac_doubles (pmbrl_mm.h), for the
 // adjoint sweep's pm_mm_bwd
-template <int DD>
+// xf / ref_in / zst: a group split over workgroups -- xf(G) delivers the s entries of the Gram tile (sums over the
+// rows of ALL parts relative to the reference point: lane c < DD of *ref_in holds its column c), zst the z
+// standardisation [zm | zi] (LDS); s is not read here then
+struct PmNoGramXch {
+  __device__ __forceinline__ bool operator()(pm_f64x4&) const { return true; }
+};
+template <int DD, class XF = PmNoGramXch>
 __device__ __forceinline__ bool pm_mm_fwd_w(const float* s, int s_ld, int M, const float* z, int z_ld, float* out,
-                                            int out_ld, int lane, double* fac_out = nullptr) {
+                                            int out_ld, int lane, double* fac_out = nullptr, XF xf = XF{},
+                                            const double* ref_in = nullptr, float* mean_out = nullptr,
+                                            const double* zst = nullptr) {
   double ref = 0.0;
-  const pm_f64x4 G = pm_mm_gram_rows<DD, false>(s, s_ld, z, z_ld, 0, 0, 0, M, lane, &ref);
+  pm_f64x4 G;
   MMW<DD> q;
-  const bool ok = pm_mmw_factor<DD>(G, M, q);
+  bool ok;
+  if constexpr (std::is_same<XF, PmNoGramXch>::value) {
+    G = pm_mm_gram_rows<DD, false>(s, s_ld, z, z_ld, 0, 0, 0, M, lane, &ref, ref_in);
+    ok = pm_mmw_factor<DD>(G, M, q);
+  } else {
+    ref = *ref_in;
+    G = pm_f64x4{0.0, 0.0, 0.0, 0.0};
+    const bool xok = xf(G);
+#pragma unroll
+    for (int j = 0; j < DD; ++j) {
+      q.zm[j] = zst[j];
+      q.zi[j] = zst[DD + j];
+    }
+    ok = pm_mmw_factor<DD, false>(G, M, q) && xok;
+  }
   // the reference row (what the Gram subtracted): lane j < DD holds column j
   double refj[DD];
 #pragma unroll
@@ -91,6 +120,10 @@ __device__ __forceinline__ bool pm_mm_fwd_w(const float* s, int s_ld, int M, con
 #pragma unroll
       for (int c = 0; c < DD; ++c) fac_out[5 * DD + j * DD + c] = c <= j ? q.L[j][c] : 0.0;
     }
+  }
+  if (mean_out && lane == 0) {      // the next step's reference point
+#pragma unroll
+    for (int j = 0; j < DD; ++j) mean_out[j] = (float)(q.mean[j] + refj[j]);
   }
   if (lane < M) {
     double zh[DD];
