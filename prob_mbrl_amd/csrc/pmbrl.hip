@@ -833,6 +833,26 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->lds_bytes = lds_need(p->RT, 0, 1);
   }
 
+  // LDS-resident tiles of the sweeps' second streamed layer (pmbrl_fast.h, lds_tile_s): the shape-specialised 16-row
+  // split-precision instances (two streamed layers of 13 or 14 tiles, stage pair = one tile) keep 8 tiles of it in the
+  // LDS the workgroup has to itself anyway; the launch decides per kernel variant (pmbrl_fast_split.hip).
+  // PMBRL_LDS_TILES=0: off.
+  p->wlds_off = 0;
+  p->lds_last_lanes = 0;
+  if (p->fast && p->RT == 1 && p->prec != 0 && p->CA + p->CB == 7 && p->pol.nl == 3 && p->dyn.nl == 3 &&
+      p->pol.nt[1] == p->dyn.nt[1] && p->pol.nt[2] == p->pol.nt[1] && p->dyn.nt[2] == p->pol.nt[1] &&
+      (p->pol.nt[1] == 13 || p->pol.nt[1] == 14) && !(c.flags & PMBRL_FLAG_NO_SHAPED) &&
+      !(getenv("PMBRL_LDS_TILES") && atoi(getenv("PMBRL_LDS_TILES")) == 0)) {
+    const int last_lanes = 16 * ((16 * p->pol.nt[1] - 32 * 6) / 8);
+    const size_t base = (p->lds_bytes + 15) / 16 * 16;
+    const size_t tiles = (size_t)PF_NW * pm_lds_tile_floats(14, 2, last_lanes) * sizeof(float);
+    if (base + tiles <= lds_cap) {
+      p->wlds_off = (int)(base / sizeof(float));
+      p->lds_last_lanes = last_lanes;
+      p->lds_bytes = base + tiles;
+    }
+  }
+
   // wide states between per-step launches: the LDS-staged multi-wave kernels (PMBRL_MM_NO_WIDE: the one-wave routines)
   p->mm_wide = p->mm_mode == 2 && !p->span && (c.flags & PMBRL_FLAG_MM_STATES) && pm_mmw_ok(p->M, c.D, c.flags) &&
                !getenv("PMBRL_MM_NO_WIDE");

@@ -105,6 +105,11 @@ struct RolloutArgs {
                        // streamed layer keep their weights in registers for the launch; the stream table then
                        // describes only the remaining tiles of that layer (res_w: the layer's full fragments)
   const float* res_w;
+  // ... and the first 8 tiles of its SECOND streamed layer live in LDS (lds_tile_s; shape-specialised instances):
+  // lds_w the layer's full fragments, wlds_off where the tiles go (floats from the LDS base), lds_last_lanes the
+  // lanes of the last K32 block that are stored
+  const float* lds_w;
+  int wlds_off, lds_last_lanes;
   float mls_pol, mls_dyn;
   NetDev pol, dyn;
   const RewardDev* rew;

@@ -594,6 +594,69 @@ __device__ __forceinline__ void resident_tile_s(const FragS<NB * NP>& w, const f
   }
 }
 
+// The same from LDS: one output tile per wave whose weights (NB K32 blocks x NP pieces, fragment order) were copied
+// into LDS at the start of the launch -- the sweep's SECOND streamed layer in the shape-specialised 16-row plain
+// instances, where a workgroup has a CU's LDS to itself and two thirds of it idle (resident_tile_s covers the first
+// streamed layer with the registers that are left).  LDS reads run at four times the rate of the L2 path and a quarter
+// of its latency: the layer then streams 5 of its 13 tiles like its sibling.  The last K32 block is stored for its
+// first `last_lanes` lanes only (K = 208 of 224: the rest is zero padding), which is what makes eight tiles fit.
+template <int RT, int NB, int NP, bool F16, class Epi>
+__device__ __forceinline__ void lds_tile_s(const float* wl, int last_lanes, const float* buf_in, unsigned ldb, int lane,
+                                           Epi& epi, int ot) {
+  typedef PmPairs<NP> PP;
+  const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
+  typename Epi::Pre pre[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) pre[rt] = epi.pre(ot, rt);
+  f32x4 acc[2][RT];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool last_on = lane < last_lanes;
+  const float* wp = wl + lane * 4;
+  const float* wlast = wl + (size_t)(NB - 1) * NP * 256 + (last_on ? lane : 0) * 4;
+  f32x4 w[NB][NP];
+  auto ldw = [&](int blk) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (blk < NB - 1) {
+        w[blk][p] = *reinterpret_cast<const f32x4*>(wp + (size_t)(blk * NP + p) * 256);
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wlast + (size_t)p * last_lanes * 4);
+        w[blk][p] = last_on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  BQ<RT, NP> b[2];
+  bq_load<RT, NP>(b[0], lb, ldb, 0);
+  ldw(0);
+  if (NB > 1) ldw(1);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int cur = blk & 1, nxt = cur ^ 1;
+    if (blk + 2 < NB) ldw(blk + 2);
+    bq_load<RT, NP>(b[nxt], lb, ldb, blk + 1 < NB ? blk + 1 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[q & 1][rt] = pm_mfma_bf<F16>(w[blk][PP::W[q]], b[cur].v[PP::A[q]][rt], acc[q & 1][rt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  Epi::wait_all();
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    epi.landed(pre[rt], rt);
+    epi(ot, rt, acc[0][rt] + acc[1][rt], pre[rt]);
+  }
+}
+// floats of one such tile in LDS
+__host__ __device__ inline size_t pm_lds_tile_floats(int n_loads, int np, int last_lanes) {
+  return (size_t)(n_loads - np) * 256 + (size_t)np * last_lanes * 4;
+}
+
 // Register-resident single-k-block layer (first layer forward / head adjoint backward).
 template <int RT>
 struct Res0 {
@@ -1111,7 +1174,10 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
   }
   n += 2 * (size_t)mm_waves * pm_mm_scratch_doubles(mm_d);
   // (+ statistics exchange: the reference point, the z standardisation [zm | zi] of every step of the launch)
-  n += 4 * (size_t)mm_group_rows * mm_d + (mm_group_rows ? 8 + 2 * (size_t)mm_steps * 2 * mm_d : 0);
+  //  and two staging sets, alternating between steps, of what wave 1 fetches a step ahead while wave 0 works: the
+  //  part's noise rows (forward sweep); scratch with the factor, the part's pre-mm rows, its noise rows (adjoint)
+  n += 4 * (size_t)mm_group_rows * mm_d +
+       (mm_group_rows ? 8 + 2 * (size_t)mm_steps * 2 * mm_d + 2 * (2 * pm_mm_scratch_doubles(mm_d) + 2 * (size_t)R * mm_d) : 0);
   return n;
 }
 
@@ -1356,9 +1422,12 @@ __device__ __forceinline__ void pm_fast_preload_shaped(const RolloutArgs& A, con
 // tile is K-split, that tile's partial / gather / epilogue around it
 #define PM_STREAM_LAYER(SI, ES, HW_UNUSED, PROF)                                                        \
   if constexpr (PR != 0) {                                                                              \
-    const int rb_ = (RESK && (SI) == 0) ? res_tiles : 0;                                                \
+    const int rb_ = (RESK && (SI) == 0) ? res_tiles : (LDSK && (SI) == 1) ? PF_NW : 0;                  \
     if constexpr (RESK) {                                                                               \
-      if (rb_) resident_tile_s<RT, CA + CB, NP, F16>(wres, X, (unsigned)LDB, lane, (ES), wid);         \
+      if ((SI) == 0 && rb_) resident_tile_s<RT, CA + CB, NP, F16>(wres, X, (unsigned)LDB, lane, (ES), wid); \
+    }                                                                                                   \
+    if constexpr (LDSK) {                                                                               \
+      if ((SI) == 1) lds_tile_s<RT, CA + CB, NP, F16>(wlds, A.lds_last_lanes, X, (unsigned)LDB, lane, (ES), wid); \
     }                                                                                                   \
     stream_layer_s<RT, CA, CB, NP, F16, SC>(sd, (SI), q, fa, fb, X, (unsigned)LDB, wid, lane, (ES), vo0, vo1, (PROF), rb_); \
   } else {                                                                                              \
@@ -1451,7 +1520,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // register-resident first tiles (resident_tile_s): compiled into the 16-row plain variants whose stage pair
   // is a whole tile; the tile counts of the stream then differ between layers (read from the table)
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
-  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
+  // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
+  constexpr bool LDSK = RESK && SH::NT > 8 && SH::NL == 3;
+  typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
                    (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKBc / (PR ? NP : 1) * 32 + 16 : 0;
@@ -1575,6 +1646,22 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       for (int i = 0; i < (CA + CB) * NP; ++i) wres.a[i] = ldg4(wp + (size_t)i * 256);
     }
   }
+  // this wave's tile of the second streamed layer -> LDS (read by this wave only: no barrier)
+  const float* wlds = nullptr;
+  if constexpr (LDSK) {
+    constexpr int NLD = (CA + CB) * NP;
+    float* dst = smem + A.wlds_off + (size_t)wid * pm_lds_tile_floats(NLD, NP, A.lds_last_lanes);
+    const float* src = A.lds_w + (size_t)wid * NLD * 256;
+    for (int i = 0; i < NLD - NP; ++i)
+      *reinterpret_cast<f32x4*>(dst + (size_t)i * 256 + lane * 4) = ldg4(src + (size_t)i * 256 + lane * 4);
+    if (lane < A.lds_last_lanes) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc)
+        *reinterpret_cast<f32x4*>(dst + (size_t)(NLD - NP) * 256 + (size_t)pc * A.lds_last_lanes * 4 + lane * 4) =
+            ldg4(src + (size_t)(NLD - NP + pc) * 256 + lane * 4);
+    }
+    wlds = dst;
+  }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
   const bool mm_in = VAR == PF_VAR_MM && A.mm_mode == 1 && mm_states;
   // ... with the group split over mm_parts workgroups: first workgroup / first row of the group, and the LDS
@@ -1593,7 +1680,17 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // ... and the standardisation of the group's noise rows, mean and 1 / std per column, for every step of the launch
   // (the noise is an input: nothing of it waits for the recursion)
   double* const mmzt = reinterpret_cast<double*>(mmg + 4 * A.M * D + 8);      // [T1 - T0][zm (D) | zi (D)]
+  // this part's noise rows, two sets [R][D] (step t in set t & 1): fetched a step ahead by wave 1 while wave 0 works
+  float* const mmzs = reinterpret_cast<float*>(mmzt + (size_t)A.H * 2 * D);
   if (mm_xch) {
+    {
+      const float* zb = pm_zbase(A.zmm, D, T0, A.Bg, A.flags);
+      const int z0 = pm_zrow0(T0, A.row_off + mmp_g0, A.flags);
+      for (int e = tid; e < nvalid * D; e += PF_NT) {
+        const int r = e / D, d = e - r * D;
+        mmzs[(T0 & 1) * R * D + e] = zb[(size_t)pm_zidx(z0, row0 - mmp_g0 + r, A.Bg) * D + d];
+      }
+    }
     const double dM = (double)A.M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(A.M - 1);
     for (int tz = T0 + wid; tz < T1; tz += PF_NW) {
       const float* zb = pm_zbase(A.zmm, D, tz, A.Bg, A.flags);
@@ -1681,7 +1778,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         // this step's moment-matching noise rows -> LDS, a whole step before they are needed (the
         // statistics loops of pm_mm_* would otherwise chase them through HBM one at a time)
         const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
-        if (mm_pair) {     // the whole group's noise rows
+        if (mm_xch) {      // (staged a step ahead, next to the moment matching)
+        } else if (mm_pair) {     // the whole group's noise rows
           const int z0 = pm_zrow0(t, A.row_off + mmp_g0, A.flags);
           for (int i = tid; i < A.M * D; i += PF_NT) {
             const int r = i / D, d = i - r * D;
@@ -1829,7 +1927,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       __syncthreads();                            // this step's sampled rows (xb) are complete
       PF_MARK(28);
       if (wid == 0) {
-        const int me = wg - mmp_first, off = row0 - mmp_g0;
+        const int me = wg - mmp_first;
         const unsigned k = (unsigned)(t - T0 + 1);
         const double refl = (double)mmc[(lane & 15) < D ? (lane & 15) : 0];
         // sums over this part's rows, relative to the reference point every part uses
@@ -1858,7 +1956,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
         for (int j = 0; j < DDc; ++j) mean[j] = q.mean[j] + pm_rl64(refl, j);
         // this part's rows of the result; the next step's reference point; the factor for the adjoint sweep
         if (lane < nvalid) {
-          const float* zr = mmg + A.M * D + (off + lane) * D;
+          const float* zr = mmzs + (t & 1) * R * D + lane * D;
           double zh[DDc];
 #pragma unroll
           for (int c = 0; c < DDc; ++c) zh[c] = ((double)zr[c] - q.zm[c]) * q.zi[c];
@@ -1888,6 +1986,15 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
               for (int c = 0; c <= j; ++c) fac[5 * DDc + j * DDc + c] = q.L[j][c];
             }
           }
+        }
+      }
+      else if (wid == 1 && t + 1 < T1) {
+        // (idle otherwise) the next step's noise rows of this part
+        const float* zb = pm_zbase(A.zmm, D, t + 1, A.Bg, A.flags);
+        const int z0 = pm_zrow0(t + 1, A.row_off + mmp_g0, A.flags);
+        for (int e = lane; e < nvalid * D; e += 64) {
+          const int r = e / D, d = e - r * D;
+          mmzs[((t + 1) & 1) * R * D + e] = zb[(size_t)pm_zidx(z0, row0 - mmp_g0 + r, A.Bg) * D + d];
         }
       }
       PF_MARK(30);
@@ -1974,7 +2081,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr int NKB32c = ((SH::NT + 1) / 2 + CA + CB - 1) / (CA + CB) * (CA + CB);   // padded K32 blocks per tile
   constexpr int NKBc = !SH::NT ? 0 : PR ? NKB32c * NP : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
-  typedef PfStream<SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0, NKBc,
+  // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
+  constexpr bool LDSK = RESK && SH::NT > 8 && SH::NL == 3;
+  typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
                    (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
   constexpr int LDBc = (PR && SH::NT) ? NKB32c * 32 + 16 : 0;
@@ -2110,6 +2219,22 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
       for (int i = 0; i < (CA + CB) * NP; ++i) wres.a[i] = ldg4(wp + (size_t)i * 256);
     }
   }
+  // this wave's tile of the second streamed layer -> LDS (read by this wave only: no barrier)
+  const float* wlds = nullptr;
+  if constexpr (LDSK) {
+    constexpr int NLD = (CA + CB) * NP;
+    float* dst = smem + A.wlds_off + (size_t)wid * pm_lds_tile_floats(NLD, NP, A.lds_last_lanes);
+    const float* src = A.lds_w + (size_t)wid * NLD * 256;
+    for (int i = 0; i < NLD - NP; ++i)
+      *reinterpret_cast<f32x4*>(dst + (size_t)i * 256 + lane * 4) = ldg4(src + (size_t)i * 256 + lane * 4);
+    if (lane < A.lds_last_lanes) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc)
+        *reinterpret_cast<f32x4*>(dst + (size_t)(NLD - NP) * 256 + (size_t)pc * A.lds_last_lanes * 4 + lane * 4) =
+            ldg4(src + (size_t)(NLD - NP + pc) * 256 + lane * 4);
+    }
+    wlds = dst;
+  }
   __syncthreads();
 
   // Per-row inputs of one step, staged in LDS: [gr | Jx(D) | Ja(U) | Td(D) | Tp(U) | a(U)].
@@ -2176,15 +2301,27 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
   const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
   float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
-  if (mm_xch) {
-    // statistics exchange: this part's noise rows of the first step swept (the later ones are staged a step ahead)
-    const float* zb = pm_zbase(A.zmm, D, T1 - 1, A.Bg, A.flags);
-    const int z0 = pm_zrow0(T1 - 1, A.row_off + mmp_g0, A.flags);
-    for (int e = tid; e < nvalid * D; e += PF_NT) {
+  // statistics exchange: two staging sets (step t in set t & 1) of [scratch with the forward sweep's factor | this
+  // part's pre-mm rows [R][D] | its noise rows [R][D]], fetched a step ahead by wave 1 while wave 0 works
+  const size_t mmst_set = 2 * pm_mm_scratch_doubles(D) + 2 * (size_t)R * D;      // floats
+  float* const mmst = mmg + 4 * A.M * D + 8 + 2 * (size_t)A.H * 2 * D;
+  auto mm_stage = [&](int ts, int i0, int istep) {
+    float* set = mmst + (size_t)(ts & 1) * mmst_set;
+    double* fdst = reinterpret_cast<double*>(set);
+    const double* fac = A.mmfac + ((size_t)ts * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
+    for (int e = i0; e < (int)pm_mm_fac_doubles(D); e += istep) fdst[e] = fac[e];
+    float* xdst = set + 2 * pm_mm_scratch_doubles(D);
+    float* zdst = xdst + R * D;
+    const float* xsrc = A.xt + ((size_t)ts * B + row0) * D;
+    const float* zb = pm_zbase(A.zmm, D, ts, A.Bg, A.flags);
+    const int z0 = pm_zrow0(ts, A.row_off + mmp_g0, A.flags);
+    for (int e = i0; e < nvalid * D; e += istep) {
       const int r = e / D, d = e - r * D;
-      mmg[A.M * D + e] = zb[(size_t)pm_zidx(z0, row0 - mmp_g0 + r, A.Bg) * D + d];
+      xdst[e] = xsrc[e];
+      zdst[e] = zb[(size_t)pm_zidx(z0, row0 - mmp_g0 + r, A.Bg) * D + d];
     }
-  }
+  };
+  if (mm_xch && T1 > T0) mm_stage(T1 - 1, tid, PF_NT);
   int gsel = 0;   // plain path: gxn alternates between L.jx and L.xb
   const int xb_off = (int)(L.xb - L.jx);
 
@@ -2253,15 +2390,15 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
     if (mm_xch) {
       // statistics exchange (see the forward sweep): wave 0 sums g^T [z | 1] over this part's rows, adds the other
       // parts' sums, and finishes the adjoint of the whole group's moment matching with the forward sweep's factor
-      // for its own rows.  What comes from HBM (the factor, this part's pre-mm rows, the NEXT step's noise rows) is
-      // requested before the sums and lands behind the exchange.
+      // for its own rows.  What comes from HBM (the factor, this part's pre-mm rows and noise rows) was staged during
+      // the previous step's moment matching by wave 1, which has nothing else to do then.
       constexpr int DDc = (SH::D >= 1 && SH::D <= 6) ? SH::D : 1;
-      constexpr int XPL = (16 * RT * DDc + 63) / 64;      // values of this part's rows per lane
-      float* const xst = mmg;                 // this part's pre-mm rows [nvalid][D]
-      float* const zst = mmg + A.M * D;       // this part's noise rows of step t [nvalid][D] (staged one step ahead)
-      const int off = row0 - mmp_g0;
+      float* const set = mmst + (size_t)(t & 1) * mmst_set;
+      float* const xst = set + 2 * pm_mm_scratch_doubles(D);      // this part's pre-mm rows [nvalid][D]
+      float* const zst = xst + R * D;                             // its noise rows of step t
       __syncthreads();          // dL/dx_{t+1} of this part's rows (gx) is complete
       PF_MARK(28);
+      if (wid == 1 && t > T0) mm_stage(t - 1, lane, 64);      // (idle otherwise) what step t - 1 will need from HBM
       if (wid == 0) {
         const int me = wg - mmp_first;
         const unsigned k = (unsigned)(T1 - t);
@@ -2269,38 +2406,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         double v[2] = {H[0], H[1]};
         PF_MARK(30);
         pm_xch_put<2>(A.xch, mmp_first, me, k, v, lane);
-        // behind the exchange: the factor, the pre-mm rows, the next step's noise rows (nothing of this is held in
-        // registers across a phase: the instances with two row tiles per wave would spill it and wait at once)
-        const MMScratch q = pm_mm_carve(L.mm, DDc);
-        const double* fac = A.mmfac + ((size_t)t * A.mmfac_groups + mmp_g0 / A.M) * pm_mm_fac_doubles(D);
-        const double f0 = fac[lane < (int)pm_mm_fac_doubles(D) ? lane : 0];
-        const double f1 = fac[lane + 64 < (int)pm_mm_fac_doubles(D) ? lane + 64 : 0];
-        const float* xsrc = A.xt + ((size_t)t * B + row0) * D;
-        float xsv[XPL], znv[XPL];
-#pragma unroll
-        for (int u = 0; u < XPL; ++u) xsv[u] = xsrc[lane + 64 * u < nvalid * D ? lane + 64 * u : 0];
-        {
-          const int tn = t > T0 ? t - 1 : t;
-          const float* zb = pm_zbase(A.zmm, D, tn, A.Bg, A.flags);
-          const int z0 = pm_zrow0(tn, A.row_off + mmp_g0, A.flags);
-#pragma unroll
-          for (int u = 0; u < XPL; ++u) {
-            const int e = lane + 64 * u < nvalid * D ? lane + 64 * u : 0, r = e / D, d = e - r * D;
-            znv[u] = zb[(size_t)pm_zidx(z0, off + r, A.Bg) * D + d];
-          }
-        }
+        const MMScratch q = pm_mm_carve(reinterpret_cast<double*>(set), DDc);      // (the factor is in place)
         const bool xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
         PF_MARK(31);
         if (!xok && lane == 0 && A.status) atomicMax(A.status, 1);
-        if (lane < (int)pm_mm_fac_doubles(D)) L.mm[lane] = f0;
-        if (lane + 64 < (int)pm_mm_fac_doubles(D)) L.mm[lane + 64] = f1;
-#pragma unroll
-        for (int u = 0; u < XPL; ++u)
-          if (lane + 64 * u < nvalid * D) {
-            xst[lane + 64 * u] = xsv[u];
-            zst[lane + 64 * u] = znv[u];      // (this step's noise rows were read by the sums above)
-          }
-        pm_wave_sync();
         // Lbar = tril((g^T z - mbar zm^T) diag(zi)), mbar = g^T 1
         {
           const int gq = lane >> 4, c = lane & 15, cc = c < DDc ? c : 0;

@@ -57,6 +57,7 @@ struct pmbrl_plan {
   // workspace offsets (bytes)
   size_t off_actT[PM_MAXL], off_gT[PM_MAXL], off_Tp, off_Td, off_xt, off_rt, off_part, off_mmfac,
       off_gxc, off_gxc2, off_gsync, off_xch, xch_bytes, off_grt, off_Jx, off_Ja, off_gmm_c, off_gmm_k, ws_bytes;
+  int wlds_off, lds_last_lanes;   // LDS-resident tiles (lds_tile_s): where they go (floats), lanes stored of the last K32 block
   const float* loss_w;   // pmbrl_plan_set_loss: dL/dr [H][B]; the forward call also leaves the loss in *loss_out
   float* loss_out;
 

@@ -1,6 +1,8 @@
-"""In-kernel moment matching with a group SPLIT over several workgroups (pmbrl.hip: mm_parts; pmbrl_fast.h:
-pm_group_sync): the workgroups of a group exchange their rows through HBM, meet at a group-local flag barrier
-and each factors the whole group.  On by default where a group needs a 64-row workgroup (the double cart-pole
+"""In-kernel moment matching with a group SPLIT over several workgroups (pmbrl.hip: mm_parts).  Instances of
+compile-time state width: every part sums the fp64 Gram tile over its own rows and the parts exchange the sums as
+data-tagged granules (pmbrl_fast.h: pm_xch_put / pm_xch_get).  Generic instances (and PMBRL_MM_XCH=0): the
+workgroups of a group exchange their rows through HBM, meet at a group-local flag barrier (pm_group_sync) and each
+factors the whole group.  On by default where a group needs a 64-row workgroup (the double cart-pole
 shape: two 25-row workgroups instead); forced here on the ordinary fixtures (PMBRL_MM_PARTS=n) and compared with
 whole groups per workgroup and with the fp64 reference numbers."""
 import contextlib
@@ -142,3 +144,20 @@ def test_split_groups_replay_in_a_graph():
         return g.cpu().numpy().copy()
 
     assert np.array_equal(go(False), go(True))
+
+
+@pytest.mark.parametrize('name,n', [('mmg_h40', 2), ('mm1_b100_h40', 4), ('full200_mmg', 3)])
+def test_statistics_exchange_matches_row_exchange(name, n):
+    """The two forms of a split group on the shapes that have a compile-time-width instance: sums exchanged as
+    granules (default) against rows + flag barrier (PMBRL_MM_XCH=0, generic instance)."""
+    d = common.load(name)
+    e1, nv1, S1, R1, g1, x1 = run(d, n)
+    assert 'PMBRL_MM_XCH' not in os.environ
+    os.environ['PMBRL_MM_XCH'] = '0'
+    try:
+        e2, nv2, S2, R2, g2, x2 = run(d, n)
+    finally:
+        del os.environ['PMBRL_MM_XCH']
+    assert e1.info['mm_parts'] == e2.info['mm_parts'] == n and nv1 == nv2 == int(d['H'])
+    assert common.rel(S2, S1) < 5e-6 and common.rel(g2, g1) < 2e-5 and common.rel(x2, x1) < 2e-5
+    assert common.rel(g1, d['ref64_grad']) < TOL_GRAD and common.rel(g2, d['ref64_grad']) < TOL_GRAD

@@ -42,4 +42,20 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
                 names.append(n)
     assert len(names) >= 19 + 16 + 6, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
     assert total_loads > 500
+    # register spills of the default-precision instances that run the cart-pole shapes: none without moment matching,
+    # none with 25-row groups split over two 16-row workgroups (statistics exchange: the rows + flags form is no
+    # longer compiled into them); the 32-row instance of the double cart-pole shape is bounded
+    import re
+    txt = open(procs[3][0]).read()          # pmbrl_fast_split.hip, PM_SPLIT_PR = 2
+    spills = {}
+    for blk in txt.split('- .agpr_count:')[1:]:
+        spills[re.search(r'\.name:\s+(\S+)', blk).group(1)] = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1))
+    shape = lambda d: 'PfShapeILi%dELi1ELi240ELi3ELi13EELi2EE' % d
+    for direction in ('fwd', 'bwd'):
+        for var, d in ((0, 4), (2, 4)):
+            n = '_Z19pm_rollout_%s_fastILi1ELi4ELi3ELi%dE7%sv11RolloutArgs' % (direction, var, shape(d))
+            # (the adjoint instance with moment matching parks one 64-bit pointer in its prologue, outside the step loop)
+            assert spills[n] <= (2 if (direction, var) == ('bwd', 2) else 0), (n, spills[n])
+        n = '_Z19pm_rollout_%s_fastILi2ELi4ELi3ELi2E7%sv11RolloutArgs' % (direction, shape(6))
+        assert spills[n] <= 64, (n, spills[n])
     shutil.rmtree(str(tmp_path), ignore_errors=True)
