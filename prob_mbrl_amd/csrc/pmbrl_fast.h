@@ -1521,7 +1521,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   // is a whole tile; the tile counts of the stream then differ between layers (read from the table)
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
-  constexpr bool LDSK = RESK && SH::NT > 8 && SH::NL == 3;
+  // (also where moment matching runs inside a 16-row sweep: no registers for resident tiles there, but the LDS is as idle)
+  constexpr bool LDSK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
+                        (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT || VAR == PF_VAR_MM);
   typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
                    (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;
@@ -2082,7 +2084,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr int NKBc = !SH::NT ? 0 : PR ? NKB32c * NP : (SH::NT + CA + CB - 1) / (CA + CB) * (CA + CB);
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
-  constexpr bool LDSK = RESK && SH::NT > 8 && SH::NL == 3;
+  // (also where moment matching runs inside a 16-row sweep: no registers for resident tiles there, but the LDS is as idle)
+  constexpr bool LDSK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
+                        (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT || VAR == PF_VAR_MM);
   typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
                    (SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - ((RESK && SH::NT > 8) ? 8 : 0)> SC;

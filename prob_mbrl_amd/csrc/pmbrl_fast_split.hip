@@ -63,8 +63,10 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
       A.res_w = sd.wf[0];
       sd.wf[0] += (size_t)8 * sd.n_kb[0] * 256;
       sd.n_ot[0] -= 8;
-      // ... and tiles 0..7 of the second streamed layer in LDS where the shape-specialised instance will run
-      // (lds_tile_s; the plan reserved the LDS)
+    }
+    // LDS-resident tiles (lds_tile_s): tiles 0..7 of the SECOND streamed layer, where a shape-specialised 16-row
+    // instance will run (plain variants and in-kernel moment matching; the plan reserved the LDS)
+    if (RT == 1 && CA + CB == 7 && np == 2 && (var == PF_VAR_LEAN || var == PF_VAR_EXT || var == PF_VAR_MM)) {
       bool shaped = false;
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
   if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
@@ -72,15 +74,16 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
     shaped = true;
       PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
 #undef PM_FAST_SHAPED
-      if (shaped && p->wlds_off > 0 && !(A.flags & PMBRL_FLAG_NO_SHAPED) && sd.n == 2 && sd.n_kb[1] == 7 * np &&
-          sd.n_ot[1] > 8) {
-        A.lds_w = sd.wf[1];
-        A.wlds_off = p->wlds_off;
-        A.lds_last_lanes = p->lds_last_lanes;
-        sd.wf[1] += (size_t)8 * sd.n_kb[1] * 256;
-        sd.n_ot[1] -= 8;
-      } else if (shaped) {
-        A.flags |= PMBRL_FLAG_NO_SHAPED;      // (those instances count on the LDS tiles: the generic one then)
+      if (shaped && !(A.flags & PMBRL_FLAG_NO_SHAPED)) {
+        if (p->wlds_off > 0 && sd.n == 2 && sd.n_kb[1] == 7 * np && sd.n_ot[1] > 8) {
+          A.lds_w = sd.wf[1];
+          A.wlds_off = p->wlds_off;
+          A.lds_last_lanes = p->lds_last_lanes;
+          sd.wf[1] += (size_t)8 * sd.n_kb[1] * 256;
+          sd.n_ot[1] -= 8;
+        } else {
+          A.flags |= PMBRL_FLAG_NO_SHAPED;      // (those instances count on the LDS tiles: the generic one then)
+        }
       }
     }
   }
