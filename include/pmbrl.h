@@ -156,6 +156,8 @@ typedef struct pmbrl_config {
  * time alternatives -- and are not needed for normal use: what they override is chosen from the configuration.
  *   PMBRL_FORCE_F32=1       exact-fp32 MFMA sweeps whatever pmbrl_config.precision says
  *   PMBRL_MM_PARTS=n        moment-matching groups split over n workgroups where that can be done (1: whole groups)
+ *   PMBRL_LDS_TILES=0       no LDS-resident weight tiles (pmbrl_fast.h, lds_tile_s): the shape-specialised 16-row
+ *                           split-precision instances count on them, so this launches the generic instances
  *   PMBRL_MM_XCH=0          split groups exchange their rows and meet at a flag barrier (the generic kernel instances)
  *                           instead of exchanging fp64 sums as data-tagged granules (tests; A/B timing)
  *   PMBRL_MM_MODE2=1        groups that span workgroups: separate moment-matching kernels between per-step launches
