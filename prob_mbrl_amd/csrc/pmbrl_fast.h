@@ -2435,13 +2435,13 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         pm_wave_sync();
         pm_mm_bwd_l_tail<DDc>(q, lane, A.M);
         const double inv_m = 1.0 / (double)A.M;
-        for (int e = lane; e < R * D; e += 64) {
-          const int r = e / D, j = e - r * D;
+        for (int e = lane; e < R * DDc; e += 64) {      // (DDc = D here: divisions by a constant)
+          const int r = e / DDc, j = e - r * DDc;
           double acc = 0.0;
-          if (e < nvalid * D) {
+          if (e < nvalid * DDc) {
             acc = q.mbar[j] * inv_m;
 #pragma unroll
-            for (int c = 0; c < DDc; ++c) acc += ((double)xst[r * D + c] - q.mean[c]) * q.P[c * DDc + j];
+            for (int c = 0; c < DDc; ++c) acc += ((double)xst[r * DDc + c] - q.mean[c]) * q.P[c * DDc + j];
           }
           gxt[e] = (float)acc;
         }
