@@ -243,8 +243,10 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
             bundle = RO.Bundle(dynamics, policy, x0_.shape[0], H, not pegasus, not pegasus,
                                mm_states, mm_rewards, mm_groups, z_mm if pegasus else None,
                                z_rr if pegasus else None, precision=prec['name'], **dist_kw)
-            cache = None if need_autograd else _adam_flat_state(opt, bundle.pol_params,
-                                                                bundle.pol_flat)
+            # (per-unit dropout rates: the kernels run on scaled copies of the parameters -- the device-side Adam step
+            #  would update the wrong numbers; the autograd form scales the gradient back)
+            cache = None if (need_autograd or bundle.unit_scaled) else _adam_flat_state(opt, bundle.pol_params,
+                                                                                         bundle.pol_flat)
             if cache is None:
                 loss, states, actions, rewards = _autograd_iteration(
                     x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_rewards, mm_groups, z_mm,

@@ -71,9 +71,19 @@ class BDropout(StochasticModule):
             return hit[1]
         p = (1 - self.rate)
         if p.numel() != 1:
-            raise NotImplementedError('per-unit BDropout rates are not offered on the device path')
+            # per-unit rates (models/modules.py:19-27 takes a tensor): the kernels scale a layer by ONE 1 / p, so
+            # the rollout folds 1 / p_j into row j of the layer that feeds this dropout (unit_inv_keep below;
+            # m_j relu(v_j) / p_j = m_j relu(v_j / p_j): ReLU is positively homogeneous) and runs the layer with 1
+            self._keep_cache = (sig, 1.0)
+            return 1.0
         self._keep_cache = (sig, float(p))
         return self._keep_cache[1]
+
+    def unit_inv_keep(self):
+        """1 / p per unit [width] when the rate is a tensor (see keep_prob), else None."""
+        if type(self) is not BDropout or self.rate.numel() == 1:
+            return None
+        return (1.0 / (1 - self.rate)).detach().reshape(-1).float()
 
     def hard_mask(self, B, width):
         """{0,1} mask [>=B, width]; (re)drawn when the stored one cannot be reused, with the

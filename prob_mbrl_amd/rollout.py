@@ -172,6 +172,11 @@ class Bundle:
         self.spec = dynamics.reward_func.spec(self.D)
         self.pol_keep = [dr.keep_prob() if dr is not None else 1.0 for dr in pdrop]
         self.dyn_keep = [dr.keep_prob() if dr is not None else 1.0 for dr in ddrop]
+        # per-unit Bernoulli rates: 1 / p_j folded into row j of the Linear in front of the dropout (models.BDropout.
+        # unit_inv_keep); the kernels then see scaled COPIES of the parameters and the gradient is scaled back
+        self.pol_unit = self._unit_rows(pdrop, self.pol_dims, dev)
+        self.dyn_unit = self._unit_rows(ddrop, self.dyn_dims, dev)
+        self.unit_scaled = bool(self.pol_unit)
         # masks (frozen unless resampled by the caller through .resample())
         self.pol_bits, self.dyn_bits = [], []
 
@@ -261,7 +266,41 @@ class Bundle:
                 raise ValueError('mm_span needs the process_group whose ranks share the groups')
             self.engine.attach_collective(process_group)
 
+    @staticmethod
+    def _unit_rows(drops, dims, dev):
+        """[(offset of W_l, offset of b_l, out, in, 1 / p [out])] of the layers followed by a per-unit BDropout, in the
+        flat parameter order W0, b0, W1, b1, ..."""
+        rows, off = [], 0
+        for l in range(len(dims) - 1):
+            n_in, n_out = dims[l], dims[l + 1]
+            dr = drops[l] if l < len(drops) else None
+            inv = dr.unit_inv_keep() if dr is not None and hasattr(dr, 'unit_inv_keep') else None
+            if inv is not None:
+                if inv.numel() != n_out:
+                    raise ValueError('BDropout rate has %d entries, its layer %d units' % (inv.numel(), n_out))
+                rows.append((off, off + n_out * n_in, n_out, n_in, inv.to(dev)))
+            off += n_out * n_in + n_out
+        return rows
+
+    @staticmethod
+    def scale_unit_rows(flat, rows):
+        """flat with row j of every listed W (and b_j) multiplied by 1 / p_j: the parameters the kernels see, and --
+        applied to the gradient they return -- dL/d(the module's parameters)."""
+        if not rows:
+            return flat
+        out = flat.clone()
+        for ow, ob, n_out, n_in, inv in rows:
+            out[ow:ow + n_out * n_in].view(n_out, n_in).mul_(inv[:, None])
+            out[ob:ob + n_out].mul_(inv)
+        return out
+
     def forward(self, x0, out=None):
+        if self.pol_unit or self.dyn_unit:
+            return self.engine.forward(x0, self.scale_unit_rows(self.pol_flat, self.pol_unit),
+                                       self.scale_unit_rows(self.dyn_flat, self.dyn_unit), self.mx, self.iSx, self.my,
+                                       self.Sy, self.scale, self.bias, self.pol_bits, self.dyn_bits,
+                                       self.z_pol, self.z_dyn, self.z_mm, self.z_rr, out=out, z_pi=self.z_pi,
+                                       u_cat=self.u_cat)
         return self.engine.forward(x0, self.pol_flat, self.dyn_flat, self.mx, self.iSx, self.my,
                                    self.Sy, self.scale, self.bias, self.pol_bits, self.dyn_bits,
                                    self.z_pol, self.z_dyn, self.z_mm, self.z_rr, out=out, z_pi=self.z_pi,
@@ -302,7 +341,7 @@ class RolloutFunction(torch.autograd.Function):
                                    want_agn=agn_out is not None)
         if agn_out is not None:
             agn_out.append(agn)
-        g = g.clone()
+        g = bundle.scale_unit_rows(g, bundle.pol_unit) if bundle.pol_unit else g.clone()
         grads, off = [], 0
         for p in bundle.pol_params:
             n = p.numel()

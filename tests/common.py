@@ -13,7 +13,7 @@ def fixture_names(kind=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
     if kind == 'iter':
         return [n for n in names if not n.startswith(('mcp_', 'ext_', 'standalone_', 'bnn_', 'experience_', 'critic_', 'bnnopt_',
-                                                      'trunc_', 'draw_'))]
+                                                      'trunc_', 'draw_', 'unit_'))]
     if kind == 'bnn':
         return [n for n in names if n.startswith('bnn_')]
     if kind == 'standalone':
@@ -100,7 +100,10 @@ def modules_from_fixture(d, name, device='cuda:0'):
     maxU = np.asarray(d['pol_scale'], dtype=np.float32)
     pol = pm.models.Policy(
         pm.models.mlp(D + len(pad), 2 * U, pol_hid,
-                      dropout_layers=[pm.models.BDropout(0.1) for _ in pol_hid],
+                      # (per-unit rates where the fixture recorded them: models/modules.py:19-27 takes a tensor)
+                      dropout_layers=[pm.models.BDropout(torch.tensor(np.asarray(d['pol_rate%d' % i], dtype=np.float32))
+                                                         if 'pol_rate%d' % i in d else 0.1)
+                                      for i in range(len(pol_hid))],
                       nonlin=torch.nn.ReLU,
                       output_nonlin=partial(pm.models.DiagGaussianDensity, U)), maxU, -maxU, angle_dims=pad).float()
     fill_modules(dyn, pol, d)

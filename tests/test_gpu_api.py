@@ -55,7 +55,22 @@ def test_rollout_resamples_masks_every_step(monkeypatch):
     assert torch.isfinite(torch.stack(s2)).all()
 
 
-@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if not n.startswith('stepmask')])
+def test_mc_pilco_with_per_unit_dropout_rates_steps():
+    """mc_pilco on a policy with per-unit dropout rates: the device-side Adam step is not taken (it would update the
+    scaled copies' originals with the wrong gradient); the autograd form runs, the loss is finite, parameters move."""
+    import prob_mbrl_amd as pm
+    d = common.load('unit_rates_d4')
+    dyn, pol = common.modules_from_fixture(d, 'unit_rates_d4', DEV)
+    opt = torch.optim.Adam(pol.parameters(), 1e-3)
+    before = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
+    x0 = torch.tensor(d['x0'], device=DEV)
+    pm.algorithms.mc_pilco(x0, dyn, pol, int(d['H']), opt, opt_iters=3, pegasus=True)
+    after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    assert torch.isfinite(after).all() and not torch.equal(after, before)
+
+
+@pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if not n.startswith('stepmask')] +
+                         ['unit_rates_d4', 'unit_rates_d4_mmg'])
 def test_rollout_autograd_matches_reference(name):
     """utils.rollout + the reference's loss + loss.backward() (algorithms/mc_pilco.py:134-197)."""
     import prob_mbrl_amd as pm

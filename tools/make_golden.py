@@ -138,7 +138,7 @@ def reward_spec(rew, D):
 # model construction exactly as examples/deep_pilco_mm.py:117-151
 # ---------------------------------------------------------------------------
 def build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_drop=0.1, dyn_drop=0.1,
-          n_data=300, y_scale=0.01, pol_angle_dims=(), dyn_angle_dims=()):
+          n_data=300, y_scale=0.01, pol_angle_dims=(), dyn_angle_dims=(), pol_unit_rates=False):
     torch.manual_seed(seed)
     np.random.seed(seed)
     pol_angle_dims, dyn_angle_dims = list(pol_angle_dims or ()), list(dyn_angle_dims or ())
@@ -155,7 +155,9 @@ def build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_drop=0.1, dyn_drop=0.1,
     pol_model = models.mlp(
         D + len(pol_angle_dims), 2 * U, pol_hid,
         dropout_layers=[
-            models.modules.BDropout(pol_drop) if pol_drop > 0 else None
+            # (per-unit rates: models/modules.py:19-27 takes a tensor)
+            models.modules.BDropout(torch.linspace(0.05, 0.35, hid) if pol_unit_rates else pol_drop)
+            if pol_drop > 0 else None
             for hid in pol_hid
         ],
         nonlin=torch.nn.ReLU,
@@ -196,6 +198,10 @@ def capture_inputs(dyn, pol, x0, H, gamma, mm_states, mm_rewards, mm_groups,
             dr = drops[i]
             if isinstance(dr, models.modules.CDropout):
                 d['pol_mask%d' % i] = f(dr.concrete_noise)
+                scales.append(1.0)
+            elif dr.p.numel() > 1:      # per-unit rates: recorded as such, the scalar slot says 1
+                d['pol_mask%d' % i] = f(dr.noise)
+                d['pol_rate%d' % i] = dr.rate.detach().double().cpu().numpy().reshape(-1)
                 scales.append(1.0)
             else:
                 d['pol_mask%d' % i] = f(dr.noise)
@@ -299,12 +305,12 @@ def _patch_build_odims():
 def make_case(name, D, U, dyn_hid, pol_hid, rew_fn, maxU, B, H, mm=False,
               mm_groups=None, discount=None, seed=0, infer_ns=False,
               maximize=True, x0_scale=0.1, P=None, weight_seed=None, pol_angle_dims=None,
-              dyn_angle_dims=None):
+              dyn_angle_dims=None, pol_unit_rates=False):
     rew = rew_fn()
     if pol_angle_dims or dyn_angle_dims:
         _patch_build_odims()
     dyn, pol = build(D, U, dyn_hid, pol_hid, rew, maxU, seed, pol_angle_dims=pol_angle_dims,
-                     dyn_angle_dims=dyn_angle_dims)
+                     dyn_angle_dims=dyn_angle_dims, pol_unit_rates=pol_unit_rates)
     if weight_seed is not None:
         # wide networks: the weights come from a seed (oracle.ref_torch.seeded_weights) so that the
         # fixture does not have to carry megabytes of them
@@ -1153,6 +1159,13 @@ CASES = {
     # BASELINE synthetic shape: raw 4-D state, angle expanded inside the reward
     'nomm_d4': lambda: make_case('nomm_d4', 4, 1, [32, 32], [32, 32],
                                  _cartpole, 10.0, 40, 12, seed=2, P=8),
+    # per-unit Bernoulli dropout rates in the policy (models/modules.py:19-27 takes a tensor), with and without
+    # moment matching; not an 'iter' fixture (the oracle keeps one rate per layer): replayed through the module API
+    'unit_rates_d4': lambda: make_case('unit_rates_d4', 4, 1, [32, 32], [32, 32],
+                                       _cartpole, 10.0, 40, 12, seed=61, P=8, pol_unit_rates=True),
+    'unit_rates_d4_mmg': lambda: make_case('unit_rates_d4_mmg', 4, 1, [32, 32], [32, 32],
+                                           _cartpole, 10.0, 40, 12, seed=62, P=8, mm=True, mm_groups=8,
+                                           pol_unit_rates=True),
     'nomm_h1': lambda: make_case('nomm_h1', 4, 1, [16, 16], [16, 16],
                                  _cartpole, 10.0, 7, 1, seed=3),
     'nomm_h40_disc': lambda: make_case('nomm_h40_disc', 4, 1, [24, 24], [24, 24],
