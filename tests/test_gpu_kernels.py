@@ -662,3 +662,27 @@ def test_in_place_layers_at_64_rows_per_workgroup(dev, name):
     for _, _, S, g in out:
         assert common.rel(S, d['ref64_states']) < TOL_TRAJ and common.rel(g, d['ref64_grad']) < TOL_GRAD
     assert common.rel(out[1][2], out[0][2]) < 1e-6 and common.rel(out[1][3], out[0][3]) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['full200_nomm', 'full200_mmg'])
+def test_lds_resident_tiles_match_the_streamed_form(dev, name, monkeypatch):
+    """The shape-specialised 16-row instances keep 8 weight tiles of the second streamed layer in LDS (pmbrl_fast.h:
+    lds_tile_s) -- plain variants and in-kernel moment matching; PMBRL_LDS_TILES=0 runs the same plan on the generic
+    instances, which stream every tile: same fixtures, same tolerances, and the two agree."""
+    d = common.load(name)
+    B = d['x0'].shape[0]
+    gw = torch.tensor(common.loss_weights(d, B), device=dev)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('PMBRL_LDS_TILES', '0')
+        eng, args, _ = common.engine_from_fixture(d, dev)
+        S, A, Rw = eng.forward(**args)
+        g = eng.backward(gw)[0].cpu().numpy().copy()
+        assert eng.valid_steps() == int(d['H']) and eng.info['fast'] and eng.info['rows_per_wg'] <= 16
+        out.append((eng.info['lds_bytes'], S.cpu().numpy(), g))
+    monkeypatch.delenv('PMBRL_LDS_TILES')
+    assert out[0][0] > out[1][0] + 100 * 1024          # (8 tiles of 13 KB)
+    for _, S, g in out:
+        assert common.rel(S, d['ref64_states']) < TOL_TRAJ and common.rel(g, d['ref64_grad']) < TOL_GRAD
+    assert common.rel(out[1][1], out[0][1]) < 2e-6 and common.rel(out[1][2], out[0][2]) < 2e-5
