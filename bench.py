@@ -311,6 +311,21 @@ def pmc_traffic(config, prec, kname, world):
     return None, None
 
 
+def pmc_mfma(config, prec, kname, world):
+    """MFMA busy cycles (per cent of all SIMD cycles) and flops issued per launch of the dominant kernel from the matrix
+    cores' own counters (rocprofv3 --pmc MfmaUtil / SQ_INSTS_VALU_MFMA_MOPS_*; tools/collect_mfma_util.sh): like the
+    HBM traffic, the committed measurement of this configuration, not a reading taken during the run."""
+    if world != 1:
+        return None
+    src = 'profiles/r03_mfma_util_%s.json' % prec
+    try:
+        e = json.load(open(os.path.join(ROOT, src)))['configs'][config][kname]
+        return dict(mfma_util_pct=e.get('mfma_util_pct'), flops_issued_per_launch=e.get('flops_issued_per_launch'),
+                    measured_in_run=False, source=src)
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     from prob_mbrl_amd import problem as PB
@@ -407,6 +422,7 @@ def main():
         roof, kname = leg.roofline(timings)
         traffic, traffic_src = pmc_traffic(a.config, prec, kname, world)
         roof.update(traffic=traffic, traffic_measured_in_run=False, traffic_source=traffic_src)
+        roof['mfma_counters'] = pmc_mfma(a.config, prec, kname, world)
         dtype = {'f32': 'f32', 'split': 'f32 via split bf16 MFMA (3 pieces fwd / 2 adjoint), fp32 accumulate',
                  'split_f16': 'f32 via split fp16 (fwd, 2 pieces) / bf16 (adjoint, 2 pieces) MFMA, fp32 accumulate'}[prec]
         out = dict(
