@@ -844,12 +844,21 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       (p->pol.nt[1] == 13 || p->pol.nt[1] == 14) && !(c.flags & PMBRL_FLAG_NO_SHAPED) &&
       !(getenv("PMBRL_LDS_TILES") && atoi(getenv("PMBRL_LDS_TILES")) == 0)) {
     const int last_lanes = 16 * ((16 * p->pol.nt[1] - 32 * 6) / 8);
-    const size_t base = (p->lds_bytes + 15) / 16 * 16;
+    size_t base = (p->lds_bytes + 15) / 16 * 16;
+    if (p->mm_parts > 1) {
+      // split groups: the instances that hold the tiles exchange sums and never touch the row blocks of the rows +
+      // flags form, the generic instances that use those never copy tiles: the two share the end of the LDS (a
+      // 100-row group in seven parts would not fit both)
+      const int mw = 1;
+      base = pm_fast_rows_area_off(16 * p->RT, p->LD, c.D, c.U, p->RT, p->pol.nt, p->pol.nl, p->dyn.nt, p->dyn.nl, c.D,
+                                   prec_for(p->RT), mw, p->M, c.H) * sizeof(float);
+      base = (base + 15) / 16 * 16;
+    }
     const size_t tiles = (size_t)PF_NW * pm_lds_tile_floats(14, 2, last_lanes) * sizeof(float);
     if (base + tiles <= lds_cap) {
       p->wlds_off = (int)(base / sizeof(float));
       p->lds_last_lanes = last_lanes;
-      p->lds_bytes = base + tiles;
+      p->lds_bytes = std::max(p->lds_bytes, base + tiles);
     }
   }
 

@@ -1149,6 +1149,14 @@ __host__ __device__ inline bool pm_fast_hp_alias(int R, int LD, int RT) {
 }
 
 #define PM_XIN_LD 24             // = 8 (mod 16): conflict-free ds_read_b128 of the MFMA B operand
+// LDS of the statistics exchange of split groups (behind wave 0's moment-matching scratch): the reference point (8),
+// the z standardisation [zm | zi] of every step of the launch, and two staging sets, alternating between steps, of
+// what wave 1 fetches a step ahead while wave 0 works -- the part's noise rows (forward sweep); scratch with the
+// factor, the part's pre-mm rows and noise rows (adjoint).  A multiple of 4 floats.
+__host__ __device__ inline size_t pm_fast_xch_floats(int R, int d, int steps) {
+  const size_t n = 8 + 2 * (size_t)steps * 2 * d + 2 * (2 * pm_mm_scratch_doubles(d) + 2 * (size_t)R * d);
+  return (n + 3) & ~(size_t)3;
+}
 __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U, int RT,
                                                      const int* pnt, int pnl, const int* dnt,
                                                      int dnl, int mm_d, int prec = 0, int mm_waves = PF_NW,
@@ -1173,12 +1181,18 @@ __host__ __device__ inline size_t pm_fast_lds_floats(int R, int LD, int D, int U
     if (tw) n += (size_t)PF_NW * RT * 256 + 4 + tw;   // tp, tcnt, tw
   }
   n += 2 * (size_t)mm_waves * pm_mm_scratch_doubles(mm_d);
-  // (+ statistics exchange: the reference point, the z standardisation [zm | zi] of every step of the launch)
-  //  and two staging sets, alternating between steps, of what wave 1 fetches a step ahead while wave 0 works: the
-  //  part's noise rows (forward sweep); scratch with the factor, the part's pre-mm rows, its noise rows (adjoint)
-  n += 4 * (size_t)mm_group_rows * mm_d +
-       (mm_group_rows ? 8 + 2 * (size_t)mm_steps * 2 * mm_d + 2 * (2 * pm_mm_scratch_doubles(mm_d) + 2 * (size_t)R * mm_d) : 0);
+  // split groups: what the statistics exchange keeps (pm_fast_xch_floats), then -- LAST, so that the LDS-resident weight
+  // tiles of the instances that never exchange rows can take its place (pm_fast_rows_area_off) -- four row blocks of
+  // the whole group for the rows + flags form
+  if (mm_group_rows) n += pm_fast_xch_floats(R, mm_d, mm_steps) + 4 * (size_t)mm_group_rows * mm_d;
   return n;
+}
+// where the row blocks of the rows + flags form start (floats from the LDS base)
+__host__ __device__ inline size_t pm_fast_rows_area_off(int R, int LD, int D, int U, int RT, const int* pnt, int pnl,
+                                                        const int* dnt, int dnl, int mm_d, int prec, int mm_waves,
+                                                        int mm_group_rows, int mm_steps) {
+  return pm_fast_lds_floats(R, LD, D, U, RT, pnt, pnl, dnt, dnl, mm_d, prec, mm_waves, mm_group_rows, mm_steps) -
+         4 * (size_t)mm_group_rows * mm_d;
 }
 
 // (pnt / dnt: 16-wide tile counts of layer inputs / outputs, nl + 1 entries each)
@@ -1676,12 +1690,14 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   const bool mm_xch = mm_pair && XW && (A.xch != nullptr);
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
   const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
-  float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
+  // LDS behind wave 0's scratch: the statistics exchange's (mmx), then the row blocks of the rows + flags form (mmg)
+  float* const mmx = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
+  float* const mmg = mmx + (mm_pair ? pm_fast_xch_floats(R, D, A.H) : 0);
   // (statistics exchange: the first reference point is the group's first row, which every part can read)
-  if (mm_xch && tid < D) mmg[4 * A.M * D + tid] = ((T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D)[(size_t)mmp_g0 * D + tid];
+  if (mm_xch && tid < D) mmx[tid] = ((T0 == 0) ? A.x0 : A.states + (size_t)T0 * B * D)[(size_t)mmp_g0 * D + tid];
   // ... and the standardisation of the group's noise rows, mean and 1 / std per column, for every step of the launch
   // (the noise is an input: nothing of it waits for the recursion)
-  double* const mmzt = reinterpret_cast<double*>(mmg + 4 * A.M * D + 8);      // [T1 - T0][zm (D) | zi (D)]
+  double* const mmzt = reinterpret_cast<double*>(mmx + 8);      // [T1 - T0][zm (D) | zi (D)]
   // this part's noise rows, two sets [R][D] (step t in set t & 1): fetched a step ahead by wave 1 while wave 0 works
   float* const mmzs = reinterpret_cast<float*>(mmzt + (size_t)A.H * 2 * D);
   if (mm_xch) {
@@ -1925,7 +1941,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       // places hold the reference point: they add nothing), adds the other parts' sums (pm_xch_sum) and goes on as
       // if it had seen the whole group -- no row exchange, no flag barrier, the same bits in every part
       constexpr int DDc = (SH::D >= 1 && SH::D <= 6) ? SH::D : 1;
-      float* const mmc = mmg + 4 * A.M * D;      // the reference point
+      float* const mmc = mmx;      // the reference point
       __syncthreads();                            // this step's sampled rows (xb) are complete
       PF_MARK(28);
       if (wid == 0) {
@@ -2304,11 +2320,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   const bool mm_xch = mm_pair && XW && (A.xch != nullptr);
   const int mmp_first = mm_pair ? (wg / A.mm_parts) * A.mm_parts : 0;
   const int mmp_g0 = mm_pair ? (wg / A.mm_parts) * A.M : 0;
-  float* const mmg = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));
+  float* const mmx = reinterpret_cast<float*>(L.mm + pm_mm_scratch_doubles(D));      // (layout: see the forward sweep)
+  float* const mmg = mmx + (mm_pair ? pm_fast_xch_floats(R, D, A.H) : 0);
   // statistics exchange: two staging sets (step t in set t & 1) of [scratch with the forward sweep's factor | this
   // part's pre-mm rows [R][D] | its noise rows [R][D]], fetched a step ahead by wave 1 while wave 0 works
   const size_t mmst_set = 2 * pm_mm_scratch_doubles(D) + 2 * (size_t)R * D;      // floats
-  float* const mmst = mmg + 4 * A.M * D + 8 + 2 * (size_t)A.H * 2 * D;
+  float* const mmst = mmx + 8 + 2 * (size_t)A.H * 2 * D;
   auto mm_stage = [&](int ts, int i0, int istep) {
     float* set = mmst + (size_t)(ts & 1) * mmst_set;
     double* fdst = reinterpret_cast<double*>(set);
