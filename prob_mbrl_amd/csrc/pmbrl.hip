@@ -839,7 +839,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   // PMBRL_LDS_TILES=0: off.
   p->wlds_off = 0;
   p->lds_last_lanes = 0;
-  if (p->fast && p->RT == 1 && p->prec != 0 && p->CA + p->CB == 7 && p->pol.nl == 3 && p->dyn.nl == 3 &&
+  if (p->fast && p->RT == 1 && p->prec == PMBRL_PREC_SPLIT_F16 && p->CA + p->CB == 7 && p->pol.nl == 3 && p->dyn.nl == 3 &&
       p->pol.nt[1] == p->dyn.nt[1] && p->pol.nt[2] == p->pol.nt[1] && p->dyn.nt[2] == p->pol.nt[1] &&
       (p->pol.nt[1] == 13 || p->pol.nt[1] == 14) && !(c.flags & PMBRL_FLAG_NO_SHAPED) &&
       !(getenv("PMBRL_LDS_TILES") && atoi(getenv("PMBRL_LDS_TILES")) == 0)) {

@@ -1536,7 +1536,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
   // (also where moment matching runs inside a 16-row sweep: no registers for resident tiles there, but the LDS is as idle)
-  constexpr bool LDSK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
+  // (fp16-piece build only: the bf16-piece build's activation planes leave no room for eight tiles)
+  constexpr bool LDSK = PR == 2 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
                         (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT || VAR == PF_VAR_MM);
   typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,
@@ -2101,7 +2102,8 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr bool RESK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT);
   // ... and LDS-resident first tiles of the second streamed layer (lds_tile_s): two streamed layers, compile-time shape
   // (also where moment matching runs inside a 16-row sweep: no registers for resident tiles there, but the LDS is as idle)
-  constexpr bool LDSK = PR != 0 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
+  // (fp16-piece build only: the bf16-piece build's activation planes leave no room for eight tiles)
+  constexpr bool LDSK = PR == 2 && NP == 2 && RT == 1 && CA + CB == 7 && SH::NT > 8 && SH::NL == 3 &&
                         (VAR == PF_VAR_LEAN || VAR == PF_VAR_EXT || VAR == PF_VAR_MM);
   typedef PfStream<(SH::NT ? SH::NT - (SKS_KNOWN ? 1 : 0) : 0) - (LDSK ? 8 : 0), NKBc,
                    (SH::NT && SH::NL) ? 2 * (SH::NL - 2) : 0,

@@ -66,7 +66,7 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
     }
     // LDS-resident tiles (lds_tile_s): tiles 0..7 of the SECOND streamed layer, where a shape-specialised 16-row
     // instance will run (plain variants and in-kernel moment matching; the plan reserved the LDS)
-    if (RT == 1 && CA + CB == 7 && np == 2 && (var == PF_VAR_LEAN || var == PF_VAR_EXT || var == PF_VAR_MM)) {
+    if (PR == 2 && RT == 1 && CA + CB == 7 && np == 2 && (var == PF_VAR_LEAN || var == PF_VAR_EXT || var == PF_VAR_MM)) {
       bool shaped = false;
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
   if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \
