@@ -344,8 +344,11 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                     if bad:
                         raise RuntimeError('adjoint sweep: a barrier between workgroups timed out')
                 if world > 1:
-                    from .distributed import grad_allreduce
+                    from .distributed import grad_allreduce, p2p_check
                     grad_allreduce(process_group, dev)(g)     # RCCL on the compute stream (C ABI)
+                    # (peer-to-peer transport: a wait that timed out anywhere -- this gradient, or the per-step
+                    #  statistics of groups spread over the ranks -- fails the iteration on every rank)
+                    p2p_check(process_group, dev)
                 if reg_weight > 0:
                     # algorithms/mc_pilco.py:193-194: a function of the parameters alone, the same on every rank
                     policy.zero_grad()
@@ -385,11 +388,24 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                             x0_tree.append(x, x0_tree.max_p)
                             x0_tree.renormalize()
                     episode_counter = exp.n_episodes()
-                # sharded run: every rank holds the same tree and draws the same GLOBAL sample (numpy's generator:
-                # seed it alike on every rank, as one process would be seeded once), then keeps its slice of the
-                # start states and importance weights; the priorities of the whole sample are updated on every
-                # rank from the gathered norms (_update_priorities), so the replicas of the tree stay identical
-                xs, replay['idxs'], w = x0_tree.sample(n_draw * world, beta=replay['beta'])
+                # sharded run: every rank holds the same tree and uses the same GLOBAL sample (drawn by rank 0), then keeps
+                # its slice of the start states and importance weights; the priorities of the whole sample are updated
+                # on every rank from the gathered norms (_update_priorities), so the replicas of the tree stay identical
+                if world > 1:
+                    # ONE draw for all ranks: rank 0's (the replicas' numpy generators are not assumed in step -- a
+                    # single user draw on one rank would silently give the ranks different samples, weights and,
+                    # through _update_priorities, different trees)
+                    import torch.distributed as dist
+                    box = [None]
+                    if rank == 0:
+                        xs, idxs0, w = x0_tree.sample(n_draw * world, beta=replay['beta'])
+                        box = [(np.asarray(idxs0), np.asarray(w))]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0), group=process_group)
+                    replay['idxs'], w = box[0]
+                    if rank != 0:
+                        xs = x0_tree.replay_sample(replay['idxs'])
+                else:
+                    xs, replay['idxs'], w = x0_tree.sample(n_draw * world, beta=replay['beta'])
                 # (sic) max, not min: beta never drops below 1 (mc_pilco.py:240-241)
                 replay['beta'] = max(1.0, replay['beta'] + priority_beta_increase)
                 lo_r, hi_r = rank * n_draw, (rank + 1) * n_draw
@@ -472,6 +488,8 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
     if world > 1:
         import torch.distributed as dist
         dkw = {k: v for k, v in (dist_kw or {}).items() if v is not None}
+        # every rank keeps the horizon of the slowest one and retries / raises with it (rollout(): agree_group)
+        dkw['agree_group'] = process_group
     policy.zero_grad()
     opt.zero_grad()
     weighted = replay is not None and replay['idxs'] is not None
@@ -521,6 +539,8 @@ def _autograd_iteration(x0_, dynamics, policy, H, opt, pegasus, mm_states, mm_re
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
         tot = torch.cat([flat, loss.detach().reshape(1)])
         grad_allreduce(process_group, tot.device)(tot)
+        from .distributed import p2p_check
+        p2p_check(process_group, tot.device)
         off = 0
         for p in params:
             p.grad = tot[off:off + p.numel()].reshape(p.shape).clone()

@@ -301,7 +301,9 @@ __global__ void pm_pack_all(const PackArgs P) {
           if (j.f16) {
             if (p == 0 && P.wflag && (!(fabsf(v[2 * e]) <= 65504.f) || !(fabsf(v[2 * e + 1]) <= 65504.f)))
               atomicMax(P.wflag, P.gen);
-            w[e] = pm_pk_f16(v[2 * e], v[2 * e + 1]);
+            // (the low piece is stored scaled by 2^11: pmbrl_split.h, PM_F16_LO_SCALE)
+            const float sc = p ? PM_F16_LO_SCALE : 1.f;
+            w[e] = pm_pk_f16(v[2 * e] * sc, v[2 * e + 1] * sc);
             const pm_f32x2 f = pm_unpk_f16(w[e]);
             v[2 * e] -= f[0];
             v[2 * e + 1] -= f[1];

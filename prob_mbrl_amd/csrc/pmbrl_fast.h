@@ -557,7 +557,7 @@ __device__ __forceinline__ void stream_layer_s(const SdV& sd, int li, Cursor& q,
     if (prof && pslot < 32) prof[pslot++] = (long long)__builtin_readcyclecounter();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      pacc[rt] = acc[0][rt] + acc[1][rt];
+      pacc[rt] = pm_chains_sum<F16, NP>(acc[0][rt], acc[1][rt]);
       ppre[rt] = pre[rt];
     }
     pot = ot + ot_base;
@@ -590,7 +590,7 @@ __device__ __forceinline__ void resident_tile_s(const FragS<NB * NP>& w, const f
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     epi.landed(pre[rt], rt);
-    epi(ot, rt, acc[0][rt] + acc[1][rt], pre[rt]);
+    epi(ot, rt, pm_chains_sum<F16, NP>(acc[0][rt], acc[1][rt]), pre[rt]);
   }
 }
 
@@ -642,14 +642,15 @@ __device__ __forceinline__ void lds_tile_s(const float* wl, int last_lanes, cons
     for (int q = 0; q < PP::N; ++q)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        acc[q & 1][rt] = pm_mfma_bf<F16>(w[blk][PP::W[q]], b[cur].v[PP::A[q]][rt], acc[q & 1][rt]);
+        acc[pm_chain<F16, NP>(q)][rt] =
+            pm_mfma_bf<F16>(w[blk][PP::W[q]], b[cur].v[PP::A[q]][rt], acc[pm_chain<F16, NP>(q)][rt]);
     __builtin_amdgcn_sched_barrier(0);
   }
   Epi::wait_all();
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     epi.landed(pre[rt], rt);
-    epi(ot, rt, acc[0][rt] + acc[1][rt], pre[rt]);
+    epi(ot, rt, pm_chains_sum<F16, NP>(acc[0][rt], acc[1][rt]), pre[rt]);
   }
 }
 // floats of one such tile in LDS

@@ -12,7 +12,10 @@
 // by the owner's loads whatever XCD's L2 either runs behind.  Why two slot sets suffice: a rank starts call g + 2
 // (which reuses the set of call g) only after it finished call g + 1, i.e. after it saw every peer's flag of call g + 1,
 // which a peer raises only after its own call g kernel -- the last reader of this rank's call-g data there -- ended.
-// Waits are bounded (~1 s): a peer that never arrives sets the error word instead of hanging the device.
+// Waits are bounded (tens of seconds, PMBRL_P2P_TIMEOUT_SPINS): a peer that never arrives sets the error word instead
+// of hanging the device; the callers read that word at their per-iteration host sync and agree on it across ranks
+// (distributed.p2p_check) -- a timed-out exchange leaves the buffer un-reduced, which must never be used silently.
+#include <cstdlib>
 #include <cstring>
 #include "pmbrl_host.h"
 
@@ -27,6 +30,7 @@ struct pmbrl_p2p {
   bool opened[PM_P2P_MAX_RANKS];
   unsigned gen;                     // calls so far
   int* err_d;                       // device word: set when a wait timed out
+  long long max_spins;              // polls of one flag before a wait gives up (PMBRL_P2P_TIMEOUT_SPINS)
 };
 
 // layout of a region: flags [MAX_RANKS][BLOCKS] unsigned (padded to 4 KB), then slots [2][MAX_RANKS][cap]
@@ -40,6 +44,7 @@ struct P2PArgs {
   size_t cap;
   long long n;
   int* err;
+  long long max_spins;
 };
 
 template <typename T>
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(PM_P2P_THREADS) void pm_p2p_allreduce_kernel(const 
     long long spins = 0;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.gen) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > 2000000ll) {     // (a few seconds)
+      if (++spins > A.max_spins) {     // (default: tens of seconds -- a late peer is waited for, a dead one is not)
         ok_s = 0;
         atomicExch(A.err, 1);
         break;
@@ -97,6 +102,13 @@ extern "C" int pmbrl_p2p_create(int32_t rank, int32_t nranks, int32_t device, in
   memset(p, 0, sizeof(*p));
   p->rank = rank; p->nranks = nranks; p->device = device;
   p->cap = ((size_t)max_bytes + 255) / 256 * 256;
+  // A rank can be seconds late (a plan rebuilt for a precision retry, a host callback, first-call skew): the wait
+  // must outlast that -- what it must not outlast is a peer that died.  ~1.5 us per poll: 20 M polls ~ 30 s.
+  p->max_spins = 20000000ll;
+  if (const char* e = getenv("PMBRL_P2P_TIMEOUT_SPINS")) {
+    const long long v = atoll(e);
+    if (v > 0) p->max_spins = v;
+  }
   void* mem = nullptr;
   // uncached: remote stores and local loads of the same bytes meet in memory, not in some XCD's L2
   if (hipExtMallocWithFlags(&mem, p2p_region_bytes(p->cap), hipDeviceMallocUncached) != hipSuccess) {
@@ -146,6 +158,7 @@ static int p2p_allreduce(pmbrl_p2p* p, void* stream, T* buf_d, int64_t n) {
   P2PArgs A;
   for (int q = 0; q < PM_P2P_MAX_RANKS; ++q) A.region[q] = q < p->nranks ? p->region[q] : nullptr;
   A.rank = p->rank; A.nranks = p->nranks; A.cap = p->cap; A.n = n; A.err = p->err_d;
+  A.max_spins = p->max_spins;
   A.gen = ++p->gen;
   hipLaunchKernelGGL(pm_p2p_allreduce_kernel<T>, dim3(PM_P2P_BLOCKS), dim3(PM_P2P_THREADS), 0, (hipStream_t)stream, A, buf_d);
   HIPCHK(hipGetLastError());

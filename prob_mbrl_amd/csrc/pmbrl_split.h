@@ -44,6 +44,50 @@ __device__ __forceinline__ f32x4 pm_mfma_bf(f32x4 a, f32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pm_bf16x8, a), __builtin_bit_cast(pm_bf16x8, b), c,
                                                    0, 0, 0);
 }
+// fp16 pieces, the weights' LOW piece: |w - hi| <= 2^-11 |w| is below fp16's normal range (6.1e-5) for every
+// |w| < 0.125 -- all of a Xavier-initialised hidden layer -- and a subnormal low piece keeps 2^-24 ABSOLUTE, not eleven
+// more bits: measured (tools/c5_precision_study.py, rows "w.lo * 2^11"; profiles/r04_c5_precision_study.txt), the trajectory
+// error of the two-piece arithmetic was 2.1x the exact-fp32 one's for that reason alone, and 4x as many ReLU units
+// changed sign against fp64 at the 3 x 512 shape.  So the low piece is stored as fp16((w - hi) * 2^11) -- the same
+// magnitude as w, eleven good bits whenever hi has them -- and the one piece product that uses it (lo x act.hi)
+// accumulates in a chain of its own that enters the result through ONE fma with 2^-11 (exact): no extra instruction
+// against the sum of two chains the kernels ended with before.  Activations keep their plain low piece: its
+// quantisation (|h| < 0.125) is an absolute 3e-8 |w| per term, below fp32's own rounding of the sum.
+#define PM_F16_LO_SCALE 2048.f
+#define PM_F16_LO_ISCALE (1.f / 2048.f)
+// accumulator chain of piece product q of PmPairs<NP>: fp16 pieces -- chain 0 = the product with the weight's low
+// piece, chain 1 = the rest; bf16 pieces -- alternating (two chains cover the dependent-MFMA latency)
+template <bool F16, int NP>
+__device__ __forceinline__ constexpr int pm_chain(int q) {
+  return (F16 && NP == 2) ? (q == 0 ? 0 : 1) : (q & 1);
+}
+template <bool F16, int NP>
+__device__ __forceinline__ f32x4 pm_chains_sum(f32x4 c0, f32x4 c1) {
+  if constexpr (F16 && NP == 2) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(c0[i], PM_F16_LO_ISCALE, c1[i]);
+    return r;
+  } else {
+    return c0 + c1;
+  }
+}
+// ... and where a routine kept ONE accumulator per output tile (the general family): a pair under fp16 pieces
+template <bool F16>
+struct PmAcc {
+  f32x4 h;
+  __device__ __forceinline__ void zero() { h = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ f32x4& chain(int) { return h; }
+  __device__ __forceinline__ f32x4 value() const { return h; }
+};
+template <>
+struct PmAcc<true> {
+  f32x4 h, l;
+  __device__ __forceinline__ void zero() { h = l = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ f32x4& chain(int wpiece) { return wpiece ? l : h; }
+  __device__ __forceinline__ f32x4 value() const { return pm_chains_sum<true, 2>(l, h); }
+};
+
 // two fp32 -> packed fp16 pair (round to nearest even) and back
 __device__ __forceinline__ unsigned pm_pk_f16(float a, float b) {
   const pm_f16x2 r = __builtin_convertvector((pm_f32x2){a, b}, pm_f16x2);
@@ -166,7 +210,8 @@ __device__ __forceinline__ void frag_compute_s(const FR& f, int kb0, int kb0_nex
       for (int q = 0; q < PP::N; ++q)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-          acc[0][rt] = pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b0.v[PP::A[q]][rt], acc[0][rt]);
+          acc[(F16 && NP == 2) ? pm_chain<F16, NP>(q) : 0][rt] =
+              pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b0.v[PP::A[q]][rt], acc[(F16 && NP == 2) ? pm_chain<F16, NP>(q) : 0][rt]);
     }
   } else {
     BQ<RT, NP> b[2];
@@ -180,7 +225,8 @@ __device__ __forceinline__ void frag_compute_s(const FR& f, int kb0, int kb0_nex
       for (int q = 0; q < PP::N; ++q)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-          acc[q & 1][rt] = pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b[cur].v[PP::A[q]][rt], acc[q & 1][rt]);
+          acc[pm_chain<F16, NP>(q)][rt] =
+              pm_mfma_bf<F16>(f.a[blk * NP + PP::W[q]], b[cur].v[PP::A[q]][rt], acc[pm_chain<F16, NP>(q)][rt]);
       __builtin_amdgcn_sched_barrier(0);
     }
     b0 = b[NB & 1];
@@ -216,8 +262,9 @@ __device__ __forceinline__ void head_partial_s(const HeadWS<NP>& h, int n_kb32, 
 #pragma unroll
   for (int q = 0; q < PP::N; ++q)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[q & 1][rt] = pm_mfma_bf<F16>(h.w[PP::W[q]], b.v[PP::A[q]][rt], acc[q & 1][rt]);
+    for (int rt = 0; rt < RT; ++rt)
+      acc[pm_chain<F16, NP>(q)][rt] = pm_mfma_bf<F16>(h.w[PP::W[q]], b.v[PP::A[q]][rt], acc[pm_chain<F16, NP>(q)][rt]);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
-    *reinterpret_cast<f32x4*>(hpart + ((size_t)(wid * RT + rt) * 64 + lane) * 4) = acc[0][rt] + acc[1][rt];
+    *reinterpret_cast<f32x4*>(hpart + ((size_t)(wid * RT + rt) * 64 + lane) * 4) = pm_chains_sum<F16, NP>(acc[0][rt], acc[1][rt]);
 }

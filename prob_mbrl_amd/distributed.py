@@ -115,6 +115,7 @@ class P2PComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         self.device = dev
+        self.max_bytes = int(max_bytes)
         self.p2p = C.c_void_p()
         _lib.check(self.lib.pmbrl_p2p_create(self.rank, self.world, dev.index or 0, int(max_bytes), C.byref(self.p2p)),
                    'pmbrl_p2p_create')
@@ -194,8 +195,44 @@ def get_p2p(group=None, device=None, max_bytes=4 << 20):
     return _P2PS[key]
 
 
+def _env_int(name, default=0):
+    v = os.environ.get(name)
+    if v is None or v.strip() == '':
+        return default
+    try:
+        return int(v)
+    except ValueError:
+        return 1 if v.strip().lower() in ('true', 'yes', 'on') else 0
+
+
 def p2p_wanted():
-    return bool(os.environ.get('PMBRL_P2P'))
+    """PMBRL_P2P=1 selects the peer-to-peer transport; 0 / unset / empty leave RCCL (parsed like the library's own
+    integer switches, PMBRL_LDS_TILES / PMBRL_MM_XCH)."""
+    return _env_int('PMBRL_P2P') != 0
+
+
+def p2p_check(group=None, device=None):
+    """Host sync + collective, once per iteration of a sharded run on the peer-to-peer transport: did ANY rank's wait
+    for a peer time out since the last check (pmbrl_p2p_error)?  A timed-out exchange returns with its buffer
+    un-reduced -- the local gradient, or local moment-matching statistics, as if they were the sum -- so every rank
+    raises together instead of letting the replicas drift apart.  No-op on the RCCL transport (which simply waits)."""
+    import torch.distributed as dist
+    if not p2p_wanted() or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    key = (id(group), str(device))
+    p2p = _P2PS.get(key)
+    if p2p is None:
+        return
+    bad = 1 if p2p.failed() else 0
+    if dist.get_backend(group) == 'nccl':
+        fl = torch.tensor([bad], dtype=torch.int32, device=device)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
+    else:
+        fl = torch.tensor([bad], dtype=torch.int32)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
+    if int(fl[0]):
+        raise RuntimeError('peer-to-peer exchange: a rank waited for a peer that did not arrive in time (the exchange '
+                           'was not completed; PMBRL_P2P_TIMEOUT_SPINS sets the wait)')
 
 
 def grad_allreduce(group=None, device=None):
@@ -211,7 +248,7 @@ def grad_allreduce(group=None, device=None):
         fallback = get_comm(group, device)
 
         def allreduce(t):      # (messages beyond the slots: the ring, which is bandwidth-bound territory anyway)
-            if t.numel() * t.element_size() <= (4 << 20):
+            if t.numel() * t.element_size() <= p2p.max_bytes:
                 return p2p.allreduce_(t)
             return fallback.allreduce_(t) if fallback is not None else allreduce_sum_(t, group)
         return allreduce

@@ -234,6 +234,16 @@ class SumTree:
         w = (self.size * (pri / total))**-beta
         return samples, idxs, w / w.max()
 
+    def replay_sample(self, idxs):
+        """What `sample` leaves behind and hands out when the draw (tree indices idxs) was made elsewhere -- by rank 0
+        of a sharded run, whose replicas of the tree must see the same draw whatever each rank's numpy generator did
+        in between: the visit counts and the stored start states of those leaves."""
+        idxs = np.asarray(idxs, dtype=np.int64)
+        leaf = idxs - self.max_size + 1
+        self.counts[leaf] += 1
+        self.max_count = max(self.max_count, self.counts[leaf].max())
+        return [self.data[i] for i in leaf]
+
 
 def apply_controller(env, policy, max_steps, preprocess=None, callback=None, realtime=False,
                      stop_when_done=True):

@@ -195,7 +195,8 @@ class CDropout(BDropout):
     def step_mask_bits(self, H, B, width):
         """H fresh eval-mode masks as bit rows, one device launch (see BDropout.step_mask_bits): new uniform noise and
         a hard sample of its concrete probabilities per step (models/modules.py:134-139,155-157).  Like the reference,
-        the module is left holding the LAST step's noise and sample."""
+        the module is left holding the LAST step's hard sample (concrete_noise) while its stored uniform noise stays
+        untouched: forward(resample=True) draws into a local (models/modules.py:139-143)."""
         if self.training:
             raise NotImplementedError('training-mode (relaxed) concrete dropout is not on the rollout path; call '
                                       'dynamics.eval() like mc_pilco does')
@@ -205,7 +206,6 @@ class CDropout(BDropout):
         if lp.numel() not in (1, width):
             raise ValueError('logit_p has %d entries for a layer of width %d' % (lp.numel(), width))
         bits, aux = E.draw_masks('concrete', seed, 0, lp, float(self.temp), H * B, width, aux=((H - 1) * B, B))
-        self.noise.data = aux['u']
         self.concrete_noise = aux['hard']
         self._mask_gen = getattr(self, '_mask_gen', 0) + 1
         self.p = self.logit_p.sigmoid()
@@ -399,6 +399,12 @@ class BSequential(nn.Sequential):
         B = x.shape[0]
         dims = [linears[0].in_features] + [l.out_features for l in linears]
         flat, _ = flat_parameters(linears, self)
+        # per-unit BDropout rates: keep_prob() is 1 for them and 1 / p_j lives in row j of the layer in front of the
+        # dropout, exactly as the rollout sees the network (rollout.Bundle.scale_unit_rows; models/modules.py:55-61)
+        from .rollout import Bundle
+        unit = Bundle._unit_rows(drops, dims, x.device)
+        if unit:
+            flat = Bundle.scale_unit_rows(flat.detach(), unit)
         mixture = isinstance(density, GaussianMixtureDensity)
         plain = density is None or mixture
         if plain:

@@ -375,6 +375,30 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
     # moment-matching groups spread over the ranks of process_group (not in the reference, which is single-process):
     # mm_span = (rows of a group over all ranks, this rank's first row inside each group, ranks, this rank)
     mm_span, process_group = kwargs.pop('mm_span', None), kwargs.pop('process_group', None)
+    # sharded callers (mc_pilco with world > 1): the group whose ranks must keep the SAME horizon and take the same
+    # retry / raise decision -- a rank that truncates, retries or raises alone leaves the others inside the next
+    # collective (the gradient all-reduce, the row gathers of CVaR and prioritised replay)
+    agree_group = kwargs.pop('agree_group', None)
+
+    def _agree(n_local, failed_local):
+        if agree_group is None:
+            return n_local, failed_local
+        import torch.distributed as dist
+        if dist.get_world_size(agree_group) == 1:
+            return n_local, failed_local
+        v = torch.tensor([n_local, -int(failed_local)], dtype=torch.int32, device=bundle.device)
+        if dist.get_backend(agree_group) == 'nccl':
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=agree_group)
+        else:
+            host = v.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MIN, group=agree_group)
+            v = host
+        n_all, failed_all = int(v[0]), int(v[1]) < 0
+        if n_all < n_local:
+            # what the adjoint sweep, the dW GEMM and the loss of THIS rank read: stop where the slowest rank stopped
+            bundle.engine.status[0:1].copy_(torch.tensor([n_all], dtype=torch.int32))
+        return n_all, failed_all
+
     while True:
         bundle = Bundle(dynamics, policy, B, int(steps), resample_state_noise, resample_action_noise,
                         mm_states, mm_rewards, mm_groups, z_mm, z_rr, B_global=B_global,
@@ -387,7 +411,8 @@ def rollout(states, dynamics, policy, steps, resample_model=False, resample_poli
         S, A, R = RolloutFunction.apply(bundle, x0, *bundle.pol_params)
         n = bundle.engine.valid_steps()
         failed = n < steps
-        if mm_span and E.safe_precision(bundle.engine.info['precision']) is not None:
+        n, failed = _agree(n, failed)
+        if agree_group is None and mm_span and E.safe_precision(bundle.engine.info['precision']) is not None:
             # groups spread over ranks: a rank retrying alone would leave the others inside a collective -- the ranks
             # agree (every one of them makes this call), and retry together if any of them failed
             failed = bundle.engine.any_rank(failed)

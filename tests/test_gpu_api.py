@@ -69,6 +69,24 @@ def test_mc_pilco_with_per_unit_dropout_rates_steps():
     assert torch.isfinite(after).all() and not torch.equal(after, before)
 
 
+def test_standalone_policy_with_per_unit_rates_is_the_policy_the_rollout_runs():
+    """Per-unit BDropout rates (models/modules.py:19-27,55-61: (x * mask) / p with p a vector): the stand-alone
+    evaluation behind Policy.__call__ / apply_controller must apply the same 1 / p_j the rollout folds into the layer
+    in front of the dropout.  The first action of a rollout IS policy(x0) with the stored masks and frozen noise."""
+    import prob_mbrl_amd as pm
+    d = common.load('unit_rates_d4')
+    dyn, pol = common.modules_from_fixture(d, 'unit_rates_d4', DEV)
+    x0 = torch.tensor(d['x0'], device=DEV)
+    _, actions, _ = pm.utils.rollout(x0, dyn, pol, int(d['H']), resample_state_noise=False,
+                                     resample_action_noise=False)
+    u = pol(x0, resample=False, resample_noise=False)
+    a0 = actions[0].detach()
+    assert common.rel(u.detach().cpu().numpy(), a0.cpu().numpy()) < 2e-6
+    # ... and differs from what dropping the 1 / p_j would give (the rates of the fixture are not all equal)
+    rates = pol.model.drop0.rate
+    assert rates.numel() > 1 and float(rates.max() - rates.min()) > 0
+
+
 @pytest.mark.parametrize('name', [n for n in common.fixture_names('iter') if not n.startswith('stepmask')] +
                          ['unit_rates_d4', 'unit_rates_d4_mmg'])
 def test_rollout_autograd_matches_reference(name):

@@ -341,12 +341,11 @@ def test_c5_full_size_parity_and_properties():
     in the pre-activations: a unit whose pre-activation lies within rounding of zero is active in one arithmetic and
     inactive in another, and each such unit moves the gradient by a finite amount.  Over 512 rows x 100 steps x 3072
     units a handful of them exist in ANY fp32-class arithmetic -- the reference's own fp32 run differs from its fp64
-    run by 9.6e-5 on these rows (measured below, not assumed), this build's exact-fp32 path by 5.6e-5 -- and the
-    default split arithmetic (fp16 x 2 pieces forward: pre-activations to 22 bits, about four times fp32's rounding)
-    meets about four times as many: 2.3e-4.  (tools/c5_precision_study.py: emulated on the CPU, forward / adjoint /
-    dW GEMMs one at a time -- only the forward's rounding moves this number; giving the adjoint sweep 22-bit pieces
-    instead of its 16 left it at 2.34e-4 on the device.)  So the bar here is the north star's 1e-4 on top of the
-    reference's own fp32-vs-fp64 distance for the exact-fp32 path, and on top of twice that distance for the default."""
+    run by 9.6e-5 on these rows (measured below, not assumed).  So the bar is the north star's 1e-4 on top of the
+    reference's own fp32-vs-fp64 distance, for the exact-fp32 path AND for the default split arithmetic -- the one
+    bench.py --config stress32 times.  (Round 3's split arithmetic sat at 2.3e-4 here: the weights' low fp16 piece was
+    subnormal for every |w| < 0.125 and kept 8 of its 11 bits at this width; since round 4 it is stored scaled by 2^11
+    -- pmbrl_split.h, PM_F16_LO_SCALE; tools/c5_precision_study.py -- and the two-piece forward is fp32-class.)"""
     d = _c5_full('stress32')
     eng, S, A, Rw, loss, g, gw = _run(d)
     assert eng.info['fast'] == 0 and eng.info['rows_per_wg'] == 32
@@ -365,7 +364,7 @@ def test_c5_full_size_parity_and_properties():
           % (e_s, e_g, e_g32, floor32))
     assert e_s < 2e-5
     assert e_g32 < 1e-4 + floor32
-    assert e_g < 1e-4 + 2.0 * floor32
+    assert e_g < 1e-4 + floor32
     # (d) linearity: the rest of the rows' gradient adds up to the whole
     g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
     assert common.rel(g_sub + g_rest, g) < 2e-6

@@ -570,7 +570,7 @@ def test_draw_masks_distribution_and_reproducibility(dev):
 def test_rollout_with_per_step_masks_uses_the_device_draw(dev):
     """utils.rollout(resample_model=True, resample_policy=True): one pmbrl_draw_masks launch per dropout layer; masks
     differ from step to step, the run is reproducible under torch.manual_seed, and the concrete-dropout modules are
-    left holding the last step's noise and hard sample (models/modules.py:134-139,155-157)."""
+    left holding the last step's hard sample next to their untouched stored noise (models/modules.py:134-143,155-157)."""
     import prob_mbrl_amd as pm
     d = common.load('nomm_d4')
     dyn, pol = common.modules_from_fixture(d, 'nomm_d4', 'cuda:0')
@@ -586,7 +586,9 @@ def test_rollout_with_per_step_masks_uses_the_device_draw(dev):
     assert all(torch.equal(a, b) for a, b in zip(S1, S2)) and not torch.equal(S1[-1], S3[-1])
     assert torch.isfinite(torch.stack(S3)).all()
     assert n1.shape == (B, dyn.model.drop0.logit_p.numel()) and set(np.unique(c1.cpu().numpy())) <= {0.0, 1.0}
-    assert torch.equal(n1, dyn.model.drop0.noise) is False       # (the third rollout drew new noise)
+    # forward(resample=True) draws its uniforms into a local: the stored noise stays, the hard sample is the last step's
+    assert torch.equal(n1, dyn.model.drop0.noise)
+    assert c1.shape == dyn.model.drop0.concrete_noise.shape and not torch.equal(c1, dyn.model.drop0.concrete_noise)
 
 
 # ---------------------------------------------------------------------------

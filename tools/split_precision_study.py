@@ -32,9 +32,16 @@ def bf16_rne(v):
 
 
 def split(v, n, kind):
-    """n pieces of fp32 array v (C-contiguous fp32)."""
+    """n pieces of fp32 array v (C-contiguous fp32).  kind 'f16s': fp16 pieces with the LOW piece taken as
+    fp16((v - hi) * 2^11) / 2^11 -- the scaled low piece of the device's weights (pmbrl_split.h, PM_F16_LO_SCALE):
+    out of fp16's subnormal range, so it keeps its eleven bits for |v| < 0.125 too."""
     v = np.ascontiguousarray(v, dtype=np.float32)
     out, r = [], v
+    if kind == 'f16s':
+        assert n == 2
+        hi = v.astype(np.float16).astype(np.float32)
+        lo = ((v - hi).astype(np.float32) * np.float32(2048.0)).astype(np.float16).astype(np.float32) / np.float32(2048.0)
+        return [hi, lo.astype(np.float32)]
     for _ in range(n):
         if kind == 'bf16t':
             p = bf16_trunc(r)
@@ -55,7 +62,8 @@ def make_mm(kind, na, nb, max_order, roles, min_k=32):
     def mm(a, b, role='fwd'):
         if role not in roles or a.shape[1] < min_k:
             return (a.astype(np.float32) @ b.astype(np.float32)).astype(np.float32)
-        pa, pb = split(a, na, kind), split(b, nb, kind)
+        # ('f16s': only the weights -- the second operand -- carry the scaled low piece)
+        pa, pb = split(a, na, 'f16' if kind == 'f16s' else kind), split(b, nb, kind)
         acc = np.zeros((a.shape[0], b.shape[1]), dtype=np.float32)
         # smallest terms first, like an accumulator chain that ends with the leading product
         pairs = sorted(((i, j) for i in range(na) for j in range(nb) if i + j <= max_order),
@@ -95,6 +103,7 @@ MODES = [
     ('f16 x1 (plain)', 'f16', 1, 1, 0, 1),
     ('f16 x2 (3 mfma)', 'f16', 2, 2, 1, 3),
     ('f16 x2 (4 mfma)', 'f16', 2, 2, 2, 4),
+    ('f16 x2, w.lo * 2^11', 'f16s', 2, 2, 1, 3),
 ]
 
 
