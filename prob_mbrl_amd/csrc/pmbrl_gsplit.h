@@ -51,14 +51,14 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
                                                    const float* buf_in, unsigned ldb, int lane, Epi& epi) {
   typedef PmPairs<2> PP;
   const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
-  PmAcc<F16> acc[NT][RT];
+  f32x4 acc[NT][RT];
   const float* wp[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int ot = ot0 + k * PM_NW;
     wp[k] = wf + ((size_t)(ot < n_ot ? ot : ot0) * n_kb) * 512 + lane * 4;   // 2 pieces x 256 floats per block
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[k][rt].zero();
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // the epilogue's HBM / L2 operands of every (tile, row tile) of the group, in flight behind the K loop
   typename Epi::Pre pre[NT][RT];
@@ -106,13 +106,14 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
       if (kb0 + c < n_kb) {
         BQ<RT, 2> b;
         bq_load<RT, 2>(b, lb, ldb, kb0 + c);
+        BScaled<RT, F16> bs(b);
 #pragma unroll
         for (int q = 0; q < PP::N; ++q)
 #pragma unroll
           for (int k = 0; k < NT; ++k)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-              acc[k][rt].chain(PP::W[q]) = pm_mfma_bf<F16>(f.a[k][c][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt].chain(PP::W[q]));
+              acc[k][rt] = pm_mfma_bf<F16>(f.a[k][c][PP::W[q]], pm_bsel<F16>(q, b, bs, rt), acc[k][rt]);
       }
     }
   };
@@ -146,7 +147,7 @@ __device__ __forceinline__ void gemm_tiles_group_s(const float* __restrict__ wf,
   for (int k = 0; k < NT; ++k) {
     if (ot0 + k * PM_NW < n_ot) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt].value(), pre[k][rt]);
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt], pre[k][rt]);
     }
   }
 }
@@ -163,7 +164,7 @@ __device__ __forceinline__ void gemm_tiles_group_small_s(const float* __restrict
                                                          const float* buf_in, unsigned ldb, int lane, Epi& epi) {
   typedef PmPairs<2> PP;
   const unsigned short* lb = pm_plane_lane(buf_in, ldb, lane);
-  PmAcc<F16> acc[NT][RT];
+  f32x4 acc[NT][RT];
   f32x4 a[NT][2][2];
   typename Epi::Pre pre[NT][RT];
 #pragma unroll
@@ -177,7 +178,7 @@ __device__ __forceinline__ void gemm_tiles_group_small_s(const float* __restrict
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      acc[k][rt].zero();
+      acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       pre[k][rt] = epi.pre(ot, rt);
     }
   }
@@ -186,19 +187,20 @@ __device__ __forceinline__ void gemm_tiles_group_small_s(const float* __restrict
     if (c < n_kb) {
       BQ<RT, 2> b;
       bq_load<RT, 2>(b, lb, ldb, c);
+      BScaled<RT, F16> bs(b);
 #pragma unroll
       for (int q = 0; q < PP::N; ++q)
 #pragma unroll
         for (int k = 0; k < NT; ++k)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[k][rt].chain(PP::W[q]) = pm_mfma_bf<F16>(a[k][c][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt].chain(PP::W[q]));
+          for (int rt = 0; rt < RT; ++rt) acc[k][rt] = pm_mfma_bf<F16>(a[k][c][PP::W[q]], pm_bsel<F16>(q, b, bs, rt), acc[k][rt]);
     }
   }
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     if (ot0 + k * PM_NW < n_ot) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt].value(), pre[k][rt]);
+      for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt], pre[k][rt]);
     }
   }
 }
@@ -232,14 +234,14 @@ __device__ __forceinline__ void gemm_tiles_inplace_s(const float* __restrict__ w
   typedef PmPairs<2> PP;
   const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
   const int ot0 = wid;
-  PmAcc<F16> acc[NT][RT];
+  f32x4 acc[NT][RT];
   const float* wp[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int ot = ot0 + k * PM_NW;
     wp[k] = wf + ((size_t)(ot < n_ot ? ot : (ot0 < n_ot ? ot0 : 0)) * n_kb) * 512 + lane * 4;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[k][rt].zero();
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   typename Epi::Pre pre[NT][RT];
   if (ot0 < n_ot) {
@@ -263,13 +265,14 @@ __device__ __forceinline__ void gemm_tiles_inplace_s(const float* __restrict__ w
       if (kb0 < n_kb) {
         BQ<RT, 2> b;
         bq_load<RT, 2>(b, lb, ldb, kb0);
+        BScaled<RT, F16> bs(b);
 #pragma unroll
         for (int q = 0; q < PP::N; ++q)
 #pragma unroll
           for (int k = 0; k < NT; ++k)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-              acc[k][rt].chain(PP::W[q]) = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt].chain(PP::W[q]));
+              acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], pm_bsel<F16>(q, b, bs, rt), acc[k][rt]);
       }
     };
     // two one-block chunks (NT x 2 KB each): one feeds the MFMAs while the other is in flight
@@ -299,7 +302,7 @@ __device__ __forceinline__ void gemm_tiles_inplace_s(const float* __restrict__ w
     for (int k = 0; k < NT; ++k) {
       if (ot0 + k * PM_NW < n_ot) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt].value(), pre[k][rt]);
+        for (int rt = 0; rt < RT; ++rt) epi(ot0 + k * PM_NW, rt, acc[k][rt], pre[k][rt]);
       }
     }
   }
@@ -324,11 +327,11 @@ __device__ __forceinline__ void gemm_ksplit_s(const float* __restrict__ wf, int 
   const int per = (n_kb + PM_NW - 1) / PM_NW;
   const int k_lo = wid * per;
   const int k_hi = min(n_kb, k_lo + per);
-  PmAcc<F16> acc[PM_KS_NT][RT];
+  f32x4 acc[PM_KS_NT][RT];
 #pragma unroll
   for (int k = 0; k < PM_KS_NT; ++k)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[k][rt].zero();
+    for (int rt = 0; rt < RT; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int kb = k_lo; kb < k_hi; ++kb) {
     f32x4 a[PM_KS_NT][2];
 #pragma unroll
@@ -339,13 +342,14 @@ __device__ __forceinline__ void gemm_ksplit_s(const float* __restrict__ wf, int 
       }
     BQ<RT, 2> b;
     bq_load<RT, 2>(b, lb, ldb, kb);
+    BScaled<RT, F16> bs(b);
 #pragma unroll
     for (int q = 0; q < PP::N; ++q)
 #pragma unroll
       for (int k = 0; k < PM_KS_NT; ++k)
         if (k < n_ot) {
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[k][rt].chain(PP::W[q]) = pm_mfma_bf<F16>(a[k][PP::W[q]], b.v[PP::A[q]][rt], acc[k][rt].chain(PP::W[q]));
+          for (int rt = 0; rt < RT; ++rt) acc[k][rt] = pm_mfma_bf<F16>(a[k][PP::W[q]], pm_bsel<F16>(q, b, bs, rt), acc[k][rt]);
         }
   }
 #pragma unroll
@@ -354,7 +358,7 @@ __device__ __forceinline__ void gemm_ksplit_s(const float* __restrict__ wf, int 
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
         *reinterpret_cast<f32x4*>(pm_part_at(part, alias, ld, (((wid * PM_KS_NT + k) * RT + rt) * 64 + lane) * 4)) =
-            acc[k][rt].value();
+            acc[k][rt];
     }
 }
 

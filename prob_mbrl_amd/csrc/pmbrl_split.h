@@ -51,8 +51,9 @@ __device__ __forceinline__ f32x4 pm_mfma_bf(f32x4 a, f32x4 b, f32x4 c) {
 // changed sign against fp64 at the 3 x 512 shape.  So the low piece is stored as fp16((w - hi) * 2^11) -- the same
 // magnitude as w, eleven good bits whenever hi has them -- and the one piece product that uses it (lo x act.hi)
 // accumulates in a chain of its own that enters the result through ONE fma with 2^-11 (exact): no extra instruction
-// against the sum of two chains the kernels ended with before.  Activations keep their plain low piece: its
-// quantisation (|h| < 0.125) is an absolute 3e-8 |w| per term, below fp32's own rounding of the sum.
+// against the sum of two chains the latency-optimised kernels ended with before (the general family, one
+// accumulator per tile, scales that product's B operand instead: BScaled below).  Activations keep their plain low
+// piece: its quantisation (|h| < 0.125) is an absolute 3e-8 |w| per term, below fp32's own rounding of the sum.
 #define PM_F16_LO_SCALE 2048.f
 #define PM_F16_LO_ISCALE (1.f / 2048.f)
 // accumulator chain of piece product q of PmPairs<NP>: fp16 pieces -- chain 0 = the product with the weight's low
@@ -72,22 +73,6 @@ __device__ __forceinline__ f32x4 pm_chains_sum(f32x4 c0, f32x4 c1) {
     return c0 + c1;
   }
 }
-// ... and where a routine kept ONE accumulator per output tile (the general family): a pair under fp16 pieces
-template <bool F16>
-struct PmAcc {
-  f32x4 h;
-  __device__ __forceinline__ void zero() { h = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  __device__ __forceinline__ f32x4& chain(int) { return h; }
-  __device__ __forceinline__ f32x4 value() const { return h; }
-};
-template <>
-struct PmAcc<true> {
-  f32x4 h, l;
-  __device__ __forceinline__ void zero() { h = l = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  __device__ __forceinline__ f32x4& chain(int wpiece) { return wpiece ? l : h; }
-  __device__ __forceinline__ f32x4 value() const { return pm_chains_sum<true, 2>(l, h); }
-};
-
 // two fp32 -> packed fp16 pair (round to nearest even) and back
 __device__ __forceinline__ unsigned pm_pk_f16(float a, float b) {
   const pm_f16x2 r = __builtin_convertvector((pm_f32x2){a, b}, pm_f16x2);
@@ -185,6 +170,31 @@ __device__ __forceinline__ void bq_load(BQ<RT, NP>& b, const unsigned short* lan
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
       b.v[p][rt] = *reinterpret_cast<const f32x4*>(lane_base + ((unsigned)(p * R) + rt * 16u) * ldb + kb * 32);
+}
+// Where a routine keeps ONE accumulator per output tile (the general family: pmbrl_gsplit.h) the 2^-11 of the
+// weights' scaled low piece goes onto the B operand of that one product instead of onto a chain of its own:
+// act.hi * 2^-11 as packed fp16 (four v_pk_mul_f16 per K32 block and row tile, shared by every output tile of the
+// wave).  Exact for |act.hi| >= 0.125; below that the product lands in fp16's subnormals and keeps 2^-25 absolute,
+// i.e. <= 1.5e-8 |w| per term -- the size of the activations' own low-piece quantisation, below fp32's rounding of
+// the sum.
+template <int RT, bool F16>
+struct BScaled {
+  f32x4 v[F16 ? RT : 1];
+  __device__ __forceinline__ explicit BScaled(const BQ<RT, 2>& b) {
+    if constexpr (F16) {
+      const _Float16 s = (_Float16)PM_F16_LO_ISCALE;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) v[rt] = __builtin_bit_cast(f32x4, __builtin_bit_cast(pm_f16x8, b.v[0][rt]) * s);
+    }
+  }
+};
+// B operand of piece product q of PmPairs<2> (q = 0: weight low piece x activation high piece)
+template <bool F16, int RT>
+__device__ __forceinline__ f32x4 pm_bsel(int q, const BQ<RT, 2>& b, const BScaled<RT, F16>& bs, int rt) {
+  if constexpr (F16) {
+    if (q == 0) return bs.v[rt];
+  }
+  return b.v[PmPairs<2>::A[q]][rt];
 }
 // this lane's base inside a plane buffer: row lane&15, k offset 8*(lane>>4)
 __device__ __forceinline__ const unsigned short* pm_plane_lane(const float* buf, unsigned ldb, int lane) {

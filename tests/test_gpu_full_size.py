@@ -90,10 +90,21 @@ def test_instantiations_agree_bitwise(config, H):
     #  rt4_split -- so the double cart-pole comparison is made in fp32, where both forms exist)
     pk = dict(precision='f32') if config == 'dcartpole_mm' else {}
     ref = _run(d, **pk)
+    # cartpole_mm: the shape-specialised instance exchanges fp64 SUMS between the two workgroups of a 25-row group
+    # (pm_xch_put / pm_xch_get), the general instance carries the rows + flags form -- the same mathematics in a
+    # different order of fp64 additions, so their fp32 results agree to rounding, not to the bit (identical bits
+    # there were a matter of which way ~1e-14 differences round).  Everything else is the same arithmetic in the same
+    # order and must agree bit for bit.
+    same_bits = lambda kw: not (config == 'cartpole_mm' and kw.get('no_shaped'))
     for kw, lean in ((dict(no_shaped=True), True), (dict(), False), (dict(no_shaped=True), False)):
         out = _run(d, lean=lean, **kw, **pk)
-        assert np.array_equal(ref[1], out[1]) and np.array_equal(ref[2], out[2]) and np.array_equal(ref[3], out[3])
-        assert np.array_equal(ref[5], out[5])
+        if same_bits(kw):
+            assert np.array_equal(ref[1], out[1]) and np.array_equal(ref[2], out[2]) and np.array_equal(ref[3], out[3])
+            assert np.array_equal(ref[5], out[5])
+        else:
+            assert ref[0].info['mm_parts'] == 2
+            assert common.rel(out[1], ref[1]) < 2e-6 and common.rel(out[2], ref[2]) < 2e-6
+            assert common.rel(out[5], ref[5]) < 2e-5
 
 
 def test_gradient_is_linear_in_loss_weights():

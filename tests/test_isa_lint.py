@@ -4,6 +4,7 @@ device code to ISA and checks that no instruction touches a register whose load 
 flight (tools/check_inflight.py) -- a register-allocator copy or spill there would be a silent
 data corruption that only shows on some shapes."""
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -28,24 +29,26 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
                                             [os.path.join(csrc, src), '-o', out], cwd=csrc)))
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import check_inflight as CI
-    names, total_loads = [], 0
+    names, total_loads, general_split = [], 0, 0
     for out, pr in procs:
         assert pr.wait() == 0
         funcs = CI.parse_functions(out)
         for n in funcs:
             # (the general family's split-operand instantiations -- template argument 2 -- stream their weights
             #  with inline-asm loads too: pmbrl_gsplit.h)
-            if 'fast' in n or 'pm_dw_kernel' in n or ('pm_rollout_' in n and n.endswith('ELi2EEv11RolloutArgs')):
+            #  (every instantiation with precision argument 2, the in-place 64-row one -- <4, 2, true> -- included)
+            if 'fast' in n or 'pm_dw_kernel' in n or re.search(r'pm_rollout_(fwd|bwd)ILi\dELi2E', n):
                 bad, nload, _ = CI.check_function(n, funcs[n])
                 assert bad == 0, '%s: %d in-flight register violations' % (n, bad)
                 total_loads += nload
                 names.append(n)
-    assert len(names) >= 19 + 16 + 6, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
+                general_split += 'fast' not in n and 'pm_dw' not in n
+    assert len(names) >= 19 + 16 + 6 + 8, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
     assert total_loads > 500
+    assert general_split == 8, general_split      # pm_rollout_fwd / bwd <1|2|4, 2, false> and <4, 2, true>
     # register spills of the default-precision instances that run the cart-pole shapes: none without moment matching,
     # none with 25-row groups split over two 16-row workgroups (statistics exchange: the rows + flags form is no
     # longer compiled into them); the 32-row instance of the double cart-pole shape is bounded
-    import re
     txt = open(procs[3][0]).read()          # pmbrl_fast_split.hip, PM_SPLIT_PR = 2
     spills = {}
     for blk in txt.split('- .agpr_count:')[1:]:
