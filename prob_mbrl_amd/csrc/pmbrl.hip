@@ -1062,6 +1062,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       }
     }
   }
+  p->reg = pm_reg_plan_ok(p) ? 1 : 0;
   // workspace carve-up
   {
     size_t off = 0;
@@ -1078,7 +1079,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         n->wb[l] = take(fr);
         n->bias[l] = take((size_t)n->nt[l + 1] * 16 * sizeof(float));
         if (l < n->nl - 1)
-          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * 4);   // u16 (generic) or 4 nibble-bytes (fast)
+          // u16 (generic) or 4 nibble-bytes (fast); 64 bytes of slack behind it: where the register-resident family's
+          // rows past the batch put their (zero) bytes (pmbrl_reg.h)
+          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * 4 + 64);
       }
     }
     const size_t Rw = 16 * p->RT;
@@ -1115,9 +1118,11 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       p->off_mmx_fac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(c.D) * sizeof(double) : 0);
       p->off_mmx_rfac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(1) * sizeof(double) : 0);
     }
+    p->off_reg_pack = take(p->reg ? pm_reg_pack_bytes() : 0);
     p->off_part = take((size_t)std::max(p->dw_nsplit, p->pipe_K > 1 ? p->pipe_rows : 0) *
                        ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
+    if (p->ws_bytes >= ((size_t)1 << 32)) p->reg = 0;      // (the family addresses its stashes with 32-bit workspace offsets)
   }
   int rc2 = 0;
   if (!p->fast && p->prec) {
@@ -1159,6 +1164,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       }
     }
   }
+  if (!rc2 && p->reg) rc2 = pm_reg_set_attr(p);
   if (rc2) { pmbrl_plan_destroy(p); return rc2; }
   if (p->mm_grid) {
     // the barrier-form sweep needs every workgroup resident at once: ask the runtime how many of THIS
@@ -1514,6 +1520,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     PK.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
     PK.gen = p->wgen;
     hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
+    if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s);
   }
   A.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
   A.wgen = p->wgen;
@@ -1540,7 +1547,8 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
     if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     if (p->mm_parts > 1 && As.xch) HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));      // ... or the granules' tags
-    launch_fwd_rt(p, As, s);
+    if (pm_reg_can_run(p, As, true)) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);
+    else launch_fwd_rt(p, As, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
     RolloutArgs Am = A, As = A;

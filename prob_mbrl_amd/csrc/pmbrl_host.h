@@ -71,6 +71,8 @@ struct pmbrl_plan {
   int inplace;   // general family on split operands: 64-row workgroups with in-place layers (pm_rollout_fwd<4, 2, true>)
   int mm_wide;   // mm_mode 2 through the LDS-staged kernels for 6 < D <= 32 (pmbrl_mm_wide.h)
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
+  int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
+  size_t off_reg_pack;   // its packed weights in the workspace
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -153,6 +155,15 @@ static inline int fast_variant(int RT, const RolloutArgs& A) {
   return mmg ? PF_VAR_MMG : mm ? PF_VAR_MM : (ext ? PF_VAR_EXT : PF_VAR_LEAN);
 }
 
+// register-resident family (pmbrl_reg.hip)
+bool pm_reg_plan_ok(const pmbrl_plan* p);
+size_t pm_reg_pack_bytes();
+int pm_reg_set_attr(const pmbrl_plan* p);
+bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd);
+void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
+                        hipStream_t s);
+void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
+                   hipStream_t s, bool fwd);
 // per-family entry points (defined in pmbrl_fast_f32.hip / pmbrl_fast_split.hip)
 // *_mmg_blocks_per_cu: workgroups of the barrier-form sweep (PF_VAR_MMG) the runtime says can be resident
 // per CU with this plan's LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor, min over forward / adjoint;

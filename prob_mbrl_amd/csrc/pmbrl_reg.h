@@ -1,0 +1,761 @@
+// Register-resident sweep kernels for the cart-pole class of shapes (round 4): three-layer policy and dynamics
+// networks with ONE hidden width of 177..208 units (13 output tiles), at most 8 network inputs (D + U <= 8), no moment
+// matching inside the sweep, 16 rows per workgroup.  Same mathematics, same stashes and the same C ABI as the
+// latency-optimised family (pmbrl_fast.h) -- what changes is where a step's time goes:
+//
+//   * FOUR waves per workgroup, one per SIMD, 512 registers each.  The hidden->hidden weights of BOTH networks
+//     (2 x 200 x 200, two 16-bit pieces each: 336 registers per wave for the 12 tiles a wave quartet shares out evenly)
+//     stay in registers for the whole launch -- 256 of them in the accumulator file, which the matrix core reads as
+//     an A operand directly (inline-asm MFMAs: hipcc would copy them back through VGPRs).  Nothing is streamed from
+//     L2 inside the horizon loop; the 13th tile, the first layers and the heads live in LDS (copied once per launch).
+//   * a step has FOUR workgroup barriers (pmbrl_fast.h: nine): per network, one after the first layer's epilogue
+//     (hidden activations -> LDS as MFMA B fragments, read back by every wave) and one after the head, which is
+//     K-split over the waves STRAIGHT FROM REGISTERS -- the K permutation below makes the epilogue's output registers
+//     the next product's B operand as they are, so the second hidden layer never goes through LDS at all.
+//   * the elementwise phases (squash, sampling, normalisation) are lane-local and computed redundantly by all four
+//     waves: input i of a network lives in lane group i / 2 of every wave, the head's output rows are permuted (at pack
+//     time, for free) so that the mean / log-std of what becomes input i come out of the MFMA in that very lane group.
+//     No LDS round trip, no barrier, no cross-lane traffic between a head and the next first layer.
+//   * first layers (K <= 8 inputs) are ONE MFMA per tile: the three piece products hi.hi, hi.lo, lo.hi and the bias
+//     sit in different k-slots of the same K = 32 block.  Hidden-layer biases ride in the free half of the last
+//     K = 32 block (13 tiles = 6.5 blocks) against a constant 1 in the activation buffer: no bias add anywhere.
+//
+// K permutation of a hidden width (both operands of a product use it; a sum over k does not care): K32 block kb,
+// lane group g = lane >> 4, slot j = 0..7  <->  feature 16 (2 kb + (j >> 2)) + 4 g + (j & 3), i.e. the four
+// accumulator registers of output tile 2 kb (j < 4) and of tile 2 kb + 1 (j >= 4) in lane group g.
+//
+// Arithmetic: pmbrl_split.h's -- forward two fp16 pieces (low weight piece scaled by 2^11, own accumulator chain),
+// adjoint two bf16 pieces.  Reference: utils/rollout.py:95-152, models/core.py:221-303, models/modules.py:46-160.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include "pmbrl_dev.h"
+#include "pmbrl_split.h"
+
+#define PR_NW 4                 // waves per workgroup: one per SIMD
+#define PR_NTHR (PR_NW * 64)
+#define PR_NT 13                // output tiles of a hidden layer (hidden width 177 .. 208)
+#define PR_KB 7                 // K32 blocks of a hidden width
+#define PR_SLOTS 3              // register-resident tiles per wave and hidden->hidden layer: tile 4 s + w
+#define PR_XT 12                // the tile that lives in LDS (run by wave pr_xwave(net))
+#define PR_FRAG 256             // floats of one fragment (64 lanes x 16 bytes)
+#define PM_GLOBAL_ __attribute__((address_space(1)))
+typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
+
+// floats of the packed sections of ONE network and direction (pm_reg_pack_kernel writes them, the sweeps read them)
+#define PR_RES_FLOATS (PR_NW * PR_SLOTS * PR_KB * 2 * PR_FRAG)    // [wave][slot][kb][piece][lane][4]
+#define PR_XT_FLOATS (PR_KB * 2 * PR_FRAG)                        // [kb][piece][lane][4]
+#define PR_L0P_FLOATS (PR_NT * 2 * PR_FRAG)                       // packed: [tile][block (forward: 1 used)][lane][4]
+#define PR_L0_FLOATS (PR_NT * PR_FRAG)                            // forward, in LDS: [tile][lane][4]
+#define PR_HEAD_FLOATS (PR_NW * 2 * 2 * PR_FRAG)                  // [wave][block][piece][lane][4]
+#define PR_NET_FLOATS (PR_RES_FLOATS + PR_XT_FLOATS + PR_L0P_FLOATS + PR_HEAD_FLOATS)
+#define PR_OFF_RES 0
+#define PR_OFF_XT (PR_RES_FLOATS)
+#define PR_OFF_L0 (PR_RES_FLOATS + PR_XT_FLOATS)
+#define PR_OFF_HEAD (PR_RES_FLOATS + PR_XT_FLOATS + PR_L0P_FLOATS)
+// the whole packed buffer: [direction (0 forward, 1 adjoint)][net (0 policy, 1 dynamics)][PR_NET_FLOATS]
+#define PR_PACK_FLOATS (4 * PR_NET_FLOATS)
+
+// the wave that runs the LDS-resident tile of a network (two different ones: they balance over a step)
+__host__ __device__ constexpr int pr_xwave(int net) { return net; }
+
+// LDS map (floats)
+#define PR_LDS_ACT 0                                   // [kb][piece][lane][4]: hidden activations as B fragments
+#define PR_LDS_PART (PR_LDS_ACT + PR_KB * 2 * PR_FRAG) // [wave][lane][4]: partial head / tail tiles
+#define PR_LDS_L0(net) (PR_LDS_PART + PR_NW * PR_FRAG + (net) * (PR_L0_FLOATS + PR_XT_FLOATS + PR_HEAD_FLOATS))
+#define PR_LDS_XT(net) (PR_LDS_L0(net) + PR_L0_FLOATS)
+#define PR_LDS_HEAD(net) (PR_LDS_XT(net) + PR_XT_FLOATS)
+// dropout multipliers {0, 1 / keep} of this lane's four values of a tile, in accumulator-register order: resident
+// tiles [wave][net][layer][slot][lane][4], the LDS-resident tile [net][layer][lane][4] (forward: the mask; adjoint: the
+// same table is rebuilt per step from the stashed activity bits)
+#define PR_LDS_MF (PR_LDS_L0(2))
+#define PR_LDS_MFX (PR_LDS_MF + PR_NW * 2 * 2 * PR_SLOTS * PR_FRAG)
+#define PR_LDS_FLAG (PR_LDS_MFX + 2 * 2 * PR_FRAG)
+#define PR_LDS_FLOATS (PR_LDS_FLAG + 16)
+
+struct RegNet {
+  int w_off[3], b_off[3];       // offsets (floats) of W_l / b_l in the flat parameter vector
+  int n_in, n_out;              // network inputs (D or D + U), head rows (2 U or 2 D)
+  const uint16_t* mask[2];      // dropout bit rows [B][PR_NT] of the two hidden layers
+  unsigned abits[2];            // stash [H][B][PR_NT][4] (byte offset in the workspace): mask & (pre-activation > 0), one
+                                // nibble-byte per lane group
+  float inv_keep[2];
+};
+
+struct RegArgs {
+  int B, H, D, U, nwg, hid;
+  float mls_pol, mls_dyn;
+  RegNet pol, dyn;
+  const float* packed;          // PR_PACK_FLOATS (this launch's weights, pm_reg_pack_kernel)
+  const float *pol_params, *dyn_params;
+  const float *x0, *mx, *iSx, *my, *Sy, *pscale, *pbias, *zpol, *zdyn;
+  float *states, *actions;
+  // everything the sweeps stash lives in ONE workspace (< 4 GB for the shapes of this family): a base and 32-bit byte
+  // offsets instead of a dozen 64-bit pointers held in scalar registers across the horizon loop
+  char* ws;
+  unsigned Tp, Td;              // [H][B][U], [H][B][D]
+  unsigned actT[3];             // policy layer inputs, feature-major blocks [H][nwg][nt * 16][16]
+  unsigned gT[3];               // policy pre-activation gradients, same layout
+  unsigned Jx, Ja;              // reward Jacobians [H][B][D], [H][B][U]
+  int* status;
+  const int* wflag;
+  int wgen;
+  // adjoint
+  const float* grad_rewards;
+  float* grad_x0;
+  const int* nvalid;
+  long long* prof;
+};
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void pr_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void pr_for(F&& f) {
+  pr_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// feature of K slot (kb, g, j) of a hidden width
+__host__ __device__ constexpr int pr_hid_feature(int kb, int g, int j) { return 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3); }
+
+// head row that lands in accumulator register r of lane group g (row m = 4 g + r of the head tile): the pair
+// (mean, log-std) of what becomes input i = 2 g + (r >> 1) of the NEXT first layer -- action i - D for the policy
+// (inputs D .. D + U - 1 of the dynamics model), next-state dimension i for the dynamics model.  -1: nothing.
+__host__ __device__ inline int pr_head_row(int net, int D, int U, int m) {
+  const int i = 2 * (m >> 2) + ((m >> 1) & 1), kind = m & 1;
+  if (net == 0) {
+    const int j = i - D;
+    return (j >= 0 && j < U) ? (kind ? U + j : j) : -1;
+  }
+  return i < D ? (kind ? D + i : i) : -1;
+}
+
+// ---------------------------------------------------------------------------
+// weight packer: one thread per (fragment, lane) = 8 sixteen-bit values
+// ---------------------------------------------------------------------------
+struct RegPackArgs {
+  const float* par[2];          // flat parameters of the policy / the dynamics model
+  int w_off[2][3], b_off[2][3];
+  int n_in[2], n_out[2];
+  int D, U, hid;
+  float* out;                   // PR_PACK_FLOATS
+  int* wflag;
+  int gen;
+  int* status;                  // the forward sweep's status word: reset here (first launch of an iteration)
+};
+
+__device__ __forceinline__ unsigned short pr_f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ unsigned short pr_bf16_bits(float v) { return (unsigned short)(pm_pk_bf16(v, 0.f) & 0xffffu); }
+// piece p of v: fp16 (low piece scaled by 2^11, pmbrl_split.h) or bf16
+__device__ __forceinline__ unsigned short pr_piece(float v, int p, bool f16) {
+  if (f16) {
+    const _Float16 h = (_Float16)v;
+    return p == 0 ? __builtin_bit_cast(unsigned short, h) : pr_f16_bits((v - (float)h) * PM_F16_LO_SCALE);
+  }
+  const unsigned a = pm_pk_bf16(v, 0.f) & 0xffffu;
+  return p == 0 ? (unsigned short)a : pr_bf16_bits(v - pm_bf_lo(a));
+}
+
+__global__ __launch_bounds__(256) void pm_reg_pack_kernel(const RegPackArgs P) {
+  if (P.status && blockIdx.x == 0 && threadIdx.x == 0) *P.status = 0x7fffffff;
+  const int n_frag_net = PR_NET_FLOATS / PR_FRAG;
+  const int total = 4 * n_frag_net * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, fr_all = idx >> 6;
+    const int dn = fr_all / n_frag_net, fr = fr_all - dn * n_frag_net;
+    const int dir = dn >> 1, net = dn & 1;
+    const bool f16 = dir == 0;
+    const float* par = P.par[net];
+    const float* W0 = par + P.w_off[net][0];
+    const float* W1 = par + P.w_off[net][1];
+    const float* W2 = par + P.w_off[net][2];
+    const float* b0 = par + P.b_off[net][0];
+    const float* b1 = par + P.b_off[net][1];
+    const int hid = P.hid, n_in = P.n_in[net], n_out = P.n_out[net];
+    const int m = lane & 15, g = lane >> 4;
+    float v[8];
+    int piece[8];       // which piece of v[e] is stored (0 / 1), per element
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = 0.f; piece[e] = 0; }
+    const int n_res = PR_RES_FLOATS / PR_FRAG, n_xt = PR_XT_FLOATS / PR_FRAG, n_l0 = PR_L0P_FLOATS / PR_FRAG;
+    if (fr < n_res + n_xt) {
+      // hidden -> hidden layer: output tile ot, K32 block kb, piece p
+      int ot, kb, p;
+      if (fr < n_res) {
+        const int w = fr / (PR_SLOTS * PR_KB * 2), r = fr - w * (PR_SLOTS * PR_KB * 2);
+        const int s = r / (PR_KB * 2), r2 = r - s * (PR_KB * 2);
+        kb = r2 >> 1; p = r2 & 1; ot = 4 * s + w;
+      } else {
+        const int r2 = fr - n_res;
+        kb = r2 >> 1; p = r2 & 1; ot = PR_XT;
+      }
+      const int o = 16 * ot + m;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = pr_hid_feature(kb, g, e);
+        piece[e] = p;
+        if (o < hid && k < hid) v[e] = dir == 0 ? W1[(size_t)o * hid + k] : W1[(size_t)k * hid + o];
+        // forward: the bias rides in slot 4 of the last block (tile 13 does not exist), lane group 0, against the
+        // constant 1 the kernel keeps in the activation buffer
+        if (dir == 0 && kb == PR_KB - 1 && e == 4 && g == 0 && o < hid) v[e] = b1[o];
+      }
+    } else if (fr < n_res + n_xt + n_l0) {
+      const int r = fr - n_res - n_xt;
+      const int ot = r >> 1, blk = r & 1;
+      const int o = 16 * ot + m;
+      if (dir == 0) {
+        // first layer: slots 3 s + {0, 1, 2} = W.hi (x act.hi), W.hi (x act.lo), W.lo (x act.hi 2^-11) of input 2 g + s;
+        // slots 6 / 7 of lane group 0: bias.hi (x 1), bias.lo (x 2^-11)
+        if (blk == 0 && o < hid) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const int i = 2 * g + e / 3;
+            if (i < n_in) { v[e] = W0[(size_t)o * n_in + i]; piece[e] = (e % 3) == 2 ? 1 : 0; }
+          }
+          if (g == 0) { v[6] = b0[o]; piece[6] = 0; v[7] = b0[o]; piece[7] = 1; }
+        }
+      } else {
+        // adjoint of the head: block 0 carries the means' rows, block 1 the log-stds'; slots 3 s + {0, 1, 2} = W.hi (x g.hi),
+        // W.hi (x g.lo), W.lo (x g.hi) of the head pair of input slot (g, s)
+        if (o < hid) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const int row = pr_head_row(net, P.D, P.U, 4 * g + 2 * (e / 3) + blk);
+            if (row >= 0 && row < n_out) { v[e] = W2[(size_t)row * hid + o]; piece[e] = (e % 3) == 2 ? 1 : 0; }
+          }
+        }
+      }
+    } else {
+      // head (forward) / tail (adjoint), K-split over the waves: block 0 = the wave's tiles of slots 0 and 1,
+      // block 1 = slot 2 and, on the wave that runs it, the LDS-resident tile
+      const int r = fr - n_res - n_xt - n_l0;
+      const int w = r >> 2, blk = (r >> 1) & 1, p = r & 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int ot = -1;
+        if (blk == 0) ot = 4 * (e >> 2) + w;
+        else if (e < 4) ot = 8 + w;
+        else if (w == pr_xwave(net)) ot = PR_XT;
+        const int k = ot >= 0 ? 16 * ot + 4 * g + (e & 3) : hid;
+        piece[e] = p;
+        if (k < hid) {
+          if (dir == 0) {
+            const int row = pr_head_row(net, P.D, P.U, m);
+            if (row >= 0 && row < n_out) v[e] = W2[(size_t)row * hid + k];
+          } else {
+            // gradient with respect to network input i = 2 (m >> 2) + ((m >> 1) & 1), in accumulator register 2 s
+            const int i = 2 * (m >> 2) + ((m >> 1) & 1);
+            if ((m & 1) == 0 && i < n_in) v[e] = W0[(size_t)k * n_in + i];
+          }
+        }
+      }
+    }
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (f16 && piece[e] == 0 && P.wflag && !(fabsf(v[e]) <= 65504.f)) atomicMax(P.wflag, P.gen);
+      h[e] = pr_piece(v[e], piece[e], f16);
+    }
+    uint4 o4;
+    o4.x = h[0] | ((unsigned)h[1] << 16);
+    o4.y = h[2] | ((unsigned)h[3] << 16);
+    o4.z = h[4] | ((unsigned)h[5] << 16);
+    o4.w = h[6] | ((unsigned)h[7] << 16);
+    *reinterpret_cast<uint4*>(P.out + ((size_t)dn * PR_NET_FLOATS + (size_t)fr * PR_FRAG) + lane * 4) = o4;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MFMA with the A operand (weights) in the accumulator file or in a VGPR.  Inline asm: the compiler schedules the
+// statement as one opaque instruction and pads nothing around it -- pr_mfma_fence() supplies the wait states
+// between a chain's last MFMA and the first VALU read of its accumulator (8-pass XDL: 12 states), pr_mfma_open()
+// those between a VALU write of an operand and the first MFMA of a group.
+// ---------------------------------------------------------------------------
+template <bool F16, bool AG>
+__device__ __forceinline__ void pr_mfma(f32x4& acc, const f32x4& w, const f32x4& b) {
+  if constexpr (F16) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+  } else {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+  }
+}
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: every stash store of
+// the phase (global_store, ~1 us to be acknowledged) would be waited for at every barrier of the horizon loop, and
+// nothing a barrier orders here goes through global memory.
+__device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// first product of a chain: C = 0 (inline constant), the accumulator is a pure output
+template <bool F16, bool AG>
+__device__ __forceinline__ void pr_mfma0(f32x4& acc, const f32x4& w, const f32x4& b) {
+  if constexpr (F16) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
+  } else {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
+  }
+}
+// One buffer descriptor over the whole workspace: every stash store of the sweeps is buffer_store v_data, v_lane_offset,
+// srd, s_uniform_offset offset:imm -- no 64-bit address arithmetic in VGPRs, no scalar register pair per array.
+typedef __amdgpu_buffer_rsrc_t pr_rsrc;
+__device__ __forceinline__ pr_rsrc pr_make_rsrc(void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ void pr_mfma_open() { asm volatile("s_nop 3"); }
+__device__ __forceinline__ void pr_mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7"); }
+
+// Register-resident weights of one sweep direction: both networks' hidden->hidden layers, PR_SLOTS tiles per wave
+// and network, PR_KB blocks x 2 pieces each = 84 fragments.  The first 64 go to the accumulator file ("a": all 256
+// of its registers), the rest to VGPRs.
+#define PR_NRESF (2 * PR_SLOTS * PR_KB * 2)
+#define PR_NAG 62
+struct RegW {
+  f32x4 a[PR_NAG];
+  f32x4 v[PR_NRESF - PR_NAG];
+};
+__host__ __device__ constexpr int pr_widx(int net, int slot, int kb, int p) { return ((net * PR_SLOTS + slot) * PR_KB + kb) * 2 + p; }
+
+__device__ __forceinline__ void pr_load_resident(RegW& W, const float* packed_dir, int wid, int lane) {
+  pr_for<PR_NRESF>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int net = I / (PR_SLOTS * PR_KB * 2), r = I % (PR_SLOTS * PR_KB * 2);
+    const float* src = packed_dir + (size_t)net * PR_NET_FLOATS + PR_OFF_RES +
+                       ((size_t)wid * (PR_SLOTS * PR_KB * 2) + r) * PR_FRAG + lane * 4;
+    if constexpr (I < PR_NAG) W.a[I] = ldg4(src);
+    else W.v[I - PR_NAG] = ldg4(src);
+  });
+}
+
+// one hidden->hidden layer of network NET on this wave's resident tiles: B fragments from the LDS activation buffer,
+// accumulators acc[slot][chain].  Chains: fp16 pieces -- 0 = the product with the weights' low piece, 1 = the rest
+// (pmbrl_split.h); bf16 pieces -- the same split (the low-piece product is simply not rescaled).
+// XT: this wave also runs the LDS-resident tile (weights read from LDS two blocks ahead) into accx.
+template <int NET, bool F16, bool XT>
+__device__ __forceinline__ void pr_hidden_layer(const RegW& W, const float* lds, const float* xtw, int lane,
+                                                f32x4 (&acc)[PR_SLOTS][2], f32x4 (&accx)[2]) {
+  const float* act = lds + PR_LDS_ACT + lane * 4;
+  f32x4 b[2][2];        // B fragments of two blocks: one feeds the MFMAs, the next is in flight
+  f32x4 xw[2][2];       // the LDS-resident tile's weights, same ring
+  auto fetch = [&](int kb) {
+    const int q = kb & 1;
+    b[q][0] = *reinterpret_cast<const f32x4*>(act + (kb * 2 + 0) * PR_FRAG);
+    b[q][1] = *reinterpret_cast<const f32x4*>(act + (kb * 2 + 1) * PR_FRAG);
+    if constexpr (XT) {
+      xw[q][0] = *reinterpret_cast<const f32x4*>(xtw + lane * 4 + (kb * 2 + 0) * PR_FRAG);
+      xw[q][1] = *reinterpret_cast<const f32x4*>(xtw + lane * 4 + (kb * 2 + 1) * PR_FRAG);
+    }
+  };
+  fetch(0);
+  pr_for<PR_KB>([&](auto ic) {
+    constexpr int kb = decltype(ic)::value;
+    constexpr int q = kb & 1;
+    if constexpr (kb + 1 < PR_KB) fetch(kb + 1);
+    // order: every chain is touched once per round of PR_SLOTS (+1) MFMAs -- the dependent-MFMA latency is covered
+    pr_for<PR_SLOTS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int I = pr_widx(NET, s, kb, 1);
+      if constexpr (kb == 0) {
+        if constexpr (I < PR_NAG) pr_mfma0<F16, true>(acc[s][0], W.a[I], b[q][0]);
+        else pr_mfma0<F16, false>(acc[s][0], W.v[I - PR_NAG], b[q][0]);
+      } else {
+        if constexpr (I < PR_NAG) pr_mfma<F16, true>(acc[s][0], W.a[I], b[q][0]);
+        else pr_mfma<F16, false>(acc[s][0], W.v[I - PR_NAG], b[q][0]);
+      }
+    });
+    if constexpr (XT) {
+      if constexpr (kb == 0) pr_mfma0<F16, false>(accx[0], xw[q][1], b[q][0]);
+      else pr_mfma<F16, false>(accx[0], xw[q][1], b[q][0]);
+    }
+    pr_for<PR_SLOTS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int I = pr_widx(NET, s, kb, 0);
+      if constexpr (kb == 0) {
+        if constexpr (I < PR_NAG) pr_mfma0<F16, true>(acc[s][1], W.a[I], b[q][1]);
+        else pr_mfma0<F16, false>(acc[s][1], W.v[I - PR_NAG], b[q][1]);
+      } else {
+        if constexpr (I < PR_NAG) pr_mfma<F16, true>(acc[s][1], W.a[I], b[q][1]);
+        else pr_mfma<F16, false>(acc[s][1], W.v[I - PR_NAG], b[q][1]);
+      }
+    });
+    if constexpr (XT) {
+      if constexpr (kb == 0) pr_mfma0<F16, false>(accx[1], xw[q][0], b[q][1]);
+      else pr_mfma<F16, false>(accx[1], xw[q][0], b[q][1]);
+    }
+    pr_for<PR_SLOTS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int I = pr_widx(NET, s, kb, 0);
+      if constexpr (I < PR_NAG) pr_mfma<F16, true>(acc[s][1], W.a[I], b[q][0]);
+      else pr_mfma<F16, false>(acc[s][1], W.v[I - PR_NAG], b[q][0]);
+    });
+    if constexpr (XT) pr_mfma<F16, false>(accx[1], xw[q][0], b[q][0]);
+  });
+  // the chains' last MFMAs are in flight: wait states before anything reads an accumulator, tied to the
+  // accumulators so that no reader is scheduled above them
+  if constexpr (XT)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                 "+v"(acc[2][1]), "+v"(accx[0]), "+v"(accx[1]));
+  else
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                 "+v"(acc[2][1]));
+}
+
+// value of a tile from its two chains
+template <bool F16>
+__device__ __forceinline__ f32x4 pr_tile_value(const f32x4 (&c)[2]) {
+  return pm_chains_sum<F16, 2>(c[0], c[1]);
+}
+
+// two packed 16-bit piece pairs of four fp32 values (hi.x = pieces of v0, v1; hi.y = of v2, v3)
+template <bool F16>
+__device__ __forceinline__ void pr_split(f32x4 h, pm_u32x2& hi, pm_u32x2& lo) {
+  pm_u32x2 pc[2];
+  pm_split4<2, F16>(h, pc);
+  hi = pc[0];
+  lo = pc[1];
+}
+
+// ===========================================================================
+// forward sweep
+// ===========================================================================
+// reciprocal to 1 ulp: v_rcp_f32 and one Newton step (the IEEE division is a dozen instructions on this part, and
+// a single wave per SIMD pays every one of them in issue slots)
+__device__ __forceinline__ float pr_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
+// tanh through one exponential: absolute error ~1e-7 (what a = scale tanh(u) + bias needs; near zero the RELATIVE
+// error is larger, which nothing here divides by)
+__device__ __forceinline__ float pr_tanh(float u) { return 1.f - 2.f * pr_rcp(1.f + expf(2.f * u)); }
+
+// epilogue arithmetic of one hidden tile: h = max(v mf, 0) (mf = dropout multiplier >= 0), activity nibble, running
+// maximum (fp16 range check), piece pairs.  Branch-free by construction: nothing here turns into an exec-masked region.
+template <bool F16>
+__device__ __forceinline__ void pr_tile_epilogue(f32x4 v, f32x4 mf, f32x4& h, unsigned& ab, unsigned& amax, pm_u32x2& hi,
+                                                 pm_u32x2& lo) {
+  const f32x4 t = v * mf;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h[r] = fmaxf(t[r], 0.f);
+  ab = min(__float_as_uint(h[0]), 1u) | (min(__float_as_uint(h[1]), 1u) << 1) | (min(__float_as_uint(h[2]), 1u) << 2) |
+       (min(__float_as_uint(h[3]), 1u) << 3);
+  // (h >= 0: the order of the bit patterns is the order of the values, a NaN's pattern is above every finite one's)
+  amax = max(max(amax, max(__float_as_uint(h[0]), __float_as_uint(h[1]))), max(__float_as_uint(h[2]), __float_as_uint(h[3])));
+  pm_u32x2 pc[2];
+  pm_split4<2, F16>(h, pc);
+  hi = pc[0];
+  lo = pc[1];
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool F16 = true;
+  typedef PM_GLOBAL_ uint8_t gu8;
+  typedef PM_GLOBAL_ float gf32;
+  typedef PM_GLOBAL_ char gch;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row = lane & 15, g = lane >> 4;
+  const int row0 = wg * 16;
+  const int nvalid = min(16, A.B - row0);
+  const bool rvalid = row < nvalid;
+  const int D = A.D, U = A.U, B = A.B;
+  const float* packed = A.packed;     // direction 0
+
+  // ---- prologue: resident weights -> registers, the rest -> LDS
+  RegW W;
+  pr_load_resident(W, packed, wid, lane);
+  for (int net = 0; net < 2; ++net) {
+    const float* src = packed + (size_t)net * PR_NET_FLOATS;
+    for (int i = tid; i < PR_L0_FLOATS / 4; i += PR_NTHR)      // (block 0 of every tile)
+      *reinterpret_cast<f32x4*>(smem + PR_LDS_L0(net) + i * 4) = ldg4(src + PR_OFF_L0 + (i >> 6) * (2 * PR_FRAG) + (i & 63) * 4);
+    for (int i = tid; i < PR_XT_FLOATS / 4; i += PR_NTHR)
+      *reinterpret_cast<f32x4*>(smem + PR_LDS_XT(net) + i * 4) = ldg4(src + PR_OFF_XT + i * 4);
+    for (int i = tid; i < PR_HEAD_FLOATS / 4; i += PR_NTHR)
+      *reinterpret_cast<f32x4*>(smem + PR_LDS_HEAD(net) + i * 4) = ldg4(src + PR_OFF_HEAD + i * 4);
+  }
+  // activation buffer: zero, then the constant 1 the hidden-layer biases multiply (slot 4 of the last block, high plane)
+  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PR_LDS_ACT + i] = 0.f;
+  // dropout multipliers of this lane's values, tile by tile (rows past the batch: zero -- their activations stay 0)
+  for (int n = 0; n < 2; ++n)
+    for (int l = 0; l < 2; ++l) {
+      const RegNet& N = n == 0 ? A.pol : A.dyn;
+      const uint16_t* mrow = N.mask[l] + (size_t)(row0 + (rvalid ? row : 0)) * PR_NT;
+      for (int q = 0; q <= PR_SLOTS; ++q) {
+        if (q == PR_SLOTS && wid != pr_xwave(n)) continue;
+        const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
+        const unsigned nib = rvalid ? (((unsigned)mrow[ot] >> (4 * g)) & 0xFu) : 0u;
+        f32x4 mf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mf[r] = ((nib >> r) & 1u) ? N.inv_keep[l] : 0.f;
+        float* dst = q < PR_SLOTS ? smem + PR_LDS_MF + (size_t)(((wid * 2 + n) * 2 + l) * PR_SLOTS + q) * PR_FRAG
+                                  : smem + PR_LDS_MFX + (size_t)(n * 2 + l) * PR_FRAG;
+        *reinterpret_cast<f32x4*>(dst + lane * 4) = mf;
+      }
+    }
+  __syncthreads();
+  if (tid < 64) reinterpret_cast<unsigned*>(smem + PR_LDS_ACT + ((PR_KB - 1) * 2 + 0) * PR_FRAG + tid * 4)[2] = 0x3c00u;   // fp16 1.0, 0
+  if (tid == 0 && A.wflag && *A.wflag == A.wgen) atomicMin(A.status, 0);
+
+  // ---- per-lane constants: input slot s (0, 1) of this lane group = network input 2 g + s
+  float c_mx[2], c_isx[2], c_sy[2], c_my[2], c_zp[2], c_zd[2], c_psc[2], c_pbi[2];
+  float x[2];                       // state dimensions 2 g, 2 g + 1 of this lane's row
+  unsigned so_x[2], so_a[2];        // byte offsets of this lane's [t][row][dim] / [t][row][action] entries at t = 0
+  bool ok_x[2], ok_a[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int i = 2 * g + s;
+    const bool isd = i < D, isa = i >= D && i < D + U;
+    const int ja = isa ? i - D : 0, id = isd ? i : 0;
+    c_mx[s] = (isd || isa) ? A.mx[i] : 0.f;
+    c_isx[s] = (isd || isa) ? A.iSx[i] : 0.f;
+    c_sy[s] = isd ? A.Sy[id] : 0.f;
+    c_my[s] = isd ? A.my[id] : 0.f;
+    c_zp[s] = (isa && rvalid) ? A.zpol[(size_t)(row0 + row) * U + ja] : 0.f;
+    c_zd[s] = (isd && rvalid) ? A.zdyn[(size_t)(row0 + row) * D + id] : 0.f;
+    c_psc[s] = isa ? A.pscale[ja] : 0.f;
+    c_pbi[s] = isa ? A.pbias[ja] : 0.f;
+    x[s] = (isd && rvalid) ? A.x0[(size_t)(row0 + row) * D + id] : 0.f;
+    ok_x[s] = isd && rvalid;
+    ok_a[s] = isa && rvalid;
+    so_x[s] = ((unsigned)(row0 + row) * D + id) * 4u;
+    so_a[s] = ((unsigned)(row0 + row) * U + ja) * 4u;
+    if (ok_x[s] && wid == 0) A.states[(size_t)(row0 + row) * D + id] = x[s];
+  }
+  f32x4 hbp, hbd;                   // head biases in accumulator-register order
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rp = pr_head_row(0, D, U, 4 * g + r), rd = pr_head_row(1, D, U, 4 * g + r);
+    hbp[r] = rp >= 0 ? (A.pol_params + A.pol.b_off[2])[rp] : 0.f;
+    hbd[r] = rd >= 0 ? (A.dyn_params + A.dyn.b_off[2])[rd] : 0.f;
+  }
+  // which input slots hold an action / a state dimension in ANY lane group (wave-uniform: the squash of a slot that
+  // is an action nowhere is skipped)
+  bool any_a[2], any_x[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    any_a[s] = false;
+    any_x[s] = false;
+    for (int gg = 0; gg < 4; ++gg) {
+      const int i = 2 * gg + s;
+      any_a[s] = any_a[s] || (i >= D && i < D + U);
+      any_x[s] = any_x[s] || i < D;
+    }
+  }
+  const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
+  unsigned amax = 0u;               // bit pattern of the largest magnitude that went into an fp16 piece so far
+  const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
+  float* const act_w = smem + PR_LDS_ACT + lane * 4;     // this lane's 16 bytes of every B fragment
+  const float* const mf_w = smem + PR_LDS_MF + (size_t)wid * (2 * 2 * PR_SLOTS * PR_FRAG) + lane * 4;
+  const float* const mfx_w = smem + PR_LDS_MFX + lane * 4;
+  const unsigned lane_st = ((4u * g) * 16u + row) * 4u;                // byte inside a stash block's tile
+  const pr_rsrc srd = pr_make_rsrc(A.ws);
+  // this lane's byte inside a step's activity bits.  Rows past the batch (the last workgroup's) write their all-zero
+  // nibbles into the 64 bytes of slack the plan leaves behind every activity-bit array and never advance: no store
+  // of the horizon loop sits under an exec mask
+  const unsigned ab_step = (unsigned)B * PR_NT * 4u;                   // bytes of a step's activity bits of one layer
+  unsigned vo_ab = rvalid ? ((unsigned)(row0 + row) * PR_NT) * 4u + g : (unsigned)A.H * ab_step + (unsigned)lane;
+  const unsigned vstep_ab = rvalid ? ab_step : 0u;
+
+  // one first layer: input B fragment from registers, one MFMA per tile, epilogue -> LDS (+ stashes)
+  auto first_layer = [&](auto netc, const float (&in)[2], int so_ab, int so_st) {
+    constexpr int NET = decltype(netc)::value;
+    // B fragment: slots 3 s + {0, 1, 2} = in.hi, in.lo, in.hi 2^-11; slots 6, 7 = 1, 2^-11
+    _Float16 hh[2], hl[2], hs[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      hh[s] = (_Float16)in[s];
+      hl[s] = (_Float16)(in[s] - (float)hh[s]);
+      hs[s] = hh[s] * (_Float16)PM_F16_LO_ISCALE;
+      amax = max(amax, __float_as_uint(in[s]) & 0x7fffffffu);
+    }
+    const pm_f16x8 bf = {hh[0], hl[0], hs[0], hh[1], hl[1], hs[1], (_Float16)1.0f, (_Float16)PM_F16_LO_ISCALE};
+    const float* l0w = smem + PR_LDS_L0(NET) + lane * 4;
+    const bool xw = NET == 0 ? xw_pol : xw_dyn;
+    f32x4 acc[PR_SLOTS + 1];
+    const f32x4 bfv = __builtin_bit_cast(f32x4, bf);
+    f32x4 wf[PR_SLOTS + 1];
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      wf[q] = *reinterpret_cast<const f32x4*>(l0w + (size_t)(4 * q + wid) * PR_FRAG);
+    });
+    wf[PR_SLOTS] = *reinterpret_cast<const f32x4*>(l0w + (size_t)PR_XT * PR_FRAG);
+    f32x4 mfv[PR_SLOTS + 1];
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      mfv[q] = *reinterpret_cast<const f32x4*>(mf_w + (size_t)((NET * 2 + 0) * PR_SLOTS + q) * PR_FRAG);
+    });
+    mfv[PR_SLOTS] = *reinterpret_cast<const f32x4*>(mfx_w + (size_t)(NET * 2 + 0) * PR_FRAG);
+    pr_mfma_open();
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      pr_mfma0<F16, false>(acc[q], wf[q], bfv);       // (the LDS-resident tile: computed by every wave, used by one)
+    });
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    auto epi = [&](auto qc, int ot) {
+      constexpr int q = decltype(qc)::value;
+      f32x4 h;
+      unsigned ab;
+      pm_u32x2 hi, lo;
+      pr_tile_epilogue<F16>(acc[q], mfv[q], h, ab, amax, hi, lo);
+      float* dst = act_w + (size_t)((ot >> 1) * 2) * PR_FRAG + 2 * (ot & 1);
+      *reinterpret_cast<pm_u32x2*>(dst) = hi;
+      *reinterpret_cast<pm_u32x2*>(dst + PR_FRAG) = lo;
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, so_ab + ot * 4, 0);
+      if constexpr (NET == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, so_st + ot * 1024, 0);
+      }
+    };
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      epi(qc, 4 * q + wid);
+    });
+    if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, PR_XT);
+  };
+
+  // hidden->hidden layer + head partial of network NET; leaves the summed head tile (+ bias) in `o`
+  auto second_layer_and_head = [&](auto netc, int so_ab, int so_st, f32x4& o) {
+    constexpr int NET = decltype(netc)::value;
+    const bool xw = NET == 0 ? xw_pol : xw_dyn;
+    f32x4 acc[PR_SLOTS][2], accx[2];
+    // LDS operands of the epilogues and of the head: requested before the MFMAs (one wave per SIMD: nothing else
+    // covers an LDS round trip taken right before its use)
+    f32x4 mfv[PR_SLOTS + 1], hwv[2][2];
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      mfv[q] = *reinterpret_cast<const f32x4*>(mf_w + (size_t)((NET * 2 + 1) * PR_SLOTS + q) * PR_FRAG);
+    });
+    mfv[PR_SLOTS] = *reinterpret_cast<const f32x4*>(mfx_w + (size_t)(NET * 2 + 1) * PR_FRAG);
+    const float* hw = smem + PR_LDS_HEAD(NET) + (size_t)wid * (4 * PR_FRAG) + lane * 4;
+#pragma unroll
+    for (int blkk = 0; blkk < 2; ++blkk) {
+      hwv[blkk][0] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 0) * PR_FRAG);
+      hwv[blkk][1] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 1) * PR_FRAG);
+    }
+    if (xw) pr_hidden_layer<NET, F16, true>(W, smem, smem + PR_LDS_XT(NET), lane, acc, accx);
+    else pr_hidden_layer<NET, F16, false>(W, smem, nullptr, lane, acc, accx);
+    // epilogues: activations of the wave's tiles as piece pairs (they ARE the head's B operand), stashes
+    pm_u32x2 hi[PR_SLOTS + 1], lo[PR_SLOTS + 1];
+    hi[PR_SLOTS] = lo[PR_SLOTS] = pm_u32x2{0u, 0u};
+    auto epi = [&](auto qc, f32x4 v, int ot) {
+      constexpr int q = decltype(qc)::value;
+      f32x4 h;
+      unsigned ab;
+      pr_tile_epilogue<F16>(v, mfv[q], h, ab, amax, hi[q], lo[q]);
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, so_ab + ot * 4, 0);
+      if constexpr (NET == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, so_st + ot * 1024, 0);
+      }
+    };
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      epi(qc, pr_tile_value<F16>(acc[q]), 4 * q + wid);
+    });
+    if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, pr_tile_value<F16>(accx), PR_XT);
+    // head, K-split: block 0 = slots 0, 1; block 1 = slot 2 and the LDS-resident tile (zeros elsewhere)
+    f32x4 c0, c1, bh[2], bl[2];
+#pragma unroll
+    for (int blkk = 0; blkk < 2; ++blkk) {
+      const pm_u32x2 ha = hi[2 * blkk], hb = hi[2 * blkk + 1], la = lo[2 * blkk], lb = lo[2 * blkk + 1];
+      bh[blkk] = __builtin_bit_cast(f32x4, (pr_u32x4){ha[0], ha[1], hb[0], hb[1]});
+      bl[blkk] = __builtin_bit_cast(f32x4, (pr_u32x4){la[0], la[1], lb[0], lb[1]});
+    }
+    pr_mfma_open();
+    pr_mfma0<F16, false>(c0, hwv[0][1], bh[0]);
+    pr_mfma0<F16, false>(c1, hwv[0][0], bl[0]);
+    pr_mfma<F16, false>(c0, hwv[1][1], bh[1]);
+    pr_mfma<F16, false>(c1, hwv[0][0], bh[0]);
+    pr_mfma<F16, false>(c1, hwv[1][0], bl[1]);
+    pr_mfma<F16, false>(c1, hwv[1][0], bh[1]);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1));
+    float* part = smem + PR_LDS_PART + lane * 4;
+    *reinterpret_cast<f32x4*>(part + wid * PR_FRAG) = pm_chains_sum<F16, 2>(c0, c1);
+    pr_barrier();
+    o = NET == 0 ? hbp : hbd;
+#pragma unroll
+    for (int w = 0; w < PR_NW; ++w) o += *reinterpret_cast<const f32x4*>(part + w * PR_FRAG);
+  };
+
+  // uniform 32-bit workspace offsets that advance with the step (one s_add each; the lanes' offsets are loop constants)
+  int so_st0 = (int)A.actT[0] + wg * 1024, so_st1 = (int)A.actT[1] + wg * (PR_NT * 1024), so_st2 = (int)A.actT[2] + wg * (PR_NT * 1024);
+  int so_td = (int)A.Td, so_tp = (int)A.Tp;
+  gch* b_states = (gch*)A.states + (size_t)B * D * 4u;     // x_{t+1}
+  gch* b_actions = (gch*)A.actions;
+  const int st_step0 = A.nwg * 1024, st_step = A.nwg * (PR_NT * 1024);
+  const unsigned x_step = (unsigned)B * D * 4u, a_step = (unsigned)B * U * 4u;
+
+  for (int t = 0; t < A.H; ++t) {
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 0] = (long long)__builtin_readcyclecounter();
+    // policy-input stash (feature-major [16][16] block: dimensions 0 .. 7 by wave 2, the zero rest by wave 3)
+    if (wid == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[s]), srd, ((2 * g + s) * 16 + row) * 4, so_st0, 0);
+    } else if (wid == 3) {
+      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 512 + lane * 4, so_st0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 768 + lane * 4, so_st0, 0);
+    }
+    // ---- policy
+    first_layer(std::integral_constant<int, 0>{}, x, (int)A.pol.abits[0], so_st1);
+    pr_barrier();
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 1] = (long long)__builtin_readcyclecounter();
+    f32x4 o;
+    second_layer_and_head(std::integral_constant<int, 0>{}, (int)A.pol.abits[1], so_st2, o);
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 2] = (long long)__builtin_readcyclecounter();
+    // ---- squash; dynamics input (normalised) in the same lane groups
+    float xin[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float v = x[s];
+      if (any_a[s]) {
+        const float mu = o[2 * s], ls = o[2 * s + 1];
+        const float sg = pr_rcp(1.f + expf(A.mls_pol - ls));
+        const float e = max_std_pol * sg;
+        const float u = mu + c_zp[s] * e;
+        const float a = c_psc[s] * pr_tanh(u) + c_pbi[s];
+        if (wid == 1 && ok_a[s]) {
+          *(gf32*)(b_actions + so_a[s]) = a;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zp[s] * e * (1.f - sg)), srd, so_a[s], so_tp, 0);
+        }
+        v = ok_a[s] ? a : v;
+      }
+      xin[s] = (v - c_mx[s]) * c_isx[s];
+    }
+    // ---- dynamics
+    first_layer(std::integral_constant<int, 1>{}, xin, (int)A.dyn.abits[0], 0);
+    pr_barrier();
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 3] = (long long)__builtin_readcyclecounter();
+    second_layer_and_head(std::integral_constant<int, 1>{}, (int)A.dyn.abits[1], 0, o);
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 4] = (long long)__builtin_readcyclecounter();
+    // ---- sample the next state
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (any_x[s]) {
+        const float mu = o[2 * s], ls = o[2 * s + 1];
+        const float sg = pr_rcp(1.f + expf(A.mls_dyn - ls));
+        const float e = max_std_dyn * c_sy[s] * sg;
+        const float xn = x[s] + (mu * c_sy[s] + c_my[s] + c_zd[s] * e);
+        if (wid == 0 && ok_x[s]) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], so_td, 0);
+          *(gf32*)(b_states + so_x[s]) = xn;
+        }
+        x[s] = ok_x[s] ? xn : 0.f;
+      }
+    }
+    // fp16 pieces: a value beyond the format's range was rounded to infinity somewhere in this step (or earlier)
+    if (amax > 0x477fe000u) atomicMin(A.status, t);      // 65504
+    // next step's bases
+    vo_ab += vstep_ab;
+    so_st0 += st_step0; so_st1 += st_step; so_st2 += st_step;
+    so_td += (int)x_step; so_tp += (int)a_step;
+    b_states += x_step; b_actions += a_step;
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
+  }
+}

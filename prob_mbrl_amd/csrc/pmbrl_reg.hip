@@ -1,0 +1,108 @@
+// Register-resident sweep kernels (pmbrl_reg.h): weight packer, attribute setup and launch dispatch.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "pmbrl_host.h"
+#include "pmbrl_reg.h"
+
+// does this plan's shape fit the family?  (decided once, at plan creation)
+bool pm_reg_plan_ok(const pmbrl_plan* p) {
+  const pmbrl_config& c = p->cfg;
+  if (const char* e = getenv("PMBRL_REG")) {
+    if (atoi(e) == 0) return false;
+  }
+  if (!p->fast || p->RT != 1 || p->prec != PMBRL_PREC_SPLIT_F16 || p->mm_mode != 0) return false;
+  if (c.flags & PMBRL_FLAG_NO_SHAPED) return false;
+  if (p->pol.nl != 3 || p->dyn.nl != 3) return false;
+  const int hid = p->pol.dim[1];
+  if (p->pol.dim[2] != hid || p->dyn.dim[1] != hid || p->dyn.dim[2] != hid) return false;
+  if ((hid + 15) / 16 != PR_NT) return false;
+  if (c.D + c.U > 8 || p->pol.dim[0] != c.D || p->dyn.dim[0] != c.D + c.U) return false;
+  if (p->pol.dim[3] != 2 * c.U || p->dyn.dim[3] != 2 * c.D) return false;
+  return true;
+}
+
+size_t pm_reg_pack_bytes() { return (size_t)PR_PACK_FLOATS * sizeof(float); }
+
+int pm_reg_set_attr(const pmbrl_plan* p) {
+  (void)p;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
+  return 0;
+}
+
+static void reg_net(const pmbrl_plan* p, const NetPlan& n, const NetDev& d, RegNet& r) {
+  (void)p;
+  for (int l = 0; l < 3; ++l) {
+    r.w_off[l] = (int)n.w_off[l];
+    r.b_off[l] = (int)n.b_off[l];
+  }
+  r.n_in = n.dim[0];
+  r.n_out = n.dim[3];
+  for (int l = 0; l < 2; ++l) {
+    r.mask[l] = d.mask[l];
+    r.abits[l] = (unsigned)n.abits[l];
+    r.inv_keep[l] = d.inv_keep[l];
+  }
+}
+
+static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* packed, const float* pol_params,
+                     const float* dyn_params, RegArgs& R) {
+  memset(&R, 0, sizeof(R));
+  R.B = A.B; R.H = A.H; R.D = A.D; R.U = A.U; R.nwg = A.nwg; R.hid = p->pol.dim[1];
+  R.mls_pol = A.mls_pol; R.mls_dyn = A.mls_dyn;
+  reg_net(p, p->pol, A.pol, R.pol);
+  reg_net(p, p->dyn, A.dyn, R.dyn);
+  R.packed = packed;
+  R.pol_params = pol_params; R.dyn_params = dyn_params;
+  R.x0 = A.x0; R.mx = A.mx; R.iSx = A.iSx; R.my = A.my; R.Sy = A.Sy; R.pscale = A.pscale; R.pbias = A.pbias;
+  R.zpol = A.zpol; R.zdyn = A.zdyn;
+  R.states = A.states; R.actions = A.actions;
+  R.ws = ws; R.Tp = (unsigned)p->off_Tp; R.Td = (unsigned)p->off_Td; R.Jx = (unsigned)p->off_Jx; R.Ja = (unsigned)p->off_Ja;
+  for (int l = 0; l < 3; ++l) { R.actT[l] = (unsigned)p->off_actT[l]; R.gT[l] = (unsigned)p->off_gT[l]; }
+  R.status = A.status;
+  R.wflag = A.wflag; R.wgen = A.wgen;
+  R.grad_rewards = A.grad_rewards; R.grad_x0 = A.grad_x0; R.nvalid = A.nvalid;
+  R.prof = A.prof;
+}
+
+// this launch can go to the family: the whole horizon in one launch, nothing optional asked for (what the LEAN
+// variant of pmbrl_fast.h serves)
+bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd) {
+  if (!p->reg || A.mm_mode != 0) return false;
+  if (!fwd) return false;      // (adjoint: not yet)
+  const bool ext = A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
+                   (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
+  return !ext;
+}
+
+void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
+                        hipStream_t s) {
+  RegPackArgs P;
+  memset(&P, 0, sizeof(P));
+  P.par[0] = pol_params; P.par[1] = dyn_params;
+  const NetPlan* nets[2] = {&p->pol, &p->dyn};
+  for (int n = 0; n < 2; ++n) {
+    for (int l = 0; l < 3; ++l) { P.w_off[n][l] = (int)nets[n]->w_off[l]; P.b_off[n][l] = (int)nets[n]->b_off[l]; }
+    P.n_in[n] = nets[n]->dim[0];
+    P.n_out[n] = nets[n]->dim[3];
+  }
+  P.D = p->cfg.D; P.U = p->cfg.U; P.hid = p->pol.dim[1];
+  P.out = reinterpret_cast<float*>(ws + p->off_reg_pack);
+  P.wflag = wflag; P.gen = gen;
+  P.status = nullptr;
+  const int total = 4 * (PR_NET_FLOATS / PR_FRAG) * 64;
+  hipLaunchKernelGGL(pm_reg_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P);
+}
+
+void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
+                   hipStream_t s, bool fwd) {
+  RegArgs R;
+  reg_args(p, ws, A, reinterpret_cast<const float*>(ws + p->off_reg_pack), pol_params, dyn_params, R);
+  if (fwd) {
+    if (R.prof) hipLaunchKernelGGL(pm_reg_fwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL(pm_reg_fwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+  }
+}
