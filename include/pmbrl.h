@@ -187,7 +187,8 @@ enum {
   PMBRL_INFO_PRECISION = 13, /* PMBRL_PREC_* actually in use */
   PMBRL_INFO_DW_PIPE = 14,   /* launches the adjoint sweep is cut into so that the dW GEMM runs behind it (1: no) */
   PMBRL_INFO_MM_PARTS = 15,  /* workgroups a moment-matching group is split over (in-kernel moment matching; 1: whole groups) */
-  PMBRL_INFO_COUNT = 16
+  PMBRL_INFO_REG = 16,       /* 1: the plain whole-horizon sweeps of this plan run on the register-resident family (pmbrl_reg.h) */
+  PMBRL_INFO_COUNT = 17
 };
 
 const char* pmbrl_last_error(void);

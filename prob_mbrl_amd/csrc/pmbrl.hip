@@ -1248,6 +1248,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[PMBRL_INFO_PRECISION] = p->prec;
   info[PMBRL_INFO_DW_PIPE] = p->pipe_K;
   info[PMBRL_INFO_MM_PARTS] = p->mm_parts;
+  info[PMBRL_INFO_REG] = p->reg;
   return 0;
 }
 
@@ -1757,7 +1758,8 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       if (A.xch) HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }
-    launch_bwd_rt(p, A, s);
+    if (pm_reg_can_run(p, A, false)) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
+    else launch_bwd_rt(p, A, s);
     A.gx_carry_out = nullptr;
   } else {
     ScopedTimer tm(p, PMBRL_TIMER_BWD, s);

@@ -273,9 +273,17 @@ __global__ __launch_bounds__(256) void pm_reg_pack_kernel(const RegPackArgs P) {
 // between a chain's last MFMA and the first VALU read of its accumulator (8-pass XDL: 12 states), pr_mfma_open()
 // those between a VALU write of an operand and the first MFMA of a group.
 // ---------------------------------------------------------------------------
-template <bool F16, bool AG>
+// NOP: two wait states in front of the instruction, INSIDE the statement.  A VGPR written by a VALU instruction may
+// not be read as an MFMA operand in the next two issue slots (hipcc pads that for its own MFMAs, not for asm), and
+// the compiler is free to schedule the VALU that builds an operand -- a cvt_pk of a fragment -- right in front of
+// the statement that consumes it: measured as garbage head / tail products before this was here.  The big hidden
+// layers need none (B operands come from ds_read, weights from the prologue).
+template <bool F16, bool AG, bool NOP = false>
 __device__ __forceinline__ void pr_mfma(f32x4& acc, const f32x4& w, const f32x4& b) {
-  if constexpr (F16) {
+  if constexpr (NOP) {
+    if constexpr (F16) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+  } else if constexpr (F16) {
     if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
     else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
   } else {
@@ -283,14 +291,13 @@ __device__ __forceinline__ void pr_mfma(f32x4& acc, const f32x4& w, const f32x4&
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
   }
 }
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: every stash store of
-// the phase (global_store, ~1 us to be acknowledged) would be waited for at every barrier of the horizon loop, and
-// nothing a barrier orders here goes through global memory.
-__device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // first product of a chain: C = 0 (inline constant), the accumulator is a pure output
-template <bool F16, bool AG>
+template <bool F16, bool AG, bool NOP = false>
 __device__ __forceinline__ void pr_mfma0(f32x4& acc, const f32x4& w, const f32x4& b) {
-  if constexpr (F16) {
+  if constexpr (NOP) {
+    if constexpr (F16) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
+  } else if constexpr (F16) {
     if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
     else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
   } else {
@@ -298,12 +305,20 @@ __device__ __forceinline__ void pr_mfma0(f32x4& acc, const f32x4& w, const f32x4
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
   }
 }
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt: every stash store of
+// the phase would be waited for at every barrier of the horizon loop, and nothing a barrier orders here goes through
+// global memory.
+__device__ __forceinline__ void pr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // One buffer descriptor over the whole workspace: every stash store of the sweeps is buffer_store v_data, v_lane_offset,
 // srd, s_uniform_offset offset:imm -- no 64-bit address arithmetic in VGPRs, no scalar register pair per array.
 typedef __amdgpu_buffer_rsrc_t pr_rsrc;
 __device__ __forceinline__ pr_rsrc pr_make_rsrc(void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000);
 }
+// a value every lane holds alike, pinned into a scalar register: the soffset operand of a buffer access must be one, and
+// hipcc wraps the access in a waterfall loop (readfirstlane / compare / saveexec per distinct value) whenever it cannot
+// PROVE that -- loop-carried offsets of the horizon loop, for one (cdna_hip_programming.md T20)
+__device__ __forceinline__ int pr_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void pr_mfma_open() { asm volatile("s_nop 3"); }
 __device__ __forceinline__ void pr_mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7"); }
 
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     pr_mfma_open();
     pr_for<PR_SLOTS + 1>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      pr_mfma0<F16, false>(acc[q], wf[q], bfv);       // (the LDS-resident tile: computed by every wave, used by one)
+      pr_mfma0<F16, false, true>(acc[q], wf[q], bfv);       // (the LDS-resident tile: computed by every wave, used by one)
     });
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     auto epi = [&](auto qc, int ot) {
@@ -604,11 +619,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       float* dst = act_w + (size_t)((ot >> 1) * 2) * PR_FRAG + 2 * (ot & 1);
       *reinterpret_cast<pm_u32x2*>(dst) = hi;
       *reinterpret_cast<pm_u32x2*>(dst + PR_FRAG) = lo;
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, so_ab + ot * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, pr_uni(so_ab + ot * 4), 0);
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, so_st + ot * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -631,14 +646,15 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       mfv[q] = *reinterpret_cast<const f32x4*>(mf_w + (size_t)((NET * 2 + 1) * PR_SLOTS + q) * PR_FRAG);
     });
     mfv[PR_SLOTS] = *reinterpret_cast<const f32x4*>(mfx_w + (size_t)(NET * 2 + 1) * PR_FRAG);
+    if (xw) pr_hidden_layer<NET, F16, true>(W, smem, smem + PR_LDS_XT(NET), lane, acc, accx);
+    else pr_hidden_layer<NET, F16, false>(W, smem, nullptr, lane, acc, accx);
+    // (the head's weights: requested here, they land behind the epilogues)
     const float* hw = smem + PR_LDS_HEAD(NET) + (size_t)wid * (4 * PR_FRAG) + lane * 4;
 #pragma unroll
     for (int blkk = 0; blkk < 2; ++blkk) {
       hwv[blkk][0] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 0) * PR_FRAG);
       hwv[blkk][1] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 1) * PR_FRAG);
     }
-    if (xw) pr_hidden_layer<NET, F16, true>(W, smem, smem + PR_LDS_XT(NET), lane, acc, accx);
-    else pr_hidden_layer<NET, F16, false>(W, smem, nullptr, lane, acc, accx);
     // epilogues: activations of the wave's tiles as piece pairs (they ARE the head's B operand), stashes
     pm_u32x2 hi[PR_SLOTS + 1], lo[PR_SLOTS + 1];
     hi[PR_SLOTS] = lo[PR_SLOTS] = pm_u32x2{0u, 0u};
@@ -647,11 +663,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       f32x4 h;
       unsigned ab;
       pr_tile_epilogue<F16>(v, mfv[q], h, ab, amax, hi[q], lo[q]);
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, so_ab + ot * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, pr_uni(so_ab + ot * 4), 0);
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, so_st + ot * 1024, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -668,12 +684,12 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       bl[blkk] = __builtin_bit_cast(f32x4, (pr_u32x4){la[0], la[1], lb[0], lb[1]});
     }
     pr_mfma_open();
-    pr_mfma0<F16, false>(c0, hwv[0][1], bh[0]);
-    pr_mfma0<F16, false>(c1, hwv[0][0], bl[0]);
-    pr_mfma<F16, false>(c0, hwv[1][1], bh[1]);
-    pr_mfma<F16, false>(c1, hwv[0][0], bh[0]);
-    pr_mfma<F16, false>(c1, hwv[1][0], bl[1]);
-    pr_mfma<F16, false>(c1, hwv[1][0], bh[1]);
+    pr_mfma0<F16, false, true>(c0, hwv[0][1], bh[0]);
+    pr_mfma0<F16, false, true>(c1, hwv[0][0], bl[0]);
+    pr_mfma<F16, false, true>(c0, hwv[1][1], bh[1]);
+    pr_mfma<F16, false, true>(c1, hwv[0][0], bh[0]);
+    pr_mfma<F16, false, true>(c1, hwv[1][0], bl[1]);
+    pr_mfma<F16, false, true>(c1, hwv[1][0], bh[1]);
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1));
     float* part = smem + PR_LDS_PART + lane * 4;
     *reinterpret_cast<f32x4*>(part + wid * PR_FRAG) = pm_chains_sum<F16, 2>(c0, c1);
@@ -697,10 +713,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     if (wid == 2) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[s]), srd, ((2 * g + s) * 16 + row) * 4, so_st0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[s]), srd, ((2 * g + s) * 16 + row) * 4, pr_uni(so_st0), 0);
     } else if (wid == 3) {
-      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 512 + lane * 4, so_st0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 768 + lane * 4, so_st0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 512 + lane * 4, pr_uni(so_st0), 0);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 768 + lane * 4, pr_uni(so_st0), 0);
     }
     // ---- policy
     first_layer(std::integral_constant<int, 0>{}, x, (int)A.pol.abits[0], so_st1);
@@ -722,7 +738,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         const float a = c_psc[s] * pr_tanh(u) + c_pbi[s];
         if (wid == 1 && ok_a[s]) {
           *(gf32*)(b_actions + so_a[s]) = a;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zp[s] * e * (1.f - sg)), srd, so_a[s], so_tp, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zp[s] * e * (1.f - sg)), srd, so_a[s], pr_uni(so_tp), 0);
         }
         v = ok_a[s] ? a : v;
       }
@@ -743,7 +759,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         const float e = max_std_dyn * c_sy[s] * sg;
         const float xn = x[s] + (mu * c_sy[s] + c_my[s] + c_zd[s] * e);
         if (wid == 0 && ok_x[s]) {
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], so_td, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], pr_uni(so_td), 0);
           *(gf32*)(b_states + so_x[s]) = xn;
         }
         x[s] = ok_x[s] ? xn : 0.f;
@@ -757,5 +773,356 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     so_td += (int)x_step; so_tp += (int)a_step;
     b_states += x_step; b_actions += a_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
+  }
+}
+
+// ===========================================================================
+// adjoint sweep
+// ===========================================================================
+// Same workgroup shape, same partition of the tiles, the transposed weights resident (two bf16 pieces: gradients of any
+// magnitude).  Per step, dynamics model first:
+//   head adjoint   [g Sy | g Td] (two K = 32 blocks: the means' rows, the log-stds' rows) -> hidden width, two MFMAs a tile
+//   x activity bits of the second hidden layer -> LDS -> barrier
+//   V1^T           resident tiles -> x activity bits of the first hidden layer (stays in registers)
+//   tail           V0, K-split over the waves from registers -> partial tiles -> barrier -> sum: gradient of [x | a]
+// then the policy the same way, with the pre-activation gradients stashed for the dW GEMM (feature-major, what
+// pm_dw_* read).  The activity nibbles of a step are fetched a step ahead; a nibble becomes its four multipliers
+// {0, 1 / keep} through a 16-entry table in LDS (one ds_read_b128).
+#define PRB_LDS_ACT 0
+#define PRB_LDS_PART (PRB_LDS_ACT + PR_KB * 2 * PR_FRAG)
+#define PRB_LDS_L0(net) (PRB_LDS_PART + PR_NW * PR_FRAG + (net) * (PR_L0P_FLOATS + PR_XT_FLOATS + PR_HEAD_FLOATS))
+#define PRB_LDS_XT(net) (PRB_LDS_L0(net) + PR_L0P_FLOATS)
+#define PRB_LDS_HEAD(net) (PRB_LDS_XT(net) + PR_XT_FLOATS)
+#define PRB_LDS_LUT (PRB_LDS_L0(2))              // [net][layer][16 nibbles][4]
+#define PRB_LDS_FLOATS (PRB_LDS_LUT + 2 * 2 * 16 * 4)
+
+template <bool PROF>
+__global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool F16 = false;
+  typedef PM_GLOBAL_ float gf32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int row = lane & 15, g = lane >> 4;
+  const int row0 = wg * 16;
+  const int nvalid = min(16, A.B - row0);
+  const bool rvalid = row < nvalid;
+  const int D = A.D, U = A.U, B = A.B;
+  int T1 = A.H;
+  if (A.nvalid) T1 = min(T1, __builtin_amdgcn_readfirstlane(*A.nvalid));
+  const float* packed = A.packed + (size_t)2 * PR_NET_FLOATS;     // direction 1
+  if (T1 <= 0) {
+    if (A.grad_x0)
+      for (int i = tid; i < nvalid * D; i += PR_NTHR) A.grad_x0[(size_t)row0 * D + i] = 0.f;
+    return;
+  }
+
+  // ---- prologue
+  RegW W;
+  pr_load_resident(W, packed, wid, lane);
+  for (int net = 0; net < 2; ++net) {
+    const float* src = packed + (size_t)net * PR_NET_FLOATS;
+    for (int i = tid; i < PR_L0P_FLOATS / 4; i += PR_NTHR)
+      *reinterpret_cast<f32x4*>(smem + PRB_LDS_L0(net) + i * 4) = ldg4(src + PR_OFF_L0 + i * 4);
+    for (int i = tid; i < PR_XT_FLOATS / 4; i += PR_NTHR)
+      *reinterpret_cast<f32x4*>(smem + PRB_LDS_XT(net) + i * 4) = ldg4(src + PR_OFF_XT + i * 4);
+    for (int i = tid; i < PR_HEAD_FLOATS / 4; i += PR_NTHR)
+      *reinterpret_cast<f32x4*>(smem + PRB_LDS_HEAD(net) + i * 4) = ldg4(src + PR_OFF_HEAD + i * 4);
+  }
+  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PRB_LDS_ACT + i] = 0.f;
+  if (tid < 64) {
+    // nibble -> {0, 1 / keep} x 4
+    const int n = tid >> 5, l = (tid >> 4) & 1, nib = tid & 15;
+    const float ik = (n == 0 ? A.pol : A.dyn).inv_keep[l];
+    f32x4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = ((nib >> r) & 1) ? ik : 0.f;
+    *reinterpret_cast<f32x4*>(smem + PRB_LDS_LUT + tid * 4) = m;
+  }
+  __syncthreads();
+
+  // ---- per-lane constants: input slot s (0, 1) of this lane group = network input 2 g + s
+  float c_isx[2], c_sy[2], c_psc[2], c_pbi[2];
+  bool ok_x[2], ok_a[2];
+  unsigned so_x[2], so_a[2];        // byte offsets of this lane's [t][row][dim] / [t][row][action] entries at t = 0
+  float gx[2] = {0.f, 0.f};         // dL/dx_{t+1} of state dimensions 2 g, 2 g + 1 of this lane's row
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int i = 2 * g + s;
+    const bool isd = i < D, isa = i >= D && i < D + U;
+    const int ja = isa ? i - D : 0, id = isd ? i : 0;
+    c_isx[s] = (isd || isa) ? A.iSx[i] : 0.f;
+    c_sy[s] = isd ? A.Sy[id] : 0.f;
+    c_psc[s] = isa ? A.pscale[ja] : 1.f;
+    c_pbi[s] = isa ? A.pbias[ja] : 0.f;
+    ok_x[s] = isd && rvalid;
+    ok_a[s] = isa && rvalid;
+    so_x[s] = ((unsigned)(row0 + row) * D + id) * 4u;
+    so_a[s] = ((unsigned)(row0 + row) * U + ja) * 4u;
+  }
+  const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
+  float* const act_w = smem + PRB_LDS_ACT + lane * 4;
+  const float* const lut = smem + PRB_LDS_LUT;
+  const unsigned lane_st = ((4u * g) * 16u + row) * 4u;
+  const pr_rsrc srd = pr_make_rsrc(A.ws);
+  const pr_rsrc srd_gr = pr_make_rsrc(const_cast<float*>(A.grad_rewards));
+  const pr_rsrc srd_act = pr_make_rsrc(A.actions);
+  const unsigned ab_step = (unsigned)B * PR_NT * 4u;
+  // this lane's activity byte of a tile, at the LAST step; rows past the batch read the slack behind the array
+  // (whatever is there: their gradients are zero anyway -- multiplied into zeros)
+  const unsigned vstep_ab = rvalid ? ab_step : 0u;
+  unsigned vo_ab = rvalid ? ((unsigned)(row0 + row) * PR_NT) * 4u + g + (unsigned)(T1 - 1) * ab_step
+                          : (unsigned)A.H * ab_step + (unsigned)lane;
+  const unsigned x_step = (unsigned)B * D * 4u, a_step = (unsigned)B * U * 4u;
+  int so_td = (int)A.Td + (T1 - 1) * (int)x_step, so_jx = (int)A.Jx + (T1 - 1) * (int)x_step;
+  int so_tp = (int)A.Tp + (T1 - 1) * (int)a_step, so_ja = (int)A.Ja + (T1 - 1) * (int)a_step;
+  int so_ac = (T1 - 1) * (int)a_step, so_gr = (T1 - 1) * B * 4;
+  const int st_step = A.nwg * (PR_NT * 1024), st_step2 = A.nwg * 1024;
+  int so_g0 = (int)A.gT[0] + ((T1 - 1) * A.nwg + wg) * (PR_NT * 1024);
+  int so_g1 = (int)A.gT[1] + ((T1 - 1) * A.nwg + wg) * (PR_NT * 1024);
+  int so_g2 = (int)A.gT[2] + ((T1 - 1) * A.nwg + wg) * 1024;
+
+  // per-row inputs of a step.  What the step needs AT ONCE -- dL/dr~, the reward Jacobian and Td of the lane's two state
+  // dimensions, the activity nibbles of the dynamics model's second hidden layer -- is fetched a step ahead; the rest
+  // (Ja, Tp, a of the action slots, the other three layers' nibbles) is requested when the step starts and used
+  // thousands of cycles later.  (Everything a step ahead was 38 more live registers than the file holds.)
+  struct StepNow {
+    float gr, jx[2], td[2];
+    unsigned ab[PR_SLOTS + 1];
+  };
+  struct StepLater {
+    float ja[2], tp[2], ac[2];
+    unsigned ab[3][PR_SLOTS + 1];      // dynamics layer 0, policy layer 1, policy layer 0
+  };
+  auto load_ab = [&](unsigned (&b)[PR_SLOTS + 1], int so) {
+#pragma unroll
+    for (int q = 0; q <= PR_SLOTS; ++q) {
+      const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
+      b[q] = __builtin_amdgcn_raw_buffer_load_b8(srd, vo_ab, pr_uni(so + ot * 4), 0);
+    }
+  };
+  auto load_now = [&](StepNow& I) {
+    I.gr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_gr, rvalid ? (row0 + row) * 4 : 0, pr_uni(so_gr), 0));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      I.jx[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_x[s], pr_uni(so_jx), 0));
+      I.td[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_x[s], pr_uni(so_td), 0));
+    }
+    load_ab(I.ab, (int)A.dyn.abits[1]);
+  };
+  auto mask_now = [&](StepNow& I) {
+    if (!rvalid) I.gr = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (!ok_x[s]) { I.jx[s] = 0.f; I.td[s] = 0.f; }
+  };
+  auto load_later = [&](StepLater& I) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      I.ja[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_a[s], pr_uni(so_ja), 0));
+      I.tp[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_a[s], pr_uni(so_tp), 0));
+      I.ac[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_act, so_a[s], pr_uni(so_ac), 0));
+    }
+    load_ab(I.ab[0], (int)A.dyn.abits[0]);
+    load_ab(I.ab[1], (int)A.pol.abits[1]);
+    load_ab(I.ab[2], (int)A.pol.abits[0]);
+  };
+
+  // head adjoint of network NET: inputs gm (x the means' rows), gl (x the log-stds' rows) of the lane's two slots;
+  // result x activity of the second hidden layer -> LDS (+ stash)
+  auto head_adjoint = [&](auto netc, const float (&gm)[2], const float (&gl)[2], const unsigned (&ab)[PR_SLOTS + 1], int so_st) {
+    constexpr int NET = decltype(netc)::value;
+    // B fragments: slots 3 s + {0, 1, 2} = g.hi, g.lo, g.hi
+    f32x4 bf[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned short hh[2], hl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float v = k == 0 ? gm[s] : gl[s];
+        const unsigned a = pm_pk_bf16(v, 0.f) & 0xffffu;
+        hh[s] = (unsigned short)a;
+        hl[s] = (unsigned short)(pm_pk_bf16(v - pm_bf_lo(a), 0.f) & 0xffffu);
+      }
+      const pr_u32x4 u = {(unsigned)hh[0] | ((unsigned)hl[0] << 16), (unsigned)hh[0] | ((unsigned)hh[1] << 16),
+                          (unsigned)hl[1] | ((unsigned)hh[1] << 16), 0u};
+      bf[k] = __builtin_bit_cast(f32x4, u);
+    }
+    const float* l0w = smem + PRB_LDS_L0(NET) + lane * 4;
+    const bool xw = NET == 0 ? xw_pol : xw_dyn;
+    f32x4 acc[PR_SLOTS + 1], wf[PR_SLOTS + 1][2], mfv[PR_SLOTS + 1];
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
+      wf[q][0] = *reinterpret_cast<const f32x4*>(l0w + (size_t)(ot * 2 + 0) * PR_FRAG);
+      wf[q][1] = *reinterpret_cast<const f32x4*>(l0w + (size_t)(ot * 2 + 1) * PR_FRAG);
+      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 1) * 16 + (ab[q] & 15u)) * 4);
+    });
+    pr_mfma_open();
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      pr_mfma0<F16, false, true>(acc[q], wf[q][0], bf[0]);
+    });
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      pr_mfma<F16, false, true>(acc[q], wf[q][1], bf[1]);
+    });
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    auto epi = [&](auto qc, int ot) {
+      constexpr int q = decltype(qc)::value;
+      const f32x4 gq = acc[q] * mfv[q];
+      pm_u32x2 pc[2];
+      pm_split4<2, false>(gq, pc);
+      float* dst = act_w + (size_t)((ot >> 1) * 2) * PR_FRAG + 2 * (ot & 1);
+      *reinterpret_cast<pm_u32x2*>(dst) = pc[0];
+      *reinterpret_cast<pm_u32x2*>(dst + PR_FRAG) = pc[1];
+      if constexpr (NET == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+      }
+    };
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      epi(qc, 4 * q + wid);
+    });
+    if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, PR_XT);
+  };
+
+  // transposed hidden->hidden layer + tail of network NET; leaves the summed tail tile in `o`
+  auto hidden_adjoint_and_tail = [&](auto netc, const unsigned (&ab)[PR_SLOTS + 1], int so_st, f32x4& o) {
+    constexpr int NET = decltype(netc)::value;
+    const bool xw = NET == 0 ? xw_pol : xw_dyn;
+    f32x4 acc[PR_SLOTS][2], accx[2];
+    f32x4 mfv[PR_SLOTS + 1], hwv[2][2];
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 0) * 16 + (ab[q] & 15u)) * 4);
+    });
+    if (xw) pr_hidden_layer<NET, F16, true>(W, smem, smem + PRB_LDS_XT(NET), lane, acc, accx);
+    else pr_hidden_layer<NET, F16, false>(W, smem, nullptr, lane, acc, accx);
+    // (the tail's weights: requested here, they land behind the epilogues)
+    const float* hw = smem + PRB_LDS_HEAD(NET) + (size_t)wid * (4 * PR_FRAG) + lane * 4;
+#pragma unroll
+    for (int blkk = 0; blkk < 2; ++blkk) {
+      hwv[blkk][0] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 0) * PR_FRAG);
+      hwv[blkk][1] = *reinterpret_cast<const f32x4*>(hw + (blkk * 2 + 1) * PR_FRAG);
+    }
+    pm_u32x2 hi[PR_SLOTS + 1], lo[PR_SLOTS + 1];
+    hi[PR_SLOTS] = lo[PR_SLOTS] = pm_u32x2{0u, 0u};
+    auto epi = [&](auto qc, f32x4 v, int ot) {
+      constexpr int q = decltype(qc)::value;
+      const f32x4 gq = v * mfv[q];
+      pm_u32x2 pc[2];
+      pm_split4<2, false>(gq, pc);
+      hi[q] = pc[0];
+      lo[q] = pc[1];
+      if constexpr (NET == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+      }
+    };
+    pr_for<PR_SLOTS>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      epi(qc, pr_tile_value<F16>(acc[q]), 4 * q + wid);
+    });
+    if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, pr_tile_value<F16>(accx), PR_XT);
+    f32x4 c0, c1, bh[2], bl[2];
+#pragma unroll
+    for (int blkk = 0; blkk < 2; ++blkk) {
+      const pm_u32x2 ha = hi[2 * blkk], hb = hi[2 * blkk + 1], la = lo[2 * blkk], lb = lo[2 * blkk + 1];
+      bh[blkk] = __builtin_bit_cast(f32x4, (pr_u32x4){ha[0], ha[1], hb[0], hb[1]});
+      bl[blkk] = __builtin_bit_cast(f32x4, (pr_u32x4){la[0], la[1], lb[0], lb[1]});
+    }
+    pr_mfma_open();
+    pr_mfma0<F16, false, true>(c0, hwv[0][1], bh[0]);
+    pr_mfma0<F16, false, true>(c1, hwv[0][0], bl[0]);
+    pr_mfma<F16, false, true>(c0, hwv[1][1], bh[1]);
+    pr_mfma<F16, false, true>(c1, hwv[0][0], bh[0]);
+    pr_mfma<F16, false, true>(c1, hwv[1][0], bl[1]);
+    pr_mfma<F16, false, true>(c1, hwv[1][0], bh[1]);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1));
+    float* part = smem + PRB_LDS_PART + lane * 4;
+    *reinterpret_cast<f32x4*>(part + wid * PR_FRAG) = c0 + c1;
+    pr_barrier();
+    o = *reinterpret_cast<const f32x4*>(part);
+#pragma unroll
+    for (int w = 1; w < PR_NW; ++w) o += *reinterpret_cast<const f32x4*>(part + w * PR_FRAG);
+  };
+
+  StepNow In, InN;
+  load_now(In);
+  mask_now(In);
+  for (int t = T1 - 1; t >= 0; --t) {
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 0] = (long long)__builtin_readcyclecounter();
+    StepLater Il;
+    load_later(Il);
+    // the early inputs of step t - 1: on their way while this step computes
+    if (t > 0) {
+      vo_ab -= vstep_ab;
+      so_td -= (int)x_step; so_jx -= (int)x_step; so_gr -= B * 4;
+      load_now(InN);
+    }
+    // ---- dynamics model: gradient of the sampled state, through the head
+    float gxn[2], gm[2], gl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float gg = gx[s] + In.gr * In.jx[s];
+      gxn[s] = gg;
+      gm[s] = gg * c_sy[s];
+      gl[s] = gg * In.td[s];
+    }
+    head_adjoint(std::integral_constant<int, 1>{}, gm, gl, In.ab, 0);
+    pr_barrier();
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 1] = (long long)__builtin_readcyclecounter();
+    f32x4 o;
+    hidden_adjoint_and_tail(std::integral_constant<int, 1>{}, Il.ab[0], 0, o);
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 2] = (long long)__builtin_readcyclecounter();
+    // ---- gradient of [x | a] (normalised inputs): state part -> gxn, action part -> through the squashing
+    float pm_[2], pl_[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float tail = o[2 * s] * c_isx[s];
+      gxn[s] += ok_x[s] ? tail : 0.f;
+      const float ga = In.gr * (ok_a[s] ? Il.ja[s] : 0.f) + tail;
+      const float th = ((ok_a[s] ? Il.ac[s] : c_pbi[s]) - c_pbi[s]) * pr_rcp(c_psc[s]);
+      const float gu = ok_a[s] ? ga * c_psc[s] * (1.f - th * th) : 0.f;
+      pm_[s] = gu;
+      pl_[s] = ok_a[s] ? gu * Il.tp[s] : 0.f;
+    }
+    // head-gradient stash of the policy ([16][16] block: row j = d mean_j, row U + j = d log-std_j, zero below)
+    if (wid == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = 2 * g + s - D;
+        if (j >= 0 && j < U) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pm_[s]), srd, (j * 16 + row) * 4, pr_uni(so_g2), 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pl_[s]), srd, ((U + j) * 16 + row) * 4, pr_uni(so_g2), 0);
+        }
+      }
+    } else if (wid == 3) {
+      for (int k = 2 * U * 16 + lane; k < 256; k += 64) __builtin_amdgcn_raw_buffer_store_b32(0u, srd, k * 4, pr_uni(so_g2), 0);
+    }
+    head_adjoint(std::integral_constant<int, 0>{}, pm_, pl_, Il.ab[1], so_g1);
+    pr_barrier();
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 3] = (long long)__builtin_readcyclecounter();
+    hidden_adjoint_and_tail(std::integral_constant<int, 0>{}, Il.ab[2], so_g0, o);
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 4] = (long long)__builtin_readcyclecounter();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) gx[s] = ok_x[s] ? gxn[s] + o[2 * s] : 0.f;
+    so_g0 -= st_step; so_g1 -= st_step; so_g2 -= st_step2;
+    so_tp -= (int)a_step; so_ja -= (int)a_step; so_ac -= (int)a_step;
+    if (t > 0) {
+      In = InN;
+      mask_now(In);
+    }
+    if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
+  }
+  if (A.grad_x0 && wid == 0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (ok_x[s]) *(gf32*)((PM_GLOBAL_ char*)A.grad_x0 + so_x[s]) = gx[s];
   }
 }

@@ -30,6 +30,10 @@ int pm_reg_set_attr(const pmbrl_plan* p) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
   return 0;
 }
 
@@ -72,7 +76,7 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
 // variant of pmbrl_fast.h serves)
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd) {
   if (!p->reg || A.mm_mode != 0) return false;
-  if (!fwd) return false;      // (adjoint: not yet)
+  if (!fwd && getenv("PMBRL_REG_BWD") && atoi(getenv("PMBRL_REG_BWD")) == 0) return false;
   const bool ext = A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
                    (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
   return !ext;
@@ -101,8 +105,15 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
                    hipStream_t s, bool fwd) {
   RegArgs R;
   reg_args(p, ws, A, reinterpret_cast<const float*>(ws + p->off_reg_pack), pol_params, dyn_params, R);
+  if (getenv("PMBRL_REG_DEBUG"))
+    fprintf(stderr, "pm_reg_launch %s: off_reg_pack %zu gT %zu %zu %zu actT %zu %zu %zu abits %zu %zu %zu %zu ws_bytes %zu\n", fwd ? "fwd" : "bwd",
+            p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
+            p->pol.abits[0], p->pol.abits[1], p->dyn.abits[0], p->dyn.abits[1], p->ws_bytes);
   if (fwd) {
     if (R.prof) hipLaunchKernelGGL(pm_reg_fwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
     else hipLaunchKernelGGL(pm_reg_fwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+  } else {
+    if (R.prof) hipLaunchKernelGGL(pm_reg_bwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL(pm_reg_bwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
   }
 }
