@@ -1079,9 +1079,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
         n->wb[l] = take(fr);
         n->bias[l] = take((size_t)n->nt[l + 1] * 16 * sizeof(float));
         if (l < n->nl - 1)
-          // u16 (generic) or 4 nibble-bytes (fast); 64 bytes of slack behind it: where the register-resident family's
-          // rows past the batch put their (zero) bytes (pmbrl_reg.h)
-          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * 4 + 64);
+          // u16 (generic) or 4 nibble-bytes (fast); 256 bytes of slack behind it: where the register-resident family's
+          // rows past the batch put their (zero) bytes -- lane (< 64) + 4 x tile (< 64) past the end (pmbrl_reg.h)
+          n->abits[l] = take((size_t)c.H * c.B * n->nt[l + 1] * 4 + 256);
       }
     }
     const size_t Rw = 16 * p->RT;

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   const unsigned lane_st = ((4u * g) * 16u + row) * 4u;                // byte inside a stash block's tile
   const pr_rsrc srd = pr_make_rsrc(A.ws);
   // this lane's byte inside a step's activity bits.  Rows past the batch (the last workgroup's) write their all-zero
-  // nibbles into the 64 bytes of slack the plan leaves behind every activity-bit array and never advance: no store
+  // nibbles into the 256 bytes of slack the plan leaves behind every activity-bit array (lane + 4 x tile < 128) and never advance: no store
   // of the horizon loop sits under an exec mask
   const unsigned ab_step = (unsigned)B * PR_NT * 4u;                   // bytes of a step's activity bits of one layer
   unsigned vo_ab = rvalid ? ((unsigned)(row0 + row) * PR_NT) * 4u + g : (unsigned)A.H * ab_step + (unsigned)lane;

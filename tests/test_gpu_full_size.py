@@ -136,7 +136,9 @@ def test_gradient_is_linear_in_loss_weights():
     w1 = gw * torch.rand_like(gw)
     ga = eng.backward(w1)[0].cpu().numpy().copy()
     gb = eng.backward(gw - w1)[0].cpu().numpy().copy()
-    assert common.rel(ga + gb, g) < 2e-6
+    # (two bf16 pieces per operand in every product of the adjoint sweep: 2^-17 per product, the sum of two roundings
+    #  is not the rounding of the sum)
+    assert common.rel(ga + gb, g) < 4e-6
 
 
 def test_rows_are_independent():

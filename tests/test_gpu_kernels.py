@@ -605,37 +605,40 @@ def test_fused_tail_matches_the_separate_launches(dev, name, generic):
     B = d['x0'].shape[0]
     gw = torch.tensor(common.loss_weights(d, B), device=dev)
 
-    def run(fused):
-        eng, args, _ = common.engine_from_fixture(d, dev, force_generic=generic)
-        p = args['pol_flat'].clone()
-        args['pol_flat'] = p
-        m, v = torch.zeros_like(p), torch.zeros_like(p)
-        step = torch.zeros(1, dtype=torch.int64, device=dev)
-        norm = torch.zeros(1, device=dev)
-        out = []
-        loss_buf = eng.set_loss(gw) if fused else torch.zeros(1, device=dev)
-        for it in range(1, 4):
-            _, _, R = eng.forward(**args)
-            if fused:
-                g, _, _ = eng.backward(gw, adam=dict(params=p, exp_avg=m, exp_avg_sq=v, step=step, lr=1e-3,
-                                                     betas=(0.9, 0.999), eps=1e-8, max_norm=0.05, norm_out=norm))
-            else:
-                eng.weighted_sum(R, gw, out=loss_buf)
-                g, _, _ = eng.backward(gw)
-                E.clip_adam(p, g, m, v, it, 1e-3, max_norm=0.05, norm_out=norm)
-            out.append((float(loss_buf), float(norm), g.clone(), p.clone(), m.clone(), v.clone()))
-        return eng, args, (p, m, v, step), out
-
-    _, _, _, ref = run(False)
-    eng, args, (p, m, v, step), got = run(True)
+    # The fused calls walk three iterations; every one of them is then replayed through the separate calls FROM THE SAME
+    # parameters and moments (not from the separate calls' own trajectory: the device-side step takes its bias corrections
+    # from device pow(), equal to the host's to rounding, and a policy gradient is not continuous in the parameters -- with
+    # 37 rows one ReLU unit changing sides under a 1e-7 parameter difference moves it by 1e-3, which says nothing about
+    # the fused tail).  Same parameters: the same kernels, the same bits for loss and gradient; the update to rounding.
+    eng, args, _ = common.engine_from_fixture(d, dev, force_generic=generic)
+    p = args['pol_flat'].clone()
+    args['pol_flat'] = p
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    norm = torch.zeros(1, device=dev)
+    loss_buf = eng.set_loss(gw)
+    walk = []
+    for it in range(1, 4):
+        before = (p.clone(), m.clone(), v.clone())
+        eng.forward(**args)
+        g, _, _ = eng.backward(gw, adam=dict(params=p, exp_avg=m, exp_avg_sq=v, step=step, lr=1e-3,
+                                             betas=(0.9, 0.999), eps=1e-8, max_norm=0.05, norm_out=norm))
+        walk.append((before, float(loss_buf), float(norm), g.clone(), p.clone(), m.clone(), v.clone()))
     assert int(step.item()) == 3
-    for a, b in zip(ref, got):
-        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-4 * a[1]
-        # (the guarded form takes its bias corrections from the device-side step counter -- device pow() against the
-        #  host's, equal to rounding -- so from the second iteration on the parameters differ in the last bits)
-        for x, y in zip(a[2:], b[2:]):
+    ref_eng, ref_args, _ = common.engine_from_fixture(d, dev, force_generic=generic)
+    for it, (before, loss_f, norm_f, g_f, p_f, m_f, v_f) in enumerate(walk, 1):
+        pr, mr, vr = (t.clone() for t in before)
+        ref_args['pol_flat'] = pr
+        ref_loss, ref_norm = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        _, _, R = ref_eng.forward(**ref_args)
+        ref_eng.weighted_sum(R, gw, out=ref_loss)
+        g_r, _, _ = ref_eng.backward(gw)
+        g_r = g_r.clone()
+        E.clip_adam(pr, g_r, mr, vr, it, 1e-3, max_norm=0.05, norm_out=ref_norm)
+        assert float(ref_loss) == loss_f and torch.equal(g_r, g_f)
+        assert abs(float(ref_norm) - norm_f) <= 1e-6 * norm_f
+        for x, y in ((pr, p_f), (mr, m_f), (vr, v_f)):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-5 * float(x.abs().max()))
-    assert torch.equal(ref[0][2], got[0][2])    # first iteration, same parameters: the same kernels, the same bits
     # a failed rollout: the status word says step 3 of H failed -> nothing moves
     eng.forward(**args)
     eng.status[0] = 3
