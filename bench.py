@@ -57,6 +57,10 @@ def parse():
     ap.add_argument('--no-second-curve', action='store_true', help='N > 1: skip the other scaling curve')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
+    ap.add_argument('--pmc', action='store_true',
+                    help='N = 1: first collect the HBM-traffic and MFMA counters of this build and configuration by re-running '
+                         'under rocprofv3 --pmc (one pass per counter set, a few minutes), write profiles/pmc_<config>_<precision>.json, '
+                         'then time as usual and report them as measured in this run')
     # debugging aids for the N>1 control flow on a box with ONE GPU (tests/test_gpu_api.py):
     # every rank on cuda:0, collectives over gloo.  Never used for a reported number.
     ap.add_argument('--transport', default='rccl', choices=['rccl', 'p2p'],
@@ -271,6 +275,9 @@ class Leg:
         kname = {'fwd': 'pm_rollout_fwd', 'bwd': 'pm_rollout_bwd', 'dw': 'pm_dw_kernel'}[dom]
         if eng.info.get('fast') and dom != 'dw':
             kname += '_fast'
+        reg = bool(eng.info.get('reg')) and dom != 'dw' and not (dom == 'bwd' and os.environ.get('PMBRL_REG_BWD') == '0')
+        if reg:         # the register-resident family (csrc/pmbrl_reg.h): weights live in the four waves' registers
+            kname = 'pm_reg_%s_kernel' % dom
         prec = eng.info['precision']
         mfma_per_product = {('f32', 'fwd'): 1, ('f32', 'bwd'): 1, ('split', 'fwd'): 6, ('split', 'bwd'): 3,
                             ('split_f16', 'fwd'): 3, ('split_f16', 'bwd'): 3}.get((prec, dom), 1)
@@ -287,43 +294,98 @@ class Leg:
         latency = bool(eng.info.get('fast')) and dom != 'dw'
         r = dict(bound='latency' if latency else 'mfma', kernel=kname, achieved=achieved, peak=peak, unit='TFLOP/s',
                  frac=achieved / peak, peak_is=peak_note, frac_of_f32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
-                 binding=('latency: H sequential steps per workgroup, %d of %d CUs occupied; weight stream L2->CU '
-                          'inside a step' % (min(n_wg, N_CUS), N_CUS)) if latency else
+                 binding=(('latency: H sequential steps per workgroup, %d of %d CUs occupied; ' % (min(n_wg, N_CUS), N_CUS)) +
+                          ('weights register-resident, one wave per SIMD: instruction issue inside a step' if reg else
+                           'weight stream L2->CU inside a step')) if latency else
                          'matrix pipe / weight fetch L2->CU: %d workgroups over %d CUs' % (n_wg, N_CUS),
                  flops_per_launch=kflops[dom], avg_launch_ms=timings[dom])
         return r, kname
 
 
-def pmc_traffic(config, prec, kname, world):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
-    Counters cannot be read from inside a run: the figure is the committed measurement of THIS command on this
-    configuration, and the line says so."""
-    if world != 1:
-        return None, None
-    for src in ('profiles/r03_pmc_traffic_%s_%s.json' % (config, prec), 'profiles/r03_pmc_traffic_%s.json' % prec):
+def build_id():
+    from prob_mbrl_amd import _lib
+    return _lib.load().pmbrl_build_id().decode()
+
+
+def pmc_path(config, prec):
+    return os.path.join(ROOT, 'profiles', 'pmc_%s_%s.json' % (config, prec))
+
+
+def collect_pmc(a, prec):
+    """bench.py --pmc: the hardware counters of THIS build on THIS configuration, taken by re-running this script
+    under `rocprofv3 --pmc <set>` once per counter set (counters are never collected together with a trace; FETCH_SIZE
+    and WRITE_SIZE do not fit one pass -- MI355X_MICROARCH.md).  Per kernel, averaged over the launches of a pass:
+    HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a 128-byte read request at 64 bytes; KiB units), MFMA busy
+    per cent, flops issued = MFMA_MOPS x 512.  Written to profiles/pmc_<config>_<precision>.json with the library's
+    build id; returns the dict."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    sets = [['FETCH_SIZE'], ['WRITE_SIZE'], ['MfmaUtil'], ['SQ_INSTS_VALU_MFMA_MOPS_F16', 'SQ_INSTS_VALU_MFMA_MOPS_BF16']]
+    steps = 3 if a.config.startswith('stress') else 6
+    inner = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', str(steps), '--warmup', '2',
+             '--no-cpu-baseline', '--no-f32-twin', '--timing-steps', '1']
+    if a.precision:
+        inner += ['--precision', a.precision]
+    if a.rows_per_wg:
+        inner += ['--rows-per-wg', str(a.rows_per_wg)]
+    env = dict(os.environ, TMPDIR='/tmp')
+    acc = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> values
+    for cs in sets:
+        tmp = tempfile.mkdtemp(prefix='pmbrl_pmc_', dir='/tmp')
         try:
-            pmc = json.load(open(os.path.join(ROOT, src)))
-            if pmc.get('config', 'cartpole_nomm') == config and kname in pmc['kernels']:
-                return pmc['kernels'][kname]['hbm_bytes_per_launch'], src
-        except Exception:
-            continue
-    return None, None
+            r = subprocess.run(['rocprofv3', '--pmc'] + cs + ['--output-format', 'csv', '-d', tmp, '--'] + inner,
+                               cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith('counter_collection.csv')]
+            if r.returncode != 0 or not files:
+                raise RuntimeError('rocprofv3 --pmc %s failed (rc %d): %s' % (' '.join(cs), r.returncode, r.stderr.decode()[-300:]))
+            for fpath in files:
+                for row in csv.DictReader(open(fpath)):
+                    name = row['Kernel_Name'].replace('void ', '').split('(')[0].split('<')[0]
+                    if name.startswith('pm_'):
+                        acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    mean = lambda v: sum(v) / len(v) if v else None
+    kernels = {}
+    for k, c in acc.items():
+        f, w = mean(c.get('FETCH_SIZE')), mean(c.get('WRITE_SIZE'))
+        mops = (mean(c.get('SQ_INSTS_VALU_MFMA_MOPS_F16')) or 0.0) + (mean(c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16')) or 0.0)
+        kernels[k] = dict(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w,
+                          hbm_bytes_per_launch=(2.0 * (f or 0.0) + (w or 0.0)) * 1024.0 if (f is not None or w is not None) else None,
+                          mfma_util_pct=mean(c.get('MfmaUtil')), flops_issued_per_launch=mops * 512.0,
+                          launches=len(c.get('FETCH_SIZE', [])))
+    out = dict(build_id=build_id(), config=a.config, precision=prec, command=' '.join(inner[1:]),
+               note='rocprofv3 --pmc, one pass per counter set: %s; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at '
+                    '64 bytes), WRITE_SIZE as reported (KiB); means over the launches of a pass' % '; '.join(' '.join(c) for c in sets),
+               kernels=kernels)
+    os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
+    json.dump(out, open(pmc_path(a.config, prec), 'w'), indent=1)
+    return out
 
 
-def pmc_mfma(config, prec, kname, world):
-    """MFMA busy cycles (per cent of all SIMD cycles) and flops issued per launch of the dominant kernel from the matrix
-    cores' own counters (rocprofv3 --pmc MfmaUtil / SQ_INSTS_VALU_MFMA_MOPS_*; tools/collect_mfma_util.sh): like the
-    HBM traffic, the committed measurement of this configuration, not a reading taken during the run."""
+def pmc_lookup(config, prec, kname, world, fresh=None):
+    """Counters of the dominant kernel: from this invocation's own --pmc passes (`fresh`), else from the committed
+    profiles/pmc_<config>_<precision>.json -- but ONLY if that file was measured on the build that is running
+    (pmbrl_build_id): a measurement of other code is not reported."""
     if world != 1:
         return None
-    src = 'profiles/r03_mfma_util_%s.json' % prec
-    try:
-        e = json.load(open(os.path.join(ROOT, src)))['configs'][config][kname]
-        return dict(mfma_util_pct=e.get('mfma_util_pct'), flops_issued_per_launch=e.get('flops_issued_per_launch'),
-                    measured_in_run=False, source=src)
-    except Exception:
-        return None
+    src, pmc = None, fresh
+    if pmc is None:
+        try:
+            pmc = json.load(open(pmc_path(config, prec)))
+            src = os.path.relpath(pmc_path(config, prec), ROOT)
+        except Exception:
+            return dict(available=False, reason='no profiles/pmc_%s_%s.json (run bench.py --pmc)' % (config, prec))
+        if pmc.get('build_id') != build_id():
+            return dict(available=False, source=src, reason='measured on build %s, this is build %s (re-run bench.py --pmc)' %
+                        (pmc.get('build_id'), build_id()))
+    k = pmc['kernels'].get(kname)
+    if k is None:
+        return dict(available=False, source=src, reason='kernel %s not in the measurement' % kname)
+    return dict(available=True, measured_in_run=fresh is not None, source=src, build_id=pmc['build_id'], **k)
 
 
 def main():
@@ -350,13 +412,42 @@ def main():
     torch.cuda.set_device(dev)
 
     allreduce, rccl_ranks = None, None
-    if a.transport == 'p2p':
-        os.environ['PMBRL_P2P'] = '1'
+    transport_note = None
     if world > 1:
-        from prob_mbrl_amd.distributed import get_comm, grad_allreduce
-        allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI, on the compute stream
+        from prob_mbrl_amd.distributed import get_comm, get_p2p, grad_allreduce
+        if a.transport == 'p2p':
+            # the one-shot peer-to-peer transport needs every rank to map every peer's buffer (hipIpcOpenMemHandle /
+            # peer access): if ANY rank cannot, all of them fall back to RCCL together and the line says so
+            os.environ['PMBRL_P2P'] = '1'
+            ok = 1
+            try:
+                get_p2p(None, dev)
+            except Exception as e:      # noqa: BLE001
+                ok, transport_note = 0, 'p2p unavailable on rank %d (%s)' % (rank, str(e)[:120])
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if a.dist_backend == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                os.environ['PMBRL_P2P'] = '0'
+                from prob_mbrl_amd import distributed as _D
+                _D._P2PS.clear()
+                a.transport = 'rccl'
+                transport_note = transport_note or 'p2p unavailable on another rank'
+        allreduce = grad_allreduce(None, dev)      # RCCL through the C ABI (or the p2p kernel), on the compute stream
         comm = get_comm(None, dev)
         rccl_ranks = comm.count() if comm is not None else None   # as the communicator reports it (ncclCommCount)
+        # start-up self-check, before anything is timed: a known vector through the transport the timed steps will use
+        # must come back as its sum over the ranks, bit for bit the same on every rank, and the communicator must have
+        # seen all N ranks
+        n_chk = 41602      # the flat policy gradient of the metric's shape (163 KiB)
+        vec = (torch.arange(n_chk, device=dev, dtype=torch.float32) % 97 + 1.0) * float(rank + 1)
+        allreduce(vec)
+        torch.cuda.synchronize()
+        want = (torch.arange(n_chk, device=dev, dtype=torch.float32) % 97 + 1.0) * float(world * (world + 1) // 2)
+        assert torch.equal(vec, want), 'gradient all-reduce self-check failed on rank %d (transport %s)' % (rank, a.transport)
+        if a.dist_backend == 'nccl' and not a.one_device and a.transport == 'rccl':
+            assert rccl_ranks == world, 'RCCL communicator reports %r ranks, launched %d' % (rccl_ranks, world)
+        from prob_mbrl_amd.distributed import p2p_check
+        p2p_check(None, dev)
 
     def make_leg(scaling, precision):
         """weak: every rank brings its own rows of a global batch of N x rows; strong: the rows of BASELINE.json's
@@ -385,6 +476,10 @@ def main():
             d['z_mm'], d['z_rr'] = dz['z_mm'], dz['z_rr']
         return Leg(a, d, dev, Bg, rank * B, precision, mm_span, world, allreduce)
 
+    fresh_pmc = None
+    if a.pmc and world == 1:
+        from prob_mbrl_amd import engine as _E
+        fresh_pmc = collect_pmc(a, a.precision or _E.get_precision())
     primary = a.scaling if world > 1 else 'weak'
     leg = make_leg(primary, a.precision)
     dt = leg.timed(a.steps, a.warmup, dev)
@@ -420,9 +515,18 @@ def main():
     if rank == 0:
         flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)
         roof, kname = leg.roofline(timings)
-        traffic, traffic_src = pmc_traffic(a.config, prec, kname, world)
-        roof.update(traffic=traffic, traffic_measured_in_run=False, traffic_source=traffic_src)
-        roof['mfma_counters'] = pmc_mfma(a.config, prec, kname, world)
+        pm = pmc_lookup(a.config, prec, kname, world, fresh_pmc)
+        if pm and pm.get('available'):
+            traffic = pm['hbm_bytes_per_launch']
+            roof.update(traffic=traffic, traffic_measured_in_run=pm['measured_in_run'], traffic_source=pm['source'] or 'this run (--pmc)',
+                        traffic_build_id=pm['build_id'],
+                        hbm_gbps=(traffic / (roof['avg_launch_ms'] * 1e-3) / 1e9) if traffic else None,
+                        hbm_frac_of_8tbps=(traffic / (roof['avg_launch_ms'] * 1e-3) / 8e12) if traffic else None,
+                        mfma_counters=dict(mfma_util_pct=pm['mfma_util_pct'], flops_issued_per_launch=pm['flops_issued_per_launch'],
+                                           measured_in_run=pm['measured_in_run']))
+        else:
+            roof.update(traffic=None, traffic_measured_in_run=False, traffic_source=None,
+                        traffic_unavailable=(pm or {}).get('reason', 'N > 1'), mfma_counters=None)
         dtype = {'f32': 'f32', 'split': 'f32 via split bf16 MFMA (3 pieces fwd / 2 adjoint), fp32 accumulate',
                  'split_f16': 'f32 via split fp16 (fwd, 2 pieces) / bf16 (adjoint, 2 pieces) MFMA, fp32 accumulate'}[prec]
         out = dict(
@@ -447,6 +551,9 @@ def main():
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
             roofline=roof)
         if world > 1:
+            out['allreduce_selfcheck'] = 'passed: %d floats summed over %d ranks, bit-identical to the closed form' % (41602, world)
+            if transport_note:
+                out['transport_fallback'] = transport_note + ' -> RCCL'
             out['rccl_ranks'] = rccl_ranks
             out['collective'] = ('one-shot peer-to-peer all-reduce (pmbrl_p2p.hip, IPC-mapped slots) on the compute stream'
                                  if a.transport == 'p2p' else

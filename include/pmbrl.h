@@ -193,6 +193,23 @@ enum {
 
 const char* pmbrl_last_error(void);
 int pmbrl_version(void);
+/* 16 hex digits: hash of the kernel sources the library was built from.  Hardware-counter measurements under
+ * profiles/ record it; bench.py reports such a measurement only if it was taken on the build it is running. */
+const char* pmbrl_build_id(void);
+
+/* hipGraph replay of library calls (the H-step loop as one captured graph).  Queue any sequence of library
+ * calls on `stream` (not the default stream) between begin and end -- a forward call, the loss, the adjoint call with its
+ * optimiser step: a whole iteration -- and replay it with ONE launch.  Pays where a call is many launches (one per
+ * step: moment-matching groups beyond a workgroup, states wider than 6, the pipelined adjoint: C5 with moment matching is
+ * 400+ launches per iteration); the sweeps of the cart-pole shapes are one launch each already.  Every buffer the calls
+ * were given must stay where it was; the status word and the optimiser's step counter are read and written on the
+ * device, so every replay is a new iteration.  Not capturable: a host-side collective (pmbrl_plan_set_collective). */
+typedef struct pmbrl_graph pmbrl_graph;
+int pmbrl_graph_capture_begin(void* stream);
+int pmbrl_graph_capture_end(void* stream, pmbrl_graph** graph_out);
+int pmbrl_graph_launch(pmbrl_graph* graph, void* stream);
+int pmbrl_graph_num_nodes(pmbrl_graph* graph, int64_t* n_out);
+void pmbrl_graph_destroy(pmbrl_graph* graph);
 
 /* Validates the shape, chooses the tiling and sizes the workspace. */
 int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan** out);

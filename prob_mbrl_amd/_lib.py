@@ -85,7 +85,8 @@ class Inputs(C.Structure):
 
 
 EXPORTS = [
-    'pmbrl_last_error', 'pmbrl_version', 'pmbrl_plan_create',
+    'pmbrl_last_error', 'pmbrl_version', 'pmbrl_build_id', 'pmbrl_plan_create',
+    'pmbrl_graph_capture_begin', 'pmbrl_graph_capture_end', 'pmbrl_graph_launch', 'pmbrl_graph_num_nodes', 'pmbrl_graph_destroy',
     'pmbrl_plan_destroy', 'pmbrl_plan_workspace_bytes', 'pmbrl_plan_info',
     'pmbrl_pack_mask', 'pmbrl_draw_masks', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd', 'pmbrl_rollout_bwd_adam',
     'pmbrl_plan_set_loss',
@@ -125,6 +126,18 @@ def load():
     lib.pmbrl_last_error.restype = C.c_char_p
     lib.pmbrl_last_error.argtypes = []
     lib.pmbrl_version.restype = C.c_int
+    lib.pmbrl_build_id.restype = C.c_char_p
+    lib.pmbrl_build_id.argtypes = []
+    lib.pmbrl_graph_capture_begin.restype = C.c_int
+    lib.pmbrl_graph_capture_begin.argtypes = [vp]
+    lib.pmbrl_graph_capture_end.restype = C.c_int
+    lib.pmbrl_graph_capture_end.argtypes = [vp, C.POINTER(vp)]
+    lib.pmbrl_graph_launch.restype = C.c_int
+    lib.pmbrl_graph_launch.argtypes = [vp, vp]
+    lib.pmbrl_graph_num_nodes.restype = C.c_int
+    lib.pmbrl_graph_num_nodes.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.pmbrl_graph_destroy.restype = None
+    lib.pmbrl_graph_destroy.argtypes = [vp]
     lib.pmbrl_plan_create.restype = C.c_int
     lib.pmbrl_plan_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(vp)]
     lib.pmbrl_plan_destroy.restype = None

@@ -28,7 +28,69 @@ int pm_fail(int code, const std::string& msg) {
 static int fail(int code, const std::string& msg) { return pm_fail(code, msg); }
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
-extern "C" int pmbrl_version(void) { return 4; }
+extern "C" int pmbrl_version(void) { return 5; }
+
+// ---------------------------------------------------------------------------
+// hipGraph entry points: record the library calls queued on a stream between begin and end, replay them with one
+// launch.  What it is for: the forms of the sweeps that are MANY launches per call (one per step: moment-matching
+// groups beyond a workgroup, wide states; pipelined adjoint) -- a plain iteration is a dozen launches the queue
+// already hides.  Everything the library queues is capturable (kernel launches, memsets, the event hand-offs of the
+// second stream); a host-side collective attached with pmbrl_plan_set_collective is not.  The status word, the step
+// counter of the guarded Adam and every pointer are device-side, so a replay is a whole new iteration as long as the
+// caller's buffers stay where they were.  (The fp16 weight-range flag of a replayed call carries the generation number
+// of the capture: exact unless an eager call on the same plan reported an overflow in between.)
+// ---------------------------------------------------------------------------
+struct pmbrl_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+extern "C" int pmbrl_graph_capture_begin(void* stream) {
+  if (!stream) return fail(-1, "graph capture needs a non-default stream");
+  HIPCHK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+  return 0;
+}
+extern "C" int pmbrl_graph_capture_end(void* stream, pmbrl_graph** out) {
+  if (!stream || !out) return fail(-1, "null argument");
+  hipGraph_t g = nullptr;
+  HIPCHK(hipStreamEndCapture((hipStream_t)stream, &g));
+  if (!g) return fail(-3, "stream capture ended without a graph (a call inside it invalidated the capture)");
+  pmbrl_graph* r = new pmbrl_graph();
+  r->graph = g;
+  r->exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    delete r;
+    return fail(-100 - (int)e, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  }
+  *out = r;
+  return 0;
+}
+extern "C" int pmbrl_graph_launch(pmbrl_graph* g, void* stream) {
+  if (!g || !g->exec) return fail(-1, "null argument");
+  HIPCHK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int pmbrl_graph_num_nodes(pmbrl_graph* g, int64_t* n_out) {
+  if (!g || !n_out) return fail(-1, "null argument");
+  size_t n = 0;
+  HIPCHK(hipGraphGetNodes(g->graph, nullptr, &n));
+  *n_out = (int64_t)n;
+  return 0;
+}
+extern "C" void pmbrl_graph_destroy(pmbrl_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+// hash of the kernel sources this library was built from (Makefile: pmbrl_build_id.inc)
+extern "C" const char* pmbrl_build_id(void) {
+  return
+#include "pmbrl_build_id.inc"
+      ;
+}
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -1490,6 +1552,19 @@ static MmxArgs mmx_args(const pmbrl_plan* p, char* ws, bool rewards) {
   return X;
 }
 
+// the sweep families' fragment-packed weights of this call's parameters (pm_pack_all); status_d: the forward
+// sweep's status word, reset by the launch (nullptr: leave it)
+static void launch_pack_all(pmbrl_plan* p, char* ws, const pmbrl_inputs* in, hipStream_t s, int32_t* status_d) {
+  PackArgs PK;
+  PK.n = 0;
+  pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
+  pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
+  PK.status = status_d;
+  PK.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
+  PK.gen = p->wgen;
+  hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
+}
+
 extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
                                  float* states_d, float* actions_d, float* rewards_d,
                                  int32_t* status_d) {
@@ -1504,24 +1579,23 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   A.states = states_d; A.actions = actions_d; A.rewards = rewards_d; A.status = status_d;
   A.prof = p->prof_fwd;
   char* ws = static_cast<char*>(workspace);
+  // the register-resident family serves this call (pmbrl_reg.h): only ITS weights are packed now -- the
+  // latency-optimised family's are packed by the adjoint call if it turns out to need them (optional outputs)
+  const bool reg_fwd = pm_reg_can_run(p, A, true);
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
-    PackArgs PK;
-    PK.wflag = nullptr;
-    PK.gen = 0;
-    PK.n = 0;
-    pack_jobs(p->pol, ws, in->pol_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
-    pack_jobs(p->dyn, ws, in->dyn_params_d, p->fast ? p->CA + p->CB : 0, PK, p->prec, !p->fast);
-    PK.status = status_d;
     if (p->wgen >= 0x7ffffff0) {   // (the flag only ever grows: start over)
       HIPCHK(hipMemsetAsync(p->wflag_d, 0, sizeof(int), s));
       p->wgen = 0;
     }
     ++p->wgen;
-    PK.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
-    PK.gen = p->wgen;
-    hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
-    if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s);
+    if (!reg_fwd) {
+      launch_pack_all(p, ws, in, s, status_d);
+      p->old_pack_stale = 0;
+    } else {
+      p->old_pack_stale = 1;
+    }
+    if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s, reg_fwd ? status_d : nullptr);
   }
   A.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
   A.wgen = p->wgen;
@@ -1644,6 +1718,13 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   A.nvalid = status_d;
   A.status = status_d ? status_d + 1 : nullptr;
   if (status_d) HIPCHK(hipMemsetAsync(status_d + 1, 0, sizeof(int32_t), s));
+  // this call goes to the latency-optimised family after a forward call that packed the register-resident family's
+  // weights only: pack the others now (same parameters: the caller hands the same inputs to both calls)
+  if (p->reg && p->old_pack_stale && !(pm_reg_can_run(p, A, false) && p->pipe_K <= 1)) {
+    if (!in->pol_params_d || !in->dyn_params_d) return fail(-1, "null parameter pointer");
+    launch_pack_all(p, ws, in, s, nullptr);
+    p->old_pack_stale = 0;
+  }
   float* grt = reinterpret_cast<float*>(ws + p->off_grt);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   if (!p->fast) { A.ext_reward = 1; }
@@ -1758,7 +1839,7 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       if (A.xch) HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }
-    if (pm_reg_can_run(p, A, false)) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
+    if (pm_reg_can_run(p, A, false) && p->pipe_K <= 1) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
     else launch_bwd_rt(p, A, s);
     A.gx_carry_out = nullptr;
   } else {

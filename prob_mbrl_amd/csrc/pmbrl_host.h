@@ -73,6 +73,7 @@ struct pmbrl_plan {
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
   int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
   size_t off_reg_pack;   // its packed weights in the workspace
+  int old_pack_stale;    // the last forward call packed the register-resident family's weights only
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -161,7 +162,7 @@ size_t pm_reg_pack_bytes();
 int pm_reg_set_attr(const pmbrl_plan* p);
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd);
 void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
-                        hipStream_t s);
+                        hipStream_t s, int* status_reset);
 void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
                    hipStream_t s, bool fwd);
 // per-family entry points (defined in pmbrl_fast_f32.hip / pmbrl_fast_split.hip)

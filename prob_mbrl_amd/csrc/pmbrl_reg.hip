@@ -83,7 +83,7 @@ bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd) {
 }
 
 void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
-                        hipStream_t s) {
+                        hipStream_t s, int* status_reset) {
   RegPackArgs P;
   memset(&P, 0, sizeof(P));
   P.par[0] = pol_params; P.par[1] = dyn_params;
@@ -96,7 +96,7 @@ void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, 
   P.D = p->cfg.D; P.U = p->cfg.U; P.hid = p->pol.dim[1];
   P.out = reinterpret_cast<float*>(ws + p->off_reg_pack);
   P.wflag = wflag; P.gen = gen;
-  P.status = nullptr;
+  P.status = status_reset;
   const int total = 4 * (PR_NET_FLOATS / PR_FRAG) * 64;
   hipLaunchKernelGGL(pm_reg_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P);
 }

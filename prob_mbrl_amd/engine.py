@@ -647,6 +647,48 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                'pmbrl_clip_adam')
 
 
+class Graph:
+    """hipGraph of library calls (pmbrl_graph_capture_* / pmbrl_graph_launch): `fn()` is recorded once on a side stream
+    and replayed with one launch.  fn may call Engine.forward (with out=...), weighted_sum (with out=...), backward,
+    clip_adam_guarded, BnnStep ... -- anything that only QUEUES work on the current stream and allocates nothing (pass the
+    output tensors in).  Where it pays: the sweeps that are one launch per step (moment-matching groups beyond a
+    workgroup, wide states), 200-400 launches per iteration."""
+
+    def __init__(self, fn, warmup=1):
+        self.lib = _lib.load()
+        self.handle = C.c_void_p()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):       # (first calls may create events / set attributes: not inside a capture)
+                fn()
+            side.synchronize()
+            _lib.check(self.lib.pmbrl_graph_capture_begin(C.c_void_p(side.cuda_stream)), 'pmbrl_graph_capture_begin')
+            try:
+                fn()
+            finally:
+                rc = self.lib.pmbrl_graph_capture_end(C.c_void_p(side.cuda_stream), C.byref(self.handle))
+            _lib.check(rc, 'pmbrl_graph_capture_end')
+        torch.cuda.current_stream().wait_stream(side)
+        self._keep = fn       # the closure keeps the captured tensors alive
+
+    def replay(self):
+        _lib.check(self.lib.pmbrl_graph_launch(self.handle, _stream()), 'pmbrl_graph_launch')
+
+    def num_nodes(self):
+        n = C.c_int64(0)
+        _lib.check(self.lib.pmbrl_graph_num_nodes(self.handle, C.byref(n)), 'pmbrl_graph_num_nodes')
+        return int(n.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pmbrl_graph_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
 def clip_adam_guarded(params, grads, exp_avg, exp_avg_sq, step_dev, lr, status, expect, betas=(0.9, 0.999),
                       eps=1e-8, max_norm=None, norm_out=None):
     """clip + Adam taken on the device only if `status` (the rollout's status word) says all

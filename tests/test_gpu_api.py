@@ -741,3 +741,58 @@ def test_iteration_is_graph_capturable():
     # capture itself does not execute: warm-up (1) + 4 replays = 5 steps... plus none from the capture
     assert n_graph == 5
     assert np.array_equal(p_eager, p_graph)
+
+
+@pytest.mark.parametrize('name,groups', [('full200_nomm', None), ('mmg_h40', 0)])
+def test_library_graph_entry_points_replay_an_iteration(name, groups, monkeypatch):
+    """pmbrl_graph_capture_begin / _end / _launch: a whole optimiser iteration -- forward call with its
+    queued loss, adjoint call with the device-guarded clip + Adam -- recorded through the C ABI's own entry points
+    and replayed: the same parameters, bit for bit, as the eager calls.  Once on the one-launch-per-sweep form and
+    once on a per-step-launch form (one moment-matching group over all rows: a launch per step), where replaying is
+    what removes the launch cost."""
+    from prob_mbrl_amd import engine as E
+    d = dict(common.load(name))
+    if groups is not None:
+        d['mm_groups'] = np.asarray(groups)
+        monkeypatch.setenv('PMBRL_MM_PERSTEP', '1')      # (the per-step-launch form, not the one-launch barrier form,
+        monkeypatch.setenv('PMBRL_MM_PARTS', '1')        #  and not the group split over several exchanging workgroups)
+    H, B = int(d['H']), d['x0'].shape[0]
+
+    def run(n, use_graph):
+        eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+        gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+        params = args['pol_flat'].clone()
+        args['pol_flat'] = params
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+        loss = eng.set_loss(gw)
+        out = (torch.empty((H + 1, B, eng.D), device=DEV), torch.empty((H, B, eng.U), device=DEV),
+               torch.empty((H, B, 1), device=DEV))
+        adam = dict(params=params, exp_avg=m, exp_avg_sq=v, step=step_dev, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                    max_norm=1.0)
+
+        def step():
+            eng.forward(**args, out=out)
+            eng.backward(gw, adam=adam)
+
+        nodes = 0
+        if not use_graph:
+            for _ in range(n):
+                step()
+        else:
+            g = E.Graph(step, warmup=1)          # one eager iteration (the warm-up), one recorded while capturing
+            nodes = g.num_nodes()
+            for _ in range(n - 1):
+                g.replay()
+        torch.cuda.synchronize()
+        assert eng.valid_steps() == H
+        return params.clone(), int(step_dev.item()), float(loss), nodes, eng.info
+
+    p_e, s_e, l_e, _, info = run(4, False)
+    p_g, s_g, l_g, nodes, _ = run(4, True)
+    assert s_e == 4 and s_g == 4
+    assert torch.equal(p_e, p_g) and l_e == l_g
+    if groups == 0:
+        assert info['mm_mode'] in (2, 3) and nodes >= H      # a launch per step at least: what the replay folds
+    else:
+        assert nodes >= 8

@@ -62,3 +62,28 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
         n = '_Z19pm_rollout_%s_fastILi2ELi4ELi3ELi2E7%sv11RolloutArgs' % (direction, shape(6))
         assert spills[n] <= 64, (n, spills[n])
     shutil.rmtree(str(tmp_path), ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
+def test_register_resident_kernels_fit_the_register_file(tmp_path):
+    """The register-resident sweep family (csrc/pmbrl_reg.h) keeps 62 weight fragments in AGPRs and the rest in VGPRs
+    at one wave per SIMD: a spill would put weights in scratch memory inside the step loop.  No vector spills, the
+    accumulation registers actually used, and one workgroup of four waves per CU."""
+    csrc = os.path.join(ROOT, 'prob_mbrl_amd', 'csrc')
+    out = str(tmp_path / 'reg.s')
+    subprocess.check_call([HIPCC, '-w', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                           '-S', '--cuda-device-only', os.path.join(csrc, 'pmbrl_reg.hip'), '-o', out], cwd=csrc)
+    txt = open(out).read()
+    seen = 0
+    for blk in txt.split('- .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+        if 'pm_reg_fwd_kernel' not in name and 'pm_reg_bwd_kernel' not in name:
+            continue
+        seen += 1
+        agpr = int(blk.split()[0])
+        vgpr = int(re.search(r'\.vgpr_count:\s+(\d+)', blk).group(1))
+        assert int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1)) == 0, name
+        assert agpr >= 4 * 62 and vgpr <= 512, (name, agpr, vgpr)
+        assert int(re.search(r'\.max_flat_workgroup_size:\s+(\d+)', blk).group(1)) == 256, name
+    assert seen == 4, seen          # forward and adjoint, each with and without the cycle-counter instrumentation
+    shutil.rmtree(str(tmp_path), ignore_errors=True)

@@ -8,33 +8,36 @@ R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# 1. the bench line (default flags: with the CPU baseline leg)
-timeout 600 python $R/bench.py > $O/bench_cartpole_nomm.json 2>$O/bench.err
+# 1. the bench line (default flags: with the CPU baseline leg), its hardware counters measured by the same command
+#    (bench.py --pmc: nested rocprofv3 --pmc passes, one per counter set; writes profiles/pmc_<config>_<precision>.json
+#    with the library's build id)
+timeout 1500 python $R/bench.py --pmc > $O/bench_cartpole_nomm.json 2>$O/bench.err
 # 2. kernel trace + stats of the same command (shorter run, no CPU leg)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- \
   python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-twin > $O/bench_under_rocprof.json 2>$O/kt.err
-# 3. HBM traffic counters, one pass each
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- \
-  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-twin --timing-steps 1 > /dev/null 2>$O/pf.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- \
-  python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-twin --timing-steps 1 > /dev/null 2>$O/pw.err
+# 3. the other configurations, each with its counters
+for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
+  timeout 900 python $R/bench.py --pmc --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-f32-twin > $O/bench_$c.json 2>$O/bench_$c.err
+done
+cp $R/profiles/pmc_*.json $O/
 # 4. in-kernel cycle stamps, the other configurations, the neighbouring paths
 timeout 120 python $R/tools/phase_prof.py > $O/phase_prof.txt 2>/dev/null
 for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do timeout 120 python $R/tools/phase_prof.py $c > $O/phase_prof_$c.txt 2>/dev/null; done
-for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
-  timeout 300 python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-f32-twin > $O/bench_$c.json 2>/dev/null
-done
 timeout 300 python $R/tools/bench_bnn.py > $O/bench_bnn.json 2>/dev/null
 timeout 300 python $R/tools/mcp_speed.py > $O/mcp_speed.txt 2>/dev/null
 timeout 300 python $R/tools/mcp_example_shape.py > $O/mcp_example_shape.txt 2>/dev/null
 timeout 300 python $R/tools/bench_single_group.py > $O/single_group.txt 2>/dev/null
 # flatten the rocprof outputs (they sit under <dir>/<host>/<pid>_*.csv)
-for d in kt pmc_fetch pmc_write; do
+for d in kt; do
   for f in $(find $O/$d -name '*.csv' 2>/dev/null); do cp $f $O/${d}_$(basename $f | sed 's/^[0-9]*_//'); done
 done
-python $R/tools/pmc_traffic.py $O/pmc_fetch_counter_collection.csv $O/pmc_write_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
-rm -rf $O/kt $O/pmc_fetch $O/pmc_write
+rm -rf $O/kt
 ls -la $O
 cat $O/bench_cartpole_nomm.json
 head -8 $O/kt_kernel_stats.csv | cut -c1-160
-cat $O/pmc_traffic.txt | head -12
+python - <<PY
+import json,glob
+for f in sorted(glob.glob('$O/pmc_*.json')):
+    d=json.load(open(f)); print(f.split('/')[-1], d['build_id'])
+    for k,v in d['kernels'].items(): print('  %-28s hbm %.3e B  mfma %s%%' % (k, v['hbm_bytes_per_launch'] or 0, v['mfma_util_pct']))
+PY
