@@ -51,6 +51,9 @@ def parse():
                     help='moment-matching configs: ONE group over the rows of all ranks (mm_groups=None, the '
                          "reference examples' default) -- per-step statistics exchange between the ranks; weak scaling only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--replay', type=int, default=None, choices=[0, 1, 2],
+                    help='pmbrl_plan_set_replay: 0 never replay repeated calls as hipGraphs, 1 the library default (the '
+                         'one-launch-per-step forms), 2 every form')
     ap.add_argument('--no-f32-twin', action='store_true', help='N = 1: skip the exact-fp32 leg')
     ap.add_argument('--no-fused-tail', action='store_true',
                     help='N = 1: separate loss / dW-reduce / norm / Adam launches (what N > 1 runs around its all-reduce)')
@@ -185,6 +188,8 @@ class Leg:
         if mm_span:
             import torch.distributed as dist
             self.eng.attach_collective(dist.group.WORLD)
+        if a.replay is not None:
+            self.eng.set_replay(a.replay)
         self.gw = torch.tensor(PB.loss_weights(d, Bg)[:, :self.B].copy(), device=dev)
         self.params = self.args['pol_flat'].clone()
         self.args['pol_flat'] = self.params
@@ -545,7 +550,7 @@ def main():
                         cu_occupancy='%d of %d CUs hold a workgroup' % (min(eng.info['n_wg'], N_CUS), N_CUS),
                         mm_mode=eng.info['mm_mode'], mm_grid=eng.info.get('mm_grid', 0),
                         **({'mm_groups': 'one group over the rows of all ranks'} if a.mm_global else {}),
-                        adjoint_sweep_launches=eng.info.get('dw_pipe', 1), **({'debug_one_device': True} if a.one_device else {})),
+                        adjoint_sweep_launches=eng.info.get('dw_pipe', 1), replay=dict(zip(('on', 'fwd_calls_replayed', 'adjoint_calls_replayed'), (eng.info.get('replay', 0),) + eng.replay_count())), **({'debug_one_device': True} if a.one_device else {})),
             algorithmic_gflop_per_step=flops_rollout * B / 1e9,
             algorithmic_tflops=flops_rollout * Bg * a.steps / dt / 1e12,
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},

@@ -188,7 +188,8 @@ enum {
   PMBRL_INFO_DW_PIPE = 14,   /* launches the adjoint sweep is cut into so that the dW GEMM runs behind it (1: no) */
   PMBRL_INFO_MM_PARTS = 15,  /* workgroups a moment-matching group is split over (in-kernel moment matching; 1: whole groups) */
   PMBRL_INFO_REG = 16,       /* 1: the plain whole-horizon sweeps of this plan run on the register-resident family (pmbrl_reg.h) */
-  PMBRL_INFO_COUNT = 17
+  PMBRL_INFO_REPLAY = 17,    /* 1: repeated calls of this plan are replayed as hipGraphs (pmbrl_plan_set_replay) */
+  PMBRL_INFO_COUNT = 18
 };
 
 const char* pmbrl_last_error(void);
@@ -435,6 +436,23 @@ enum {
   PMBRL_TIMER_COUNT = 8
 };
 int pmbrl_plan_set_timing(pmbrl_plan* plan, int on);
+
+/* Replay of repeated calls.  Some forms of the sweeps are ONE LAUNCH PER STEP (moment-matching groups
+ * beyond what a workgroup or a set of exchanging workgroups holds, wide states): 100-400 launches per iteration, whose
+ * launch cost is then most of the iteration.  With replay on, pmbrl_rollout_fwd / pmbrl_rollout_bwd(_adam) compare their
+ * arguments (stream, workspace, every pointer and scalar of the call, the queued loss) with the previous call's: the
+ * second identical call is recorded as a hipGraph (nothing but launches, memsets and event
+ * hand-offs is queued by these calls) and launched, every further one is ONE hipGraphLaunch.  Any difference drops the
+ * graph and runs the call as usual: an optimisation loop that keeps its buffers gets the replay, a caller that
+ * allocates new outputs every time never pays for a capture.  Results are those of the eager calls bit for bit (the
+ * same kernels in the same order).  The recording is made on a stream of the plan's own, so the caller's may be the
+ * legacy default stream.  Not used while per-kernel timing or the cycle-stamp profile is on, inside a capture of the
+ * caller's own, or with a host-side collective attached.
+ * Default: on for the one-launch-per-step forms, off elsewhere (a plain iteration is a dozen launches the queue
+ * already hides).  on = 0: never; 1: the default; 2: every form.  Environment PMBRL_REPLAY=0|1|2 sets the default. */
+int pmbrl_plan_set_replay(pmbrl_plan* plan, int on);
+/* calls that went out as one graph launch so far: n_out[0] forward calls, n_out[1] adjoint calls */
+int pmbrl_plan_replay_count(const pmbrl_plan* plan, int64_t* n_out /* [2] */);
 int pmbrl_plan_read_timing(pmbrl_plan* plan, float* ms /* [PMBRL_TIMER_COUNT] */);
 
 /* Debug: workgroup 0 writes shader-clock stamps [H][32] at its phase boundaries

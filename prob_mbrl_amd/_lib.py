@@ -22,7 +22,7 @@ FLAG_GMM_EXACT_NOISE_GRAD = 256
 MAX_COMP = 8
 REWARD_EXP, REWARD_NEG = 0, 1
 PREC_F32, PREC_SPLIT, PREC_SPLIT_F16 = 0, 1, 2
-INFO_COUNT = 17
+INFO_COUNT = 18
 TIMER_COUNT = 8
 TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce', 'reward']
 
@@ -91,7 +91,7 @@ EXPORTS = [
     'pmbrl_pack_mask', 'pmbrl_draw_masks', 'pmbrl_rollout_fwd', 'pmbrl_rollout_bwd', 'pmbrl_rollout_bwd_adam',
     'pmbrl_plan_set_loss',
     'pmbrl_weighted_sum', 'pmbrl_weighted_sum_steps', 'pmbrl_clip_adam', 'pmbrl_clip_adam_guarded', 'pmbrl_debug_linear',
-    'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof',
+    'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof', 'pmbrl_plan_set_replay', 'pmbrl_plan_replay_count',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
     'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
@@ -183,6 +183,10 @@ def load():
     lib.pmbrl_bnn_loss_grad_ex.argtypes = [vp] * 13 + [i32]
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.pmbrl_plan_set_replay.restype = C.c_int
+    lib.pmbrl_plan_set_replay.argtypes = [vp, C.c_int]
+    lib.pmbrl_plan_replay_count.restype = C.c_int
+    lib.pmbrl_plan_replay_count.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.pmbrl_plan_set_timing.restype = C.c_int
     lib.pmbrl_plan_set_timing.argtypes = [vp, C.c_int]
     lib.pmbrl_plan_read_timing.restype = C.c_int

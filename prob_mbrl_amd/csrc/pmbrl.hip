@@ -28,7 +28,7 @@ int pm_fail(int code, const std::string& msg) {
 static int fail(int code, const std::string& msg) { return pm_fail(code, msg); }
 
 extern "C" const char* pmbrl_last_error(void) { return g_err.c_str(); }
-extern "C" int pmbrl_version(void) { return 5; }
+extern "C" int pmbrl_version(void) { return 6; }
 
 // ---------------------------------------------------------------------------
 // hipGraph entry points: record the library calls queued on a stream between begin and end, replay them with one
@@ -635,6 +635,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   p->cfg = c;
   if (p->cfg.B_global <= 0) p->cfg.B_global = c.B;
   p->device = device;
+  p->replay = 1;
+  if (const char* e = getenv("PMBRL_REPLAY")) p->replay = std::max(0, std::min(2, atoi(e)));
   if (c.n_pol_angle < 0 || c.n_pol_angle > PMBRL_MAX_ANGLE || c.n_dyn_angle < 0 || c.n_dyn_angle > PMBRL_MAX_ANGLE) {
     delete p;
     return fail(-2, "n_pol_angle / n_dyn_angle out of range");
@@ -1181,6 +1183,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       p->off_mmx_rfac = take(p->span ? (size_t)c.H * p->G * pm_mm_fac_doubles(1) * sizeof(double) : 0);
     }
     p->off_reg_pack = take(p->reg ? pm_reg_pack_bytes() : 0);
+    for (int n = 0; n < 2; ++n)
+      for (int l = 0; l < 2; ++l) p->off_reg_ab[n][l] = take(p->reg ? (size_t)c.H * p->nwg * 1024 : 0);
     p->off_part = take((size_t)std::max(p->dw_nsplit, p->pipe_K > 1 ? p->pipe_rows : 0) *
                        ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
@@ -1242,6 +1246,101 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// replay of repeated calls (include/pmbrl.h: pmbrl_plan_set_replay)
+// ---------------------------------------------------------------------------
+static bool per_step_launches(const pmbrl_plan* p) {
+  return (p->mm_mode == 2 || (p->mm_mode == 3 && !p->mm_grid)) && p->cfg.H >= 4;
+}
+static bool replay_wanted(const pmbrl_plan* p) {
+  if (p->replay == 0 || p->span || p->coll) return false;
+  return p->replay >= 2 || per_step_launches(p);
+}
+static void replay_drop(pmbrl_plan* p, int slot) {
+  if (p->rp[slot].exec) (void)hipGraphExecDestroy(p->rp[slot].exec);
+  p->rp[slot].exec = nullptr;
+  p->rp[slot].seen = 0;
+}
+struct ReplayKey {
+  unsigned long long h = 1469598103934665603ull;
+  void add(const void* q, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(q);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  }
+  template <class T> void val(const T& v) { add(&v, sizeof(T)); }
+};
+// body(): queues the call on s.  Returns its code; *replayed = the call went out as a graph launch.
+template <class Body>
+static int replay_call(pmbrl_plan* p, int slot, unsigned long long key, hipStream_t s, Body body) {
+  pmbrl_plan::ReplaySlot& R = p->rp[slot];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  // (the legacy default stream cannot be asked, and cannot be recording)
+  const bool usable = replay_wanted(p) && !p->timing && !p->prof_fwd && !p->prof_bwd && !R.dead &&
+                      (!s || (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone));
+  if (!usable) {
+    if (R.exec || R.seen) replay_drop(p, slot);
+    return body(s);
+  }
+  if (R.exec && R.key == key) {
+    HIPCHK(hipGraphLaunch(R.exec, s));
+    ++R.launches;
+    if (slot == 0) { p->old_pack_stale = R.aux & 1; p->abits_packed = (R.aux >> 1) & 1; }   // (the host-side notes the recorded call left: which families' weights it packed, the form of its activity bits)
+    return 0;
+  }
+  if (R.key != key || R.seen == 0) {      // first sight of these arguments: as usual, remember them
+    replay_drop(p, slot);
+    R.key = key;
+    R.seen = 1;
+    return body(s);
+  }
+  // second identical call: record it on a stream of the plan's own (the caller's may be the legacy default stream, which
+  // cannot record; nothing runs while recording), then launch what was recorded on the caller's
+  hipGraph_t g = nullptr;
+  if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) p->cap_stream = nullptr;
+  if (!p->cap_stream || hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    R.dead = 1;
+    return body(s);
+  }
+  const int rc = body(p->cap_stream);
+  const hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
+  if (rc != 0 || e != hipSuccess || !g) {
+    // (a call inside invalidated the capture, or the body failed: nothing was queued -- run it eagerly, never try again)
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    R.dead = 1;
+    replay_drop(p, slot);
+    return rc != 0 ? rc : body(s);
+  }
+  hipGraphExec_t ex = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess || !ex) {
+    (void)hipGetLastError();
+    R.dead = 1;
+    replay_drop(p, slot);
+    return body(s);
+  }
+  R.exec = ex;
+  R.aux = (p->old_pack_stale & 1) | ((p->abits_packed & 1) << 1);
+  HIPCHK(hipGraphLaunch(R.exec, s));
+  ++R.launches;
+  return 0;
+}
+
+extern "C" int pmbrl_plan_set_replay(pmbrl_plan* p, int on) {
+  if (!p || on < 0 || on > 2) return fail(-1, "bad argument");
+  p->replay = on;
+  for (int k = 0; k < 2; ++k) { replay_drop(p, k); p->rp[k].dead = 0; }
+  return 0;
+}
+
+extern "C" int pmbrl_plan_replay_count(const pmbrl_plan* p, int64_t* n_out) {
+  if (!p || !n_out) return fail(-1, "null argument");
+  for (int k = 0; k < 2; ++k) n_out[k] = p->rp[k].launches;
+  return 0;
+}
+
 extern "C" int pmbrl_plan_set_prof(pmbrl_plan* p, long long* fwd_d, long long* bwd_d) {
   if (!p) return fail(-1, "null argument");
   p->prof_fwd = fwd_d;
@@ -1277,6 +1376,8 @@ extern "C" void pmbrl_plan_destroy(pmbrl_plan* p) {
   if (p->ev[0][0])
     for (int i = 0; i < PMBRL_TIMER_COUNT; ++i)
       for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->ev[i][j]);
+  for (int k = 0; k < 2; ++k) replay_drop(p, k);
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   if (p->rew_d) (void)hipFree(p->rew_d);
   if (p->wflag_d) (void)hipFree(p->wflag_d);
   if (p->ang_d) (void)hipFree(p->ang_d);
@@ -1311,6 +1412,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[PMBRL_INFO_DW_PIPE] = p->pipe_K;
   info[PMBRL_INFO_MM_PARTS] = p->mm_parts;
   info[PMBRL_INFO_REG] = p->reg;
+  info[PMBRL_INFO_REPLAY] = replay_wanted(p) ? 1 : 0;
   return 0;
 }
 
@@ -1565,14 +1667,27 @@ static void launch_pack_all(pmbrl_plan* p, char* ws, const pmbrl_inputs* in, hip
   hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
 }
 
+static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
+                            float* states_d, float* actions_d, float* rewards_d, int32_t* status_d);
+
 extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
                                  float* states_d, float* actions_d, float* rewards_d,
                                  int32_t* status_d) {
   if (!p || !workspace || !in || !states_d || !actions_d || !rewards_d || !status_d)
     return fail(-1, "null argument");
   if (!in->pol_params_d || !in->dyn_params_d) return fail(-1, "null parameter pointer");
-  hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(p->device));
+  ReplayKey K;
+  K.val(stream); K.val(workspace); K.add(in, sizeof(*in));
+  K.val(states_d); K.val(actions_d); K.val(rewards_d); K.val(status_d); K.val(p->loss_w); K.val(p->loss_out);
+  return replay_call(p, 0, K.h, (hipStream_t)stream, [&](hipStream_t on) {
+    return rollout_fwd_impl(p, on, workspace, in, states_d, actions_d, rewards_d, status_d);
+  });
+}
+
+static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
+                            float* states_d, float* actions_d, float* rewards_d, int32_t* status_d) {
+  hipStream_t s = (hipStream_t)stream;
   RolloutArgs A;
   int rc = fill_args(p, workspace, in, A);
   if (rc) return rc;
@@ -1584,9 +1699,13 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   const bool reg_fwd = pm_reg_can_run(p, A, true);
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
-    if (p->wgen >= 0x7ffffff0) {   // (the flag only ever grows: start over)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    // (the flag only ever grows: start over before the counter wraps -- and in every recorded call, whose replays all
+    //  carry the generation number of the recording)
+    if (p->wgen >= 0x7ffffff0 || cap == hipStreamCaptureStatusActive) {
       HIPCHK(hipMemsetAsync(p->wflag_d, 0, sizeof(int), s));
-      p->wgen = 0;
+      if (p->wgen >= 0x7ffffff0) p->wgen = 0;
     }
     ++p->wgen;
     if (!reg_fwd) {
@@ -1595,6 +1714,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
     } else {
       p->old_pack_stale = 1;
     }
+    p->abits_packed = reg_fwd ? 1 : 0;
     if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s, reg_fwd ? status_d : nullptr);
   }
   A.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
@@ -1720,11 +1840,14 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   if (status_d) HIPCHK(hipMemsetAsync(status_d + 1, 0, sizeof(int32_t), s));
   // this call goes to the latency-optimised family after a forward call that packed the register-resident family's
   // weights only: pack the others now (same parameters: the caller hands the same inputs to both calls)
-  if (p->reg && p->old_pack_stale && !(pm_reg_can_run(p, A, false) && p->pipe_K <= 1)) {
+  const bool reg_bwd = pm_reg_can_run(p, A, false);
+  if (p->reg && p->old_pack_stale && !reg_bwd) {
     if (!in->pol_params_d || !in->dyn_params_d) return fail(-1, "null parameter pointer");
     launch_pack_all(p, ws, in, s, nullptr);
-    p->old_pack_stale = 0;
   }
+  // ... and its activity bits are in that family's form.  (Neither note is cleared here: a recorded adjoint call --
+  // pmbrl_plan_set_replay -- must contain both conversions whenever the forward call before it was of that kind.)
+  if (p->reg && p->abits_packed && !reg_bwd) pm_reg_unpack_abits(p, ws, s);
   float* grt = reinterpret_cast<float*>(ws + p->off_grt);
   const bool mm_r = (p->cfg.flags & PMBRL_FLAG_MM_REWARDS) != 0;
   if (!p->fast) { A.ext_reward = 1; }
@@ -1821,7 +1944,8 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       A.t0 = p->pipe_lo[k];
       A.t1 = k ? p->pipe_lo[k - 1] : p->cfg.H;
       A.gx_from_carry = k > 0;
-      launch_bwd_rt(p, A, s);
+      if (reg_bwd) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
+      else launch_bwd_rt(p, A, s);
       if (k + 1 < p->pipe_K) {
         HIPCHK(hipEventRecord(p->pipe_ev[k], s));
         HIPCHK(hipStreamWaitEvent(p->pipe_stream, p->pipe_ev[k], 0));
@@ -1839,7 +1963,7 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       if (A.xch) HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }
-    if (pm_reg_can_run(p, A, false) && p->pipe_K <= 1) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
+    if (reg_bwd) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);
     else launch_bwd_rt(p, A, s);
     A.gx_carry_out = nullptr;
   } else {
@@ -1909,14 +2033,35 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   return 0;
 }
 
+static int rollout_bwd_replay(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
+                              const float* states_d, const float* actions_d,
+                              const float* rewards_d, const float* grad_rewards_d,
+                              const float* grad_states_d, const float* grad_actions_d,
+                              float* grad_pol_flat_d, float* grad_x0_d,
+                              float* action_grad_norms_d, int32_t* status_d, const pmbrl_adam* opt) {
+  if (!p || !in) return fail(-1, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  ReplayKey K;
+  K.val(stream); K.val(workspace); K.add(in, sizeof(*in));
+  K.val(states_d); K.val(actions_d); K.val(rewards_d); K.val(grad_rewards_d); K.val(grad_states_d); K.val(grad_actions_d);
+  K.val(grad_pol_flat_d); K.val(grad_x0_d); K.val(action_grad_norms_d); K.val(status_d);
+  const int has_opt = opt ? 1 : 0;
+  K.val(has_opt);
+  if (opt) K.add(opt, sizeof(*opt));
+  return replay_call(p, 1, K.h, (hipStream_t)stream, [&](hipStream_t on) {
+    return rollout_bwd(p, on, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
+                       grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, opt);
+  });
+}
+
 extern "C" int pmbrl_rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
                                  const float* states_d, const float* actions_d,
                                  const float* rewards_d, const float* grad_rewards_d,
                                  const float* grad_states_d, const float* grad_actions_d,
                                  float* grad_pol_flat_d, float* grad_x0_d,
                                  float* action_grad_norms_d, int32_t* status_d) {
-  return rollout_bwd(p, stream, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
-                     grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, nullptr);
+  return rollout_bwd_replay(p, stream, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
+                            grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, nullptr);
 }
 
 extern "C" int pmbrl_rollout_bwd_adam(pmbrl_plan* p, void* stream, void* workspace, const pmbrl_inputs* in,
@@ -1927,8 +2072,8 @@ extern "C" int pmbrl_rollout_bwd_adam(pmbrl_plan* p, void* stream, void* workspa
                                       float* action_grad_norms_d, int32_t* status_d, const pmbrl_adam* opt) {
   if (!opt || !status_d || !opt->params_d || !opt->exp_avg_d || !opt->exp_avg_sq_d || !opt->step_d)
     return fail(-1, "null argument");
-  return rollout_bwd(p, stream, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
-                     grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, opt);
+  return rollout_bwd_replay(p, stream, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
+                            grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, opt);
 }
 
 // ---------------------------------------------------------------------------

@@ -73,7 +73,14 @@ struct pmbrl_plan {
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
   int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
   size_t off_reg_pack;   // its packed weights in the workspace
+  size_t off_reg_ab[2][2];   // its activity words [net][hidden layer]: [step][workgroup][wave][lane] x 32 bits (pmbrl_reg.h)
+  int abits_packed;      // the last forward call left the activity bits in that form only (pm_reg_unpack_abits: -> NetPlan::abits)
   int old_pack_stale;    // the last forward call packed the register-resident family's weights only
+  // Replay (pmbrl_plan_set_replay): a call whose arguments equal the previous call's is recorded as a hipGraph the second
+  // time it is seen and launched as one graph from then on.  Slot 0: pmbrl_rollout_fwd, slot 1: pmbrl_rollout_bwd(_adam).
+  int replay;            // 0 off, 1 the one-launch-per-step forms, 2 every form
+  hipStream_t cap_stream;   // what the calls are recorded on
+  struct ReplaySlot { unsigned long long key; int seen, dead, aux; hipGraphExec_t exec; long long launches; } rp[2];
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -163,6 +170,7 @@ int pm_reg_set_attr(const pmbrl_plan* p);
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd);
 void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
                         hipStream_t s, int* status_reset);
+void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s);
 void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
                    hipStream_t s, bool fwd);
 // per-family entry points (defined in pmbrl_fast_f32.hip / pmbrl_fast_split.hip)

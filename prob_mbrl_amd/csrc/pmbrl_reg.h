@@ -41,6 +41,7 @@
 #define PR_FRAG 256             // floats of one fragment (64 lanes x 16 bytes)
 #define PM_GLOBAL_ __attribute__((address_space(1)))
 typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // floats of the packed sections of ONE network and direction (pm_reg_pack_kernel writes them, the sweeps read them)
 #define PR_RES_FLOATS (PR_NW * PR_SLOTS * PR_KB * 2 * PR_FRAG)    // [wave][slot][kb][piece][lane][4]
@@ -104,6 +105,12 @@ struct RegArgs {
   const float* grad_rewards;
   float* grad_x0;
   const int* nvalid;
+  // adjoint sweep over the steps [t0, t1) only (the dW GEMM of a finished range runs behind the next one, pmbrl.hip):
+  // dL/dx_{t1} comes from gx_in ([B][D]; nullptr: zero, the sweep starts at the horizon), dL/dx_{t0} goes to gx_out
+  // (nullptr: not wanted) and, at t0 = 0, to grad_x0
+  int t0, t1;
+  const float* gx_in;
+  float* gx_out;
   long long* prof;
 };
 
@@ -319,6 +326,38 @@ __device__ __forceinline__ pr_rsrc pr_make_rsrc(void* base) {
 // hipcc wraps the access in a waterfall loop (readfirstlane / compare / saveexec per distinct value) whenever it cannot
 // PROVE that -- loop-carried offsets of the horizon loop, for one (cdna_hip_programming.md T20)
 __device__ __forceinline__ int pr_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Loads the compiler does not track (inline asm): the adjoint sweep fetches a step's per-row inputs a step (or half a
+// step) before they are used, and hipcc's own s_waitcnt placement -- one counter for loads AND stores on gfx9, merged
+// conservatively over the loop's back edge -- made the first use of a prefetched value wait for everything issued
+// since, the loads requested a few instructions earlier included: a full memory round trip at the top of every step
+// (3.8 k of a step's 10 k cycles).  With these the wait is written by hand: pr_landed<N>(values...) = s_waitcnt vmcnt(N)
+// with N a LOWER bound of the memory operations issued after the loads in question (returns are in order), tied to the
+// destination registers so that no use moves above it.  tools/check_inflight.py checks that nothing touches a
+// destination in between (tests/test_isa_lint.py).
+#ifdef PR_EXP_NOSTASH      // timing experiment only (tools/ubench): what a step costs without its stash stores
+#define PR_EXP_STASH(x) ;
+#else
+#define PR_EXP_STASH(x) x
+#endif
+typedef int pr_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pr_i32x4 pr_rsrc_words(const void* base) {
+  const unsigned long long a = (unsigned long long)base;
+  pr_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = -1;
+  r[3] = 0x00020000;
+  return r;
+}
+// (s_nop 4 in front: a scalar offset that a v_readfirstlane has just written needs 5 wait states before a vector-memory
+//  instruction may read it, and the compiler's hazard recogniser does not look inside an asm statement)
+__device__ __forceinline__ void pr_aload4_b8(unsigned (&d)[4], const pr_i32x4& srd, unsigned voff, int s0, int s1, int s2, int s3) {
+  asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %4, %5, %6 offen\n\tbuffer_load_ubyte %1, %4, %5, %7 offen\n\t"
+               "buffer_load_ubyte %2, %4, %5, %8 offen\n\tbuffer_load_ubyte %3, %4, %5, %9 offen"
+               : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+               : "v"(voff), "s"(srd), "s"(s0), "s"(s1), "s"(s2), "s"(s3)
+               : "memory");
+}
 __device__ __forceinline__ void pr_mfma_open() { asm volatile("s_nop 3"); }
 __device__ __forceinline__ void pr_mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7"); }
 
@@ -568,12 +607,12 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   const float* const mfx_w = smem + PR_LDS_MFX + lane * 4;
   const unsigned lane_st = ((4u * g) * 16u + row) * 4u;                // byte inside a stash block's tile
   const pr_rsrc srd = pr_make_rsrc(A.ws);
-  // this lane's byte inside a step's activity bits.  Rows past the batch (the last workgroup's) write their all-zero
-  // nibbles into the 256 bytes of slack the plan leaves behind every activity-bit array (lane + 4 x tile < 128) and never advance: no store
-  // of the horizon loop sits under an exec mask
-  const unsigned ab_step = (unsigned)B * PR_NT * 4u;                   // bytes of a step's activity bits of one layer
-  unsigned vo_ab = rvalid ? ((unsigned)(row0 + row) * PR_NT) * 4u + g : (unsigned)A.H * ab_step + (unsigned)lane;
-  const unsigned vstep_ab = rvalid ? ab_step : 0u;
+  // activity bits: one 32-bit word per lane, layer and step -- nibble q = the 4 features of this wave's tile in slot q
+  // (q = 3: the LDS-resident tile, written by the wave that runs it), [step][workgroup][wave][lane] (PR_ABP_*): one
+  // coalesced 256-byte store per wave and layer instead of a byte store per tile
+  const unsigned vo_abp = (unsigned)lane * 4u;
+  int so_abp = (wg * PR_NW + wid) * 256;
+  const int abp_step = A.nwg * (PR_NW * 256);
 
   // one first layer: input B fragment from registers, one MFMA per tile, epilogue -> LDS (+ stashes)
   auto first_layer = [&](auto netc, const float (&in)[2], int so_ab, int so_st) {
@@ -610,6 +649,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       pr_mfma0<F16, false, true>(acc[q], wf[q], bfv);       // (the LDS-resident tile: computed by every wave, used by one)
     });
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    unsigned abw = 0u;
     auto epi = [&](auto qc, int ot) {
       constexpr int q = decltype(qc)::value;
       f32x4 h;
@@ -619,11 +659,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       float* dst = act_w + (size_t)((ot >> 1) * 2) * PR_FRAG + 2 * (ot & 1);
       *reinterpret_cast<pm_u32x2*>(dst) = hi;
       *reinterpret_cast<pm_u32x2*>(dst + PR_FRAG) = lo;
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, pr_uni(so_ab + ot * 4), 0);
+      abw |= ab << (4 * q);
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+          PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);)
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -631,6 +671,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       epi(qc, 4 * q + wid);
     });
     if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, PR_XT);
+    PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(abw, srd, vo_abp, pr_uni(so_ab), 0);)
   };
 
   // hidden->hidden layer + head partial of network NET; leaves the summed head tile (+ bias) in `o`
@@ -658,16 +699,17 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     // epilogues: activations of the wave's tiles as piece pairs (they ARE the head's B operand), stashes
     pm_u32x2 hi[PR_SLOTS + 1], lo[PR_SLOTS + 1];
     hi[PR_SLOTS] = lo[PR_SLOTS] = pm_u32x2{0u, 0u};
+    unsigned abw = 0u;
     auto epi = [&](auto qc, f32x4 v, int ot) {
       constexpr int q = decltype(qc)::value;
       f32x4 h;
       unsigned ab;
       pr_tile_epilogue<F16>(v, mfv[q], h, ab, amax, hi[q], lo[q]);
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)ab, srd, vo_ab, pr_uni(so_ab + ot * 4), 0);
+      abw |= ab << (4 * q);
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+          PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);)
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -675,6 +717,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       epi(qc, pr_tile_value<F16>(acc[q]), 4 * q + wid);
     });
     if (xw) epi(std::integral_constant<int, PR_SLOTS>{}, pr_tile_value<F16>(accx), PR_XT);
+    PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(abw, srd, vo_abp, pr_uni(so_ab), 0);)
     // head, K-split: block 0 = slots 0, 1; block 1 = slot 2 and the LDS-resident tile (zeros elsewhere)
     f32x4 c0, c1, bh[2], bl[2];
 #pragma unroll
@@ -719,11 +762,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       __builtin_amdgcn_raw_buffer_store_b32(0u, srd, 768 + lane * 4, pr_uni(so_st0), 0);
     }
     // ---- policy
-    first_layer(std::integral_constant<int, 0>{}, x, (int)A.pol.abits[0], so_st1);
+    first_layer(std::integral_constant<int, 0>{}, x, (int)A.pol.abits[0] + so_abp, so_st1);
     pr_barrier();
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 1] = (long long)__builtin_readcyclecounter();
     f32x4 o;
-    second_layer_and_head(std::integral_constant<int, 0>{}, (int)A.pol.abits[1], so_st2, o);
+    second_layer_and_head(std::integral_constant<int, 0>{}, (int)A.pol.abits[1] + so_abp, so_st2, o);
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 2] = (long long)__builtin_readcyclecounter();
     // ---- squash; dynamics input (normalised) in the same lane groups
     float xin[2];
@@ -745,10 +788,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       xin[s] = (v - c_mx[s]) * c_isx[s];
     }
     // ---- dynamics
-    first_layer(std::integral_constant<int, 1>{}, xin, (int)A.dyn.abits[0], 0);
+    first_layer(std::integral_constant<int, 1>{}, xin, (int)A.dyn.abits[0] + so_abp, 0);
     pr_barrier();
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 3] = (long long)__builtin_readcyclecounter();
-    second_layer_and_head(std::integral_constant<int, 1>{}, (int)A.dyn.abits[1], 0, o);
+    second_layer_and_head(std::integral_constant<int, 1>{}, (int)A.dyn.abits[1] + so_abp, 0, o);
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 4] = (long long)__builtin_readcyclecounter();
     // ---- sample the next state
 #pragma unroll
@@ -768,12 +811,32 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     // fp16 pieces: a value beyond the format's range was rounded to infinity somewhere in this step (or earlier)
     if (amax > 0x477fe000u) atomicMin(A.status, t);      // 65504
     // next step's bases
-    vo_ab += vstep_ab;
+    so_abp += abp_step;
     so_st0 += st_step0; so_st1 += st_step; so_st2 += st_step;
     so_td += (int)x_step; so_tp += (int)a_step;
     b_states += x_step; b_actions += a_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
   }
+}
+
+// activity words -> the per-tile nibble bytes [step][row][tile][lane group] of pmbrl_fast.h
+struct RegUnpackArgs {
+  int B, H, nwg;
+  const unsigned* src[2][2];
+  unsigned char* dst[2][2];
+};
+__global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegUnpackArgs U) {
+  const int wg = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int rowg = wg * 16 + (lane & 15), g = lane >> 4;
+  if (rowg >= U.B) return;
+  for (int n = 0; n < 2; ++n)
+    for (int l = 0; l < 2; ++l) {
+      const unsigned w = U.src[n][l][((size_t)t * U.nwg + wg) * PR_NTHR + tid];
+      unsigned char* d = U.dst[n][l] + ((size_t)t * U.B + rowg) * (PR_NT * 4) + g;
+#pragma unroll
+      for (int q = 0; q < PR_SLOTS; ++q) d[(4 * q + wid) * 4] = (unsigned char)((w >> (4 * q)) & 15u);
+      if (wid == pr_xwave(n)) d[PR_XT * 4] = (unsigned char)((w >> (4 * PR_SLOTS)) & 15u);
+    }
 }
 
 // ===========================================================================
@@ -794,7 +857,9 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
 #define PRB_LDS_XT(net) (PRB_LDS_L0(net) + PR_L0P_FLOATS)
 #define PRB_LDS_HEAD(net) (PRB_LDS_XT(net) + PR_XT_FLOATS)
 #define PRB_LDS_LUT (PRB_LDS_L0(2))              // [net][layer][16 nibbles][4]
-#define PRB_LDS_FLOATS (PRB_LDS_LUT + 2 * 2 * 16 * 4)
+#define PRB_IN_COLS 32
+#define PRB_LDS_IN (PRB_LDS_LUT + 2 * 2 * 16 * 4)    // [16 rows][PRB_IN_COLS]: the step's per-row inputs
+#define PRB_LDS_FLOATS (PRB_LDS_IN + 16 * PRB_IN_COLS)
 
 template <bool PROF>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
@@ -809,12 +874,15 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
   const int nvalid = min(16, A.B - row0);
   const bool rvalid = row < nvalid;
   const int D = A.D, U = A.U, B = A.B;
-  int T1 = A.H;
+  const int T0 = A.t0;
+  int T1 = A.t1;
   if (A.nvalid) T1 = min(T1, __builtin_amdgcn_readfirstlane(*A.nvalid));
   const float* packed = A.packed + (size_t)2 * PR_NET_FLOATS;     // direction 1
-  if (T1 <= 0) {
-    if (A.grad_x0)
-      for (int i = tid; i < nvalid * D; i += PR_NTHR) A.grad_x0[(size_t)row0 * D + i] = 0.f;
+  if (T1 <= T0) {
+    for (int i = tid; i < nvalid * D; i += PR_NTHR) {
+      if (A.grad_x0 && T0 == 0) A.grad_x0[(size_t)row0 * D + i] = 0.f;
+      if (A.gx_out) A.gx_out[(size_t)row0 * D + i] = A.gx_in ? A.gx_in[(size_t)row0 * D + i] : 0.f;
+    }
     return;
   }
 
@@ -860,78 +928,102 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     ok_a[s] = isa && rvalid;
     so_x[s] = ((unsigned)(row0 + row) * D + id) * 4u;
     so_a[s] = ((unsigned)(row0 + row) * U + ja) * 4u;
+    if (A.gx_in && ok_x[s]) gx[s] = *(const gf32*)((const PM_GLOBAL_ char*)A.gx_in + so_x[s]);
   }
   const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
   float* const act_w = smem + PRB_LDS_ACT + lane * 4;
   const float* const lut = smem + PRB_LDS_LUT;
   const unsigned lane_st = ((4u * g) * 16u + row) * 4u;
   const pr_rsrc srd = pr_make_rsrc(A.ws);
-  const pr_rsrc srd_gr = pr_make_rsrc(const_cast<float*>(A.grad_rewards));
-  const pr_rsrc srd_act = pr_make_rsrc(A.actions);
-  const unsigned ab_step = (unsigned)B * PR_NT * 4u;
-  // this lane's activity byte of a tile, at the LAST step; rows past the batch read the slack behind the array
-  // (whatever is there: their gradients are zero anyway -- multiplied into zeros)
-  const unsigned vstep_ab = rvalid ? ab_step : 0u;
-  unsigned vo_ab = rvalid ? ((unsigned)(row0 + row) * PR_NT) * 4u + g + (unsigned)(T1 - 1) * ab_step
-                          : (unsigned)A.H * ab_step + (unsigned)lane;
   const unsigned x_step = (unsigned)B * D * 4u, a_step = (unsigned)B * U * 4u;
-  int so_td = (int)A.Td + (T1 - 1) * (int)x_step, so_jx = (int)A.Jx + (T1 - 1) * (int)x_step;
-  int so_tp = (int)A.Tp + (T1 - 1) * (int)a_step, so_ja = (int)A.Ja + (T1 - 1) * (int)a_step;
-  int so_ac = (T1 - 1) * (int)a_step, so_gr = (T1 - 1) * B * 4;
   const int st_step = A.nwg * (PR_NT * 1024), st_step2 = A.nwg * 1024;
   int so_g0 = (int)A.gT[0] + ((T1 - 1) * A.nwg + wg) * (PR_NT * 1024);
   int so_g1 = (int)A.gT[1] + ((T1 - 1) * A.nwg + wg) * (PR_NT * 1024);
   int so_g2 = (int)A.gT[2] + ((T1 - 1) * A.nwg + wg) * 1024;
 
-  // per-row inputs of a step.  What the step needs AT ONCE -- dL/dr~, the reward Jacobian and Td of the lane's two state
-  // dimensions, the activity nibbles of the dynamics model's second hidden layer -- is fetched a step ahead; the rest
-  // (Ja, Tp, a of the action slots, the other three layers' nibbles) is requested when the step starts and used
-  // thousands of cycles later.  (Everything a step ahead was 38 more live registers than the file holds.)
-  struct StepNow {
+  // ---- per-row inputs of a step, staged through LDS.  The 16 rows of a step need dL/dr~, the reward Jacobian Jx | Ja,
+  // Td | Tp and the action of every input slot: PRB_IN_COLS floats a row, the same for all four waves.  The 512 floats of
+  // the stage are fetched by the workgroup ONCE, two a thread (thread e -> row e >> 5, column e & 31; every column of
+  // every array at its own address: a 64-bit pointer a thread, stepped back by the array's step stride), a step ahead of
+  // their use, parked in LDS between the step's third and fourth barrier, and read by the lanes that need them at the
+  // top of the next step (a ds_read_b64 an array).  36 vector-memory loads a wave and step became 6 (with the activity
+  // words below): the loads of four waves queued behind one another in the CU's one address unit were 2 k of a step's
+  // 10 k cycles.
+  //   column 0: dL/dr~;  2 + i: Jx[i] (i < D) or Ja[i - D];  10 + i: Td[i] or Tp[i - D];  18 + i: a[i - D]
+  float* const stage = smem + PRB_LDS_IN;
+  typedef const PM_GLOBAL_ char* gcp;
+  gcp sp[2];
+  unsigned sstep[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + k * PR_NTHR, r = e >> 5, c = e & 31;
+    const long long grow = row0 + r;
+    gcp q = (gcp)A.ws;
+    unsigned st = 0u;
+    if (r < nvalid) {
+      const int i = c >= 18 ? c - 18 : (c >= 10 ? c - 10 : c - 2);
+      if (c == 0) {
+        q = (gcp)A.grad_rewards + ((long long)(T1 - 1) * B + grow) * 4;
+        st = (unsigned)B * 4u;
+      } else if (c >= 2 && c < 26 && i < D && c < 18) {
+        q = (gcp)A.ws + (c < 10 ? A.Jx : A.Td) + ((long long)(T1 - 1) * B + grow) * D * 4 + i * 4;
+        st = x_step;
+      } else if (c >= 2 && c < 26 && i >= D && i < D + U) {
+        q = (c >= 18 ? (gcp)A.actions : (gcp)A.ws + (c < 10 ? A.Ja : A.Tp)) + ((long long)(T1 - 1) * B + grow) * U * 4 + (i - D) * 4;
+        st = a_step;
+      }
+    }
+    sp[k] = q;
+    sstep[k] = st;
+  }
+  float sv[2];
+  auto stage_load = [&]() {
+    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(sv[0]), "=&v"(sv[1]) : "v"(sp[0]), "v"(sp[1]) : "memory");
+  };
+  auto stage_landed = [&](auto nc, float (&v)[2]) {
+    constexpr int N = decltype(nc)::value;
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N) : "memory");
+  };
+  auto stage_park = [&]() {
+    stage[tid] = sv[0];
+    stage[tid + PR_NTHR] = sv[1];
+  };
+  // activity words of a step's four hidden layers (pm_reg_fwd_kernel: one word a lane, nibble q = the wave's tile in slot
+  // q): [0] dynamics layer 1, [1] dynamics layer 0, [2] policy layer 1, [3] policy layer 0
+  const pr_i32x4 wsrd = pr_rsrc_words(A.ws);
+  const unsigned vo_abp = (unsigned)lane * 4u;
+  const int abp_step = A.nwg * (PR_NW * 256);
+  int so_abp = ((T1 - 1) * A.nwg + wg) * (PR_NW * 256) + wid * 256;
+  auto ab_load = [&](unsigned (&w)[4]) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %4, %5, %6 offen\n\tbuffer_load_dword %1, %4, %5, %7 offen\n\t"
+                 "buffer_load_dword %2, %4, %5, %8 offen\n\tbuffer_load_dword %3, %4, %5, %9 offen"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(vo_abp), "s"(wsrd), "s"(pr_uni((int)A.dyn.abits[1] + so_abp)), "s"(pr_uni((int)A.dyn.abits[0] + so_abp)),
+                   "s"(pr_uni((int)A.pol.abits[1] + so_abp)), "s"(pr_uni((int)A.pol.abits[0] + so_abp))
+                 : "memory");
+  };
+  auto ab_landed = [&](auto nc, unsigned (&w)[4]) {
+    constexpr int N = decltype(nc)::value;
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
+  };
+  // what a lane reads back from the stage
+  const float* const st_row = stage + row * PRB_IN_COLS;
+  struct StepIn {
     float gr, jx[2], td[2];
-    unsigned ab[PR_SLOTS + 1];
   };
-  struct StepLater {
-    float ja[2], tp[2], ac[2];
-    unsigned ab[3][PR_SLOTS + 1];      // dynamics layer 0, policy layer 1, policy layer 0
-  };
-  auto load_ab = [&](unsigned (&b)[PR_SLOTS + 1], int so) {
-#pragma unroll
-    for (int q = 0; q <= PR_SLOTS; ++q) {
-      const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
-      b[q] = __builtin_amdgcn_raw_buffer_load_b8(srd, vo_ab, pr_uni(so + ot * 4), 0);
-    }
-  };
-  auto load_now = [&](StepNow& I) {
-    I.gr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_gr, rvalid ? (row0 + row) * 4 : 0, pr_uni(so_gr), 0));
+  auto read_in = [&](StepIn& I) {
+    const f32x2 a = *reinterpret_cast<const f32x2*>(st_row + 2 + 2 * g), b = *reinterpret_cast<const f32x2*>(st_row + 10 + 2 * g);
+    I.gr = rvalid ? st_row[0] : 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      I.jx[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_x[s], pr_uni(so_jx), 0));
-      I.td[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_x[s], pr_uni(so_td), 0));
+      I.jx[s] = ok_x[s] ? a[s] : 0.f;
+      I.td[s] = ok_x[s] ? b[s] : 0.f;
     }
-    load_ab(I.ab, (int)A.dyn.abits[1]);
-  };
-  auto mask_now = [&](StepNow& I) {
-    if (!rvalid) I.gr = 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (!ok_x[s]) { I.jx[s] = 0.f; I.td[s] = 0.f; }
-  };
-  auto load_later = [&](StepLater& I) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      I.ja[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_a[s], pr_uni(so_ja), 0));
-      I.tp[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, so_a[s], pr_uni(so_tp), 0));
-      I.ac[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd_act, so_a[s], pr_uni(so_ac), 0));
-    }
-    load_ab(I.ab[0], (int)A.dyn.abits[0]);
-    load_ab(I.ab[1], (int)A.pol.abits[1]);
-    load_ab(I.ab[2], (int)A.pol.abits[0]);
   };
 
   // head adjoint of network NET: inputs gm (x the means' rows), gl (x the log-stds' rows) of the lane's two slots;
   // result x activity of the second hidden layer -> LDS (+ stash)
-  auto head_adjoint = [&](auto netc, const float (&gm)[2], const float (&gl)[2], const unsigned (&ab)[PR_SLOTS + 1], int so_st) {
+  auto head_adjoint = [&](auto netc, const float (&gm)[2], const float (&gl)[2], const unsigned abw, int so_st) {
     constexpr int NET = decltype(netc)::value;
     // B fragments: slots 3 s + {0, 1, 2} = g.hi, g.lo, g.hi
     f32x4 bf[2];
@@ -957,7 +1049,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
       wf[q][0] = *reinterpret_cast<const f32x4*>(l0w + (size_t)(ot * 2 + 0) * PR_FRAG);
       wf[q][1] = *reinterpret_cast<const f32x4*>(l0w + (size_t)(ot * 2 + 1) * PR_FRAG);
-      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 1) * 16 + (ab[q] & 15u)) * 4);
+      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 1) * 16 + ((abw >> (4 * q)) & 15u)) * 4);
     });
     pr_mfma_open();
     pr_for<PR_SLOTS + 1>([&](auto qc) {
@@ -980,7 +1072,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+          PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);)
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -991,17 +1083,19 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
   };
 
   // transposed hidden->hidden layer + tail of network NET; leaves the summed tail tile in `o`
-  auto hidden_adjoint_and_tail = [&](auto netc, const unsigned (&ab)[PR_SLOTS + 1], int so_st, f32x4& o) {
+  // (`arrived`: called behind the MFMA loop -- where the step's staged inputs are parked)
+  auto hidden_adjoint_and_tail = [&](auto netc, const unsigned abw, int so_st, f32x4& o, auto arrived) {
     constexpr int NET = decltype(netc)::value;
     const bool xw = NET == 0 ? xw_pol : xw_dyn;
     f32x4 acc[PR_SLOTS][2], accx[2];
     f32x4 mfv[PR_SLOTS + 1], hwv[2][2];
-    pr_for<PR_SLOTS + 1>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 0) * 16 + (ab[q] & 15u)) * 4);
-    });
     if (xw) pr_hidden_layer<NET, F16, true>(W, smem, smem + PRB_LDS_XT(NET), lane, acc, accx);
     else pr_hidden_layer<NET, F16, false>(W, smem, nullptr, lane, acc, accx);
+    arrived();
+    pr_for<PR_SLOTS + 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      mfv[q] = *reinterpret_cast<const f32x4*>(lut + ((NET * 2 + 0) * 16 + ((abw >> (4 * q)) & 15u)) * 4);
+    });
     // (the tail's weights: requested here, they land behind the epilogues)
     const float* hw = smem + PRB_LDS_HEAD(NET) + (size_t)wid * (4 * PR_FRAG) + lane * 4;
 #pragma unroll
@@ -1021,7 +1115,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       if constexpr (NET == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);
+          PR_EXP_STASH(__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gq[r]), srd, lane_st + r * 64, pr_uni(so_st + ot * 1024), 0);)
       }
     };
     pr_for<PR_SLOTS>([&](auto qc) {
@@ -1052,19 +1146,27 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     for (int w = 1; w < PR_NW; ++w) o += *reinterpret_cast<const f32x4*>(part + w * PR_FRAG);
   };
 
-  StepNow In, InN;
-  load_now(In);
-  mask_now(In);
-  for (int t = T1 - 1; t >= 0; --t) {
+  // prologue: the last step's inputs and activity words
+  unsigned abc[4], abn[4];
+  stage_load();
+  ab_load(abc);
+  stage_landed(std::integral_constant<int, 0>{}, sv);
+  ab_landed(std::integral_constant<int, 0>{}, abc);
+  stage_park();
+  __syncthreads();
+  for (int t = T1 - 1; t >= T0; --t) {
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 0] = (long long)__builtin_readcyclecounter();
-    StepLater Il;
-    load_later(Il);
-    // the early inputs of step t - 1: on their way while this step computes
-    if (t > 0) {
-      vo_ab -= vstep_ab;
-      so_td -= (int)x_step; so_jx -= (int)x_step; so_gr -= B * 4;
-      load_now(InN);
+    StepIn In;
+    read_in(In);
+    // the inputs of step t - 1: on their way while this step computes (the last step of the range asks for its own once
+    // more: the count of operations in flight is the same at every step)
+    if (t > T0) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) sp[k] -= sstep[k];
+      so_abp -= abp_step;
     }
+    stage_load();
+    ab_load(abn);
     // ---- dynamics model: gradient of the sampled state, through the head
     float gxn[2], gm[2], gl[2];
 #pragma unroll
@@ -1074,23 +1176,27 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       gm[s] = gg * c_sy[s];
       gl[s] = gg * In.td[s];
     }
-    head_adjoint(std::integral_constant<int, 1>{}, gm, gl, In.ab, 0);
+    head_adjoint(std::integral_constant<int, 1>{}, gm, gl, abc[0], 0);
     pr_barrier();
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 1] = (long long)__builtin_readcyclecounter();
     f32x4 o;
-    hidden_adjoint_and_tail(std::integral_constant<int, 1>{}, Il.ab[0], 0, o);
+    hidden_adjoint_and_tail(std::integral_constant<int, 1>{}, abc[1], 0, o, []() {});
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 2] = (long long)__builtin_readcyclecounter();
     // ---- gradient of [x | a] (normalised inputs): state part -> gxn, action part -> through the squashing
     float pm_[2], pl_[2];
+    {
+      const f32x2 ja = *reinterpret_cast<const f32x2*>(st_row + 2 + 2 * g), tp = *reinterpret_cast<const f32x2*>(st_row + 10 + 2 * g),
+                  ac = *reinterpret_cast<const f32x2*>(st_row + 18 + 2 * g);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const float tail = o[2 * s] * c_isx[s];
-      gxn[s] += ok_x[s] ? tail : 0.f;
-      const float ga = In.gr * (ok_a[s] ? Il.ja[s] : 0.f) + tail;
-      const float th = ((ok_a[s] ? Il.ac[s] : c_pbi[s]) - c_pbi[s]) * pr_rcp(c_psc[s]);
-      const float gu = ok_a[s] ? ga * c_psc[s] * (1.f - th * th) : 0.f;
-      pm_[s] = gu;
-      pl_[s] = ok_a[s] ? gu * Il.tp[s] : 0.f;
+      for (int s = 0; s < 2; ++s) {
+        const float tail = o[2 * s] * c_isx[s];
+        gxn[s] += ok_x[s] ? tail : 0.f;
+        const float ga = In.gr * (ok_a[s] ? ja[s] : 0.f) + tail;
+        const float th = ((ok_a[s] ? ac[s] : c_pbi[s]) - c_pbi[s]) * pr_rcp(c_psc[s]);
+        const float gu = ok_a[s] ? ga * c_psc[s] * (1.f - th * th) : 0.f;
+        pm_[s] = gu;
+        pl_[s] = ok_a[s] ? gu * tp[s] : 0.f;
+      }
     }
     // head-gradient stash of the policy ([16][16] block: row j = d mean_j, row U + j = d log-std_j, zero below)
     if (wid == 2) {
@@ -1105,24 +1211,40 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     } else if (wid == 3) {
       for (int k = 2 * U * 16 + lane; k < 256; k += 64) __builtin_amdgcn_raw_buffer_store_b32(0u, srd, k * 4, pr_uni(so_g2), 0);
     }
-    head_adjoint(std::integral_constant<int, 0>{}, pm_, pl_, Il.ab[1], so_g1);
+    head_adjoint(std::integral_constant<int, 0>{}, pm_, pl_, abc[2], so_g1);
     pr_barrier();
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 3] = (long long)__builtin_readcyclecounter();
-    hidden_adjoint_and_tail(std::integral_constant<int, 0>{}, Il.ab[2], so_g0, o);
+    // (between the step's third and fourth barrier: every lane has read this step's inputs, none reads the next one's
+    //  before the fourth.  Behind the two staged loads: the 4 activity-word loads and at least the 12 stash stores of the
+    //  policy's head adjoint)
+    hidden_adjoint_and_tail(std::integral_constant<int, 0>{}, abc[3], so_g0, o, [&]() {
+#ifdef PR_EXP_NOSTASH
+      stage_landed(std::integral_constant<int, 0>{}, sv);
+#else
+      stage_landed(std::integral_constant<int, 16>{}, sv);
+#endif
+      stage_park();
+    });
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 4] = (long long)__builtin_readcyclecounter();
 #pragma unroll
     for (int s = 0; s < 2; ++s) gx[s] = ok_x[s] ? gxn[s] + o[2 * s] : 0.f;
     so_g0 -= st_step; so_g1 -= st_step; so_g2 -= st_step2;
-    so_tp -= (int)a_step; so_ja -= (int)a_step; so_ac -= (int)a_step;
-    if (t > 0) {
-      In = InN;
-      mask_now(In);
-    }
+    // the next step's activity words: requested a step ago; behind them this step issued at least the 24 stash stores of
+    // the policy's two hidden layers (3 tiles x 4 registers each, every wave)
+#ifdef PR_EXP_NOSTASH
+    ab_landed(std::integral_constant<int, 0>{}, abn);
+#else
+    ab_landed(std::integral_constant<int, 24>{}, abn);
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k) abc[k] = abn[k];
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
   }
-  if (A.grad_x0 && wid == 0) {
+  if (wid == 0) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (ok_x[s]) *(gf32*)((PM_GLOBAL_ char*)A.grad_x0 + so_x[s]) = gx[s];
+    for (int s = 0; s < 2; ++s) {
+      if (A.grad_x0 && T0 == 0 && ok_x[s]) *(gf32*)((PM_GLOBAL_ char*)A.grad_x0 + so_x[s]) = gx[s];
+      if (A.gx_out && ok_x[s]) *(gf32*)((PM_GLOBAL_ char*)A.gx_out + so_x[s]) = gx[s];
+    }
   }
 }

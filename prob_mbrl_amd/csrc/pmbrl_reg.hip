@@ -37,8 +37,7 @@ int pm_reg_set_attr(const pmbrl_plan* p) {
   return 0;
 }
 
-static void reg_net(const pmbrl_plan* p, const NetPlan& n, const NetDev& d, RegNet& r) {
-  (void)p;
+static void reg_net(const pmbrl_plan* p, int net, const NetPlan& n, const NetDev& d, RegNet& r) {
   for (int l = 0; l < 3; ++l) {
     r.w_off[l] = (int)n.w_off[l];
     r.b_off[l] = (int)n.b_off[l];
@@ -47,7 +46,7 @@ static void reg_net(const pmbrl_plan* p, const NetPlan& n, const NetDev& d, RegN
   r.n_out = n.dim[3];
   for (int l = 0; l < 2; ++l) {
     r.mask[l] = d.mask[l];
-    r.abits[l] = (unsigned)n.abits[l];
+    r.abits[l] = (unsigned)p->off_reg_ab[net][l];
     r.inv_keep[l] = d.inv_keep[l];
   }
 }
@@ -57,8 +56,8 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
   memset(&R, 0, sizeof(R));
   R.B = A.B; R.H = A.H; R.D = A.D; R.U = A.U; R.nwg = A.nwg; R.hid = p->pol.dim[1];
   R.mls_pol = A.mls_pol; R.mls_dyn = A.mls_dyn;
-  reg_net(p, p->pol, A.pol, R.pol);
-  reg_net(p, p->dyn, A.dyn, R.dyn);
+  reg_net(p, 0, p->pol, A.pol, R.pol);
+  reg_net(p, 1, p->dyn, A.dyn, R.dyn);
   R.packed = packed;
   R.pol_params = pol_params; R.dyn_params = dyn_params;
   R.x0 = A.x0; R.mx = A.mx; R.iSx = A.iSx; R.my = A.my; R.Sy = A.Sy; R.pscale = A.pscale; R.pbias = A.pbias;
@@ -69,6 +68,9 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
   R.status = A.status;
   R.wflag = A.wflag; R.wgen = A.wgen;
   R.grad_rewards = A.grad_rewards; R.grad_x0 = A.grad_x0; R.nvalid = A.nvalid;
+  R.t0 = A.t0; R.t1 = A.t1;
+  R.gx_in = A.gx_from_carry ? A.gx_carry : nullptr;
+  R.gx_out = (A.gx_carry && A.t0 > 0) ? A.gx_carry : nullptr;
   R.prof = A.prof;
 }
 
@@ -101,6 +103,20 @@ void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, 
   hipLaunchKernelGGL(pm_reg_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P);
 }
 
+// the activity bits of the last forward sweep, from the family's words to the per-tile bytes the latency-optimised
+// family's adjoint sweep reads (an adjoint call with optional outputs after a forward call this family served)
+void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s) {
+  RegUnpackArgs U;
+  U.B = p->cfg.B; U.H = p->cfg.H; U.nwg = p->nwg;
+  const NetPlan* nets[2] = {&p->pol, &p->dyn};
+  for (int n = 0; n < 2; ++n)
+    for (int l = 0; l < 2; ++l) {
+      U.src[n][l] = reinterpret_cast<const unsigned*>(ws + p->off_reg_ab[n][l]);
+      U.dst[n][l] = reinterpret_cast<unsigned char*>(ws + nets[n]->abits[l]);
+    }
+  hipLaunchKernelGGL(pm_reg_unpack_abits_kernel, dim3(p->nwg, p->cfg.H), dim3(PR_NTHR), 0, s, U);
+}
+
 void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
                    hipStream_t s, bool fwd) {
   RegArgs R;
@@ -108,7 +124,7 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
   if (getenv("PMBRL_REG_DEBUG"))
     fprintf(stderr, "pm_reg_launch %s: off_reg_pack %zu gT %zu %zu %zu actT %zu %zu %zu abits %zu %zu %zu %zu ws_bytes %zu\n", fwd ? "fwd" : "bwd",
             p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
-            p->pol.abits[0], p->pol.abits[1], p->dyn.abits[0], p->dyn.abits[1], p->ws_bytes);
+            p->off_reg_ab[0][0], p->off_reg_ab[0][1], p->off_reg_ab[1][0], p->off_reg_ab[1][1], p->ws_bytes);
   if (fwd) {
     if (R.prof) hipLaunchKernelGGL(pm_reg_fwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
     else hipLaunchKernelGGL(pm_reg_fwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);

@@ -370,7 +370,7 @@ class Engine:
                          dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9],
                          fast=info[10], stages=(info[11] >> 4, info[11] & 15), mm_grid=info[12],
                          precision={_lib.PREC_SPLIT: 'split', _lib.PREC_SPLIT_F16: 'split_f16'}.get(info[13], 'f32'),
-                         dw_pipe=info[14], mm_parts=info[15], reg=info[16])
+                         dw_pipe=info[14], mm_parts=info[15], reg=info[16], replay=info[17])
         self.n_pol_params = info[4]
         self.n_dyn_params = info[5]
         ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)
@@ -608,6 +608,20 @@ class Engine:
                                               _ptr(agn), _ptr(self.status)),
                    'pmbrl_rollout_bwd')
         return self.grad_flat, gx0, agn
+
+    def set_replay(self, on=1):
+        """0: never replay repeated calls as hipGraphs; 1: the library's default (the one-launch-per-step forms); 2: every
+        form (pmbrl_plan_set_replay)."""
+        _lib.check(self.lib.pmbrl_plan_set_replay(self.plan, int(on)), 'set_replay')
+        info = (C.c_int32 * _lib.INFO_COUNT)()
+        _lib.check(self.lib.pmbrl_plan_info(self.plan, info), 'plan_info')
+        self.info['replay'] = int(info[17])
+
+    def replay_count(self):
+        """(forward calls, adjoint calls) that went out as one graph launch so far."""
+        n = (C.c_int64 * 2)()
+        _lib.check(self.lib.pmbrl_plan_replay_count(self.plan, n), 'replay_count')
+        return int(n[0]), int(n[1])
 
     def set_timing(self, on=True):
         _lib.check(self.lib.pmbrl_plan_set_timing(self.plan, 1 if on else 0), 'set_timing')

@@ -796,3 +796,56 @@ def test_library_graph_entry_points_replay_an_iteration(name, groups, monkeypatc
         assert info['mm_mode'] in (2, 3) and nodes >= H      # a launch per step at least: what the replay folds
     else:
         assert nodes >= 8
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_repeated_calls_are_replayed_and_match_eager_calls(mode, monkeypatch):
+    """pmbrl_plan_set_replay.  mode 1, the default: a per-step-launch form (one moment-matching group
+    over 100 rows, a launch per step and more) replays its repeated forward and adjoint calls as hipGraphs from the third
+    identical call on; mode 2: so does a one-launch form when asked.  The parameters after 6 optimiser iterations are
+    those of the eager calls bit for bit; a call with other arguments in between (another output buffer) runs eagerly
+    and the replay resumes after it."""
+    name = 'mmg_h40' if mode == 1 else 'full200_nomm'
+    d = dict(common.load(name))
+    if mode == 1:
+        d['mm_groups'] = np.asarray(0)
+        monkeypatch.setenv('PMBRL_MM_PERSTEP', '1')
+        monkeypatch.setenv('PMBRL_MM_PARTS', '1')
+    H, B = int(d['H']), d['x0'].shape[0]
+
+    def run(replay):
+        eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+        eng.set_replay(replay)
+        assert eng.info['replay'] == (1 if replay else 0)
+        gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+        params = args['pol_flat'].clone()
+        args['pol_flat'] = params
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+        loss = eng.set_loss(gw)
+        adam = dict(params=params, exp_avg=m, exp_avg_sq=v, step=step_dev, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0)
+        other = (torch.empty((H + 1, B, eng.D), device=DEV), torch.empty((H, B, eng.U), device=DEV),
+                 torch.empty((H, B, 1), device=DEV))
+        losses = []
+        for it in range(7):
+            if it == 4:       # other output tensors: not the recorded call
+                eng.forward(**args, out=other)
+            else:
+                eng.forward(**args)
+            eng.backward(gw, adam=adam)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert eng.valid_steps() == H
+        return params.clone(), int(step_dev.item()), losses, eng.replay_count(), eng.info
+
+    p_e, s_e, l_e, n_e, info = run(0)
+    p_r, s_r, l_r, n_r, _ = run(mode)
+    if mode == 1:
+        assert info['mm_mode'] in (2, 3)
+    assert n_e == (0, 0)
+    # forward: calls 0, 1 eager (1 = the recording, launched as a graph), 2, 3 replayed, 4 eager (other outputs), 5 eager
+    # (first sight again), 6 recorded + launched; the adjoint's arguments change with the forward's outputs at 4 and 5
+    assert n_r[0] >= 3 and n_r[1] >= 3, n_r
+    assert s_e == 7 and s_r == 7
+    assert l_e == l_r
+    assert torch.equal(p_e, p_r)

@@ -7,7 +7,8 @@ still being written, so a register-allocator copy / spill / reuse of a destinati
 between the load and the wait that covers it would silently read stale data.  This script
 walks the control-flow graph of the generated ISA (hipcc -S), tracking on every path which
 inline-asm loads are still outstanding (an inline-asm `s_waitcnt vmcnt(N)` retires all but the
-N youngest), and reports any instruction that touches a register that is in flight.
+N youngest vector-memory operations -- stores and the compiler's own loads take their places in that queue too), and
+reports any instruction that touches a register that is in flight.
 
 usage: check_inflight.py file.s [function-name-substring]
 """
@@ -17,6 +18,8 @@ import sys
 REG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
 LABEL = re.compile(r'^(\.LBB\d+_\d+):')
 FUNC = re.compile(r'^(_Z\w+):')
+VMEM = re.compile(r'^(global|buffer|flat|scratch)_(load|store|atomic)')
+LOAD = re.compile(r'^(global|buffer)_load')
 
 
 def regs_of(text):
@@ -96,11 +99,28 @@ def check_function(name, items):
         succ = [bi + 1]
         for kind, code, ln, raw in blocks[bi]:
             used = None
-            if kind == 'asm' and code.startswith('global_load'):
+            if VMEM.match(code) and not (kind == 'asm' and LOAD.match(code)):
+                # any other vector-memory operation (the compiler's own loads, every store): it takes a place in the
+                # in-order return queue that vmcnt counts, and has no destination to watch
+                used = regs_of(code)
+                for at in st:
+                    if not at:
+                        continue
+                    hit = used & dst_regs[at]
+                    if hit:
+                        bad.add((ln, at, raw.strip(), tuple(sorted(hit))))
+                if st:            # (anonymous, and of interest only while a watched load is older than it)
+                    st.append(0)
+                    if len(st) > 64:      # vmcnt counts to 63: forgetting an anonymous entry only errs on the safe side
+                        st.remove(0)      # (fewer entries behind a load = a wait retires less of what is watched)
+                continue
+            if kind == 'asm' and LOAD.match(code):
                 dst = code.split()[1].rstrip(',')
                 dst_regs[ln] = regs_of(dst)
                 used = regs_of(code.split(',', 1)[1]) | dst_regs[ln]
                 for at in st:
+                    if not at:
+                        continue
                     hit = used & dst_regs[at]
                     if hit:
                         bad.add((ln, at, raw.strip(), tuple(sorted(hit))))
@@ -110,11 +130,13 @@ def check_function(name, items):
                     st.remove(ln)
                 st.append(ln)
                 continue
-            if kind == 'asm' and code.startswith('s_waitcnt'):
+            if code.startswith('s_waitcnt'):      # (hand-written or the compiler's: the hardware does not care)
                 mm = re.search(r'vmcnt\((\d+)\)', code)
                 if mm:
                     keep = int(mm.group(1))
                     st = st[len(st) - keep:] if keep else []
+                    while st and st[0] == 0:
+                        st.pop(0)
                 continue
             if code.startswith('s_endpgm'):
                 succ = []
@@ -127,12 +149,14 @@ def check_function(name, items):
                 break
             used = regs_of(code)
             for at in st:
+                if not at:
+                    continue
                 hit = used & dst_regs[at]
                 if hit:
                     bad.add((ln, at, raw.strip(), tuple(sorted(hit))))
         for s in succ:
             work.append((s, tuple(st)))
-    nload = len(dst_regs)
+    nload = sum(1 for v in dst_regs.values() if v)
     for ln, at, raw, hit in sorted(bad):
         print('%s:%d: touches v%s, in flight since line %d\n    %s' % (name, ln, list(hit), at, raw))
     return len(bad), nload, len(seen)
