@@ -417,6 +417,32 @@ __host__ __device__ inline size_t pm_mm_kernel_doubles(int D) {
     case 6: { CALL(6); break; }        \
     default: { ELSE; }                 \
   }
+// Standardisation of a large group's noise rows, mean and 1 / std per column and step (what every part of a split group
+// needs of the WHOLE group): grid (H, groups), wave w takes the columns w, w + 4, ...; same formula and summation scheme
+// as the sweeps' own prologue (pmbrl_fast.h).
+__global__ __launch_bounds__(256) void pm_mm_ztable_kernel(RolloutArgs A, double* tab) {
+  const int t = blockIdx.x, gi = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int D = A.D;
+  const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+  const int z0 = pm_zrow0(t, A.row_off + gi * A.M, A.flags);
+  const double dM = (double)A.M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(A.M - 1);
+  double* out = tab + ((size_t)t * gridDim.y + gi) * 2 * D;
+  for (int j = wid; j < D; j += 4) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < A.M; r += 64) {
+      const double zv = (double)zb[(size_t)pm_zidx(z0, r, A.Bg) * D + j];
+      s1 += zv;
+      s2 += zv * zv;
+    }
+    const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
+    const double zm = sm * inv_m;
+    if (lane == 0) {
+      out[j] = zm;
+      out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
+    }
+  }
+}
+
 __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A, int t) {
   extern __shared__ __attribute__((aligned(16))) double mmscr[];
   const int gi = blockIdx.x, lane = threadIdx.x & 63;
@@ -737,7 +763,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // workgroups: wave 0, and the whole group's rows in LDS)
       const int mw = parts > 1 ? 1 : (mmd && p->M <= 16 * RT) ? std::min(PF_NW, std::max(1, 16 * RT / p->M)) : PF_NW;
       return pm_fast_lds_floats(16 * RT, p->LD, c.D, c.U, RT, p->pol.nt, p->pol.nl, p->dyn.nt,
-                                p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? p->M : 0, parts > 1 ? c.H : 0) * sizeof(float);
+                                p->dyn.nl, mmd, prec_for(RT), mw, parts > 1 ? (parts > 8 ? 16 : p->M) : 0, parts > 1 ? c.H : 0) * sizeof(float);
     }
     return pm_lds_floats(16 * RT, p->LD, c.D, c.U, RT, mmd, p->inplace != 0) * sizeof(float);
   };
@@ -816,6 +842,32 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
           p->mm_parts = want;
           p->RT = rt;
           p->rows_per_wg = rpw;
+        }
+      }
+      // A group beyond 8 parts of 32 rows -- ONE group over the whole batch, the reference's default (mm_groups=None,
+      // examples/deep_pilco_mm.py:31): 16-row parts whose sums travel over two levels (pm_xch_get_tree), every workgroup
+      // resident.  Only where the instance that exchanges sums runs (compile-time state width, the cart-pole shape:
+      // PM_SPLIT_SHAPED_CASES) -- the rows + flags form of the generic instances keeps the whole group's rows in LDS.
+      // 2 500 rows: 157 parts, 13 collectors; against the device-wide-barrier form (every workgroup re-reads and
+      // re-reduces the whole group's rows every step) 3.0 -> see profiles/r04*_single_group.txt.  PMBRL_MM_TREE=0: off.
+      const bool shaped_mm1 = p->fast && prec_for(1) == PMBRL_PREC_SPLIT_F16 && c.D == 4 && c.U == 1 && p->pol.nl == 3 &&
+                              p->dyn.nl == 3 && p->pol.nt[1] == 13 && p->pol.nt[2] == 13 && p->dyn.nt[1] == 13 && p->dyn.nt[2] == 13 &&
+                              !(c.flags & PMBRL_FLAG_NO_SHAPED) && !(getenv("PMBRL_LDS_TILES") && atoi(getenv("PMBRL_LDS_TILES")) == 0) &&
+                              !(getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0);
+      if (p->mm_mode == 2 && !p->span && !e && shaped_mm1 && (c.flags & PMBRL_FLAG_MM_STATES) &&
+          !(getenv("PMBRL_MM_TREE") && atoi(getenv("PMBRL_MM_TREE")) == 0)) {
+        const int parts = (p->M + 15) / 16;
+        if (parts > 8 && (long long)p->G * parts <= max_wg && ld_for(1) == 240) {
+          const size_t tiles = (size_t)PF_NW * pm_lds_tile_floats(14, 2, 16 * ((16 * 13 - 32 * 6) / 8)) * sizeof(float);
+          if (lds_need(1, c.D, parts) + tiles + 16 <= lds_cap) {
+            p->mm_mode = 1;
+            p->mm_parts = parts;
+            p->RT = 1;
+            p->rows_per_wg = 16;
+            int fan = 2;
+            while (fan * fan < parts) ++fan;
+            p->mm_fan = fan;
+          }
         }
       }
     }
@@ -917,7 +969,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // 100-row group in seven parts would not fit both)
       const int mw = 1;
       base = pm_fast_rows_area_off(16 * p->RT, p->LD, c.D, c.U, p->RT, p->pol.nt, p->pol.nl, p->dyn.nt, p->dyn.nl, c.D,
-                                   prec_for(p->RT), mw, p->M, c.H) * sizeof(float);
+                                   prec_for(p->RT), mw, p->mm_parts > 8 ? 16 : p->M, c.H) * sizeof(float);
       base = (base + 15) / 16 * 16;
     }
     const size_t tiles = (size_t)PF_NW * pm_lds_tile_floats(14, 2, last_lanes) * sizeof(float);
@@ -1170,9 +1222,11 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // groups split over workgroups: the granules of their statistics exchange (pm_xch_sum; PMBRL_MM_XCH=0: rows + flags)
     p->xch_bytes = 0;
     if (p->mm_parts > 1 && !(getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0)) {
-      p->xch_bytes = (size_t)p->nwg * PM_XCH_WG_WORDS(2) * sizeof(unsigned long long);
+      // (more than 8 parts: a second set of slots, the collectors')
+      p->xch_bytes = (size_t)(p->mm_parts > 8 ? 2 : 1) * p->nwg * PM_XCH_WG_WORDS(2) * sizeof(unsigned long long);
       p->off_xch = take(p->xch_bytes);
     }
+    p->off_ztab = take(p->mm_fan ? (size_t)c.H * p->G * 2 * c.D * sizeof(double) : 0);
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     {
       // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
@@ -1523,6 +1577,8 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.gx_carry = reinterpret_cast<float*>(ws + p->off_gxc);
   A.mm_grid = p->mm_grid;
   A.mm_parts = p->mm_parts;
+  A.mm_fan = p->mm_fan;
+  A.mm_ztab = p->mm_fan ? reinterpret_cast<const double*>(ws + p->off_ztab) : nullptr;
   A.gsync = reinterpret_cast<unsigned*>(ws + p->off_gsync);
   A.xch = p->xch_bytes ? reinterpret_cast<unsigned long long*>(ws + p->off_xch) : nullptr;
   A.gx_carry_out = nullptr;
@@ -1740,6 +1796,7 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
   } else if (p->mm_mode != 2) {
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
+    if (p->mm_fan) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
     if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     if (p->mm_parts > 1 && As.xch) HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));      // ... or the granules' tags
     if (pm_reg_can_run(p, As, true)) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);

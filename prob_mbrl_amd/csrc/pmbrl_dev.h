@@ -147,6 +147,11 @@ struct RolloutArgs {
   // the workgroups of a group exchange their rows through HBM and meet at a group-local flag barrier
   // (pmbrl_fast.h, pm_group_sync); every one of them factors the whole group, each keeps its own rows
   int mm_parts;
+  // ... more than 8 parts: the sums travel over two levels (pm_xch_get) -- mm_fan consecutive parts per collector;
+  // the z standardisation of the whole group then comes from mm_ztab ([H][groups][zm (D) | zi (D)] doubles,
+  // pm_mm_ztable_kernel) instead of every part walking the group's noise rows
+  int mm_fan;
+  const double* mm_ztab;
   // mm_mode 3 with every workgroup resident at once: ONE launch over the horizon, the workgroups
   // meet at a device-wide barrier (arrival counter gsync) where the per-step launches ended
   int mm_grid;

@@ -189,6 +189,14 @@ __device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int pa
 // writes its step k + 2 only after it read everybody's k + 1, which was written after that part had read this k.
 // A wait that does not end (a partner that is not resident -- the host checks that all are) gives up after ~1 s.
 #define PM_XCH_WG_WORDS(NV) (2 * (NV) * 2 * 64)
+// More than PM_XCH_FLAT parts (one moment-matching group over the whole batch: 157 parts at 2 500 rows): TWO LEVELS.
+// Every `fan` consecutive parts have a collector (the first of them), which adds up their sums in part order and
+// publishes the result in a slot of its own (slot nwg + first + c: the buffer holds 2 x nwg slots); every part then
+// adds up the collectors' slots in collector order -- the same bits everywhere again, two hops of at most `fan` slots
+// each instead of one walk over every part's slot (157 x 2 KB per part and step).  Slots are polled in batches of 8
+// (all their granules requested before the first is looked at: one memory round trip a batch, not one a slot).
+// The alternation argument above holds level by level.
+#define PM_XCH_FLAT 8
 // publish this part's NV doubles per lane for step k (nothing is waited for: the stores are on their way)
 template <int NV>
 __device__ __forceinline__ void pm_xch_put(unsigned long long* xb, int first, int me, unsigned k, const double (&v)[NV],
@@ -241,6 +249,61 @@ __device__ __forceinline__ bool pm_xch_get(const unsigned long long* xb, int fir
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = tot[i];
+  return ok;
+}
+
+// tot += the sums in slots [slot0, slot0 + n), in slot order; batches of 8 slots in flight
+template <int NV>
+__device__ __forceinline__ bool pm_xch_add_slots(const unsigned long long* xb, int slot0, int n, unsigned k, double (&tot)[NV],
+                                                 int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  constexpr int NB = 8;
+  for (int q0 = 0; q0 < n; q0 += NB) {
+    const int nb = n - q0 < NB ? n - q0 : NB;
+    unsigned long long g[NB][2 * NV];
+    for (int spins = 0;;) {
+      bool here = true;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int q = q0 + (b < nb ? b : 0);        // (a short last batch asks for its first slot again)
+        const gu64* theirs = (const gu64*)xb + (size_t)(slot0 + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) here = here && (g[b][i] >> 32) == (unsigned long long)k;
+      if (__all(here)) break;
+      if (++spins > (1 << 19)) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (b < nb) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          tot[i] += __longlong_as_double((long long)(((g[b][2 * i] & 0xffffffffull) << 32) | (g[b][2 * i + 1] & 0xffffffffull)));
+      }
+  }
+  return true;
+}
+// v <- the sum over all parts, two levels (v holds this part's own contribution on entry, already published by pm_xch_put)
+template <int NV>
+__device__ __forceinline__ bool pm_xch_get_tree(unsigned long long* xb, int nwg, int first, int parts, int fan, int me, unsigned k,
+                                                double (&v)[NV], int lane) {
+  const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
+  bool ok = true;
+  if (me == c0) {
+    double tot[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+    ok = pm_xch_add_slots<NV>(xb, first + c0, (parts - c0 < fan ? parts - c0 : fan), k, tot, lane);
+    pm_xch_put<NV>(xb, nwg + first, c, k, tot, lane);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  ok = pm_xch_add_slots<NV>(xb, nwg + first, nc, k, v, lane) && ok;
   return ok;
 }
 
@@ -1507,6 +1570,14 @@ __device__ inline void pm_fast_preload_tails(const StreamDesc& sd, const FastLds
 template <int D_, int U_, int LD_, int NL_, int NT_>
 struct PfShape {
   static constexpr int D = D_, U = U_, LD = LD_, NL = NL_, NT = NT_;
+  static constexpr bool TREE = false;
+};
+// ... of a launch whose moment-matching groups are split over MORE than PM_XCH_FLAT workgroups: the two-level sum
+// exchange (pm_xch_get_tree) keeps 64 registers of granules in flight, which the instances that never use it should
+// not pay for (inlined under a run-time test it cost the cart-pole instance 20 spilled registers on every path)
+template <int D_, int U_, int LD_, int NL_, int NT_>
+struct PfShapeTree : PfShape<D_, U_, LD_, NL_, NT_> {
+  static constexpr bool TREE = true;
 };
 typedef PfShape<0, 0, 0, 0, 0> PfShapeAny;
 
@@ -1712,6 +1783,10 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       }
     }
     const double dM = (double)A.M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(A.M - 1);
+    if (A.mm_ztab) {      // (worked out once for the launch by pm_mm_ztable_kernel: a large group)
+      const double* zt = A.mm_ztab + ((size_t)T0 * A.mmfac_groups + mmp_g0 / A.M) * 2 * D;
+      for (int e = tid; e < (T1 - T0) * 2 * D; e += PF_NT) mmzt[e] = zt[(size_t)(e / (2 * D)) * A.mmfac_groups * 2 * D + e % (2 * D)];
+    } else
     for (int tz = T0 + wid; tz < T1; tz += PF_NW) {
       const float* zb = pm_zbase(A.zmm, D, tz, A.Bg, A.flags);
       const int z0 = pm_zrow0(tz, A.row_off + mmp_g0, A.flags);
@@ -1965,7 +2040,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
             q.zi[j] = zt[DDc + j];
           }
         }
-        const bool xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
+        bool xok;
+        if constexpr (SH::TREE) xok = pm_xch_get_tree<2>(A.xch, A.nwg, mmp_first, A.mm_parts, A.mm_fan, me, k, v, lane);
+        else xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
         PF_MARK(31);
         G[0] = v[0];
         G[1] = v[1];
@@ -2431,7 +2508,9 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         PF_MARK(30);
         pm_xch_put<2>(A.xch, mmp_first, me, k, v, lane);
         const MMScratch q = pm_mm_carve(reinterpret_cast<double*>(set), DDc);      // (the factor is in place)
-        const bool xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
+        bool xok;
+        if constexpr (SH::TREE) xok = pm_xch_get_tree<2>(A.xch, A.nwg, mmp_first, A.mm_parts, A.mm_fan, me, k, v, lane);
+        else xok = pm_xch_get<2>(A.xch, mmp_first, A.mm_parts, me, k, v, lane);
         PF_MARK(31);
         if (!xok && lane == 0 && A.status) atomicMax(A.status, 1);
         // Lbar = tril((g^T z - mbar zm^T) diag(zi)), mbar = g^T 1

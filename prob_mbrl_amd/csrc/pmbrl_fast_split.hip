@@ -42,6 +42,12 @@ static int set_attr_split(size_t lds) {
   }
   PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))
 #undef PM_FAST_SHAPED
+  if constexpr (PR == 2 && RT == 1 && CA == 4 && CB == 3) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd_fast<1, 4, 3, PF_VAR_MM, PfShapeTree<4, 1, 240, 3, 13>, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd_fast<1, 4, 3, PF_VAR_MM, PfShapeTree<4, 1, 240, 3, 13>, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   return 0;
 }
 
@@ -97,6 +103,21 @@ static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t
       hipLaunchKernelGGL((pm_rollout_bwd_fast<RTV, CAV, CBV, VARV, PfShape<DV, UV, LDV, NLV, NTV>, PR>), g, b,    \
                          p->lds_bytes, s, A);                                                               \
     return;                                                                                                 \
+  }
+  // groups split over more than 8 workgroups (the plan chose that only where this instance exists): two-level exchange
+  if constexpr (PR == 2 && RT == 1 && CA == 4 && CB == 3) {
+    if (A.mm_mode == 1 && A.mm_parts > 8) {
+      if (var != PF_VAR_MM || A.D != 4 || A.U != 1 || A.LD != 240 || A.pol.nl != 3 || A.dyn.nl != 3 || hidden_tiles(A) != 13 ||
+          (A.flags & PMBRL_FLAG_NO_SHAPED) || !A.xch) {
+        fprintf(stderr, "pmbrl: no instance for a moment-matching group split over %d workgroups on this shape\n", A.mm_parts);
+        abort();
+      }
+      if (fwd)
+        hipLaunchKernelGGL((pm_rollout_fwd_fast<1, 4, 3, PF_VAR_MM, PfShapeTree<4, 1, 240, 3, 13>, 2>), g, b, p->lds_bytes, s, A);
+      else
+        hipLaunchKernelGGL((pm_rollout_bwd_fast<1, 4, 3, PF_VAR_MM, PfShapeTree<4, 1, 240, 3, 13>, 2>), g, b, p->lds_bytes, s, A);
+      return;
+    }
   }
   if (!(A.flags & PMBRL_FLAG_NO_SHAPED)) {
     PM_SPLIT_SHAPED_CASES((PR == 2 ? 240 : 360))

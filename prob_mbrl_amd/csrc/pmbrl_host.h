@@ -71,6 +71,8 @@ struct pmbrl_plan {
   int inplace;   // general family on split operands: 64-row workgroups with in-place layers (pm_rollout_fwd<4, 2, true>)
   int mm_wide;   // mm_mode 2 through the LDS-staged kernels for 6 < D <= 32 (pmbrl_mm_wide.h)
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
+  int mm_fan;    // ... more than 8: parts per collector of the two-level sum exchange (0: one level)
+  size_t off_ztab;   // ... and the noise standardisation of the whole group per step (pm_mm_ztable_kernel)
   int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
   size_t off_reg_pack;   // its packed weights in the workspace
   size_t off_reg_ab[2][2];   // its activity words [net][hidden layer]: [step][workgroup][wave][lane] x 32 bits (pmbrl_reg.h)

@@ -179,6 +179,39 @@ def test_groups_spanning_workgroups_match_oracle(groups):
         del os.environ['PMBRL_MM_PARTS']
 
 
+@pytest.mark.parametrize('groups', [0, 5], ids=['one 2500-row group', '500-row groups'])
+def test_large_groups_split_over_many_workgroups_match_oracle(groups):
+    """Groups beyond 8 x 32 rows on the cart-pole shape: 16-row parts whose Gram sums travel over two levels (collectors
+    of ~sqrt(parts) parts, pm_xch_get_tree) instead of the device-wide barrier form -- mm_groups=None, the reference
+    examples' default (examples/deep_pilco_mm.py:31), is 157 parts.  Against the fp64 oracle at the plain bars, and
+    against the device-wide barrier form (other summation order: rounding only)."""
+    import os
+    from oracle import ref_torch as R
+    d = _problem('cartpole_mm', 12)
+    d['mm_groups'] = np.asarray(groups)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    M = 2500 // max(groups, 1)
+    assert eng.info['mm_mode'] == 1 and eng.info['mm_parts'] == (M + 15) // 16 and eng.info['rows_per_wg'] == 16
+    assert eng.valid_steps() == int(d['H'])
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    torch.set_num_threads(8)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, True, True,
+                                            meta['mm_groups'], z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
+    os.environ['PMBRL_MM_TREE'] = '0'
+    try:
+        eng3, S3, A3, Rw3, loss3, g3, _ = _run(d)
+    finally:
+        del os.environ['PMBRL_MM_TREE']
+    assert eng3.info['mm_mode'] in (2, 3)
+    assert common.rel(S3, S) < 5e-6 and common.rel(g3, g) < 2e-5
+    # the same bits from run to run (fixed summation order at both levels)
+    eng_b, S_b, A_b, Rw_b, loss_b, g_b, _ = _run(d)
+    assert np.array_equal(S, S_b) and np.array_equal(g, g_b)
+
+
 def _spanning_forms(d, groups, split):
     import os
     from oracle import ref_torch as R
