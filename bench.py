@@ -361,7 +361,10 @@ def collect_pmc(a, prec):
         kernels[k] = dict(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w,
                           hbm_bytes_per_launch=(2.0 * (f or 0.0) + (w or 0.0)) * 1024.0 if (f is not None or w is not None) else None,
                           mfma_util_pct=mean(c.get('MfmaUtil')), flops_issued_per_launch=mops * 512.0,
-                          launches=len(c.get('FETCH_SIZE', [])))
+                          launches=len(c.get('FETCH_SIZE', [])),
+                          # (bench iterations of a pass: warm-up + timed + the timing step; the sweeps of the one-launch-per-step
+                          #  forms are many launches under one timer)
+                          launches_per_iteration=len(c.get('FETCH_SIZE', [])) / float(steps + 2 + 1))
     out = dict(build_id=build_id(), config=a.config, precision=prec, command=' '.join(inner[1:]),
                note='rocprofv3 --pmc, one pass per counter set: %s; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at '
                     '64 bytes), WRITE_SIZE as reported (KiB); means over the launches of a pass' % '; '.join(' '.join(c) for c in sets),
@@ -525,8 +528,11 @@ def main():
             traffic = pm['hbm_bytes_per_launch']
             roof.update(traffic=traffic, traffic_measured_in_run=pm['measured_in_run'], traffic_source=pm['source'] or 'this run (--pmc)',
                         traffic_build_id=pm['build_id'],
-                        hbm_gbps=(traffic / (roof['avg_launch_ms'] * 1e-3) / 1e9) if traffic else None,
-                        hbm_frac_of_8tbps=(traffic / (roof['avg_launch_ms'] * 1e-3) / 8e12) if traffic else None,
+                        launches_under_timer=max(1.0, round(pm.get('launches_per_iteration') or 1.0)),
+                        hbm_gbps=(traffic * max(1.0, round(pm.get('launches_per_iteration') or 1.0)) /
+                                  (roof['avg_launch_ms'] * 1e-3) / 1e9) if traffic else None,
+                        hbm_frac_of_8tbps=(traffic * max(1.0, round(pm.get('launches_per_iteration') or 1.0)) /
+                                           (roof['avg_launch_ms'] * 1e-3) / 8e12) if traffic else None,
                         mfma_counters=dict(mfma_util_pct=pm['mfma_util_pct'], flops_issued_per_launch=pm['flops_issued_per_launch'],
                                            measured_in_run=pm['measured_in_run']))
         else:
