@@ -372,15 +372,27 @@ struct RegW {
 };
 __host__ __device__ constexpr int pr_widx(int net, int slot, int kb, int p) { return ((net * PR_SLOTS + slot) * PR_KB + kb) * 2 + p; }
 
+// (inline-asm loads, the accumulator-file fragments STRAIGHT into AGPRs: through the compiler they went to VGPRs first and
+//  were copied over in batches of what the VGPR file had room for -- five serial memory round trips of the prologue.
+//  All 84 requests go out back to back; one wait; the empty statements behind it hang every later use on the wait.)
+template <int I>
+__device__ __forceinline__ void pr_res_load(RegW& W, unsigned voff, const float* packed_dir, int wid) {
+  typedef const PM_GLOBAL_ char* gcp;
+  constexpr int net = I / (PR_SLOTS * PR_KB * 2), r = I % (PR_SLOTS * PR_KB * 2);
+  gcp src = (gcp)(packed_dir + (size_t)net * PR_NET_FLOATS + PR_OFF_RES + ((size_t)wid * (PR_SLOTS * PR_KB * 2) + r) * PR_FRAG);
+  if constexpr (I < PR_NAG) asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(W.a[I]) : "v"(voff), "s"(src) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(W.v[I - PR_NAG]) : "v"(voff), "s"(src) : "memory");
+}
+template <int I>
+__device__ __forceinline__ void pr_res_tie(RegW& W) {
+  if constexpr (I < PR_NAG) asm volatile("" : "+a"(W.a[I]));
+  else asm volatile("" : "+v"(W.v[I - PR_NAG]));
+}
 __device__ __forceinline__ void pr_load_resident(RegW& W, const float* packed_dir, int wid, int lane) {
-  pr_for<PR_NRESF>([&](auto ic) {
-    constexpr int I = decltype(ic)::value;
-    constexpr int net = I / (PR_SLOTS * PR_KB * 2), r = I % (PR_SLOTS * PR_KB * 2);
-    const float* src = packed_dir + (size_t)net * PR_NET_FLOATS + PR_OFF_RES +
-                       ((size_t)wid * (PR_SLOTS * PR_KB * 2) + r) * PR_FRAG + lane * 4;
-    if constexpr (I < PR_NAG) W.a[I] = ldg4(src);
-    else W.v[I - PR_NAG] = ldg4(src);
-  });
+  const unsigned voff = (unsigned)lane * 16u;
+  pr_for<PR_NRESF>([&](auto ic) { pr_res_load<decltype(ic)::value>(W, voff, packed_dir, wid); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  pr_for<PR_NRESF>([&](auto ic) { pr_res_tie<decltype(ic)::value>(W); });
 }
 
 // one hidden->hidden layer of network NET on this wave's resident tiles: B fragments from the LDS activation buffer,
@@ -502,6 +514,35 @@ __device__ __forceinline__ void pr_tile_epilogue(f32x4 v, f32x4 mf, f32x4& h, un
   lo = pc[1];
 }
 
+// Copy of the LDS-resident sections of one network's pack (first layer, 13th tile, head), ALL loads requested before the
+// first store: written as three copy loops, every iteration waited for its own load -- 14 serial memory round trips a
+// network, 36 k cycles (16 us) of prologue in each sweep kernel.  L0_BLOCKS: blocks per tile the destination keeps (the
+// forward sweep keeps block 0 only of the packed [tile][2 blocks]).
+template <int L0_BLOCKS>
+__device__ __forceinline__ void pr_copy_net_to_lds(float* smem, int lds_l0, int lds_xt, int lds_head, const float* src, int tid) {
+  constexpr int N_L0 = PR_NT * L0_BLOCKS * PR_FRAG / 4, N_XT = PR_XT_FLOATS / 4, N_HD = PR_HEAD_FLOATS / 4;
+  constexpr int I_L0 = (N_L0 + PR_NTHR - 1) / PR_NTHR, I_XT = (N_XT + PR_NTHR - 1) / PR_NTHR, I_HD = (N_HD + PR_NTHR - 1) / PR_NTHR;
+  f32x4 a[I_L0], b[I_XT], c[I_HD];
+#pragma unroll
+  for (int k = 0; k < I_L0; ++k) {
+    const int i = min(tid + k * PR_NTHR, N_L0 - 1);
+    a[k] = ldg4(src + PR_OFF_L0 + (L0_BLOCKS == 1 ? (i >> 6) * (2 * PR_FRAG) + (i & 63) * 4 : i * 4));
+  }
+#pragma unroll
+  for (int k = 0; k < I_XT; ++k) b[k] = ldg4(src + PR_OFF_XT + min(tid + k * PR_NTHR, N_XT - 1) * 4);
+#pragma unroll
+  for (int k = 0; k < I_HD; ++k) c[k] = ldg4(src + PR_OFF_HEAD + min(tid + k * PR_NTHR, N_HD - 1) * 4);
+#pragma unroll
+  for (int k = 0; k < I_L0; ++k)
+    if (tid + k * PR_NTHR < N_L0) *reinterpret_cast<f32x4*>(smem + lds_l0 + (tid + k * PR_NTHR) * 4) = a[k];
+#pragma unroll
+  for (int k = 0; k < I_XT; ++k)
+    if (tid + k * PR_NTHR < N_XT) *reinterpret_cast<f32x4*>(smem + lds_xt + (tid + k * PR_NTHR) * 4) = b[k];
+#pragma unroll
+  for (int k = 0; k < I_HD; ++k)
+    if (tid + k * PR_NTHR < N_HD) *reinterpret_cast<f32x4*>(smem + lds_head + (tid + k * PR_NTHR) * 4) = c[k];
+}
+
 template <bool PROF>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -519,41 +560,14 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   const int D = A.D, U = A.U, B = A.B;
   const float* packed = A.packed;     // direction 0
 
-  // ---- prologue: resident weights -> registers, the rest -> LDS
-  RegW W;
-  pr_load_resident(W, packed, wid, lane);
-  for (int net = 0; net < 2; ++net) {
-    const float* src = packed + (size_t)net * PR_NET_FLOATS;
-    for (int i = tid; i < PR_L0_FLOATS / 4; i += PR_NTHR)      // (block 0 of every tile)
-      *reinterpret_cast<f32x4*>(smem + PR_LDS_L0(net) + i * 4) = ldg4(src + PR_OFF_L0 + (i >> 6) * (2 * PR_FRAG) + (i & 63) * 4);
-    for (int i = tid; i < PR_XT_FLOATS / 4; i += PR_NTHR)
-      *reinterpret_cast<f32x4*>(smem + PR_LDS_XT(net) + i * 4) = ldg4(src + PR_OFF_XT + i * 4);
-    for (int i = tid; i < PR_HEAD_FLOATS / 4; i += PR_NTHR)
-      *reinterpret_cast<f32x4*>(smem + PR_LDS_HEAD(net) + i * 4) = ldg4(src + PR_OFF_HEAD + i * 4);
+  // (cycle stamps of the launch as a whole in row 0: slot 30 kernel entry, 31 kernel end; 28 / 29 the same instants on the
+  //  constant 100 MHz clock -- the ratio is the shader clock the sweep actually ran at)
+  if (PROF && wg == 0 && tid == 0) {
+    A.prof[30] = (long long)__builtin_readcyclecounter();
+    A.prof[28] = (long long)__builtin_amdgcn_s_memrealtime();
   }
-  // activation buffer: zero, then the constant 1 the hidden-layer biases multiply (slot 4 of the last block, high plane)
-  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PR_LDS_ACT + i] = 0.f;
-  // dropout multipliers of this lane's values, tile by tile (rows past the batch: zero -- their activations stay 0)
-  for (int n = 0; n < 2; ++n)
-    for (int l = 0; l < 2; ++l) {
-      const RegNet& N = n == 0 ? A.pol : A.dyn;
-      const uint16_t* mrow = N.mask[l] + (size_t)(row0 + (rvalid ? row : 0)) * PR_NT;
-      for (int q = 0; q <= PR_SLOTS; ++q) {
-        if (q == PR_SLOTS && wid != pr_xwave(n)) continue;
-        const int ot = q < PR_SLOTS ? 4 * q + wid : PR_XT;
-        const unsigned nib = rvalid ? (((unsigned)mrow[ot] >> (4 * g)) & 0xFu) : 0u;
-        f32x4 mf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mf[r] = ((nib >> r) & 1u) ? N.inv_keep[l] : 0.f;
-        float* dst = q < PR_SLOTS ? smem + PR_LDS_MF + (size_t)(((wid * 2 + n) * 2 + l) * PR_SLOTS + q) * PR_FRAG
-                                  : smem + PR_LDS_MFX + (size_t)(n * 2 + l) * PR_FRAG;
-        *reinterpret_cast<f32x4*>(dst + lane * 4) = mf;
-      }
-    }
-  __syncthreads();
-  if (tid < 64) reinterpret_cast<unsigned*>(smem + PR_LDS_ACT + ((PR_KB - 1) * 2 + 0) * PR_FRAG + tid * 4)[2] = 0x3c00u;   // fp16 1.0, 0
-  if (tid == 0 && A.wflag && *A.wflag == A.wgen) atomicMin(A.status, 0);
-
+  // (first what comes from HBM in small pieces -- the lanes' constants, the mask rows: requested here, they land while the
+  //  weights stream in; asked for afterwards they were three more serial round trips of the prologue)
   // ---- per-lane constants: input slot s (0, 1) of this lane group = network input 2 g + s
   float c_mx[2], c_isx[2], c_sy[2], c_my[2], c_zp[2], c_zd[2], c_psc[2], c_pbi[2];
   float x[2];                       // state dimensions 2 g, 2 g + 1 of this lane's row
@@ -577,7 +591,6 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     ok_a[s] = isa && rvalid;
     so_x[s] = ((unsigned)(row0 + row) * D + id) * 4u;
     so_a[s] = ((unsigned)(row0 + row) * U + ja) * 4u;
-    if (ok_x[s] && wid == 0) A.states[(size_t)(row0 + row) * D + id] = x[s];
   }
   f32x4 hbp, hbd;                   // head biases in accumulator-register order
 #pragma unroll
@@ -586,6 +599,50 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     hbp[r] = rp >= 0 ? (A.pol_params + A.pol.b_off[2])[rp] : 0.f;
     hbd[r] = rd >= 0 ? (A.dyn_params + A.dyn.b_off[2])[rd] : 0.f;
   }
+  unsigned mbits[2][2][PR_SLOTS + 1];      // (all sixteen requested before the first is used)
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const uint16_t* mrow = (n == 0 ? A.pol : A.dyn).mask[l] + (size_t)(row0 + (rvalid ? row : 0)) * PR_NT;
+#pragma unroll
+      for (int q = 0; q <= PR_SLOTS; ++q) mbits[n][l][q] = (unsigned)mrow[q < PR_SLOTS ? 4 * q + wid : PR_XT];
+    }
+  // ---- prologue: resident weights -> registers, the rest -> LDS
+  RegW W;
+  pr_load_resident(W, packed, wid, lane);
+  if (PROF && wg == 0 && tid == 0) A.prof[27] = (long long)__builtin_readcyclecounter();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)      // x_0 into the trajectory
+    if (ok_x[s] && wid == 0) *(gf32*)((gch*)A.states + so_x[s]) = x[s];
+  pr_copy_net_to_lds<1>(smem, PR_LDS_L0(0), PR_LDS_XT(0), PR_LDS_HEAD(0), packed, tid);
+  pr_copy_net_to_lds<1>(smem, PR_LDS_L0(1), PR_LDS_XT(1), PR_LDS_HEAD(1), packed + PR_NET_FLOATS, tid);
+  if (PROF && wg == 0 && tid == 0) A.prof[26] = (long long)__builtin_readcyclecounter();
+  // activation buffer: zero, then the constant 1 the hidden-layer biases multiply (slot 4 of the last block, high plane)
+  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PR_LDS_ACT + i] = 0.f;
+  // dropout multipliers of this lane's values, tile by tile (rows past the batch: zero -- their activations stay 0)
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const RegNet& N = n == 0 ? A.pol : A.dyn;
+#pragma unroll
+      for (int q = 0; q <= PR_SLOTS; ++q) {
+        if (q == PR_SLOTS && wid != pr_xwave(n)) continue;
+        const unsigned nib = rvalid ? ((mbits[n][l][q] >> (4 * g)) & 0xFu) : 0u;
+        f32x4 mf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mf[r] = ((nib >> r) & 1u) ? N.inv_keep[l] : 0.f;
+        float* dst = q < PR_SLOTS ? smem + PR_LDS_MF + (size_t)(((wid * 2 + n) * 2 + l) * PR_SLOTS + q) * PR_FRAG
+                                  : smem + PR_LDS_MFX + (size_t)(n * 2 + l) * PR_FRAG;
+        *reinterpret_cast<f32x4*>(dst + lane * 4) = mf;
+      }
+    }
+  __syncthreads();
+  if (tid < 64) reinterpret_cast<unsigned*>(smem + PR_LDS_ACT + ((PR_KB - 1) * 2 + 0) * PR_FRAG + tid * 4)[2] = 0x3c00u;   // fp16 1.0, 0
+  if (tid == 0 && A.wflag && *A.wflag == A.wgen) atomicMin(A.status, 0);
+  if (PROF && wg == 0 && tid == 0) A.prof[25] = (long long)__builtin_readcyclecounter();
+
   // which input slots hold an action / a state dimension in ANY lane group (wave-uniform: the squash of a slot that
   // is an action nowhere is skipped)
   bool any_a[2], any_x[2];
@@ -817,6 +874,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     b_states += x_step; b_actions += a_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
   }
+  if (PROF && wg == 0 && tid == 0) {
+    A.prof[31] = (long long)__builtin_readcyclecounter();
+    A.prof[29] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // activity words -> the per-tile nibble bytes [step][row][tile][lane group] of pmbrl_fast.h
@@ -886,30 +947,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     return;
   }
 
-  // ---- prologue
-  RegW W;
-  pr_load_resident(W, packed, wid, lane);
-  for (int net = 0; net < 2; ++net) {
-    const float* src = packed + (size_t)net * PR_NET_FLOATS;
-    for (int i = tid; i < PR_L0P_FLOATS / 4; i += PR_NTHR)
-      *reinterpret_cast<f32x4*>(smem + PRB_LDS_L0(net) + i * 4) = ldg4(src + PR_OFF_L0 + i * 4);
-    for (int i = tid; i < PR_XT_FLOATS / 4; i += PR_NTHR)
-      *reinterpret_cast<f32x4*>(smem + PRB_LDS_XT(net) + i * 4) = ldg4(src + PR_OFF_XT + i * 4);
-    for (int i = tid; i < PR_HEAD_FLOATS / 4; i += PR_NTHR)
-      *reinterpret_cast<f32x4*>(smem + PRB_LDS_HEAD(net) + i * 4) = ldg4(src + PR_OFF_HEAD + i * 4);
+  if (PROF && wg == 0 && tid == 0) {
+    A.prof[30] = (long long)__builtin_readcyclecounter();
+    A.prof[28] = (long long)__builtin_amdgcn_s_memrealtime();
   }
-  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PRB_LDS_ACT + i] = 0.f;
-  if (tid < 64) {
-    // nibble -> {0, 1 / keep} x 4
-    const int n = tid >> 5, l = (tid >> 4) & 1, nib = tid & 15;
-    const float ik = (n == 0 ? A.pol : A.dyn).inv_keep[l];
-    f32x4 m;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) m[r] = ((nib >> r) & 1) ? ik : 0.f;
-    *reinterpret_cast<f32x4*>(smem + PRB_LDS_LUT + tid * 4) = m;
-  }
-  __syncthreads();
-
+  // (requested before the weights: they land while those stream in)
   // ---- per-lane constants: input slot s (0, 1) of this lane group = network input 2 g + s
   float c_isx[2], c_sy[2], c_psc[2], c_pbi[2];
   bool ok_x[2], ok_a[2];
@@ -930,6 +972,23 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     so_a[s] = ((unsigned)(row0 + row) * U + ja) * 4u;
     if (A.gx_in && ok_x[s]) gx[s] = *(const gf32*)((const PM_GLOBAL_ char*)A.gx_in + so_x[s]);
   }
+  // ---- prologue
+  RegW W;
+  pr_load_resident(W, packed, wid, lane);
+  pr_copy_net_to_lds<2>(smem, PRB_LDS_L0(0), PRB_LDS_XT(0), PRB_LDS_HEAD(0), packed, tid);
+  pr_copy_net_to_lds<2>(smem, PRB_LDS_L0(1), PRB_LDS_XT(1), PRB_LDS_HEAD(1), packed + PR_NET_FLOATS, tid);
+  for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PRB_LDS_ACT + i] = 0.f;
+  if (tid < 64) {
+    // nibble -> {0, 1 / keep} x 4
+    const int n = tid >> 5, l = (tid >> 4) & 1, nib = tid & 15;
+    const float ik = (n == 0 ? A.pol : A.dyn).inv_keep[l];
+    f32x4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = ((nib >> r) & 1) ? ik : 0.f;
+    *reinterpret_cast<f32x4*>(smem + PRB_LDS_LUT + tid * 4) = m;
+  }
+  __syncthreads();
+
   const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
   float* const act_w = smem + PRB_LDS_ACT + lane * 4;
   const float* const lut = smem + PRB_LDS_LUT;
@@ -1239,6 +1298,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
 #pragma unroll
     for (int k = 0; k < 4; ++k) abc[k] = abn[k];
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
+  }
+  if (PROF && wg == 0 && tid == 0) {
+    A.prof[31] = (long long)__builtin_readcyclecounter();
+    A.prof[29] = (long long)__builtin_amdgcn_s_memrealtime();
   }
   if (wid == 0) {
 #pragma unroll

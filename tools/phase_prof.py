@@ -51,6 +51,14 @@ def main():
                 tot += dl
                 print('   %2d -> %2d : %8.0f cycles' % (prev, s, dl))
             prev = s
+        if a[0, 30] and a[0, 31]:      # whole-launch stamps (register-resident family)
+            first = a[0, 0] if name == 'fwd' else a[H - 1, 0]
+            last = a[H - 1, 5] if name == 'fwd' else a[0, 5]
+            cyc, rt = a[0, 31] - a[0, 30], (a[0, 29] - a[0, 28]) / 100.0      # cycles, microseconds
+            print('   launch (workgroup 0): %d cycles = %.1f us -> %.2f GHz; prologue %d cycles, epilogue %d' %
+                  (cyc, rt, cyc / rt / 1e3 if rt else 0.0, first - a[0, 30], a[0, 31] - last))
+            if a[0, 27]:
+                print('   prologue stamps (cycles from entry):', [int(a[0, k] - a[0, 30]) for k in (27, 26, 25) if a[0, k]])
         print('   step total (marked span): %.0f cycles; step period: %.0f' %
               (tot, np.median(np.abs(np.diff(a[:, order[0]])))))
 
