@@ -189,7 +189,8 @@ enum {
   PMBRL_INFO_MM_PARTS = 15,  /* workgroups a moment-matching group is split over (in-kernel moment matching; 1: whole groups) */
   PMBRL_INFO_REG = 16,       /* 1: the plain whole-horizon sweeps of this plan run on the register-resident family (pmbrl_reg.h) */
   PMBRL_INFO_REPLAY = 17,    /* 1: repeated calls of this plan are replayed as hipGraphs (pmbrl_plan_set_replay) */
-  PMBRL_INFO_COUNT = 18
+  PMBRL_INFO_INPLACE = 18,   /* general family: 0 two activation buffers, 1 in-place layers (64-row workgroups), 2 the same on the 512-wide layers of pmbrl_wide.h */
+  PMBRL_INFO_COUNT = 19
 };
 
 const char* pmbrl_last_error(void);

@@ -896,9 +896,22 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // no angle features.
     if (gsplit && !angles && !gmm && maxnt <= 32 && 2 * c.D <= PM_IP_NOFF && 2 * c.U <= PM_IP_NOFF &&
         c.D + c.U <= PM_IP_NOFF && RT < 4) {
-      const bool want = c.rows_per_wg_hint >= 64;
+      // every hidden layer 512 wide: the in-place layers of pmbrl_wide.h (compile-time shape, lean epilogue) -- taken by
+      // default as soon as 64-row workgroups still give every CU one (PMBRL_WIDE=0: the generic in-place form on
+      // request only, as before)
+      bool wide = true;
+      for (int i = 1; i < p->pol.nl; ++i) wide = wide && p->pol.nt[i] == 32;
+      for (int i = 1; i < p->dyn.nl; ++i) wide = wide && p->dyn.nt[i] == 32;
+      if (const char* e = getenv("PMBRL_WIDE")) wide = wide && atoi(e) != 0;
+      int cus = 0;
+      if (wide && c.rows_per_wg_hint == 0) {
+        hipDeviceProp_t pr;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+      }
+      const bool want = c.rows_per_wg_hint >= 64 || (wide && c.rows_per_wg_hint == 0 && cus > 0 && (c.B + 63) / 64 >= cus);
       if (want) {
-        p->inplace = 1;
+        p->inplace = wide ? 2 : 1;
         if (lds_need(4, 0) <= lds_cap) RT = 4;
         else p->inplace = 0;
       }
@@ -1467,6 +1480,7 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[PMBRL_INFO_MM_PARTS] = p->mm_parts;
   info[PMBRL_INFO_REG] = p->reg;
   info[PMBRL_INFO_REPLAY] = replay_wanted(p) ? 1 : 0;
+  info[PMBRL_INFO_INPLACE] = p->inplace;
   return 0;
 }
 

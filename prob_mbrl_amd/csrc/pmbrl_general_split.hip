@@ -13,10 +13,17 @@ static int set_attr_gs(size_t lds) {
   return 0;
 }
 int pm_general_split_set_attr(const pmbrl_plan* p) {
-  if (p->inplace) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<4, 2, true>),
+  if (p->inplace == 2) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<4, 2, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, true>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    return 0;
+  }
+  if (p->inplace) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<4, 2, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, 1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     return 0;
   }
@@ -32,9 +39,14 @@ static void launch_gs(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, 
   else hipLaunchKernelGGL((pm_rollout_bwd<RT, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 void pm_general_split_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  if (p->inplace == 2) {
+    if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    return;
+  }
   if (p->inplace) {
-    if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, true>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
-    else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, true>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, 1>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, 1>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
     return;
   }
   switch (p->RT) {

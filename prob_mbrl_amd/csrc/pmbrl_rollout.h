@@ -8,6 +8,7 @@
 #include "pmbrl_dev.h"
 #include "pmbrl_mm.h"
 #include "pmbrl_gsplit.h"
+#include "pmbrl_wide.h"
 
 // ---------------------------------------------------------------------------
 // epilogues
@@ -228,7 +229,7 @@ __device__ __forceinline__ int pm_zrow0(int t, int row, int flags) {
 }
 
 struct LdsMap {
-  float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr, *part;
+  float *bufA, *bufB, *xa, *xb, *av, *gad, *rr, *gr, *part, *tbl;
   double* mm;
 };
 // ip: in-place layers (gemm_layer_inplace_s) -- ONE activation buffer, narrow GEMM outputs at column PM_IP_NOFF of it
@@ -240,6 +241,7 @@ __host__ __device__ inline size_t pm_lds_floats(int R, int LD, int D, int U, int
   n += (size_t)R * 16;                    // gad (action gradient, U <= 16)
   n += 2 * (size_t)R;                     // rr, gr
   if (!ip && !pm_part_alias_ok(R, LD, RT)) n += (size_t)PM_NW * PM_KS_NT * RT * 256;  // K-split partials (else: in the output buffer)
+  if (ip) n += 64;                        // nibble -> multipliers (pmbrl_wide.h)
   n = (n + 3) & ~(size_t)3;
   n += 2 * (size_t)PM_NW * pm_mm_scratch_doubles(mm_d);  // per-wave fp64 scratch
   return n;
@@ -256,6 +258,8 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
   m.gr = m.rr + R;
   m.part = m.gr + R;
   size_t n = (size_t)(m.part - base);
+  m.tbl = m.part;
+  if (ip) n += 64;
   if (ip || pm_part_alias_ok(R, LD, RT)) m.part = nullptr;
   else n += (size_t)PM_NW * PM_KS_NT * RT * 256;
   n = (n + 3) & ~(size_t)3;
@@ -267,8 +271,9 @@ __device__ inline LdsMap pm_lds_carve(float* base, int R, int LD, int D, int U, 
 // forward
 // ===========================================================================
 // PR = 0: exact fp32 MFMA; PR = 2: split operands (pmbrl_gsplit.h) -- two fp16 pieces
-// IP: in-place layers (PR = 2 only; widths <= 512, narrow widths <= PM_IP_NOFF, no mixture head)
-template <int RT, int PR = 0, bool IP = false>
+// IP: in-place layers (PR = 2 only; widths <= 512, narrow widths <= PM_IP_NOFF, no mixture head); IP = 2: every hidden
+// layer is 512 wide and runs on pmbrl_wide.h
+template <int RT, int PR = 0, int IP = 0>
 __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -280,12 +285,13 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   const int row0 = wg * A.rows_per_wg;
   const int nvalid = min(A.rows_per_wg, A.B - row0);
   const int D = A.D, U = A.U, LD = A.LD, B = A.B;
-  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP);
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP != 0);
   float* xa = L.xa;   // current state x_t
   float* xb = L.xb;   // pre-moment-matching next state
   // PR = 2: set when an activation leaves fp16's range (the action-gradient rows are idle in the forward sweep)
   int* const p_ovf = reinterpret_cast<int*>(L.gad);
   if (SP && tid == 0) *p_ovf = (A.wflag && *A.wflag == A.wgen) ? 1 : 0;   // (1: a weight did not fit fp16, pm_pack_all)
+  if constexpr (IP == 2) pw_table_init(L.tbl, tid);
 
   // initial state (states[t0] is x0 for t0 == 0, the previous launch's output otherwise)
   {
@@ -306,6 +312,12 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   const FeatMap* dmap = A.ang ? &A.ang->dyn : nullptr;
 
   for (int t = A.t0; t < A.t1; ++t) {
+    // (IP = 2: nothing derived from the thread index is carried across steps -- hoisted out of the step loop, the
+    //  address arithmetic of the elementwise phases alone kept some sixty registers live through the layers, and what
+    //  the layers then spilled came back through scratch loads behind vmcnt(0): a memory round trip each)
+    int tid_s = tid;
+    if constexpr (IP == 2) asm volatile("" : "+v"(tid_s));
+    const int tid = tid_s, lane = tid & 63;
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
@@ -342,10 +354,16 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], IP ? X : Y,
                                         A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane,
                                         p_ovf};
-      if constexpr (IP) gemm_layer_inplace_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) {
+        const PwFwd w{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], X,
+                      A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, L.tbl, row0, nvalid, p_ovf,
+                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 5 : nullptr};
+        pw_hidden_fwd<true>(P.wf[l], pm_kb32(P.nt[l]), w, wid, lane);
+      } else if constexpr (IP) gemm_layer_inplace_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
-      __syncthreads();
+      if constexpr (IP == 2) pw_lds_barrier();
+      else __syncthreads();
       PM_MARK(2 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
@@ -354,7 +372,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       // fp32 rows at column PM_IP_NOFF of the one buffer: clear of the 64 plane columns the next phase writes
       Y = X + PM_IP_NOFF;
       EpiPlain e{P.bias[P.nl - 1], Y, LD, lane};
-      gemm_layer_inplace_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
+      else gemm_layer_inplace_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
       gemm_narrow_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), P.bias[P.nl - 1], X, LDB, Y, LD,
@@ -364,7 +383,45 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
                       wid, lane, tid);
     PM_MARK(10);
     // ---- squash + dynamics input (models/densities.py:87-121, models/core.py:243,169-177)
-    {
+    if constexpr (IP == 2) {
+      // (the loop below walks (row, column) pairs: eight iterations at 64 x 64, each with its own dependent loads of
+      //  the normalisation constants and, in the action columns, of the noise -- 29 k cycles of a step.  Here every
+      //  action element is ONE thread with all its loads up front, and a thread of the copy part keeps its column)
+      const int K16 = pm_kb32(F.nt[0]) * 32;
+      for (int i = tid; i < R * U; i += PM_NT) {
+        const int r = i / U, j = i - r * U, k = D + j;
+        const bool valid = r < nvalid;
+        const float z = valid ? A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j] : 0.f;
+        const float sc = A.pscale[j], pb = A.pbias[j], mxk = A.mx[k], isk = A.iSx[k];
+        const float mu = Y[r * LD + j];
+        const float ls = Y[r * LD + U + j];
+        const float lc = -softplusf(-ls + A.mls_pol) + A.mls_pol;
+        const float e = expf(lc);
+        const float u = mu + z * e;
+        const float a = sc * tanhf(u) + pb;
+        L.av[r * U + j] = a;
+        if (valid) {
+          const size_t o = ((size_t)t * B + row0 + r) * U + j;
+          A.actions[o] = a;
+          A.Tp[o] = z * e * sigmoidf(-ls + A.mls_pol);
+        }
+        const float v = (a - mxk) * isk;
+        if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
+        pm_put_planes<R, true>(X, LDB, r, k, v);
+      }
+      {
+        const int k = tid % K16, rstep = PM_NT / K16;
+        const bool state = k < D, pad = k >= D + U;
+        const float mxk = state ? A.mx[k] : 0.f, isk = state ? A.iSx[k] : 0.f;
+        if (state || pad) {
+          for (int r = tid / K16; r < R; r += rstep) {
+            const float v = state ? (xa[r * D + k] - mxk) * isk : 0.f;
+            if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
+            pm_put_planes<R, true>(X, LDB, r, k, v);
+          }
+        }
+      }
+    } else {
       const int K16 = SP ? pm_kb32(F.nt[0]) * 32 : F.nt[0] * 16;
       for (int i = tid; i < R * K16; i += PM_NT) {
         const int r = i / K16, k = i - r * K16;
@@ -412,10 +469,15 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       const uint16_t* mk = F.mask[l] + ((A.flags & PMBRL_FLAG_DYN_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
       EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], IP ? X : Y,
                                         nullptr, LD, A.Rw, row0, nvalid, nt, lane, p_ovf};
-      if constexpr (IP) gemm_layer_inplace_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) {
+        const PwFwd w{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], X, nullptr, L.tbl, row0, nvalid, p_ovf,
+                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 15 : nullptr};
+        pw_hidden_fwd<false>(F.wf[l], pm_kb32(F.nt[l]), w, wid, lane);
+      } else if constexpr (IP) gemm_layer_inplace_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
-      __syncthreads();
+      if constexpr (IP == 2) pw_lds_barrier();
+      else __syncthreads();
       PM_MARK(12 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
@@ -423,7 +485,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{F.bias[F.nl - 1], Y, LD, lane};
-      gemm_layer_inplace_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
+      else gemm_layer_inplace_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
       gemm_narrow_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), F.bias[F.nl - 1], X, LDB, Y, LD,
@@ -496,6 +559,27 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           }
           cp[(size_t)n * D] = ct * sigmoidf(lt) / (temp * temp);   // d/d log-temperature
           if (d == 0) A.gmm_k[row] = kc;
+        }
+      }
+    } else if (IP == 2 && PM_NT % D == 0) {
+      // (a thread keeps its state dimension: the constants once, the rows' noise requested together)
+      const int d = tid % D, rstep = PM_NT / D;
+      const float Sy = A.Sy[d], lSy = logf(Sy), myd = A.my[d];
+#pragma unroll 4
+      for (int r = tid / D; r < R; r += rstep) {
+        const int i = r * D + d;
+        const float mu = Y[r * LD + d];
+        const float ls = Y[r * LD + D + d];
+        const float z = (r < nvalid) ? A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d] : 0.f;
+        const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + lSy;
+        const float e = expf(lc);
+        const float xn = xa[i] + (mu * Sy + myd + z * e);
+        xb[i] = xn;
+        if (r < nvalid) {
+          const size_t o = ((size_t)t * B + row0 + r) * D + d;
+          A.Td[o] = z * e * sigmoidf(-ls + A.mls_dyn);
+          if (A.flags & PMBRL_FLAG_MM_STATES) A.xt[o] = xn;
+          else A.states[o + (size_t)B * D] = xn;
         }
       }
     } else
@@ -587,7 +671,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
 // dW GEMM; policy dW/db are NOT accumulated here.
 // ===========================================================================
 // (PR = 2: two bf16 pieces -- the adjoint is linear in the incoming gradient, profiles/r02_split_precision_study.txt)
-template <int RT, int PR = 0, bool IP = false>
+template <int RT, int PR = 0, int IP = 0>
 __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16 * RT;
@@ -599,7 +683,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
   const int row0 = wg * A.rows_per_wg;
   const int nvalid = min(A.rows_per_wg, A.B - row0);
   const int D = A.D, U = A.U, LD = A.LD, B = A.B;
-  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP);
+  LdsMap L = pm_lds_carve(smem, R, LD, D, U, RT, IP != 0);
   float* gx = L.xa;    // dL/dx_{t+1} on entry of a step, dL/dx_t on exit
   float* gxt = L.xb;   // dL/dx~ (pre-mm next state)
   const NetDev& P = A.pol;
@@ -611,6 +695,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
   // truncated horizon (utils/rollout.py:154-157): only the steps the forward sweep completed
   const int T1 = A.nvalid ? min(A.t1, *A.nvalid) : A.t1;
 
+  if constexpr (IP == 2) pw_table_init(L.tbl, tid);
   // dL/dx_T1: zero, the carried value from the previous launch, or the terminal grad_states
   for (int i = tid; i < R * D; i += PM_NT) {
     const int r = i / D, d = i - r * D;
@@ -624,10 +709,48 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
   __syncthreads();
 
   for (int t = T1 - 1; t >= A.t0; --t) {
+    int tid_s = tid;
+    if constexpr (IP == 2) asm volatile("" : "+v"(tid_s));   // (see the forward sweep)
+    const int tid = tid_s, lane = tid & 63;
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
+    if constexpr (IP == 2) {
+      // The general family's in-place sweeps take their rewards' Jacobians from pm_reward_all_kernel and never do the
+      // moment matching in the kernel (mm_mode 0 / 2), no mixture head: the four phases below (row loads, copy, reward
+      // adjoint, head-adjoint input: 40 k cycles of dependent loads, a barrier each) are ONE pass --
+      //   dL/dx~ = dL/dx_{t+1} + dL/dr J_x;  X = [dL/dx~ Sy | dL/dx~ Td | 0];  direct action gradient dL/dr J_a
+      // every element's loads independent of every other's, so that an unrolled loop has them all in flight.
+      const int K16 = pm_kb32(F.nt[F.nl]) * 32;
+#pragma unroll 4
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, d = i - r * D;
+        const bool v = r < nvalid;
+        const size_t row = (size_t)t * B + row0 + (v ? r : 0);
+        const float gr = v ? A.grad_rewards[row] : 0.f;
+        const float jx = v ? A.Jx[row * D + d] : 0.f;
+        const float td = v ? A.Td[row * D + d] : 0.f;
+        const float g = gx[i] + gr * jx;
+        gxt[i] = g;
+        pm_put_planes<R, false>(X, LDB, r, d, v ? g * A.Sy[d] : 0.f);
+        pm_put_planes<R, false>(X, LDB, r, D + d, g * td);
+      }
+      for (int i = tid; i < R * U; i += PM_NT) {
+        const int r = i / U, j = i - r * U;
+        const bool v = r < nvalid;
+        const size_t row = (size_t)t * B + row0 + (v ? r : 0);
+        const float gr = v ? A.grad_rewards[row] : 0.f;
+        L.gad[r * 16 + j] = v ? gr * A.Ja[row * U + j] : 0.f;
+        L.av[i] = v ? A.actions[row * U + j] : 0.f;
+      }
+      for (int i = tid; i < R * (K16 - 2 * D); i += PM_NT) {
+        const int r = i / (K16 - 2 * D), k = i - r * (K16 - 2 * D);
+        pm_put_planes<R, false>(X, LDB, r, 2 * D + k, 0.f);
+      }
+      __syncthreads();
+      PM_MARK(3);
+    } else {
     // ---- load x~ rows (for reward / mm recompute) into Y scratch columns, actions, upstream gr
     //      Y[r][0..D) = x~ ; L.av = a ; L.gr = dL/dr ; L.rr = r~
     {
@@ -733,15 +856,21 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     }
     __syncthreads();
     PM_MARK(3);
+    }
     // ---- dynamics trunk, dX only (weights frozen: no dV)
     for (int l = F.nl - 1; l >= 1; --l) {
       const int nt = F.nt[l];
       EpiHiddenBwdT<SP ? 2 : 0, R> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], IP ? X : Y, nullptr, LD, A.Rw,
                                     row0, nvalid, nt, lane};
-      if constexpr (IP) gemm_layer_inplace_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) {
+        const PwBwd w{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], X, nullptr, L.tbl, row0, nvalid,
+                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 8 : nullptr};
+        pw_hidden_bwd<false>(F.wb[l], pm_kb32(F.nt[l + 1]), w, wid, lane);
+      } else if constexpr (IP) gemm_layer_inplace_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
-      __syncthreads();
+      if constexpr (IP == 2) pw_lds_barrier();
+      else __syncthreads();
       PM_MARK(4 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
@@ -749,7 +878,8 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      gemm_layer_inplace_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
+      else gemm_layer_inplace_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
       gemm_narrow_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);
@@ -757,7 +887,42 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
     PM_MARK(12);
     // ---- phase B: split into state / action parts; policy head adjoint -> X
-    {
+    if constexpr (IP == 2) {
+      // (as above: the state part, the action part and the padding as separate loops with independent elements)
+      const int K16 = P.nt[P.nl] * 16;
+      const int KP = pm_kb32(P.nt[P.nl]) * 32;
+      float* gst = A.gT[P.nl - 1] + blk * (size_t)K16 * A.Rw;
+#pragma unroll 4
+      for (int i = tid; i < R * D; i += PM_NT) {
+        const int r = i / D, k = i - r * D;
+        gxt[i] += Y[r * LD + k] * A.iSx[k];
+      }
+      for (int i = tid; i < R * U; i += PM_NT) {
+        const int r = i / U, j = i - r * U;
+        float go_mu = 0.f, go_ls = 0.f;
+        if (r < nvalid) {
+          const size_t o = ((size_t)t * B + row0 + r) * U + j;
+          const float tp = A.Tp[o];
+          const float sc = A.pscale[j], pb = A.pbias[j];
+          float ga = L.gad[r * 16 + j] + Y[r * LD + D + j] * A.iSx[D + j];
+          if (A.grad_actions) ga += A.grad_actions[o];
+          L.gad[r * 16 + j] = ga;   // total dL/da_t (for the priority hook below)
+          const float th = (L.av[r * U + j] - pb) / sc;
+          const float gu = ga * sc * (1.f - th * th);
+          go_mu = gu;
+          go_ls = gu * tp;
+        }
+        pm_put_planes<R, false>(X, LDB, r, j, go_mu);
+        pm_put_planes<R, false>(X, LDB, r, U + j, go_ls);
+        gst[(size_t)j * A.Rw + r] = go_mu;
+        gst[(size_t)(U + j) * A.Rw + r] = go_ls;
+      }
+      for (int i = tid; i < R * (KP - 2 * U); i += PM_NT) {
+        const int r = i / (KP - 2 * U), k = 2 * U + i - r * (KP - 2 * U);
+        pm_put_planes<R, false>(X, LDB, r, k, 0.f);
+        if (k < K16) gst[(size_t)k * A.Rw + r] = 0.f;
+      }
+    } else {
       const int K16 = P.nt[P.nl] * 16;
       const int KP = SP ? pm_kb32(P.nt[P.nl]) * 32 : K16;   // split: the head-gradient tile is whole K32 blocks wide
       float* gst = A.gT[P.nl - 1] + blk * (size_t)K16 * A.Rw;
@@ -826,17 +991,24 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       const int nt = P.nt[l];
       EpiHiddenBwdT<SP ? 2 : 0, R> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], IP ? X : Y,
                                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      if constexpr (IP) gemm_layer_inplace_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) {
+        const PwBwd w{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], X,
+                      A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, L.tbl, row0, nvalid,
+                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 18 : nullptr};
+        pw_hidden_bwd<true>(P.wb[l], pm_kb32(P.nt[l + 1]), w, wid, lane);
+      } else if constexpr (IP) gemm_layer_inplace_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
-      __syncthreads();
+      if constexpr (IP == 2) pw_lds_barrier();
+      else __syncthreads();
       PM_MARK(14 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
     }
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      gemm_layer_inplace_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
+      else gemm_layer_inplace_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
       gemm_narrow_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), nullptr, X, LDB, Y, LD, L.part, wid, lane, tid);

@@ -1,0 +1,365 @@
+// WIDE hidden layers of the general family: 512-wide layers on 64-row workgroups, in place (pm_rollout_fwd / _bwd
+// <4, 2, 2>; round 4).
+//
+// Where the 3 x 512 stress shape (C5) stood (profiles/r03b_inplace_*, r04h_phase_prof_stress32.txt): at 32 rows per
+// workgroup a 512 x 512 layer streams 1 MB of weight pieces L2 -> CU for 12.3 k cycles of MFMAs -- 35 k cycles per
+// layer-step, 512 workgroups in two rounds.  64 rows per workgroup (one workgroup per CU, ONE round) halve the bytes
+// per row; round 3's in-place form (gemm_layer_inplace_s: ONE activation buffer of 64 x 512 two-piece values = 135
+// KB, a barrier between the last operand read and the first output write) lost that again in its epilogue: generic
+// code, 150 instructions per 16 x 16 output tile, 150 spilled registers whose reloads sit behind vmcnt(0) (a memory
+// round trip each) -- 33 k cycles for the 16 tiles of a wave with nothing to overlap them.
+//
+// This file is that layer with a compile-time shape (32 output tiles; wave w owns tiles 4 w .. 4 w + 3 for all four
+// row tiles) and an epilogue written for its instruction count (45 per tile):
+//   * dropout / activity bits reach a lane as ONE 8-byte word per row (its four tiles are adjacent) through a buffer
+//     load with range checking (absent rows read 0: no branches), requested before the K loop, and become multipliers
+//     through a 16-entry LDS table (nibble -> four 0/1 floats: one v_bfe, one ds_read_b128);
+//   * the wave's 64 bias values live in ONE register per lane and are fetched by DPP row_share;
+//   * h = max(acc + b, 0) * (m / keep): the other forms' bits;
+//   * fp16 pieces: v_cvt_pk_f16_f32 for the high pair, v_fma_mix_f32 (reads the fp16 half directly) for the residuals;
+//   * activity bits from the bit pattern of h (h >= +0: min(bits, 1)), one 16-bit field per tile, OR-ed over the four
+//     16-lane groups once per layer with v_permlane32_swap / v_permlane16_swap (VALU, no LDS), one 8-byte store per lane;
+//   * every stash store is buffer_store_dword v, v_lane, s[desc], s_tile offset:r*Rw*4 -- no address arithmetic;
+//   * the fp16 range guard is a running integer max, tested once per layer;
+//   * ALL of that runs in front of the barrier (results parked as packed pieces in the accumulators' registers);
+//     behind it only the 32 ds_write_b64.
+// K loop: a ring of three one-block chunks per wave with inline-asm loads and explicit waits, no load past the last
+// block.  Nothing derived from the thread index is carried across steps (pmbrl_rollout.h launders it per step): the
+// address arithmetic the compiler hoisted out of the step loop was what the layers spilled around.
+//
+// Measured at C5 (profiles/r04i_*): a hidden layer-step of 64 rows 86 k -> 46 k cycles (forward, with the stash) and
+// 66 k -> 43 k (adjoint); forward sweep 19.3 -> 12.6 ms, adjoint 18.2 -> 10.5 ms, MfmaUtil 24 % -> 37 %.  What binds
+// a layer now, from per-wave stamps and elimination builds (profiles/r04i_notes.txt): the older wave of each SIMD
+// leaves the K loop after 24 k cycles, the younger after 36 k, for 24.6 k cycles of MFMAs per SIMD; with the weight
+// loads compiled out 20 k / 32 k, with the MFMAs compiled out 21 k / 27 k -- the instruction stream beside the MFMAs
+// (per block and wave 8 ds_read_b128, 16 v_pk_mul_f16 for the scaled operand, 8 loads and their addresses, the wait
+// selection: ~50 issue slots for 48 MFMAs) and the fetch each cost about a third on top and overlap imperfectly.
+// Not kept (measured, no change): B operands read a half ahead across block boundaries; K order rotated per wave or
+// per workgroup (no L2-channel hot spot); stash stores as sc0 sc1; the bias staged through LDS.
+// Same LDS buffer, same stashes, same activity-bit layout as the other forms of the family: the sweeps of the three
+// forms are interchangeable (tests/test_gpu_wide.py).
+#pragma once
+#include "pmbrl_gsplit.h"
+
+#ifndef PW_STASH_AUX
+#define PW_STASH_AUX 2   // nt
+#endif
+#define PW_RW 64      // rows per workgroup (= the stashes' row pitch)
+#define PW_STAMP(i) do { if (e.prof && lane == 0 && wid == 0) e.prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define PW_LDB 528u   // elements per row of a piece plane (512 + 16: conflict-free ds_read_b128)
+
+typedef __amdgpu_buffer_rsrc_t pw_rsrc;
+__device__ __forceinline__ pw_rsrc pw_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int pw_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// nibble -> four multipliers; 64 floats of LDS, written once per launch
+__device__ __forceinline__ void pw_table_init(float* tbl, int tid) {
+  if (tid < 64) tbl[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 1.f : 0.f;
+}
+
+// acc[k][rt] = sum over K of W[tile 4 wid + k] x X[row tile rt]; weights [tile][K32 block][piece][lane][4 floats].
+// A ring of THREE one-block chunks (4 tiles x 2 pieces = 8 KB per wave each): two in flight while one feeds the
+// MFMAs -- with one in flight (round 3's in-place loop) a block took a memory round trip (2.1 k cycles against the
+// 1.5 k its 96 MFMAs keep a SIMD's two waves busy: 34 k cycles per 512 x 512 layer, profiles/r04i_*).
+template <bool F16>
+__device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb, const float* buf, int wid, int lane,
+                                         f32x4 (&acc)[4][4]) {
+  typedef PmPairs<2> PP;
+  constexpr unsigned ldb = PW_LDB;
+  const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
+  // the wave's four tile bases as scalars: every load is  global_load_dwordx4 v, v_offset, s[base]  -- one 32-bit
+  // lane offset per chunk, no 64-bit address arithmetic per load
+  const char* tb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long a = (unsigned long long)(wf + ((size_t)(4 * wid + k) * n_kb) * 512);
+    tb[k] = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  GsFrag<4> f0, f1, f2;
+  constexpr int NLD = 8;   // loads per one-block chunk
+  // A chunk past the last block is loaded all the same -- the ring keeps its fixed shape: every wait is "all but the two
+  // youngest chunks", which tools/check_inflight.py can follow on every path -- but with lane offset 0: every lane
+  // reads the first 16 bytes of its tile, two cache lines per load instead of sixteen, from L1 after the first.
+  auto load = [&](GsFrag<4>& f, int kb) {
+    // (the lane offset is rebuilt from the lane id here: kept in a register across the loop it was the one value the
+    //  allocator spilled INSIDE the loop, and a scratch reload between the ring's loads is waited for with vmcnt(0))
+    unsigned ones = ~0u;
+    asm volatile("" : "+s"(ones));
+    const unsigned lid = __builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    const unsigned vo = kb < n_kb ? (lid << 4) + (unsigned)kb * 2048u : 0u;
+    // (s_nop 4: an SGPR a VALU instruction -- v_readfirstlane -- has just written needs 5 wait states before a
+    //  vector-memory instruction reads it, and the hazard recogniser does not look inside an asm statement)
+    asm volatile("s_nop 4");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(f.a[k][0][0]) : "v"(vo), "s"(tb[k]));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(f.a[k][0][1]) : "v"(vo), "s"(tb[k]));
+    }
+  };
+  // One row tile at a time: its two B operands (8 registers) and the scaled one (4) are read right in front of its 12
+  // MFMAs -- the SIMD's other wave covers the LDS latency -- so that the loop's registers are the accumulators, the
+  // ring and a dozen more, and nothing it uses is spilled: a scratch reload between the ring's loads is waited for by
+  // the compiler with vmcnt(0), which drains the ring every iteration (measured: 27.7 k -> 30 k cycles per layer and
+  // first layers 23 k -> 32 k when ONE pointer was reloaded at the loop's top).
+  auto compute = [&](GsFrag<4>& f, int kb) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD));      // this chunk has landed: the two younger ones may be out
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(f.a[k][0][p]));
+    if (kb < n_kb) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        BQ<1, 2> b;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          b.v[p][0] = *reinterpret_cast<const f32x4*>(lb + ((unsigned)(p * 64) + rt * 16u) * ldb + kb * 32);
+        BScaled<1, F16> bs(b);
+#pragma unroll
+        for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], pm_bsel<F16>(q, b, bs, 0), acc[k][rt]);
+      }
+    }
+  };
+  load(f0, 0);
+  load(f1, 1);
+  for (int kb0 = 0; kb0 < n_kb; kb0 += 3) {
+    load(f2, kb0 + 2);
+    compute(f0, kb0);
+    load(f0, kb0 + 3);
+    compute(f1, kb0 + 1);
+    load(f1, kb0 + 4);
+    compute(f2, kb0 + 2);
+  }
+  // the look-ahead chunks (past the end: zeros, no traffic) land before their registers are reused
+  asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      asm volatile("" : "+v"(f0.a[k][0][p]));
+      asm volatile("" : "+v"(f1.a[k][0][p]));
+      asm volatile("" : "+v"(f2.a[k][0][p]));
+    }
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads also drains its stash stores: 9 k cycles
+// behind a policy layer)
+__device__ __forceinline__ void pw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// OR over the four 16-lane groups of a wave (every lane ends with the OR of lanes c, c + 16, c + 32, c + 48)
+__device__ __forceinline__ unsigned pw_or_groups(unsigned w) {
+  auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  w = a[0] | a[1];
+  auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+  return b[0] | b[1];
+}
+
+// the 16-bit words (dropout bits / activity bits, [row][32 tiles]) of the wave's 16 tiles: lane (g, c) gets row
+// 16 rt + c, tiles 4 wid .. 4 wid + 3 -- eight contiguous bytes, one load per row tile; rows past nvalid read as 0
+// (the descriptor's range check), no branches, no 64-bit address arithmetic
+__device__ __forceinline__ void pw_load_words(pm_u32x2 (&mw)[4], const uint16_t* words, int row0, int nvalid, int wid,
+                                              int c) {
+  const pw_rsrc rd = pw_make_rsrc(words + (size_t)row0 * 32, (unsigned)nvalid * 64u);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+    mw[rt] = __builtin_bit_cast(pm_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, (rt * 16 + c) * 64, pw_uni(wid * 8), 0));
+}
+// nibble g of tile k's word
+__device__ __forceinline__ unsigned pw_nibble(const pm_u32x2& w, int k, int g) {
+  return (w[k >> 1] >> (16 * (k & 1) + 4 * g)) & 15u;
+}
+// 1 for a non-zero bit pattern (v_min_u32; written as min(u, 1) the compiler makes a compare and a select of it)
+__device__ __forceinline__ unsigned pw_nz(unsigned u) {
+  unsigned r;
+  asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(u));
+  return r;
+}
+
+struct PwFwd {
+  const float* bias;
+  const uint16_t* mask;   // [B][32] of this step (or the frozen masks)
+  uint16_t* abits;        // [B][32] slice of step t
+  float keep;
+  float* buf;             // the one activation buffer (piece planes, 64 rows each)
+  float* stash;           // feature-major block [512][Rw] of this (step, workgroup) or nullptr
+  float* tbl;             // LDS: nibble -> multipliers (64 floats), then the layer's bias (512 floats)
+  int row0, nvalid;
+  int* ovf;
+  long long* prof;        // debug: four cycle stamps of this layer (workgroup 0, thread 0) or nullptr
+};
+
+// lane (g, c) -> the value lane (g, n) holds, n a constant: DPP row_share (a 16-lane row is one lane group g)
+template <int N>
+__device__ __forceinline__ float pw_row_share(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x150 + N, 0xf, 0xf, false));
+}
+
+// hidden layer, forward, in place:  h = relu(W x + b) * mask / keep   (models/modules.py:46-61,120-160)
+// Contains the barrier between the last read of the input and the first write of the output; the caller
+// synchronises behind it.  Everything but the LDS writes happens IN FRONT of that barrier: a wave that leaves the K
+// loop early (of a SIMD's two waves one does) runs its epilogue while its partner still feeds the matrix core, and the
+// results wait for the barrier as packed pieces in the accumulators' registers.
+template <bool STASH>
+__device__ __forceinline__ void pw_hidden_fwd(const float* __restrict__ wf, int n_kb, const PwFwd& e, int wid, int lane) {
+  constexpr int R = 64;
+  const int g = lane >> 4, c = lane & 15;
+  // the dropout words of the wave's 16 tiles: in flight behind the K loop
+  pm_u32x2 mw[4];
+  pw_load_words(mw, e.mask, e.row0, e.nvalid, wid, c);
+  // the wave's 64 bias values, ONE register a lane (lane (g, c) holds value 4 g + (c & 3) of tile c >> 2; the lanes
+  // of a group fetch each other's by DPP row_share): 16 registers a lane the K loop does not have
+  const float breg = e.bias[(4 * wid + (c >> 2)) * 16 + 4 * g + (c & 3)];
+  f32x4 acc[4][4];
+  pw_kloop<true>(wf, n_kb, e.buf, wid, lane, acc);
+  PW_STAMP(0);
+  const float ik = 1.f / e.keep;
+  const f32x4 ik4 = {ik, ik, ik, ik};
+  f32x4 bk[4];
+  bk[0] = f32x4{pw_row_share<0>(breg), pw_row_share<1>(breg), pw_row_share<2>(breg), pw_row_share<3>(breg)};
+  bk[1] = f32x4{pw_row_share<4>(breg), pw_row_share<5>(breg), pw_row_share<6>(breg), pw_row_share<7>(breg)};
+  bk[2] = f32x4{pw_row_share<8>(breg), pw_row_share<9>(breg), pw_row_share<10>(breg), pw_row_share<11>(breg)};
+  bk[3] = f32x4{pw_row_share<12>(breg), pw_row_share<13>(breg), pw_row_share<14>(breg), pw_row_share<15>(breg)};
+  // multipliers of a tile's four row tiles: looked up one tile ahead of their use
+  auto lookup = [&](f32x4 (&m)[4], int k) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) m[rt] = *reinterpret_cast<const f32x4*>(e.tbl + 4 * pw_nibble(mw[rt], k, g));
+  };
+  f32x4 m[2][4];
+  lookup(m[0], 0);
+  const pw_rsrc srd = pw_make_rsrc(e.stash, 0xffffffffu);
+  const int vo_st = (4 * g * PW_RW + c) * 4;
+  unsigned aw[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};   // [row tile][tile pair]: 16-bit field per tile
+  unsigned hmax = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < 3) lookup(m[(k + 1) & 1], k + 1);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      // (the two-buffer form's arithmetic, bit for bit: (acc + b) * (1 / keep) for an active unit)
+      const f32x4 v = acc[k][rt] + bk[k];
+      f32x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = fmaxf(v[r], 0.f);
+      h *= m[k & 1][rt] * ik4;
+      const unsigned u0 = __float_as_uint(h[0]), u1 = __float_as_uint(h[1]), u2 = __float_as_uint(h[2]),
+                     u3 = __float_as_uint(h[3]);
+      hmax = max(max(hmax, max(u0, u1)), max(u2, u3));
+      const unsigned nb = pw_nz(u0) | (pw_nz(u1) << 1) | (pw_nz(u2) << 2) | (pw_nz(u3) << 3);
+      aw[rt][k >> 1] |= nb << (16 * (k & 1));
+      if constexpr (STASH) {
+        const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
+      }
+      // two fp16 pieces: residuals h - hi in fp32 (v_fma_mix_f32 reads the fp16 half directly), then the same RNE pair
+      // conversion as the other forms (the low piece of |h| < 0.125 is an fp16 subnormal: kept)
+      const unsigned ha = pm_pk_f16(h[0], h[1]), hb = pm_pk_f16(h[2], h[3]);
+      float l0, l1, l2, l3;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ha), "v"(h[0]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ha), "v"(h[1]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(hb), "v"(h[2]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(hb), "v"(h[3]));
+      // ... parked where the accumulator was
+      acc[k][rt] = f32x4{__uint_as_float(ha), __uint_as_float(hb), __uint_as_float(pm_pk_f16(l0, l1)),
+                         __uint_as_float(pm_pk_f16(l2, l3))};
+    }
+  }
+  if (hmax > 0x477fe000u) *e.ovf = 1;   // an activation beyond fp16's range (65504; h >= +0, inf and NaN compare above)
+  // activity bits: every lane's nibble goes to bit 4 g of its tile's 16-bit field; OR over the four lane groups;
+  // lane group g stores row tile g: the row's four words are eight contiguous bytes
+  const pw_rsrc ard = pw_make_rsrc(e.abits + (size_t)e.row0 * 32, (unsigned)e.nvalid * 64u);
+  pm_u32x2 out = {0u, 0u};
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const unsigned w0 = pw_or_groups(aw[rt][0] << (4 * g)), w1 = pw_or_groups(aw[rt][1] << (4 * g));
+    if (g == rt) out = pm_u32x2{w0, w1};
+  }
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(ard, 0, 0, 0)), out), ard,
+                                        (g * 16 + c) * 64, pw_uni(wid * 8), 0);
+  PW_STAMP(1);
+  pw_lds_barrier();          // every wave has read its last operand: the buffer may be overwritten
+  PW_STAMP(2);
+  unsigned short* q0 = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB + (unsigned)(wid * 64 + 4 * g);
+  unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const unsigned eo = (unsigned)(rt * 16) * PW_LDB + (unsigned)(k * 16);
+      *reinterpret_cast<pm_u32x2*>(q0 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][0]), __float_as_uint(acc[k][rt][1])};
+      *reinterpret_cast<pm_u32x2*>(q1 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][2]), __float_as_uint(acc[k][rt][3])};
+    }
+}
+
+struct PwBwd {
+  const uint16_t* abits;  // [B][32] slice of step t
+  float keep;
+  float* buf;
+  float* stash;           // gT block [512][Rw] or nullptr
+  const float* tbl;
+  int row0, nvalid;
+  long long* prof;
+};
+
+// hidden layer, adjoint, in place:  g_pre = active ? (W^T g) / keep : 0   (bf16 pieces; as the forward layer)
+template <bool STASH>
+__device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int n_kb, const PwBwd& e, int wid, int lane) {
+  constexpr int R = 64;
+  const int g = lane >> 4, c = lane & 15;
+  pm_u32x2 mw[4];
+  pw_load_words(mw, e.abits, e.row0, e.nvalid, wid, c);
+  f32x4 acc[4][4];
+  pw_kloop<false>(wb, n_kb, e.buf, wid, lane, acc);
+  PW_STAMP(0);
+  const float ik = 1.f / e.keep;
+  auto lookup = [&](f32x4 (&m)[4], int k) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) m[rt] = *reinterpret_cast<const f32x4*>(e.tbl + 4 * pw_nibble(mw[rt], k, g));
+  };
+  f32x4 m[2][4];
+  lookup(m[0], 0);
+  const pw_rsrc srd = pw_make_rsrc(e.stash, 0xffffffffu);
+  const int vo_st = (4 * g * PW_RW + c) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < 3) lookup(m[(k + 1) & 1], k + 1);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const f32x4 h = acc[k][rt] * ik * m[k & 1][rt];
+      if constexpr (STASH) {
+        const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
+      }
+      pm_u32x2 pc[2];
+      pm_split4<2, false>(h, pc);
+      acc[k][rt] = f32x4{__uint_as_float(pc[0][0]), __uint_as_float(pc[0][1]), __uint_as_float(pc[1][0]),
+                         __uint_as_float(pc[1][1])};
+    }
+  }
+  PW_STAMP(1);
+  pw_lds_barrier();
+  PW_STAMP(2);
+  unsigned short* q0 = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB + (unsigned)(wid * 64 + 4 * g);
+  unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const unsigned eo = (unsigned)(rt * 16) * PW_LDB + (unsigned)(k * 16);
+      *reinterpret_cast<pm_u32x2*>(q0 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][0]), __float_as_uint(acc[k][rt][1])};
+      *reinterpret_cast<pm_u32x2*>(q1 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][2]), __float_as_uint(acc[k][rt][3])};
+    }
+}

@@ -370,7 +370,7 @@ class Engine:
                          dw_splits=info[6], mm_mode=info[7], LD=info[8], dw_blocks=info[9],
                          fast=info[10], stages=(info[11] >> 4, info[11] & 15), mm_grid=info[12],
                          precision={_lib.PREC_SPLIT: 'split', _lib.PREC_SPLIT_F16: 'split_f16'}.get(info[13], 'f32'),
-                         dw_pipe=info[14], mm_parts=info[15], reg=info[16], replay=info[17])
+                         dw_pipe=info[14], mm_parts=info[15], reg=info[16], replay=info[17], inplace=info[18])
         self.n_pol_params = info[4]
         self.n_dyn_params = info[5]
         ws_bytes = self.lib.pmbrl_plan_workspace_bytes(plan)

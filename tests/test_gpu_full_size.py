@@ -415,7 +415,8 @@ def test_c5_full_size_parity_and_properties():
     -- pmbrl_split.h, PM_F16_LO_SCALE; tools/c5_precision_study.py -- and the two-piece forward is fp32-class.)"""
     d = _c5_full('stress32')
     eng, S, A, Rw, loss, g, gw = _run(d)
-    assert eng.info['fast'] == 0 and eng.info['rows_per_wg'] == 32
+    # (round 4: 64-row workgroups on the in-place 512-wide layers of pmbrl_wide.h -- one workgroup per CU)
+    assert eng.info['fast'] == 0 and eng.info['rows_per_wg'] == 64 and eng.info['inplace'] == 2
     S64, l64, g64 = _oracle_on_first_rows(d, 512)
     floor32 = _fp32_floor_on_first_rows(d, 512, g64)
     g_sub = eng.backward(_masked(gw, 512))[0].cpu().numpy().copy()
@@ -435,11 +436,16 @@ def test_c5_full_size_parity_and_properties():
     # (d) linearity: the rest of the rows' gradient adds up to the whole
     g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
     assert common.rel(g_sub + g_rest, g) < 2e-6
-    # (c) 16-row workgroups
-    eng16, S16, _, _, _, g16, _ = _run(d, rows_per_wg_hint=16)
-    assert eng16.info['rows_per_wg'] == 16
-    assert common.rel(S16, S) < 1e-6 and common.rel(g16, g) < 1e-5
-    del eng16
+    # (c) 16- and 32-row workgroups (the two-buffer form).  Its hidden layers are the wide layers' bit for bit, its
+    #     heads sum their K in another order (K-split over the waves): trajectories agree to fp32 rounding, and between
+    #     two such arithmetics the gradient at this size carries the same handful of borderline ReLU units as (a) --
+    #     the bar is (a)'s
+    for hint in (16, 32):
+        eng16, S16, _, _, _, g16, _ = _run(d, rows_per_wg_hint=hint)
+        assert eng16.info['rows_per_wg'] == hint and eng16.info['inplace'] == 0
+        print('C5 %d-row two-buffer form vs the wide layers: states %.2e grad %.2e' % (hint, common.rel(S16, S), common.rel(g16, g)))
+        assert common.rel(S16, S) < 2e-6 and common.rel(g16, g) < 1e-4 + floor32
+        del eng16
     # (b) row reversal
     B = d['x0'].shape[0]
     e = dict(d)
