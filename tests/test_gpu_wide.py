@@ -46,7 +46,7 @@ def test_wide_layers_match_reference_and_other_forms(dev, name, monkeypatch):
     for S, g in ((Sw, gwide), (S16, g16), (Sg, gg)):
         assert common.rel(S, d['ref64_states']) < TOL_TRAJ and common.rel(g, d['ref64_grad']) < TOL_GRAD
     assert common.rel(Aw, d['ref64_actions']) < TOL_TRAJ and common.rel(Rw, d['ref64_rewards']) < TOL_TRAJ
-    # the forms differ by the rounding of one fma per pre-activation (fma(acc, 1/keep, b/keep) against (acc + b) / keep)
+    # (hidden layers bit for bit the other forms'; the heads sum their K in another order than the two-buffer form's)
     assert common.rel(Sw, S16) < 2e-6 and common.rel(gwide, g16) < 2e-5
     assert common.rel(Sw, Sg) < 2e-6 and common.rel(gwide, gg) < 2e-5
 
