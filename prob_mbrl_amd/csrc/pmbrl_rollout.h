@@ -372,7 +372,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       // fp32 rows at column PM_IP_NOFF of the one buffer: clear of the 64 plane columns the next phase writes
       Y = X + PM_IP_NOFF;
       EpiPlain e{P.bias[P.nl - 1], Y, LD, lane};
-      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) pw_narrow<true>(P.wf[P.nl - 1], P.nt[P.nl], X, P.bias[P.nl - 1], Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{F.bias[F.nl - 1], Y, LD, lane};
-      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) pw_narrow<true>(F.wf[F.nl - 1], F.nt[F.nl], X, F.bias[F.nl - 1], Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) pw_narrow<false>(F.wb[0], F.nt[0], X, nullptr, Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      if constexpr (IP == 2) gemm_tiles_inplace_s<RT, 1, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
+      if constexpr (IP == 2) pw_narrow<false>(P.wb[0], P.nt[0], X, nullptr, Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)

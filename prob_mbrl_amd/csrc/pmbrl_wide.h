@@ -363,3 +363,58 @@ __device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int 
       *reinterpret_cast<pm_u32x2*>(q1 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][2]), __float_as_uint(acc[k][rt][3])};
     }
 }
+
+// Narrow layers behind a 512-wide one (the heads: 2U / 2D outputs; the first layers' adjoints: D / D + U outputs): at
+// most four output tiles, K = 512.  The generic in-place routine gives one TILE to a wave -- one wave busy for the
+// policy head, four for the dynamics head -- and walks its sixteen K blocks two loads at a time: 11-13 k cycles of
+// exposed round trips for 0.4 k of MFMAs per wave.  Here a wave takes one or two ROW TILES of a tile (all eight waves
+// busy at four tiles), requests the tile's 32 fragments at once (128 registers: this is a layer without a ring) and
+// consumes them in order as they land -- the same K order and piece order per accumulator as before: bit-identical.
+// fp32 rows (with bias) to out[row][0 .. 16 n_ot), leading dimension ld floats, which may alias the input planes:
+// contains the barrier between the last operand read and the first write; the caller synchronises behind it.
+template <bool F16>
+__device__ __forceinline__ void pw_narrow(const float* __restrict__ wf, int n_ot, const float* buf, const float* bias,
+                                          float* out, int ld, int wid, int lane) {
+  typedef PmPairs<2> PP;
+  constexpr int NKB = 16;
+  constexpr unsigned ldb = PW_LDB;
+  const int g = lane >> 4, c = lane & 15;
+  const int n_items = n_ot * 4;
+  const int per = n_items > PM_NW ? 2 : 1;
+  const int i0 = wid * per;
+  const bool work = i0 < n_items;
+  const int k = work ? i0 >> 2 : 0, rt0 = i0 & 3;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (work) {
+    f32x4 a[NKB][2];
+    const float* wp = wf + (size_t)k * NKB * 512 + lane * 4;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a[kb][p] = ldg4(wp + (kb * 2 + p) * 256);
+    if (bias) b4 = ldg4(bias + k * 16 + 4 * g);
+    const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j < per) {
+          BQ<1, 2> b;
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            b.v[p][0] = *reinterpret_cast<const f32x4*>(lb + ((unsigned)(p * 64) + (unsigned)(rt0 + j) * 16u) * ldb + kb * 32);
+          BScaled<1, F16> bs(b);
+#pragma unroll
+          for (int q = 0; q < PP::N; ++q) acc[j] = pm_mfma_bf<F16>(a[kb][PP::W[q]], pm_bsel<F16>(q, b, bs, 0), acc[j]);
+        }
+      }
+    }
+  }
+  __syncthreads();          // every wave has read its last operand: the buffer may be overwritten
+  if (work) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (j < per) *reinterpret_cast<f32x4*>(out + ((rt0 + j) * 16 + c) * ld + k * 16 + 4 * g) = acc[j] + b4;
+  }
+}

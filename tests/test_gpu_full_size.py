@@ -476,7 +476,11 @@ def test_c5_mm_full_size_parity_and_properties():
     g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
     assert common.rel(g_sub + g_rest, g) < 2e-6
     # (b) the first 8 groups as a shard of the 16 384-row global batch
-    sh, args, _ = PB.engine_from_problem(_sub_rows(d, 512), DEV, B_global=16384, row_offset=0)
+    # (in the same kernel form as the whole batch -- 64-row workgroups on the wide layers: a 512-row plan would take
+    #  the two-buffer form by itself, whose policy head sums its K in another order)
+    sh, args, _ = PB.engine_from_problem(_sub_rows(d, 512), DEV, B_global=16384, row_offset=0,
+                                         rows_per_wg_hint=eng.info['rows_per_wg'])
+    assert sh.info['inplace'] == eng.info['inplace']
     Ss, As_, Rs = sh.forward(**args)
     gs = sh.backward(gw[:, :512].contiguous())[0].cpu().numpy()
     assert sh.valid_steps() == 100
