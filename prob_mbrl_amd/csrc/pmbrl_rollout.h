@@ -339,7 +339,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           // an INPUT out of fp16's range would become inf, inf x 0-weight NaN, and vanish in the ReLU: reported like an
           // activation out of range (the host re-runs in fp32)
           if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
-          pm_put_planes<R, true>(X, LDB, r, k, v);
+          pm_put_planes<R, true>(X, LDB, r, IP == 2 ? pw_sw(r, k) : k, v);
         }
         else X[r * LD + k] = v;
         if (k < K16) st[(size_t)k * A.Rw + r] = v;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         }
         const float v = (a - mxk) * isk;
         if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
-        pm_put_planes<R, true>(X, LDB, r, k, v);
+        pm_put_planes<R, true>(X, LDB, r, pw_sw(r, k), v);
       }
       {
         const int k = tid % K16, rstep = PM_NT / K16;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           for (int r = tid / K16; r < R; r += rstep) {
             const float v = state ? (xa[r * D + k] - mxk) * isk : 0.f;
             if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
-            pm_put_planes<R, true>(X, LDB, r, k, v);
+            pm_put_planes<R, true>(X, LDB, r, pw_sw(r, k), v);
           }
         }
       }
@@ -733,8 +733,8 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
         const float td = v ? A.Td[row * D + d] : 0.f;
         const float g = gx[i] + gr * jx;
         gxt[i] = g;
-        pm_put_planes<R, false>(X, LDB, r, d, v ? g * A.Sy[d] : 0.f);
-        pm_put_planes<R, false>(X, LDB, r, D + d, g * td);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, d), v ? g * A.Sy[d] : 0.f);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, D + d), g * td);
       }
       for (int i = tid; i < R * U; i += PM_NT) {
         const int r = i / U, j = i - r * U;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       }
       for (int i = tid; i < R * (K16 - 2 * D); i += PM_NT) {
         const int r = i / (K16 - 2 * D), k = i - r * (K16 - 2 * D);
-        pm_put_planes<R, false>(X, LDB, r, 2 * D + k, 0.f);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, 2 * D + k), 0.f);
       }
       __syncthreads();
       PM_MARK(3);
@@ -912,14 +912,14 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
           go_mu = gu;
           go_ls = gu * tp;
         }
-        pm_put_planes<R, false>(X, LDB, r, j, go_mu);
-        pm_put_planes<R, false>(X, LDB, r, U + j, go_ls);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, j), go_mu);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, U + j), go_ls);
         gst[(size_t)j * A.Rw + r] = go_mu;
         gst[(size_t)(U + j) * A.Rw + r] = go_ls;
       }
       for (int i = tid; i < R * (KP - 2 * U); i += PM_NT) {
         const int r = i / (KP - 2 * U), k = 2 * U + i - r * (KP - 2 * U);
-        pm_put_planes<R, false>(X, LDB, r, k, 0.f);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, k), 0.f);
         if (k < K16) gst[(size_t)k * A.Rw + r] = 0.f;
       }
     } else {

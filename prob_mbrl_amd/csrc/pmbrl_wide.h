@@ -23,17 +23,21 @@
 //   * the fp16 range guard is a running integer max, tested once per layer;
 //   * ALL of that runs in front of the barrier (results parked as packed pieces in the accumulators' registers);
 //     behind it only the 32 ds_write_b64.
-// K loop: a ring of three one-block chunks per wave with inline-asm loads and explicit waits, no load past the last
-// block.  Nothing derived from the thread index is carried across steps (pmbrl_rollout.h launders it per step): the
-// address arithmetic the compiler hoisted out of the step loop was what the layers spilled around.
+// K loop: a ring of three one-block chunks per wave (inline-asm loads through scalar tile bases, explicit waits, a fixed
+// shape tools/check_inflight.py can follow; chunks past the end read 16 bytes per lane group), one row tile's operands
+// at a time so that nothing the loop uses is spilled.  Nothing derived from the thread index is carried across steps
+// (pmbrl_rollout.h launders it per step): the address arithmetic the compiler hoisted out of the step loop was what
+// the layers spilled around.  The piece planes are chunk-swizzled (pw_sw): the epilogue's writes two-way instead of
+// four-way conflicted.  Narrow layers (heads, first-layer adjoints): pw_narrow.
 //
-// Measured at C5 (profiles/r04i_*): a hidden layer-step of 64 rows 86 k -> 46 k cycles (forward, with the stash) and
-// 66 k -> 43 k (adjoint); forward sweep 19.3 -> 12.6 ms, adjoint 18.2 -> 10.5 ms, MfmaUtil 24 % -> 37 %.  What binds
-// a layer now, from per-wave stamps and elimination builds (profiles/r04i_notes.txt): the older wave of each SIMD
+// Measured at C5 (profiles/r04i_notes.txt has every step): a hidden layer-step of 64 rows 86 k -> 42 k cycles (forward,
+// with the stash) and 66 k -> 38-42 k (adjoint); forward sweep 19.3 -> 11.9 ms, adjoint 18.2 -> 10.8 ms, MfmaUtil
+// 24 % -> 41 % / 44 %.  What binds a layer now, from per-wave stamps and elimination builds: the older wave of each SIMD
 // leaves the K loop after 24 k cycles, the younger after 36 k, for 24.6 k cycles of MFMAs per SIMD; with the weight
 // loads compiled out 20 k / 32 k, with the MFMAs compiled out 21 k / 27 k -- the instruction stream beside the MFMAs
-// (per block and wave 8 ds_read_b128, 16 v_pk_mul_f16 for the scaled operand, 8 loads and their addresses, the wait
-// selection: ~50 issue slots for 48 MFMAs) and the fetch each cost about a third on top and overlap imperfectly.
+// (per block and wave 8 ds_read_b128, 16 v_pk_mul_f16 for the scaled operand, 8 loads, waits: ~50 issue slots for 48
+// MFMAs) and the fetch each cost about a third on top and overlap imperfectly; and the part clocks down as the duty
+// rises (2.3 -> 2.0 GHz between the first and the last build of this file).
 // Not kept (measured, no change): B operands read a half ahead across block boundaries; K order rotated per wave or
 // per workgroup (no L2-channel hot spot); stash stores as sc0 sc1; the bias staged through LDS.
 // Same LDS buffer, same stashes, same activity-bit layout as the other forms of the family: the sweeps of the three
@@ -54,6 +58,21 @@ __device__ __forceinline__ pw_rsrc pw_make_rsrc(const void* base, unsigned bytes
 }
 __device__ __forceinline__ int pw_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Where feature column `col` of row `row` sits in a piece plane of the wide layers: the index of its 16-byte chunk is
+// XOR-ed with bits 2..3 of the row.  The plain layout (row pitch 528 elements = 8 banks mod 32) is conflict-free for the
+// ds_read_b128 of the B operands, but the epilogue's ds_write_b64 covers 16 ROWS per 16-lane group and rows r, r + 4,
+// r + 8, r + 12 meet in one bank pair: a four-way conflict, 4.4 k cycles for the 32 writes of a wave behind every
+// layer.  With the XOR the reads stay conflict-free (a chunk moves inside its K32 block only) and the writes are
+// two-way (the floor for 8-byte writes at this pitch: tools/ubench/lds_swizzle.py enumerates the lane groups).
+__device__ __forceinline__ unsigned pw_sw(unsigned row, unsigned col) {
+  return (((col >> 3) ^ ((row >> 2) & 3u)) << 3) | (col & 7u);
+}
+// this lane's base for the B operands of row tile 0 (row lane & 15, chunk lane >> 4 of a K32 block)
+__device__ __forceinline__ const unsigned short* pw_plane_lane(const float* buf, int lane) {
+  const unsigned c = (unsigned)lane & 15u, g = (unsigned)lane >> 4;
+  return reinterpret_cast<const unsigned short*>(buf) + c * PW_LDB + 8u * (g ^ ((c >> 2) & 3u));
+}
+
 // nibble -> four multipliers; 64 floats of LDS, written once per launch
 __device__ __forceinline__ void pw_table_init(float* tbl, int tid) {
   if (tid < 64) tbl[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 1.f : 0.f;
@@ -68,7 +87,7 @@ __device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb,
                                          f32x4 (&acc)[4][4]) {
   typedef PmPairs<2> PP;
   constexpr unsigned ldb = PW_LDB;
-  const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
+  const unsigned short* lb = pw_plane_lane(buf, lane);
   // the wave's four tile bases as scalars: every load is  global_load_dwordx4 v, v_offset, s[base]  -- one 32-bit
   // lane offset per chunk, no 64-bit address arithmetic per load
   const char* tb[4];
@@ -290,16 +309,18 @@ __device__ __forceinline__ void pw_hidden_fwd(const float* __restrict__ wf, int 
   PW_STAMP(1);
   pw_lds_barrier();          // every wave has read its last operand: the buffer may be overwritten
   PW_STAMP(2);
-  unsigned short* q0 = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB + (unsigned)(wid * 64 + 4 * g);
-  unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
+  unsigned short* pb = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
+    unsigned short* q0 = pb + pw_sw((unsigned)c, (unsigned)(wid * 64 + k * 16 + 4 * g));   // (row tile: same bits 2..3)
+    unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const unsigned eo = (unsigned)(rt * 16) * PW_LDB + (unsigned)(k * 16);
+      const unsigned eo = (unsigned)(rt * 16) * PW_LDB;
       *reinterpret_cast<pm_u32x2*>(q0 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][0]), __float_as_uint(acc[k][rt][1])};
       *reinterpret_cast<pm_u32x2*>(q1 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][2]), __float_as_uint(acc[k][rt][3])};
     }
+  }
 }
 
 struct PwBwd {
@@ -352,16 +373,18 @@ __device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int 
   PW_STAMP(1);
   pw_lds_barrier();
   PW_STAMP(2);
-  unsigned short* q0 = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB + (unsigned)(wid * 64 + 4 * g);
-  unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
+  unsigned short* pb = reinterpret_cast<unsigned short*>(e.buf) + (unsigned)c * PW_LDB;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
+    unsigned short* q0 = pb + pw_sw((unsigned)c, (unsigned)(wid * 64 + k * 16 + 4 * g));   // (row tile: same bits 2..3)
+    unsigned short* q1 = q0 + (unsigned)R * PW_LDB;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const unsigned eo = (unsigned)(rt * 16) * PW_LDB + (unsigned)(k * 16);
+      const unsigned eo = (unsigned)(rt * 16) * PW_LDB;
       *reinterpret_cast<pm_u32x2*>(q0 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][0]), __float_as_uint(acc[k][rt][1])};
       *reinterpret_cast<pm_u32x2*>(q1 + eo) = pm_u32x2{__float_as_uint(acc[k][rt][2]), __float_as_uint(acc[k][rt][3])};
     }
+  }
 }
 
 // Narrow layers behind a 512-wide one (the heads: 2U / 2D outputs; the first layers' adjoints: D / D + U outputs): at
@@ -394,7 +417,7 @@ __device__ __forceinline__ void pw_narrow(const float* __restrict__ wf, int n_ot
 #pragma unroll
       for (int p = 0; p < 2; ++p) a[kb][p] = ldg4(wp + (kb * 2 + p) * 256);
     if (bias) b4 = ldg4(bias + k * 16 + 4 * g);
-    const unsigned short* lb = pm_plane_lane(buf, ldb, lane);
+    const unsigned short* lb = pw_plane_lane(buf, lane);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
