@@ -37,6 +37,8 @@ struct DwBlock {      // one wave block
   int16_t layer, ot0, it0, n_ot, n_it, pad;
 };
 
+struct PmTrue { static constexpr bool value = true; };
+struct PmFalse { static constexpr bool value = false; };
 // one 256 x 128 output tile of a wide layer (pm_dw_wide_kernel)
 struct DwUnit {
   int16_t layer, m0, n0, pad;      // first output feature / first input feature of the tile
@@ -473,7 +475,32 @@ __global__ __launch_bounds__(PM_DW_NT, 4) void pm_dw_wide_kernel(const DwArgs A,
   // staging: thread -> (feature f = idx >> 3, k quad kq = idx & 7), idx = tid + 512 j
   f32x4 ra0[2], rb0[2];
   float bs[2] = {0.f, 0.f};
-  auto fetch = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], int c) {
+  // Whole tiles of 32- / 64-row stash blocks (every tile of the 3 x 512 stress shape): the step's operands are
+  //   base + [block b = c / RT, row tile c % RT: scalar] + [feature row, k quad: a per-thread constant]
+  // -- loads with a scalar base and one 32-bit lane offset.  (The general form below recomputed c / RT by a software
+  // division and a 64-bit address per load, behind a branch per load for the edge tiles: ~150 vector and ~170 scalar
+  // instructions a wave-step beside 24 MFMAs, four waves a SIMD -- the kernel was bound by that instruction stream,
+  // MfmaUtil 33 %.)
+  const bool whole = A.RT >= 2 && (A.RT & (A.RT - 1)) == 0 && U.m0 + PM_DWW_TM <= Fo16 && U.n0 + PM_DWW_TN <= Fi16;
+  const int rt_sh = A.RT >= 4 ? 2 : 1;
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + PM_DW_NT * j;
+    offA[j] = (unsigned)((U.m0 + (idx >> 3)) * A.Rw + (idx & 7) * 4);
+    offB[j] = (unsigned)((U.n0 + (idx >> 3)) * A.Rw + (idx & 7) * 4);
+  }
+  auto fetch = [&](auto fast, f32x4 (&ra)[2], f32x4 (&rb)[2], int c) {
+    if constexpr (decltype(fast)::value) {
+      const int b = c >> rt_sh, rt = c & (A.RT - 1);
+      const float* pg = gbase + (size_t)b * gblk + rt * 16;
+      const float* pa = abase + (size_t)b * ablk + rt * 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pg + offA[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pa + offB[j]);
+      return;
+    }
     const bool second = c + 1 < R.c_hi;      // (16-row blocks: rows 16..31 of the step are the next chunk)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -560,17 +587,25 @@ __global__ __launch_bounds__(PM_DW_NT, 4) void pm_dw_wide_kernel(const DwArgs A,
   };
   // step c from LDS stage st; the registers receive step c + 2 meanwhile (the CU's other workgroup covers what of
   // that round trip the MFMAs of one step do not)
-  fetch(ra0, rb0, R.c_lo);
-  stage(ra0, rb0, 0);
-  __syncthreads();
-  int st = 0;
-  for (int c = R.c_lo; c < R.c_hi; c += 2, st ^= 1) {
-    const bool more = c + 2 < R.c_hi;
-    if (more) fetch(ra0, rb0, c + 2);
-    mfmas(st);
-    if (more) stage(ra0, rb0, st ^ 1);
+  // (two steps ahead -- a second register set, the loop unrolled by two -- does not fit the 128 registers of two
+  //  workgroups per CU: the allocator spilled freshly loaded operands behind vmcnt(0); with one A fragment pair at a
+  //  time to make room, 24 spills.  Not run.)
+  // (nor does issuing the next fetch right behind the staging, in front of the barrier: 6.5 -> 7.2 ms.)
+  auto sweep = [&](auto fast) {
+    fetch(fast, ra0, rb0, R.c_lo);
+    stage(ra0, rb0, 0);
     __syncthreads();
-  }
+    int st = 0;
+    for (int c = R.c_lo; c < R.c_hi; c += 2, st ^= 1) {
+      const bool more = c + 2 < R.c_hi;
+      if (more) fetch(fast, ra0, rb0, c + 2);
+      mfmas(st);
+      if (more) stage(ra0, rb0, st ^ 1);
+      __syncthreads();
+    }
+  };
+  if (whole) sweep(PmTrue{});
+  else sweep(PmFalse{});
   // partial tile: lane holds dW[o = m0 + 32 wm + 16 i + 4 g + r][k = n0 + 64 wn + 16 j + c16]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -642,8 +677,37 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_layer_kernel(const DwArgs A
     }
     dst = live ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  // A step with both its 16-row chunks (every step but an odd range's last): scalar base of the step + a per-thread
+  // constant -- loads with a scalar base and one 32-bit lane offset, no branch per load (a feature row past the layer's
+  // is clamped to the last one: it is never staged).  fetch1 above is what remains for the odd step; it was ~25
+  // instructions and a branch per load, eight loads a thread and step (as in pm_dw_wide_kernel).
+  const bool pow2 = (A.RT & (A.RT - 1)) == 0;
+  const int rt_sh = A.RT >= 4 ? 2 : (A.RT >= 2 ? 1 : 0);
+  unsigned offA[PM_DWL_Q], offB[PM_DWL_Q];
+#pragma unroll
+  for (int j = 0; j < PM_DWL_Q; ++j) {
+    const int idx = tid + PM_DW_NT * j, f = idx >> 3, kq = idx & 7;
+    const int fa = min(f, Fo16 - 1), fb = min(f, Fi16 - 1);
+    if (A.RT >= 2) {
+      offA[j] = (unsigned)(fa * A.Rw + kq * 4);
+      offB[j] = (unsigned)(fb * A.Rw + kq * 4);
+    } else {
+      offA[j] = (unsigned)((kq >> 2) * (int)gblk + fa * 16 + (kq & 3) * 4);
+      offB[j] = (unsigned)((kq >> 2) * (int)ablk + fb * 16 + (kq & 3) * 4);
+    }
+  }
   auto fetch = [&](int c) {
     const bool second = c + 1 < R.c_hi;
+    if (second && pow2) {
+      const int b = A.RT >= 2 ? c >> rt_sh : c, rt = A.RT >= 2 ? (c & (A.RT - 1)) : 0;
+      const float* pg = gbase + (size_t)b * gblk + rt * 16;
+      const float* pa = abase + (size_t)b * ablk + rt * 16;
+#pragma unroll
+      for (int j = 0; j < PM_DWL_Q; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pg + offA[j]);
+#pragma unroll
+      for (int j = 0; j < PM_DWL_Q; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pa + offB[j]);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < PM_DWL_Q; ++j) {
       const int idx = tid + PM_DW_NT * j;      // (idx >= 13 * 16 * 8: feature >= 208 >= F16 -> zeros, never staged)
