@@ -391,7 +391,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       for (int i = tid; i < R * U; i += PM_NT) {
         const int r = i / U, j = i - r * U, k = D + j;
         const bool valid = r < nvalid;
-        const float z = valid ? A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + r) * U + j] : 0.f;
+        const float z0 = A.zpol[(size_t)t * A.zpol_ss + (size_t)(row0 + (valid ? r : 0)) * U + j];
+        const float z = valid ? z0 : 0.f;
         const float sc = A.pscale[j], pb = A.pbias[j], mxk = A.mx[k], isk = A.iSx[k];
         const float mu = Y[r * LD + j];
         const float ls = Y[r * LD + U + j];
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
         const int i = r * D + d;
         const float mu = Y[r * LD + d];
         const float ls = Y[r * LD + D + d];
-        const float z = (r < nvalid) ? A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + r) * D + d] : 0.f;
+        const float z0 = A.zdyn[(size_t)t * A.zdyn_ss + (size_t)(row0 + (r < nvalid ? r : 0)) * D + d];
+        const float z = (r < nvalid) ? z0 : 0.f;
         const float lc = -softplusf(-ls + A.mls_dyn) + A.mls_dyn + lSy;
         const float e = expf(lc);
         const float xn = xa[i] + (mu * Sy + myd + z * e);
@@ -728,21 +730,22 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
         const int r = i / D, d = i - r * D;
         const bool v = r < nvalid;
         const size_t row = (size_t)t * B + row0 + (v ? r : 0);
-        const float gr = v ? A.grad_rewards[row] : 0.f;
-        const float jx = v ? A.Jx[row * D + d] : 0.f;
-        const float td = v ? A.Td[row * D + d] : 0.f;
+        // (loads unconditional on a clamped row, the selection behind them: a load under `v ? .. : 0` is a branch,
+        //  and a branch per load is what keeps an unrolled loop from having its loads in flight together)
+        const float gr0 = A.grad_rewards[row], jx0 = A.Jx[row * D + d], td0 = A.Td[row * D + d], sy = A.Sy[d];
+        const float gr = v ? gr0 : 0.f, jx = v ? jx0 : 0.f, td = v ? td0 : 0.f;
         const float g = gx[i] + gr * jx;
         gxt[i] = g;
-        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, d), v ? g * A.Sy[d] : 0.f);
+        pm_put_planes<R, false>(X, LDB, r, pw_sw(r, d), v ? g * sy : 0.f);
         pm_put_planes<R, false>(X, LDB, r, pw_sw(r, D + d), g * td);
       }
       for (int i = tid; i < R * U; i += PM_NT) {
         const int r = i / U, j = i - r * U;
         const bool v = r < nvalid;
         const size_t row = (size_t)t * B + row0 + (v ? r : 0);
-        const float gr = v ? A.grad_rewards[row] : 0.f;
-        L.gad[r * 16 + j] = v ? gr * A.Ja[row * U + j] : 0.f;
-        L.av[i] = v ? A.actions[row * U + j] : 0.f;
+        const float gr0 = A.grad_rewards[row], ja0 = A.Ja[row * U + j], ac0 = A.actions[row * U + j];
+        L.gad[r * 16 + j] = v ? gr0 * ja0 : 0.f;
+        L.av[i] = v ? ac0 : 0.f;
       }
       for (int i = tid; i < R * (K16 - 2 * D); i += PM_NT) {
         const int r = i / (K16 - 2 * D), k = i - r * (K16 - 2 * D);
