@@ -55,11 +55,16 @@ def parse():
                     help='pmbrl_plan_set_replay: 0 never replay repeated calls as hipGraphs, 1 the library default (the '
                          'one-launch-per-step forms), 2 every form')
     ap.add_argument('--no-f32-twin', action='store_true', help='N = 1: skip the exact-fp32 leg')
+    ap.add_argument('--no-sclk', action='store_true', help='skip the shader-clock probe (three instrumented forward launches)')
     ap.add_argument('--no-fused-tail', action='store_true',
                     help='N = 1: separate loss / dW-reduce / norm / Adam launches (what N > 1 runs around its all-reduce)')
     ap.add_argument('--no-second-curve', action='store_true', help='N > 1: skip the other scaling curve')
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
+    ap.add_argument('--repeats', type=int, default=0,
+                    help='timed blocks of EXACTLY --steps steps each (every block bracketed by barrier + synchronize); '
+                         '`value` is the median block.  0 (default): as many as give >= 0.25 s of device time, at least 25 '
+                         'for blocks under 10 ms, at most 200')
     ap.add_argument('--pmc', action='store_true',
                     help='N = 1: first collect the HBM-traffic and MFMA counters of this build and configuration by re-running '
                          'under rocprofv3 --pmc (one pass per counter set, a few minutes), write profiles/pmc_<config>_<precision>.json, '
@@ -227,26 +232,35 @@ class Leg:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(self, steps, warmup, dev):
-        """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize; max over ranks."""
+    def timed(self, steps, warmup, dev, repeats=0):
+        """W untimed steps, then blocks of EXACTLY `steps` steps, each between barrier + synchronize, max over ranks per
+        block.  Returns (median block seconds, [all block seconds]).  One 20-step block of the metric's shape is 10 ms of
+        device time -- the clock the part settles at moves a single sample by +-3 %; the median of >= 25 blocks does not."""
         for _ in range(warmup):
             self.step()
-        self.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
-        self.sync()
-        dt = time.perf_counter() - t0
-        if self.world > 1:
-            import torch.distributed as dist
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        blocks = []
+        n_blocks = max(1, repeats)
+        while len(blocks) < n_blocks:
+            self.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.sync()
+            dt = time.perf_counter() - t0
+            if self.world > 1:
+                import torch.distributed as dist
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            blocks.append(dt)
+            if repeats == 0 and len(blocks) == 1:
+                # every rank derives the same count from the (max-reduced) first block
+                n_blocks = int(min(200, max(25 if dt < 0.010 else 3, np.ceil(0.25 / max(dt, 1e-6)))))
         assert self.eng.valid_steps() == self.H, 'numerical failure inside the benchmark rollout'
         assert bool(torch.isfinite(self.params).all()) and bool(torch.isfinite(self.loss_buf).all())
         if self.fused:      # every optimiser step was taken (the device-side counter says so)
             assert int(self.step_dev.item()) == self.n, (int(self.step_dev.item()), self.n)
-        return dt
+        return float(np.median(blocks)), blocks
 
     def kernel_ms(self, n):
         """Per-kernel durations (HIP events on the launch stream), outside the timed region.  Every rank runs these
@@ -307,6 +321,31 @@ class Leg:
         return r, kname
 
 
+def sclk_mhz(leg):
+    """Shader clock the part ran the sweep at, right after the timed region: cycle counter against the constant 100 MHz
+    clock, both stamped by workgroup 0 at entry and exit of ONE instrumented forward launch (register-resident family
+    only: slots 28..31 of pmbrl_plan_set_prof's buffer).  None where the running kernels carry no such stamps."""
+    import ctypes as C
+    from prob_mbrl_amd import _lib
+    try:
+        eng = leg.eng
+        if not eng.info.get('reg'):
+            return None
+        H = eng.H
+        pf = torch.zeros(H * 32, dtype=torch.int64, device=leg.params.device)
+        pb = torch.zeros(H * 32, dtype=torch.int64, device=leg.params.device)
+        _lib.check(eng.lib.pmbrl_plan_set_prof(eng.plan, C.c_void_p(pf.data_ptr()), C.c_void_p(pb.data_ptr())), 'prof')
+        for _ in range(3):
+            eng.forward(**leg.args)
+        torch.cuda.synchronize()
+        _lib.check(eng.lib.pmbrl_plan_set_prof(eng.plan, C.c_void_p(0), C.c_void_p(0)), 'prof')
+        a = pf.cpu().numpy().reshape(H, 32)
+        cyc, us = float(a[0, 31] - a[0, 30]), float(a[0, 29] - a[0, 28]) / 100.0
+        return round(cyc / us, 1) if us > 0 and cyc > 0 else None
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def build_id():
     from prob_mbrl_amd import _lib
     return _lib.load().pmbrl_build_id().decode()
@@ -330,8 +369,12 @@ def collect_pmc(a, prec):
     from collections import defaultdict
     sets = [['FETCH_SIZE'], ['WRITE_SIZE'], ['MfmaUtil'], ['SQ_INSTS_VALU_MFMA_MOPS_F16', 'SQ_INSTS_VALU_MFMA_MOPS_BF16']]
     steps = 3 if a.config.startswith('stress') else 6
-    inner = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', str(steps), '--warmup', '2',
-             '--no-cpu-baseline', '--no-f32-twin', '--timing-steps', '1']
+    warm, tsteps, reps = 2, 1, 1
+    # bench iterations of one pass: warm-up + the timed block(s) + the timing steps; --replay 0: every launch is a kernel
+    # dispatch the counters see, never a node of a replayed hipGraph
+    iters = warm + steps * reps + tsteps
+    inner = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', str(steps), '--warmup', str(warm),
+             '--repeats', str(reps), '--replay', '0', '--no-sclk', '--no-cpu-baseline', '--no-f32-twin', '--timing-steps', str(tsteps)]
     if a.precision:
         inner += ['--precision', a.precision]
     if a.rows_per_wg:
@@ -361,16 +404,48 @@ def collect_pmc(a, prec):
         kernels[k] = dict(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w,
                           hbm_bytes_per_launch=(2.0 * (f or 0.0) + (w or 0.0)) * 1024.0 if (f is not None or w is not None) else None,
                           mfma_util_pct=mean(c.get('MfmaUtil')), flops_issued_per_launch=mops * 512.0,
-                          launches=len(c.get('FETCH_SIZE', [])),
-                          # (bench iterations of a pass: warm-up + timed + the timing step; the sweeps of the one-launch-per-step
-                          #  forms are many launches under one timer)
-                          launches_per_iteration=len(c.get('FETCH_SIZE', [])) / float(steps + 2 + 1))
+                          launches=len(c.get('FETCH_SIZE', [])), iterations_per_pass=iters,
+                          # (the sweeps of the one-launch-per-step forms are many launches under one timer)
+                          launches_per_iteration=len(c.get('FETCH_SIZE', [])) / float(iters))
     out = dict(build_id=build_id(), config=a.config, precision=prec, command=' '.join(inner[1:]),
                note='rocprofv3 --pmc, one pass per counter set: %s; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at '
                     '64 bytes), WRITE_SIZE as reported (KiB); means over the launches of a pass' % '; '.join(' '.join(c) for c in sets),
                kernels=kernels)
     os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
     json.dump(out, open(pmc_path(a.config, prec), 'w'), indent=1)
+    return out
+
+
+def pmc_by_timer(pmc, timings, top=3):
+    """Achieved HBM GB/s of the `top` longest phases of an iteration: the counter file's per-kernel HBM bytes (x launches per
+    iteration), grouped under the library timer that brackets the kernel, over that timer's HIP-event duration in THIS run."""
+    def timer_of(k):
+        if 'dw_reduce' in k:
+            return 'dw_reduce'
+        if 'pm_dw' in k:
+            return 'dw'
+        if 'reward' in k:
+            return 'reward'
+        if 'fwd' in k:
+            return 'fwd'
+        if 'bwd' in k:
+            return 'bwd'
+        if 'pack' in k:
+            return 'pack'
+        return None
+    acc = {}
+    for k, c in pmc['kernels'].items():
+        t = timer_of(k)
+        if t is None or c.get('hbm_bytes_per_launch') is None:
+            continue
+        e = acc.setdefault(t, dict(bytes=0.0, kernels=[]))
+        e['bytes'] += c['hbm_bytes_per_launch'] * max(1.0, round(c.get('launches_per_iteration') or 1.0))
+        e['kernels'].append(k)
+    out = {}
+    for t in sorted((t for t in acc if timings.get(t, 0.0) > 0.0), key=lambda t: -timings[t])[:top]:
+        gbps = acc[t]['bytes'] / (timings[t] * 1e-3) / 1e9
+        out[t] = dict(kernels=sorted(acc[t]['kernels']), hbm_bytes_per_iteration=acc[t]['bytes'], ms=round(timings[t], 4),
+                      hbm_gbps=round(gbps, 1), frac_of_8tbps=round(gbps / 8000.0, 4))
     return out
 
 
@@ -393,7 +468,31 @@ def pmc_lookup(config, prec, kname, world, fresh=None):
     k = pmc['kernels'].get(kname)
     if k is None:
         return dict(available=False, source=src, reason='kernel %s not in the measurement' % kname)
-    return dict(available=True, measured_in_run=fresh is not None, source=src, build_id=pmc['build_id'], **k)
+    return dict(available=True, measured_in_run=fresh is not None, source=src, build_id=pmc['build_id'], _all=pmc, **k)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
+    torch.distributed.run, rendezvous on 127.0.0.1 at a free port.  The children inherit stdout / stderr (rank 0 prints
+    the one JSON line); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# DESIGN.md section 5: what the weak curve should look like if the one exposed 163 KiB all-reduce per iteration costs what a
+# ring over xGMI is expected to cost (2 (N - 1) hops of 2-3 us) -- kept in the line so that the record can be checked
+# against it
+PREDICTED_WEAK = {2: dict(ms_per_step=0.50, value=10.0e6, efficiency=0.94), 4: dict(ms_per_step=0.51, value=19.5e6, efficiency=0.92),
+                  8: dict(ms_per_step=0.53, value=37.9e6, efficiency=0.89)}
 
 
 def main():
@@ -406,6 +505,10 @@ def main():
         d = PB.synthetic_problem(a.config, seed=0, data_seed=0)
         print(json.dumps(cpu_baseline(d)))
         return
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher -- one process per GPU through
+        # torch.distributed.run on this node, rank 0's JSON line comes out of this process's stdout
+        sys.exit(self_launch(a.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     dist = None
     if world > 1:
@@ -415,7 +518,8 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=a.dist_backend, rank=rank, world_size=world)
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    assert world == a.gpus, ('WORLD_SIZE=%d but --gpus %d: start as `python bench.py --gpus N` (launches itself) or under '
+                             'torch.distributed.run --nproc-per-node N' % (world, a.gpus))
     dev = torch.device('cuda:%d' % local_rank)
     torch.cuda.set_device(dev)
 
@@ -490,7 +594,7 @@ def main():
         fresh_pmc = collect_pmc(a, a.precision or _E.get_precision())
     primary = a.scaling if world > 1 else 'weak'
     leg = make_leg(primary, a.precision)
-    dt = leg.timed(a.steps, a.warmup, dev)
+    dt, blocks = leg.timed(a.steps, a.warmup, dev, a.repeats)
     timings = leg.kernel_ms(a.timing_steps)
     eng, d, B, Bg, H = leg.eng, leg.d, leg.B, leg.Bg, leg.H
     prec = eng.info['precision']
@@ -500,11 +604,13 @@ def main():
         # the other scaling curve in the same invocation, timed the same way
         other = 'strong' if primary == 'weak' else 'weak'
         leg2 = make_leg(other, a.precision)
-        dt2 = leg2.timed(a.steps, a.warmup, dev)
+        dt2, blocks2 = leg2.timed(a.steps, a.warmup, dev, a.repeats)
         rows = torch.tensor([leg2.B], device=dev, dtype=torch.int64)
         lst = [torch.zeros_like(rows) for _ in range(world)]
         dist.all_gather(lst, rows)
         extra[other] = dict(value=leg2.Bg * a.steps / dt2, unit='rollouts/s', ms_per_step=dt2 / a.steps * 1e3,
+                            value_min=leg2.Bg * a.steps / max(blocks2), value_max=leg2.Bg * a.steps / min(blocks2),
+                            timed_blocks=len(blocks2),
                             global_rows=leg2.Bg, rows_per_gpu=[int(x.item()) for x in lst], steps=a.steps,
                             warmup=a.warmup, workgroups_rank0=leg2.eng.info['n_wg'],
                             rows_per_wg=leg2.eng.info['rows_per_wg'])
@@ -512,10 +618,12 @@ def main():
     if world == 1 and prec != 'f32' and not a.no_f32_twin:
         # the exact-fp32 MFMA path on the same problem in the same invocation (the reference's arithmetic)
         leg3 = make_leg('weak', 'f32')
-        dt3 = leg3.timed(a.steps, a.warmup, dev)
+        dt3, blocks3 = leg3.timed(a.steps, a.warmup, dev, a.repeats)
         t3 = leg3.kernel_ms(a.timing_steps)
         r3, _ = leg3.roofline(t3)
         extra['f32'] = dict(value=leg3.Bg * a.steps / dt3, unit='rollouts/s', ms_per_step=dt3 / a.steps * 1e3,
+                            value_min=leg3.Bg * a.steps / max(blocks3), value_max=leg3.Bg * a.steps / min(blocks3),
+                            timed_blocks=len(blocks3),
                             steps=a.steps, warmup=a.warmup, dtype='f32 (v_mfma_f32_16x16x4_f32)',
                             kernel_ms={k: round(vv, 4) for k, vv in t3.items()}, roofline=r3)
         del leg3
@@ -534,7 +642,8 @@ def main():
                         hbm_frac_of_8tbps=(traffic * max(1.0, round(pm.get('launches_per_iteration') or 1.0)) /
                                            (roof['avg_launch_ms'] * 1e-3) / 8e12) if traffic else None,
                         mfma_counters=dict(mfma_util_pct=pm['mfma_util_pct'], flops_issued_per_launch=pm['flops_issued_per_launch'],
-                                           measured_in_run=pm['measured_in_run']))
+                                           measured_in_run=pm['measured_in_run']),
+                        hbm_top3=pmc_by_timer(pm['_all'], timings))
         else:
             roof.update(traffic=None, traffic_measured_in_run=False, traffic_source=None,
                         traffic_unavailable=(pm or {}).get('reason', 'N > 1'), mfma_counters=None)
@@ -545,6 +654,10 @@ def main():
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
             higher_is_better=True, scaling=primary, vs_baseline=None, dtype=dtype,
             data='synthetic',
+            # `value` = the MEDIAN of `timed_blocks` blocks of exactly `steps` steps each (every block bracketed by barrier +
+            # synchronize, max over ranks); the spread is the clock the part settles at
+            value_min=Bg * a.steps / max(blocks), value_max=Bg * a.steps / min(blocks), timed_blocks=len(blocks),
+            timed_seconds=float(sum(blocks)), sclk_mhz=None if a.no_sclk else sclk_mhz(leg),
             config=dict(workload='%s: D=%d U=%d pol=%s dyn=%s rows/GPU=%d (%s) H=%d mm=%s; full '
                                  'iteration = rollout fwd + loss + adjoint + dW + %sclip + Adam' %
                                  (a.config, d['x0'].shape[1], d['pol_z'].shape[1],
@@ -562,6 +675,13 @@ def main():
             kernel_ms={k: round(vv, 4) for k, vv in timings.items()},
             roofline=roof)
         if world > 1:
+            out['scaling_note'] = ('`value` is the %s curve: ' % primary) + (
+                'every rank owns its own %d rows (global batch N x %d = %d rows); the STRONG curve -- the 100 x 25 = 2 500 rows '
+                'BASELINE.json\'s metric names, dealt over the N ranks -- is under `strong` and is flat by construction: a '
+                'sweep is %d sequential steps whatever the row count per GPU' % (B, B, Bg, H) if primary == 'weak' else
+                'the %d rows of the metric dealt over the ranks; the weak curve (N x 2 500 rows) is under `weak`' % Bg)
+            if a.config == 'cartpole_nomm' and world in PREDICTED_WEAK:
+                out['predicted'] = dict(weak=PREDICTED_WEAK[world], source='DESIGN.md section 5 (before any multi-GPU run)')
             out['allreduce_selfcheck'] = 'passed: %d floats summed over %d ranks, bit-identical to the closed form' % (41602, world)
             if transport_note:
                 out['transport_fallback'] = transport_note + ' -> RCCL'

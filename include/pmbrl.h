@@ -190,7 +190,9 @@ enum {
   PMBRL_INFO_REG = 16,       /* 1: the plain whole-horizon sweeps of this plan run on the register-resident family (pmbrl_reg.h) */
   PMBRL_INFO_REPLAY = 17,    /* 1: repeated calls of this plan are replayed as hipGraphs (pmbrl_plan_set_replay) */
   PMBRL_INFO_INPLACE = 18,   /* general family: 0 two activation buffers, 1 in-place layers (64-row workgroups), 2 the same on the 512-wide layers of pmbrl_wide.h */
-  PMBRL_INFO_COUNT = 19
+  PMBRL_INFO_REG_FWD_CALLS = 19, /* forward sweeps of this plan the register-resident family has served so far (a graph replay counts once, when recorded) */
+  PMBRL_INFO_REG_BWD_CALLS = 20, /* ... adjoint sweeps */
+  PMBRL_INFO_COUNT = 21
 };
 
 const char* pmbrl_last_error(void);
@@ -205,7 +207,8 @@ const char* pmbrl_build_id(void);
  * step: moment-matching groups beyond a workgroup, states wider than 6, the pipelined adjoint: C5 with moment matching is
  * 400+ launches per iteration); the sweeps of the cart-pole shapes are one launch each already.  Every buffer the calls
  * were given must stay where it was; the status word and the optimiser's step counter are read and written on the
- * device, so every replay is a new iteration.  Not capturable: a host-side collective (pmbrl_plan_set_collective). */
+ * device, so every replay is a new iteration.  Not capturable: a host-side collective (pmbrl_plan_set_collective) and the
+ * peer-to-peer all-reduce (pmbrl_p2p_allreduce_*: returns -4 on a recording stream). */
 typedef struct pmbrl_graph pmbrl_graph;
 int pmbrl_graph_capture_begin(void* stream);
 int pmbrl_graph_capture_end(void* stream, pmbrl_graph** graph_out);
@@ -410,7 +413,9 @@ int pmbrl_plan_set_collective(pmbrl_plan* plan, pmbrl_collective_fn fn, void* ct
  * sized for messages of up to max_bytes), exports a 64-byte handle (hipIpcGetMemHandle), the launcher carries the
  * handles to all ranks by any channel, every rank opens every peer's.  Ranks may be processes on different GPUs of
  * one node, or on ONE GPU (how the tests run it).  Waits are bounded: pmbrl_p2p_error reports a peer that never
- * arrived.  pmbrl_plan_set_p2p attaches it as the statistics exchange of a plan (like pmbrl_plan_set_comm). */
+ * arrived.  pmbrl_plan_set_p2p attaches it as the statistics exchange of a plan (like pmbrl_plan_set_comm).
+ * NOT capturable: pmbrl_p2p_allreduce_* returns -4 on a stream that is recording (pmbrl_graph_capture_begin): the
+ * generation its flags carry is a kernel argument, a replay would read stale slots. */
 #define PMBRL_P2P_HANDLE_BYTES 64
 #define PMBRL_P2P_MAX_RANKS 16
 typedef struct pmbrl_p2p pmbrl_p2p;

@@ -22,7 +22,7 @@ FLAG_GMM_EXACT_NOISE_GRAD = 256
 MAX_COMP = 8
 REWARD_EXP, REWARD_NEG = 0, 1
 PREC_F32, PREC_SPLIT, PREC_SPLIT_F16 = 0, 1, 2
-INFO_COUNT = 19
+INFO_COUNT = 21
 TIMER_COUNT = 8
 TIMER_NAMES = ['pack', 'fwd', 'bwd', 'dw', 'dw_reduce', 'reward']
 

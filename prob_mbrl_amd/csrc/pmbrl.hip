@@ -904,11 +904,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       for (int i = 1; i < p->dyn.nl; ++i) wide = wide && p->dyn.nt[i] == 32;
       if (const char* e = getenv("PMBRL_WIDE")) wide = wide && atoi(e) != 0;
       int cus = 0;
-      if (wide && c.rows_per_wg_hint == 0) {
-        hipDeviceProp_t pr;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-      }
+      if (wide && c.rows_per_wg_hint == 0)      // (of the device the plan is for, not of the current one)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
       const bool want = c.rows_per_wg_hint >= 64 || (wide && c.rows_per_wg_hint == 0 && cus > 0 && (c.B + 63) / 64 >= cus);
       if (want) {
         p->inplace = wide ? 2 : 1;
@@ -1192,6 +1189,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     }
   }
   p->reg = pm_reg_plan_ok(p) ? 1 : 0;
+  p->reg_mm = pm_reg_mm_width(p);
+  p->reg_bwd = !(getenv("PMBRL_REG_BWD") && atoi(getenv("PMBRL_REG_BWD")) == 0);      // (read once: a recorded call bakes the choice in)
   // workspace carve-up
   {
     size_t off = 0;
@@ -1239,7 +1238,8 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       p->xch_bytes = (size_t)(p->mm_parts > 8 ? 2 : 1) * p->nwg * PM_XCH_WG_WORDS(2) * sizeof(unsigned long long);
       p->off_xch = take(p->xch_bytes);
     }
-    p->off_ztab = take(p->mm_fan ? (size_t)c.H * p->G * 2 * c.D * sizeof(double) : 0);
+    p->off_ztab = take((p->mm_fan || p->reg_mm) ? (size_t)c.H * p->G * 2 * c.D * sizeof(double) : 0);
+    p->off_reg_linv = take(p->reg_mm ? (size_t)c.H * p->G * c.D * c.D * sizeof(double) : 0);
     p->off_grt = take((size_t)c.H * c.B * sizeof(float));
     {
       // statistics exchange of groups spread over ranks: forward slots of every rank (states of one step, or the
@@ -1255,7 +1255,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     p->off_part = take((size_t)std::max(p->dw_nsplit, p->pipe_K > 1 ? p->pipe_rows : 0) *
                        ((p->pol.n_params + 3) / 4 * 4) * sizeof(float));
     p->ws_bytes = off;
-    if (p->ws_bytes >= ((size_t)1 << 32)) p->reg = 0;      // (the family addresses its stashes with 32-bit workspace offsets)
+    if (p->ws_bytes >= ((size_t)1 << 32)) p->reg = p->reg_mm = 0;      // (the family addresses its stashes with 32-bit workspace offsets)
   }
   int rc2 = 0;
   if (!p->fast && p->prec) {
@@ -1328,17 +1328,21 @@ static void replay_drop(pmbrl_plan* p, int slot) {
   p->rp[slot].exec = nullptr;
   p->rp[slot].seen = 0;
 }
+// what makes two calls "the same": every argument byte, kept (a hash alone would replay a stale recording on a collision)
 struct ReplayKey {
   unsigned long long h = 1469598103934665603ull;
+  std::vector<unsigned char> bytes;
   void add(const void* q, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(q);
     for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    bytes.insert(bytes.end(), b, b + n);
   }
   template <class T> void val(const T& v) { add(&v, sizeof(T)); }
 };
 // body(): queues the call on s.  Returns its code; *replayed = the call went out as a graph launch.
 template <class Body>
-static int replay_call(pmbrl_plan* p, int slot, unsigned long long key, hipStream_t s, Body body) {
+static int replay_call(pmbrl_plan* p, int slot, const ReplayKey& K, hipStream_t s, Body body) {
+  const unsigned long long key = K.h;
   pmbrl_plan::ReplaySlot& R = p->rp[slot];
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   // (the legacy default stream cannot be asked, and cannot be recording)
@@ -1348,15 +1352,17 @@ static int replay_call(pmbrl_plan* p, int slot, unsigned long long key, hipStrea
     if (R.exec || R.seen) replay_drop(p, slot);
     return body(s);
   }
-  if (R.exec && R.key == key) {
+  const bool same = R.key == key && R.bytes == K.bytes;
+  if (R.exec && same) {
     HIPCHK(hipGraphLaunch(R.exec, s));
     ++R.launches;
     if (slot == 0) { p->old_pack_stale = R.aux & 1; p->abits_packed = (R.aux >> 1) & 1; }   // (the host-side notes the recorded call left: which families' weights it packed, the form of its activity bits)
     return 0;
   }
-  if (R.key != key || R.seen == 0) {      // first sight of these arguments: as usual, remember them
+  if (!same || R.seen == 0) {      // first sight of these arguments: as usual, remember them
     replay_drop(p, slot);
     R.key = key;
+    R.bytes = K.bytes;
     R.seen = 1;
     return body(s);
   }
@@ -1481,6 +1487,8 @@ extern "C" int pmbrl_plan_info(const pmbrl_plan* p, int32_t* info) {
   info[PMBRL_INFO_REG] = p->reg;
   info[PMBRL_INFO_REPLAY] = replay_wanted(p) ? 1 : 0;
   info[PMBRL_INFO_INPLACE] = p->inplace;
+  info[PMBRL_INFO_REG_FWD_CALLS] = p->reg_calls[0];
+  info[PMBRL_INFO_REG_BWD_CALLS] = p->reg_calls[1];
   return 0;
 }
 
@@ -1592,7 +1600,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.mm_grid = p->mm_grid;
   A.mm_parts = p->mm_parts;
   A.mm_fan = p->mm_fan;
-  A.mm_ztab = p->mm_fan ? reinterpret_cast<const double*>(ws + p->off_ztab) : nullptr;
+  A.mm_ztab = (p->mm_fan || p->reg_mm) ? reinterpret_cast<const double*>(ws + p->off_ztab) : nullptr;
   A.gsync = reinterpret_cast<unsigned*>(ws + p->off_gsync);
   A.xch = p->xch_bytes ? reinterpret_cast<unsigned long long*>(ws + p->off_xch) : nullptr;
   A.gx_carry_out = nullptr;
@@ -1750,7 +1758,7 @@ extern "C" int pmbrl_rollout_fwd(pmbrl_plan* p, void* stream, void* workspace, c
   ReplayKey K;
   K.val(stream); K.val(workspace); K.add(in, sizeof(*in));
   K.val(states_d); K.val(actions_d); K.val(rewards_d); K.val(status_d); K.val(p->loss_w); K.val(p->loss_out);
-  return replay_call(p, 0, K.h, (hipStream_t)stream, [&](hipStream_t on) {
+  return replay_call(p, 0, K, (hipStream_t)stream, [&](hipStream_t on) {
     return rollout_fwd_impl(p, on, workspace, in, states_d, actions_d, rewards_d, status_d);
   });
 }
@@ -1810,7 +1818,7 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
   } else if (p->mm_mode != 2) {
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
-    if (p->mm_fan) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
+    if (p->mm_fan || p->reg_mm) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
     if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     if (p->mm_parts > 1 && As.xch) HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));      // ... or the granules' tags
     if (pm_reg_can_run(p, As, true)) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);
@@ -2118,8 +2126,15 @@ static int rollout_bwd_replay(pmbrl_plan* p, void* stream, void* workspace, cons
   K.val(grad_pol_flat_d); K.val(grad_x0_d); K.val(action_grad_norms_d); K.val(status_d);
   const int has_opt = opt ? 1 : 0;
   K.val(has_opt);
-  if (opt) K.add(opt, sizeof(*opt));
-  return replay_call(p, 1, K.h, (hipStream_t)stream, [&](hipStream_t on) {
+  if (opt) {      // field by field: the struct's padding bytes are not arguments (a caller's stack copy need not repeat them)
+    K.val(opt->params_d); K.val(opt->exp_avg_d); K.val(opt->exp_avg_sq_d); K.val(opt->step_d);
+    K.val(opt->lr); K.val(opt->beta1); K.val(opt->beta2); K.val(opt->eps); K.val(opt->max_norm);
+    K.val(opt->norm_out_d); K.val(opt->expect_steps);
+  }
+  // what the forward call left behind decides which conversions the adjoint call queues (weights repacked for the other
+  // family, activity words unpacked): a recording is only good for the state it was recorded in
+  K.val(p->old_pack_stale); K.val(p->abits_packed);
+  return replay_call(p, 1, K, (hipStream_t)stream, [&](hipStream_t on) {
     return rollout_bwd(p, on, workspace, in, states_d, actions_d, rewards_d, grad_rewards_d, grad_states_d,
                        grad_actions_d, grad_pol_flat_d, grad_x0_d, action_grad_norms_d, status_d, opt);
   });

@@ -74,6 +74,9 @@ struct pmbrl_plan {
   int mm_fan;    // ... more than 8: parts per collector of the two-level sum exchange (0: one level)
   size_t off_ztab;   // ... and the noise standardisation of the whole group per step (pm_mm_ztable_kernel)
   int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
+  mutable int reg_calls[2];   // sweeps it has served: [0] forward, [1] adjoint (pmbrl_plan_info)
+  int reg_mm;    // ... including the sweeps that moment-match the states of split groups (pmbrl_reg_mm.h): state width, 0 = no
+  size_t off_reg_linv;   // [H][groups][D D] doubles: L^-1, forward sweep -> adjoint sweep
   size_t off_reg_pack;   // its packed weights in the workspace
   size_t off_reg_ab[2][2];   // its activity words [net][hidden layer]: [step][workgroup][wave][lane] x 32 bits (pmbrl_reg.h)
   int abits_packed;      // the last forward call left the activity bits in that form only (pm_reg_unpack_abits: -> NetPlan::abits)
@@ -82,7 +85,8 @@ struct pmbrl_plan {
   // time it is seen and launched as one graph from then on.  Slot 0: pmbrl_rollout_fwd, slot 1: pmbrl_rollout_bwd(_adam).
   int replay;            // 0 off, 1 the one-launch-per-step forms, 2 every form
   hipStream_t cap_stream;   // what the calls are recorded on
-  struct ReplaySlot { unsigned long long key; int seen, dead, aux; hipGraphExec_t exec; long long launches; } rp[2];
+  struct ReplaySlot { unsigned long long key; std::vector<unsigned char> bytes; int seen, dead, aux; hipGraphExec_t exec; long long launches; } rp[2];
+  int reg_bwd;   // PMBRL_REG_BWD at plan creation (0: the family's adjoint sweep is off -- debugging aid)
   // optional per-kernel timing (hipEvents on the caller's stream)
   long long* prof_fwd;
   long long* prof_bwd;
@@ -167,6 +171,7 @@ static inline int fast_variant(int RT, const RolloutArgs& A) {
 
 // register-resident family (pmbrl_reg.hip)
 bool pm_reg_plan_ok(const pmbrl_plan* p);
+int pm_reg_mm_width(const pmbrl_plan* p);
 size_t pm_reg_pack_bytes();
 int pm_reg_set_attr(const pmbrl_plan* p);
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd);

@@ -155,6 +155,13 @@ static int p2p_allreduce(pmbrl_p2p* p, void* stream, T* buf_d, int64_t n) {
   for (int q = 0; q < p->nranks; ++q)
     if (!p->region[q]) return pm_fail(-3, "pmbrl_p2p: a peer's buffer has not been opened");
   if (n == 0) return 0;
+  {
+    // not capturable: the generation the flags are compared with is a kernel ARGUMENT -- a replayed recording would find
+    // last time's flags already raised and add up stale slots
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return pm_fail(-4, "pmbrl_p2p: the peer-to-peer all-reduce cannot be recorded into a hipGraph (its generation counter is a kernel argument)");
+  }
   P2PArgs A;
   for (int q = 0; q < PM_P2P_MAX_RANKS; ++q) A.region[q] = q < p->nranks ? p->region[q] : nullptr;
   A.rank = p->rank; A.nranks = p->nranks; A.cap = p->cap; A.n = n; A.err = p->err_d;

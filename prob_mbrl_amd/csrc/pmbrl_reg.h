@@ -31,6 +31,7 @@
 #include <utility>
 #include "pmbrl_dev.h"
 #include "pmbrl_split.h"
+#include "pmbrl_reg_mm.h"
 
 #define PR_NW 4                 // waves per workgroup: one per SIMD
 #define PR_NTHR (PR_NW * 64)
@@ -72,7 +73,8 @@ __host__ __device__ constexpr int pr_xwave(int net) { return net; }
 #define PR_LDS_MF (PR_LDS_L0(2))
 #define PR_LDS_MFX (PR_LDS_MF + PR_NW * 2 * 2 * PR_SLOTS * PR_FRAG)
 #define PR_LDS_FLAG (PR_LDS_MFX + 2 * 2 * PR_FRAG)
-#define PR_LDS_FLOATS (PR_LDS_FLAG + 16)
+#define PR_LDS_XB (PR_LDS_FLAG + 16)             // [16 rows][8]: the moment-matched rows, wave 0 -> every wave
+#define PR_LDS_FLOATS (PR_LDS_XB + 128)
 
 struct RegNet {
   int w_off[3], b_off[3];       // offsets (floats) of W_l / b_l in the flat parameter vector
@@ -112,7 +114,19 @@ struct RegArgs {
   const float* gx_in;
   float* gx_out;
   long long* prof;
+  RegMM mm;                     // moment matching of states inside the sweep (pmbrl_reg_mm.h)
 };
+// rows of workgroup wg: 16 consecutive rows, or -- moment matching -- part wg % parts of group wg / parts
+__device__ __forceinline__ void pr_rows(const RegArgs& A, int wg, int& row0, int& nvalid) {
+  if (A.mm.on) {
+    const int gi = wg / A.mm.parts, me = wg - gi * A.mm.parts;
+    row0 = gi * A.mm.M + me * A.mm.rpw;
+    nvalid = min(A.mm.rpw, A.mm.M - me * A.mm.rpw);
+  } else {
+    row0 = wg * 16;
+    nvalid = min(16, A.B - row0);
+  }
+}
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void pr_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -543,10 +557,12 @@ __device__ __forceinline__ void pr_copy_net_to_lds(float* smem, int lds_l0, int 
     if (tid + k * PR_NTHR < N_HD) *reinterpret_cast<f32x4*>(smem + lds_head + (tid + k * PR_NTHR) * 4) = c[k];
 }
 
-template <bool PROF>
+// MMD: 0, or the state width of the instance that moment-matches the sampled states inside the sweep (pmbrl_reg_mm.h)
+template <bool PROF, int MMD = 0>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool F16 = true;
+  constexpr int MMDc = MMD ? MMD : 2;
   typedef PM_GLOBAL_ uint8_t gu8;
   typedef PM_GLOBAL_ float gf32;
   typedef PM_GLOBAL_ char gch;
@@ -554,8 +570,8 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
   const int row = lane & 15, g = lane >> 4;
-  const int row0 = wg * 16;
-  const int nvalid = min(16, A.B - row0);
+  int row0, nvalid;
+  pr_rows(A, wg, row0, nvalid);
   const bool rvalid = row < nvalid;
   const int D = A.D, U = A.U, B = A.B;
   const float* packed = A.packed;     // direction 0
@@ -657,6 +673,13 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     }
   }
   const float max_std_pol = expf(A.mls_pol), max_std_dyn = expf(A.mls_dyn);
+  // moment matching: wave 0's state across the steps -- the reference point's column lane & 15 (the first one: the
+  // group's first row, which every part can read) and the step's noise row / standardisation, requested a step ahead
+  const int mm_gi = MMD ? wg / A.mm.parts : 0, mm_me = MMD ? wg - mm_gi * A.mm.parts : 0, mm_g0 = mm_gi * (MMD ? A.mm.M : 0);
+  double mm_ref = 0.0;
+  if constexpr (MMD != 0) {
+    if (wid == 0) mm_ref = row < MMD ? (double)A.x0[(size_t)mm_g0 * D + row] : 0.0;
+  }
   unsigned amax = 0u;               // bit pattern of the largest magnitude that went into an fp16 piece so far
   const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
   float* const act_w = smem + PR_LDS_ACT + lane * 4;     // this lane's 16 bytes of every B fragment
@@ -803,6 +826,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   int so_st0 = (int)A.actT[0] + wg * 1024, so_st1 = (int)A.actT[1] + wg * (PR_NT * 1024), so_st2 = (int)A.actT[2] + wg * (PR_NT * 1024);
   int so_td = (int)A.Td, so_tp = (int)A.Tp;
   gch* b_states = (gch*)A.states + (size_t)B * D * 4u;     // x_{t+1}
+  gch* b_xt = (gch*)A.mm.xt;                               // x~_{t+1} (moment matching: the pre-mm sample)
   gch* b_actions = (gch*)A.actions;
   const int st_step0 = A.nwg * 1024, st_step = A.nwg * (PR_NT * 1024);
   const unsigned x_step = (unsigned)B * D * 4u, a_step = (unsigned)B * U * 4u;
@@ -851,6 +875,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     second_layer_and_head(std::integral_constant<int, 1>{}, (int)A.dyn.abits[1] + so_abp, 0, o);
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 4] = (long long)__builtin_readcyclecounter();
     // ---- sample the next state
+    float xs[2] = {0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (any_x[s]) {
@@ -860,10 +885,36 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         const float xn = x[s] + (mu * c_sy[s] + c_my[s] + c_zd[s] * e);
         if (wid == 0 && ok_x[s]) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], pr_uni(so_td), 0);
-          *(gf32*)(b_states + so_x[s]) = xn;
+          if constexpr (MMD != 0) *(gf32*)(b_xt + so_x[s]) = xn;      // the sample the reward sees; x_{t+1} is its moment-matched twin
+          else *(gf32*)(b_states + so_x[s]) = xn;
         }
         x[s] = ok_x[s] ? xn : 0.f;
+        xs[s] = x[s];
       }
+    }
+    if constexpr (MMD != 0) {
+      // ---- moment matching of the group's sampled states (utils/rollout.py:20-29): wave 0, the others wait
+      if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
+      if (wid == 0) {
+        float xo[2];
+        // (the lane index laundered per step: hoisted out of the horizon loop, the chain's per-lane constants -- masks as
+        //  doubles, addresses -- would sit in registers through the GEMM phases, which have none to spare)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lrow = min(ln & 15, nvalid - 1);
+        const bool ok = pr_mm_fwd_chain<MMDc>(A.mm, t, (unsigned)(t + 1), mm_gi, mm_g0, row0 - mm_g0 + lrow, mm_me,
+                                               mm_gi * A.mm.parts, nvalid, ln, xs, mm_ref, xo);
+        if (!ok && lane == 0) atomicMin(A.status, t);
+        *reinterpret_cast<f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g) = f32x2{xo[0], xo[1]};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          if (ok_x[s]) *(gf32*)(b_states + so_x[s]) = xo[s];
+      }
+      pr_barrier();
+      const f32x2 xm = *reinterpret_cast<const f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) x[s] = ok_x[s] ? xm[s] : 0.f;
+      if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 7] = (long long)__builtin_readcyclecounter();
     }
     // fp16 pieces: a value beyond the format's range was rounded to infinity somewhere in this step (or earlier)
     if (amax > 0x477fe000u) atomicMin(A.status, t);      // 65504
@@ -871,7 +922,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     so_abp += abp_step;
     so_st0 += st_step0; so_st1 += st_step; so_st2 += st_step;
     so_td += (int)x_step; so_tp += (int)a_step;
-    b_states += x_step; b_actions += a_step;
+    b_states += x_step; b_actions += a_step; b_xt += x_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
   }
   if (PROF && wg == 0 && tid == 0) {
@@ -883,13 +934,20 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
 // activity words -> the per-tile nibble bytes [step][row][tile][lane group] of pmbrl_fast.h
 struct RegUnpackArgs {
   int B, H, nwg;
+  int mm_on, M, parts, rpw;      // the workgroups' rows under moment matching (pr_rows)
   const unsigned* src[2][2];
   unsigned char* dst[2][2];
 };
 __global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegUnpackArgs U) {
   const int wg = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-  const int rowg = wg * 16 + (lane & 15), g = lane >> 4;
-  if (rowg >= U.B) return;
+  int row0 = wg * 16, nvalid = min(16, U.B - wg * 16);
+  if (U.mm_on) {
+    const int gi = wg / U.parts, me = wg - gi * U.parts;
+    row0 = gi * U.M + me * U.rpw;
+    nvalid = min(U.rpw, U.M - me * U.rpw);
+  }
+  const int rowg = row0 + (lane & 15), g = lane >> 4;
+  if ((lane & 15) >= nvalid) return;
   for (int n = 0; n < 2; ++n)
     for (int l = 0; l < 2; ++l) {
       const unsigned w = U.src[n][l][((size_t)t * U.nwg + wg) * PR_NTHR + tid];
@@ -920,19 +978,21 @@ __global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegU
 #define PRB_LDS_LUT (PRB_LDS_L0(2))              // [net][layer][16 nibbles][4]
 #define PRB_IN_COLS 32
 #define PRB_LDS_IN (PRB_LDS_LUT + 2 * 2 * 16 * 4)    // [16 rows][PRB_IN_COLS]: the step's per-row inputs
-#define PRB_LDS_FLOATS (PRB_LDS_IN + 16 * PRB_IN_COLS)
+#define PRB_LDS_XB (PRB_LDS_IN + 16 * PRB_IN_COLS)  // [16 rows][8]: dL/dx~ behind the moment matching's adjoint, wave 0 -> every wave
+#define PRB_LDS_FLOATS (PRB_LDS_XB + 128)
 
-template <bool PROF>
+template <bool PROF, int MMD = 0>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool F16 = false;
+  constexpr int MMDc = MMD ? MMD : 2;
   typedef PM_GLOBAL_ float gf32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
   const int row = lane & 15, g = lane >> 4;
-  const int row0 = wg * 16;
-  const int nvalid = min(16, A.B - row0);
+  int row0, nvalid;
+  pr_rows(A, wg, row0, nvalid);
   const bool rvalid = row < nvalid;
   const int D = A.D, U = A.U, B = A.B;
   const int T0 = A.t0;
@@ -1205,6 +1265,12 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     for (int w = 1; w < PR_NW; ++w) o += *reinterpret_cast<const f32x4*>(part + w * PR_FRAG);
   };
 
+  // moment matching: wave 0's inputs of the adjoint chain, requested a step ahead (pmbrl_reg_mm.h)
+  const int mm_gi = MMD ? wg / A.mm.parts : 0, mm_me = MMD ? wg - mm_gi * A.mm.parts : 0, mm_g0 = mm_gi * (MMD ? A.mm.M : 0);
+  float mm_z[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MMD != 0) {
+    if (wid == 0) pr_mm_bwd_fetch<MMDc>(A.mm, T1 - 1, mm_g0, row0, nvalid, lane, mm_z);
+  }
   // prologue: the last step's inputs and activity words
   unsigned abc[4], abn[4];
   stage_load();
@@ -1217,6 +1283,33 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 0] = (long long)__builtin_readcyclecounter();
     StepIn In;
     read_in(In);
+    if constexpr (MMD != 0) {
+      // ---- adjoint of the moment matching that produced x_{t+1}: dL/dx_{t+1} -> dL/dx~ (wave 0; the others wait).  The
+      // horizon's last step carries no gradient yet unless one was handed in (every part of a group skips it alike)
+      if (t < T1 - 1 || A.gx_in) {
+        if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
+        if (wid == 0) {
+          float go[(MMDc + 3) / 4];
+          int ln = lane;      // (laundered per step: see the forward sweep)
+          asm volatile("" : "+v"(ln));
+          const bool ok = pr_mm_bwd_chain<MMDc>(A.mm, B, t, (unsigned)(T1 - t), mm_gi, row0, mm_me, mm_gi * A.mm.parts, nvalid, ln,
+                                                 gx, mm_z, go);
+          if (!ok && lane == 0 && A.status) atomicMax(A.status, 1);
+#pragma unroll
+          for (int rr = 0; rr < (MMDc + 3) / 4; ++rr) smem[PRB_LDS_XB + row * 8 + g + 4 * rr] = go[rr];
+        }
+        pr_barrier();
+        const f32x2 gm = *reinterpret_cast<const f32x2*>(smem + PRB_LDS_XB + row * 8 + 2 * g);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gx[s] = ok_x[s] ? gm[s] : 0.f;
+        if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 7] = (long long)__builtin_readcyclecounter();
+      }
+      if (wid == 0 && t > T0) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        pr_mm_bwd_fetch<MMDc>(A.mm, t - 1, mm_g0, row0, nvalid, ln, mm_z);
+      }
+    }
     // the inputs of step t - 1: on their way while this step computes (the last step of the range asks for its own once
     // more: the count of operations in flight is the same at every step)
     if (t > T0) {

@@ -11,8 +11,18 @@ bool pm_reg_plan_ok(const pmbrl_plan* p) {
   if (const char* e = getenv("PMBRL_REG")) {
     if (atoi(e) == 0) return false;
   }
-  if (!p->fast || p->RT != 1 || p->prec != PMBRL_PREC_SPLIT_F16 || p->mm_mode != 0) return false;
+  if (!p->fast || p->RT != 1 || p->prec != PMBRL_PREC_SPLIT_F16) return false;
   if (c.flags & PMBRL_FLAG_NO_SHAPED) return false;
+  if (p->mm_mode != 0) {
+    // moment matching inside the sweep (pmbrl_reg_mm.h): the states of groups that are ONE workgroup of <= 16 rows or
+    // split over 2..8 of them with the statistics exchange; state widths 4..6.  (Moment matching of the rewards alone
+    // leaves the sweep plain but lays the rows out by groups: the latency-optimised family's.)
+    if (p->mm_mode != 1 || !(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS)) return false;
+    if (c.D < 4 || c.D > 6 || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16) return false;
+    if (p->mm_parts <= 1 && p->rows_per_wg != p->M) return false;      // (several whole groups per workgroup: not here)
+    if (getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0) return false;
+    if (getenv("PMBRL_REG_MM") && atoi(getenv("PMBRL_REG_MM")) == 0) return false;
+  }
   if (p->pol.nl != 3 || p->dyn.nl != 3) return false;
   const int hid = p->pol.dim[1];
   if (p->pol.dim[2] != hid || p->dyn.dim[1] != hid || p->dyn.dim[2] != hid) return false;
@@ -24,17 +34,28 @@ bool pm_reg_plan_ok(const pmbrl_plan* p) {
 
 size_t pm_reg_pack_bytes() { return (size_t)PR_PACK_FLOATS * sizeof(float); }
 
-int pm_reg_set_attr(const pmbrl_plan* p) {
-  (void)p;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<false>),
+// state width of the moment-matching instance this plan's sweeps run on (0: the plain instance)
+int pm_reg_mm_width(const pmbrl_plan* p) { return (p->reg && p->mm_mode == 1) ? p->cfg.D : 0; }
+
+template <int MMD>
+static int reg_set_attr_mm() {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<false, MMD>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true, MMD>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<false>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<false, MMD>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<true>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<true, MMD>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
   return 0;
+}
+int pm_reg_set_attr(const pmbrl_plan* p) {
+  switch (p->reg_mm) {
+    case 4: return reg_set_attr_mm<4>();
+    case 5: return reg_set_attr_mm<5>();
+    case 6: return reg_set_attr_mm<6>();
+    default: return reg_set_attr_mm<0>();
+  }
 }
 
 static void reg_net(const pmbrl_plan* p, int net, const NetPlan& n, const NetDev& d, RegNet& r) {
@@ -72,15 +93,30 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
   R.gx_in = A.gx_from_carry ? A.gx_carry : nullptr;
   R.gx_out = (A.gx_carry && A.t0 > 0) ? A.gx_carry : nullptr;
   R.prof = A.prof;
+  memset(&R.mm, 0, sizeof(R.mm));
+  if (p->reg_mm) {
+    R.mm.on = 1;
+    R.mm.M = p->M; R.mm.parts = p->mm_parts; R.mm.rpw = p->rows_per_wg; R.mm.groups = p->G;
+    R.mm.Bg = A.Bg; R.mm.row_off = A.row_off; R.mm.flags = A.flags;
+    R.mm.zmm = A.zmm;
+    R.mm.ztab = A.mm_ztab;
+    R.mm.mmfac = A.mmfac;
+    R.mm.linv = reinterpret_cast<double*>(ws + p->off_reg_linv);
+    R.mm.xt = A.xt;
+    R.mm.xch = A.xch;
+    R.mm.inv_m = 1.0 / (double)p->M;
+    R.mm.inv_m1 = 1.0 / (double)(p->M - 1);
+  }
 }
 
 // this launch can go to the family: the whole horizon in one launch, nothing optional asked for (what the LEAN
 // variant of pmbrl_fast.h serves)
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd) {
-  if (!p->reg || A.mm_mode != 0) return false;
-  if (!fwd && getenv("PMBRL_REG_BWD") && atoi(getenv("PMBRL_REG_BWD")) == 0) return false;
+  if (!p->reg || (A.mm_mode != 0) != (p->reg_mm != 0)) return false;
+  if (!fwd && !p->reg_bwd) return false;
   const bool ext = A.grad_states || A.grad_actions || A.agn || A.zpol_ss != 0 || A.zdyn_ss != 0 ||
-                   (A.flags & PMBRL_FLAG_MM_STATES) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
+                   (((A.flags & PMBRL_FLAG_MM_STATES) != 0) != (p->reg_mm != 0)) || A.t0 != 0 || A.t1 != A.H || A.gx_from_carry;
+  if (p->reg_mm && p->mm_parts > 1 && !A.xch) return false;
   return !ext;
 }
 
@@ -108,6 +144,7 @@ void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, 
 void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s) {
   RegUnpackArgs U;
   U.B = p->cfg.B; U.H = p->cfg.H; U.nwg = p->nwg;
+  U.mm_on = p->reg_mm ? 1 : 0; U.M = p->M; U.parts = p->mm_parts; U.rpw = p->rows_per_wg;
   const NetPlan* nets[2] = {&p->pol, &p->dyn};
   for (int n = 0; n < 2; ++n)
     for (int l = 0; l < 2; ++l) {
@@ -117,19 +154,30 @@ void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s) {
   hipLaunchKernelGGL(pm_reg_unpack_abits_kernel, dim3(p->nwg, p->cfg.H), dim3(PR_NTHR), 0, s, U);
 }
 
+template <int MMD>
+static void reg_launch_mm(const pmbrl_plan* p, const RegArgs& R, hipStream_t s, bool fwd) {
+  if (fwd) {
+    if (R.prof) hipLaunchKernelGGL((pm_reg_fwd_kernel<true, MMD>), dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_fwd_kernel<false, MMD>), dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+  } else {
+    if (R.prof) hipLaunchKernelGGL((pm_reg_bwd_kernel<true, MMD>), dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_bwd_kernel<false, MMD>), dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+  }
+}
+
 void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
                    hipStream_t s, bool fwd) {
+  ++p->reg_calls[fwd ? 0 : 1];
   RegArgs R;
   reg_args(p, ws, A, reinterpret_cast<const float*>(ws + p->off_reg_pack), pol_params, dyn_params, R);
   if (getenv("PMBRL_REG_DEBUG"))
     fprintf(stderr, "pm_reg_launch %s: off_reg_pack %zu gT %zu %zu %zu actT %zu %zu %zu abits %zu %zu %zu %zu ws_bytes %zu\n", fwd ? "fwd" : "bwd",
             p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
             p->off_reg_ab[0][0], p->off_reg_ab[0][1], p->off_reg_ab[1][0], p->off_reg_ab[1][1], p->ws_bytes);
-  if (fwd) {
-    if (R.prof) hipLaunchKernelGGL(pm_reg_fwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL(pm_reg_fwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
-  } else {
-    if (R.prof) hipLaunchKernelGGL(pm_reg_bwd_kernel<true>, dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL(pm_reg_bwd_kernel<false>, dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+  switch (p->reg_mm) {
+    case 4: reg_launch_mm<4>(p, R, s, fwd); break;
+    case 5: reg_launch_mm<5>(p, R, s, fwd); break;
+    case 6: reg_launch_mm<6>(p, R, s, fwd); break;
+    default: reg_launch_mm<0>(p, R, s, fwd); break;
   }
 }

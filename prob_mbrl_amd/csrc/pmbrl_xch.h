@@ -1,0 +1,81 @@
+// Statistics exchange between the workgroups that share a moment-matching group (data-tagged 8-byte granules; no
+// flag, no barrier, no row exchange).  Used by the latency-optimised sweeps (pmbrl_fast.h) and by the register-resident
+// family's moment-matching instances (pmbrl_reg.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#ifndef PM_GLOBAL
+#define PM_GLOBAL __attribute__((address_space(1)))
+#endif
+
+// Statistics of a moment-matching group that is split over `parts` workgroups: every part computes the sums over its
+// OWN rows (relative to a reference point all parts share), and wave 0 of each adds up the parts' sums -- NV doubles
+// per lane, element-wise, in part order (so every part ends with the same bits).  The doubles travel as data-tagged
+// 8-byte granules {tag = k, 32 bits of the value} written by one device-scope store each and polled by the reader:
+// no flag, no barrier, no row exchange (cdna_hip_programming.md, Guideline 16, form R2).  xb: [nwg][2][NV][2][64]
+// granules, zeroed before every launch (tag 0 = nothing yet); the two sets alternate between steps -- a part
+// writes its step k + 2 only after it read everybody's k + 1, which was written after that part had read this k.
+// A wait that does not end (a partner that is not resident -- the host checks that all are) gives up after ~1 s.
+#define PM_XCH_WG_WORDS(NV) (2 * (NV) * 2 * 64)
+// More than PM_XCH_FLAT parts (one moment-matching group over the whole batch: 157 parts at 2 500 rows): TWO LEVELS.
+// Every `fan` consecutive parts have a collector (the first of them), which adds up their sums in part order and
+// publishes the result in a slot of its own (slot nwg + first + c: the buffer holds 2 x nwg slots); every part then
+// adds up the collectors' slots in collector order -- the same bits everywhere again, two hops of at most `fan` slots
+// each instead of one walk over every part's slot (157 x 2 KB per part and step).  Slots are polled in batches of 8
+// (all their granules requested before the first is looked at: one memory round trip a batch, not one a slot).
+// The alternation argument above holds level by level.
+#define PM_XCH_FLAT 8
+// publish this part's NV doubles per lane for step k (nothing is waited for: the stores are on their way)
+template <int NV>
+__device__ __forceinline__ void pm_xch_put(unsigned long long* xb, int first, int me, unsigned k, const double (&v)[NV],
+                                           int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  const unsigned long long tag = (unsigned long long)k << 32;
+  gu64* mine = (gu64*)xb + (size_t)(first + me) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+    __hip_atomic_store(mine + (2 * i) * 64, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + (2 * i + 1) * 64, tag | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// v <- the sum over all parts, in part order (v holds this part's own contribution on entry)
+template <int NV>
+__device__ __forceinline__ bool pm_xch_get(const unsigned long long* xb, int first, int parts, int me, unsigned k,
+                                           double (&v)[NV], int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  double tot[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+  bool ok = true;
+  for (int q = 0; q < parts; ++q) {
+    if (q == me) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) tot[i] += v[i];
+      continue;
+    }
+    const gu64* theirs = (const gu64*)xb + (size_t)(first + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+    unsigned long long g[2 * NV];
+    for (int spins = 0;;) {
+      bool here = true;
+#pragma unroll
+      for (int i = 0; i < 2 * NV; ++i) {
+        g[i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        here = here && (g[i] >> 32) == (unsigned long long)k;
+      }
+      if (__all(here)) break;
+      if (++spins > (1 << 19)) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) break;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      tot[i] += __longlong_as_double((long long)(((g[2 * i] & 0xffffffffull) << 32) | (g[2 * i + 1] & 0xffffffffull)));
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = tot[i];
+  return ok;
+}
+

@@ -221,9 +221,9 @@ def p2p_check(group=None, device=None):
         return
     key = (id(group), str(device))
     p2p = _P2PS.get(key)
-    if p2p is None:
-        return
-    bad = 1 if p2p.failed() else 0
+    # (a rank without the cached object still ENTERS the collective below: p2p_wanted() is the same on every rank, the
+    #  cache lookup need not be -- a rank that returned here would leave the others waiting in the all-reduce)
+    bad = 1 if (p2p is not None and p2p.failed()) else 0
     if dist.get_backend(group) == 'nccl':
         fl = torch.tensor([bad], dtype=torch.int32, device=device)
         dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)

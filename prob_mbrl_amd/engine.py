@@ -617,6 +617,12 @@ class Engine:
         _lib.check(self.lib.pmbrl_plan_info(self.plan, info), 'plan_info')
         self.info['replay'] = int(info[17])
 
+    def reg_calls(self):
+        """(forward sweeps, adjoint sweeps) of this plan that ran on the register-resident family (csrc/pmbrl_reg.h)."""
+        info = (C.c_int32 * _lib.INFO_COUNT)()
+        _lib.check(self.lib.pmbrl_plan_info(self.plan, info), 'plan_info')
+        return int(info[19]), int(info[20])
+
     def replay_count(self):
         """(forward calls, adjoint calls) that went out as one graph launch so far."""
         n = (C.c_int64 * 2)()
@@ -666,7 +672,9 @@ class Graph:
     and replayed with one launch.  fn may call Engine.forward (with out=...), weighted_sum (with out=...), backward,
     clip_adam_guarded, BnnStep ... -- anything that only QUEUES work on the current stream and allocates nothing (pass the
     output tensors in).  Where it pays: the sweeps that are one launch per step (moment-matching groups beyond a
-    workgroup, wide states), 200-400 launches per iteration."""
+    workgroup, wide states), 200-400 launches per iteration.  NOT recordable: collectives that go through the host
+    (Engine.attach_collective with a torch.distributed group) and the peer-to-peer all-reduce of distributed.P2P (its
+    generation counter is a kernel argument; the library call returns an error on a recording stream)."""
 
     def __init__(self, fn, warmup=1):
         self.lib = _lib.load()

@@ -431,8 +431,11 @@ def test_c5_full_size_parity_and_properties():
     print('C5 16384 rows, first 512 vs oracle: states %.2e grad %.2e (exact-fp32 path %.2e, reference fp32 vs fp64 %.2e)'
           % (e_s, e_g, e_g32, floor32))
     assert e_s < 2e-5
+    # the benchmarked (default, split) arithmetic holds the PLAIN bar (measured 4.3e-5): a regression towards round 3's
+    # 2.3e-4 must not pass.  The widened bar stays only for the exact-fp32 comparison path, whose distance to fp64 is the
+    # reference's own kind of rounding (5.6e-5 measured, against the reference's 9.6e-5)
+    assert e_g < 1e-4, e_g
     assert e_g32 < 1e-4 + floor32
-    assert e_g < 1e-4 + floor32
     # (d) linearity: the rest of the rows' gradient adds up to the whole
     g_rest = eng.backward(gw - _masked(gw, 512))[0].cpu().numpy().copy()
     assert common.rel(g_sub + g_rest, g) < 2e-6

@@ -2,6 +2,8 @@
 fixtures.  Tolerances: the north star asks for 1e-4 relative on trajectory cost
 and policy gradient; the tests hold the kernels to 2e-5 against the fp64
 reference values (fp32 MFMA + fp32 transcendentals)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,6 +142,49 @@ def test_rollout_parity(dev, name, generic):
     assert common.rel(g, d['ref64_grad']) < TOL_GRAD
     if 'ref32_grad' in d:
         assert common.rel(g, d['ref32_grad']) < TOL_GRAD + common.rel(d['ref32_grad'], d['ref64_grad'])
+
+
+def _reg_fixtures():
+    """fixtures whose shape the register-resident family takes (three-layer nets of hidden width 177..208, D + U <= 8)"""
+    out = []
+    for n in common.fixture_names('iter'):
+        d = np.load(os.path.join(common.GOLDEN, n + '.npz'))
+        if ('pol_W1' in d and int(d['pol_n_layers']) == 3 and int(d['dyn_n_layers']) == 3 and
+                176 < d['pol_W0'].shape[0] <= 208 and d['pol_W0'].shape[0] == d['dyn_W0'].shape[0]):
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize('name', _reg_fixtures())
+def test_rollout_parity_lean(dev, name):
+    """The HEADLINE kernels against reference-generated vectors: the plain call -- no optional outputs -- is what
+    bench.py and mc_pilco's fused iteration issue, and what the register-resident family (csrc/pmbrl_reg.h:
+    pm_reg_fwd_kernel / pm_reg_bwd_kernel) serves; test_rollout_parity above asks for dL/dx0 and the action-gradient
+    norms, which routes its adjoint to the latency-optimised family."""
+    d = common.load(name)
+    eng, args, _ = common.engine_from_fixture(d, dev)
+    if not eng.info['reg']:
+        pytest.skip('the register-resident family does not take this configuration (moment matching: %s)' % bool(d['mm_states']))
+    S, A, Rw = eng.forward(**args)
+    B = d['x0'].shape[0]
+    gw = torch.tensor(common.loss_weights(d, B), device=dev)
+    loss = float(eng.weighted_sum(Rw, gw))
+    g, _, _ = eng.backward(gw)
+    torch.cuda.synchronize()
+    assert eng.reg_calls() == (1, 1), eng.reg_calls()          # both sweeps ran on pm_reg_*
+    assert eng.valid_steps() == int(d['H'])
+    assert common.rel(S.cpu().numpy(), d['ref64_states']) < TOL_TRAJ
+    assert common.rel(A.cpu().numpy(), d['ref64_actions']) < TOL_TRAJ
+    assert common.rel(Rw.cpu().numpy().reshape(d['ref64_rewards'].shape), d['ref64_rewards']) < TOL_TRAJ
+    assert abs(loss - float(d['ref64_loss'])) <= TOL_TRAJ * abs(float(d['ref64_loss']))
+    assert common.rel(g.cpu().numpy(), d['ref64_grad']) < TOL_GRAD
+    # ... and the other family from the same stashes: same trajectory bit for bit is not promised (different K order),
+    # the gradient agrees far inside the bar
+    g_reg = g.cpu().numpy().copy()
+    g2, _, _ = eng.backward(gw, want_x0=True, want_agn=True)
+    torch.cuda.synchronize()
+    assert eng.reg_calls() == (1, 1)                           # that call did NOT run on the family
+    assert common.rel(g2.cpu().numpy(), g_reg) < 2e-5
 
 
 @pytest.mark.parametrize('name', [n for n, g in _PARITY_CASES if g])

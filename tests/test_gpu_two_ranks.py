@@ -31,7 +31,7 @@ def test_bench_two_ranks_one_device():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device']
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device', '--repeats', '1']
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -46,12 +46,30 @@ def test_bench_two_ranks_one_device():
     assert 'rccl_ranks' in out and out['rccl_ranks'] is None      # gloo here: no RCCL communicator to ask
 
 
+def test_bench_launches_itself_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver that knows nothing of
+    torch.distributed.run would start the scaling run): the script becomes its own launcher, rank 0 prints the one JSON
+    line, and the line says which curve `value` is and what DESIGN.md predicted for it."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--timing-steps', '1',
+           '--dist-backend', 'gloo', '--one-device', '--repeats', '2']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['timed_blocks'] == 2
+    assert out['value_min'] <= out['value'] <= out['value_max']
+    assert 'weak curve' in out['scaling_note'] or '`value` is the weak' in out['scaling_note']
+    assert out['predicted']['weak']['value'] == 10.0e6 and out['strong']['global_rows'] == 2500
+
+
 def test_bench_three_ranks_uneven_strong_split():
     """100 moment-matching groups over 3 ranks: 34 / 33 / 33 whole groups (strong curve), 3 x 2500 rows (weak)."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '1', '--config', 'cartpole_mm',
-           '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device']
+           '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device', '--repeats', '1']
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
@@ -65,7 +83,7 @@ def test_bench_two_ranks_strong_scaling():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--scaling', 'strong',
-           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device']
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device', '--repeats', '1']
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
@@ -78,7 +96,7 @@ def test_bench_two_ranks_one_global_moment_matching_group():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', 'cartpole_mm',
-           '--mm-global', '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device']
+           '--mm-global', '--timing-steps', '1', '--dist-backend', 'gloo', '--one-device', '--repeats', '1']
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
@@ -342,7 +360,7 @@ def test_bench_two_ranks_p2p_transport_one_device():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--transport', 'p2p',
-           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device', '--no-second-curve']
+           '--timing-steps', '2', '--dist-backend', 'gloo', '--one-device', '--repeats', '1', '--no-second-curve']
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
