@@ -197,6 +197,7 @@ class Leg:
             self.eng.set_replay(a.replay)
         self.gw = torch.tensor(PB.loss_weights(d, Bg)[:, :self.B].copy(), device=dev)
         self.params = self.args['pol_flat'].clone()
+        self.params0 = self.params.clone()
         self.args['pol_flat'] = self.params
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
@@ -225,6 +226,13 @@ class Leg:
             self.allreduce(g)
         self.E.clip_adam(self.params, g, self.m, self.v, self.n, 1e-4, max_norm=1.0)
 
+    def restart(self):
+        self.params.copy_(self.params0)
+        self.m.zero_()
+        self.v.zero_()
+        self.step_dev.zero_()
+        self.n = 0
+
     def sync(self):
         torch.cuda.synchronize()
         if self.world > 1:
@@ -241,6 +249,10 @@ class Leg:
         blocks = []
         n_blocks = max(1, repeats)
         while len(blocks) < n_blocks:
+            # every block is the SAME work: the optimiser restarts from the initial parameters (a few hundred Adam steps on
+            # a synthetic problem would otherwise walk the policy to where a group's particles collapse and the moment
+            # matching loses its pivot -- a truncated horizon, which is less work per step); outside the timed region
+            self.restart()
             self.sync()
             t0 = time.perf_counter()
             for _ in range(steps):

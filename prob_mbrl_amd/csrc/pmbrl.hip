@@ -824,17 +824,27 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       // that bring a part down to 16 rows while every workgroup stays resident, else to 32 rows.
       // PMBRL_MM_PARTS=n: n parts wherever that can be done (tests); 1: whole groups.
       const bool big = !p->span && ((p->mm_mode == 1 && p->RT >= 2) || p->mm_mode == 2 || (e && p->mm_mode == 1));
-      auto fits = [&](int parts, int max_rows) {
+      auto fits = [&](int parts, int max_rows, bool resident = true) {
         const int rpw = (p->M + parts - 1) / parts;      // the last part takes what is left of the group
-        return rpw <= max_rows && (parts - 1) * rpw < p->M && p->G * parts <= max_wg;
+        return rpw <= max_rows && (parts - 1) * rpw < p->M && (!resident || p->G * parts <= max_wg);
       };
       int want = 0;
+      // Round 5: 16-row parts even where they are more workgroups than CUs (the double cart-pole shape: 100 groups of 50
+      // rows = 400 parts of <= 13 rows) IF the register-resident family takes the shape (pmbrl_reg_mm.h) -- its 16-row step
+      // is a third of the latency-optimised family's 32-row step, so two launches of 200 workgroups (batches of whole groups:
+      // what the statistics exchange needs resident together is one GROUP's workgroups) beat one launch of 200 32-row ones
+      bool batched = false;
       if (e) want = atoi(e);
       else {
         for (int parts = 2; parts <= 8 && !want; ++parts) if (fits(parts, 16)) want = parts;
+        if (!want && max_wg >= 64 && pm_reg_mm_shape_ok(p, prec_for(1)) && !getenv("PMBRL_MM_NO_BATCH"))
+          for (int parts = 2; parts <= 8 && !want; ++parts)
+            if (fits(parts, 16, false) && p->G * parts <= 1024) { want = parts; batched = true; }
         for (int parts = 2; parts <= 8 && !want; ++parts) if (fits(parts, 32)) want = parts;
       }
-      if (p->fast && want >= 2 && want <= 8 && big && p->M <= 128 && fits(want, 32) && (c.flags & PMBRL_FLAG_MM_STATES)) {
+      p->mm_gpb = 0;
+      if (p->fast && want >= 2 && want <= 8 && big && p->M <= 128 && (batched ? fits(want, 16, false) : fits(want, 32)) &&
+          (c.flags & PMBRL_FLAG_MM_STATES)) {
         const int rpw = (p->M + want - 1) / want;
         const int rt = rpw <= 16 ? 1 : 2;
         if (lds_need(rt, c.D, want) <= lds_cap) {
@@ -842,6 +852,10 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
           p->mm_parts = want;
           p->RT = rt;
           p->rows_per_wg = rpw;
+          if (batched) {      // balanced batches of whole groups, each batch's workgroups resident together
+            const int nb = (p->G * want + max_wg - 1) / max_wg;
+            p->mm_gpb = (p->G + nb - 1) / nb;
+          }
         }
       }
       // A group beyond 8 parts of 32 rows -- ONE group over the whole batch, the reference's default (mm_groups=None,
@@ -1684,10 +1698,17 @@ template <int RT>
 static void launch_bwd(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   hipLaunchKernelGGL(pm_rollout_bwd<RT>, dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
-static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
-  if (p->prec == PMBRL_PREC_SPLIT_F16) return pm_fast_split2_launch(p, A, s, fwd);
-  if (p->prec) return pm_fast_split1_launch(p, A, s, fwd);
-  pm_fast_f32_launch(p, A, s, fwd);
+static void launch_fast_rt(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t s, bool fwd) {
+  // (more groups than fit the chip at once: batches of whole groups, one launch each -- pmbrl_host.h, mm_gpb)
+  const int per = (p->mm_gpb > 0 && A0.mm_mode == 1) ? p->mm_gpb * p->mm_parts : p->nwg;
+  for (int w0 = 0; w0 < p->nwg; w0 += per) {
+    RolloutArgs A = A0;
+    A.wg0 = w0;
+    A.launch_wg = std::min(per, p->nwg - w0);
+    if (p->prec == PMBRL_PREC_SPLIT_F16) pm_fast_split2_launch(p, A, s, fwd);
+    else if (p->prec) pm_fast_split1_launch(p, A, s, fwd);
+    else pm_fast_f32_launch(p, A, s, fwd);
+  }
 }
 static void launch_fwd_rt(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s) {
   if (p->fast) return launch_fast_rt(p, A, s, true);

@@ -147,6 +147,9 @@ struct RolloutArgs {
   // the workgroups of a group exchange their rows through HBM and meet at a group-local flag barrier
   // (pmbrl_fast.h, pm_group_sync); every one of them factors the whole group, each keeps its own rows
   int mm_parts;
+  // more groups than fit the chip at once (the statistics exchange needs every workgroup of a group resident): the launch
+  // covers the groups in batches; wg0 = first workgroup of this launch's batch (workgroup = blockIdx.x + wg0)
+  int wg0, launch_wg;      // (launch_wg: workgroups of this launch; 0 = nwg)
   // ... more than 8 parts: the sums travel over two levels (pm_xch_get) -- mm_fan consecutive parts per collector;
   // the z standardisation of the whole group then comes from mm_ztab ([H][groups][zm (D) | zi (D)] doubles,
   // pm_mm_ztable_kernel) instead of every part walking the group's noise rows

@@ -159,12 +159,12 @@ __device__ __forceinline__ bool pm_grid_barrier(unsigned* flags, unsigned k) {
 // + parts)): a handful of flags to poll instead of every workgroup's -- the device-wide barrier costs ~11 us at
 // 250 workgroups, this one a memory round trip.  Needs the group's workgroups resident together (the host
 // checks that ALL are, as for the device-wide barrier); a wait that does not end poisons the group's flags.
-__device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int parts, unsigned k) {
+__device__ __forceinline__ bool pm_group_sync(unsigned* flags, int self, int first, int parts, unsigned k) {
   bool ok = true;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_fetch_max(flags + blockIdx.x, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(flags + self, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x < 64) {
     const int w = first + ((int)threadIdx.x < parts ? (int)threadIdx.x : 0);
     long long spins = 0;
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool pm_group_sync(unsigned* flags, int first, int pa
         break;
       }
     }
-    if (__hip_atomic_load(flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) ok = false;
+    if (__hip_atomic_load(flags + self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) ok = false;
   }
   __syncthreads();
   return ok;
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x + A.wg0;
   const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
   // (a group split over mm_parts workgroups: part p owns rows [p * rows_per_wg, ...) of its group, the last
   //  part what is left of the group's M rows)
@@ -2031,7 +2031,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_fwd_fast(const RolloutArg
       // every workgroup of the group has its sampled rows of this step in A.xt once the group has met; each of
       // them then matches the moments of the WHOLE group (redundantly: the d x d chain is serial anyway) and
       // keeps its own rows
-      if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(t - T0 + 1)) && tid == 0) atomicMin(A.status, t);
+      if (!pm_group_sync(A.gsync, wg, mmp_first, A.mm_parts, (unsigned)(t - T0 + 1)) && tid == 0) atomicMin(A.status, t);
       PF_MARK(28);
       const float* xg = A.xt + ((size_t)t * B + mmp_g0) * D;
       for (int i = tid; i < A.M * D; i += PF_NT) mmg[i] = pm_ldc<true>(xg + i);
@@ -2132,7 +2132,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
   constexpr int R = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x + A.wg0;
   const int rows_per_wg = MM ? A.rows_per_wg : 16 * RT;   // whole groups under MM, else full tiles
   // (a group split over mm_parts workgroups: part p owns rows [p * rows_per_wg, ...) of its group, the last
   //  part what is left of the group's M rows)
@@ -2499,7 +2499,7 @@ __global__ __launch_bounds__(PF_NT, 2) void pm_rollout_bwd_fast(const RolloutArg
         if (SH::D >= 1 && SH::D <= 6 && A.M <= 64 && wid == 0)
           for (int e = lane; e < (int)pm_mm_fac_doubles(D); e += 64) L.mm[e] = fac[e];
       }
-      if (!pm_group_sync(A.gsync, mmp_first, A.mm_parts, (unsigned)(T1 - t)) && tid == 0 && A.status) atomicMax(A.status, 1);
+      if (!pm_group_sync(A.gsync, wg, mmp_first, A.mm_parts, (unsigned)(T1 - t)) && tid == 0 && A.status) atomicMax(A.status, 1);
       for (int i = tid; i < A.M * D; i += PF_NT) mmg[2 * A.M * D + i] = pm_ldc<true>(carry + (size_t)mmp_g0 * D + i);
       __syncthreads();
       if (wid == 0) {

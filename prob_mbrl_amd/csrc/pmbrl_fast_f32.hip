@@ -39,7 +39,7 @@ template <int RT, int CA, int CB>
 static void launch_fast(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
   const int var = fast_variant(RT, A);
   const bool mm = var == PF_VAR_MM, ext = var == PF_VAR_EXT, mmg = var == PF_VAR_MMG;
-  const dim3 g(p->nwg), b(PF_NT);
+  const dim3 g(A.launch_wg > 0 ? A.launch_wg : p->nwg), b(PF_NT);
   // a shape-specialised instantiation if there is one for this plan
 #define PM_FAST_SHAPED(RTV, CAV, CBV, VARV, DV, UV, LDV, NLV, NTV)                                             \
   if (RT == RTV && CA == CAV && CB == CBV && var == VARV && A.D == DV && A.U == UV && A.LD == LDV &&        \

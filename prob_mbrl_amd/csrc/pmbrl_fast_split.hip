@@ -55,7 +55,7 @@ static int set_attr_split(size_t lds) {
 template <int RT, int CA, int CB, int PR>
 static void launch_split(const pmbrl_plan* p, const RolloutArgs& A0, hipStream_t s, bool fwd) {
   const int var = fast_variant(RT, A0);
-  const dim3 g(p->nwg), b(PF_NT);
+  const dim3 g(A0.launch_wg > 0 ? A0.launch_wg : p->nwg), b(PF_NT);
   RolloutArgs A = A0;
   // Register-resident first tiles (pmbrl_fast.h, resident_tile_s): the 16-row plain variants keep output
   // tile `wave` of the sweep's first streamed layer in registers when a tile is exactly one stage pair and

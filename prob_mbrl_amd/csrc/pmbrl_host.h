@@ -71,6 +71,8 @@ struct pmbrl_plan {
   int inplace;   // general family on split operands: 64-row workgroups with in-place layers (pm_rollout_fwd<4, 2, true>)
   int mm_wide;   // mm_mode 2 through the LDS-staged kernels for 6 < D <= 32 (pmbrl_mm_wide.h)
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
+  int mm_gpb;    // ... launched in batches of this many groups (0: all at once) -- more workgroups than CUs, and the
+                 // statistics exchange needs a group's workgroups resident together
   int mm_fan;    // ... more than 8: parts per collector of the two-level sum exchange (0: one level)
   size_t off_ztab;   // ... and the noise standardisation of the whole group per step (pm_mm_ztable_kernel)
   int reg;       // the register-resident family (pmbrl_reg.h) serves this plan's plain whole-horizon launches
@@ -171,6 +173,8 @@ static inline int fast_variant(int RT, const RolloutArgs& A) {
 
 // register-resident family (pmbrl_reg.hip)
 bool pm_reg_plan_ok(const pmbrl_plan* p);
+bool pm_reg_shape_ok(const pmbrl_plan* p, int prec1);
+bool pm_reg_mm_shape_ok(const pmbrl_plan* p, int prec1);
 int pm_reg_mm_width(const pmbrl_plan* p);
 size_t pm_reg_pack_bytes();
 int pm_reg_set_attr(const pmbrl_plan* p);

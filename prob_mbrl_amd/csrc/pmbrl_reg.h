@@ -27,6 +27,7 @@
 // Arithmetic: pmbrl_split.h's -- forward two fp16 pieces (low weight piece scaled by 2^11, own accumulator chain),
 // adjoint two bf16 pieces.  Reference: utils/rollout.py:95-152, models/core.py:221-303, models/modules.py:46-160.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 #include <utility>
 #include "pmbrl_dev.h"
@@ -74,7 +75,8 @@ __host__ __device__ constexpr int pr_xwave(int net) { return net; }
 #define PR_LDS_MFX (PR_LDS_MF + PR_NW * 2 * 2 * PR_SLOTS * PR_FRAG)
 #define PR_LDS_FLAG (PR_LDS_MFX + 2 * 2 * PR_FRAG)
 #define PR_LDS_XB (PR_LDS_FLAG + 16)             // [16 rows][8]: the moment-matched rows, wave 0 -> every wave
-#define PR_LDS_FLOATS (PR_LDS_XB + 128)
+#define PR_LDS_ZH (PR_LDS_XB + 128)              // [2][16 rows][<= 6] doubles: standardised noise rows, wave 1 -> wave 0
+#define PR_LDS_FLOATS (PR_LDS_ZH + 2 * PR_MM_ZH_DOUBLES(6))
 
 struct RegNet {
   int w_off[3], b_off[3];       // offsets (floats) of W_l / b_l in the flat parameter vector
@@ -115,7 +117,14 @@ struct RegArgs {
   float* gx_out;
   long long* prof;
   RegMM mm;                     // moment matching of states inside the sweep (pmbrl_reg_mm.h)
+  int wg0;                      // first workgroup of this launch (groups launched in batches: workgroup = blockIdx.x + wg0)
 };
+// the moment-matching arguments where the launch put them, in the kernel-argument segment (NOT &A.mm: the address of a
+// by-value kernel argument makes the compiler copy the whole struct to scratch)
+__device__ __forceinline__ const RegMM* pr_mm_args() {
+  typedef __attribute__((address_space(4))) const char* kcp;
+  return (const RegMM*)((kcp)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RegArgs, mm));
+}
 // rows of workgroup wg: 16 consecutive rows, or -- moment matching -- part wg % parts of group wg / parts
 __device__ __forceinline__ void pr_rows(const RegArgs& A, int wg, int& row0, int& nvalid) {
   if (A.mm.on) {
@@ -508,7 +517,15 @@ __device__ __forceinline__ float pr_rcp(float d) {
 }
 // tanh through one exponential: absolute error ~1e-7 (what a = scale tanh(u) + bias needs; near zero the RELATIVE
 // error is larger, which nothing here divides by)
-__device__ __forceinline__ float pr_tanh(float u) { return 1.f - 2.f * pr_rcp(1.f + expf(2.f * u)); }
+// (|u| clamped to 15: tanh is +-1 to fp32 there already, and exp(2 u) overflows at u = 44 -- the reciprocal's Newton step
+//  turns an infinity into a NaN: a policy that saturates hard, the double cart-pole shape late in the horizon, produced NaN
+//  actions here until round 5)
+__device__ __forceinline__ float pr_tanh(float u) {
+  return 1.f - 2.f * pr_rcp(1.f + expf(2.f * __builtin_amdgcn_fmed3f(u, -15.f, 15.f)));
+}
+// logistic function of x = ls - max_log_std through the same reciprocal: the exponent clamped for the same reason
+// (sigma(-80) = 2e-35: zero to everything downstream)
+__device__ __forceinline__ float pr_sigmoid_neg(float y) { return pr_rcp(1.f + expf(fminf(y, 80.f))); }
 
 // epilogue arithmetic of one hidden tile: h = max(v mf, 0) (mf = dropout multiplier >= 0), activity nibble, running
 // maximum (fp16 range check), piece pairs.  Branch-free by construction: nothing here turns into an exec-masked region.
@@ -568,7 +585,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   typedef PM_GLOBAL_ char gch;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x + A.wg0;
   const int row = lane & 15, g = lane >> 4;
   int row0, nvalid;
   pr_rows(A, wg, row0, nvalid);
@@ -677,8 +694,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   // group's first row, which every part can read) and the step's noise row / standardisation, requested a step ahead
   const int mm_gi = MMD ? wg / A.mm.parts : 0, mm_me = MMD ? wg - mm_gi * A.mm.parts : 0, mm_g0 = mm_gi * (MMD ? A.mm.M : 0);
   double mm_ref = 0.0;
+  double* const mm_zh = reinterpret_cast<double*>(smem + PR_LDS_ZH);
   if constexpr (MMD != 0) {
     if (wid == 0) mm_ref = row < MMD ? (double)A.x0[(size_t)mm_g0 * D + row] : 0.0;
+    if (wid == 1) pr_mm_fwd_prep<MMDc>(A.mm, 0, mm_gi, mm_g0, row0, nvalid, mm_me, lane, mm_zh);
   }
   unsigned amax = 0u;               // bit pattern of the largest magnitude that went into an fp16 piece so far
   const bool xw_pol = wid == pr_xwave(0), xw_dyn = wid == pr_xwave(1);
@@ -705,6 +724,9 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       hl[s] = (_Float16)(in[s] - (float)hh[s]);
       hs[s] = hh[s] * (_Float16)PM_F16_LO_ISCALE;
       amax = max(amax, __float_as_uint(in[s]) & 0x7fffffffu);
+#ifdef PR_EXP_AMAX_CODE
+      if (!(fabsf(in[s]) <= 3.0e38f)) atomicMin(A.status, -((NET + 1) * 1000000 + lane * 1000 + s * 100 + wg));
+#endif
     }
     const pm_f16x8 bf = {hh[0], hl[0], hs[0], hh[1], hl[1], hs[1], (_Float16)1.0f, (_Float16)PM_F16_LO_ISCALE};
     const float* l0w = smem + PR_LDS_L0(NET) + lane * 4;
@@ -826,7 +848,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   int so_st0 = (int)A.actT[0] + wg * 1024, so_st1 = (int)A.actT[1] + wg * (PR_NT * 1024), so_st2 = (int)A.actT[2] + wg * (PR_NT * 1024);
   int so_td = (int)A.Td, so_tp = (int)A.Tp;
   gch* b_states = (gch*)A.states + (size_t)B * D * 4u;     // x_{t+1}
-  gch* b_xt = (gch*)A.mm.xt;                               // x~_{t+1} (moment matching: the pre-mm sample)
+  int so_xt = (int)A.mm.xt_off;                            // x~_{t+1} (moment matching: the pre-mm sample), in the workspace
   gch* b_actions = (gch*)A.actions;
   const int st_step0 = A.nwg * 1024, st_step = A.nwg * (PR_NT * 1024);
   const unsigned x_step = (unsigned)B * D * 4u, a_step = (unsigned)B * U * 4u;
@@ -856,7 +878,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       float v = x[s];
       if (any_a[s]) {
         const float mu = o[2 * s], ls = o[2 * s + 1];
-        const float sg = pr_rcp(1.f + expf(A.mls_pol - ls));
+        const float sg = pr_sigmoid_neg(A.mls_pol - ls);
         const float e = max_std_pol * sg;
         const float u = mu + c_zp[s] * e;
         const float a = c_psc[s] * pr_tanh(u) + c_pbi[s];
@@ -880,12 +902,13 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     for (int s = 0; s < 2; ++s) {
       if (any_x[s]) {
         const float mu = o[2 * s], ls = o[2 * s + 1];
-        const float sg = pr_rcp(1.f + expf(A.mls_dyn - ls));
+        const float sg = pr_sigmoid_neg(A.mls_dyn - ls);
         const float e = max_std_dyn * c_sy[s] * sg;
         const float xn = x[s] + (mu * c_sy[s] + c_my[s] + c_zd[s] * e);
         if (wid == 0 && ok_x[s]) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], pr_uni(so_td), 0);
-          if constexpr (MMD != 0) *(gf32*)(b_xt + so_x[s]) = xn;      // the sample the reward sees; x_{t+1} is its moment-matched twin
+          // (moment matching: the sample the reward sees goes to its own stash; x_{t+1} is its moment-matched twin)
+          if constexpr (MMD != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn), srd, so_x[s], pr_uni(so_xt), 0);
           else *(gf32*)(b_states + so_x[s]) = xn;
         }
         x[s] = ok_x[s] ? xn : 0.f;
@@ -895,15 +918,25 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     if constexpr (MMD != 0) {
       // ---- moment matching of the group's sampled states (utils/rollout.py:20-29): wave 0, the others wait
       if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
+      // (the lane index laundered per step: hoisted out of the horizon loop, the chain's per-lane constants -- masks as
+      //  doubles, addresses -- would sit in registers through the GEMM phases, which have none to spare)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      // (... and the moment matching's arguments re-read from the kernel-argument segment per step: a dozen pointers and
+      //  counts held in scalar registers across the loop are what the loop's own uniform offsets were spilled for)
+      const RegMM* Qp = pr_mm_args();
+      asm volatile("" : "+s"(Qp));
+      const RegMM Q = *Qp;      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
+      if (wid == 1 && t + 1 < A.H) {
+        // (idle otherwise) the next step's standardised noise rows
+        pr_mm_fwd_prep<MMDc>(Q, t + 1, mm_gi, mm_g0, row0, nvalid, mm_me, ln, mm_zh + ((t + 1) & 1) * (16 * MMDc));
+        if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 13] = (long long)__builtin_readcyclecounter();
+      }
       if (wid == 0) {
         float xo[2];
-        // (the lane index laundered per step: hoisted out of the horizon loop, the chain's per-lane constants -- masks as
-        //  doubles, addresses -- would sit in registers through the GEMM phases, which have none to spare)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int lrow = min(ln & 15, nvalid - 1);
-        const bool ok = pr_mm_fwd_chain<MMDc>(A.mm, t, (unsigned)(t + 1), mm_gi, mm_g0, row0 - mm_g0 + lrow, mm_me,
-                                               mm_gi * A.mm.parts, nvalid, ln, xs, mm_ref, xo);
+        const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
+                                               mm_zh + (t & 1) * (16 * MMDc), xo,
+                                               (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
         *reinterpret_cast<f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g) = f32x2{xo[0], xo[1]};
 #pragma unroll
@@ -917,12 +950,16 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 7] = (long long)__builtin_readcyclecounter();
     }
     // fp16 pieces: a value beyond the format's range was rounded to infinity somewhere in this step (or earlier)
+#ifdef PR_EXP_AMAX_CODE
+    if (amax > 0x477fe000u) atomicMin(A.status, -1);
+#else
     if (amax > 0x477fe000u) atomicMin(A.status, t);      // 65504
+#endif
     // next step's bases
     so_abp += abp_step;
     so_st0 += st_step0; so_st1 += st_step; so_st2 += st_step;
     so_td += (int)x_step; so_tp += (int)a_step;
-    b_states += x_step; b_actions += a_step; b_xt += x_step;
+    b_states += x_step; b_actions += a_step; so_xt += (int)x_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
   }
   if (PROF && wg == 0 && tid == 0) {
@@ -979,7 +1016,9 @@ __global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegU
 #define PRB_IN_COLS 32
 #define PRB_LDS_IN (PRB_LDS_LUT + 2 * 2 * 16 * 4)    // [16 rows][PRB_IN_COLS]: the step's per-row inputs
 #define PRB_LDS_XB (PRB_LDS_IN + 16 * PRB_IN_COLS)  // [16 rows][8]: dL/dx~ behind the moment matching's adjoint, wave 0 -> every wave
-#define PRB_LDS_FLOATS (PRB_LDS_XB + 128)
+#define PRB_LDS_MMB (PRB_LDS_XB + 128)              // [2][4][64] doubles: the noise operand, wave 1 -> wave 0 (pmbrl_reg_mm.h)
+#define PRB_LDS_MMY (PRB_LDS_MMB + 2 * 2 * PR_MM_BOP_DOUBLES)    // [2][3 NK][64] doubles: Y1 | L | L^-T, wave 2 -> wave 0
+#define PRB_LDS_FLOATS (PRB_LDS_MMY + 2 * 2 * PR_MM_YOP_DOUBLES(6))
 
 template <bool PROF, int MMD = 0>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
@@ -989,7 +1028,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
   typedef PM_GLOBAL_ float gf32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x + A.wg0;
   const int row = lane & 15, g = lane >> 4;
   int row0, nvalid;
   pr_rows(A, wg, row0, nvalid);
@@ -1267,9 +1306,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
 
   // moment matching: wave 0's inputs of the adjoint chain, requested a step ahead (pmbrl_reg_mm.h)
   const int mm_gi = MMD ? wg / A.mm.parts : 0, mm_me = MMD ? wg - mm_gi * A.mm.parts : 0, mm_g0 = mm_gi * (MMD ? A.mm.M : 0);
-  float mm_z[4] = {0.f, 0.f, 0.f, 0.f};
+  double* const mm_bop = reinterpret_cast<double*>(smem + PRB_LDS_MMB);
+  double* const mm_yop = reinterpret_cast<double*>(smem + PRB_LDS_MMY);
   if constexpr (MMD != 0) {
-    if (wid == 0) pr_mm_bwd_fetch<MMDc>(A.mm, T1 - 1, mm_g0, row0, nvalid, lane, mm_z);
+    if (wid == 1) pr_mm_bwd_prep_noise<MMDc>(A.mm, T1 - 1, mm_gi, mm_g0, row0, nvalid, lane, mm_bop + ((T1 - 1) & 1) * PR_MM_BOP_DOUBLES);
+    if (wid == 2) pr_mm_bwd_prep_factor<MMDc>(A.mm, B, T1 - 1, mm_gi, row0, nvalid, lane, mm_yop + ((T1 - 1) & 1) * PR_MM_YOP_DOUBLES(MMDc));
   }
   // prologue: the last step's inputs and activity words
   unsigned abc[4], abn[4];
@@ -1286,14 +1327,28 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
     if constexpr (MMD != 0) {
       // ---- adjoint of the moment matching that produced x_{t+1}: dL/dx_{t+1} -> dL/dx~ (wave 0; the others wait).  The
       // horizon's last step carries no gradient yet unless one was handed in (every part of a group skips it alike)
-      if (t < T1 - 1 || A.gx_in) {
-        if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
+      const bool do_chain = t < T1 - 1 || A.gx_in;
+      int ln = lane;      // (laundered per step, the arguments re-read per step: see the forward sweep)
+      asm volatile("" : "+v"(ln));
+      const RegMM* Qp = pr_mm_args();
+      asm volatile("" : "+s"(Qp));
+      const RegMM Q = *Qp;      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
+      if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
+      if (wid == 1 && t > T0) {
+        // (idle otherwise) what step t - 1's chain needs that does not wait for the recursion: its noise operand ...
+        pr_mm_bwd_prep_noise<MMDc>(Q, t - 1, mm_gi, mm_g0, row0, nvalid, ln, mm_bop + ((t - 1) & 1) * PR_MM_BOP_DOUBLES);
+        if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 13] = (long long)__builtin_readcyclecounter();
+      } else if (wid == 2 && t > T0) {
+        // ... and, from the forward sweep's factor, Y1 = L^-1 Delta^T and the factor in operand layout
+        pr_mm_bwd_prep_factor<MMDc>(Q, B, t - 1, mm_gi, row0, nvalid, ln, mm_yop + ((t - 1) & 1) * PR_MM_YOP_DOUBLES(MMDc));
+        if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 14] = (long long)__builtin_readcyclecounter();
+      }
+      if (do_chain) {
         if (wid == 0) {
           float go[(MMDc + 3) / 4];
-          int ln = lane;      // (laundered per step: see the forward sweep)
-          asm volatile("" : "+v"(ln));
-          const bool ok = pr_mm_bwd_chain<MMDc>(A.mm, B, t, (unsigned)(T1 - t), mm_gi, row0, mm_me, mm_gi * A.mm.parts, nvalid, ln,
-                                                 gx, mm_z, go);
+          const bool ok = pr_mm_bwd_chain<MMDc>(Q, (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
+                                                 mm_bop + (t & 1) * PR_MM_BOP_DOUBLES, mm_yop + (t & 1) * PR_MM_YOP_DOUBLES(MMDc), go,
+                                                 (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
           if (!ok && lane == 0 && A.status) atomicMax(A.status, 1);
 #pragma unroll
           for (int rr = 0; rr < (MMDc + 3) / 4; ++rr) smem[PRB_LDS_XB + row * 8 + g + 4 * rr] = go[rr];
@@ -1303,11 +1358,6 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
 #pragma unroll
         for (int s = 0; s < 2; ++s) gx[s] = ok_x[s] ? gm[s] : 0.f;
         if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 7] = (long long)__builtin_readcyclecounter();
-      }
-      if (wid == 0 && t > T0) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        pr_mm_bwd_fetch<MMDc>(A.mm, t - 1, mm_g0, row0, nvalid, ln, mm_z);
       }
     }
     // the inputs of step t - 1: on their way while this step computes (the last step of the range asks for its own once

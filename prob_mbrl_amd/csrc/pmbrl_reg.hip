@@ -1,4 +1,5 @@
 // Register-resident sweep kernels (pmbrl_reg.h): weight packer, attribute setup and launch dispatch.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -6,29 +7,43 @@
 #include "pmbrl_reg.h"
 
 // does this plan's shape fit the family?  (decided once, at plan creation)
-bool pm_reg_plan_ok(const pmbrl_plan* p) {
+// the shape alone (networks, widths, arithmetic): what the plan asks BEFORE it settles rows per workgroup and the split of
+// the moment-matching groups, so that it can lay the groups out for this family
+bool pm_reg_shape_ok(const pmbrl_plan* p, int prec1) {
   const pmbrl_config& c = p->cfg;
   if (const char* e = getenv("PMBRL_REG")) {
     if (atoi(e) == 0) return false;
   }
-  if (!p->fast || p->RT != 1 || p->prec != PMBRL_PREC_SPLIT_F16) return false;
-  if (c.flags & PMBRL_FLAG_NO_SHAPED) return false;
-  if (p->mm_mode != 0) {
-    // moment matching inside the sweep (pmbrl_reg_mm.h): the states of groups that are ONE workgroup of <= 16 rows or
-    // split over 2..8 of them with the statistics exchange; state widths 4..6.  (Moment matching of the rewards alone
-    // leaves the sweep plain but lays the rows out by groups: the latency-optimised family's.)
-    if (p->mm_mode != 1 || !(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS)) return false;
-    if (c.D < 4 || c.D > 6 || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16) return false;
-    if (p->mm_parts <= 1 && p->rows_per_wg != p->M) return false;      // (several whole groups per workgroup: not here)
-    if (getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0) return false;
-    if (getenv("PMBRL_REG_MM") && atoi(getenv("PMBRL_REG_MM")) == 0) return false;
-  }
+  if (!p->fast || prec1 != PMBRL_PREC_SPLIT_F16 || (c.flags & PMBRL_FLAG_NO_SHAPED)) return false;
   if (p->pol.nl != 3 || p->dyn.nl != 3) return false;
   const int hid = p->pol.dim[1];
   if (p->pol.dim[2] != hid || p->dyn.dim[1] != hid || p->dyn.dim[2] != hid) return false;
   if ((hid + 15) / 16 != PR_NT) return false;
   if (c.D + c.U > 8 || p->pol.dim[0] != c.D || p->dyn.dim[0] != c.D + c.U) return false;
   if (p->pol.dim[3] != 2 * c.U || p->dyn.dim[3] != 2 * c.D) return false;
+  return true;
+}
+// ... and what its moment-matching instances take of a configuration (state width, flags, switches)
+bool pm_reg_mm_shape_ok(const pmbrl_plan* p, int prec1) {
+  const pmbrl_config& c = p->cfg;
+  if (!pm_reg_shape_ok(p, prec1)) return false;
+  if (!(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS) || c.D < 4 || c.D > 6) return false;
+  if (getenv("PMBRL_MM_XCH") && atoi(getenv("PMBRL_MM_XCH")) == 0) return false;
+  if (getenv("PMBRL_REG_MM") && atoi(getenv("PMBRL_REG_MM")) == 0) return false;
+  return true;
+}
+
+bool pm_reg_plan_ok(const pmbrl_plan* p) {
+  const pmbrl_config& c = p->cfg;
+  if (!pm_reg_shape_ok(p, p->prec) || p->RT != 1) return false;
+  if (p->mm_mode != 0) {
+    // moment matching inside the sweep (pmbrl_reg_mm.h): the states of groups that are ONE workgroup of <= 16 rows or
+    // split over 2..8 of them with the statistics exchange; state widths 4..6.  (Moment matching of the rewards alone
+    // leaves the sweep plain but lays the rows out by groups: the latency-optimised family's.)
+    if (p->mm_mode != 1 || !(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS)) return false;
+    if (!pm_reg_mm_shape_ok(p, p->prec) || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16) return false;
+    if (p->mm_parts <= 1 && p->rows_per_wg != p->M) return false;      // (several whole groups per workgroup: not here)
+  }
   return true;
 }
 
@@ -103,6 +118,7 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
     R.mm.mmfac = A.mmfac;
     R.mm.linv = reinterpret_cast<double*>(ws + p->off_reg_linv);
     R.mm.xt = A.xt;
+    R.mm.xt_off = (unsigned)p->off_xt;
     R.mm.xch = A.xch;
     R.mm.inv_m = 1.0 / (double)p->M;
     R.mm.inv_m1 = 1.0 / (double)(p->M - 1);
@@ -155,13 +171,13 @@ void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s) {
 }
 
 template <int MMD>
-static void reg_launch_mm(const pmbrl_plan* p, const RegArgs& R, hipStream_t s, bool fwd) {
+static void reg_launch_mm(int nwg, const RegArgs& R, hipStream_t s, bool fwd) {
   if (fwd) {
-    if (R.prof) hipLaunchKernelGGL((pm_reg_fwd_kernel<true, MMD>), dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL((pm_reg_fwd_kernel<false, MMD>), dim3(p->nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    if (R.prof) hipLaunchKernelGGL((pm_reg_fwd_kernel<true, MMD>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_fwd_kernel<false, MMD>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
   } else {
-    if (R.prof) hipLaunchKernelGGL((pm_reg_bwd_kernel<true, MMD>), dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL((pm_reg_bwd_kernel<false, MMD>), dim3(p->nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    if (R.prof) hipLaunchKernelGGL((pm_reg_bwd_kernel<true, MMD>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_bwd_kernel<false, MMD>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
   }
 }
 
@@ -171,13 +187,19 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
   RegArgs R;
   reg_args(p, ws, A, reinterpret_cast<const float*>(ws + p->off_reg_pack), pol_params, dyn_params, R);
   if (getenv("PMBRL_REG_DEBUG"))
-    fprintf(stderr, "pm_reg_launch %s: off_reg_pack %zu gT %zu %zu %zu actT %zu %zu %zu abits %zu %zu %zu %zu ws_bytes %zu\n", fwd ? "fwd" : "bwd",
-            p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
+    fprintf(stderr, "pm_reg_launch %s: off_mmfac %zu off_reg_pack %zu gT %zu %zu %zu actT %zu %zu %zu abits %zu %zu %zu %zu ws_bytes %zu\n", fwd ? "fwd" : "bwd",
+            p->off_mmfac, p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
             p->off_reg_ab[0][0], p->off_reg_ab[0][1], p->off_reg_ab[1][0], p->off_reg_ab[1][1], p->ws_bytes);
-  switch (p->reg_mm) {
-    case 4: reg_launch_mm<4>(p, R, s, fwd); break;
-    case 5: reg_launch_mm<5>(p, R, s, fwd); break;
-    case 6: reg_launch_mm<6>(p, R, s, fwd); break;
-    default: reg_launch_mm<0>(p, R, s, fwd); break;
+  // (more groups than fit the chip at once: batches of whole groups, one launch each -- pmbrl_host.h, mm_gpb)
+  const int per = (p->reg_mm && p->mm_gpb > 0) ? p->mm_gpb * p->mm_parts : p->nwg;
+  for (int w0 = 0; w0 < p->nwg; w0 += per) {
+    R.wg0 = w0;
+    const int n = std::min(per, p->nwg - w0);
+    switch (p->reg_mm) {
+      case 4: reg_launch_mm<4>(n, R, s, fwd); break;
+      case 5: reg_launch_mm<5>(n, R, s, fwd); break;
+      case 6: reg_launch_mm<6>(n, R, s, fwd); break;
+      default: reg_launch_mm<0>(n, R, s, fwd); break;
+    }
   }
 }

@@ -20,11 +20,14 @@
 //             -- three dependent MFMA levels (one MFMA each for d <= 4, two for d <= 8) instead of two triangular
 //             solves in scalar code: ~0.3 k cycles against 2-5 k in the latency-optimised family's one-wave chain.
 //
-// What wave 0 needs from memory (its row of the noise, the group's noise standardisation, the forward sweep's factor, the
-// part's pre-mm rows) is requested by plain per-lane loads in exactly the operand layout it is used in, at the START
-// of the chain -- the loads land while the sums travel (~1.6 k cycles), and nothing of the moment matching is live
-// across the step's GEMM phases (whose register budget is spoken for); only the adjoint's noise operand, which the
-// chain needs at once, is requested a step ahead (four registers).
+// One wave per SIMD issues an instruction every 5-7 cycles, so what the chain costs is wave 0's instruction count --
+// and three waves idle while it runs.  Everything of a step's chain that does NOT depend on the recursion is therefore
+// prepared by the idle waves DURING THE PREVIOUS STEP'S CHAIN and handed over through LDS (two buffers, step t in buffer
+// t & 1; the barrier that ends a chain orders the hand-over): the standardised noise rows (forward: wave 1), the
+// adjoint's noise operand [zhat | 1] in MFMA layout (wave 1) and, from the forward sweep's stashed factor, L / L^-T in
+// operand layout and Y1 = L^-1 Delta^T (wave 2, with its own MFMAs).  Wave 0 touches global memory only for the
+// exchange and the factor it stashes; nothing of the moment matching is live across the step's GEMM phases, whose
+// register budget is spoken for.
 #pragma once
 #include "pmbrl_mm_w.h"
 #include "pmbrl_xch.h"
@@ -38,6 +41,7 @@ struct RegMM {
   double* mmfac;                 // [H][groups][5 D + D D]: mean | zm | zi | - | 1 / diag L | L (pmbrl_mm.h, pm_mm_carve)
   double* linv;                  // [H][groups][D D]: L^-1
   float* xt;                     // [H][B][D]: the sampled (pre-mm) states
+  unsigned xt_off;               // ... as a byte offset in the workspace (the forward sweep's buffer stores)
   unsigned long long* xch;       // granules of the statistics exchange (parts > 1)
   double inv_m, inv_m1;          // 1 / M, 1 / (M - 1) (from the host: an fp64 division is thirty instructions)
 };
@@ -46,22 +50,24 @@ struct RegMM {
 // pm_mmw_factor (pmbrl_mm_w.h) with the reciprocals handed in.  Same pivot rule (a pivot that has shed more than fp32's
 // precision counts as lost: the reference factors in fp32 and raises, utils/rollout.py:154-157).
 template <int DD>
-__device__ __forceinline__ bool pr_mm_factor(const pm_f64x4& G, double dM, double inv_m, double inv_m1, MMW<DD>& q) {
-  double A[DD][DD];
+__device__ __forceinline__ bool pr_mm_factor(const pm_f64x4& G, double dM, double inv_m, double inv_m1, MMW<DD>& q,
+                                             double* ratio_out = nullptr) {
+  double rmin = 1.0;
 #pragma unroll
   for (int j = 0; j < DD; ++j) q.mean[j] = PM_G(G, DD, j) * inv_m;
-#pragma unroll
-  for (int i = 0; i < DD; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j)
-      A[i][j] = (PM_G(G, i, j) - dM * q.mean[i] * q.mean[j]) * inv_m1 + (i == j ? 1e-12 : 0.0);
   bool ok = true;
+  // (column by column: the covariance entries of column k leave the tile when the factor gets there -- forming the
+  //  whole matrix first keeps d (d + 1) / 2 more doubles alive than a 6 x 6 factorisation has registers for)
 #pragma unroll
   for (int k = 0; k < DD; ++k) {
-    const double d0 = A[k][k];
+    double col[DD];
+#pragma unroll
+    for (int i = k; i < DD; ++i) col[i] = (PM_G(G, i, k) - dM * q.mean[i] * q.mean[k]) * inv_m1 + (i == k ? 1e-12 : 0.0);
+    const double d0 = col[k];
     double piv = d0;
 #pragma unroll
     for (int c = 0; c < k; ++c) piv -= q.L[k][c] * q.L[k][c];
+    rmin = fmin(rmin, piv / d0);
     if (!(piv > 6e-8 * d0)) {
       ok = false;
       piv = 1.0;
@@ -71,14 +77,30 @@ __device__ __forceinline__ bool pr_mm_factor(const pm_f64x4& G, double dM, doubl
     q.invd[k] = rs;
 #pragma unroll
     for (int i = k + 1; i < DD; ++i) {
-      double a = A[i][k];
+      double a = col[i];
 #pragma unroll
       for (int c = 0; c < k; ++c) a -= q.L[i][c] * q.L[k][c];
       q.L[i][k] = a * rs;
     }
   }
+  if (ratio_out) *ratio_out = rmin;
   return ok;
 }
+
+// fp64 16x16x4 MFMA with the accumulator in VGPRs: through the builtin hipcc put these accumulators into the accumulator
+// file -- where the sweeps' weight fragments live -- and saved / restored eight of them around every chain (32 moves a step)
+// (hazards the compiler's recogniser does not see inside asm, padded by hand: an operand written by a VALU instruction
+//  needs 2 wait states before the MFMA reads it; a 16x16 DGEMM result needs 9 before the next DGEMM reads it as SrcC, 18
+//  before a VALU instruction reads it)
+__device__ __forceinline__ void pr_mfma64(pm_f64x4& acc, double a, double b) {
+  asm volatile("s_nop 9\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pr_mfma64_0(pm_f64x4& acc, double a, double b) {      // first product of a chain: C = 0
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pr_mfma64_fence(pm_f64x4& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ void pr_mfma64_fence(pm_f64x4& a, pm_f64x4& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pr_mfma64_open() {}
 
 // value `dim` of row `rr`'s state from the lanes' registers: it sits in lane rr + 16 (dim >> 1), slot dim & 1
 __device__ __forceinline__ float pr_mm_gather(const float (&v)[2], int rr, int dim) {
@@ -98,67 +120,105 @@ __device__ __forceinline__ const float* pr_mm_zrow(const RegMM& Q, int D, int t,
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-// xn: the sampled dimensions 2 g, 2 g + 1 of row lane & 15 (finite everywhere).  refl: column lane & 15 of the reference
-// point every part of the group subtracts (in / out: the next step's is this step's mean).  lrow: this lane's row inside
-// the group (clamped to a row of the part).  Returns false on a lost pivot or a partner that never arrived.
-// xout: dimensions 2 g, 2 g + 1 of the moment-matched row.
-// (What the tail needs from memory -- the lane's noise row, the group's noise standardisation -- is requested HERE and
-//  lands while the sums travel: nothing of the moment matching is live across the step's GEMM phases, whose register
-//  budget has no room for it.)
+// LDS hand-over of the forward sweep: [2 buffers][16 rows][DD] doubles -- the standardised noise of the part's rows
+#define PR_MM_ZH_DOUBLES(DD) (2 * 16 * (DD))
+// (an idle wave, during the previous step's chain) zhat of the part's rows at step t -> zh; part 0 also files the
+// standardisation in the factor record the latency-optimised family's adjoint reads (pmbrl_mm.h: mean | zm | zi | ...)
 template <int DD>
-__device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned kstep, int gi, int g0, int lrow, int me,
-                                                int first_wg, int nvalid, int lane, const float (&xn)[2], double& refl,
-                                                float (&xout)[2]) {
-  static_assert(DD >= 2 && DD <= 6, "state widths 2..6");
-  const int c = lane & 15, k = lane >> 4;
-  float z[DD];
-  double zt[2 * DD];      // zm | zi of the group at this step (the same in every lane)
-  {
-    const float* zr = pr_mm_zrow(Q, DD, t, g0, lrow);
+__device__ __forceinline__ void pr_mm_fwd_prep(const RegMM& Q, int t, int gi, int g0, int row0, int nvalid, int me, int lane,
+                                               double* zh) {
+  const int r = lane & 15, cg = lane >> 4;
+  const float* zr = pr_mm_zrow(Q, DD, t, g0, row0 - g0 + (r < nvalid ? r : 0));
+  const double* zt = Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
+  double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
 #pragma unroll
-    for (int cc = 0; cc < DD; ++cc) z[cc] = zr[cc];
-    const double* ztp = Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
-#pragma unroll
-    for (int cc = 0; cc < 2 * DD; ++cc) zt[cc] = ztp[cc];
-  }
-  pm_f64x4 G0 = {0.0, 0.0, 0.0, 0.0}, G1 = {0.0, 0.0, 0.0, 0.0};
-  {
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = pr_mm_gather(xn, 4 * q + k, c);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double x = c < DD ? (double)v[q] - refl : (c == DD ? 1.0 : 0.0);
-      x = 4 * q + k < nvalid ? x : 0.0;
-      if (4 * q < nvalid) {      // (uniform)
-        if (q & 1) G1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G1, 0, 0, 0);
-        else G0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, G0, 0, 0, 0);
+  for (int u = 0; u < 2; ++u) {
+    const int c = cg + 4 * u;
+    if (c < DD) {
+      const double zm = zt[c], zi = zt[DD + c];
+      zh[r * DD + c] = ((double)zr[c] - zm) * zi;
+      if (me == 0 && r == 0) {
+        fac[DD + c] = zm;
+        fac[2 * DD + c] = zi;
       }
     }
   }
+}
+
+// pf: cycle stamps of the chain's stations (slots 8 ..; nullptr: none)
+#define PR_MM_STAMP(slot) do { if (pf && lane == 0) pf[slot] = (long long)__builtin_readcyclecounter(); } while (0)
+// xn: the sampled dimensions 2 g, 2 g + 1 of row lane & 15 (finite everywhere).  refl: column lane & 15 of the reference
+// point every part of the group subtracts (in / out: the next step's is this step's mean).  zh: this step's hand-over
+// buffer.  Returns false on a lost pivot or a partner that never arrived.  xout: dimensions 2 g, 2 g + 1 of the
+// moment-matched row.
+template <int DD>
+__device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned kstep, int gi, int me, int first_wg, int nvalid,
+                                                int lane, const float (&xn)[2], double& refl, const double* zh,
+                                                float (&xout)[2], long long* pf = nullptr) {
+  static_assert(DD >= 2 && DD <= 6, "state widths 2..6");
+  const int c = lane & 15, k = lane >> 4;
+  pm_f64x4 G0, G1;
+  {
+    // operand of quad q: x~ - c in the state columns, 1 in column d, 0 elsewhere and in rows past the part.  The masks act
+    // on the FLOAT (the reference point is a float by construction: a masked lane holds it and subtracts to exactly 0)
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = pr_mm_gather(xn, 4 * q + k, c);
+    const float fill = (float)refl, one = c == DD ? 1.f : 0.f;      // (refl = 0 in the columns >= d)
+    double x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float u = c < DD ? v[q] : one;
+      u = 4 * q + k < nvalid ? u : fill;
+      x[q] = (double)u - refl;
+    }
+    pr_mfma64_open();
+    pr_mfma64_0(G0, x[0], x[0]);
+    pr_mfma64_0(G1, x[1], x[1]);
+    pr_mfma64(G0, x[2], x[2]);
+    pr_mfma64(G1, x[3], x[3]);
+    pr_mfma64_fence(G0, G1);
+  }
   pm_f64x4 G = G0 + G1;
   bool ok = true;
-  if (Q.parts > 1) {
-    double v[2] = {G[0], G[1]};
-    pm_xch_put<2>(Q.xch, first_wg, me, kstep, v, lane);
-    ok = pm_xch_get<2>(Q.xch, first_wg, Q.parts, me, kstep, v, lane);
-    G[0] = v[0];
-    G[1] = v[1];
+  PR_MM_STAMP(8);
+  double v2[2] = {G[0], G[1]};
+  if (Q.parts > 1) pm_xch_put<2>(Q.xch, first_wg, me, kstep, v2, lane);
+  // (this lane's row of the standardised noise: requested here, used behind the factorisation -- at d > 4 requested behind
+  //  it: the factorisation of a 5 x 5 or 6 x 6 covariance has no registers to carry the row through)
+  double zhr[DD];
+  if constexpr (DD <= 4) {
+#pragma unroll
+    for (int cc = 0; cc < DD; ++cc) zhr[cc] = zh[c * DD + cc];
   }
+  if (Q.parts > 1) {
+    ok = pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
+    G[0] = v2[0];
+    G[1] = v2[1];
+  }
+  PR_MM_STAMP(9);
   MMW<DD> q;
+#ifdef PR_MM_DEBUG_RATIO
+  double dbg_ratio;
+  ok = pr_mm_factor<DD>(G, (double)Q.M, Q.inv_m, Q.inv_m1, q, &dbg_ratio) && ok;
+#else
   ok = pr_mm_factor<DD>(G, (double)Q.M, Q.inv_m, Q.inv_m1, q) && ok;
+#endif
+  PR_MM_STAMP(10);
+  if constexpr (DD > 4) {
+#pragma unroll
+    for (int cc = 0; cc < DD; ++cc) zhr[cc] = zh[c * DD + cc];
+  }
   double mean[DD];
 #pragma unroll
   for (int j = 0; j < DD; ++j) mean[j] = q.mean[j] + pm_rl64(refl, j);
   // this lane's row: m + zhat L^T, all d entries (d (d + 1) / 2 products), then the two this lane group keeps
-  double zh[DD], acc[DD + 2];
-#pragma unroll
-  for (int cc = 0; cc < DD; ++cc) zh[cc] = ((double)z[cc] - zt[cc]) * zt[DD + cc];
+  double acc[DD + 2];
 #pragma unroll
   for (int j = 0; j < DD; ++j) {
     double a = mean[j];
 #pragma unroll
-    for (int cc = 0; cc <= j; ++cc) a += zh[cc] * q.L[j][cc];
+    for (int cc = 0; cc <= j; ++cc) a += zhr[cc] * q.L[j][cc];
     acc[j] = a;
   }
   acc[DD] = acc[DD + 1] = 0.0;
@@ -173,6 +233,7 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
   }
   xout[0] = (float)o0;
   xout[1] = (float)o1;
+  PR_MM_STAMP(11);
   // the next step's reference point (every part computes the same bits)
   {
     double r = 0.0;
@@ -180,118 +241,166 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     for (int j = 0; j < DD; ++j) r = c == j ? (double)(float)mean[j] : r;
     refl = r;
   }
-  // the factor for the adjoint sweep: mean | zm | zi | - | 1 / diag L | L row-major (what the latency-optimised family's
-  // adjoint reads as well), and L^-1
-  if (me == 0) {
-    double Li[DD][DD];
-#pragma unroll
-    for (int i = 0; i < DD; ++i) {
-      Li[i][i] = q.invd[i];
-#pragma unroll
-      for (int j = 0; j < i; ++j) {
-        double a = 0.0;
-#pragma unroll
-        for (int cc = j; cc < i; ++cc) a += q.L[i][cc] * Li[cc][j];
-        Li[i][j] = -a * q.invd[i];
-      }
-    }
-    if (lane == 0) {
-      double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
-      double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
+  // the factor for the adjoint sweep (one lane's stores: the values are the same in all of them).  Part 0 files
+  // mean | . | . | . | 1 / diag L | L row-major (pm_mm_carve's record); the LAST part L^-1 -- the duty is shared because
+  // the parts wait for each other again one step later
+  {
+    // (the stores' duty is dealt over the parts: what one part spends here, all of them wait for one step later)
+    double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+    if (lane == 0 && me == 0) {
 #pragma unroll
       for (int j = 0; j < DD; ++j) {
         fac[j] = mean[j];
-        fac[DD + j] = zt[j];
-        fac[2 * DD + j] = zt[DD + j];
         fac[4 * DD + j] = q.invd[j];
+      }
+    }
+    if (lane == 0 && me == (Q.parts >= 3 ? 1 : 0)) {
 #pragma unroll
-        for (int cc = 0; cc < DD; ++cc) {
-          fac[5 * DD + j * DD + cc] = cc <= j ? q.L[j][cc] : 0.0;
-          li[j * DD + cc] = cc <= j ? Li[j][cc] : 0.0;
-        }
+      for (int j = 0; j < DD; ++j)
+#pragma unroll
+        for (int cc = 0; cc < DD; ++cc) fac[5 * DD + j * DD + cc] = cc <= j ? q.L[j][cc] : 0.0;
+    }
+  }
+  if (me == Q.parts - 1) {
+    // (column by column, each stored as soon as it is solved: the whole inverse at once is d (d + 1) / 2 more doubles than
+    //  the chain has registers for at d = 6 -- the overflow went to the accumulator file and evicted weight fragments)
+    double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
+#pragma unroll
+    for (int j = 0; j < DD; ++j) {
+      double x[DD];
+      x[j] = q.invd[j];
+#pragma unroll
+      for (int i = j + 1; i < DD; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int cc = j; cc < i; ++cc) a += q.L[i][cc] * x[cc];
+        x[i] = -a * q.invd[i];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < DD; ++i) li[i * DD + j] = i >= j ? x[i] : 0.0;
       }
     }
   }
+  PR_MM_STAMP(12);
   return ok;
 }
 
 // ---------------------------------------------------------------------------
 // adjoint
 // ---------------------------------------------------------------------------
-// the noise of rows 4 q + k, column c (lane: c = lane & 15, k = lane >> 4): the one input the chain needs at its very
-// start -- requested a step ahead, four registers across the step
+// LDS hand-over of the adjoint sweep, per buffer: the noise operand [4 row quads][64 lanes] and, per lane,
+// Y1 (NK registers) | L (NK) | L^-T (NK) -- doubles
+#define PR_MM_BOP_DOUBLES (4 * 64)
+#define PR_MM_YOP_DOUBLES(DD) (3 * (((DD) + 3) / 4) * 64)
+// (wave 1, during the next-higher step's chain) the B operand of H = g^T [zhat | 1] at step t: lane (c, k), quad q
 template <int DD>
-__device__ __forceinline__ void pr_mm_bwd_fetch(const RegMM& Q, int t, int g0, int row0, int nvalid, int lane, float (&z)[4]) {
+__device__ __forceinline__ void pr_mm_bwd_prep_noise(const RegMM& Q, int t, int gi, int g0, int row0, int nvalid, int lane,
+                                                     double* bop) {
   const int c = lane & 15, k = lane >> 4, cc = c < DD ? c : DD - 1;
+  const double* zt = Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
+  const double zm = zt[cc], zi = zt[DD + cc];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int rr = 4 * q + k < nvalid ? 4 * q + k : 0;
-    z[q] = pr_mm_zrow(Q, DD, t, g0, row0 - g0 + rr)[cc];
+    const bool rok = 4 * q + k < nvalid;
+    const float z = pr_mm_zrow(Q, DD, t, g0, row0 - g0 + (rok ? 4 * q + k : 0))[cc];
+    const double b = c < DD ? ((double)z - zm) * zi : (c == DD ? 1.0 : 0.0);
+    bop[q * 64 + lane] = rok ? b : 0.0;
+  }
+}
+// (wave 2, likewise) from the forward sweep's factor at step t: Y1 = L^-1 Delta^T of the part's rows, L and L^-T in
+// operand layout -- lane (c, k): L[4 kk + k][c], L^-1[4 kk + k][c]
+template <int DD>
+__device__ __forceinline__ void pr_mm_bwd_prep_factor(const RegMM& Q, int B, int t, int gi, int row0, int nvalid, int lane,
+                                                      double* yop) {
+  constexpr int NK = (DD + 3) / 4;
+  const int c = lane & 15, k = lane >> 4, cc = c < DD ? c : DD - 1;
+  const double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+  const double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
+  const float* xr = Q.xt + ((size_t)t * B + row0 + (c < nvalid ? c : 0)) * DD;
+  double la[NK], lia[NK], lit[NK], dl[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int i = 4 * kk + k, ii = i < DD ? i : DD - 1;
+    const bool live = i < DD && c < DD;
+    const double a = fac[5 * DD + ii * DD + cc], b = li[cc * DD + ii], e = li[ii * DD + cc];
+    la[kk] = live ? a : 0.0;
+    lia[kk] = live ? b : 0.0;
+    lit[kk] = live ? e : 0.0;
+    dl[kk] = (i < DD && c < nvalid) ? (double)xr[ii] - fac[ii] : 0.0;
+  }
+  pm_f64x4 Y1;
+  pr_mfma64_open();
+  pr_mfma64_0(Y1, lia[0], dl[0]);
+  if constexpr (NK > 1) pr_mfma64(Y1, lia[1], dl[1]);
+  pr_mfma64_fence(Y1);
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    yop[(0 * NK + kk) * 64 + lane] = Y1[kk];
+    yop[(1 * NK + kk) * 64 + lane] = la[kk];
+    yop[(2 * NK + kk) * 64 + lane] = lit[kk];
   }
 }
 
 // gx: dL/dx_{t+1}, dimensions 2 g, 2 g + 1 of row lane & 15 (zero in rows past the part).  out[rr]: dL/dx~ of dimension
-// (lane >> 4) + 4 rr of row lane & 15.  Everything else the chain reads (the forward sweep's factor, the part's pre-mm
-// rows) is requested at its start, in the operand layout it is used in, and lands while the sums travel.
+// (lane >> 4) + 4 rr of row lane & 15.  bop / yop: this step's hand-over buffers.
 template <int DD>
-__device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, int B, int t, unsigned kstep, int gi, int row0, int me,
-                                                int first_wg, int nvalid, int lane, const float (&gx)[2], const float (&z)[4],
-                                                float (&out)[(DD + 3) / 4]) {
+__device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, int me, int first_wg, int nvalid, int lane,
+                                                const float (&gx)[2], const double* bop, const double* yop,
+                                                float (&out)[(DD + 3) / 4], long long* pf = nullptr) {
   constexpr int NK = (DD + 3) / 4;
-  const int c = lane & 15, k = lane >> 4, cc = c < DD ? c : DD - 1;
-  // lane (c, k):  zm / zi of column c;  LA = L[4 kk + k][c];  LiA = L^-1[c][4 kk + k];  LiT = L^-1[4 kk + k][c];
-  // xt = pre-mm sample of row c, dimension 4 kk + k;  mean of dimension 4 kk + k
-  double zm, zi, LA[NK], LiA[NK], LiT[NK], mean[NK];
-  float xt[NK];
+  const int c = lane & 15, k = lane >> 4;
+  // H = g^T [zhat | 1]
+  pm_f64x4 H0, H1;
   {
-    const double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
-    const double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
-    zm = fac[DD + cc];
-    zi = fac[2 * DD + cc];
-    const float* xr = Q.xt + ((size_t)t * B + row0 + (c < nvalid ? c : 0)) * DD;
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      const int i = 4 * kk + k, ii = i < DD ? i : DD - 1;
-      LA[kk] = fac[5 * DD + ii * DD + cc];
-      LiA[kk] = li[cc * DD + ii];
-      LiT[kk] = li[ii * DD + cc];
-      xt[kk] = xr[ii];
-      mean[kk] = fac[ii];
-    }
-  }
-  // H = g^T [z | 1] with the RAW noise (standardised behind the exchange: the sums are linear in z)
-  pm_f64x4 H0 = {0.0, 0.0, 0.0, 0.0}, H1 = {0.0, 0.0, 0.0, 0.0};
-  {
+    // (rows past the part: the noise operand is zero there, whatever the gradient lanes hold -- dL/dx is kept at zero in
+    //  them anyway; the columns >= d of the gradient operand are masked on the float)
     float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = pr_mm_gather(gx, 4 * q + k, c);
+    double b[4], a[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const bool rok = 4 * q + k < nvalid;
-      const double a = (c < DD && rok) ? (double)v[q] : 0.0;
-      double b = c < DD ? (double)z[q] : (c == DD ? 1.0 : 0.0);
-      b = rok ? b : 0.0;
-      if (4 * q < nvalid) {
-        if (q & 1) H1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H1, 0, 0, 0);
-        else H0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, H0, 0, 0, 0);
-      }
+      v[q] = pr_mm_gather(gx, 4 * q + k, c);
+      b[q] = bop[q * 64 + lane];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = (double)(c < DD ? v[q] : 0.f);
+    pr_mfma64_open();
+    pr_mfma64_0(H0, a[0], b[0]);
+    pr_mfma64_0(H1, a[1], b[1]);
+    pr_mfma64(H0, a[2], b[2]);
+    pr_mfma64(H1, a[3], b[3]);
+    pr_mfma64_fence(H0, H1);
   }
   pm_f64x4 H = H0 + H1;
   double hs[2] = {H[0], H[1]};
+  PR_MM_STAMP(8);
   if (Q.parts > 1) pm_xch_put<2>(Q.xch, first_wg, me, kstep, hs, lane);
-  // while the sums travel: Y1 = L^-1 Delta^T (rows of this part in the columns)
-  pm_f64x4 Y1 = {0.0, 0.0, 0.0, 0.0};
+  double Y1[NK], LA[NK], LiT[NK];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) {
-    const bool live = 4 * kk + k < DD;
-    const double dl = (live && c < nvalid) ? (double)xt[kk] - mean[kk] : 0.0;
-    const double la = (live && c < DD) ? LiA[kk] : 0.0;
-    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(la, dl, Y1, 0, 0, 0);
+    Y1[kk] = yop[(0 * NK + kk) * 64 + lane];
+    LA[kk] = yop[(1 * NK + kk) * 64 + lane];
+    LiT[kk] = yop[(2 * NK + kk) * 64 + lane];
   }
   bool ok = true;
-  if (Q.parts > 1) ok = pm_xch_get<2>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+  PR_MM_STAMP(9);
+  if (Q.parts > 1) ok = pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+  PR_MM_STAMP(10);
+  // Lbar = tril(H[:, :d]) in the tile's own registers (row i = k + 4 kk, column c)
+  double lb[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) lb[kk] = (c <= k + 4 * kk && k + 4 * kk < DD) ? hs[kk] : 0.0;
+  pm_f64x4 Ph, Pt;
+  pr_mfma64_open();
+  pr_mfma64_0(Ph, LA[0], lb[0]);
+  pr_mfma64_0(Pt, lb[0], LA[0]);
+  if constexpr (NK > 1) {
+    pr_mfma64(Ph, LA[1], lb[1]);
+    pr_mfma64(Pt, lb[1], LA[1]);
+  }
+  pr_mfma64_fence(Ph, Pt);
   // mbar[i] = H[i][d] sits in lane (d, i & 3), register i >> 2; this lane's rows are i = k + 4 r: lane d + 16 k, register r
+  // (behind the first products: only the last line needs it)
   double mb[NK];
 #pragma unroll
   for (int r = 0; r < NK; ++r) {
@@ -299,17 +408,6 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, int B, int t, un
     const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute((DD + 16 * k) * 4, (int)(unsigned)u);
     const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((DD + 16 * k) * 4, (int)(unsigned)(u >> 32));
     mb[r] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-  }
-  // Lbar = tril((g^T z - mbar zm^T) diag(zi)) in the tile's own registers (row i = k + 4 kk, column c)
-  double lb[NK];
-#pragma unroll
-  for (int kk = 0; kk < NK; ++kk) lb[kk] = (c <= k + 4 * kk && k + 4 * kk < DD) ? (hs[kk] - zm * mb[kk]) * zi : 0.0;
-  pm_f64x4 Ph = {0.0, 0.0, 0.0, 0.0}, Pt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kk = 0; kk < NK; ++kk) {
-    const double la = (4 * kk + k < DD && c < DD) ? LA[kk] : 0.0;
-    Ph = __builtin_amdgcn_mfma_f64_16x16x4f64(la, lb[kk], Ph, 0, 0, 0);
-    Pt = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[kk], la, Pt, 0, 0, 0);
   }
   // Psi = low(Phi) + up(Phi^T), diagonal halved in both (entry (a, b): a = k + 4 r, b = c)
   double ps[NK];
@@ -319,15 +417,19 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, int B, int t, un
     const double m1 = a > c ? 1.0 : (a == c ? 0.5 : 0.0), m2 = c > a ? 1.0 : (a == c ? 0.5 : 0.0);
     ps[r] = (a < DD && c < DD) ? m1 * Ph[r] + m2 * Pt[r] : 0.0;
   }
-  pm_f64x4 Y2 = {0.0, 0.0, 0.0, 0.0}, Y3 = {0.0, 0.0, 0.0, 0.0};
+  pm_f64x4 Y2, Y3;
+  pr_mfma64_open();
+  pr_mfma64_0(Y2, ps[0], Y1[0]);
+  if constexpr (NK > 1) pr_mfma64(Y2, ps[1], Y1[1]);
+  pr_mfma64_fence(Y2);
+  double y2[NK];
 #pragma unroll
-  for (int kk = 0; kk < NK; ++kk) Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps[kk], Y1[kk], Y2, 0, 0, 0);
-#pragma unroll
-  for (int kk = 0; kk < NK; ++kk) {
-    const double lt = (4 * kk + k < DD && c < DD) ? LiT[kk] : 0.0;
-    Y3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt, Y2[kk], Y3, 0, 0, 0);
-  }
+  for (int kk = 0; kk < NK; ++kk) y2[kk] = Y2[kk];
+  pr_mfma64_0(Y3, LiT[0], y2[0]);
+  if constexpr (NK > 1) pr_mfma64(Y3, LiT[1], y2[1]);
+  pr_mfma64_fence(Y3);
 #pragma unroll
   for (int rr = 0; rr < NK; ++rr) out[rr] = (float)__builtin_fma(Y3[rr], Q.inv_m1, mb[rr] * Q.inv_m);
+  PR_MM_STAMP(11);
   return ok;
 }

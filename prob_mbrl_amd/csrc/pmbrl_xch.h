@@ -79,3 +79,50 @@ __device__ __forceinline__ bool pm_xch_get(const unsigned long long* xb, int fir
   return ok;
 }
 
+
+// The same with the partners' granules requested TOGETHER (batches of NB slots): pm_xch_get walks the parts one memory
+// round trip after the other -- three of them for a group in four parts, ~0.7 k cycles each even when everything has long
+// arrived.  This part's own contribution comes from its registers (v on entry); the sum is taken in part order, so every
+// part ends with the same bits.
+template <int NV, int NB>
+__device__ __forceinline__ bool pm_xch_get_all(const unsigned long long* xb, int first, int parts, int me, unsigned k,
+                                               double (&v)[NV], int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  double tot[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+  for (int q0 = 0; q0 < parts; q0 += NB) {
+    unsigned long long g[NB][2 * NV];
+    for (int spins = 0;;) {
+      bool here = true;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int q = q0 + b < parts ? q0 + b : q0;      // (a short last batch asks for its first slot again)
+        const gu64* theirs = (const gu64*)xb + (size_t)(first + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const bool mine = q0 + b == me || q0 + b >= parts;
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) here = here && (mine || (g[b][i] >> 32) == (unsigned long long)k);
+      }
+      if (__all(here)) break;
+      if (++spins > (1 << 19)) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (q0 + b < parts) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double theirs = __longlong_as_double((long long)(((g[b][2 * i] & 0xffffffffull) << 32) | (g[b][2 * i + 1] & 0xffffffffull)));
+          tot[i] += q0 + b == me ? v[i] : theirs;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = tot[i];
+  return true;
+}

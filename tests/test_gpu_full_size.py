@@ -98,7 +98,8 @@ def test_instantiations_agree_bitwise(config, H):
     # the EXT instances on the latency-optimised one.  Everything else is the same arithmetic in the same order and
     # must agree bit for bit.
     reg = bool(ref[0].info.get('reg'))
-    assert reg == (config == 'cartpole_nomm')
+    # (round 5: the register-resident family also serves the moment-matching cart-pole shapes -- pmbrl_reg_mm.h)
+    assert reg == (config in ('cartpole_nomm', 'cartpole_mm'))
     outs = {}
     for kw, lean in ((dict(no_shaped=True), True), (dict(), False), (dict(no_shaped=True), False)):
         outs[(bool(kw), lean)] = _run(d, lean=lean, **kw, **pk)
@@ -107,14 +108,24 @@ def test_instantiations_agree_bitwise(config, H):
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
         assert np.array_equal(a[5], b[5])
 
-    def same_rounding(a, b):
-        assert common.rel(b[1], a[1]) < 2e-6 and common.rel(b[2], a[2]) < 2e-6 and common.rel(b[5], a[5]) < 2e-5
+    def same_rounding(a, b, g_tol=2e-5):
+        assert common.rel(b[1], a[1]) < 2e-6 and common.rel(b[2], a[2]) < 2e-6 and common.rel(b[5], a[5]) < g_tol, \
+            (common.rel(b[1], a[1]), common.rel(b[2], a[2]), common.rel(b[5], a[5]))
 
     if config == 'cartpole_mm':
         assert ref[0].info['mm_parts'] == 2
-        same_bits(ref, outs[(False, False)])
+        # ref: both sweeps on the register-resident family; (False, False): its forward, the latency-optimised family's
+        # adjoint from the same stashes; the general instances carry the rows + flags form of the split groups -- the same
+        # mathematics in another order of fp64 additions
+        for k in (1, 2, 3):
+            assert np.array_equal(ref[k], outs[(False, False)][k])
+        # (the two families' adjoints of the moment matching differ in more than the order of a sum -- triangular solves
+        #  in scalar fp64 there, products with the stashed L^-1 on the fp64 matrix core here -- and the adjoint of a
+        #  Cholesky factor amplifies what differs: against the fp64 oracle they measure 1.6e-5 and 3.1e-5
+        #  (test_full_size_matches_oracle holds each to 1e-4), against each other 2.9e-5)
+        same_rounding(ref, outs[(False, False)], g_tol=6e-5)
         same_bits(outs[(True, True)], outs[(True, False)])
-        same_rounding(ref, outs[(True, True)])
+        same_rounding(ref, outs[(True, True)], g_tol=6e-5)
     elif reg:
         # (the EXT call's forward is the same register-resident launch: identical trajectories; its adjoint is the
         #  latency-optimised family's)

@@ -59,6 +59,11 @@ def main():
                   (cyc, rt, cyc / rt / 1e3 if rt else 0.0, first - a[0, 30], a[0, 31] - last))
             if a[0, 27]:
                 print('   prologue stamps (cycles from entry):', [int(a[0, k] - a[0, 30]) for k in (27, 26, 25) if a[0, k]])
+        # partner workgroup's chain stations (slots 16..20 = its 8..12), relative to ITS OWN first stamp -- clocks of
+        # different CUs are not comparable
+        if a[H // 2, 16] != 0:
+            ps = [s for s in range(16, 24) if a[H // 2, s] != 0]
+            print('   partner workgroup (slots %s): deltas %s' % (ps, [int(np.median(a[1:-1, ps[i + 1]] - a[1:-1, ps[i]])) for i in range(len(ps) - 1)]))
         print('   step total (marked span): %.0f cycles; step period: %.0f' %
               (tot, np.median(np.abs(np.diff(a[:, order[0]])))))
 
