@@ -46,6 +46,16 @@ struct RegMM {
   double inv_m, inv_m1;          // 1 / M, 1 / (M - 1) (from the host: an fp64 division is thirty instructions)
 };
 
+// 1 / sqrt(x): the hardware estimate (2^-26) and TWO Newton steps (pm_rsqrt takes three: on the one-wave chain every
+// fp64 instruction is six cycles of the step)
+__device__ __forceinline__ double pr_mm_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
+  return y;
+}
+
 // mean (relative to the reference point), covariance and its Cholesky factor from the Gram tile of [s - ref | 1]:
 // pm_mmw_factor (pmbrl_mm_w.h) with the reciprocals handed in.  Same pivot rule (a pivot that has shed more than fp32's
 // precision counts as lost: the reference factors in fp32 and raises, utils/rollout.py:154-157).
@@ -72,7 +82,7 @@ __device__ __forceinline__ bool pr_mm_factor(const pm_f64x4& G, double dM, doubl
       ok = false;
       piv = 1.0;
     }
-    const double rs = pm_rsqrt(piv);
+    const double rs = pr_mm_rsqrt(piv);
     q.L[k][k] = piv * rs;
     q.invd[k] = rs;
 #pragma unroll
@@ -102,6 +112,12 @@ __device__ __forceinline__ void pr_mfma64_fence(pm_f64x4& acc) { asm volatile("s
 __device__ __forceinline__ void pr_mfma64_fence(pm_f64x4& a, pm_f64x4& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pr_mfma64_open() {}
 
+// (pointers read out of the argument struct carry no address space: accesses through them would be FLAT, which completes
+//  out of order with LDS and degrades every LDS wait of the wave to lgkmcnt(0))
+typedef PM_GLOBAL double* pr_gd;
+typedef const PM_GLOBAL double* pr_gcd;
+typedef const PM_GLOBAL float* pr_gcf;
+
 // value `dim` of row `rr`'s state from the lanes' registers: it sits in lane rr + 16 (dim >> 1), slot dim & 1
 __device__ __forceinline__ float pr_mm_gather(const float (&v)[2], int rr, int dim) {
   const int src = (rr + 16 * ((dim >> 1) & 3)) * 4;
@@ -111,8 +127,8 @@ __device__ __forceinline__ float pr_mm_gather(const float (&v)[2], int rr, int d
 }
 
 // cyclic noise row of local row r of the group that starts at device row g0 (utils/rollout.py:53-59)
-__device__ __forceinline__ const float* pr_mm_zrow(const RegMM& Q, int D, int t, int g0, int r) {
-  const float* zb = (Q.flags & PMBRL_FLAG_ZMM_PER_STEP) ? Q.zmm + (size_t)t * Q.Bg * D : Q.zmm;
+__device__ __forceinline__ pr_gcf pr_mm_zrow(const RegMM& Q, int D, int t, int g0, int r) {
+  pr_gcf zb = (Q.flags & PMBRL_FLAG_ZMM_PER_STEP) ? (pr_gcf)Q.zmm + (size_t)t * Q.Bg * D : (pr_gcf)Q.zmm;
   const int z0 = (Q.flags & PMBRL_FLAG_ZMM_PER_STEP) ? Q.row_off + g0 : t + Q.row_off + g0;
   return zb + (size_t)pm_zidx(z0, r, Q.Bg) * D;
 }
@@ -128,9 +144,9 @@ template <int DD>
 __device__ __forceinline__ void pr_mm_fwd_prep(const RegMM& Q, int t, int gi, int g0, int row0, int nvalid, int me, int lane,
                                                double* zh) {
   const int r = lane & 15, cg = lane >> 4;
-  const float* zr = pr_mm_zrow(Q, DD, t, g0, row0 - g0 + (r < nvalid ? r : 0));
-  const double* zt = Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
-  double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+  pr_gcf zr = pr_mm_zrow(Q, DD, t, g0, row0 - g0 + (r < nvalid ? r : 0));
+  pr_gcd zt = (pr_gcd)Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
+  pr_gd fac = (pr_gd)Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int c = cg + 4 * u;
@@ -192,7 +208,8 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     for (int cc = 0; cc < DD; ++cc) zhr[cc] = zh[c * DD + cc];
   }
   if (Q.parts > 1) {
-    ok = pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
+    ok = Q.parts == 2 ? pm_xch_get_pair<2>(Q.xch, first_wg, me, kstep, v2, lane)
+                      : pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
     G[0] = v2[0];
     G[1] = v2[1];
   }
@@ -246,7 +263,7 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
   // the parts wait for each other again one step later
   {
     // (the stores' duty is dealt over the parts: what one part spends here, all of them wait for one step later)
-    double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+    pr_gd fac = (pr_gd)Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
     if (lane == 0 && me == 0) {
 #pragma unroll
       for (int j = 0; j < DD; ++j) {
@@ -264,7 +281,7 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
   if (me == Q.parts - 1) {
     // (column by column, each stored as soon as it is solved: the whole inverse at once is d (d + 1) / 2 more doubles than
     //  the chain has registers for at d = 6 -- the overflow went to the accumulator file and evicted weight fragments)
-    double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
+    pr_gd li = (pr_gd)Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
 #pragma unroll
     for (int j = 0; j < DD; ++j) {
       double x[DD];
@@ -298,7 +315,7 @@ template <int DD>
 __device__ __forceinline__ void pr_mm_bwd_prep_noise(const RegMM& Q, int t, int gi, int g0, int row0, int nvalid, int lane,
                                                      double* bop) {
   const int c = lane & 15, k = lane >> 4, cc = c < DD ? c : DD - 1;
-  const double* zt = Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
+  pr_gcd zt = (pr_gcd)Q.ztab + ((size_t)t * Q.groups + gi) * 2 * DD;
   const double zm = zt[cc], zi = zt[DD + cc];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -315,9 +332,9 @@ __device__ __forceinline__ void pr_mm_bwd_prep_factor(const RegMM& Q, int B, int
                                                       double* yop) {
   constexpr int NK = (DD + 3) / 4;
   const int c = lane & 15, k = lane >> 4, cc = c < DD ? c : DD - 1;
-  const double* fac = Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
-  const double* li = Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
-  const float* xr = Q.xt + ((size_t)t * B + row0 + (c < nvalid ? c : 0)) * DD;
+  pr_gcd fac = (pr_gcd)Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+  pr_gcd li = (pr_gcd)Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
+  pr_gcf xr = (pr_gcf)Q.xt + ((size_t)t * B + row0 + (c < nvalid ? c : 0)) * DD;
   double la[NK], lia[NK], lit[NK], dl[NK];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) {
@@ -384,7 +401,9 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, 
   }
   bool ok = true;
   PR_MM_STAMP(9);
-  if (Q.parts > 1) ok = pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+  if (Q.parts > 1)
+    ok = Q.parts == 2 ? pm_xch_get_pair<2>(Q.xch, first_wg, me, kstep, hs, lane)
+                      : pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
   PR_MM_STAMP(10);
   // Lbar = tril(H[:, :d]) in the tile's own registers (row i = k + 4 kk, column c)
   double lb[NK];

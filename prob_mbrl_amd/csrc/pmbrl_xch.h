@@ -80,6 +80,33 @@ __device__ __forceinline__ bool pm_xch_get(const unsigned long long* xb, int fir
 }
 
 
+// Two parts: the one partner's granules, the sum in part order (pm_xch_get's arithmetic without its loop over the parts:
+// a poll is 2 NV loads and as many compares, and what stands between the arrival of the partner's sums and their use is
+// one such round)
+template <int NV>
+__device__ __forceinline__ bool pm_xch_get_pair(const unsigned long long* xb, int first, int me, unsigned k, double (&v)[NV], int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  const gu64* theirs = (const gu64*)xb + (size_t)(first + (me ^ 1)) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+  unsigned long long g[2 * NV];
+  for (int spins = 0;;) {
+    unsigned tags = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) {
+      g[i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tags &= (unsigned)(g[i] >> 32) ^ ~k;      // all ones where the tag is k
+    }
+    if (__all(tags == 0xffffffffu)) break;
+    if (++spins > (1 << 19)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double t = __longlong_as_double((long long)(((g[2 * i] & 0xffffffffull) << 32) | (g[2 * i + 1] & 0xffffffffull)));
+    v[i] = me == 0 ? v[i] + t : t + v[i];
+  }
+  return true;
+}
+
 // The same with the partners' granules requested TOGETHER (batches of NB slots): pm_xch_get walks the parts one memory
 // round trip after the other -- three of them for a group in four parts, ~0.7 k cycles each even when everything has long
 // arrived.  This part's own contribution comes from its registers (v on entry); the sum is taken in part order, so every

@@ -100,14 +100,29 @@ def test_double_cartpole_shape_splits_its_groups_by_default():
     assert 'PMBRL_MM_PARTS' not in os.environ
     pr = PB.synthetic_problem('dcartpole_mm', seed=0, data_seed=0)
     eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
-    assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 25 and eng.info['n_wg'] == 200, eng.info
+    # (round 5: four parts of <= 13 rows on the register-resident family, 400 workgroups launched as two batches of 50
+    #  whole groups -- the statistics exchange needs ONE group's workgroups resident together, not all of them)
+    assert eng.info['mm_parts'] == 4 and eng.info['rows_per_wg'] == 13 and eng.info['n_wg'] == 400 and eng.info['reg'], eng.info
+    os.environ['PMBRL_MM_NO_BATCH'] = '1'
+    try:
+        eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    finally:
+        del os.environ['PMBRL_MM_NO_BATCH']
+    assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 25 and eng.info['n_wg'] == 200 and not eng.info['reg'], eng.info
     # 25-row groups: 13 + 12 rows in two 16-row workgroups instead of one 32-row workgroup
     pr = PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0)
     eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
     assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 13 and eng.info['n_wg'] == 200, eng.info
-    # more groups than half the CUs: whole groups per workgroup as before
+    # more groups than half the CUs: still two parts on the register-resident family, in two launches (before round 5, and
+    # for shapes that family does not take: whole groups per 32-row workgroup)
     pr = PB.synthetic_problem('cartpole_mm', seed=0, data_seed=0, P=160)
     eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    assert eng.info['mm_parts'] == 2 and eng.info['rows_per_wg'] == 13 and eng.info['n_wg'] == 320 and eng.info['reg'], eng.info
+    os.environ['PMBRL_MM_NO_BATCH'] = '1'
+    try:
+        eng = PB.engine_from_problem(pr, torch.device(DEV))[0]
+    finally:
+        del os.environ['PMBRL_MM_NO_BATCH']
     assert eng.info['mm_parts'] == 1 and eng.info['rows_per_wg'] == 25, eng.info
 
 
