@@ -563,6 +563,21 @@ int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* plan, void* stream, void* workspace_d
                            float* grad_flat_d, float* loss_out_d,
                            const float* row_weight_d, float* row_logprob_d, int32_t terms);
 
+/* Whole training iterations of utils/train_regressor.py:113-131 (loss_kind 0: Gaussian likelihood + regulariser, then
+ * torch.optim.Adam's step -- the reference clips nothing here) queued by ONE call, two launches an iteration:
+ * forward + backward over the minibatch, then dW / db / regulariser / Adam / re-packed weights / loss in one kernel.
+ * Minibatch i = rows idx_all_d[i * M .. (i + 1) * M).  Dropout noise: recorded draws u_d / bvar_d
+ * ([n_steps][M * sum_h], the layout of pmbrl_bnn_loss_grad) or, when both are null, drawn inside the kernel (Philox
+ * keyed by `seed`, counter = (row, unit, layer, first_step + i)).  exp_avg / exp_avg_sq / step_d: Adam's state (the
+ * device-side step counter is advanced by every iteration).  loss_out_d [3]: the last iteration's loss, -E[lml],
+ * reg; loss_hist_d (optional) [n_steps][3]: every iteration's.  Replaces eight launches and two torch.rand calls per
+ * iteration (train_regressor.py:58-165 runs 2 000 of them per policy-search round). */
+int pmbrl_bnn_train_steps(pmbrl_bnn_plan* plan, void* stream, void* workspace_d, const float* Xn_d, const float* Yn_d,
+                          const int32_t* idx_all_d, int32_t n_steps, float* params_flat_d, float* exp_avg_d,
+                          float* exp_avg_sq_d, int64_t* step_d, double lr, double beta1, double beta2, double eps,
+                          uint64_t seed, uint64_t first_step, const float* u_d, const float* bvar_d,
+                          float* loss_out_d, float* loss_hist_d);
+
 /* ---- test hooks (used by tests/ only) ---------------------------------- */
 /* y[R,O] = x[R,K] W[O,K]^T + b through the same MFMA tile routine the rollout
  * kernels use (R <= 64). */

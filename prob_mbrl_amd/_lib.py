@@ -94,7 +94,7 @@ EXPORTS = [
     'pmbrl_plan_set_timing', 'pmbrl_plan_read_timing', 'pmbrl_plan_set_prof', 'pmbrl_plan_set_replay', 'pmbrl_plan_replay_count',
     'pmbrl_mlp_workspace_bytes', 'pmbrl_mlp_forward', 'pmbrl_mlp_grad_input',
     'pmbrl_bnn_plan_create', 'pmbrl_bnn_plan_destroy', 'pmbrl_bnn_plan_workspace_bytes',
-    'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex',
+    'pmbrl_bnn_plan_n_params', 'pmbrl_bnn_loss_grad', 'pmbrl_bnn_loss_grad_ex', 'pmbrl_bnn_train_steps',
     'pmbrl_comm_unique_id', 'pmbrl_comm_init', 'pmbrl_allreduce_sum', 'pmbrl_comm_count', 'pmbrl_comm_destroy',
     'pmbrl_plan_set_comm', 'pmbrl_plan_set_collective',
     'pmbrl_p2p_create', 'pmbrl_p2p_handle', 'pmbrl_p2p_open', 'pmbrl_p2p_allreduce_f32', 'pmbrl_p2p_allreduce_f64',
@@ -181,6 +181,8 @@ def load():
     lib.pmbrl_bnn_loss_grad.argtypes = [vp] * 11
     lib.pmbrl_bnn_loss_grad_ex.restype = C.c_int
     lib.pmbrl_bnn_loss_grad_ex.argtypes = [vp] * 13 + [i32]
+    lib.pmbrl_bnn_train_steps.restype = C.c_int
+    lib.pmbrl_bnn_train_steps.argtypes = ([vp] * 6 + [i32] + [vp] * 4 + [C.c_double] * 4 + [C.c_uint64] * 2 + [vp] * 4)
     lib.pmbrl_debug_linear.restype = C.c_int
     lib.pmbrl_debug_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.pmbrl_plan_set_replay.restype = C.c_int

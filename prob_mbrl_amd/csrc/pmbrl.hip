@@ -140,21 +140,6 @@ __global__ void pm_set_int(int* p, int v) { *p = v; }
 // offset): a draw depends on (seed, offset, row, unit) alone, not on the launch shape.  Stream 0: the uniform noise u;
 // stream 1: the uniform the hard Bernoulli sample is thresholded with.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void pm_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                          unsigned (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (unsigned)p1;
-    c3 = (unsigned)p0;
-    c0 = n0;
-    c2 = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 struct DrawArgs {
   int kind;              // 0: Bernoulli(keep) -- BDropout.update_noise, models/modules.py:40-44;  1: concrete -- :95-118
   unsigned long long seed, offset;
@@ -2516,6 +2501,97 @@ extern "C" int pmbrl_bnn_loss_grad_ex(pmbrl_bnn_plan* p, void* stream, void* wor
   if (nfb < 1) nfb = 1;
   hipLaunchKernelGGL(pm_bnn_finish, dim3(nfb), dim3(256), 0, s, Fa);
   hipLaunchKernelGGL(pm_bnn_loss, dim3(1), dim3(64), 0, s, Fa, nfb);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Whole training iterations of utils/train_regressor.py:113-131 (likelihood + regulariser, Adam, no clipping) in TWO
+// launches each: pm_bnn_fwd_bwd, pm_bnn_tail (pmbrl_bnn.h).  n_steps iterations are queued by ONE call: minibatch i takes
+// rows idx_all_d[i * M ..]; the dropout noise comes from the in-kernel generator (seed, first_step + i) unless recorded
+// draws are handed in (u_d / bvar_d: [n_steps][M * sum_h]).  The weights' fragments are packed once at the start of the
+// call (the parameters may have changed outside) and kept current by the tail of every iteration.
+extern "C" int pmbrl_bnn_train_steps(pmbrl_bnn_plan* p, void* stream, void* workspace_d, const float* Xn_d, const float* Yn_d,
+                                     const int32_t* idx_all_d, int32_t n_steps, float* params_flat_d, float* exp_avg_d,
+                                     float* exp_avg_sq_d, int64_t* step_d, double lr, double beta1, double beta2, double eps,
+                                     uint64_t seed, uint64_t first_step, const float* u_d, const float* bvar_d,
+                                     float* loss_out_d, float* loss_hist_d) {
+  if (!p || !workspace_d || !Xn_d || !Yn_d || !idx_all_d || !params_flat_d || !exp_avg_d || !exp_avg_sq_d || !step_d ||
+      !loss_out_d || n_steps < 1)
+    return fail(-1, "bad argument");
+  if (p->cfg.loss_kind != 0) return fail(-3, "pmbrl_bnn_train_steps: the diagonal-Gaussian likelihood only (use pmbrl_bnn_loss_grad_ex)");
+  if ((u_d == nullptr) != (bvar_d == nullptr)) return fail(-1, "bnn: u and bvar come together");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(p->device));
+  char* ws = static_cast<char*>(workspace_d);
+  PackArgs PK;
+  PK.wflag = nullptr; PK.gen = 0; PK.n = 0; PK.status = nullptr;
+  BnnArgs A;
+  memset(&A, 0, sizeof(A));
+  A.M = p->cfg.M; A.nl = p->nl; A.LD = p->LD; A.n_out = p->dim[p->nl] / 2; A.nwg = p->nwg;
+  A.n_in = p->dim[0]; A.sum_h = p->sum_h;
+  BnnTailArgs T;
+  memset(&T, 0, sizeof(T));
+  T.nl = p->nl; T.n_chunks = p->nwg; T.sum_h = p->sum_h; T.N = p->cfg.N;
+  int units = 0;
+  for (int i = 0; i <= p->nl; ++i) { A.dim[i] = T.dim[i] = p->dim[i]; A.nt[i] = T.nt[i] = p->nt[i]; }
+  for (int l = 0; l < p->nl; ++l) {
+    float* wf = reinterpret_cast<float*>(ws + p->off_wf[l]);
+    float* wb = reinterpret_cast<float*>(ws + p->off_wb[l]);
+    float* bs = reinterpret_cast<float*>(ws + p->off_bias[l]);
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wf, p->dim[l + 1], p->dim[l], 0, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->w_off[l], wb, p->dim[l + 1], p->dim[l], 1, 1, 0, 0, 0};
+    PK.job[PK.n++] = PackJob{params_flat_d + p->b_off[l], bs, p->dim[l + 1], p->dim[l], 0, 1, 1, 0, 0};
+    A.wf[l] = wf; A.wb[l] = wb; A.bias[l] = bs;
+    T.wf[l] = wf; T.wb[l] = wb; T.bias[l] = bs;
+    A.actT[l] = reinterpret_cast<float*>(ws + p->off_actT[l]);
+    A.gT[l] = reinterpret_cast<float*>(ws + p->off_gT[l]);
+    T.actT[l] = A.actT[l]; T.gT[l] = A.gT[l];
+    A.lp_off[l] = T.lp_off[l] = p->lp_off[l];
+    T.w_off[l] = p->w_off[l]; T.b_off[l] = p->b_off[l]; T.lp_poff[l] = p->lp_poff[l];
+    T.has_drop[l] = p->has_drop[l];
+    T.reg_scale[l] = p->cfg.reg_scale[l]; T.drop_reg[l] = p->cfg.drop_reg[l];
+    T.unit0[l] = units;
+    units += p->nt[l];
+    if (p->has_drop[l]) {
+      A.logit_p[l] = params_flat_d + p->lp_poff[l];
+      A.inv_temp[l] = 1.f / p->cfg.temperature[l];
+    }
+  }
+  T.unit0[p->nl] = units;
+  if (units > 512) return fail(-3, "pmbrl_bnn_train_steps: network too wide for the fused tail");
+  A.X = Xn_d; A.Y = Yn_d;
+  A.mls = p->cfg.max_log_std;
+  A.inv_M = T.inv_M = 1.f / (float)p->cfg.M;
+  A.part_lp = reinterpret_cast<float*>(ws + p->off_part_lp);
+  A.part_loss = reinterpret_cast<float*>(ws + p->off_part_loss);
+  T.part_lp = A.part_lp; T.part_loss = A.part_loss; T.n_part_loss = p->nwg;
+  T.reg_weight = p->cfg.reg_weight;
+  T.params = params_flat_d; T.m = exp_avg_d; T.v = exp_avg_sq_d;
+  T.reg_part = reinterpret_cast<float*>(ws + p->off_reg_part);
+  T.counter = reinterpret_cast<unsigned*>(ws + p->off_reg_part) + 1000;
+  T.step = reinterpret_cast<long long*>(step_d);
+  T.lr = (float)lr; T.b1 = (float)beta1; T.b2 = (float)beta2; T.eps = (float)eps;
+  T.ln_b1 = log(beta1); T.ln_b2 = log(beta2);
+  A.rng = u_d ? 0 : 1;
+  A.prof = getenv("PMBRL_BNN_PROF") ? reinterpret_cast<long long*>(ws + p->off_reg_part) + 256 : nullptr;      // (debugging: stamps at floats 512.. of the scratch)
+  A.rng_k0 = (unsigned)seed; A.rng_k1 = (unsigned)(seed >> 32);
+  HIPCHK(hipMemsetAsync(T.counter, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(pm_pack_all, dim3(32, PK.n), dim3(256), 0, s, PK);
+  const size_t noise = (size_t)p->cfg.M * p->sum_h;
+  for (int i = 0; i < n_steps; ++i) {
+    A.idx = idx_all_d + (size_t)i * p->cfg.M;
+    A.rng_step = (unsigned)(first_step + (uint64_t)i);
+    for (int l = 0; l < p->nl; ++l)
+      if (p->has_drop[l] && u_d) {
+        A.u[l] = u_d + (size_t)i * noise + (size_t)p->cfg.M * p->lp_off[l];
+        A.bvar[l] = bvar_d + (size_t)i * noise + (size_t)p->cfg.M * p->lp_off[l];
+      }
+    T.loss_out = loss_hist_d ? loss_hist_d + (size_t)3 * i : loss_out_d;
+    hipLaunchKernelGGL(pm_bnn_fwd_bwd, dim3(p->nwg), dim3(PM_NT), p->lds, s, A);
+    hipLaunchKernelGGL(pm_bnn_tail, dim3(units), dim3(PM_BNT_NT), 0, s, T);
+  }
+  if (loss_hist_d)
+    HIPCHK(hipMemcpyAsync(loss_out_d, loss_hist_d + (size_t)3 * (n_steps - 1), 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   return 0;
 }

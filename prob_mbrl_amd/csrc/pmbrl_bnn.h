@@ -37,7 +37,18 @@ struct BnnArgs {
   float* gT[PM_MAXL];              // stash: grad wrt pre-activation of layer l [wg][nt[l+1]*16][16]
   float* part_lp;                  // [nwg][sum_h]
   float* part_loss;                // [nwg]
+  // u / bvar drawn inside the kernel (pmbrl_bnn_train_steps without recorded draws): Philox keyed by the caller's seed,
+  // counter = (minibatch row, feature quad, hidden layer | stream << 8, step)
+  int rng;
+  unsigned rng_k0, rng_k1, rng_step;
+  long long* prof;                 // debugging: cycle stamps of workgroup 0 (nullptr: none)
 };
+
+// 1 / x to an ulp or two: v_rcp_f32 and one Newton step
+__device__ __forceinline__ float pm_fast_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
 
 // hidden layer forward: out = relu(acc + b) * hard ;  q = relu(.) * d mask / d logit_p
 struct EpiBnnFwd {
@@ -47,11 +58,18 @@ struct EpiBnnFwd {
   float inv_temp;
   float *h_out, *q_out, *stash;
   int ld, row0, nvalid, width, lane;
+  int rng;                       // 1: u / bvar from the generator (rk0, rk1, rstep; rlayer = this hidden layer)
+  unsigned rk0, rk1, rstep, rlayer;
   __device__ __forceinline__ void operator()(int ot, int rt, f32x4 acc) {
     const int g = lane >> 4, lrow = lane & 15;
     const int f0 = ot * 16 + 4 * g;
     const f32x4 b = ldg4(bias + f0);
     f32x4 h, q;
+    unsigned ru[4] = {0u, 0u, 0u, 0u}, rv[4] = {0u, 0u, 0u, 0u};
+    if (rng && logit_p) {      // 24-bit uniforms in [0, 1), what torch.rand gives a float tensor
+      pm_philox((unsigned)(row0 + lrow), (unsigned)(f0 >> 2), rlayer, rstep, rk0, rk1, ru);
+      pm_philox((unsigned)(row0 + lrow), (unsigned)(f0 >> 2), rlayer | 0x100u, rstep, rk0, rk1, rv);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = f0 + r;
@@ -59,10 +77,12 @@ struct EpiBnnFwd {
       float hv = v, qv = 0.f;
       if (logit_p && f < width && lrow < nvalid) {
         const size_t o = (size_t)(row0 + lrow) * width + f;
-        const float uu = u[o];
+        const float uu = rng ? (float)(ru[r] >> 8) * (1.0f / 16777216.0f) : u[o];
+        // (hardware log / exp / reciprocal instead of the IEEE sequences were measured here: no change -- the layer's time
+        //  is not in its arithmetic -- and the reciprocal's Newton step turns exp's overflow into a NaN; not kept)
         const float cp = logit_p[f] + logf((uu + 1e-7f) / (1.f - (uu - 1e-7f)));
         const float pr = sigmoidf(cp * inv_temp);
-        const bool hard = bvar[o] < pr;
+        const bool hard = (rng ? (float)(rv[r] >> 8) * (1.0f / 16777216.0f) : bvar[o]) < pr;
         hv = hard ? v : 0.f;
         qv = v * pr * (1.f - pr) * inv_temp;
       }
@@ -101,6 +121,8 @@ struct EpiBnnBwd {
   }
 };
 
+// (A GEMM variant that requests ALL of a wave's weight fragments of a layer at once was measured: pm_bnn_fwd_bwd 27.7 ->
+//  34.3 us -- the first MFMA then waits for 32 loads where gemm_tiles starts on four; the layer chain is not what bounds it.)
 __host__ __device__ inline size_t pm_bnn_lds_floats(int nl, int LD) {
   // H[0..nl-1], Q[0..nl-2], two gradient buffers, one gq buffer, K-split scratch, loss scratch
   return ((size_t)nl + (nl - 1) + 3) * 16 * LD + (size_t)PM_NW * PM_KS_NT * 256 + PM_NT;
@@ -122,6 +144,8 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
   float* GQ = G1 + (size_t)R * LD;
   float* part = GQ + (size_t)R * LD;
   float* red = part + (size_t)PM_NW * PM_KS_NT * 256;
+#define BNN_STAMP(i) do { if (A.prof && wg == 0 && tid == 0) A.prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  BNN_STAMP(0);
 
   // ---- gather the minibatch rows (+ dW stash of the first layer's input)
   {
@@ -136,16 +160,20 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
     }
   }
   __syncthreads();
+  BNN_STAMP(1);
   // ---- forward
   for (int l = 0; l < nl - 1; ++l) {
     EpiBnnFwd e{A.bias[l], A.logit_p[l], A.u[l], A.bvar[l], A.inv_temp[l],
                 H + (size_t)(l + 1) * R * LD, Q + (size_t)l * R * LD,
-                A.actT[l + 1] + (size_t)wg * A.nt[l + 1] * 16 * 16, LD, row0, nvalid, A.dim[l + 1], lane};
+                A.actT[l + 1] + (size_t)wg * A.nt[l + 1] * 16 * 16, LD, row0, nvalid, A.dim[l + 1], lane,
+                A.rng, A.rng_k0, A.rng_k1, A.rng_step, (unsigned)l};
     gemm_tiles<1>(A.wf[l], A.nt[l + 1], A.nt[l], H + (size_t)l * R * LD, LD, wid, lane, e);
     __syncthreads();
+    BNN_STAMP(2 + l);
   }
   gemm_narrow<1>(A.wf[nl - 1], A.nt[nl], A.nt[nl - 1], A.bias[nl - 1], H + (size_t)(nl - 1) * R * LD, G1, LD, part,
                  wid, lane, tid);
+  BNN_STAMP(10);
   // ---- mixture negative log-likelihood (losses.py:40-64; head parametrisation models/densities.py:173-207):
   //      ll = logsumexp_c [log_softmax(logit / T)_c - sum_d lsc_dc - D/2 log 2 pi - 1/2 sum_d t_dc^2]
   if (A.gmm_n > 1) {
@@ -273,6 +301,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
     if (A.row_lp && tid < nvalid) A.row_lp[row0 + tid] = rowlp[tid];
   }
   __syncthreads();
+  BNN_STAMP(11);
   // ---- backward: dX chain, dropout-logit terms, G stash
   float* Gin = G0;
   float* Gout = G1;
@@ -291,8 +320,10 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_bnn_fwd_bwd(const BnnArgs A) {
       }
     }
     __syncthreads();
+    BNN_STAMP(12 + (nl - 1 - l));
     float* t = Gin; Gin = Gout; Gout = t;
   }
+  BNN_STAMP(20);
 }
 
 // regulariser + reductions.  Flat layouts: params / grad = [W0, b0, W1, b1, ...] at w_off / b_off,
@@ -391,4 +422,235 @@ __global__ void pm_bnn_loss(const BnnFinishArgs A, int n_reg_part) {
   A.loss_out[0] = (float)(en + reg / (double)A.N);
   A.loss_out[1] = (float)en;
   A.loss_out[2] = (float)reg;
+}
+
+
+// ---------------------------------------------------------------------------
+// The rest of a training iteration in ONE launch (round 5; pmbrl_bnn_train_steps): dW / db from the stashes of
+// pm_bnn_fwd_bwd, the regulariser's gradient (pm_bnn_finish's arithmetic), Adam (torch.optim.Adam's, no clipping --
+// utils/train_regressor.py:113-131 clips nothing), the updated weights written back BOTH as the flat parameter vector
+// and as the MFMA fragments the next iteration's pm_bnn_fwd_bwd reads (pm_pack_all's layouts), and the loss.
+// The iteration used to be eight launches around 3 us of arithmetic (pack, forward + backward, dW, dW reduce,
+// regulariser, loss, Adam + the two torch.rand): 77 us.  Adam without a global norm is element-wise, so the
+// workgroup that forms a block of dW can finish those parameters on the spot.
+//
+// A workgroup = (layer L, 16 input columns kt of W_L): all output tiles of those columns, dealt to its four waves.
+// It owns what the regulariser couples: the columns' sums of squares feed the gradient of the dropout logits of the
+// hidden units that ARE those columns (hidden layer L - 1).  Column tile 0 of a layer also does the layer's bias.
+// ---------------------------------------------------------------------------
+#define PM_BNT_NW 8
+#define PM_BNT_NT (PM_BNT_NW * 64)
+struct BnnTailArgs {
+  int nl, n_chunks, sum_h, N;
+  int dim[PM_MAXL + 1], nt[PM_MAXL + 1];
+  int w_off[PM_MAXL], b_off[PM_MAXL], lp_poff[PM_MAXL], lp_off[PM_MAXL];
+  int has_drop[PM_MAXL];            // dropout behind hidden layer l (the output of Linear l)
+  int unit0[PM_MAXL + 1];           // first workgroup of layer l (prefix sums of nt[l])
+  float reg_scale[PM_MAXL], drop_reg[PM_MAXL];
+  float reg_weight, inv_M;
+  float *params, *m, *v;            // flat: parameters, Adam moments
+  float* wf[PM_MAXL];
+  float* wb[PM_MAXL];
+  float* bias[PM_MAXL];
+  const float* actT[PM_MAXL];
+  const float* gT[PM_MAXL];
+  const float* part_lp;
+  const float* part_loss;
+  int n_part_loss;
+  float* reg_part;                  // [gridDim.x]
+  unsigned* counter;                // arrival counter of the launch (left at zero)
+  float* loss_out;                  // [3]: loss, -E[lml], reg
+  long long* step;                  // device-side Adam step counter: this launch applies step[0] + 1, its last workgroup stores it
+  float lr, b1, b2, eps;
+  double ln_b1, ln_b2;              // ln beta1, ln beta2 (from the host)
+};
+
+struct BnnAdam {
+  float b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, inv_bc2;
+  // torch.optim.Adam (pm_clip_adam_kernel's arithmetic): returns the new parameter
+  __device__ __forceinline__ float operator()(float p, float g, float& m, float& v) const {
+    m = m * b1 + omb1 * g;
+    v = v * b2 + omb2 * g * g;
+    return p - step_size * (m * pm_fast_rcp(sqrtf(v) * inv_bc2 + eps));
+  }
+};
+
+__global__ __launch_bounds__(PM_BNT_NT) void pm_bnn_tail(const BnnTailArgs A) {
+  __shared__ float s_s2[PM_BNT_NW][16];
+  __shared__ double s_reg[PM_BNT_NT];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  int L = 0;
+  while (L + 1 < A.nl && (int)blockIdx.x >= A.unit0[L + 1]) ++L;
+  const int kt = (int)blockIdx.x - A.unit0[L];
+  const int O = A.dim[L + 1], K = A.dim[L], n_ot = A.nt[L + 1], n_kb = A.nt[L];
+  const int O16 = n_ot * 16, K16 = n_kb * 16;
+  BnnAdam ad;
+  {
+    // bias corrections 1 - beta^t from the device-side step count: beta^t = exp(t ln beta), the exponent formed in double
+    // (two double-precision pow calls were several hundred instructions at the head of every workgroup)
+    const double st = (double)(A.step[0] + 1);
+    ad.b1 = A.b1; ad.b2 = A.b2; ad.omb1 = 1.f - A.b1; ad.omb2 = 1.f - A.b2; ad.eps = A.eps;
+    ad.step_size = A.lr / (1.f - __expf((float)(st * A.ln_b1)));
+    ad.bc2_sqrt = sqrtf(1.f - __expf((float)(st * A.ln_b2)));
+    ad.inv_bc2 = 1.f / ad.bc2_sqrt;
+  }
+  // regulariser of the dropout layer in FRONT of Linear L (hidden layer q = L - 1): weight decay scaled by the units' keep
+  // logits; none in front of the first layer
+  const int q = L - 1;
+  const bool drop = L >= 1 && A.has_drop[q] != 0;
+  const float c = A.reg_weight / (float)A.N;
+  const float rs = drop ? A.reg_scale[q] : 0.f, dr = drop ? A.drop_reg[q] : 0.f;
+  const int k = kt * 16 + c16;      // this lane's input column
+  float p_k = 0.f;
+  if (drop && k < K) p_k = sigmoidf(A.params[A.lp_poff[q] + k]);
+  const float cw = 2.f * c * rs * p_k;
+  double reg = 0.0;
+  float s2 = 0.f;
+  const float* gbase = A.gT[L];
+  const float* abase = A.actT[L] + (size_t)(kt * 16 + c16) * 16 + 4 * g;
+  // A wave's tiles two at a time, EVERYTHING they read requested before the first value is used -- the gradient chunks
+  // (eight at a time), the parameters and both moments: taken in program order the kernel was a chain of dependent memory
+  // round trips (seven per tile for the chunks, one more for the optimiser state: 26 us for 3 us of arithmetic).
+  constexpr int CB = 8, TB = 2;
+  f32x4 bv[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) bv[u] = ldg4(abase + (size_t)min(u, A.n_chunks - 1) * K16 * 16);
+  for (int ot0 = wid; ot0 < n_ot; ot0 += TB * PM_BNT_NW) {
+    f32x4 a[TB][CB];
+    float pw[TB][4], pm[TB][4], pv[TB][4], pb[TB], pbm[TB], pbv[TB];
+    int pidx[TB][4];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int ot = min(ot0 + tb * PM_BNT_NW, n_ot - 1);
+      const float* gp = gbase + (size_t)(ot * 16 + c16) * 16 + 4 * g;
+#pragma unroll
+      for (int u = 0; u < CB; ++u) a[tb][u] = ldg4(gp + (size_t)min(u, A.n_chunks - 1) * O16 * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = min(ot * 16 + 4 * g + r, O - 1);
+        pidx[tb][r] = A.w_off[L] + o * K + min(k, K - 1);
+        pw[tb][r] = A.params[pidx[tb][r]];
+        pm[tb][r] = A.m[pidx[tb][r]];
+        pv[tb][r] = A.v[pidx[tb][r]];
+      }
+      const int ob = A.b_off[L] + min(ot * 16 + c16, O - 1);
+      pb[tb] = A.params[ob];
+      pbm[tb] = A.m[ob];
+      pbv[tb] = A.v[ob];
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int ot = ot0 + tb * PM_BNT_NW;
+      if (ot >= n_ot) break;
+      // dW tile: sum over the minibatch rows of g[o][row] act[k][row]; a lane's four k-values of a chunk are its rows
+      // 4 g .. 4 g + 3 (a sum over rows does not care about their order: one 16-byte load per operand and chunk)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float bsum = 0.f;
+      const float* gp = gbase + (size_t)(ot * 16 + c16) * 16 + 4 * g;
+      for (int c0 = 0; c0 < A.n_chunks; c0 += CB) {
+        if (c0 > 0) {      // (minibatches beyond 128 rows: the further chunks as they come)
+#pragma unroll
+          for (int u = 0; u < CB; ++u) {
+            a[tb][u] = ldg4(gp + (size_t)min(c0 + u, A.n_chunks - 1) * O16 * 16);
+            bv[u] = ldg4(abase + (size_t)min(c0 + u, A.n_chunks - 1) * K16 * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+          if (c0 + u < A.n_chunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma4(a[tb][u][j], bv[u][j], acc);
+            bsum += (a[tb][u][0] + a[tb][u][1]) + (a[tb][u][2] + a[tb][u][3]);
+          }
+        }
+      }
+      if (A.n_chunks > CB) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) bv[u] = ldg4(abase + (size_t)u * K16 * 16);
+      }
+      // lane: dW[o = 16 ot + 4 g + r][k]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ot * 16 + 4 * g + r;
+        if (o < O && k < K) {
+          const int idx = pidx[tb][r];
+          const float w = pw[tb][r];
+          float mi = pm[tb][r], vi = pv[tb][r];
+          const float wn = ad(w, acc[r] + cw * w, mi, vi);
+          s2 = fmaf(w, w, s2);
+          A.params[idx] = wn;
+          A.m[idx] = mi;
+          A.v[idx] = vi;
+          // forward fragments [ot][kb][lane (o % 16, (k % 16) / 4)][k % 4]; transposed ones [kt][ob][lane (k % 16, (o % 16) / 4)][o % 4]
+          A.wf[L][(((size_t)ot * n_kb + kt) * 64 + ((4 * g + r) + 16 * (c16 >> 2))) * 4 + (c16 & 3)] = wn;
+          A.wb[L][(((size_t)kt * n_ot + ot) * 64 + (c16 + 16 * g)) * 4 + r] = wn;
+        }
+      }
+      if (kt == 0) {
+        // bias of Linear L: db[o] = sum over rows of g[o][row] (lanes (o, g): partial over their rows)
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        const int o = ot * 16 + c16;
+        if (g == 0 && o < O) {
+          const int idx = A.b_off[L] + o;
+          const float bb = pb[tb];
+          float mi = pbm[tb], vi = pbv[tb];
+          const float bn = ad(bb, bsum + (drop ? 2.f * c * rs * bb : 0.f), mi, vi);
+          if (drop) reg += (double)(rs * bb * bb);
+          A.params[idx] = bn;
+          A.m[idx] = mi;
+          A.v[idx] = vi;
+          A.bias[L][o] = bn;
+        }
+      }
+    }
+  }
+  // the columns' sums of squares: over the lane groups, then over the waves
+  s2 += __shfl_xor(s2, 16);
+  s2 += __shfl_xor(s2, 32);
+  if (g == 0) s_s2[wid][c16] = s2;
+  __syncthreads();
+  if (drop && wid == 0 && g == 0 && k < K) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < PM_BNT_NW; ++w) tot += s_s2[w][c16];
+    float gdata = 0.f;
+    for (int w = 0; w < A.n_chunks; ++w) gdata += A.part_lp[(size_t)w * A.sum_h + A.lp_off[q] + k];
+    const float lgp = logf(p_k), lg1 = logf(1.f - p_k);
+    const int idx = A.lp_poff[q] + k;
+    float mi = A.m[idx], vi = A.v[idx];
+    const float ln = ad(A.params[idx], gdata + c * p_k * (1.f - p_k) * (rs * tot + dr * (lgp - lg1)), mi, vi);
+    reg += (double)(rs * p_k * tot + dr * (p_k * lgp + (1.f - p_k) * lg1));
+    A.params[idx] = ln;
+    A.m[idx] = mi;
+    A.v[idx] = vi;
+  }
+  s_reg[tid] = reg;
+  __syncthreads();
+  for (int o = PM_BNT_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) s_reg[tid] += s_reg[tid + o];
+    __syncthreads();
+  }
+  // the loss: the last workgroup to arrive adds the partials in a fixed order and advances the step counter
+  if (tid == 0) {
+    A.reg_part[blockIdx.x] = (float)s_reg[0];
+    __threadfence();
+    s_last = atomicAdd(A.counter, 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last && tid == 0) {
+    __threadfence();
+    double rsum = 0.0, nll = 0.0;
+    for (unsigned i = 0; i < gridDim.x; ++i) rsum += (double)__hip_atomic_load(A.reg_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = 0; w < A.n_part_loss; ++w) nll += (double)A.part_loss[w];
+    rsum *= (double)A.reg_weight;
+    const double en = nll * (double)A.inv_M;
+    A.loss_out[0] = (float)(en + rsum / (double)A.N);
+    A.loss_out[1] = (float)en;
+    A.loss_out[2] = (float)rsum;
+    A.step[0] += 1;
+    *A.counter = 0u;
+  }
 }

@@ -477,6 +477,24 @@ __device__ __forceinline__ void gemm_narrow(const float* __restrict__ wf, int n_
   __syncthreads();
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> four 32-bit words (pmbrl_draw_masks, the BNN
+// training step's in-kernel dropout noise)
+__device__ __forceinline__ void pm_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                          unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // numerically careful scalar helpers (match torch CPU within fp32 rounding)
 __device__ __forceinline__ float softplusf(float x) {
   // torch.nn.functional.softplus, threshold 20 (models/densities.py:97)

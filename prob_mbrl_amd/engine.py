@@ -263,6 +263,30 @@ class BnnStep:
                                                    int(terms)), 'pmbrl_bnn_loss_grad_ex')
         return grad, self.loss
 
+    def train_steps(self, Xn, Yn, idx_all, params, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+                    seed=0, first_step=0, u=None, bvar=None, loss_hist=None):
+        """Whole training iterations (loss, gradient, torch.optim.Adam's step: utils/train_regressor.py:113-131) in two
+        launches each, all queued by this one call (pmbrl_bnn_train_steps).  idx_all int32 [n_steps, M]; params /
+        exp_avg / exp_avg_sq flat fp32, updated in place; step: int64 device tensor [1] (Adam's step count, advanced on
+        the device).  u, bvar: recorded dropout draws [n_steps, M * sum_h], or None: drawn in the kernel from `seed`
+        (counter first_step + i).  loss_hist: optional fp32 [n_steps, 3].  Returns loss[3] of the last iteration."""
+        for t in (Xn, Yn, params, exp_avg, exp_avg_sq):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert idx_all.is_cuda and idx_all.dtype == torch.int32 and idx_all.is_contiguous() and idx_all.numel() % self.M == 0
+        n_steps = idx_all.numel() // self.M
+        assert n_steps >= 1 and params.numel() == self.n_params == exp_avg.numel() == exp_avg_sq.numel()
+        assert step.is_cuda and step.dtype == torch.int64 and step.numel() == 1
+        for t in (u, bvar):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and
+                                 t.numel() == n_steps * self.M * self.sum_h)
+        assert loss_hist is None or (loss_hist.is_cuda and loss_hist.dtype == torch.float32 and loss_hist.numel() == 3 * n_steps)
+        _lib.check(self.lib.pmbrl_bnn_train_steps(self.plan, _stream(), _ptr(self.ws), _ptr(Xn), _ptr(Yn), _ptr(idx_all),
+                                                  n_steps, _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(step),
+                                                  float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                  int(seed) & (2 ** 64 - 1), int(first_step), _ptr(u), _ptr(bvar),
+                                                  _ptr(self.loss), _ptr(loss_hist)), 'pmbrl_bnn_train_steps')
+        return self.loss
+
 
 def make_reward_struct(spec, D, U):
     """spec: dict(kind, expand, angle_dims, C [k,De], tip_target [k], norm, w,

@@ -2,6 +2,8 @@
 training of the Bayesian dynamics model.  The iteration body -- forward in train() mode with
 concrete dropout, Gaussian log-likelihood, dropout regulariser, backward -- is one device call
 (pmbrl_bnn_loss_grad), the optimiser step is the fused Adam of the policy path (pmbrl_clip_adam)."""
+import os
+
 import numpy as np
 import torch
 
@@ -179,6 +181,62 @@ def train_regressor(model, iters=2000, batchsize=100, resample=True, optimizer=N
     rng = range(iters + 1)       # the reference runs iters + 1 steps (`if i == iters: break` after the step)
     pbar = pbar_class(rng, total=iters) if pbar_class is not None else rng
     last = None
+    # The plain call (what the example scripts issue 2 000 iterations at a time, examples/deep_pilco_mm.py:218-227): whole
+    # iterations on the device, two launches each, queued in chunks by ONE library call per chunk (pmbrl_bnn_train_steps) --
+    # minibatch indices uploaded per chunk, dropout noise drawn in the kernel from a seed taken from torch's generator
+    # (reproducible under torch.manual_seed), Adam's step on the device.  The recorded draws of a test replay go through
+    # the same kernels, one iteration per call.
+    fused = (not mixture and not prioritized_sampling and not decoupled_reg and sum_h > 0 and
+             (resample or _replay is not None) and os.environ.get('PMBRL_BNN_FUSED', '1') != '0')
+    if fused:
+        g = cache['group']
+        step_dev = torch.tensor([int(cache['step'])], dtype=torch.int64, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if _replay is None else 0
+        chunk = 1 if _replay is not None else 50
+        n_total, done = iters + 1, 0
+        pending = []
+        it_pbar = iter(pbar)
+        while done < n_total:
+            # consecutive minibatches of one size (an epoch's last one may be short)
+            if not pending:
+                pending.append(next(batches)[0])
+            M = len(pending[0])
+            take = [pending.pop(0)]
+            while len(take) < min(chunk, n_total - done):
+                nxt = next(batches)[0]
+                if len(nxt) != M:
+                    pending.append(nxt)
+                    break
+                take.append(nxt)
+            st = steps.get(M)
+            if st is None:
+                st = steps[M] = E.BnnStep(dims, temps, rscale, dreg, M, N, reg_weight,
+                                          max_log_std=float(density.max_log_std), device=dev)
+            idx_all = torch.as_tensor(np.stack(take).astype(np.int32), device=dev).contiguous()
+            u = bv = None
+            if _replay is not None:
+                f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev).reshape(-1)  # noqa: E731
+                u = torch.cat([f32(a) for a in _replay['u'][done]]).contiguous()
+                bv = torch.cat([1.0 - f32(a) for a in _replay['hard'][done]]).contiguous()      # hard = (bvar < probs)
+            hist = torch.empty(len(take), 3, dtype=torch.float32, device=dev)
+            loss = st.train_steps(Xn, Yn, idx_all, flat, cache['m'], cache['v'], step_dev, g['lr'], g['betas'], g['eps'],
+                                  seed=seed, first_step=done, u=u, bvar=bv, loss_hist=hist)
+            cache['step'] += len(take)
+            last = loss
+            if summary_writer is not None:
+                names = ['training_loss', 'E_lml', 'reg_loss']
+                if summary_scope:
+                    names = ['/'.join([summary_scope, n]) for n in names]
+                for k, lv in enumerate(hist.tolist()):
+                    summary_writer.add_scalar(names[0], lv[0], done + k)
+                    summary_writer.add_scalar(names[1], -lv[1], done + k)
+                    summary_writer.add_scalar(names[2], lv[2], done + k)
+            for k in range(len(take)):
+                i = next(it_pbar, None)
+                if i is not None and hasattr(pbar, 'set_description') and (i % 50 == 0):
+                    pbar.set_description('log-likelihood of data: %f' % (-float(hist[k, 1])))
+            done += len(take)
+        pbar = ()
     for i in pbar:
         idx_np, tree_idx, w_np = next(batches)
         M = len(idx_np)

@@ -394,6 +394,64 @@ def test_mlp_forward_matches_torch(B, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n in common.fixture_names('bnn') if n != 'bnn_gmm'])
+def test_bnn_fused_training_matches_reference(name):
+    """pmbrl_bnn_train_steps -- whole iterations in two launches each (forward + backward; dW, regulariser, Adam, re-packed
+    weights and loss in one kernel), ALL of the fixture's iterations queued by one call -- replaying the reference's
+    train_regressor run (recorded minibatches and dropout draws): every iteration's loss and the final parameters.  The
+    re-packed weight fragments are what the second and later iterations compute with: a wrong fragment shows in their
+    losses."""
+    from prob_mbrl_amd import engine as E
+    d = np.load(common.os.path.join(common.GOLDEN, name + '.npz'))
+    dev = torch.device('cuda:0')
+    nl = int(d['n_layers'])
+    T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)  # noqa: E731
+    parts, keys = [], []
+    for l in range(nl):
+        parts += [T(d['W%d_init' % l]).reshape(-1), T(d['b%d_init' % l]).reshape(-1)]
+        keys += ['W%d' % l, 'b%d' % l]
+        if l < nl - 1:
+            parts.append(T(d['logit_p%d_init' % l]).reshape(-1))
+            keys.append('logit_p%d' % l)
+    flat = torch.cat(parts).contiguous()
+    sizes = [p.numel() for p in parts]
+    dims = [d['W0_init'].shape[1]] + [d['W%d_init' % l].shape[0] for l in range(nl)]
+    M, N, iters = int(d['M']), int(d['N']), int(d['iters'])
+    step = E.BnnStep(dims, [float(d['temp%d' % l]) for l in range(nl - 1)], [float(d['reg_scale%d' % l]) for l in range(nl - 1)],
+                     [float(d['drop_reg%d' % l]) for l in range(nl - 1)], M, N, float(d['reg_weight']),
+                     max_log_std=float(d['max_log_std']), device=dev)
+    Xn, Yn = T(d['Xn']), T(d['Yn'])
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    idx = torch.tensor(np.stack([d['idx_it%d' % it].astype(np.int32) for it in range(iters)]), device=dev).contiguous()
+    u = torch.stack([torch.cat([T(d['u%d_it%d' % (l, it)]).reshape(-1) for l in range(nl - 1)]) for it in range(iters)]).contiguous()
+    bvar = torch.stack([torch.cat([1.0 - T(d['hard%d_it%d' % (l, it)]).reshape(-1) for l in range(nl - 1)])
+                        for it in range(iters)]).contiguous()
+    stepc = torch.zeros(1, dtype=torch.int64, device=dev)
+    hist = torch.zeros(iters, 3, device=dev)
+    loss = step.train_steps(Xn, Yn, idx, flat, m, v, stepc, float(d['lr']), u=u, bvar=bvar, loss_hist=hist)
+    torch.cuda.synchronize()
+    assert int(stepc.item()) == iters
+    assert np.allclose(hist.cpu().numpy(), d['losses'][:iters], rtol=3e-5, atol=2e-6), (hist, d['losses'])
+    assert torch.equal(loss.cpu(), hist[-1].cpu())
+    off = 0
+    for key, n in zip(keys, sizes):
+        got = flat[off:off + n].cpu().numpy()
+        want = d[key + '_final'].reshape(-1)
+        assert np.allclose(got, want, rtol=1e-4, atol=2e-6), (key, np.abs(got - want).max())
+        off += n
+    # the in-kernel noise: reproducible from its seed, different from step to step, and the loss of a fit goes down
+    flat2, m2, v2 = torch.cat(parts).contiguous(), torch.zeros_like(flat), torch.zeros_like(flat)
+    runs = []
+    for _ in range(2):
+        f, mm, vv, sc = flat2.clone(), m2.clone(), v2.clone(), torch.zeros(1, dtype=torch.int64, device=dev)
+        h = torch.zeros(40, 3, device=dev)
+        ix = torch.randint(0, N, (40, M), device=dev, dtype=torch.int32, generator=torch.Generator(device=dev).manual_seed(3))
+        step.train_steps(Xn, Yn, ix, f, mm, vv, sc, 1e-3, seed=1234, first_step=0, loss_hist=h)
+        runs.append((f.cpu(), h.cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert bool(torch.isfinite(runs[0][1]).all()) and float(runs[0][1][-5:, 0].mean()) < float(runs[0][1][:5, 0].mean())
+
+
 @pytest.mark.parametrize('name', common.fixture_names('bnn'))
 def test_bnn_training_matches_reference(name):
     """pmbrl_bnn_loss_grad + pmbrl_clip_adam replaying the reference's train_regressor

@@ -50,20 +50,40 @@ def main():
         step.loss_grad(Xn, Yn, idx, flat, u, b, g)
         E.clip_adam(flat, g, m, v, i + 1, 1e-4, max_norm=None)
 
+    # round 5: whole iterations in two launches each, queued 100 at a time by one library call (pmbrl_bnn_train_steps:
+    # in-kernel dropout noise, Adam on the device; the minibatch rows of a chunk drawn by ONE torch.randint); the
+    # launch-per-piece path above is kept as `unfused` in the line
     for i in range(20):
         it(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.iters):
+    for i in range(a.iters // 4):
         it(20 + i)
     torch.cuda.synchronize()
+    dt_unfused = (time.perf_counter() - t0) / (a.iters // 4)
+    stepc = torch.zeros(1, dtype=torch.int64, device=dev)
+    CH = 100
+
+    def chunk(k):
+        idx = torch.randint(0, a.N, (CH, a.batch), device=dev, dtype=torch.int32)
+        step.train_steps(Xn, Yn, idx, flat, m, v, stepc, 1e-4, seed=7, first_step=k * CH)
+
+    chunk(0)
+    torch.cuda.synchronize()
+    n_chunks = max(1, a.iters // CH)
+    t0 = time.perf_counter()
+    for k in range(n_chunks):
+        chunk(1 + k)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(flat).all())
+    a.iters = n_chunks * CH
+    assert bool(torch.isfinite(flat).all()) and int(stepc.item()) == (n_chunks + 1) * CH
     # CPU leg: bench.py's cpu_baseline code times the oracle's step on the host (bounded sample)
     from bench import cpu_baseline_bnn
     rate_cpu, cores = cpu_baseline_bnn(dims, h, Xn.cpu(), Yn.cpu(), a.N, a.batch, a.cpu_iters)
     print(json.dumps(dict(metric='bnn_training_iterations_per_sec', value=a.iters / dt, unit='it/s',
-                          us_per_iteration=dt / a.iters * 1e6,
+                          us_per_iteration=dt / a.iters * 1e6, launches_per_iteration=2,
+                          unfused=dict(value=1.0 / dt_unfused, us_per_iteration=dt_unfused * 1e6, launches_per_iteration=10),
                           config=dict(workload='dynamics BNN %s, minibatch %d of %d rows, concrete dropout, '
                                                'Gaussian NLL + regulariser, Adam' % (dims, a.batch, a.N)),
                           cpu_baseline=dict(value=rate_cpu, unit='it/s', cores=cores,
