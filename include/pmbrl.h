@@ -301,8 +301,10 @@ int pmbrl_rollout_fwd(pmbrl_plan* plan, void* stream, void* workspace_d,
  * (utils/rollout.py:154-157): grad_rewards / grad_actions of steps >= n are ignored,
  * the terminal state gradient is grad_states[n], action_grad_norms rows >= n are
  * left untouched.  Read on the device: no host round trip between the sweeps.
- * status_d[1] is cleared and then set non-zero if the sweep itself failed (the
- * device-wide barrier of a moment-matching group spanning workgroups timed out).
+ * status_d[1] is set non-zero if the sweep itself failed (a barrier or a statistics
+ * exchange of a moment-matching group spanning workgroups timed out); it is CLEARED BY
+ * pmbrl_rollout_fwd (the forward call's status array must be this one: int32[2]) --
+ * a second adjoint call behind a failed one still reports the failure.
  * NULL: the full horizon. */
 int pmbrl_rollout_bwd(pmbrl_plan* plan, void* stream, void* workspace_d,
                       const pmbrl_inputs* in, const float* states_d,

@@ -1826,8 +1826,14 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
     if (p->mm_fan || p->reg_mm) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
     if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
-    if (p->mm_parts > 1 && As.xch) HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));      // ... or the granules' tags
-    if (pm_reg_can_run(p, As, true)) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);
+    // (the granules' tags: zeroed per launch for the latency-optimised family, whose tags count the steps from 1; the
+    //  register-resident family's carry a launch generation instead -- once zeroed, never again: two 5 us fill kernels less)
+    const bool reg_now = pm_reg_can_run(p, As, true);
+    if (p->mm_parts > 1 && As.xch && (!reg_now || !p->xch_zeroed)) {
+      HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));
+      p->xch_zeroed = reg_now ? 1 : 0;
+    }
+    if (reg_now) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);
     else launch_fwd_rt(p, As, s);
   } else {
     const size_t smem = pm_mm_kernel_doubles(p->cfg.D) * sizeof(double);
@@ -1922,7 +1928,8 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   // the sweep if its device-wide barrier timed out
   A.nvalid = status_d;
   A.status = status_d ? status_d + 1 : nullptr;
-  if (status_d) HIPCHK(hipMemsetAsync(status_d + 1, 0, sizeof(int32_t), s));
+  // (cleared by the FORWARD call's reward launch -- pm_reward_all_kernel -- since round 5: as a memset of its own here it
+  //  was a 5 us fill kernel in every iteration, 1 % of the cart-pole shape's)
   // this call goes to the latency-optimised family after a forward call that packed the register-resident family's
   // weights only: pack the others now (same parameters: the caller hands the same inputs to both calls)
   const bool reg_bwd = pm_reg_can_run(p, A, false);
@@ -2045,7 +2052,10 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       // groups split over workgroups: their own flags, and two buffers for the rows of dL/dx they exchange
       A.gsync += 1024;
       HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
-      if (A.xch) HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
+      if (A.xch && (!reg_bwd || !p->xch_zeroed)) {
+        HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
+        p->xch_zeroed = reg_bwd ? 1 : 0;
+      }
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }
     if (reg_bwd) pm_reg_launch(p, ws, A, in->pol_params_d, in->dyn_params_d, s, false);

@@ -1000,6 +1000,8 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   const long long i = i0 + threadIdx.x;
   const int D = A.D, U = A.U;
   const int ld = D | 1;
+  // (the adjoint call's failure flag, the status word's second entry: cleared here, by a launch every forward call makes)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && A.status) A.status[1] = 0;
   const int nrow = (int)min((long long)blockDim.x, n - i0);
   {
     const float* src = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i0 * D : A.states + ((size_t)i0 + A.B) * D;

@@ -71,6 +71,8 @@ struct pmbrl_plan {
   int inplace;   // general family on split operands: 64-row workgroups with in-place layers (pm_rollout_fwd<4, 2, true>)
   int mm_wide;   // mm_mode 2 through the LDS-staged kernels for 6 < D <= 32 (pmbrl_mm_wide.h)
   int mm_parts;  // mm_mode 1 with every group split over this many workgroups (RolloutArgs::mm_parts); 1: whole groups
+  int xch_zeroed;          // the exchange's granules hold no tag a launch of the register-resident family could mistake for its own
+  mutable unsigned xch_gen;   // ... whose tags carry this launch generation (pmbrl_reg_mm.h)
   int mm_gpb;    // ... launched in batches of this many groups (0: all at once) -- more workgroups than CUs, and the
                  // statistics exchange needs a group's workgroups resident together
   int mm_fan;    // ... more than 8: parts per collector of the two-level sum exchange (0: one level)

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       }
       if (wid == 0) {
         float xo[2];
-        const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
+        const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, Q.tag0 + (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
                                                mm_zh + (t & 1) * (16 * MMDc), xo,
                                                (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       if (do_chain) {
         if (wid == 0) {
           float go[(MMDc + 3) / 4];
-          const bool ok = pr_mm_bwd_chain<MMDc>(Q, (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
+          const bool ok = pr_mm_bwd_chain<MMDc>(Q, Q.tag0 + (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
                                                  mm_bop + (t & 1) * PR_MM_BOP_DOUBLES, mm_yop + (t & 1) * PR_MM_YOP_DOUBLES(MMDc), go,
                                                  (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
           if (!ok && lane == 0 && A.status) atomicMax(A.status, 1);

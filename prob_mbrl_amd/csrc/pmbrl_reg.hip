@@ -41,7 +41,7 @@ bool pm_reg_plan_ok(const pmbrl_plan* p) {
     // split over 2..8 of them with the statistics exchange; state widths 4..6.  (Moment matching of the rewards alone
     // leaves the sweep plain but lays the rows out by groups: the latency-optimised family's.)
     if (p->mm_mode != 1 || !(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS)) return false;
-    if (!pm_reg_mm_shape_ok(p, p->prec) || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16) return false;
+    if (!pm_reg_mm_shape_ok(p, p->prec) || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16 || c.H >= 4096) return false;
     if (p->mm_parts <= 1 && p->rows_per_wg != p->M) return false;      // (several whole groups per workgroup: not here)
   }
   return true;
@@ -120,6 +120,7 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
     R.mm.xt = A.xt;
     R.mm.xt_off = (unsigned)p->off_xt;
     R.mm.xch = A.xch;
+    R.mm.tag0 = (++p->xch_gen) << 12;      // (steps < 4096; the parity of a tag is the parity of its step: the two sets alternate)
     R.mm.inv_m = 1.0 / (double)p->M;
     R.mm.inv_m1 = 1.0 / (double)(p->M - 1);
   }

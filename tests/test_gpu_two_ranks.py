@@ -365,3 +365,59 @@ def test_bench_two_ranks_p2p_transport_one_device():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and 'peer-to-peer' in out['collective']
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import prob_mbrl_amd as pm
+        from prob_mbrl_amd import distributed as D
+        from prob_mbrl_amd import engine as E
+        d = dict(common.load('nomm_d4'))
+        B, H = d['x0'].shape[0], int(d['H'])
+        lo, hi = D.shard_bounds(B, None, world, rank)
+        for k in list(d):
+            if k == 'x0' or k in ('pol_z', 'dyn_z') or '_mask' in k:
+                d[k] = d[k][lo:hi]
+        dyn, pol = common.modules_from_fixture(d, 'nomm_d4', 'cuda:0')
+        real = E.Engine.valid_steps
+        if rank == 1:      # this rank's device "finds" a failure at step 8 of 12: the other rank must stop there too
+            def failing(self):
+                real(self)
+                self.status[0] = 8
+                return 8
+            E.Engine.valid_steps = failing
+        S, A, R = pm.utils.rollout(torch.tensor(d['x0'], device='cuda:0'), dyn, pol, H, resample_state_noise=False,
+                                   resample_action_noise=False, agree_group=dist.group.WORLD, B_global=B, row_offset=lo)
+        E.Engine.valid_steps = real
+        # p2p_check without a cached peer-to-peer object on one of the ranks: both must still enter its all-reduce
+        os.environ['PMBRL_P2P'] = '1'
+        if rank == 0:
+            D._P2PS[(id(None), 'cuda:0')] = type('FakeP2P', (), {'failed': lambda self: False})()
+        D.p2p_check(None, torch.device('cuda:0'))
+        del os.environ['PMBRL_P2P']
+        D._P2PS.clear()
+        out.put((rank, len(S), len(A), len(R)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_truncated_horizon_and_all_enter_p2p_check():
+    """rollout(agree_group=...): a failure only ONE rank's device reports truncates the horizon on every rank (a rank
+    that truncated alone would leave the others inside the next collective); p2p_check enters its all-reduce on every
+    rank whether or not the rank holds a cached peer-to-peer object (a rank that returned early hung the others)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 9, 8, 8), (1, 9, 8, 8)], res
