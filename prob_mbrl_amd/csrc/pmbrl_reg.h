@@ -125,6 +125,16 @@ __device__ __forceinline__ const RegMM* pr_mm_args() {
   typedef __attribute__((address_space(4))) const char* kcp;
   return (const RegMM*)((kcp)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RegArgs, mm));
 }
+// Logical workgroup of this hardware workgroup (-1: none -- padding).  Workgroups go round-robin to the 8 XCDs, each with an
+// L2 of its own: dealt in blocks of 8 groups -- hardware workgroup 8 j + i of a block = part j of the block's group i --
+// the parts of a group land on ONE XCD and their statistics exchange meets in that L2 instead of crossing the fabric.
+__device__ __forceinline__ int pr_wg(const RegArgs& A) {
+  const int hw = (int)blockIdx.x + A.wg0;
+  if (!A.mm.on || !A.mm.xcd) return hw;
+  const int P = A.mm.parts, blk = hw / (8 * P), r = hw - blk * (8 * P);
+  const int gi = blk * 8 + (r & 7);
+  return gi < A.mm.groups ? gi * P + (r >> 3) : -1;
+}
 // rows of workgroup wg: 16 consecutive rows, or -- moment matching -- part wg % parts of group wg / parts
 __device__ __forceinline__ void pr_rows(const RegArgs& A, int wg, int& row0, int& nvalid) {
   if (A.mm.on) {
@@ -585,7 +595,8 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   typedef PM_GLOBAL_ char gch;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x + A.wg0;
+  const int wg = pr_wg(A);
+  if (wg < 0) return;
   const int row = lane & 15, g = lane >> 4;
   int row0, nvalid;
   pr_rows(A, wg, row0, nvalid);
@@ -1028,7 +1039,8 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
   typedef PM_GLOBAL_ float gf32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x + A.wg0;
+  const int wg = pr_wg(A);
+  if (wg < 0) return;
   const int row = lane & 15, g = lane >> 4;
   int row0, nvalid;
   pr_rows(A, wg, row0, nvalid);

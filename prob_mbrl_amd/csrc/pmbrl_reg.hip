@@ -120,6 +120,7 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
     R.mm.xt = A.xt;
     R.mm.xt_off = (unsigned)p->off_xt;
     R.mm.xch = A.xch;
+    R.mm.xcd = (p->mm_parts > 1 && !(getenv("PMBRL_XCH_XCD") && atoi(getenv("PMBRL_XCH_XCD")) == 0)) ? 1 : 0;
     R.mm.tag0 = (++p->xch_gen) << 12;      // (steps < 4096; the parity of a tag is the parity of its step: the two sets alternate)
     R.mm.inv_m = 1.0 / (double)p->M;
     R.mm.inv_m1 = 1.0 / (double)(p->M - 1);
@@ -192,10 +193,14 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
             p->off_mmfac, p->off_reg_pack, p->off_gT[0], p->off_gT[1], p->off_gT[2], p->off_actT[0], p->off_actT[1], p->off_actT[2],
             p->off_reg_ab[0][0], p->off_reg_ab[0][1], p->off_reg_ab[1][0], p->off_reg_ab[1][1], p->ws_bytes);
   // (more groups than fit the chip at once: batches of whole groups, one launch each -- pmbrl_host.h, mm_gpb)
-  const int per = (p->reg_mm && p->mm_gpb > 0) ? p->mm_gpb * p->mm_parts : p->nwg;
-  for (int w0 = 0; w0 < p->nwg; w0 += per) {
+  // (groups' parts on one XCD -- pr_wg: hardware workgroups in blocks of 8 groups, the last block padded with workgroups
+  //  that exit at once; a batch is a whole number of blocks)
+  const int total = R.mm.xcd ? (p->G + 7) / 8 * 8 * p->mm_parts : p->nwg;
+  int per = (p->reg_mm && p->mm_gpb > 0) ? p->mm_gpb * p->mm_parts : total;
+  if (R.mm.xcd && per < total) per = (p->mm_gpb + 7) / 8 * 8 * p->mm_parts;
+  for (int w0 = 0; w0 < total; w0 += per) {
     R.wg0 = w0;
-    const int n = std::min(per, p->nwg - w0);
+    const int n = std::min(per, total - w0);
     switch (p->reg_mm) {
       case 4: reg_launch_mm<4>(n, R, s, fwd); break;
       case 5: reg_launch_mm<5>(n, R, s, fwd); break;

@@ -43,6 +43,7 @@ struct RegMM {
   float* xt;                     // [H][B][D]: the sampled (pre-mm) states
   unsigned xt_off;               // ... as a byte offset in the workspace (the forward sweep's buffer stores)
   unsigned long long* xch;       // granules of the statistics exchange (parts > 1)
+  int xcd;                       // 1: the launch's workgroups are dealt so that a group's parts share an XCD (pr_wg)
   unsigned tag0;                 // generation of this launch, shifted past the step count: the granules' tags are tag0 + step
                                  // (no two launches share a tag, so the buffer is never zeroed between them)
   double inv_m, inv_m1;          // 1 / M, 1 / (M - 1) (from the host: an fp64 division is thirty instructions)

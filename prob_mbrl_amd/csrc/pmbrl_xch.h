@@ -3,6 +3,12 @@
 // family's moment-matching instances (pmbrl_reg.h).
 #pragma once
 #include <hip/hip_runtime.h>
+// (polling with workgroup-scope loads -- sc0: meant to meet a same-XCD partner's stores in the shared L2 -- was tried once the
+//  parts of a group were placed on one XCD: the CU's L1 serves the poller its own stale line, the wait never ends.  Agent
+//  scope stays; the placement alone is worth 2-4 %.)
+#ifndef PM_XCH_POLL_SCOPE
+#define PM_XCH_POLL_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 #ifndef PM_GLOBAL
 #define PM_GLOBAL __attribute__((address_space(1)))
 #endif
@@ -92,7 +98,7 @@ __device__ __forceinline__ bool pm_xch_get_pair(const unsigned long long* xb, in
     unsigned tags = 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < 2 * NV; ++i) {
-      g[i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g[i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, PM_XCH_POLL_SCOPE);
       tags &= (unsigned)(g[i] >> 32) ^ ~k;      // all ones where the tag is k
     }
     if (__all(tags == 0xffffffffu)) break;
@@ -127,7 +133,7 @@ __device__ __forceinline__ bool pm_xch_get_all(const unsigned long long* xb, int
         const int q = q0 + b < parts ? q0 + b : q0;      // (a short last batch asks for its first slot again)
         const gu64* theirs = (const gu64*)xb + (size_t)(first + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, PM_XCH_POLL_SCOPE);
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
