@@ -27,6 +27,14 @@ timeout 300 python $R/tools/bench_bnn.py > $O/bench_bnn.json 2>/dev/null
 timeout 300 python $R/tools/mcp_speed.py > $O/mcp_speed.txt 2>/dev/null
 timeout 300 python $R/tools/mcp_example_shape.py > $O/mcp_example_shape.txt 2>/dev/null
 timeout 300 python $R/tools/bench_single_group.py > $O/single_group.txt 2>/dev/null
+# 5. kernel stats of the other configurations (one rocprofv3 pass each, no counters)
+for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$c -- \
+    python $R/bench.py --config $c --steps 10 --warmup 2 --repeats 2 --no-cpu-baseline --no-f32-twin > /dev/null 2>$O/ks_$c.err
+  f=$(find $O/ks_$c -name '*kernel_stats.csv' | head -1)
+  if [ -n "$f" ]; then cp "$f" $O/kstats_$c.csv; fi
+  rm -rf $O/ks_$c
+done
 # flatten the rocprof outputs (they sit under <dir>/<host>/<pid>_*.csv)
 for d in kt; do
   for f in $(find $O/$d -name '*.csv' 2>/dev/null); do cp $f $O/${d}_$(basename $f | sed 's/^[0-9]*_//'); done
