@@ -76,7 +76,9 @@ __host__ __device__ constexpr int pr_xwave(int net) { return net; }
 #define PR_LDS_FLAG (PR_LDS_MFX + 2 * 2 * PR_FRAG)
 #define PR_LDS_XB (PR_LDS_FLAG + 16)             // [16 rows][8]: the moment-matched rows, wave 0 -> every wave
 #define PR_LDS_ZH (PR_LDS_XB + 128)              // [2][16 rows][<= 6] doubles: standardised noise rows, wave 1 -> wave 0
-#define PR_LDS_FLOATS (PR_LDS_ZH + 2 * PR_MM_ZH_DOUBLES(6))
+#define PR_LDS_REC (PR_LDS_ZH + 2 * PR_MM_ZH_DOUBLES(6))      // [3][64] doubles: the factor record's inputs, wave 0 -> wave 2
+#define PR_LDS_FLOATS (PR_LDS_REC + 2 * PR_MM_REC_DOUBLES)
+static_assert(PR_LDS_FLOATS * 4 <= 160 * 1024, "forward sweep: LDS");
 
 struct RegNet {
   int w_off[3], b_off[3];       // offsets (floats) of W_l / b_l in the flat parameter vector
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   const int mm_gi = MMD ? wg / A.mm.parts : 0, mm_me = MMD ? wg - mm_gi * A.mm.parts : 0, mm_g0 = mm_gi * (MMD ? A.mm.M : 0);
   double mm_ref = 0.0;
   double* const mm_zh = reinterpret_cast<double*>(smem + PR_LDS_ZH);
+  double* const mm_rec = reinterpret_cast<double*>(smem + PR_LDS_REC);
   if constexpr (MMD != 0) {
     if (wid == 0) mm_ref = row < MMD ? (double)A.x0[(size_t)mm_g0 * D + row] : 0.0;
     if (wid == 1) pr_mm_fwd_prep<MMDc>(A.mm, 0, mm_gi, mm_g0, row0, nvalid, mm_me, lane, mm_zh);
@@ -943,10 +946,17 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         pr_mm_fwd_prep<MMDc>(Q, t + 1, mm_gi, mm_g0, row0, nvalid, mm_me, ln, mm_zh + ((t + 1) & 1) * (16 * MMDc));
         if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 13] = (long long)__builtin_readcyclecounter();
       }
+      // (idle otherwise) the previous step's factor record for the adjoint sweep, from what wave 0 left behind that step's barrier
+      if (wid == 2 && t > 0) {
+        if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 14] = (long long)__builtin_readcyclecounter();
+        pr_mm_fwd_file<MMDc>(Q, t - 1, mm_gi, mm_me, ln, mm_rec);
+        if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 15] = (long long)__builtin_readcyclecounter();
+      }
+      double rec[3] = {0.0, 0.0, 0.0};
       if (wid == 0) {
         float xo[2];
         const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, Q.tag0 + (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
-                                               mm_zh + (t & 1) * (16 * MMDc), xo,
+                                               mm_zh + (t & 1) * (16 * MMDc), xo, rec,
                                                (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
         *reinterpret_cast<f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g) = f32x2{xo[0], xo[1]};
@@ -955,6 +965,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
           if (ok_x[s]) *(gf32*)(b_states + so_x[s]) = xo[s];
       }
       pr_barrier();
+      // (behind the barrier: wave 2 has read the previous step's hand-over)
+      if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mm_rec[i * 64 + ln] = rec[i];
+      }
       const f32x2 xm = *reinterpret_cast<const f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g);
 #pragma unroll
       for (int s = 0; s < 2; ++s) x[s] = ok_x[s] ? xm[s] : 0.f;
@@ -972,6 +987,14 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     so_td += (int)x_step; so_tp += (int)a_step;
     b_states += x_step; b_actions += a_step; so_xt += (int)x_step;
     if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 5] = (long long)__builtin_readcyclecounter();
+  }
+  if constexpr (MMD != 0) {
+    // the last step's factor record
+    pr_barrier();
+    if (wid == 2 && A.H > 0) {
+      const RegMM Q = *pr_mm_args();
+      pr_mm_fwd_file<MMDc>(Q, A.H - 1, mm_gi, mm_me, lane, mm_rec);
+    }
   }
   if (PROF && wg == 0 && tid == 0) {
     A.prof[31] = (long long)__builtin_readcyclecounter();

@@ -141,6 +141,8 @@ __device__ __forceinline__ pr_gcf pr_mm_zrow(const RegMM& Q, int D, int t, int g
 // ---------------------------------------------------------------------------
 // LDS hand-over of the forward sweep: [2 buffers][16 rows][DD] doubles -- the standardised noise of the part's rows
 #define PR_MM_ZH_DOUBLES(DD) (2 * 16 * (DD))
+// ... and of the factor record's inputs, wave 0 -> wave 2 (pr_mm_fwd_file): [Gram register 0 | 1 | reference point][64 lanes]
+#define PR_MM_REC_DOUBLES (3 * 64)
 // (an idle wave, during the previous step's chain) zhat of the part's rows at step t -> zh; part 0 also files the
 // standardisation in the factor record the latency-optimised family's adjoint reads (pmbrl_mm.h: mean | zm | zi | ...)
 template <int DD>
@@ -170,10 +172,12 @@ __device__ __forceinline__ void pr_mm_fwd_prep(const RegMM& Q, int t, int gi, in
 // point every part of the group subtracts (in / out: the next step's is this step's mean).  zh: this step's hand-over
 // buffer.  Returns false on a lost pivot or a partner that never arrived.  xout: dimensions 2 g, 2 g + 1 of the
 // moment-matched row.
+// rec: what pr_mm_fwd_file needs to write this step's factor record -- the group's Gram sums (two registers of the tile) and
+// the reference point they are relative to.
 template <int DD>
 __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned kstep, int gi, int me, int first_wg, int nvalid,
                                                 int lane, const float (&xn)[2], double& refl, const double* zh,
-                                                float (&xout)[2], long long* pf = nullptr) {
+                                                float (&xout)[2], double (&rec)[3], long long* pf = nullptr) {
   static_assert(DD >= 2 && DD <= 6, "state widths 2..6");
   const int c = lane & 15, k = lane >> 4;
   pm_f64x4 G0, G1;
@@ -217,6 +221,9 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     G[1] = v2[1];
   }
   PR_MM_STAMP(9);
+  rec[0] = G[0];
+  rec[1] = G[1];
+  rec[2] = refl;
   MMW<DD> q;
 #ifdef PR_MM_DEBUG_RATIO
   double dbg_ratio;
@@ -261,29 +268,50 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     for (int j = 0; j < DD; ++j) r = c == j ? (double)(float)mean[j] : r;
     refl = r;
   }
-  // the factor for the adjoint sweep (one lane's stores: the values are the same in all of them).  Part 0 files
-  // mean | . | . | . | 1 / diag L | L row-major (pm_mm_carve's record); the LAST part L^-1 -- the duty is shared because
-  // the parts wait for each other again one step later
-  {
-    // (the stores' duty is dealt over the parts: what one part spends here, all of them wait for one step later)
-    pr_gd fac = (pr_gd)Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
-    if (lane == 0 && me == 0) {
+  PR_MM_STAMP(12);
+  return ok;
+}
+
+// The factor record of step t for the adjoint sweep, from the chain's hand-over (rec: [3][64] doubles in LDS -- the Gram
+// sums' two registers and the reference point, lane by lane): an IDLE wave runs this one step later, next to the next
+// step's chain.  (Until round 5 the chain's own wave did it behind the moment-matched rows: 1.1 k cycles of a 13.9 k-cycle
+// step at d = 4 that every wave of the workgroup -- and, one step later, every part of the group -- waited for.)  The same
+// factorisation on the same sums: the bits the chain used.  The duty is dealt over the parts: part 0 files
+// mean | . | . | . | 1 / diag L, part 1 (of three or more; else part 0) L row-major (pm_mm_carve's record), the LAST
+// part L^-1.
+template <int DD>
+__device__ __forceinline__ void pr_mm_fwd_file(const RegMM& Q, int t, int gi, int me, int lane, const double* rec) {
+  const int l_part = Q.parts >= 3 ? 1 : 0;
+  if (me != 0 && me != l_part && me != Q.parts - 1) return;
+  pm_f64x4 G;
+  G[0] = rec[lane];
+  G[1] = rec[64 + lane];
+  G[2] = G[3] = 0.0;
+  double refl = rec[128 + lane];
+  asm volatile("" : "+v"(refl));
+  MMW<DD> q;
+  (void)pr_mm_factor<DD>(G, (double)Q.M, Q.inv_m, Q.inv_m1, q);
+  // (the cross-lane reads HERE, with every lane active: inside the one-lane branch below the compiler sinks the LDS read of
+  //  `refl` into the branch too, and the lanes 1 .. d - 1 it is read from never load it)
+  double mean[DD];
 #pragma unroll
-      for (int j = 0; j < DD; ++j) {
-        fac[j] = mean[j];
-        fac[4 * DD + j] = q.invd[j];
-      }
-    }
-    if (lane == 0 && me == (Q.parts >= 3 ? 1 : 0)) {
+  for (int j = 0; j < DD; ++j) mean[j] = q.mean[j] + pm_rl64(refl, j);
+  pr_gd fac = (pr_gd)Q.mmfac + ((size_t)t * Q.groups + gi) * pm_mm_fac_doubles(DD);
+  if (lane == 0 && me == 0) {
 #pragma unroll
-      for (int j = 0; j < DD; ++j)
-#pragma unroll
-        for (int cc = 0; cc < DD; ++cc) fac[5 * DD + j * DD + cc] = cc <= j ? q.L[j][cc] : 0.0;
+    for (int j = 0; j < DD; ++j) {
+      fac[j] = mean[j];
+      fac[4 * DD + j] = q.invd[j];
     }
   }
+  if (lane == 0 && me == l_part) {
+#pragma unroll
+    for (int j = 0; j < DD; ++j)
+#pragma unroll
+      for (int cc = 0; cc < DD; ++cc) fac[5 * DD + j * DD + cc] = cc <= j ? q.L[j][cc] : 0.0;
+  }
   if (me == Q.parts - 1) {
-    // (column by column, each stored as soon as it is solved: the whole inverse at once is d (d + 1) / 2 more doubles than
-    //  the chain has registers for at d = 6 -- the overflow went to the accumulator file and evicted weight fragments)
+    // (column by column, each stored as soon as it is solved)
     pr_gd li = (pr_gd)Q.linv + ((size_t)t * Q.groups + gi) * (DD * DD);
 #pragma unroll
     for (int j = 0; j < DD; ++j) {
@@ -302,8 +330,6 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
       }
     }
   }
-  PR_MM_STAMP(12);
-  return ok;
 }
 
 // ---------------------------------------------------------------------------
