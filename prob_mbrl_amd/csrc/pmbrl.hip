@@ -273,20 +273,34 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
                                                            float b2, float omb1, float omb2, float eps,
                                                            float bc1, float bc2_sqrt, float max_norm,
                                                            float* __restrict__ norm_out,
-                                                           const long long* __restrict__ step, int guarded) {
+                                                           const long long* __restrict__ step, int guarded,
+                                                           double ln_b1, double ln_b2, double lr_d) {
   if (guarded && !g_adam_go) return;   // the rollout failed: leave parameters and moments alone
-  if (step) {                   // guarded form: bias corrections of the device-side step counter
+  double step_size_d = lr_d / (double)bc1;
+  if (step) {
+    // guarded form: bias corrections 1 - beta^t of the device-side step counter as -expm1(t ln beta), the exponent formed
+    // and evaluated in double (torch forms them in Python floats; in fp32 the sixth digit of the step size differs and a
+    // five-iteration comparison of the moments notices), ln beta from the host -- two double-precision pow calls were a
+    // thousand instructions at the head of every thread, expm1 is a third of that
     const double st = (double)step[0];
-    bc1 = (float)(1.0 - pow((double)b1, st));
-    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    bc1 = (float)-expm1(st * ln_b1);
+    bc2_sqrt = (float)sqrt(-expm1(st * ln_b2));
+    step_size_d = lr_d / -expm1(st * ln_b1);      // (torch: lr / bias_correction1 in Python floats, rounded once)
   }
+  // the partial sums of squares, one (or two) per lane and a fixed butterfly: the same bits in every wave of every block
+  // (as a loop of n_part dependent loads and double additions in every thread: the front of this launch)
   double t = 0.0;
-  for (int b = 0; b < n_part; ++b) t += g_red_part[1][b];
+  {
+    const int lane = threadIdx.x & 63;
+    for (int b = lane; b < n_part; b += 64) t += g_red_part[1][b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  }
   const float norm = (float)sqrt(t);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
-  const float step_size = lr / bc1;
+  const float step_size = (float)step_size_d;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
@@ -1825,10 +1839,11 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
     if (p->mm_fan || p->reg_mm) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
-    if (p->mm_parts > 1) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     // (the granules' tags: zeroed per launch for the latency-optimised family, whose tags count the steps from 1; the
-    //  register-resident family's carry a launch generation instead -- once zeroed, never again: two 5 us fill kernels less)
+    //  register-resident family's carry a launch generation instead -- once zeroed, never again: two 5 us fill kernels less;
+    //  nor does that family touch the group-local barrier flags: two more)
     const bool reg_now = pm_reg_can_run(p, As, true);
+    if (p->mm_parts > 1 && !reg_now) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
     if (p->mm_parts > 1 && As.xch && (!reg_now || !p->xch_zeroed)) {
       HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));
       p->xch_zeroed = reg_now ? 1 : 0;
@@ -2051,7 +2066,7 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
     if (p->mm_parts > 1) {
       // groups split over workgroups: their own flags, and two buffers for the rows of dL/dx they exchange
       A.gsync += 1024;
-      HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
+      if (!reg_bwd) HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
       if (A.xch && (!reg_bwd || !p->xch_zeroed)) {
         HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
         p->xch_zeroed = reg_bwd ? 1 : 0;
@@ -2745,7 +2760,7 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, need_norm ? nb : 0, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0);
+                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0, 0.0, 0.0, lr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2762,7 +2777,7 @@ extern "C" int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* gra
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f,
-                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1);
+                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1, log(beta1), log(beta2), lr);
   HIPCHK(hipGetLastError());
   return 0;
 }

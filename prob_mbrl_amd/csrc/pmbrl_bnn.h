@@ -492,12 +492,12 @@ __global__ __launch_bounds__(PM_BNT_NT) void pm_bnn_tail(const BnnTailArgs A) {
   const int O16 = n_ot * 16, K16 = n_kb * 16;
   BnnAdam ad;
   {
-    // bias corrections 1 - beta^t from the device-side step count: beta^t = exp(t ln beta), the exponent formed in double
+    // bias corrections 1 - beta^t from the device-side step count as -expm1(t ln beta), the exponent formed in double
     // (two double-precision pow calls were several hundred instructions at the head of every workgroup)
     const double st = (double)(A.step[0] + 1);
     ad.b1 = A.b1; ad.b2 = A.b2; ad.omb1 = 1.f - A.b1; ad.omb2 = 1.f - A.b2; ad.eps = A.eps;
-    ad.step_size = A.lr / (1.f - __expf((float)(st * A.ln_b1)));
-    ad.bc2_sqrt = sqrtf(1.f - __expf((float)(st * A.ln_b2)));
+    ad.step_size = A.lr / -expm1f((float)(st * A.ln_b1));
+    ad.bc2_sqrt = sqrtf(-expm1f((float)(st * A.ln_b2)));
     ad.inv_bc2 = 1.f / ad.bc2_sqrt;
   }
   // regulariser of the dropout layer in FRONT of Linear L (hidden layer q = L - 1): weight decay scaled by the units' keep

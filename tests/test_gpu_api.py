@@ -172,7 +172,14 @@ def test_mc_pilco_matches_reference_iterations(name):
     st = opt.state[lins[0].weight]
     assert int(st['step']) == int(d['mcp_n_iters'])
     m = torch.cat([opt.state[t]['exp_avg'].reshape(-1) for l in lins for t in (l.weight, l.bias)])
-    assert np.allclose(m.cpu().numpy(), d['ref32_mcp_exp_avg'], rtol=1e-3, atol=1e-7)
+    # the first moment against the reference's, on the moment's own scale: 1e-3 of the element + 1e-4 of the vector's rms
+    # (north_star's bar for the gradient this is the running mean of).  Until round 5 the floor was a fixed 1e-7 -- the size
+    # of the whole vector in three of the fixtures (rms 1e-7 .. 2e-6: nothing was compared) and 4e-5 of the rms in mcp_mm1,
+    # the split-precision gradient's own noise (one element of 1314 sat 4e-9 beyond it)
+    m_ref = np.asarray(d['ref32_mcp_exp_avg'], dtype=np.float64)
+    m_err = np.abs(m.cpu().numpy().astype(np.float64) - m_ref)
+    m_tol = 1e-3 * np.abs(m_ref) + 1e-4 * np.sqrt(np.mean(m_ref ** 2))
+    assert np.all(m_err <= m_tol), (int((m_err > m_tol).sum()), float((m_err - m_tol).max()))
 
 
 def test_rollout_truncated_horizon_matches_reference(monkeypatch):
