@@ -702,7 +702,9 @@ def test_fused_tail_matches_the_separate_launches(dev, name, generic):
     """The iteration tail queued by two calls (pmbrl_plan_set_loss: the loss behind the forward call;
     pmbrl_rollout_bwd_adam: adjoint, dW, clip and the device-guarded Adam) against the separate calls (weighted_sum,
     backward, clip_adam): the same loss and clipped gradient, parameters and moments to rounding, over three iterations;
-    a rollout marked as failed leaves parameters, moments and the step counter alone."""
+    a rollout marked as failed leaves parameters, moments and the step counter alone.  (Each iteration is replayed from
+    the fused path's own parameters -- see below; the comparison of the two paths' OWN three-iteration trajectories is
+    tests/test_gpu_full_size.py::test_fused_tail_walks_the_separate_launches_trajectory_at_full_size, at 2 500 rows.)"""
     from prob_mbrl_amd import engine as E
     d = common.load(name)
     B = d['x0'].shape[0]
