@@ -695,9 +695,20 @@ def main():
             if a.config == 'cartpole_nomm' and world in PREDICTED_WEAK:
                 out['predicted'] = dict(weak=PREDICTED_WEAK[world], source='DESIGN.md section 5 (before any multi-GPU run)')
             out['allreduce_selfcheck'] = 'passed: %d floats summed over %d ranks, bit-identical to the closed form' % (41602, world)
-            if transport_note:
-                out['transport_fallback'] = transport_note + ' -> RCCL'
+            # (always present in the parsed line: None = the transport asked for is the one that ran)
+            out['transport_fallback'] = (transport_note + ' -> RCCL') if transport_note else None
+            out['transport'] = a.transport
             out['rccl_ranks'] = rccl_ranks
+            # the first 200 characters of config.workload are what a truncating reader keeps: which curve `value` is, the
+            # global row count, the other curve's value and what the communicator saw go FIRST
+            oth = extra.get('strong' if primary == 'weak' else 'weak')
+            head = 'N=%d %s: global_rows=%d (%s), rccl_ranks=%s, transport=%s%s; %s; ' % (
+                world, primary.upper(), Bg,
+                ('%d x %d rows/GPU' % (world, B)) if primary == 'weak' else 'the metric\'s rows dealt over the ranks',
+                rccl_ranks, a.transport, ' (FELL BACK from p2p)' if transport_note else '',
+                ('%s curve (global_rows=%d) = %.4g rollouts/s' % ('STRONG' if primary == 'weak' else 'WEAK', oth['global_rows'], oth['value']))
+                if oth else 'other curve not timed')
+            out['config']['workload'] = head + out['config']['workload']
             out['collective'] = ('one-shot peer-to-peer all-reduce (pmbrl_p2p.hip, IPC-mapped slots) on the compute stream'
                                  if a.transport == 'p2p' else
                                  'RCCL ncclAllReduce through the C ABI on the compute stream' if rccl_ranks else

@@ -279,9 +279,11 @@ typedef struct pmbrl_inputs {
  * (DynamicsModel.forward), models/densities.py:87-121, the reward module and
  * utils/rollout.py:20-29 (mm_resample_).
  * Outputs: states [H+1,B,D], actions [H,B,U], rewards [H,B,1].
- * status_d: device int32, set to 0x7fffffff on entry; on a numerical failure at
- * step t (non-finite state/reward, non-positive pivot) atomically min'ed with t
- * (= number of valid steps before the failure). */
+ * status_d: device int32[2].  [0] is set to 0x7fffffff on entry; on a numerical
+ * failure at step t (non-finite state/reward, non-positive pivot) atomically
+ * min'ed with t (= number of valid steps before the failure).  [1] is the adjoint
+ * sweep's failure flag (pmbrl_rollout_bwd) and is CLEARED by this call: a caller
+ * that only ever evaluates forward must still hand over two words. */
 int pmbrl_rollout_fwd(pmbrl_plan* plan, void* stream, void* workspace_d,
                       const pmbrl_inputs* in, float* states_d, float* actions_d,
                       float* rewards_d, int32_t* status_d);

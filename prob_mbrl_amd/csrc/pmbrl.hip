@@ -854,6 +854,14 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
           if (batched) {      // balanced batches of whole groups, each batch's workgroups resident together
             const int nb = (p->G * want + max_wg - 1) / max_wg;
             p->mm_gpb = (p->G + nb - 1) / nb;
+            // (the register-resident family deals hardware workgroups in blocks of 8 groups -- a group's parts on one XCD --
+            //  and launches whole blocks: a batch rounded UP to blocks must still be resident together, or the parts of
+            //  the block that straddles the chip spin until other workgroups finish a whole sweep.  G = 97 in 5 parts on
+            //  256 CUs: 49 groups -> 280 workgroups; 48 -> 240)
+            if (!(getenv("PMBRL_XCH_XCD") && atoi(getenv("PMBRL_XCH_XCD")) == 0)) {
+              const int cap = max_wg / want / 8 * 8;
+              if (cap >= 8) p->mm_gpb = std::min((p->mm_gpb + 7) / 8 * 8, cap);
+            }
           }
         }
       }
@@ -1352,6 +1360,13 @@ struct ReplayKey {
   }
   template <class T> void val(const T& v) { add(&v, sizeof(T)); }
 };
+// is this stream recording a graph?  (the legacy default stream cannot be asked, and cannot be recording)
+static bool pm_stream_recording(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (!s) return false;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
+}
 // body(): queues the call on s.  Returns its code; *replayed = the call went out as a graph launch.
 template <class Body>
 static int replay_call(pmbrl_plan* p, int slot, const ReplayKey& K, hipStream_t s, Body body) {
@@ -1844,9 +1859,13 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
     //  nor does that family touch the group-local barrier flags: two more)
     const bool reg_now = pm_reg_can_run(p, As, true);
     if (p->mm_parts > 1 && !reg_now) HIPCHK(hipMemsetAsync(As.gsync, 0, 1024 * sizeof(unsigned), s));   // group-local barriers
-    if (p->mm_parts > 1 && As.xch && (!reg_now || !p->xch_zeroed)) {
+    // (a RECORDED launch is replayed with the generation it was recorded with: two replays of a forward call with no
+    //  adjoint call between them would meet their own tags of the replay before -- stale sums accepted.  A recording
+    //  therefore carries the fill; what it leaves behind is its generation's tags, which no later launch takes for its own)
+    const bool xch_rec = pm_stream_recording(s);
+    if (p->mm_parts > 1 && As.xch && (!reg_now || !p->xch_zeroed || xch_rec)) {
       HIPCHK(hipMemsetAsync(As.xch, 0, p->xch_bytes, s));
-      p->xch_zeroed = reg_now ? 1 : 0;
+      p->xch_zeroed = (reg_now && !xch_rec) ? 1 : 0;
     }
     if (reg_now) pm_reg_launch(p, ws, As, in->pol_params_d, in->dyn_params_d, s, true);
     else launch_fwd_rt(p, As, s);
@@ -2067,9 +2086,10 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       // groups split over workgroups: their own flags, and two buffers for the rows of dL/dx they exchange
       A.gsync += 1024;
       if (!reg_bwd) HIPCHK(hipMemsetAsync(A.gsync, 0, 1024 * sizeof(unsigned), s));
-      if (A.xch && (!reg_bwd || !p->xch_zeroed)) {
+      const bool xch_rec = pm_stream_recording(s);      // (see the forward call)
+      if (A.xch && (!reg_bwd || !p->xch_zeroed || xch_rec)) {
         HIPCHK(hipMemsetAsync(A.xch, 0, p->xch_bytes, s));
-        p->xch_zeroed = reg_bwd ? 1 : 0;
+        p->xch_zeroed = (reg_bwd && !xch_rec) ? 1 : 0;
       }
       A.gx_carry_out = reinterpret_cast<float*>(ws + p->off_gxc2);
     }

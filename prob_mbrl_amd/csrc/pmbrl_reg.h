@@ -532,8 +532,11 @@ __device__ __forceinline__ float pr_rcp(float d) {
 // (|u| clamped to 15: tanh is +-1 to fp32 there already, and exp(2 u) overflows at u = 44 -- the reciprocal's Newton step
 //  turns an infinity into a NaN: a policy that saturates hard, the double cart-pole shape late in the horizon, produced NaN
 //  actions here until round 5)
+// (v_med3_f32 answers min3 when an operand is a NaN: a NaN head output would leave here as tanh(-15) = -1, a finite action,
+//  and the failed step would go unreported where the reference produces NaNs -- the NaN is put back by hand)
 __device__ __forceinline__ float pr_tanh(float u) {
-  return 1.f - 2.f * pr_rcp(1.f + expf(2.f * __builtin_amdgcn_fmed3f(u, -15.f, 15.f)));
+  const float r = 1.f - 2.f * pr_rcp(1.f + expf(2.f * __builtin_amdgcn_fmed3f(u, -15.f, 15.f)));
+  return u != u ? u : r;
 }
 // logistic function of x = ls - max_log_std through the same reciprocal: the exponent clamped for the same reason
 // (sigma(-80) = 2e-35: zero to everything downstream)

@@ -144,7 +144,7 @@ def test_mc_pilco_matches_reference_iterations(name):
         on_iteration=lambda i, loss, *a: losses.append(float(loss)),
         frozen_noise=dict(z_mm=torch.tensor(d['z_mm']), z_rr=torch.tensor(d['z_rr'])))
     assert np.allclose(losses, d['ref32_mcp_losses'], rtol=5e-5)
-    if name == 'mcp_full200':
+    if name in ('mcp_full200', 'mcp_full200_mmg'):
         # the 2 x 200 shape of BASELINE.json's metric: every iteration's sweeps ran on the register-resident family
         # (csrc/pmbrl_reg.h) -- the engines mc_pilco builds are cached per shape (rollout._ENGINES)
         n = int(d['mcp_n_iters'])
@@ -167,7 +167,19 @@ def test_mc_pilco_matches_reference_iterations(name):
     print('%s: parameters beyond the plain bar %d of %d (worst %.2e at |g| = %.2e, gradient rms %.2e)' %
           (name, int((err > plain).sum()), err.size, float(err.max()), float(g_abs[np.argmax(err)]), float(eps_g * 1e4)))
     assert np.all(err <= tol), (int((err > tol).sum()), float((err - tol).max()), float(err.max()))
-    assert np.mean(err <= 1e-4 * np.abs(d['ref32_mcp_final']) + 2e-6) > 0.995      # ... and all but a handful hold the plain bar
+    # FROZEN (round 6): these bars may only tighten.  The per-element bar above admits whatever Adam can reach for an element
+    # whose gradient is rounding noise; what guards against a systematic error is (a) the COUNT of elements beyond the plain
+    # bar -- a regression threshold, measured 0 in all seven fixtures on the round-6 build -- and (b) the update direction,
+    # a quantity rounding does not move: the cosine between this run's total parameter update and the reference's.
+    n_beyond = int((err > plain).sum())
+    assert n_beyond <= (4 if err.size > 40000 else 0), n_beyond
+    from prob_mbrl_amd.problem import flat_params
+    init = flat_params(d, 'pol').astype(np.float64)          # the policy the fixture's run started from
+    upd = final.astype(np.float64) - init
+    upd_ref = np.asarray(d['ref32_mcp_final'], np.float64) - init
+    cos = float(upd @ upd_ref / (np.linalg.norm(upd) * np.linalg.norm(upd_ref)))
+    print('%s: cosine of the total update 1 - %.2e' % (name, 1.0 - cos))
+    assert cos > 1.0 - 1e-7, cos          # (measured: 1 - 6.3e-9 at worst, mcp_mm1)
     # Adam state is visible through the torch optimiser object (drop-in: same opt reused later)
     st = opt.state[lins[0].weight]
     assert int(st['step']) == int(d['mcp_n_iters'])
@@ -180,6 +192,11 @@ def test_mc_pilco_matches_reference_iterations(name):
     m_err = np.abs(m.cpu().numpy().astype(np.float64) - m_ref)
     m_tol = 1e-3 * np.abs(m_ref) + 1e-4 * np.sqrt(np.mean(m_ref ** 2))
     assert np.all(m_err <= m_tol), (int((m_err > m_tol).sum()), float((m_err - m_tol).max()))
+    # ... and as a vector (rounding-insensitive: the first moment is a running mean of the gradients, linear in them):
+    # north_star's bar for the gradient itself
+    m_rel = float(np.linalg.norm(m.cpu().numpy().astype(np.float64) - m_ref) / np.linalg.norm(m_ref))
+    print('%s: first moment, relative L2 error %.2e' % (name, m_rel))
+    assert m_rel < 5e-5, m_rel           # (measured: 1.4e-5 at worst, mcp_mm1)
 
 
 def test_rollout_truncated_horizon_matches_reference(monkeypatch):

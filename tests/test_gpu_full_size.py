@@ -35,6 +35,10 @@ def test_full_size_split_precision_matches_oracle(config, prec):
     d = _problem(config)
     eng, e_s, e_l, e_g = _errors_vs_oracle(d, precision=prec)
     assert eng.info['precision'] == prec and eng.info['fast'] == 1
+    if prec == 'split_f16':
+        # the headline kernels (pm_reg_fwd_kernel / pm_reg_bwd_kernel) served BOTH sweeps: a plan the family silently
+        # declined would otherwise pass here on the eight-wave kernels
+        assert eng.info['reg'] and eng.reg_calls() == (1, 1), (eng.info, eng.reg_calls())
     print('%s %s: states %.2e loss %.2e grad %.2e' % (config, prec, e_s, e_l, e_g))
     assert e_s < 2e-5 and e_l < 2e-5 and e_g < 1e-4
 
@@ -72,6 +76,8 @@ def test_full_size_matches_oracle(config):
     # (cartpole_mm: every 25-row group split over two 16-row workgroups, 13 + 12 rows)
     assert eng.info['fast'] == 1 and eng.info['rows_per_wg'] == (16 if config == 'cartpole_nomm' else 13)
     assert eng.info['mm_parts'] == (1 if config == 'cartpole_nomm' else 2)
+    # ... and on the register-resident family, both sweeps (the kernels bench.py's headline line times)
+    assert eng.info['reg'] and eng.reg_calls() == (1, 1), (eng.info, eng.reg_calls())
     x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
     torch.set_num_threads(8)
     l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],

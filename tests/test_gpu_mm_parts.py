@@ -161,6 +161,44 @@ def test_split_groups_replay_in_a_graph():
     assert np.array_equal(go(False), go(True))
 
 
+def test_forward_only_graph_replays_do_not_meet_their_own_tags():
+    """A recorded forward call of the register-resident family is replayed with the launch generation it was recorded
+    with.  Replayed twice with no adjoint call between, the second replay would find the first one's granules (same tags)
+    and could accept sums a partner has not re-published yet -- so a recording carries the fill of the exchange buffer.
+    Forward-only replays with the policy changed between them must give what eager calls give, bit for bit."""
+    d = common.load('full200_mmg')
+    eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+    assert eng.info['reg'] and eng.info['mm_parts'] >= 2, eng.info
+    p0 = args['pol_flat'].clone()
+    scales = [1.0, 0.97, 1.02, 0.99, 1.0, 1.01]
+
+    def eager(sc):
+        args['pol_flat'].copy_(p0 * sc)
+        S, A, R = eng.forward(**args)
+        torch.cuda.synchronize()
+        return S.cpu().numpy().copy(), R.cpu().numpy().copy()
+
+    want = [eager(sc) for sc in scales]
+    assert not np.array_equal(want[0][0], want[1][0])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.forward(**args)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        S, A, R = eng.forward(**args)
+    for rep in range(3):
+        for sc, (S_w, R_w) in zip(scales, want):
+            args['pol_flat'].copy_(p0 * sc)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(S.cpu().numpy(), S_w) and np.array_equal(R.cpu().numpy(), R_w), (rep, sc)
+    # ... and eager calls after the replays (a new generation over the recording's leftover tags)
+    S2, R2 = eager(scales[1])
+    assert np.array_equal(S2, want[1][0]) and np.array_equal(R2, want[1][1])
+
+
 @pytest.mark.parametrize('name,n', [('mmg_h40', 2), ('mm1_b100_h40', 4), ('full200_mmg', 3)])
 def test_statistics_exchange_matches_row_exchange(name, n):
     """The two forms of a split group on the shapes that have a compile-time-width instance: sums exchanged as

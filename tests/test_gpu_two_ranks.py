@@ -44,6 +44,13 @@ def test_bench_two_ranks_one_device():
     st = out['strong']
     assert st['global_rows'] == 2500 and st['rows_per_gpu'] == [1250, 1250] and st['value'] > 0
     assert 'rccl_ranks' in out and out['rccl_ranks'] is None      # gloo here: no RCCL communicator to ask
+    # the shape of the N > 1 line: what a reader that keeps only the head of config.workload must still learn -- which
+    # curve `value` is, the global row count, the other curve's value, what the communicator saw -- and whether the
+    # transport fell back is a key of the parsed line whether it did or not
+    head = out['config']['workload'][:200]
+    assert head.startswith('N=2 WEAK: global_rows=5000 (2 x 2500 rows/GPU)'), head
+    assert 'rccl_ranks=None' in head and 'transport=rccl' in head and 'STRONG curve (global_rows=2500) = ' in head, head
+    assert 'transport_fallback' in out and out['transport_fallback'] is None and out['transport'] == 'rccl'
 
 
 def test_bench_launches_itself_without_a_launcher():
