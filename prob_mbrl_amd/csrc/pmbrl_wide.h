@@ -81,8 +81,10 @@ __device__ __forceinline__ void pw_table_init(float* tbl, int tid) {
 // acc[k][rt] = sum over K of W[tile 4 wid + k] x X[row tile rt]; weights [tile][K32 block][piece][lane][4 floats].
 // A ring of THREE one-block chunks (4 tiles x 2 pieces = 8 KB per wave each): two in flight while one feeds the
 // MFMAs -- with one in flight (round 3's in-place loop) a block took a memory round trip (2.1 k cycles against the
-// 1.5 k its 96 MFMAs keep a SIMD's two waves busy: 34 k cycles per 512 x 512 layer, profiles/r04i_*).
-template <bool F16>
+// 1.5 k its 96 MFMAs keep a SIMD's two waves busy: 34 k cycles per 512 x 512 layer, profiles/r04i_*).  NR = 4 (round
+// 6, the adjoint): a fourth chunk where the registers allow it -- 255, no spill; the forward sweep's layers spill 79
+// around the loop with it and lose what the loop gains (profiles/r06_c5_notes.txt): 10.69 -> 10.27 ms per adjoint sweep.
+template <bool F16, int NR = 3>
 __device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb, const float* buf, int wid, int lane,
                                          f32x4 (&acc)[4][4]) {
   typedef PmPairs<2> PP;
@@ -101,7 +103,7 @@ __device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb,
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[k][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  GsFrag<4> f0, f1, f2;
+  GsFrag<4> f0, f1, f2, f3;
   constexpr int NLD = 8;   // loads per one-block chunk
   // A chunk past the last block is loaded all the same -- the ring keeps its fixed shape: every wait is "all but the two
   // youngest chunks", which tools/check_inflight.py can follow on every path -- but with lane offset 0: every lane
@@ -122,45 +124,104 @@ __device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb,
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(f.a[k][0][1]) : "v"(vo), "s"(tb[k]));
     }
   };
-  // One row tile at a time: its two B operands (8 registers) and the scaled one (4) are read right in front of its 12
-  // MFMAs -- the SIMD's other wave covers the LDS latency -- so that the loop's registers are the accumulators, the
-  // ring and a dozen more, and nothing it uses is spilled: a scratch reload between the ring's loads is waited for by
-  // the compiler with vmcnt(0), which drains the ring every iteration (measured: 27.7 k -> 30 k cycles per layer and
-  // first layers 23 k -> 32 k when ONE pointer was reloaded at the loop's top).
+  // B operands (PF, the adjoint): TWO sets of {high, low} piece (16 registers), the reads of the NEXT row tile (behind the block's last:
+  // of the next block's first) issued in front of a row tile's 12 MFMAs.  Round 6: until then a row tile's operands were
+  // read right in front of its MFMAs -- ds_read, s_waitcnt lgkmcnt(0), MFMAs -- and only the SIMD's other wave covered
+  // the LDS latency: a wave alone kept the matrix core busy half of the time, and of a SIMD's two waves the younger ran
+  // its last third alone (24 k / 36 k cycles for 24.6 k of MFMAs).
+  // The reads are inline asm with hand-written waits, like the weight ring: LDS returns in order, every row tile's wait
+  // is "all but the two youngest" (lgkmcnt(2)) -- left to the compiler the first wait of every block came out as
+  // lgkmcnt(0) (the pending reads of the block before are behind a join of the control flow), one exposed LDS round trip
+  // per block.  Nothing else of the loop touches LDS or scalar memory; a compiler-issued wait can only be more
+  // conservative for the asm reads it does not know of.
+  constexpr bool PF = NR == 4;      // (the adjoint: look-ahead operands and a fourth chunk; the forward sweep: neither)
+  f32x4 bq[2][2];
+  const unsigned la = (unsigned)(unsigned long long)(const void*)lb;
+  auto bread = [&](f32x4 (&b)[2], auto rtc, int kb) {
+    constexpr int rt = decltype(rtc)::value;
+    const unsigned a0 = la + (unsigned)kb * 64u, a1 = a0 + 64u * ldb * 2u;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(b[0]) : "v"(a0), "n"(rt * 16 * (int)PW_LDB * 2));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(b[1]) : "v"(a1), "n"(rt * 16 * (int)PW_LDB * 2));
+  };
+  auto row_tile = [&](GsFrag<4>& f, auto rtc, int kb, int kbn) {
+    constexpr int rt = decltype(rtc)::value;
+    if constexpr (rt < 3) bread(bq[(rt + 1) & 1], std::integral_constant<int, (rt + 1) & 3>{}, kb);
+    else bread(bq[0], std::integral_constant<int, 0>{}, kbn);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[rt & 1][0]), "+v"(bq[rt & 1][1]));
+    // (fp16 pieces: the product with the weights' scaled low piece takes act.hi * 2^-11 -- pmbrl_split.h, BScaled)
+    BQ<1, 2> b;
+    b.v[0][0] = bq[rt & 1][0];
+    b.v[1][0] = bq[rt & 1][1];
+    BScaled<1, F16> bs(b);
+#pragma unroll
+    for (int q = 0; q < PP::N; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], pm_bsel<F16>(q, b, bs, 0), acc[k][rt]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto compute = [&](GsFrag<4>& f, int kb) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD));      // this chunk has landed: the two younger ones may be out
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NR - 1) * NLD));      // this chunk has landed: the NR - 1 younger ones may be out
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(f.a[k][0][p]));
     if (kb < n_kb) {
+      if constexpr (PF) {
+        const int kbn = kb + 1 < n_kb ? kb + 1 : kb;      // (past the end: a harmless re-read)
+        row_tile(f, std::integral_constant<int, 0>{}, kb, kbn);
+        row_tile(f, std::integral_constant<int, 1>{}, kb, kbn);
+        row_tile(f, std::integral_constant<int, 2>{}, kb, kbn);
+        row_tile(f, std::integral_constant<int, 3>{}, kb, kbn);
+      } else {
+        // the forward sweep: a row tile's two B operands (8 registers) and the scaled one (4) read right in front of its
+        // 12 MFMAs -- the SIMD's other wave covers the LDS latency (with the look-ahead form the forward layers spill 50
+        // registers around the loop and gain nothing: profiles/r06_c5_notes.txt)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        BQ<1, 2> b;
+        for (int rt = 0; rt < 4; ++rt) {
+          BQ<1, 2> b;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-          b.v[p][0] = *reinterpret_cast<const f32x4*>(lb + ((unsigned)(p * 64) + rt * 16u) * ldb + kb * 32);
-        BScaled<1, F16> bs(b);
+          for (int p = 0; p < 2; ++p)
+            b.v[p][0] = *reinterpret_cast<const f32x4*>(lb + ((unsigned)(p * 64) + rt * 16u) * ldb + kb * 32);
+          BScaled<1, F16> bs(b);
 #pragma unroll
-        for (int q = 0; q < PP::N; ++q)
+          for (int q = 0; q < PP::N; ++q)
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], pm_bsel<F16>(q, b, bs, 0), acc[k][rt]);
+            for (int k = 0; k < 4; ++k)
+              acc[k][rt] = pm_mfma_bf<F16>(f.a[k][0][PP::W[q]], pm_bsel<F16>(q, b, bs, 0), acc[k][rt]);
+        }
       }
     }
   };
+  if constexpr (PF) bread(bq[0], std::integral_constant<int, 0>{}, 0);
   load(f0, 0);
   load(f1, 1);
-  for (int kb0 = 0; kb0 < n_kb; kb0 += 3) {
-    load(f2, kb0 + 2);
-    compute(f0, kb0);
-    load(f0, kb0 + 3);
-    compute(f1, kb0 + 1);
-    load(f1, kb0 + 4);
-    compute(f2, kb0 + 2);
+  if constexpr (NR == 4) {
+    load(f2, 2);
+    for (int kb0 = 0; kb0 < n_kb; kb0 += 4) {
+      load(f3, kb0 + 3);
+      compute(f0, kb0);
+      load(f0, kb0 + 4);
+      compute(f1, kb0 + 1);
+      load(f1, kb0 + 5);
+      compute(f2, kb0 + 2);
+      load(f2, kb0 + 6);
+      compute(f3, kb0 + 3);
+    }
+  } else {
+    for (int kb0 = 0; kb0 < n_kb; kb0 += 3) {
+      load(f2, kb0 + 2);
+      compute(f0, kb0);
+      load(f0, kb0 + 3);
+      compute(f1, kb0 + 1);
+      load(f1, kb0 + 4);
+      compute(f2, kb0 + 2);
+    }
   }
-  // the look-ahead chunks (past the end: zeros, no traffic) land before their registers are reused
-  asm volatile("s_waitcnt vmcnt(0)");
+  // the look-ahead chunks (past the end: zeros, no traffic) and the last block's look-ahead operands land before their
+  // registers are reused
+  if constexpr (PF) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]));
+  else asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -168,6 +229,7 @@ __device__ __forceinline__ void pw_kloop(const float* __restrict__ wf, int n_kb,
       asm volatile("" : "+v"(f0.a[k][0][p]));
       asm volatile("" : "+v"(f1.a[k][0][p]));
       asm volatile("" : "+v"(f2.a[k][0][p]));
+      if constexpr (NR == 4) asm volatile("" : "+v"(f3.a[k][0][p]));
     }
 }
 
@@ -341,7 +403,7 @@ __device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int 
   pm_u32x2 mw[4];
   pw_load_words(mw, e.abits, e.row0, e.nvalid, wid, c);
   f32x4 acc[4][4];
-  pw_kloop<false>(wb, n_kb, e.buf, wid, lane, acc);
+  pw_kloop<false, 4>(wb, n_kb, e.buf, wid, lane, acc);      // (the adjoint has the registers for a fourth chunk: 255, no spill)
   PW_STAMP(0);
   const float ik = 1.f / e.keep;
   auto lookup = [&](f32x4 (&m)[4], int k) {
