@@ -887,6 +887,10 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
             p->rows_per_wg = 16;
             int fan = 2;
             while (fan * fan < parts) ++fan;
+            // ONE group (mm_groups=None): two collectors per XCD -- 2 fan parts of the group on every XCD, so that the
+            // members' hop to their collector stays inside that XCD's L2 (the register-resident family deals its workgroups
+            // that way: pmbrl_reg.h, pr_wg; the latency-optimised family walks the same slots in dispatch order)
+            if (p->G == 1 && parts <= 256) fan = (parts + 15) / 16;
             p->mm_fan = fan;
           }
         }

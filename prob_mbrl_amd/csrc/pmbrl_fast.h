@@ -183,61 +183,6 @@ __device__ __forceinline__ bool pm_group_sync(unsigned* flags, int self, int fir
   return ok;
 }
 
-// tot += the sums in slots [slot0, slot0 + n), in slot order; batches of 8 slots in flight
-template <int NV>
-__device__ __forceinline__ bool pm_xch_add_slots(const unsigned long long* xb, int slot0, int n, unsigned k, double (&tot)[NV],
-                                                 int lane) {
-  typedef PM_GLOBAL unsigned long long gu64;
-  constexpr int NB = 8;
-  for (int q0 = 0; q0 < n; q0 += NB) {
-    const int nb = n - q0 < NB ? n - q0 : NB;
-    unsigned long long g[NB][2 * NV];
-    for (int spins = 0;;) {
-      bool here = true;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int q = q0 + (b < nb ? b : 0);        // (a short last batch asks for its first slot again)
-        const gu64* theirs = (const gu64*)xb + (size_t)(slot0 + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
-#pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) here = here && (g[b][i] >> 32) == (unsigned long long)k;
-      if (__all(here)) break;
-      if (++spins > (1 << 19)) return false;
-      __builtin_amdgcn_s_sleep(1);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-      if (b < nb) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          tot[i] += __longlong_as_double((long long)(((g[b][2 * i] & 0xffffffffull) << 32) | (g[b][2 * i + 1] & 0xffffffffull)));
-      }
-  }
-  return true;
-}
-// v <- the sum over all parts, two levels (v holds this part's own contribution on entry, already published by pm_xch_put)
-template <int NV>
-__device__ __forceinline__ bool pm_xch_get_tree(unsigned long long* xb, int nwg, int first, int parts, int fan, int me, unsigned k,
-                                                double (&v)[NV], int lane) {
-  const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
-  bool ok = true;
-  if (me == c0) {
-    double tot[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) tot[i] = 0.0;
-    ok = pm_xch_add_slots<NV>(xb, first + c0, (parts - c0 < fan ? parts - c0 : fan), k, tot, lane);
-    pm_xch_put<NV>(xb, nwg + first, c, k, tot, lane);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  ok = pm_xch_add_slots<NV>(xb, nwg + first, nc, k, v, lane) && ok;
-  return ok;
-}
-
 struct SdV {
   int n, v;
   int k;   // lane 4*l + {0: ks, 1: tw_off, 2: n_kb_real} of streamed layer l

@@ -133,6 +133,12 @@ __device__ __forceinline__ const RegMM* pr_mm_args() {
 __device__ __forceinline__ int pr_wg(const RegArgs& A) {
   const int hw = (int)blockIdx.x + A.wg0;
   if (!A.mm.on || !A.mm.xcd) return hw;
+  if (A.mm.xcd == 2) {
+    // ONE group over the batch, two-level exchange: XCD x holds the parts [x * 2 fan, (x + 1) * 2 fan) -- two collectors and
+    // their members: the first hop stays inside the XCD's L2, the second (<= 16 collectors' slots) crosses the fabric
+    const int per = 2 * A.mm.fan, pw = (hw & 7) * per + (hw >> 3);
+    return pw < A.mm.parts ? pw : -1;
+  }
   const int P = A.mm.parts, blk = hw / (8 * P), r = hw - blk * (8 * P);
   const int gi = blk * 8 + (r & 7);
   return gi < A.mm.groups ? gi * P + (r >> 3) : -1;
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
   if (PROF && wg == 0 && tid == 0) A.prof[26] = (long long)__builtin_readcyclecounter();
   // activation buffer: zero, then the constant 1 the hidden-layer biases multiply (slot 4 of the last block, high plane)
   for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PR_LDS_ACT + i] = 0.f;
+  if (tid < 16) smem[PR_LDS_FLAG + tid] = 0.f;      // (the two-level exchange's tags: pmbrl_xch.h)
   // dropout multipliers of this lane's values, tile by tile (rows past the batch: zero -- their activations stay 0)
 #pragma unroll
   for (int n = 0; n < 2; ++n)
@@ -955,11 +962,25 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         pr_mm_fwd_file<MMDc>(Q, t - 1, mm_gi, mm_me, ln, mm_rec);
         if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 15] = (long long)__builtin_readcyclecounter();
       }
+      // ONE group in more than 8 parts (the two-level exchange): the waves that are not the chain's poll a quarter of each
+      // level's slots and leave the sums in LDS (pmbrl_xch.h) -- in the heads' partial-tile buffer (3 of its 4 KB), which is
+      // dead from the dynamics head's last read to the next step's policy head; the barrier is what says that every wave HAS
+      // read its head value (the forward sweep's LDS is full: 448 bytes free).  The tags live in words of their own.
+      double* const xh = reinterpret_cast<double*>(smem + PR_LDS_PART);
+      volatile unsigned* const xtag = reinterpret_cast<volatile unsigned*>(smem + PR_LDS_FLAG);
+      if constexpr (MMD == 4) {
+        if (Q.fan) pr_barrier();
+        if (wid != 0 && Q.fan) {
+          const bool okh = pm_xch_tree_help<PR_MM_NVX(4), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(t + 1), wid, xh,
+                                                  xtag, ln);
+          if (!okh && lane == 0) atomicMin(A.status, t);
+        }
+      }
       double rec[3] = {0.0, 0.0, 0.0};
       if (wid == 0) {
         float xo[2];
         const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, Q.tag0 + (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
-                                               mm_zh + (t & 1) * (16 * MMDc), xo, rec,
+                                               mm_zh + (t & 1) * (16 * MMDc), xo, rec, xh, xtag,
                                                (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
         *reinterpret_cast<f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g) = f32x2{xo[0], xo[1]};
@@ -1055,7 +1076,9 @@ __global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegU
 #define PRB_LDS_XB (PRB_LDS_IN + 16 * PRB_IN_COLS)  // [16 rows][8]: dL/dx~ behind the moment matching's adjoint, wave 0 -> every wave
 #define PRB_LDS_MMB (PRB_LDS_XB + 128)              // [2][4][64] doubles: the noise operand, wave 1 -> wave 0 (pmbrl_reg_mm.h)
 #define PRB_LDS_MMY (PRB_LDS_MMB + 2 * 2 * PR_MM_BOP_DOUBLES)    // [2][3 NK][64] doubles: Y1 | L | L^-T, wave 2 -> wave 0
-#define PRB_LDS_FLOATS (PRB_LDS_MMY + 2 * 2 * PR_MM_YOP_DOUBLES(6))
+#define PRB_LDS_XH (PRB_LDS_MMY + 2 * 2 * PR_MM_YOP_DOUBLES(6))      // the two-level exchange's helper sums (pmbrl_xch.h): 6 KB
+#define PRB_LDS_XTAG (PRB_LDS_XH + 2 * PM_XCH_HELP_DOUBLES(2))        // ... and their tags: [2 levels][3 waves] + 1 words
+#define PRB_LDS_FLOATS (PRB_LDS_XTAG + 16)
 
 template <bool PROF, int MMD = 0>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
@@ -1115,6 +1138,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
   pr_copy_net_to_lds<2>(smem, PRB_LDS_L0(0), PRB_LDS_XT(0), PRB_LDS_HEAD(0), packed, tid);
   pr_copy_net_to_lds<2>(smem, PRB_LDS_L0(1), PRB_LDS_XT(1), PRB_LDS_HEAD(1), packed + PR_NET_FLOATS, tid);
   for (int i = tid; i < PR_KB * 2 * PR_FRAG; i += PR_NTHR) smem[PRB_LDS_ACT + i] = 0.f;
+  if (tid < 16) smem[PRB_LDS_XTAG + tid] = 0.f;     // (the two-level exchange's tags: pmbrl_xch.h)
   if (tid < 64) {
     // nibble -> {0, 1 / keep} x 4
     const int n = tid >> 5, l = (tid >> 4) & 1, nib = tid & 15;
@@ -1382,11 +1406,21 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
         if (PROF && wg == 0 && lane == 0) A.prof[(size_t)t * 32 + 14] = (long long)__builtin_readcyclecounter();
       }
       if (do_chain) {
+        double* const xh = reinterpret_cast<double*>(smem + PRB_LDS_XH);
+        volatile unsigned* const xtag = reinterpret_cast<volatile unsigned*>(smem + PRB_LDS_XTAG);
+        if constexpr (MMD == 4) {
+          // (the two-level exchange: the other waves poll a quarter of each level's slots -- see the forward sweep)
+          if (wid != 0 && Q.fan) {
+            const bool okh = pm_xch_tree_help<PR_MM_NVX(4), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(T1 - t), wid, xh,
+                                                    xtag, ln);
+            if (!okh && lane == 0 && A.status) atomicMax(A.status, 1);
+          }
+        }
         if (wid == 0) {
           float go[(MMDc + 3) / 4];
           const bool ok = pr_mm_bwd_chain<MMDc>(Q, Q.tag0 + (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
                                                  mm_bop + (t & 1) * PR_MM_BOP_DOUBLES, mm_yop + (t & 1) * PR_MM_YOP_DOUBLES(MMDc), go,
-                                                 (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
+                                                 xh, xtag, (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
           if (!ok && lane == 0 && A.status) atomicMax(A.status, 1);
 #pragma unroll
           for (int rr = 0; rr < (MMDc + 3) / 4; ++rr) smem[PRB_LDS_XB + row * 8 + g + 4 * rr] = go[rr];

@@ -41,11 +41,18 @@ bool pm_reg_plan_ok(const pmbrl_plan* p) {
     // split over 2..8 of them with the statistics exchange; state widths 4..6.  (Moment matching of the rewards alone
     // leaves the sweep plain but lays the rows out by groups: the latency-optimised family's.)
     if (p->mm_mode != 1 || !(c.flags & PMBRL_FLAG_MM_STATES) || (c.flags & PMBRL_FLAG_INFER_NS)) return false;
-    if (!pm_reg_mm_shape_ok(p, p->prec) || p->mm_fan || p->mm_parts > 8 || p->rows_per_wg > 16 || c.H >= 4096) return false;
+    // (more than 8 parts: only with the two-level exchange -- mm_fan, ONE group over the batch)
+    if (!pm_reg_mm_shape_ok(p, p->prec) || (p->mm_parts > 8) != (p->mm_fan != 0) || p->rows_per_wg > 16 || c.H >= 4096) return false;
+    // (every wave of a workgroup polls four slots of a level: at most 16 members per collector, at most 16 collectors)
+    if (p->mm_fan && (p->mm_fan > 16 || (p->mm_parts + p->mm_fan - 1) / p->mm_fan > 16 || c.D != 4)) return false;
+    if (getenv("PMBRL_REG_TREE") && atoi(getenv("PMBRL_REG_TREE")) == 0 && p->mm_fan) return false;
     if (p->mm_parts <= 1 && p->rows_per_wg != p->M) return false;      // (several whole groups per workgroup: not here)
   }
   return true;
 }
+
+// one group over the batch with the collectors laid out per XCD (pmbrl.hip): 2 fan parts per XCD
+bool pm_reg_tree_xcd(const pmbrl_plan* p) { return p->mm_fan && p->G == 1 && 16 * p->mm_fan >= p->mm_parts && p->mm_fan <= 16; }
 
 size_t pm_reg_pack_bytes() { return (size_t)PR_PACK_FLOATS * sizeof(float); }
 
@@ -120,7 +127,11 @@ static void reg_args(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const 
     R.mm.xt = A.xt;
     R.mm.xt_off = (unsigned)p->off_xt;
     R.mm.xch = A.xch;
-    R.mm.xcd = (p->mm_parts > 1 && !(getenv("PMBRL_XCH_XCD") && atoi(getenv("PMBRL_XCH_XCD")) == 0)) ? 1 : 0;
+    R.mm.fan = p->mm_fan; R.mm.nwg = p->nwg;
+    // (a group in more parts than an XCD has CUs cannot sit on one: the two-level exchange crosses the fabric)
+    //  -- unless it is the ONLY group and its collectors were laid out per XCD: pmbrl.hip, mm_fan; pr_wg, mode 2)
+    const bool xcd_on = !(getenv("PMBRL_XCH_XCD") && atoi(getenv("PMBRL_XCH_XCD")) == 0);
+    R.mm.xcd = (p->mm_parts > 1 && xcd_on) ? (p->mm_fan ? (pm_reg_tree_xcd(p) ? 2 : 0) : 1) : 0;
     R.mm.tag0 = (++p->xch_gen) << 12;      // (steps < 4096; the parity of a tag is the parity of its step: the two sets alternate)
     R.mm.inv_m = 1.0 / (double)p->M;
     R.mm.inv_m1 = 1.0 / (double)(p->M - 1);
@@ -195,9 +206,9 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
   // (more groups than fit the chip at once: batches of whole groups, one launch each -- pmbrl_host.h, mm_gpb)
   // (groups' parts on one XCD -- pr_wg: hardware workgroups in blocks of 8 groups, the last block padded with workgroups
   //  that exit at once; a batch is a whole number of blocks)
-  const int total = R.mm.xcd ? (p->G + 7) / 8 * 8 * p->mm_parts : p->nwg;
+  const int total = R.mm.xcd == 2 ? 8 * 2 * p->mm_fan : R.mm.xcd ? (p->G + 7) / 8 * 8 * p->mm_parts : p->nwg;
   int per = (p->reg_mm && p->mm_gpb > 0) ? p->mm_gpb * p->mm_parts : total;
-  if (R.mm.xcd && per < total) per = (p->mm_gpb + 7) / 8 * 8 * p->mm_parts;
+  if (R.mm.xcd == 1 && per < total) per = (p->mm_gpb + 7) / 8 * 8 * p->mm_parts;
   for (int w0 = 0; w0 < total; w0 += per) {
     R.wg0 = w0;
     const int n = std::min(per, total - w0);

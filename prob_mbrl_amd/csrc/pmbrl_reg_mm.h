@@ -1,5 +1,7 @@
 // Moment matching inside the register-resident sweeps (pmbrl_reg.h), round 5: utils/rollout.py:20-29 and its adjoint
 //  for a group that is split over the `parts` consecutive workgroups of <= 16 rows that hold it.
+// Round 6: also ONE group over the whole batch (mm_groups=None, the reference examples' default --
+// examples/deep_pilco_mm.py:31, utils/rollout.py:127-128): 157 parts at 2 500 rows, the sums over two levels.
 //
 // The state of a row lives in the lanes of every wave as x[s] = dimension 2 g + s (g = lane >> 4, row = lane & 15).  ONE
 // wave (wave 0) runs the chain while the other three wait at the step's fifth barrier; what it costs is the length of
@@ -43,11 +45,17 @@ struct RegMM {
   float* xt;                     // [H][B][D]: the sampled (pre-mm) states
   unsigned xt_off;               // ... as a byte offset in the workspace (the forward sweep's buffer stores)
   unsigned long long* xch;       // granules of the statistics exchange (parts > 1)
+  int fan, nwg;                  // more than 8 parts (mm_groups=None: ONE group over the batch): the sums travel over two levels --
+                                 // every `fan` consecutive parts have a collector (pmbrl_xch.h, pm_xch_get_tree); nwg: the
+                                 // launch's logical workgroups (the collectors' slots follow the parts')
   int xcd;                       // 1: the launch's workgroups are dealt so that a group's parts share an XCD (pr_wg)
   unsigned tag0;                 // generation of this launch, shifted past the step count: the granules' tags are tag0 + step
                                  // (no two launches share a tag, so the buffer is never zeroed between them)
   double inv_m, inv_m1;          // 1 / M, 1 / (M - 1) (from the host: an fp64 division is thirty instructions)
 };
+
+// doubles per lane the parts of a group exchange: the Gram / H tile's register 0 (rows 0 .. 3) and, beyond d = 4, register 1
+#define PR_MM_NVX(DD) ((DD) <= 4 ? 1 : 2)
 
 // 1 / sqrt(x): the hardware estimate (2^-26) and TWO Newton steps (pm_rsqrt takes three: on the one-wave chain every
 // fp64 instruction is six cycles of the step)
@@ -66,8 +74,11 @@ template <int DD>
 __device__ __forceinline__ bool pr_mm_factor(const pm_f64x4& G, double dM, double inv_m, double inv_m1, MMW<DD>& q,
                                              double* ratio_out = nullptr) {
   double rmin = 1.0;
+  // (the tile is symmetric bit for bit -- both operands of its products are the same registers -- so the column sums are read
+  //  from COLUMN d of the rows 0 .. d - 1: at d = 4 nothing of the tile's second register is used, and the parts of a group
+  //  exchange one double per lane instead of two: PR_MM_NVX)
 #pragma unroll
-  for (int j = 0; j < DD; ++j) q.mean[j] = PM_G(G, DD, j) * inv_m;
+  for (int j = 0; j < DD; ++j) q.mean[j] = (DD <= 4 ? PM_G(G, j, DD) : PM_G(G, DD, j)) * inv_m;
   bool ok = true;
   // (column by column: the covariance entries of column k leave the tile when the factor gets there -- forming the
   //  whole matrix first keeps d (d + 1) / 2 more doubles alive than a 6 x 6 factorisation has registers for)
@@ -177,7 +188,8 @@ __device__ __forceinline__ void pr_mm_fwd_prep(const RegMM& Q, int t, int gi, in
 template <int DD>
 __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned kstep, int gi, int me, int first_wg, int nvalid,
                                                 int lane, const float (&xn)[2], double& refl, const double* zh,
-                                                float (&xout)[2], double (&rec)[3], long long* pf = nullptr) {
+                                                float (&xout)[2], double (&rec)[3], const double* hp, volatile unsigned* tags,
+                                                long long* pf = nullptr) {
   static_assert(DD >= 2 && DD <= 6, "state widths 2..6");
   const int c = lane & 15, k = lane >> 4;
   pm_f64x4 G0, G1;
@@ -205,8 +217,11 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
   pm_f64x4 G = G0 + G1;
   bool ok = true;
   PR_MM_STAMP(8);
-  double v2[2] = {G[0], G[1]};
-  if (Q.parts > 1) pm_xch_put<2>(Q.xch, first_wg, me, kstep, v2, lane);
+  constexpr int NVX = PR_MM_NVX(DD);
+  double v2[NVX];
+#pragma unroll
+  for (int i = 0; i < NVX; ++i) v2[i] = G[i];
+  if (Q.parts > 1) pm_xch_put<NVX>(Q.xch, first_wg, me, kstep, v2, lane);
   // (this lane's row of the standardised noise: requested here, used behind the factorisation -- at d > 4 requested behind
   //  it: the factorisation of a 5 x 5 or 6 x 6 covariance has no registers to carry the row through)
   double zhr[DD];
@@ -215,10 +230,11 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     for (int cc = 0; cc < DD; ++cc) zhr[cc] = zh[c * DD + cc];
   }
   if (Q.parts > 1) {
-    ok = Q.parts == 2 ? pm_xch_get_pair<2>(Q.xch, first_wg, me, kstep, v2, lane)
-                      : pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
-    G[0] = v2[0];
-    G[1] = v2[1];
+    ok = Q.fan ? pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, v2, hp, tags, lane)
+               : Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, v2, lane)
+                              : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) G[i] = v2[i];
   }
   PR_MM_STAMP(9);
   rec[0] = G[0];
@@ -393,7 +409,8 @@ __device__ __forceinline__ void pr_mm_bwd_prep_factor(const RegMM& Q, int B, int
 template <int DD>
 __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, int me, int first_wg, int nvalid, int lane,
                                                 const float (&gx)[2], const double* bop, const double* yop,
-                                                float (&out)[(DD + 3) / 4], long long* pf = nullptr) {
+                                                float (&out)[(DD + 3) / 4], const double* hp, volatile unsigned* tags,
+                                                long long* pf = nullptr) {
   constexpr int NK = (DD + 3) / 4;
   const int c = lane & 15, k = lane >> 4;
   // H = g^T [zhat | 1]
@@ -418,9 +435,14 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, 
     pr_mfma64_fence(H0, H1);
   }
   pm_f64x4 H = H0 + H1;
-  double hs[2] = {H[0], H[1]};
+  // (rows i < d of H: register i >> 2 -- at d = 4 the first alone)
+  constexpr int NVX = PR_MM_NVX(DD);
+  static_assert(NVX == NK, "the H tile's registers the algebra reads are the ones exchanged");
+  double hs[NVX];
+#pragma unroll
+  for (int i = 0; i < NVX; ++i) hs[i] = H[i];
   PR_MM_STAMP(8);
-  if (Q.parts > 1) pm_xch_put<2>(Q.xch, first_wg, me, kstep, hs, lane);
+  if (Q.parts > 1) pm_xch_put<NVX>(Q.xch, first_wg, me, kstep, hs, lane);
   double Y1[NK], LA[NK], LiT[NK];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) {
@@ -431,8 +453,9 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, 
   bool ok = true;
   PR_MM_STAMP(9);
   if (Q.parts > 1)
-    ok = Q.parts == 2 ? pm_xch_get_pair<2>(Q.xch, first_wg, me, kstep, hs, lane)
-                      : pm_xch_get_all<2, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+    ok = Q.fan ? pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, hs, hp, tags, lane)
+               : Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, hs, lane)
+                              : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
   PR_MM_STAMP(10);
   // Lbar = tril(H[:, :d]) in the tile's own registers (row i = k + 4 kk, column c)
   double lb[NK];

@@ -159,3 +159,155 @@ __device__ __forceinline__ bool pm_xch_get_all(const unsigned long long* xb, int
   for (int i = 0; i < NV; ++i) v[i] = tot[i];
   return true;
 }
+
+// tot += the sums in slots [slot0, slot0 + n), in slot order; batches of 8 slots in flight
+// PRE: wait for ONE granule (lane 0's first word of the batch's last slot: every lane asks for the same 8 bytes) before the
+// batch is asked for -- with hundreds of waves polling the same dozen slots (one group over the batch: every part reads
+// every collector's slot) the full-batch polls, 4 NV NB x 512 bytes each, are a flood of uncached reads that the stores they
+// wait for queue behind (MI355X_MICROARCH.md: "255 pollers cut chip bandwidth 37-71 %"; poll one word, then read)
+template <int NV, int NB = 8, bool PRE = false>
+__device__ __forceinline__ bool pm_xch_add_slots(const unsigned long long* xb, int slot0, int n, unsigned k, double (&tot)[NV],
+                                                 int lane) {
+  typedef PM_GLOBAL unsigned long long gu64;
+  for (int q0 = 0; q0 < n; q0 += NB) {
+    const int nb = n - q0 < NB ? n - q0 : NB;
+    if constexpr (PRE) {
+      const gu64* one = (const gu64*)xb + (size_t)(slot0 + q0 + nb - 1) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64);
+      for (int spins = 0;;) {
+        const unsigned long long g1 = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((g1 >> 32) == (unsigned long long)k) break;
+        if (++spins > (1 << 19)) return false;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    unsigned long long g[NB][2 * NV];
+    for (int spins = 0;;) {
+      bool here = true;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int q = q0 + (b < nb ? b : 0);        // (a short last batch asks for its first slot again)
+        const gu64* theirs = (const gu64*)xb + (size_t)(slot0 + q) * PM_XCH_WG_WORDS(NV) + (size_t)(k & 1u) * (NV * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) g[b][i] = __hip_atomic_load(theirs + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) here = here && (g[b][i] >> 32) == (unsigned long long)k;
+      if (__all(here)) break;
+      if (++spins > (1 << 19)) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (b < nb) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          tot[i] += __longlong_as_double((long long)(((g[b][2 * i] & 0xffffffffull) << 32) | (g[b][2 * i + 1] & 0xffffffffull)));
+      }
+  }
+  return true;
+}
+// v <- the sum over all parts, two levels (v holds this part's own contribution on entry, already published by pm_xch_put)
+// (NB: slots in flight per batch -- 4 NV NB registers of granules)
+template <int NV, int NB = 8>
+__device__ __forceinline__ bool pm_xch_get_tree(unsigned long long* xb, int nwg, int first, int parts, int fan, int me, unsigned k,
+                                                double (&v)[NV], int lane) {
+  const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
+  bool ok = true;
+  if (me == c0) {
+    double tot[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+    ok = pm_xch_add_slots<NV, NB>(xb, first + c0, (parts - c0 < fan ? parts - c0 : fan), k, tot, lane);
+    pm_xch_put<NV>(xb, nwg + first, c, k, tot, lane);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  ok = pm_xch_add_slots<NV, NB>(xb, nwg + first, nc, k, v, lane) && ok;
+  return ok;
+}
+
+// ---------------------------------------------------------------------------
+// The two-level exchange with ALL waves of the workgroup polling (the register-resident family, round 6).  One wave walks a
+// level's <= 13 slots in batches of NB = 4 (what its registers hold): four memory round trips per level, eight per step --
+// 14 k cycles of a 27 k-cycle step at 157 parts (profiles/r06_single_group.txt).  The workgroup's other waves idle during
+// the chain: wave w (1 .. 3) takes the slots [w NB, (w + 1) NB) of a level in ONE batch, leaves their sum (slot order) in
+// LDS behind a tag, and the chain's wave adds  (its own batch) + p1 + p2 + p3  -- the same association in every part, so
+// every part still ends with the same bits.  One round trip per level; <= 4 NB = 16 slots per level (256 parts).
+// hp: LDS [3 helper waves][NV][64] doubles, shared by the two levels -- a collector's helper writes its level-2 sum only
+// once the chain's wave has acknowledged reading the level-1 sums (tags[6]); tags: LDS [2 levels][3 waves] + the
+// acknowledgement, 7 words, zero at launch (a tag is a step's k > 0).
+// ---------------------------------------------------------------------------
+#define PM_XCH_HELP_DOUBLES(NV) (3 * (NV) * 64)
+__device__ __forceinline__ bool pm_xch_lds_wait(volatile const unsigned* tag, unsigned k) {
+  for (int spins = 0;;) {
+    if (*tag == k) return true;
+    if (++spins > (1 << 19)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+template <int NV, int NB>
+__device__ __forceinline__ bool pm_xch_help_one(const unsigned long long* xb, int slot0, int n, int w, unsigned k, double* part,
+                                                volatile unsigned* tag, volatile const unsigned* ack, int lane) {
+  const int lo = w * NB;
+  if (lo >= n) return true;
+  double tot[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+  bool ok = pm_xch_add_slots<NV, NB, true>(xb, slot0 + lo, n - lo < NB ? n - lo : NB, k, tot, lane);
+  if (ack) ok = pm_xch_lds_wait(ack, k) && ok;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) part[i * 64 + lane] = tot[i];
+  // (a wave's LDS operations complete in order: the tag is written once the sums are in LDS)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  *tag = k;
+  return ok;
+}
+// helper wave w (1 .. 3) of part `me`
+template <int NV, int NB>
+__device__ __forceinline__ bool pm_xch_tree_help(const unsigned long long* xb, int nwg, int first, int parts, int fan, int me,
+                                                 unsigned k, int w, double* hp, volatile unsigned* tags, int lane) {
+  const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
+  double* part = hp + (size_t)(w - 1) * NV * 64;
+  bool ok = true;
+  const int n1 = parts - c0 < fan ? parts - c0 : fan;
+  const bool wrote1 = me == c0 && w * NB < n1;
+  if (me == c0) ok = pm_xch_help_one<NV, NB>(xb, first + c0, n1, w, k, part, tags + (w - 1), nullptr, lane);
+  ok = pm_xch_help_one<NV, NB>(xb, nwg + first, nc, w, k, part, tags + 3 + (w - 1), wrote1 ? tags + 6 : nullptr, lane) && ok;
+  return ok;
+}
+// the chain's wave: tot <- (slots 0 .. NB - 1) + the helpers' partial sums, in wave order
+template <int NV, int NB>
+__device__ __forceinline__ bool pm_xch_sum_helped(const unsigned long long* xb, int slot0, int n, unsigned k, double (&tot)[NV],
+                                                  const double* hp, volatile const unsigned* tags, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tot[i] = 0.0;
+  const bool ok = pm_xch_add_slots<NV, NB, true>(xb, slot0, n < NB ? n : NB, k, tot, lane);
+  for (int w = 1; w < 4; ++w) {
+    if (w * NB >= n) break;
+    if (!pm_xch_lds_wait(tags + (w - 1), k)) return false;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tot[i] += hp[(size_t)(w - 1) * NV * 64 + i * 64 + lane];
+  }
+  return ok;
+}
+// v <- the sum over all parts (this part's own contribution already published by pm_xch_put)
+template <int NV, int NB>
+__device__ __forceinline__ bool pm_xch_get_tree_helped(unsigned long long* xb, int nwg, int first, int parts, int fan, int me,
+                                                       unsigned k, double (&v)[NV], const double* hp, volatile unsigned* tags,
+                                                       int lane) {
+  const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
+  bool ok = true;
+  if (me == c0) {
+    double tot[NV];
+    ok = pm_xch_sum_helped<NV, NB>(xb, first + c0, parts - c0 < fan ? parts - c0 : fan, k, tot, hp, tags, lane);
+    // (the level-1 sums are in registers -- the additions above waited for them: their buffer is the helpers' again)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tags[6] = k;
+    pm_xch_put<NV>(xb, nwg + first, c, k, tot, lane);
+  }
+  ok = pm_xch_sum_helped<NV, NB>(xb, nwg + first, nc, k, v, hp, tags + 3, lane) && ok;
+  return ok;
+}
