@@ -59,6 +59,8 @@ def parse():
     ap.add_argument('--no-fused-tail', action='store_true',
                     help='N = 1: separate loss / dW-reduce / norm / Adam launches (what N > 1 runs around its all-reduce)')
     ap.add_argument('--no-second-curve', action='store_true', help='N > 1: skip the other scaling curve')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help="N = 1, headline config: skip the short legs of BASELINE.json's other configurations (`other_configs`)")
     ap.add_argument('--cpu-only', action='store_true', help='only time the CPU baseline (no GPU needed)')
     ap.add_argument('--timing-steps', type=int, default=10)
     ap.add_argument('--repeats', type=int, default=0,
@@ -507,6 +509,36 @@ PREDICTED_WEAK = {2: dict(ms_per_step=0.50, value=10.0e6, efficiency=0.94), 4: d
                   8: dict(ms_per_step=0.53, value=37.9e6, efficiency=0.89)}
 
 
+def other_configs(a, dev):
+    """Short timed legs of the configurations the headline line does not time: {name: {value, ms_per_step, ...}}."""
+    import copy
+    from prob_mbrl_amd import problem as PB
+    out = {}
+    for name, cfg, groups, steps, reps in (('cartpole_mm', 'cartpole_mm', None, 20, 5),
+                                           ('cartpole_mm_g1', 'cartpole_mm', 0, 20, 5),
+                                           ('dcartpole_mm', 'dcartpole_mm', None, 10, 5),
+                                           ('stress32', 'stress32', None, 3, 2)):
+        b = copy.copy(a)
+        b.config, b.no_fused_tail = cfg, False
+        d = dict(PB.synthetic_problem(cfg, seed=0, data_seed=0))
+        if groups is not None:
+            d['mm_groups'] = np.asarray(groups)
+        try:
+            leg = Leg(b, d, dev, d['x0'].shape[0], 0, a.precision, None, 1, None)
+            dt, blocks = leg.timed(steps, 2, dev, reps)
+            t = leg.kernel_ms(2)
+            out[name] = dict(value=leg.Bg * steps / dt, unit='rollouts/s', ms_per_step=dt / steps * 1e3, steps=steps,
+                             timed_blocks=len(blocks), value_min=leg.Bg * steps / max(blocks), value_max=leg.Bg * steps / min(blocks),
+                             rows=leg.B, horizon=leg.H, mm_groups=int(d['mm_groups']), precision=leg.eng.info['precision'],
+                             workgroups=leg.eng.info['n_wg'], rows_per_wg=leg.eng.info['rows_per_wg'],
+                             register_resident=bool(leg.eng.info.get('reg')), kernel_ms={k: round(v, 4) for k, v in t.items()})
+            del leg
+        except Exception as e:      # noqa: BLE001  (a leg that cannot run must not take the headline line with it)
+            out[name] = dict(error=str(e)[:200])
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     from prob_mbrl_amd import problem as PB
@@ -639,6 +671,13 @@ def main():
                             steps=a.steps, warmup=a.warmup, dtype='f32 (v_mfma_f32_16x16x4_f32)',
                             kernel_ms={k: round(vv, 4) for k, vv in t3.items()}, roofline=r3)
         del leg3
+
+    if world == 1 and a.config == 'cartpole_nomm' and not a.no_other_configs and not a.rows_per_wg:
+        # BASELINE.json's other configurations in the SAME invocation (short legs, same timing protocol: blocks between
+        # barrier + synchronize, median): whoever times this script times them too -- until round 6 only the headline
+        # configuration had a number the builder had not run himself.  C3 = cartpole_mm (25-row groups), its
+        # mm_groups=None form (ONE 2 500-row group, the reference examples' default), C4 = dcartpole_mm, C5 = stress32.
+        extra['other_configs'] = other_configs(a, dev)
 
     if rank == 0:
         flops_rollout, Pm, Fm = PB.algorithmic_flops_per_rollout(d)

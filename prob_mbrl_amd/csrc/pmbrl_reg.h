@@ -596,7 +596,9 @@ __device__ __forceinline__ void pr_copy_net_to_lds(float* smem, int lds_l0, int 
 }
 
 // MMD: 0, or the state width of the instance that moment-matches the sampled states inside the sweep (pmbrl_reg_mm.h)
-template <bool PROF, int MMD = 0>
+// TREE: the instance that carries the two-level statistics exchange (ONE group in more than 8 parts) -- its own: compiled
+// into the shared instances its polling code cost them 12-21 more spilled scalar registers and 3-5 % of a sweep
+template <bool PROF, int MMD = 0, bool TREE = false>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool F16 = true;
@@ -968,10 +970,10 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       // read its head value (the forward sweep's LDS is full: 448 bytes free).  The tags live in words of their own.
       double* const xh = reinterpret_cast<double*>(smem + PR_LDS_PART);
       volatile unsigned* const xtag = reinterpret_cast<volatile unsigned*>(smem + PR_LDS_FLAG);
-      if constexpr (MMD == 4) {
-        if (Q.fan) pr_barrier();
-        if (wid != 0 && Q.fan) {
-          const bool okh = pm_xch_tree_help<PR_MM_NVX(4), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(t + 1), wid, xh,
+      if constexpr (TREE) {
+        pr_barrier();
+        if (wid != 0) {
+          const bool okh = pm_xch_tree_help<PR_MM_NVX(MMDc), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(t + 1), wid, xh,
                                                   xtag, ln);
           if (!okh && lane == 0) atomicMin(A.status, t);
         }
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       double rec[3] = {0.0, 0.0, 0.0};
       if (wid == 0) {
         float xo[2];
-        const bool ok = pr_mm_fwd_chain<MMDc>(Q, t, Q.tag0 + (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
+        const bool ok = pr_mm_fwd_chain<MMDc, TREE>(Q, t, Q.tag0 + (unsigned)(t + 1), mm_gi, mm_me, mm_gi * Q.parts, nvalid, ln, xs, mm_ref,
                                                mm_zh + (t & 1) * (16 * MMDc), xo, rec, xh, xtag,
                                                (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
@@ -1080,7 +1082,9 @@ __global__ __launch_bounds__(PR_NTHR) void pm_reg_unpack_abits_kernel(const RegU
 #define PRB_LDS_XTAG (PRB_LDS_XH + 2 * PM_XCH_HELP_DOUBLES(2))        // ... and their tags: [2 levels][3 waves] + 1 words
 #define PRB_LDS_FLOATS (PRB_LDS_XTAG + 16)
 
-template <bool PROF, int MMD = 0>
+// TREE: the instance that carries the two-level statistics exchange (ONE group in more than 8 parts) -- its own: compiled
+// into the shared instances its polling code cost them 12-21 more spilled scalar registers and 3-5 % of a sweep
+template <bool PROF, int MMD = 0, bool TREE = false>
 __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool F16 = false;
@@ -1408,17 +1412,17 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       if (do_chain) {
         double* const xh = reinterpret_cast<double*>(smem + PRB_LDS_XH);
         volatile unsigned* const xtag = reinterpret_cast<volatile unsigned*>(smem + PRB_LDS_XTAG);
-        if constexpr (MMD == 4) {
+        if constexpr (TREE) {
           // (the two-level exchange: the other waves poll a quarter of each level's slots -- see the forward sweep)
-          if (wid != 0 && Q.fan) {
-            const bool okh = pm_xch_tree_help<PR_MM_NVX(4), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(T1 - t), wid, xh,
+          if (wid != 0) {
+            const bool okh = pm_xch_tree_help<PR_MM_NVX(MMDc), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(T1 - t), wid, xh,
                                                     xtag, ln);
             if (!okh && lane == 0 && A.status) atomicMax(A.status, 1);
           }
         }
         if (wid == 0) {
           float go[(MMDc + 3) / 4];
-          const bool ok = pr_mm_bwd_chain<MMDc>(Q, Q.tag0 + (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
+          const bool ok = pr_mm_bwd_chain<MMDc, TREE>(Q, Q.tag0 + (unsigned)(T1 - t), mm_me, mm_gi * Q.parts, nvalid, ln, gx,
                                                  mm_bop + (t & 1) * PR_MM_BOP_DOUBLES, mm_yop + (t & 1) * PR_MM_YOP_DOUBLES(MMDc), go,
                                                  xh, xtag, (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
           if (!ok && lane == 0 && A.status) atomicMax(A.status, 1);

@@ -59,19 +59,20 @@ size_t pm_reg_pack_bytes() { return (size_t)PR_PACK_FLOATS * sizeof(float); }
 // state width of the moment-matching instance this plan's sweeps run on (0: the plain instance)
 int pm_reg_mm_width(const pmbrl_plan* p) { return (p->reg && p->mm_mode == 1) ? p->cfg.D : 0; }
 
-template <int MMD>
+template <int MMD, bool TREE = false>
 static int reg_set_attr_mm() {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<false, MMD>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<false, MMD, TREE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true, MMD>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_fwd_kernel<true, MMD, TREE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PR_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<false, MMD>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<false, MMD, TREE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<true, MMD>),
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_reg_bwd_kernel<true, MMD, TREE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRB_LDS_FLOATS * sizeof(float))));
   return 0;
 }
 int pm_reg_set_attr(const pmbrl_plan* p) {
+  if (p->reg_mm == 4 && p->mm_fan) return reg_set_attr_mm<4, true>();
   switch (p->reg_mm) {
     case 4: return reg_set_attr_mm<4>();
     case 5: return reg_set_attr_mm<5>();
@@ -183,14 +184,14 @@ void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s) {
   hipLaunchKernelGGL(pm_reg_unpack_abits_kernel, dim3(p->nwg, p->cfg.H), dim3(PR_NTHR), 0, s, U);
 }
 
-template <int MMD>
+template <int MMD, bool TREE = false>
 static void reg_launch_mm(int nwg, const RegArgs& R, hipStream_t s, bool fwd) {
   if (fwd) {
-    if (R.prof) hipLaunchKernelGGL((pm_reg_fwd_kernel<true, MMD>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL((pm_reg_fwd_kernel<false, MMD>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    if (R.prof) hipLaunchKernelGGL((pm_reg_fwd_kernel<true, MMD, TREE>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_fwd_kernel<false, MMD, TREE>), dim3(nwg), dim3(PR_NTHR), PR_LDS_FLOATS * sizeof(float), s, R);
   } else {
-    if (R.prof) hipLaunchKernelGGL((pm_reg_bwd_kernel<true, MMD>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
-    else hipLaunchKernelGGL((pm_reg_bwd_kernel<false, MMD>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    if (R.prof) hipLaunchKernelGGL((pm_reg_bwd_kernel<true, MMD, TREE>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
+    else hipLaunchKernelGGL((pm_reg_bwd_kernel<false, MMD, TREE>), dim3(nwg), dim3(PR_NTHR), PRB_LDS_FLOATS * sizeof(float), s, R);
   }
 }
 
@@ -212,6 +213,7 @@ void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const fl
   for (int w0 = 0; w0 < total; w0 += per) {
     R.wg0 = w0;
     const int n = std::min(per, total - w0);
+    if (p->reg_mm == 4 && p->mm_fan) { reg_launch_mm<4, true>(n, R, s, fwd); continue; }
     switch (p->reg_mm) {
       case 4: reg_launch_mm<4>(n, R, s, fwd); break;
       case 5: reg_launch_mm<5>(n, R, s, fwd); break;

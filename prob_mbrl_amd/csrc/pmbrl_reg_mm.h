@@ -185,7 +185,7 @@ __device__ __forceinline__ void pr_mm_fwd_prep(const RegMM& Q, int t, int gi, in
 // moment-matched row.
 // rec: what pr_mm_fwd_file needs to write this step's factor record -- the group's Gram sums (two registers of the tile) and
 // the reference point they are relative to.
-template <int DD>
+template <int DD, bool TREE = false>
 __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned kstep, int gi, int me, int first_wg, int nvalid,
                                                 int lane, const float (&xn)[2], double& refl, const double* zh,
                                                 float (&xout)[2], double (&rec)[3], const double* hp, volatile unsigned* tags,
@@ -230,9 +230,9 @@ __device__ __forceinline__ bool pr_mm_fwd_chain(const RegMM& Q, int t, unsigned 
     for (int cc = 0; cc < DD; ++cc) zhr[cc] = zh[c * DD + cc];
   }
   if (Q.parts > 1) {
-    ok = Q.fan ? pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, v2, hp, tags, lane)
-               : Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, v2, lane)
-                              : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
+    if constexpr (TREE) ok = pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, v2, hp, tags, lane);
+    else ok = Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, v2, lane)
+                           : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, v2, lane);
 #pragma unroll
     for (int i = 0; i < NVX; ++i) G[i] = v2[i];
   }
@@ -406,7 +406,7 @@ __device__ __forceinline__ void pr_mm_bwd_prep_factor(const RegMM& Q, int B, int
 
 // gx: dL/dx_{t+1}, dimensions 2 g, 2 g + 1 of row lane & 15 (zero in rows past the part).  out[rr]: dL/dx~ of dimension
 // (lane >> 4) + 4 rr of row lane & 15.  bop / yop: this step's hand-over buffers.
-template <int DD>
+template <int DD, bool TREE = false>
 __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, int me, int first_wg, int nvalid, int lane,
                                                 const float (&gx)[2], const double* bop, const double* yop,
                                                 float (&out)[(DD + 3) / 4], const double* hp, volatile unsigned* tags,
@@ -453,9 +453,11 @@ __device__ __forceinline__ bool pr_mm_bwd_chain(const RegMM& Q, unsigned kstep, 
   bool ok = true;
   PR_MM_STAMP(9);
   if (Q.parts > 1)
-    ok = Q.fan ? pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, hs, hp, tags, lane)
-               : Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, hs, lane)
-                              : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+  {
+    if constexpr (TREE) ok = pm_xch_get_tree_helped<NVX, 4>(Q.xch, Q.nwg, first_wg, Q.parts, Q.fan, me, kstep, hs, hp, tags, lane);
+    else ok = Q.parts == 2 ? pm_xch_get_pair<NVX>(Q.xch, first_wg, me, kstep, hs, lane)
+                           : pm_xch_get_all<NVX, 4>(Q.xch, first_wg, Q.parts, me, kstep, hs, lane);
+  }
   PR_MM_STAMP(10);
   // Lbar = tril(H[:, :d]) in the tile's own registers (row i = k + 4 kk, column c)
   double lb[NK];

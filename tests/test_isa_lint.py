@@ -99,6 +99,7 @@ def test_register_resident_kernels_fit_the_register_file(tmp_path):
         assert agpr >= 4 * 62 and vgpr <= 512, (name, agpr, vgpr)
         assert int(re.search(r'\.max_flat_workgroup_size:\s+(\d+)', blk).group(1)) == 256, name
     # forward and adjoint, each with and without the cycle-counter instrumentation, each plain and with the in-sweep moment
-    # matching of state widths 4, 5, 6 (pmbrl_reg_mm.h: C3's and C4's shapes among them)
-    assert seen == 16, seen
+    # matching of state widths 4, 5, 6 (pmbrl_reg_mm.h: C3's and C4's shapes among them), and the four instances of width 4
+    # that carry the two-level exchange of ONE group over the batch (mm_groups=None)
+    assert seen == 20, seen
     shutil.rmtree(str(tmp_path), ignore_errors=True)
