@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256) void pm_draw_masks_kernel(const DrawArgs A) {
 // Small reductions: per-block partial sums in a per-device scratch, finished in FIXED order
 // (bit-reproducible).  The scratch is shared by all calls on a device: calls are expected to
 // be stream-ordered (one optimisation loop per device), like the rest of a plan's work.
+static inline int pm_norm_blocks(long long n) { return (int)std::max<long long>(1, std::min<long long>(PM_NORM_MAXB, (n + 255) / 256)); }
+static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d, float* exp_avg_d, float* exp_avg_sq_d,
+                                  int64_t n, int64_t* step_d, double lr, double beta1, double beta2, double eps,
+                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done);
 #define PM_RED_MAXB 128
 __device__ double g_red_part[2][PM_RED_MAXB];
 __device__ unsigned g_red_count;
@@ -240,31 +244,28 @@ __global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __res
   }
 }
 
-// clip_grad_norm_ + Adam in two launches: (1) per-block partial sums of g^2, (2) every block
-// adds the partials in the same order (identical norm everywhere) and updates its slice.
-// Guarded form (pmbrl_clip_adam_guarded): block 0 also decides whether the step is taken (the
-// rollout's status word says every horizon step completed) and, if so, advances the device-side
-// step counter; pm_clip_adam_kernel (next launch) reads both.
-__device__ int g_adam_go;
-__global__ __launch_bounds__(256) void pm_gradnorm_kernel(const float* __restrict__ g, long long n,
-                                                          const int* __restrict__ status, int expect,
-                                                          long long* __restrict__ step) {
-  __shared__ double sm[256];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // status[0]: steps the forward sweep completed; status[1]: set by the adjoint sweep when one of its barriers
-    // timed out (pmbrl_rollout_bwd) -- the gradient is garbage then, and the step is skipped like a failed rollout
-    const int go = (!status || (status[0] >= expect && status[1] == 0)) ? 1 : 0;
-    g_adam_go = go;
-    if (go && step) step[0] += 1;
+// clip_grad_norm_ + Adam in two launches: (1) partial sums of g^2 over blocks of 256 elements (pmbrl_dw.h, pm_sq4_wave:
+// the same partial sums the fused iteration's gradient reduction forms on the way), (2) every block adds the partials in
+// the same order (identical norm everywhere) and updates its slice.
+// Guarded form (pmbrl_clip_adam_guarded): block 0 also decides whether the step is taken (the rollout's status word says
+// every horizon step completed) and, if so, advances the device-side step counter; pm_clip_adam_kernel (next launch)
+// reads both.
+__global__ __launch_bounds__(64) void pm_gradnorm_kernel(const float* __restrict__ g, long long n,
+                                                         const int* __restrict__ status, int expect,
+                                                         long long* __restrict__ step, int guarded) {
+  if (guarded && blockIdx.x == 0 && threadIdx.x == 0) pm_adam_decide(status, expect, step);
+  // (one block of 256 elements per workgroup up to PM_NORM_MAXB of them; a longer vector is walked in strides, the
+  //  blocks' sums added in block order)
+  double tot = 0.0;
+  for (long long eb = blockIdx.x; eb * 256 < n; eb += gridDim.x) {
+    const long long i0 = eb * 256 + 4 * (long long)threadIdx.x;
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i0 + 3 < n) t = *reinterpret_cast<const f32x4*>(g + i0);
+    else
+      for (int r = 0; r < 4; ++r) t[r] = i0 + r < n ? g[i0 + r] : 0.f;
+    tot += pm_sq4_wave(t, i0, n);
   }
-  double s = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const double x = g[i];
-    s += x * x;
-  }
-  const double tot = pm_block_sum(s, sm);
-  if (threadIdx.x == 0) g_red_part[1][blockIdx.x] = tot;
+  if (threadIdx.x == 0) g_norm_part[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
   double t = 0.0;
   {
     const int lane = threadIdx.x & 63;
-    for (int b = lane; b < n_part; b += 64) t += g_red_part[1][b];
+    for (int b = lane; b < n_part; b += 64) t += g_norm_part[b];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
   }
@@ -2147,6 +2148,10 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
     }
   }
   const int n = (int)p->pol.n_params;
+  // the fused iteration (one process, optimiser attached): the reduction forms the gradient norm's partial sums and the
+  // go / no-go decision on the way -- pm_gradnorm_kernel's launch is not needed (PMBRL_FUSE_NORM=0: the separate launch)
+  const bool norm_fused = opt && !piped && (n + 255) / 256 <= PM_NORM_MAXB &&
+                          !(getenv("PMBRL_FUSE_NORM") && atoi(getenv("PMBRL_FUSE_NORM")) == 0);
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
     if (piped)   // every partial row was written (pm_dw_range)
@@ -2154,16 +2159,18 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
                          W.part_stride, grad_pol_flat_d, (const int*)nullptr, 0, 1);
     else
       hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
-                         W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split);
+                         W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split,
+                         norm_fused ? 1 : 0, (const int*)status_d, opt ? (opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H) : 0,
+                         opt ? reinterpret_cast<long long*>(opt->step_d) : (long long*)nullptr);
   }
   HIPCHK(hipGetLastError());
   // the optimiser step behind it, decided on the device (a form with the reduction, the norm and the update in ONE launch
   // around a device-wide barrier was measured at the C2 shape: 25.6 us against 13.7 + 4.7 + 7.1 us for the three launches
   // -- the barrier's L2 round trips cost what two launches do; not kept)
   if (opt)
-    return pmbrl_clip_adam_guarded(stream, opt->params_d, grad_pol_flat_d, opt->exp_avg_d, opt->exp_avg_sq_d, n, opt->step_d,
-                                   opt->lr, opt->beta1, opt->beta2, opt->eps, opt->max_norm, opt->norm_out_d, status_d,
-                                   opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H);
+    return clip_adam_guarded_impl(stream, opt->params_d, grad_pol_flat_d, opt->exp_avg_d, opt->exp_avg_sq_d, n, opt->step_d,
+                                  opt->lr, opt->beta1, opt->beta2, opt->eps, opt->max_norm, opt->norm_out_d, status_d,
+                                  opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H, norm_fused);
   return 0;
 }
 
@@ -2776,13 +2783,14 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
+  const int np = pm_norm_blocks(n);
   // without clipping and without a norm to report there is nothing for the norm kernel to do
   const bool need_norm = max_norm > 0.0 || norm_out_d != nullptr;
   if (need_norm)
-    hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
-                       (long long)n, (const int*)nullptr, 0, (long long*)nullptr);
+    hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(np), dim3(64), 0, (hipStream_t)stream, grads_d,
+                       (long long)n, (const int*)nullptr, 0, (long long*)nullptr, 0);
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
-                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, need_norm ? nb : 0, (float)lr, (float)beta1,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, need_norm ? np : 0, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                      (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0, 0.0, 0.0, lr);
   HIPCHK(hipGetLastError());
@@ -2795,11 +2803,21 @@ extern "C" int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* gra
                                        float* norm_out_d, const int32_t* status_d, int32_t expect) {
   if (!params_d || !grads_d || !exp_avg_d || !exp_avg_sq_d || !step_d || !status_d || n < 1)
     return fail(-1, "bad argument");
+  return clip_adam_guarded_impl(stream, params_d, grads_d, exp_avg_d, exp_avg_sq_d, n, step_d, lr, beta1, beta2, eps, max_norm,
+                                norm_out_d, status_d, expect, false);
+}
+// norm_done: the partial sums of squares and the go / no-go decision are already on the device (the fused iteration's
+// gradient reduction formed them: pm_dw_reduce, norm_on)
+static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d, float* exp_avg_d, float* exp_avg_sq_d,
+                                  int64_t n, int64_t* step_d, double lr, double beta1, double beta2, double eps,
+                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done) {
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
-  hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grads_d,
-                     (long long)n, (const int*)status_d, (int)expect, reinterpret_cast<long long*>(step_d));
+  const int np = pm_norm_blocks(n);
+  if (!norm_done)
+    hipLaunchKernelGGL(pm_gradnorm_kernel, dim3(np), dim3(64), 0, (hipStream_t)stream, grads_d,
+                       (long long)n, (const int*)status_d, (int)expect, reinterpret_cast<long long*>(step_d), 1);
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
-                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, nb, (float)lr, (float)beta1,
+                     grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, np, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f,
                      (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1, log(beta1), log(beta2), lr);
   HIPCHK(hipGetLastError());

@@ -804,12 +804,43 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_layer_kernel(const DwArgs A
   }
 }
 
+// Squared norm of the gradient for clip_grad_norm_ (algorithms/mc_pilco.py:199-200): partial sums over blocks of 256
+// consecutive elements, ONE definition for the two kernels that form them -- pm_gradnorm_kernel (its own launch) and
+// pm_dw_reduce (round 6: the fused iteration's reduction forms them on the way, one launch less) -- so that the two
+// forms of an iteration walk the same trajectory bit for bit.  Lane c of a wave holds elements 4 c .. 4 c + 3 of the
+// block: squares added in element order, then a fixed butterfly over the 64 lanes.
+#define PM_NORM_MAXB 8192      // blocks of 256 elements: gradients of up to 2 M parameters (beyond: pm_gradnorm_kernel strides)
+__device__ double g_norm_part[PM_NORM_MAXB];
+__device__ int g_adam_go;
+__device__ __forceinline__ double pm_sq4_wave(const f32x4& t, long long i0, long long n) {
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double x = i0 + r < n ? (double)t[r] : 0.0;
+    s += x * x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  return s;
+}
+// the optimiser step of a guarded iteration is taken if the rollout completed: status[0] = steps the forward sweep
+// completed, status[1] = set by the adjoint sweep when one of its exchanges timed out (the gradient is garbage then)
+__device__ __forceinline__ void pm_adam_decide(const int* status, int expect, long long* step) {
+  const int go = (!status || (status[0] >= expect && status[1] == 0)) ? 1 : 0;
+  g_adam_go = go;
+  if (go && step) step[0] += 1;
+}
+
 // grad[i] = sum_s part[s][i] in fixed order.  A workgroup = 64 float4 columns x 8 slices of the
 // split range: every wave reads whole 1 KiB rows, a thread keeps 8 independent loads in flight.
+// norm_on: also the partial sums of squares of ITS 256 elements and (block 0) the decision whether the guarded optimiser
+// step is taken -- what pm_gradnorm_kernel does in a launch of its own.
 __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
                                                     int stride, float* __restrict__ grad,
                                                     const int* __restrict__ nvalid = nullptr, int chunks_per_step = 0,
-                                                    int chunks_per_split = 1) {
+                                                    int chunks_per_split = 1, int norm_on = 0,
+                                                    const int* __restrict__ status = nullptr, int expect = 0,
+                                                    long long* __restrict__ step = nullptr) {
   __shared__ f32x4 sm[8][64];
   if (nvalid) {   // truncated horizon: only the splits that own a chunk of a valid step wrote a partial
     const long long nc = (long long)max(0, *nvalid) * chunks_per_step;
@@ -834,13 +865,23 @@ __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ pa
   }
   sm[sl][col] = s;
   __syncthreads();
-  if (sl == 0 && c4 * 4 < n) {
-    f32x4 t = sm[0][col];
+  if (sl == 0) {
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < n) {
+      t = sm[0][col];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += sm[k][col];
+      for (int k = 1; k < 8; ++k) t += sm[k][col];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (c4 * 4 + r < n) grad[c4 * 4 + r] = t[r];
+      for (int r = 0; r < 4; ++r)
+        if (c4 * 4 + r < n) grad[c4 * 4 + r] = t[r];
+    }
+    if (norm_on) {
+      const double s2 = pm_sq4_wave(t, (long long)c4 * 4, n);
+      if (col == 0) {
+        g_norm_part[blockIdx.x] = s2;
+        if (blockIdx.x == 0) pm_adam_decide(status, expect, step);
+      }
+    }
   }
 }
 #endif   // PM_MAIN_TU
