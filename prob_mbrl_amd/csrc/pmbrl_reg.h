@@ -518,10 +518,23 @@ __device__ __forceinline__ f32x4 pr_tile_value(const f32x4 (&c)[2]) {
 // two packed 16-bit piece pairs of four fp32 values (hi.x = pieces of v0, v1; hi.y = of v2, v3)
 template <bool F16>
 __device__ __forceinline__ void pr_split(f32x4 h, pm_u32x2& hi, pm_u32x2& lo) {
-  pm_u32x2 pc[2];
-  pm_split4<2, F16>(h, pc);
-  hi = pc[0];
-  lo = pc[1];
+  if constexpr (F16) {
+    // two fp16 pieces: the residuals h - hi in one v_fma_mix_f32 each (it reads the fp16 half directly; pm_split4's form is
+    // four conversions back and two packed subtractions) -- the same bits
+    const unsigned ha = pm_pk_f16(h[0], h[1]), hb = pm_pk_f16(h[2], h[3]);
+    float l0, l1, l2, l3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ha), "v"(h[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ha), "v"(h[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(hb), "v"(h[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(hb), "v"(h[3]));
+    hi = pm_u32x2{ha, hb};
+    lo = pm_u32x2{pm_pk_f16(l0, l1), pm_pk_f16(l2, l3)};
+  } else {
+    pm_u32x2 pc[2];
+    pm_split4<2, F16>(h, pc);
+    hi = pc[0];
+    lo = pc[1];
+  }
 }
 
 // ===========================================================================
@@ -538,15 +551,25 @@ __device__ __forceinline__ float pr_rcp(float d) {
 // (|u| clamped to 15: tanh is +-1 to fp32 there already, and exp(2 u) overflows at u = 44 -- the reciprocal's Newton step
 //  turns an infinity into a NaN: a policy that saturates hard, the double cart-pole shape late in the horizon, produced NaN
 //  actions here until round 5)
+// e^x for the clamped arguments of the two functions below (|x| <= 80): 2^(x log2 e) by v_exp_f32, the rounding error of the
+// product x log2 e -- up to 2^-18 absolute at |x| = 80 -- put back through e^x (1 + eps ln 2).  Six instructions; libm's expf
+// inlines to fifteen (range reduction by hand, ldexp, two range selects), four of them a step on a wave that is instruction issue
+__device__ __forceinline__ float pr_exp(float x) {
+  const float t = x * 1.44269504f;
+  const float eps = __builtin_fmaf(x, 1.92596299e-8f, __builtin_fmaf(x, 1.44269504f, -t));
+  const float p = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(p, eps * 0.693147181f, p);
+}
 // (v_med3_f32 answers min3 when an operand is a NaN: a NaN head output would leave here as tanh(-15) = -1, a finite action,
 //  and the failed step would go unreported where the reference produces NaNs -- the NaN is put back by hand)
 __device__ __forceinline__ float pr_tanh(float u) {
-  const float r = 1.f - 2.f * pr_rcp(1.f + expf(2.f * __builtin_amdgcn_fmed3f(u, -15.f, 15.f)));
+  const float r = 1.f - 2.f * pr_rcp(1.f + pr_exp(2.f * __builtin_amdgcn_fmed3f(u, -15.f, 15.f)));
   return u != u ? u : r;
 }
 // logistic function of x = ls - max_log_std through the same reciprocal: the exponent clamped for the same reason
 // (sigma(-80) = 2e-35: zero to everything downstream)
-__device__ __forceinline__ float pr_sigmoid_neg(float y) { return pr_rcp(1.f + expf(fminf(y, 80.f))); }
+// (both ways: pr_exp's error term is inf - inf at y = -inf)
+__device__ __forceinline__ float pr_sigmoid_neg(float y) { return pr_rcp(1.f + pr_exp(__builtin_amdgcn_fmed3f(y, -80.f, 80.f))); }
 
 // epilogue arithmetic of one hidden tile: h = max(v mf, 0) (mf = dropout multiplier >= 0), activity nibble, running
 // maximum (fp16 range check), piece pairs.  Branch-free by construction: nothing here turns into an exec-masked region.
@@ -556,14 +579,38 @@ __device__ __forceinline__ void pr_tile_epilogue(f32x4 v, f32x4 mf, f32x4& h, un
   const f32x4 t = v * mf;
 #pragma unroll
   for (int r = 0; r < 4; ++r) h[r] = fmaxf(t[r], 0.f);
-  ab = min(__float_as_uint(h[0]), 1u) | (min(__float_as_uint(h[1]), 1u) << 1) | (min(__float_as_uint(h[2]), 1u) << 2) |
-       (min(__float_as_uint(h[3]), 1u) << 3);
+  // (h >= +0: a unit is active iff its bit pattern is non-zero.  v_min_u32 by hand -- written as min(u, 1) the compiler makes a
+  //  v_cmp_class and a v_cndmask of each: ten instructions a tile where seven do, in a kernel that is instruction issue)
+  {
+    unsigned x0, x1, x2, x3;
+    asm("v_min_u32 %0, 1, %1" : "=v"(x0) : "v"(__float_as_uint(h[0])));
+    asm("v_min_u32 %0, 1, %1" : "=v"(x1) : "v"(__float_as_uint(h[1])));
+    asm("v_min_u32 %0, 1, %1" : "=v"(x2) : "v"(__float_as_uint(h[2])));
+    asm("v_min_u32 %0, 1, %1" : "=v"(x3) : "v"(__float_as_uint(h[3])));
+    unsigned a01, a23;
+    asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(a01) : "v"(x1), "v"(x0));
+    asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(a23) : "v"(x3), "v"(x2));
+    asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(ab) : "v"(a23), "v"(a01));
+  }
   // (h >= 0: the order of the bit patterns is the order of the values, a NaN's pattern is above every finite one's)
   amax = max(max(amax, max(__float_as_uint(h[0]), __float_as_uint(h[1]))), max(__float_as_uint(h[2]), __float_as_uint(h[3])));
-  pm_u32x2 pc[2];
-  pm_split4<2, F16>(h, pc);
-  hi = pc[0];
-  lo = pc[1];
+  if constexpr (F16) {
+    // two fp16 pieces: the residuals h - hi in one v_fma_mix_f32 each (it reads the fp16 half directly; pm_split4's form is
+    // four conversions back and two packed subtractions) -- the same bits
+    const unsigned ha = pm_pk_f16(h[0], h[1]), hb = pm_pk_f16(h[2], h[3]);
+    float l0, l1, l2, l3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ha), "v"(h[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ha), "v"(h[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(hb), "v"(h[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(hb), "v"(h[3]));
+    hi = pm_u32x2{ha, hb};
+    lo = pm_u32x2{pm_pk_f16(l0, l1), pm_pk_f16(l2, l3)};
+  } else {
+    pm_u32x2 pc[2];
+    pm_split4<2, F16>(h, pc);
+    hi = pc[0];
+    lo = pc[1];
+  }
 }
 
 // Copy of the LDS-resident sections of one network's pack (first layer, 13th tile, head), ALL loads requested before the
