@@ -123,9 +123,22 @@ struct RegArgs {
 };
 // the moment-matching arguments where the launch put them, in the kernel-argument segment (NOT &A.mm: the address of a
 // by-value kernel argument makes the compiler copy the whole struct to scratch)
-__device__ __forceinline__ const RegMM* pr_mm_args() {
+// (the pointer KEEPS the constant address space: cast to a generic pointer -- as it was until round 6 -- the per-step copy of
+//  the struct compiled to FLAT vector loads with a uniform address, waited for with vmcnt(0) lgkmcnt(0): a memory round trip
+//  and a drain of the wave's stash stores at the head of every chain.  Scalar loads from the constant cache now.)
+typedef __attribute__((address_space(4))) const RegMM* pr_mm_kptr;
+__device__ __forceinline__ pr_mm_kptr pr_mm_args() {
   typedef __attribute__((address_space(4))) const char* kcp;
-  return (const RegMM*)((kcp)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RegArgs, mm));
+  return (pr_mm_kptr)((kcp)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RegArgs, mm));
+}
+// (the host pass type-checks kernel bodies too, and knows no copy out of the constant address space)
+__device__ __forceinline__ RegMM pr_mm_load(pr_mm_kptr p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  (void)p;
+  return RegMM{};
+#endif
 }
 // Logical workgroup of this hardware workgroup (-1: none -- padding).  Workgroups go round-robin to the 8 XCDs, each with an
 // L2 of its own: dealt in blocks of 8 groups -- hardware workgroup 8 j + i of a block = part j of the block's group i --
@@ -978,14 +991,20 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
         const float sg = pr_sigmoid_neg(A.mls_dyn - ls);
         const float e = max_std_dyn * c_sy[s] * sg;
         const float xn = x[s] + (mu * c_sy[s] + c_my[s] + c_zd[s] * e);
-        if (wid == 0 && ok_x[s]) {
+        // (wave 3 stores: the moment matching's chain runs on wave 0 right behind this, and reuses the registers a store of
+        //  its own would still be reading -- the compiler waits for such a store with vmcnt(0), a write's round trip)
+        if (wid == 3 && ok_x[s]) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c_zd[s] * e * (1.f - sg)), srd, so_x[s], pr_uni(so_td), 0);
           // (moment matching: the sample the reward sees goes to its own stash; x_{t+1} is its moment-matched twin)
           if constexpr (MMD != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn), srd, so_x[s], pr_uni(so_xt), 0);
-          else *(gf32*)(b_states + so_x[s]) = xn;
         }
         x[s] = ok_x[s] ? xn : 0.f;
         xs[s] = x[s];
+        // (x_{t+1} from the register that carries it through the next step: a store of a temporary is waited for -- vmcnt(0),
+        //  a write's round trip -- as soon as the temporary's register is reused)
+        if constexpr (MMD == 0) {
+          if (wid == 3 && ok_x[s]) *(gf32*)(b_states + so_x[s]) = x[s];
+        }
       }
     }
     if constexpr (MMD != 0) {
@@ -997,9 +1016,13 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       asm volatile("" : "+v"(ln));
       // (... and the moment matching's arguments re-read from the kernel-argument segment per step: a dozen pointers and
       //  counts held in scalar registers across the loop are what the loop's own uniform offsets were spilled for)
-      const RegMM* Qp = pr_mm_args();
+      pr_mm_kptr Qp = pr_mm_args();
       asm volatile("" : "+s"(Qp));
-      const RegMM Q = *Qp;      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
+      const RegMM Q = pr_mm_load(Qp);      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
+      // (TREE -- the two-level exchange, below: the barrier that frees the heads' partial-tile buffer for the helper waves'
+      //  sums stands HERE, in front of the other waves' duties: behind them the chain's wave waited for the factor record
+      //  to be filed, 1.5 k cycles a step)
+      if constexpr (TREE) pr_barrier();
       if (wid == 1 && t + 1 < A.H) {
         // (idle otherwise) the next step's standardised noise rows
         pr_mm_fwd_prep<MMDc>(Q, t + 1, mm_gi, mm_g0, row0, nvalid, mm_me, ln, mm_zh + ((t + 1) & 1) * (16 * MMDc));
@@ -1018,7 +1041,6 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       double* const xh = reinterpret_cast<double*>(smem + PR_LDS_PART);
       volatile unsigned* const xtag = reinterpret_cast<volatile unsigned*>(smem + PR_LDS_FLAG);
       if constexpr (TREE) {
-        pr_barrier();
         if (wid != 0) {
           const bool okh = pm_xch_tree_help<PR_MM_NVX(MMDc), 4>(Q.xch, Q.nwg, mm_gi * Q.parts, Q.parts, Q.fan, mm_me, Q.tag0 + (unsigned)(t + 1), wid, xh,
                                                   xtag, ln);
@@ -1033,9 +1055,6 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
                                                (PROF && wg <= 1) ? A.prof + (size_t)t * 32 + 8 * wg : nullptr);
         if (!ok && lane == 0) atomicMin(A.status, t);
         *reinterpret_cast<f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g) = f32x2{xo[0], xo[1]};
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          if (ok_x[s]) *(gf32*)(b_states + so_x[s]) = xo[s];
       }
       pr_barrier();
       // (behind the barrier: wave 2 has read the previous step's hand-over)
@@ -1046,6 +1065,11 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
       const f32x2 xm = *reinterpret_cast<const f32x2*>(smem + PR_LDS_XB + row * 8 + 2 * g);
 #pragma unroll
       for (int s = 0; s < 2; ++s) x[s] = ok_x[s] ? xm[s] : 0.f;
+      // (the moment-matched x_{t+1} into the trajectory: by wave 3, from the registers that carry it -- stored by the chain's
+      //  wave from its temporaries, that wave sat out the store's round trip at the next reuse of the register)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (wid == 3 && ok_x[s]) *(gf32*)(b_states + so_x[s]) = x[s];
       if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 7] = (long long)__builtin_readcyclecounter();
     }
     // fp16 pieces: a value beyond the format's range was rounded to infinity somewhere in this step (or earlier)
@@ -1065,7 +1089,7 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_fwd_kernel(const RegArgs A)
     // the last step's factor record
     pr_barrier();
     if (wid == 2 && A.H > 0) {
-      const RegMM Q = *pr_mm_args();
+      const RegMM Q = pr_mm_load(pr_mm_args());
       pr_mm_fwd_file<MMDc>(Q, A.H - 1, mm_gi, mm_me, lane, mm_rec);
     }
   }
@@ -1443,9 +1467,9 @@ __global__ __launch_bounds__(PR_NTHR, 1) void pm_reg_bwd_kernel(const RegArgs A)
       const bool do_chain = t < T1 - 1 || A.gx_in;
       int ln = lane;      // (laundered per step, the arguments re-read per step: see the forward sweep)
       asm volatile("" : "+v"(ln));
-      const RegMM* Qp = pr_mm_args();
+      pr_mm_kptr Qp = pr_mm_args();
       asm volatile("" : "+s"(Qp));
-      const RegMM Q = *Qp;      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
+      const RegMM Q = pr_mm_load(Qp);      // (ONE batch of scalar loads, one wait -- through the pointer every use was a round trip of its own)
       if (PROF && wg == 0 && tid == 0) A.prof[(size_t)t * 32 + 6] = (long long)__builtin_readcyclecounter();
       if (wid == 1 && t > T0) {
         // (idle otherwise) what step t - 1's chain needs that does not wait for the recursion: its noise operand ...
