@@ -240,7 +240,14 @@ __device__ __forceinline__ bool pm_xch_get_tree(unsigned long long* xb, int nwg,
 // acknowledgement, 7 words, zero at launch (a tag is a step's k > 0).
 // ---------------------------------------------------------------------------
 #define PM_XCH_HELP_DOUBLES(NV) (3 * (NV) * 64)
-__device__ __forceinline__ bool pm_xch_lds_wait(volatile const unsigned* tag, unsigned k) {
+// (LDS pointers carry their address space: through generic pointers the tags and the sums were FLAT accesses -- counted by
+//  vmcnt AND lgkmcnt, out of order with the LDS traffic around them)
+#define PM_LDS __attribute__((address_space(3)))
+typedef PM_LDS double* pm_lds_d;
+typedef PM_LDS const double* pm_lds_cd;
+typedef PM_LDS volatile unsigned* pm_lds_vu;
+typedef PM_LDS volatile const unsigned* pm_lds_cvu;
+__device__ __forceinline__ bool pm_xch_lds_wait(pm_lds_cvu tag, unsigned k) {
   for (int spins = 0;;) {
     if (*tag == k) return true;
     if (++spins > (1 << 19)) return false;
@@ -248,8 +255,8 @@ __device__ __forceinline__ bool pm_xch_lds_wait(volatile const unsigned* tag, un
   }
 }
 template <int NV, int NB>
-__device__ __forceinline__ bool pm_xch_help_one(const unsigned long long* xb, int slot0, int n, int w, unsigned k, double* part,
-                                                volatile unsigned* tag, volatile const unsigned* ack, int lane) {
+__device__ __forceinline__ bool pm_xch_help_one(const unsigned long long* xb, int slot0, int n, int w, unsigned k, pm_lds_d part,
+                                                pm_lds_vu tag, pm_lds_cvu ack, int lane) {
   const int lo = w * NB;
   if (lo >= n) return true;
   double tot[NV];
@@ -267,20 +274,22 @@ __device__ __forceinline__ bool pm_xch_help_one(const unsigned long long* xb, in
 // helper wave w (1 .. 3) of part `me`
 template <int NV, int NB>
 __device__ __forceinline__ bool pm_xch_tree_help(const unsigned long long* xb, int nwg, int first, int parts, int fan, int me,
-                                                 unsigned k, int w, double* hp, volatile unsigned* tags, int lane) {
+                                                 unsigned k, int w, double* hp_, volatile unsigned* tags_, int lane) {
+  const pm_lds_d hp = (pm_lds_d)hp_;
+  const pm_lds_vu tags = (pm_lds_vu)tags_;
   const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
-  double* part = hp + (size_t)(w - 1) * NV * 64;
+  const pm_lds_d part = hp + (w - 1) * NV * 64;
   bool ok = true;
   const int n1 = parts - c0 < fan ? parts - c0 : fan;
   const bool wrote1 = me == c0 && w * NB < n1;
-  if (me == c0) ok = pm_xch_help_one<NV, NB>(xb, first + c0, n1, w, k, part, tags + (w - 1), nullptr, lane);
-  ok = pm_xch_help_one<NV, NB>(xb, nwg + first, nc, w, k, part, tags + 3 + (w - 1), wrote1 ? tags + 6 : nullptr, lane) && ok;
+  if (me == c0) ok = pm_xch_help_one<NV, NB>(xb, first + c0, n1, w, k, part, tags + (w - 1), (pm_lds_cvu)nullptr, lane);
+  ok = pm_xch_help_one<NV, NB>(xb, nwg + first, nc, w, k, part, tags + 3 + (w - 1), wrote1 ? (pm_lds_cvu)(tags + 6) : (pm_lds_cvu)nullptr, lane) && ok;
   return ok;
 }
 // the chain's wave: tot <- (slots 0 .. NB - 1) + the helpers' partial sums, in wave order
 template <int NV, int NB>
 __device__ __forceinline__ bool pm_xch_sum_helped(const unsigned long long* xb, int slot0, int n, unsigned k, double (&tot)[NV],
-                                                  const double* hp, volatile const unsigned* tags, int lane) {
+                                                  pm_lds_cd hp, pm_lds_cvu tags, int lane) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) tot[i] = 0.0;
   const bool ok = pm_xch_add_slots<NV, NB, true>(xb, slot0, n < NB ? n : NB, k, tot, lane);
@@ -289,15 +298,17 @@ __device__ __forceinline__ bool pm_xch_sum_helped(const unsigned long long* xb, 
     if (!pm_xch_lds_wait(tags + (w - 1), k)) return false;
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < NV; ++i) tot[i] += hp[(size_t)(w - 1) * NV * 64 + i * 64 + lane];
+    for (int i = 0; i < NV; ++i) tot[i] += hp[(w - 1) * NV * 64 + i * 64 + lane];
   }
   return ok;
 }
 // v <- the sum over all parts (this part's own contribution already published by pm_xch_put)
 template <int NV, int NB>
 __device__ __forceinline__ bool pm_xch_get_tree_helped(unsigned long long* xb, int nwg, int first, int parts, int fan, int me,
-                                                       unsigned k, double (&v)[NV], const double* hp, volatile unsigned* tags,
+                                                       unsigned k, double (&v)[NV], const double* hp_, volatile unsigned* tags_,
                                                        int lane) {
+  const pm_lds_cd hp = (pm_lds_cd)hp_;
+  const pm_lds_vu tags = (pm_lds_vu)tags_;
   const int c = me / fan, c0 = c * fan, nc = (parts + fan - 1) / fan;
   bool ok = true;
   if (me == c0) {
