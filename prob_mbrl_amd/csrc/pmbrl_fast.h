@@ -958,7 +958,14 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   __syncthreads();
   if (i < n) {
   const int t = (int)(i / A.B);
-  const RewardDev* __restrict__ rw = A.rew;
+  // (the reward's constants through a constant-address-space pointer: wave-uniform indices make scalar loads of them; as a
+  //  generic pointer every coefficient was a vector load from global memory per thread -- a hundred of them a row-step)
+  typedef __attribute__((address_space(4))) const RewardDev* rew_kptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const rew_kptr rw = (rew_kptr)A.rew;
+#else
+  const RewardDev* rw = A.rew;
+#endif
   float* xs = rw_rows + threadIdx.x * ld;
   const float* as = A.actions + (size_t)i * U;
   // No per-thread array is indexed at run time (that would live in scratch): the feature map is
