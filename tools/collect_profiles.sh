@@ -27,6 +27,7 @@ timeout 300 python $R/tools/bench_bnn.py > $O/bench_bnn.json 2>/dev/null
 timeout 300 python $R/tools/mcp_speed.py > $O/mcp_speed.txt 2>/dev/null
 timeout 300 python $R/tools/mcp_example_shape.py > $O/mcp_example_shape.txt 2>/dev/null
 timeout 300 python $R/tools/bench_single_group.py > $O/single_group.txt 2>/dev/null
+timeout 120 python $R/tools/phase_prof.py cartpole_mm 0 100 25 0 > $O/phase_prof_cartpole_mm_g1.txt 2>/dev/null
 # 5. kernel stats of the other configurations (one rocprofv3 pass each, no counters)
 for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$c -- \
