@@ -388,7 +388,8 @@ def collect_pmc(a, prec):
     # dispatch the counters see, never a node of a replayed hipGraph
     iters = warm + steps * reps + tsteps
     inner = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', str(steps), '--warmup', str(warm),
-             '--repeats', str(reps), '--replay', '0', '--no-sclk', '--no-cpu-baseline', '--no-f32-twin', '--timing-steps', str(tsteps)]
+             '--repeats', str(reps), '--replay', '0', '--no-sclk', '--no-cpu-baseline', '--no-f32-twin', '--no-other-configs',
+             '--timing-steps', str(tsteps)]
     if a.precision:
         inner += ['--precision', a.precision]
     if a.rows_per_wg:

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 1500 python $R/bench.py --pmc > $O/bench_cartpole_nomm.json 2>$O/bench.err
 # 2. kernel trace + stats of the same command (shorter run, no CPU leg)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- \
-  python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-twin > $O/bench_under_rocprof.json 2>$O/kt.err
+  python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-twin --no-other-configs > $O/bench_under_rocprof.json 2>$O/kt.err
 # 3. the other configurations, each with its counters
 for c in cartpole_mm dcartpole_mm stress32 stress32_mm; do
   timeout 900 python $R/bench.py --pmc --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-f32-twin > $O/bench_$c.json 2>$O/bench_$c.err
