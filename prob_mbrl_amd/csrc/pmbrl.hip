@@ -1139,12 +1139,51 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
           for (int m0 = 0; m0 < p->pol.nt[l + 1] * 16; m0 += PM_DWW_TM)
             for (int n0 = 0; n0 < p->pol.nt[l] * 16; n0 += PM_DWW_TN) units.push_back(DwUnit{(int16_t)l, (int16_t)m0, (int16_t)n0, 0});
         }
+    // Round 6: the wide sweeps (64-row workgroups, in-place 512-wide layers: pmbrl_wide.h) write the stashes of the 512 x 512
+    // layers PRE-SPLIT, in the layout pm_dw_wide_pre_kernel streams into LDS without touching a register (pmbrl_dw.h).
+    // Every wide layer 512 x 512 exactly (32 tiles: the stash block's tile count); PMBRL_DW_PRE=0: the fp32 stash.
+    p->dw_pre_mask = 0;
+    if (!units.empty() && p->inplace == 2 && p->RT == 4 && !(getenv("PMBRL_DW_PRE") && atoi(getenv("PMBRL_DW_PRE")) == 0)) {
+      bool all = true;
+      for (const DwUnit& u : units) all = all && p->pol.nt[u.layer] == 32 && p->pol.nt[u.layer + 1] == 32 &&
+                                          p->pol.dim[u.layer] == 512 && p->pol.dim[u.layer + 1] == 512;
+      // ... and every OTHER layer narrow on one side, 512 wide on the other (first layer: <= 32 inputs; head: <= 32 outputs):
+      // pm_dw_narrow_pre_kernel -- so that EVERY 512-wide stash is pre-split and the sweeps carry one form of stash store
+      for (int l = 0; l < p->pol.nl && all; ++l) {
+        bool is = false;
+        for (const DwUnit& u : units) is = is || u.layer == l;
+        p->dw_narrow[l] = 0;
+        if (is) continue;
+        if (p->pol.nt[l + 1] == 32 && p->pol.dim[l + 1] == 512 && p->pol.nt[l] <= 2) p->dw_narrow[l] = 1;
+        else if (p->pol.nt[l] == 32 && p->pol.dim[l] == 512 && p->pol.nt[l + 1] <= 2) p->dw_narrow[l] = 2;
+        else all = false;
+      }
+      if (all) {
+        std::vector<DwUnit> pre;
+        for (int l = 0; l < p->pol.nl; ++l) {
+          if (p->dw_narrow[l]) { wide[l] = true; continue; }      // (not the block kernels': skipped by build_dw_blocks)
+          p->dw_pre_mask |= 1u << l;
+          for (int m0 = 0; m0 < 512; m0 += PM_DWP_TM)
+            for (int n0 = 0; n0 < 512; n0 += PM_DWP_TN) pre.push_back(DwUnit{(int16_t)l, (int16_t)m0, (int16_t)n0, 0});
+        }
+        units = pre;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_narrow_pre_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWP_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_narrow_pre_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWP_LDS_BYTES));
+      } else {
+        for (int l = 0; l < PM_MAXL; ++l) p->dw_narrow[l] = 0;
+      }
+    }
     p->n_dw_units = (int)units.size();
     if (p->n_dw_units) {
       HIPCHK(hipMalloc(&p->dw_units_d, units.size() * sizeof(DwUnit)));
       HIPCHK(hipMemcpy(p->dw_units_d, units.data(), units.size() * sizeof(DwUnit), hipMemcpyHostToDevice));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_wide_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWW_LDS_BYTES));
+      if (p->dw_pre_mask)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_dw_wide_pre_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, PM_DWP_LDS_BYTES));
     }
     p->n_dw_blocks = build_dw_blocks(p->pol.nl, p->pol.nt, blocks, p->dw_wave_first, p->dw_split ? PM_DW_TN_S : PM_DW_TN, wide);
     p->dw_n_chunks = c.H * p->nwg * p->RT;
@@ -1168,6 +1207,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // with workgroups that cannot share a CU with the sweep's.  Only the last, short range is exposed.
     // Correctness never depends on the overlap: every dependency is a stream event.
     p->pipe_K = 1;
+    const bool no_pipe_pre = p->dw_pre_mask != 0;      // (the pre-split GEMMs run once, behind the whole sweep)
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
     const char* e = getenv("PMBRL_DW_PIPE");
@@ -1179,7 +1219,7 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
     // (6 / 13 us per step) lose 1-5 %.  Proxy for the step time: rows per workgroup x weights of both nets.
     const bool explicit_ranges = e && e[0] >= '0' && e[0] <= '9';
     const bool long_steps = (long long)p->RT * (long long)(p->pol.n_params + p->dyn.n_params) >= 256 * 1024 && c.H >= 16;
-    if (single && n_free >= cus / 8 && c.H >= 2 && !(e && !strcmp(e, "off")) && (long_steps || explicit_ranges)) {
+    if (single && !no_pipe_pre && n_free >= cus / 8 && c.H >= 2 && !(e && !strcmp(e, "off")) && (long_steps || explicit_ranges)) {
       std::vector<int> cnt;
       if (explicit_ranges) {     // PMBRL_DW_PIPE=n0,n1,...: steps per range, highest steps first (tests, tuning)
         int sum = 0;
@@ -1585,6 +1625,7 @@ static int fill_args(const pmbrl_plan* p, void* workspace, const pmbrl_inputs* i
   A.G = p->G; A.M = p->M; A.mm_mode = p->mm_mode;
   A.t0 = 0; A.t1 = c.H;
   A.rows_per_wg = p->rows_per_wg; A.nwg = p->nwg; A.Rw = 16 * p->RT; A.LD = p->LD; A.LDB = p->LDB;
+  A.stash_pre = p->dw_pre_mask;
   A.mls_pol = c.max_log_std_pol; A.mls_dyn = c.max_log_std_dyn;
   for (int l = 0; l < p->pol.nl - 1; ++l)
     if (!in->pol_mask_bits_d[l]) return fail(-1, "missing policy mask bits");
@@ -2040,7 +2081,10 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
     if (p->dw_split) Wk.chunks_per_split = (Wk.chunks_per_split + 1) & ~1;
     if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
     else hipLaunchKernelGGL(pm_dw_kernel, dim3(Wk.nsplit), dim3(PM_DW_NT), 0, st, Wk);
-    if (p->n_dw_units)
+    if (p->n_dw_units && p->dw_pre_mask)
+      hipLaunchKernelGGL(pm_dw_wide_pre_kernel, dim3((Wk.nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DWP_NT), PM_DWP_LDS_BYTES, st, Wk,
+                         p->dw_units_d, p->n_dw_units);
+    else if (p->n_dw_units)
       hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((Wk.nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, st, Wk,
                          p->dw_units_d, p->n_dw_units);
     if (p->dw_layer13 >= 0)
@@ -2138,9 +2182,20 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       launch_dw(p->pipe_K - 1, s);
     }
     else {
-      if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
+      if (p->n_dw_blocks == 0) {}      // (every layer has a GEMM kernel of its own: below)
+      else if (p->dw_split) hipLaunchKernelGGL(pm_dw_kernel_s, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
       else hipLaunchKernelGGL(pm_dw_kernel, dim3(p->dw_nsplit), dim3(PM_DW_NT), 0, s, W);
-      if (p->n_dw_units)
+      if (p->dw_pre_mask)
+        for (int l = 0; l < p->pol.nl; ++l) {
+          if (!p->dw_narrow[l]) continue;
+          const int g_wide = p->dw_narrow[l] == 1 ? 1 : 0, nt_n = g_wide ? p->pol.nt[l] : p->pol.nt[l + 1];
+          if (nt_n <= 1) hipLaunchKernelGGL(pm_dw_narrow_pre_kernel<1>, dim3(p->dw_nsplit), dim3(PM_DWP_NT), PM_DWP_LDS_BYTES, s, W, l, g_wide);
+          else hipLaunchKernelGGL(pm_dw_narrow_pre_kernel<2>, dim3(p->dw_nsplit), dim3(PM_DWP_NT), PM_DWP_LDS_BYTES, s, W, l, g_wide);
+        }
+      if (p->n_dw_units && p->dw_pre_mask)
+        hipLaunchKernelGGL(pm_dw_wide_pre_kernel, dim3((p->dw_nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DWP_NT), PM_DWP_LDS_BYTES, s, W,
+                           p->dw_units_d, p->n_dw_units);
+      else if (p->n_dw_units)
         hipLaunchKernelGGL(pm_dw_wide_kernel, dim3((p->dw_nsplit + 7) / 8 * 8 * p->n_dw_units), dim3(PM_DW_NT), PM_DWW_LDS_BYTES, s, W,
                            p->dw_units_d, p->n_dw_units);
       if (p->dw_layer13 >= 0)

@@ -133,6 +133,7 @@ struct RolloutArgs {
   float *states, *actions, *rewards;
   float* actT[PM_MAXL];   // policy layer inputs, feature-major blocks [H][nwg][nt*16][Rw]
   float* gT[PM_MAXL];     // policy pre-activation grads, same layout
+  unsigned stash_pre;     // bit l: layer l's dW GEMM reads PRE-SPLIT stashes (actT[l], gT[l]: pmbrl_dw.h, pm_dw_wide_pre_kernel)
   float *Tp, *Td;         // [H][B][U], [H][B][D]
   float *xt, *rt;         // pre-moment-matching next state / reward [H][B][D], [H][B]
   double* mmfac;          // in-kernel moment matching: statistics + factor per (step, group), forward -> adjoint

@@ -26,6 +26,14 @@
 #include "pmbrl_dev.h"
 #include "pmbrl_split.h"
 
+#include <utility>
+#include <type_traits>
+template <class F, int... I>
+__device__ __forceinline__ void pr_for_dw_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void pr_for_dw(F&& f) { pr_for_dw_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+typedef unsigned pr_u32x4_dw __attribute__((ext_vector_type(4)));
+typedef unsigned long long pr_u64x2_dw __attribute__((ext_vector_type(2)));
 #define PM_DW_NW 8
 #define PM_DW_NT (PM_DW_NW * 64)
 #define PM_DW_TM 4
@@ -629,6 +637,363 @@ __global__ __launch_bounds__(PM_DW_NT, 4) void pm_dw_wide_kernel(const DwArgs A,
       const int idx = tid + PM_DW_NT * j, o = U.m0 + (idx >> 3);
       if ((idx & 7) == 0 && o < O) pm_dw_put(part + A.b_off[l] + o, v, R.add);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Wide layers from a PRE-SPLIT stash (round 6; the wide sweeps of pmbrl_wide.h write it: pw_stash_pre).  The kernel above
+// fetches fp32 tiles into registers, splits them into two bf16 pieces and stages them through LDS: per K = 32 step and
+// thread ~80 vector instructions beside 24 MFMAs, one register set (no fetch in flight while it converts), MfmaUtil 46 %.
+// The split is what the sweeps' epilogues have in registers anyway (the adjoint's bit for bit: its LDS planes ARE these
+// pieces).  Stash block of one (step, workgroup), 128 KB as before:
+//     [piece (hi, lo)][tile of 16 features (32)][row (64)][16 features] bf16
+// -- row-major inside a tile: an epilogue lane holds four consecutive features of a row (ONE 8-byte store per piece
+// instead of four 4-byte ones), and a [32 rows][16 features] sub-tile -- what one K = 32 step needs of a tile -- is 1 KB
+// CONTIGUOUS in HBM: one global_load_lds_dwordx4 per sub-tile and wave, no register, no conversion, no ds_write.  The
+// MFMA operands (8 consecutive rows of one feature per lane) come out of the row-major image by ds_read_b64_tr_b16
+// (lane t of a 16-lane group addresses row t >> 2, 8-byte chunk t & 3 of a [4 rows][16] block and receives column t:
+// tools/ubench/tr_probe.hip); a sub-tile's rows are 32 bytes apart: the conflict-free image of the transposing read.
+// A workgroup = 8 waves (2 x 4), ONE per CU, a 256 x 256 output tile of one layer over its row-step range: 64 KB of
+// operand pieces per K = 32 step for 3 k cycles of MFMAs per SIMD -- 21 B/clk, inside the ~30 B/clk a CU pulls from L2
+// (the first build, 256 x 128 tiles on 16 waves, needed 31 B/clk: 3.1 ms with its MFMAs compiled out, 4.3 with them).
+// Two LDS stages of 64 KB: the transfers of step i + 1 run while the matrix core works on step i; one raw barrier per step.
+// A wave keeps 8 x 4 accumulator tiles, the four B sub-tiles' operands for the whole step and the A operands of one
+// sub-tile a read ahead.  Bias gradients by two extra MFMAs per A sub-tile against a column of ones (waves of the first
+// column of wave tiles, units of the first input tile).
+#define PM_DWP_TM 256
+#define PM_DWP_TN 256
+#define PM_DWP_NW 8
+#define PM_DWP_NT (PM_DWP_NW * 64)
+#define PM_DWP_STAGE (64 * 1024)                 // bytes: A 2 pieces x 16 sub-tiles + B 2 pieces x 16 sub-tiles, 1 KB each
+#define PM_DWP_LDS_BYTES (2 * PM_DWP_STAGE)
+#define PM_DWP_BLOCK 131072u                     // bytes of a stash block: 2 pieces x 32 tiles x 64 rows x 16 x 2
+__global__ __launch_bounds__(PM_DWP_NT, 1) void pm_dw_wide_pre_kernel(const DwArgs A, const DwUnit* __restrict__ units,
+                                                                      int n_units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short dww_lds[];
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;       // (the tiles of a row-step range on ONE XCD: see pm_dw_wide_kernel)
+  const int row = (jx / n_units) * 8 + xcd, unit = jx % n_units;
+  if (row >= A.nsplit) return;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  const DwUnit U = units[unit];
+  const int l = U.layer;
+  const int O = A.dim[l + 1], K = A.dim[l];
+  float* part = A.part + (size_t)row * A.part_stride;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int wm = wid & 1, wn = wid >> 1;      // 128 output features (8 tiles) x 64 input features (4 tiles) per wave
+  if (R.zero) {
+    for (int e = tid; e < PM_DWP_TM * PM_DWP_TN; e += PM_DWP_NT) {
+      const int o = U.m0 + e / PM_DWP_TN, k = U.n0 + e % PM_DWP_TN;
+      if (o < O && k < K) part[A.w_off[l] + (size_t)o * K + k] = 0.f;
+    }
+    if (U.n0 == 0)
+      for (int e = tid; e < PM_DWP_TM; e += PM_DWP_NT)
+        if (U.m0 + e < O) part[A.b_off[l] + U.m0 + e] = 0.f;
+    return;
+  }
+  // (uniform bases of the two stashes at this unit's first tile; a step = chunks c, c + 1 = rows 32 hh .. 32 hh + 31 of block c >> 2)
+  const char* gb = reinterpret_cast<const char*>(A.gT[l]) + (size_t)(U.m0 >> 4) * 2048;
+  const char* ab = reinterpret_cast<const char*>(A.actT[l]) + (size_t)(U.n0 >> 4) * 2048;
+  const unsigned lds0 = (unsigned)(unsigned long long)(const void*)dww_lds;
+  // A step's 64 KB reach LDS over BOTH paths a CU has: the A operand's 32 sub-tile slots (piece x 16) by LDS-DMA, four
+  // instructions a wave; the B operand's 32 through registers -- four 16-byte chunks a thread, loaded a step ahead, written
+  // (ds_write_b128, the same lane-linear image) behind the step's barrier.  (All 64 slots by DMA: the kernel ran at the
+  // DMA's rate, ~16 B/clk/CU -- 4.0 ms, 2.9 ms with its MFMAs compiled out; touching the lines a few steps ahead changed
+  // nothing: it is a rate, not a latency.)
+  auto dma = [&](int c, int st) {
+    const size_t boff = (size_t)(c >> 2) * PM_DWP_BLOCK + (size_t)((c >> 1) & 1) * 1024 + (size_t)lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = wid + 8 * j;                    // slot: piece idx >> 4, sub-tile idx & 15
+      const char* src = gb + (size_t)(j >> 1) * 65536 + (size_t)(idx & 15) * 2048;
+      const unsigned dst = (unsigned)st * PM_DWP_STAGE + (unsigned)idx * 1024u;
+#ifndef PM_EXP_DWP_NODMA
+      __builtin_amdgcn_global_load_lds((glb_vp)(src + boff), (lds_vp)(reinterpret_cast<char*>(dww_lds) + dst), 16, 0, 0);
+#endif
+    }
+  };
+  f32x4 breg[4];
+  auto bload = [&](int c) {
+    const size_t boff = (size_t)(c >> 2) * PM_DWP_BLOCK + (size_t)((c >> 1) & 1) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + PM_DWP_NT * j, slot = q >> 6;      // chunk q of the B region: slot q >> 6 (piece slot >> 4), 16 bytes (q & 63)
+      breg[j] = *reinterpret_cast<const f32x4*>(ab + (size_t)(slot >> 4) * 65536 + (size_t)(slot & 15) * 2048 + boff + (size_t)(q & 63) * 16);
+    }
+  };
+  auto bwrite = [&](int st) {
+    char* dst = reinterpret_cast<char*>(dww_lds) + (size_t)st * PM_DWP_STAGE + 32768;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (size_t)(tid + PM_DWP_NT * j) * 16) = breg[j];
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool bias = U.n0 == 0 && wn == 0;
+  const f32x4 ones = __builtin_bit_cast(f32x4, (pr_u32x4_dw){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+  // transposing reads: lane (t, kq) addresses row 8 kq + (t >> 2) (+ 4: the second read), 8-byte chunk t & 3 of a sub-tile
+  const unsigned la = lds0 + (unsigned)((8 * g + (c16 >> 2)) * 32 + (c16 & 3) * 8);
+  auto tr2 = [&](f32x4& d, unsigned addr, auto offc) {
+    constexpr int off = decltype(offc)::value;
+    unsigned long long r0, r1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r0) : "v"(addr), "n"(off));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r1) : "v"(addr), "n"(off + 128));
+    d = __builtin_bit_cast(f32x4, (pr_u64x2_dw){r0, r1});
+  };
+  const int n_steps = (R.c_hi - R.c_lo + 1) >> 1;
+  dma(R.c_lo, 0);
+  bload(R.c_lo);
+  bwrite(0);
+  if (n_steps > 1) bload(R.c_lo + 2);
+  int st = 0;
+  for (int i = 0; i < n_steps; ++i) {
+    // this wave's transfers and loads for step i (+ 1) have landed, then everybody's -- and everybody is done with step
+    // i - 1, whose stage takes step i + 1 while the matrix core works on step i
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 1 < n_steps) {
+      bwrite(st ^ 1);
+      dma(R.c_lo + 2 * (i + 1), st ^ 1);
+    }
+    if (i + 2 < n_steps) bload(R.c_lo + 2 * (i + 2));
+    const unsigned sa = la + (unsigned)st * PM_DWP_STAGE + (unsigned)wm * 8192u;             // A: sub-tiles 8 wm .. 8 wm + 7
+    const unsigned sb = la + (unsigned)st * PM_DWP_STAGE + 32768u + (unsigned)wn * 4096u;    // B: sub-tiles 4 wn .. 4 wn + 3
+    f32x4 bh[4], bl[4], ah[2], al[2];
+    tr2(bh[0], sb, std::integral_constant<int, 0>{});      tr2(bl[0], sb, std::integral_constant<int, 16384>{});
+    tr2(bh[1], sb, std::integral_constant<int, 1024>{});   tr2(bl[1], sb, std::integral_constant<int, 16384 + 1024>{});
+    tr2(bh[2], sb, std::integral_constant<int, 2048>{});   tr2(bl[2], sb, std::integral_constant<int, 16384 + 2048>{});
+    tr2(bh[3], sb, std::integral_constant<int, 3072>{});   tr2(bl[3], sb, std::integral_constant<int, 16384 + 3072>{});
+    tr2(ah[0], sa, std::integral_constant<int, 0>{});      tr2(al[0], sa, std::integral_constant<int, 16384>{});
+    pr_for_dw<8>([&](auto ic) {
+      constexpr int i2 = decltype(ic)::value;
+      constexpr int cur = i2 & 1, nxt = cur ^ 1;
+      if constexpr (i2 < 7) {
+        tr2(ah[nxt], sa, std::integral_constant<int, (i2 + 1) * 1024>{});
+        tr2(al[nxt], sa, std::integral_constant<int, 16384 + (i2 + 1) * 1024>{});
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[cur]), "+v"(al[cur]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]),
+                     "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
+      }
+#ifdef PM_EXP_DWP_NOMFMA
+      acc[i2][0] += ah[cur] + al[cur] + bh[0] + bl[0] + bh[1] + bl[1] + bh[2] + bl[2] + bh[3] + bl[3];
+#else
+      // per accumulator the smallest contributions first: lo x hi, hi x lo, hi x hi (pm_dw_wide_kernel's order)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i2][j] = pm_mfma_bf<false>(al[cur], bh[j], acc[i2][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i2][j] = pm_mfma_bf<false>(ah[cur], bl[j], acc[i2][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i2][j] = pm_mfma_bf<false>(ah[cur], bh[j], acc[i2][j]);
+      if (bias) {
+        accb[i2] = pm_mfma_bf<false>(al[cur], ones, accb[i2]);
+        accb[i2] = pm_mfma_bf<false>(ah[cur], ones, accb[i2]);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    st ^= 1;
+  }
+  // partial tile: lane holds dW[o = m0 + 128 wm + 16 i + 4 g + r][k = n0 + 64 wn + 16 j + c16]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = U.n0 + wn * 64 + j * 16 + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = U.m0 + wm * 128 + i * 16 + 4 * g + r;
+        if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], R.add);
+      }
+    }
+  if (bias && c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = U.m0 + wm * 128 + i * 16 + 4 * g + r;
+        if (o < O) pm_dw_put(part + A.b_off[l] + o, accb[i][r], R.add);
+      }
+  }
+}
+
+// The two NARROW layers beside the 512 x 512 ones -- the first layer (512 x <= 32: its delta stash is 512 wide) and the head
+// (<= 16 x 512: its input stash is) -- from the same pre-split stashes: with every 512-wide stash of the wide sweeps in ONE
+// form the sweeps carry one form of the stash stores (two forms in one kernel cost the forward sweep 0.5 ms).  C = Wide^T
+// Narrow over the row-steps: the wide operand (all 32 tiles x 2 pieces = 64 KB per K = 32 step: the high pieces by LDS-DMA,
+// the low ones through registers) is the MFMA's A operand, wave w its tiles 4 w .. 4 w + 3; the narrow one (fp32 feature-major
+// rows, as every family writes it) is read straight into B operand registers and split there.  wide_is_g: C = dW (first
+// layer), bias sums from the wide operand; else C = dW^T (head), bias sums from the narrow one.  Bound by the stash read.
+template <int NT>
+__global__ __launch_bounds__(PM_DWP_NT, 1) void pm_dw_narrow_pre_kernel(const DwArgs A, int l, int wide_is_g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short dww_lds[];
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  DwRange R;
+  if (!pm_dw_range(A, row, R)) return;
+  const int O = A.dim[l + 1], K = A.dim[l];
+  float* part = A.part + (size_t)row * A.part_stride;
+  const int g = lane >> 4, c16 = lane & 15;
+  if (R.zero) {
+    for (int e = tid; e < O * K; e += PM_DWP_NT) part[A.w_off[l] + e] = 0.f;
+    for (int e = tid; e < O; e += PM_DWP_NT) part[A.b_off[l] + e] = 0.f;
+    return;
+  }
+  const char* wb = reinterpret_cast<const char*>(wide_is_g ? A.gT[l] : A.actT[l]);
+  const float* nb = wide_is_g ? A.actT[l] : A.gT[l];
+  const int NF16 = (wide_is_g ? A.nt[l] : A.nt[l + 1]) * 16;      // the narrow stash's feature rows per block
+  const unsigned lds0 = (unsigned)(unsigned long long)(const void*)dww_lds;
+  auto dma = [&](int c, int st) {      // high pieces: slots 0 .. 31, four a wave
+    const size_t boff = (size_t)(c >> 2) * PM_DWP_BLOCK + (size_t)((c >> 1) & 1) * 1024 + (size_t)lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = wid + 8 * j;
+      __builtin_amdgcn_global_load_lds((glb_vp)(wb + (size_t)idx * 2048 + boff),
+                                       (lds_vp)(reinterpret_cast<char*>(dww_lds) + (unsigned)st * PM_DWP_STAGE + (unsigned)idx * 1024u), 16, 0, 0);
+    }
+  };
+  f32x4 breg[4];
+  auto bload = [&](int c) {            // low pieces: slots 32 .. 63, four 16-byte chunks a thread
+    const size_t boff = (size_t)(c >> 2) * PM_DWP_BLOCK + (size_t)((c >> 1) & 1) * 1024 + 65536;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + PM_DWP_NT * j;
+      breg[j] = *reinterpret_cast<const f32x4*>(wb + (size_t)(q >> 6) * 2048 + boff + (size_t)(q & 63) * 16);
+    }
+  };
+  auto bwrite = [&](int st) {
+    char* dst = reinterpret_cast<char*>(dww_lds) + (size_t)st * PM_DWP_STAGE + 32768;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (size_t)(tid + PM_DWP_NT * j) * 16) = breg[j];
+  };
+  // the narrow operand of step c: lane (n, kq) holds rows 8 kq .. 8 kq + 7 of feature 16 nt + n -- 32 contiguous bytes of the
+  // feature-major block
+  f32x4 nraw[NT][2];
+  auto nload = [&](int c) {
+    const float* blk = nb + (size_t)(c >> 2) * NF16 * A.Rw + ((c >> 1) & 1) * 32 + 8 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float* q = blk + (size_t)(16 * nt + c16) * A.Rw;
+      nraw[nt][0] = *reinterpret_cast<const f32x4*>(q);
+      nraw[nt][1] = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+  };
+  f32x4 acc[4][NT], accb[4], accn[NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) accn[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 ones = __builtin_bit_cast(f32x4, (pr_u32x4_dw){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+  const unsigned la = lds0 + (unsigned)((8 * g + (c16 >> 2)) * 32 + (c16 & 3) * 8);
+  auto tr2 = [&](f32x4& d, unsigned addr, auto offc) {
+    constexpr int off = decltype(offc)::value;
+    unsigned long long r0, r1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r0) : "v"(addr), "n"(off));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r1) : "v"(addr), "n"(off + 128));
+    d = __builtin_bit_cast(f32x4, (pr_u64x2_dw){r0, r1});
+  };
+  const int n_steps = (R.c_hi - R.c_lo + 1) >> 1;
+  dma(R.c_lo, 0);
+  bload(R.c_lo);
+  bwrite(0);
+  if (n_steps > 1) bload(R.c_lo + 2);
+  nload(R.c_lo);
+  int st = 0;
+  for (int i = 0; i < n_steps; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]) : : "memory");
+    // (this step's narrow operand: split into two bf16 pieces here -- a few hundred values a wave)
+    f32x4 nh[NT], nl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      pm_u32x2 p0[2], p1[2];
+      pm_split4<2, false>(nraw[nt][0], p0);
+      pm_split4<2, false>(nraw[nt][1], p1);
+      nh[nt] = __builtin_bit_cast(f32x4, (pr_u32x4_dw){p0[0][0], p0[0][1], p1[0][0], p1[0][1]});
+      nl[nt] = __builtin_bit_cast(f32x4, (pr_u32x4_dw){p0[1][0], p0[1][1], p1[1][0], p1[1][1]});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 1 < n_steps) {
+      bwrite(st ^ 1);
+      dma(R.c_lo + 2 * (i + 1), st ^ 1);
+      nload(R.c_lo + 2 * (i + 1));
+    }
+    if (i + 2 < n_steps) bload(R.c_lo + 2 * (i + 2));
+    const unsigned sa = la + (unsigned)st * PM_DWP_STAGE + (unsigned)wid * 4096u;      // sub-tiles 4 wid .. 4 wid + 3, high pieces
+    f32x4 ah[4], al[4];
+    tr2(ah[0], sa, std::integral_constant<int, 0>{});      tr2(al[0], sa, std::integral_constant<int, 32768>{});
+    tr2(ah[1], sa, std::integral_constant<int, 1024>{});   tr2(al[1], sa, std::integral_constant<int, 32768 + 1024>{});
+    tr2(ah[2], sa, std::integral_constant<int, 2048>{});   tr2(al[2], sa, std::integral_constant<int, 32768 + 2048>{});
+    tr2(ah[3], sa, std::integral_constant<int, 3072>{});   tr2(al[3], sa, std::integral_constant<int, 32768 + 3072>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) acc[i2][j] = pm_mfma_bf<false>(al[i2], nh[j], acc[i2][j]);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) acc[i2][j] = pm_mfma_bf<false>(ah[i2], nl[j], acc[i2][j]);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) acc[i2][j] = pm_mfma_bf<false>(ah[i2], nh[j], acc[i2][j]);
+    }
+    if (wide_is_g) {
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) accb[i2] = pm_mfma_bf<false>(al[i2], ones, accb[i2]);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) accb[i2] = pm_mfma_bf<false>(ah[i2], ones, accb[i2]);
+    } else if (wid == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        accn[j] = pm_mfma_bf<false>(ones, nl[j], accn[j]);
+        accn[j] = pm_mfma_bf<false>(ones, nh[j], accn[j]);
+      }
+    }
+    st ^= 1;
+  }
+  // lane holds C[m = 64 wid + 16 i + 4 g + r][n = 16 j + c16]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = 16 * j + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 64 * wid + 16 * i + 4 * g + r;
+        if (wide_is_g) {
+          if (m < O && n < K) pm_dw_put(part + A.w_off[l] + (size_t)m * K + n, acc[i][j][r], R.add);
+        } else {
+          if (n < O && m < K) pm_dw_put(part + A.w_off[l] + (size_t)n * K + m, acc[i][j][r], R.add);
+        }
+      }
+    }
+  if (wide_is_g) {
+    if (c16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 64 * wid + 16 * i + 4 * g + r;
+          if (m < O) pm_dw_put(part + A.b_off[l] + m, accb[i][r], R.add);
+        }
+    }
+  } else if (wid == 0 && g == 0) {      // (every row of the ones product is the column sum: row 0 = lane group 0, register 0)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      if (16 * j + c16 < O) pm_dw_put(part + A.b_off[l] + 16 * j + c16, accn[j][0], R.add);
   }
 }
 

@@ -18,6 +18,11 @@ int pm_general_split_set_attr(const pmbrl_plan* p) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    // (<4, 2, 3>: the wide layers with every 512-wide stash pre-split for the dW GEMM -- pmbrl_dw.h, pm_dw_wide_pre_kernel)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_fwd<4, 2, 3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pm_rollout_bwd<4, 2, 3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     return 0;
   }
   if (p->inplace) {
@@ -39,6 +44,11 @@ static void launch_gs(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, 
   else hipLaunchKernelGGL((pm_rollout_bwd<RT, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
 }
 void pm_general_split_launch(const pmbrl_plan* p, const RolloutArgs& A, hipStream_t s, bool fwd) {
+  if (p->inplace == 2 && p->dw_pre_mask) {
+    if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, 3>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, 3>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
+    return;
+  }
   if (p->inplace == 2) {
     if (fwd) hipLaunchKernelGGL((pm_rollout_fwd<4, 2, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);
     else hipLaunchKernelGGL((pm_rollout_bwd<4, 2, 2>), dim3(p->nwg), dim3(PM_NT), p->lds_bytes, s, A);

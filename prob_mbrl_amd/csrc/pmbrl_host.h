@@ -45,6 +45,8 @@ struct pmbrl_plan {
   DwBlock* dw_blocks_d;
   DwUnit* dw_units_d;   // 256 x 128 output tiles of the wide layers (pm_dw_wide_kernel); their blocks are not in dw_blocks_d
   int n_dw_units;
+  int dw_narrow[PM_MAXL]; // 1: first-layer type (delta stash 512 wide), 2: head type (input stash 512 wide): pm_dw_narrow_pre_kernel
+  unsigned dw_pre_mask;   // layers whose dW GEMM reads pre-split stashes (pm_dw_wide_pre_kernel; the wide sweeps write them)
   int dw_layer13;       // >= 0: this layer (at most 13 x 13 tiles) runs whole in one workgroup per row-step range (pm_dw_layer_kernel)
   int n_dw_blocks, dw_nsplit, dw_chunks_per_split, dw_n_chunks;
   // dW GEMM behind the adjoint sweep (pmbrl_rollout_bwd): the sweep as pipe_K launches over descending step

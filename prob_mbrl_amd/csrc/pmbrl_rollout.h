@@ -291,7 +291,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
   // PR = 2: set when an activation leaves fp16's range (the action-gradient rows are idle in the forward sweep)
   int* const p_ovf = reinterpret_cast<int*>(L.gad);
   if (SP && tid == 0) *p_ovf = (A.wflag && *A.wflag == A.wgen) ? 1 : 0;   // (1: a weight did not fit fp16, pm_pack_all)
-  if constexpr (IP == 2) pw_table_init(L.tbl, tid);
+  if constexpr (IP >= 2) pw_table_init(L.tbl, tid);
 
   // initial state (states[t0] is x0 for t0 == 0, the previous launch's output otherwise)
   {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     //  address arithmetic of the elementwise phases alone kept some sixty registers live through the layers, and what
     //  the layers then spilled came back through scratch loads behind vmcnt(0): a memory round trip each)
     int tid_s = tid;
-    if constexpr (IP == 2) asm volatile("" : "+v"(tid_s));
+    if constexpr (IP >= 2) asm volatile("" : "+v"(tid_s));
     const int tid = tid_s, lane = tid & 63;
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           // an INPUT out of fp16's range would become inf, inf x 0-weight NaN, and vanish in the ReLU: reported like an
           // activation out of range (the host re-runs in fp32)
           if (!(fabsf(v) <= 65504.f)) *p_ovf = 1;
-          pm_put_planes<R, true>(X, LDB, r, IP == 2 ? pw_sw(r, k) : k, v);
+          pm_put_planes<R, true>(X, LDB, r, IP >= 2 ? pw_sw(r, k) : k, v);
         }
         else X[r * LD + k] = v;
         if (k < K16) st[(size_t)k * A.Rw + r] = v;
@@ -354,15 +354,18 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], IP ? X : Y,
                                         A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane,
                                         p_ovf};
-      if constexpr (IP == 2) {
+      if constexpr (IP >= 2) {
         const PwFwd w{P.bias[l], mk, P.abits[l] + (size_t)t * B * nt, P.keep[l], X,
                       A.actT[l + 1] + blk * (size_t)nt * 16 * A.Rw, L.tbl, row0, nvalid, p_ovf,
-                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 5 : nullptr};
-        pw_hidden_fwd<true>(P.wf[l], pm_kb32(P.nt[l]), w, wid, lane);
+                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 5 : nullptr,
+                      (int)((A.stash_pre >> (l + 1)) & 1u)};      // (pre-split where the next layer's dW GEMM is pm_dw_wide_pre_kernel's)
+        // (IP = 3: every 512-wide stash pre-split -- ONE form of the stash stores per kernel instance: two forms in one
+        //  kernel, as two instances of the layer or as a branch around the stores, cost the forward sweep 0.5-1 ms)
+        pw_hidden_fwd<IP == 3 ? 2 : 1>(P.wf[l], pm_kb32(P.nt[l]), w, wid, lane);
       } else if constexpr (IP) gemm_layer_inplace_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, true>(P.wf[l], nt, pm_kb32(P.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wf[l], nt, P.nt[l], X, LD, wid, lane, e);
-      if constexpr (IP == 2) pw_lds_barrier();
+      if constexpr (IP >= 2) pw_lds_barrier();
       else __syncthreads();
       PM_MARK(2 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       // fp32 rows at column PM_IP_NOFF of the one buffer: clear of the 64 plane columns the next phase writes
       Y = X + PM_IP_NOFF;
       EpiPlain e{P.bias[P.nl - 1], Y, LD, lane};
-      if constexpr (IP == 2) pw_narrow<true>(P.wf[P.nl - 1], P.nt[P.nl], X, P.bias[P.nl - 1], Y, LD, wid, lane);
+      if constexpr (IP >= 2) pw_narrow<true>(P.wf[P.nl - 1], P.nt[P.nl], X, P.bias[P.nl - 1], Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, true>(P.wf[P.nl - 1], P.nt[P.nl], pm_kb32(P.nt[P.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
                       wid, lane, tid);
     PM_MARK(10);
     // ---- squash + dynamics input (models/densities.py:87-121, models/core.py:243,169-177)
-    if constexpr (IP == 2) {
+    if constexpr (IP >= 2) {
       // (the loop below walks (row, column) pairs: eight iterations at 64 x 64, each with its own dependent loads of
       //  the normalisation constants and, in the action columns, of the noise -- 29 k cycles of a step.  Here every
       //  action element is ONE thread with all its loads up front, and a thread of the copy part keeps its column)
@@ -470,14 +473,14 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
       const uint16_t* mk = F.mask[l] + ((A.flags & PMBRL_FLAG_DYN_MASKS_PER_STEP) ? (size_t)t * B * nt : 0);
       EpiHiddenFwdT<SP ? 2 : 0, SP, R> e{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], IP ? X : Y,
                                         nullptr, LD, A.Rw, row0, nvalid, nt, lane, p_ovf};
-      if constexpr (IP == 2) {
+      if constexpr (IP >= 2) {
         const PwFwd w{F.bias[l], mk, F.abits[l] + (size_t)t * B * nt, F.keep[l], X, nullptr, L.tbl, row0, nvalid, p_ovf,
-                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 15 : nullptr};
-        pw_hidden_fwd<false>(F.wf[l], pm_kb32(F.nt[l]), w, wid, lane);
+                      (A.prof && wg == 0 && l == 1) ? A.prof + (size_t)t * 32 + 15 : nullptr, 0};
+        pw_hidden_fwd<0>(F.wf[l], pm_kb32(F.nt[l]), w, wid, lane);
       } else if constexpr (IP) gemm_layer_inplace_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, true>(F.wf[l], nt, pm_kb32(F.nt[l]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wf[l], nt, F.nt[l], X, LD, wid, lane, e);
-      if constexpr (IP == 2) pw_lds_barrier();
+      if constexpr (IP >= 2) pw_lds_barrier();
       else __syncthreads();
       PM_MARK(12 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{F.bias[F.nl - 1], Y, LD, lane};
-      if constexpr (IP == 2) pw_narrow<true>(F.wf[F.nl - 1], F.nt[F.nl], X, F.bias[F.nl - 1], Y, LD, wid, lane);
+      if constexpr (IP >= 2) pw_narrow<true>(F.wf[F.nl - 1], F.nt[F.nl], X, F.bias[F.nl - 1], Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, true>(F.wf[F.nl - 1], F.nt[F.nl], pm_kb32(F.nt[F.nl - 1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(PM_NT, 1) void pm_rollout_fwd(const RolloutArgs A) 
           if (d == 0) A.gmm_k[row] = kc;
         }
       }
-    } else if (IP == 2 && PM_NT % D == 0) {
+    } else if (IP >= 2 && PM_NT % D == 0) {
       // (a thread keeps its state dimension: the constants once, the rows' noise requested together)
       const int d = tid % D, rstep = PM_NT / D;
       const float Sy = A.Sy[d], lSy = logf(Sy), myd = A.my[d];
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
   // truncated horizon (utils/rollout.py:154-157): only the steps the forward sweep completed
   const int T1 = A.nvalid ? min(A.t1, *A.nvalid) : A.t1;
 
-  if constexpr (IP == 2) pw_table_init(L.tbl, tid);
+  if constexpr (IP >= 2) pw_table_init(L.tbl, tid);
   // dL/dx_T1: zero, the carried value from the previous launch, or the terminal grad_states
   for (int i = tid; i < R * D; i += PM_NT) {
     const int r = i / D, d = i - r * D;
@@ -712,13 +715,13 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
 
   for (int t = T1 - 1; t >= A.t0; --t) {
     int tid_s = tid;
-    if constexpr (IP == 2) asm volatile("" : "+v"(tid_s));   // (see the forward sweep)
+    if constexpr (IP >= 2) asm volatile("" : "+v"(tid_s));   // (see the forward sweep)
     const int tid = tid_s, lane = tid & 63;
     const size_t blk = (size_t)t * A.nwg + wg;
     float* X = L.bufA;
     float* Y = L.bufB;
     PM_MARK(0);
-    if constexpr (IP == 2) {
+    if constexpr (IP >= 2) {
       // The general family's in-place sweeps take their rewards' Jacobians from pm_reward_all_kernel and never do the
       // moment matching in the kernel (mm_mode 0 / 2), no mixture head: the four phases below (row loads, copy, reward
       // adjoint, head-adjoint input: 40 k cycles of dependent loads, a barrier each) are ONE pass --
@@ -865,14 +868,14 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       const int nt = F.nt[l];
       EpiHiddenBwdT<SP ? 2 : 0, R> e{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], IP ? X : Y, nullptr, LD, A.Rw,
                                     row0, nvalid, nt, lane};
-      if constexpr (IP == 2) {
+      if constexpr (IP >= 2) {
         const PwBwd w{F.abits[l - 1] + (size_t)t * B * nt, F.keep[l - 1], X, nullptr, L.tbl, row0, nvalid,
-                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 8 : nullptr};
-        pw_hidden_bwd<false>(F.wb[l], pm_kb32(F.nt[l + 1]), w, wid, lane);
+                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 8 : nullptr, 0};
+        pw_hidden_bwd<0>(F.wb[l], pm_kb32(F.nt[l + 1]), w, wid, lane);
       } else if constexpr (IP) gemm_layer_inplace_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, false>(F.wb[l], nt, pm_kb32(F.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(F.wb[l], nt, F.nt[l + 1], X, LD, wid, lane, e);
-      if constexpr (IP == 2) pw_lds_barrier();
+      if constexpr (IP >= 2) pw_lds_barrier();
       else __syncthreads();
       PM_MARK(4 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      if constexpr (IP == 2) pw_narrow<false>(F.wb[0], F.nt[0], X, nullptr, Y, LD, wid, lane);
+      if constexpr (IP >= 2) pw_narrow<false>(F.wb[0], F.nt[0], X, nullptr, Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, false>(F.wb[0], F.nt[0], pm_kb32(F.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       gemm_narrow<RT>(F.wb[0], F.nt[0], F.nt[1], nullptr, X, Y, LD, L.part, wid, lane, tid);
     PM_MARK(12);
     // ---- phase B: split into state / action parts; policy head adjoint -> X
-    if constexpr (IP == 2) {
+    if constexpr (IP >= 2) {
       // (as above: the state part, the action part and the padding as separate loops with independent elements)
       const int K16 = P.nt[P.nl] * 16;
       const int KP = pm_kb32(P.nt[P.nl]) * 32;
@@ -994,15 +997,16 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
       const int nt = P.nt[l];
       EpiHiddenBwdT<SP ? 2 : 0, R> e{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], IP ? X : Y,
                                     A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, LD, A.Rw, row0, nvalid, nt, lane};
-      if constexpr (IP == 2) {
+      if constexpr (IP >= 2) {
         const PwBwd w{P.abits[l - 1] + (size_t)t * B * nt, P.keep[l - 1], X,
                       A.gT[l - 1] + blk * (size_t)nt * 16 * A.Rw, L.tbl, row0, nvalid,
-                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 18 : nullptr};
-        pw_hidden_bwd<true>(P.wb[l], pm_kb32(P.nt[l + 1]), w, wid, lane);
+                      (A.prof && wg == 0 && l == 2) ? A.prof + (size_t)t * 32 + 18 : nullptr,
+                      (int)((A.stash_pre >> (l - 1)) & 1u)};
+        pw_hidden_bwd<IP == 3 ? 2 : 1>(P.wb[l], pm_kb32(P.nt[l + 1]), w, wid, lane);
       } else if constexpr (IP) gemm_layer_inplace_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
       else if constexpr (SP) gemm_tiles_s<RT, false>(P.wb[l], nt, pm_kb32(P.nt[l + 1]), X, LDB, wid, lane, e);
       else gemm_tiles<RT>(P.wb[l], nt, P.nt[l + 1], X, LD, wid, lane, e);
-      if constexpr (IP == 2) pw_lds_barrier();
+      if constexpr (IP >= 2) pw_lds_barrier();
       else __syncthreads();
       PM_MARK(14 + l);
       if constexpr (!IP) { float* tmp = X; X = Y; Y = tmp; }
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(PM_NT, PR ? 1 : 2) void pm_rollout_bwd(const Rollou
     if constexpr (IP) {
       Y = X + PM_IP_NOFF;
       EpiPlain e{nullptr, Y, LD, lane};
-      if constexpr (IP == 2) pw_narrow<false>(P.wb[0], P.nt[0], X, nullptr, Y, LD, wid, lane);
+      if constexpr (IP >= 2) pw_narrow<false>(P.wb[0], P.nt[0], X, nullptr, Y, LD, wid, lane);
       else gemm_layer_inplace_s<RT, false>(P.wb[0], P.nt[0], pm_kb32(P.nt[1]), X, LDB, wid, lane, e);
       __syncthreads();
     } else if constexpr (SP)

@@ -277,6 +277,7 @@ struct PwFwd {
   int row0, nvalid;
   int* ovf;
   long long* prof;        // debug: four cycle stamps of this layer (workgroup 0, thread 0) or nullptr
+  int pre;                // the stash in the pre-split form (pw_stash_pre) instead of fp32 rows
 };
 
 // lane (g, c) -> the value lane (g, n) holds, n a constant: DPP row_share (a 16-lane row is one lane group g)
@@ -290,7 +291,15 @@ __device__ __forceinline__ float pw_row_share(float v) {
 // synchronises behind it.  Everything but the LDS writes happens IN FRONT of that barrier: a wave that leaves the K
 // loop early (of a SIMD's two waves one does) runs its epilogue while its partner still feeds the matrix core, and the
 // results wait for the barrier as packed pieces in the accumulators' registers.
-template <bool STASH>
+// STASH: 0 none; 1 fp32, feature-major [512][Rw] (what the fp32-stash kernels of pmbrl_dw.h read); 2 PRE-SPLIT for
+// pm_dw_wide_pre_kernel / pm_dw_narrow_pre_kernel: [piece][tile][row (64)][16 features] bf16 -- a lane's four features of a
+// row are one 8-byte store per piece (pw_stash_pre).  One form per kernel instance (pm_rollout_fwd / _bwd <4, 2, 2 | 3>).
+__device__ __forceinline__ void pw_stash_pre(const pw_rsrc& srd, int vo, int so, const pm_u32x2& hi, const pm_u32x2& lo) {
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(srd, 0, 0, 0)) b64_t;
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64_t, hi), srd, vo, so, PW_STASH_AUX);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64_t, lo), srd, vo, so + 65536, PW_STASH_AUX);
+}
+template <int STASH>
 __device__ __forceinline__ void pw_hidden_fwd(const float* __restrict__ wf, int n_kb, const PwFwd& e, int wid, int lane) {
   constexpr int R = 64;
   const int g = lane >> 4, c = lane & 15;
@@ -337,11 +346,18 @@ __device__ __forceinline__ void pw_hidden_fwd(const float* __restrict__ wf, int 
       hmax = max(max(hmax, max(u0, u1)), max(u2, u3));
       const unsigned nb = pw_nz(u0) | (pw_nz(u1) << 1) | (pw_nz(u2) << 2) | (pw_nz(u3) << 3);
       aw[rt][k >> 1] |= nb << (16 * (k & 1));
-      if constexpr (STASH) {
-        const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
+      if constexpr (STASH != 0) {
+        if constexpr (STASH == 2) {
+          // the dW GEMM's operands: two bf16 pieces of h -- what pm_dw_wide_kernel made of the fp32 value, bit for bit
+          pm_u32x2 pc[2];
+          pm_split4<2, false>(h, pc);
+          pw_stash_pre(srd, (c * 32 + g * 8), pw_uni((4 * wid + k) * 2048 + rt * 512), pc[0], pc[1]);
+        } else {
+          const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
+          for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
+        }
       }
       // two fp16 pieces: residuals h - hi in fp32 (v_fma_mix_f32 reads the fp16 half directly), then the same RNE pair
       // conversion as the other forms (the low piece of |h| < 0.125 is an fp16 subnormal: kept)
@@ -393,10 +409,11 @@ struct PwBwd {
   const float* tbl;
   int row0, nvalid;
   long long* prof;
+  int pre;                // the stash in the pre-split form (pw_stash_pre)
 };
 
 // hidden layer, adjoint, in place:  g_pre = active ? (W^T g) / keep : 0   (bf16 pieces; as the forward layer)
-template <bool STASH>
+template <int STASH>
 __device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int n_kb, const PwBwd& e, int wid, int lane) {
   constexpr int R = 64;
   const int g = lane >> 4, c = lane & 15;
@@ -420,14 +437,19 @@ __device__ __forceinline__ void pw_hidden_bwd(const float* __restrict__ wb, int 
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       const f32x4 h = acc[k][rt] * ik * m[k & 1][rt];
-      if constexpr (STASH) {
-        const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
-      }
       pm_u32x2 pc[2];
       pm_split4<2, false>(h, pc);
+      if constexpr (STASH != 0) {
+        // (pre-split stash: the pieces the next layer reads from LDS are the dW GEMM's operands)
+        if constexpr (STASH == 2) {
+          pw_stash_pre(srd, (c * 32 + g * 8), pw_uni((4 * wid + k) * 2048 + rt * 512), pc[0], pc[1]);
+        } else {
+          const int so = pw_uni(((4 * wid + k) * 16 * PW_RW + rt * 16) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[r]), srd, vo_st + r * PW_RW * 4, so, PW_STASH_AUX);
+        }
+      }
       acc[k][rt] = f32x4{__uint_as_float(pc[0][0]), __uint_as_float(pc[0][1]), __uint_as_float(pc[1][0]),
                          __uint_as_float(pc[1][1])};
     }

@@ -45,8 +45,9 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
                 general_split += 'fast' not in n and 'pm_dw' not in n
     assert len(names) >= 19 + 16 + 6 + 8, len(names)     # fp32 instantiations + the dW kernel + the split-precision ones
     assert total_loads > 500
-    # pm_rollout_fwd / bwd <1|2|4, 2, 0>, the in-place <4, 2, 1> and the in-place wide layers <4, 2, 2> (pmbrl_wide.h)
-    assert general_split == 10, general_split
+    # pm_rollout_fwd / bwd <1|2|4, 2, 0>, the in-place <4, 2, 1>, the in-place wide layers <4, 2, 2> (pmbrl_wide.h) and the
+    # same with pre-split stashes <4, 2, 3> (round 6: pmbrl_dw.h, pm_dw_wide_pre_kernel)
+    assert general_split == 12, general_split
     # register spills of the default-precision instances that run the cart-pole shapes: none without moment matching,
     # none with 25-row groups split over two 16-row workgroups (statistics exchange: the rows + flags form is no
     # longer compiled into them); the 32-row instance of the double cart-pole shape is bounded
@@ -69,9 +70,9 @@ def test_no_instruction_touches_in_flight_registers(tmp_path):
     for blk in txt.split('- .agpr_count:')[1:]:
         name = re.search(r'\.name:\s+(\S+)', blk).group(1)
         sp = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1))
-        if 'pm_rollout_bwdILi4ELi2ELi2E' in name:
+        if 'pm_rollout_bwdILi4ELi2ELi2E' in name or 'pm_rollout_bwdILi4ELi2ELi3E' in name:
             assert sp == 0, (name, sp)
-        if 'pm_rollout_fwdILi4ELi2ELi2E' in name:
+        if 'pm_rollout_fwdILi4ELi2ELi2E' in name or 'pm_rollout_fwdILi4ELi2ELi3E' in name:
             assert sp <= 32, (name, sp)
     shutil.rmtree(str(tmp_path), ignore_errors=True)
 
