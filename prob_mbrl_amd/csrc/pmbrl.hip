@@ -217,13 +217,27 @@ __global__ __launch_bounds__(256) void pm_weighted_sum_kernel(const float* __res
   __shared__ unsigned ticket;
   if (nvalid) n = min(n, (long long)max(0, *nvalid) * n_per_step);   // truncated horizon
   double s = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-    s += (double)a[i] * (double)w[i];
+  // (eight elements' loads in flight at a time, added in the order a one-by-one loop adds them: as that loop -- load, wait,
+  //  convert, add -- a thread's eight elements at C2 were eight memory round trips in a row, most of this launch)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 8 * stride) {
+    float av[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      // (beyond n: the last element's address, its value dropped below -- a load under a condition is waited for where
+      //  the branches join, one at a time again)
+      const long long j = min(i + u * stride, n - 1);
+      av[u] = a[j];
+      wv[u] = w[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += i + u * stride < n ? (double)av[u] * (double)wv[u] : 0.0;
+  }
   const double tot = pm_block_sum(s, sm);
   if (threadIdx.x == 0) {
-    g_red_part[0][blockIdx.x] = tot;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (a device-scope store, then the ticket: a release FENCE here is a write-back of this XCD's whole L2 -- the reward
+    //  launch's stash is still in it)
+    __hip_atomic_store(&g_red_part[0][blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ticket = __hip_atomic_fetch_add(&g_red_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -276,6 +290,28 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
                                                            float* __restrict__ norm_out,
                                                            const long long* __restrict__ step, int guarded,
                                                            double ln_b1, double ln_b2, double lr_d) {
+  // The first four elements of this thread and the norm's partial sums are requested before anything is decided: as
+  // "go? -> step counter -> partial sums (a loop of dependent loads) -> elements (a loop of four)" this launch was ten
+  // memory round trips in a row around a few hundred instructions.
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float gq[4], mq[4], vq[4], pq[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    // (beyond n: the last element's address, never used -- loads under a condition are waited for one by one)
+    const long long j = min(i0 + u * stride, n - 1);
+    gq[u] = g[j];
+    mq[u] = m[j];
+    vq[u] = v[j];
+    pq[u] = p[j];
+  }
+  const int lane = threadIdx.x & 63;
+  double part[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const double x = g_norm_part[min(lane + 64 * u, PM_NORM_MAXB - 1)];
+    part[u] = lane + 64 * u < n_part ? x : 0.0;
+  }
   if (guarded && !g_adam_go) return;   // the rollout failed: leave parameters and moments alone
   double step_size_d = lr_d / (double)bc1;
   if (step) {
@@ -288,12 +324,13 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
     bc2_sqrt = (float)sqrt(-expm1(st * ln_b2));
     step_size_d = lr_d / -expm1(st * ln_b1);      // (torch: lr / bias_correction1 in Python floats, rounded once)
   }
-  // the partial sums of squares, one (or two) per lane and a fixed butterfly: the same bits in every wave of every block
-  // (as a loop of n_part dependent loads and double additions in every thread: the front of this launch)
+  // the partial sums of squares, block b on lane b mod 64 in block order, and a fixed butterfly: the same bits in every wave
+  // of every block
   double t = 0.0;
   {
-    const int lane = threadIdx.x & 63;
-    for (int b = lane; b < n_part; b += 64) t += g_norm_part[b];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t += part[u];                         // (absent: + 0)
+    for (int b = lane + 256; b < n_part; b += 64) t += g_norm_part[b];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
   }
@@ -302,16 +339,31 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
   const float step_size = (float)step_size_d;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    const float mi = m[i] * b1 + omb1 * gi;
-    const float vi = v[i] * b2 + omb2 * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    g[i] = gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = p[i] - step_size * (mi / denom);
+  for (long long i = i0;;) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long j = i + u * stride;
+      if (j < n) {
+        const float gi = gq[u] * coef;
+        const float mi = mq[u] * b1 + omb1 * gi;
+        const float vi = vq[u] * b2 + omb2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        g[j] = gi;
+        m[j] = mi;
+        v[j] = vi;
+        p[j] = pq[u] - step_size * (mi / denom);
+      }
+    }
+    i += 4 * stride;
+    if (i >= n) break;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long j = min(i + u * stride, n - 1);
+      gq[u] = g[j];
+      mq[u] = m[j];
+      vq[u] = v[j];
+      pq[u] = p[j];
+    }
   }
 }
 
@@ -418,21 +470,63 @@ __host__ __device__ inline size_t pm_mm_kernel_doubles(int D) {
     default: { ELSE; }                 \
   }
 // Standardisation of a large group's noise rows, mean and 1 / std per column and step (what every part of a split group
-// needs of the WHOLE group): grid (H, groups), wave w takes the columns w, w + 4, ...; same formula and summation scheme
-// as the sweeps' own prologue (pmbrl_fast.h).
-__global__ __launch_bounds__(256) void pm_mm_ztable_kernel(RolloutArgs A, double* tab) {
-  const int t = blockIdx.x, gi = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int D = A.D;
+// needs of the WHOLE group); same formula and summation scheme as the sweeps' own prologue (pmbrl_fast.h): lane l adds the
+// rows l, l + 64, ... in that order, a butterfly joins the lanes.
+//   pack = 0: grid (H, groups), wave w takes the columns w, w + 4, ... (large groups: eight rows' loads in flight per lane --
+//             one at a time, a 2 500-row group was 39 memory round trips in a row, 14 us);
+//   pack = 1: groups of <= 64 rows and D <= 8: a WAVE per (step, group), four to a workgroup, the columns' loads issued
+//             together (4 000 workgroups of four waves for 25 rows each were bound by their dispatch: 7 us at C3).
+__global__ __launch_bounds__(256) void pm_mm_ztable_kernel(RolloutArgs A, double* tab, int pack) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int D = A.D, M = A.M;
+  const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
+  if (pack) {
+    const int item = blockIdx.x * 4 + wid;
+    if (item >= A.H * A.G) return;
+    const int t = item / A.G, gi = item - t * A.G;
+    const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
+    const int z0 = pm_zrow0(t, A.row_off + gi * M, A.flags);
+    double* out = tab + (size_t)item * 2 * D;
+    const float* zr = zb + (size_t)pm_zidx(z0, min(lane, M - 1), A.Bg) * D;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = zr[min(j, D - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < D) {
+        double s1 = 0.0, s2 = 0.0;
+        if (lane < M) {
+          const double zv = (double)v[j];
+          s1 += zv;
+          s2 += zv * zv;
+        }
+        const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
+        const double zm = sm * inv_m;
+        if (lane == 0) {
+          out[j] = zm;
+          out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
+        }
+      }
+    }
+    return;
+  }
+  const int t = blockIdx.x, gi = blockIdx.y;
   const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
-  const int z0 = pm_zrow0(t, A.row_off + gi * A.M, A.flags);
-  const double dM = (double)A.M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(A.M - 1);
+  const int z0 = pm_zrow0(t, A.row_off + gi * M, A.flags);
   double* out = tab + ((size_t)t * gridDim.y + gi) * 2 * D;
   for (int j = wid; j < D; j += 4) {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = lane; r < A.M; r += 64) {
-      const double zv = (double)zb[(size_t)pm_zidx(z0, r, A.Bg) * D + j];
-      s1 += zv;
-      s2 += zv * zv;
+    for (int r0 = lane; r0 < M; r0 += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = zb[(size_t)pm_zidx(z0, min(r0 + 64 * u, M - 1), A.Bg) * D + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 64 * u < M) {
+          const double zv = (double)v[u];
+          s1 += zv;
+          s2 += zv * zv;
+        }
     }
     const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
     const double zm = sm * inv_m;
@@ -1899,7 +1993,11 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
   } else if (p->mm_mode != 2) {
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
-    if (p->mm_fan || p->reg_mm) hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(p->cfg.H, p->G), dim3(256), 0, s, As, const_cast<double*>(As.mm_ztab));
+    if (p->mm_fan || p->reg_mm) {
+      const bool zpack = p->M <= 64 && p->cfg.D <= 8;
+      hipLaunchKernelGGL(pm_mm_ztable_kernel, zpack ? dim3((p->cfg.H * p->G + 3) / 4) : dim3(p->cfg.H, p->G), dim3(256), 0, s, As,
+                         const_cast<double*>(As.mm_ztab), zpack ? 1 : 0);
+    }
     // (the granules' tags: zeroed per launch for the latency-optimised family, whose tags count the steps from 1; the
     //  register-resident family's carry a launch generation instead -- once zeroed, never again: two 5 us fill kernels less;
     //  nor does that family touch the group-local barrier flags: two more)
@@ -1958,8 +2056,7 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
       if (int rc = mmx_exchange(p, s, X.buf, (size_t)X.nranks * n_items * pm_mmx_slot_doubles(1))) return rc;
       hipLaunchKernelGGL(pm_mmx_apply_kernel<1>, dim3(n_items), dim3(64 * nw), mmx_apply_lds(1, X, scr), s, A, X, 0);
     } else if (mm_r)
-      hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
-                         pm_mm_scratch_doubles(1) * sizeof(double), s, A);
+      hipLaunchKernelGGL(pm_mm_rewards_fwd_kernel, dim3(p->cfg.H * p->G), dim3(64), pm_mmr_lds_bytes(p->M, 2), s, A);
     if (p->loss_w) {
       // (folding this sum into the reward launch -- per-block partials, last block finishes -- was measured: the
       //  reward launch grew by what the separate reduction costs, 391 arrivals on one counter; not kept)
@@ -2034,8 +2131,7 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
     A.grad_rewards = grt;
   } else if (mm_r) {
     // adjoint of the reward moment matching for all (t, group) up front
-    hipLaunchKernelGGL(pm_mm_rewards_bwd_kernel, dim3(p->cfg.H * p->G), dim3(64),
-                       pm_mm_scratch_doubles(1) * sizeof(double), s, A, grt);
+    hipLaunchKernelGGL(pm_mm_rewards_bwd_kernel, dim3(p->cfg.H * p->G), dim3(64), pm_mmr_lds_bytes(p->M, 3), s, A, grt);
     A.grad_rewards = grt;
   }
   if (!p->fast) A.flags &= ~PMBRL_FLAG_MM_REWARDS;   // (general sweeps: the reward side is done, see ext_reward)

@@ -1197,7 +1197,7 @@ __device__ __forceinline__ void pm_adam_decide(const int* status, int expect, lo
 }
 
 // grad[i] = sum_s part[s][i] in fixed order.  A workgroup = 64 float4 columns x 8 slices of the
-// split range: every wave reads whole 1 KiB rows, a thread keeps 8 independent loads in flight.
+// split range: every wave reads whole 1 KiB rows, a thread keeps 16 independent loads in flight.
 // norm_on: also the partial sums of squares of ITS 256 elements and (block 0) the decision whether the guarded optimiser
 // step is taken -- what pm_gradnorm_kernel does in a launch of its own.
 __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ part, int nsplit, int n,
@@ -1218,15 +1218,23 @@ __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ pa
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c4 * 4 < n) {
     const float* p = part + (size_t)c4 * 4;
+    // (sixteen rows in flight per thread, the tail as one predicated batch of eight: at C2 a slice is 33 rows -- as
+    //  8 + 8 + 8 + 8 + 1 it was five memory round trips in a row, now three; the order of the additions is the rows')
     int k = k_lo;
-    for (; k + 8 <= k_hi; k += 8) {
+    for (; k + 16 <= k_hi; k += 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = ldg4(p + (size_t)(k + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; k < k_hi; k += 8) {
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ldg4(p + (size_t)(k + u) * stride);
+      for (int u = 0; u < 8; ++u) v[u] = ldg4(p + (size_t)min(k + u, k_hi - 1) * stride);   // (beyond: dropped below)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += k + u < k_hi ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (; k < k_hi; ++k) s += ldg4(p + (size_t)k * stride);
   }
   sm[sl][col] = s;
   __syncthreads();

@@ -940,6 +940,25 @@ struct EpiBwdL {
 // Jacobian row overwrites the state row in place and leaves the same way.
 __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A) {
   extern __shared__ float rw_rows[];
+  // The cache lines of the reward's constants a row-step will read -- the heads of its arrays: the scalar cache met each of
+  // them as a miss of its own, one behind the other, in the middle of the arithmetic; requested here they arrive while
+  // the states do.  The values are not used: the registers are held until the barrier below.
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned pf[16];
+  {
+    typedef __attribute__((address_space(4))) const unsigned* kup;
+    const kup rp = (kup)A.rew;
+    constexpr int PFO[16] = {0,
+                             (int)offsetof(RewardDev, C), (int)offsetof(RewardDev, C) + 64, (int)offsetof(RewardDev, tt),
+                             (int)offsetof(RewardDev, Q), (int)offsetof(RewardDev, Q) + 64, (int)offsetof(RewardDev, QQ),
+                             (int)offsetof(RewardDev, QQ) + 64, (int)offsetof(RewardDev, R), (int)offsetof(RewardDev, RR),
+                             (int)offsetof(RewardDev, phi_src), (int)offsetof(RewardDev, phi_mode),
+                             (int)offsetof(RewardDev, d_copy), (int)offsetof(RewardDev, d_sin),
+                             (int)offsetof(RewardDev, d_cos), (int)offsetof(RewardDev, w)};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) asm volatile("s_load_dword %0, %1, %2" : "=s"(pf[u]) : "s"(rp), "n"(PFO[u]));
+  }
+#endif
   const long long n = (long long)A.H * A.B;
   const long long i0 = (long long)blockIdx.x * blockDim.x;
   const long long i = i0 + threadIdx.x;
@@ -950,12 +969,35 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   const int nrow = (int)min((long long)blockDim.x, n - i0);
   {
     const float* src = (A.flags & PMBRL_FLAG_MM_STATES) ? A.xt + (size_t)i0 * D : A.states + ((size_t)i0 + A.B) * D;
-    for (int e = threadIdx.x; e < nrow * D; e += blockDim.x) {
-      const int r = e / D, d = e - r * D;
-      rw_rows[r * ld + d] = src[e];
+    // (eight loads in flight per thread: one at a time -- load, wait, write -- the D = 4 block was four memory round trips
+    //  in a row, a third of this launch at C2)
+    const int ne = nrow * D;
+    for (int e0 = threadIdx.x; e0 < ne; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + 256 * u, ne - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < ne) {
+          const int r = e / D, d = e - r * D;
+          rw_rows[r * ld + d] = v[u];
+        }
+      }
     }
   }
+  // (the row's first four actions: requested here, beside the states)
+  float a4[4];
+  {
+    const float* ac = A.actions + (size_t)min(i, n - 1) * U;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] = ac[min(u, U - 1)];
+  }
   __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) asm volatile("" ::"s"(pf[u]));
+#endif
   if (i < n) {
   const int t = (int)(i / A.B);
   // (the reward's constants through a constant-address-space pointer: wave-uniform indices make scalar loads of them; as a
@@ -981,25 +1023,48 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
     const float xv = xs[rw->phi_src[j]];
     const int md = rw->phi_mode[j];
     const float ph = md == 0 ? xv : (md == 1 ? sinf(xv) : cosf(xv));
+    // (the coefficients of all PMBRL_MAX_TIP rows are loaded, the rows beyond k dropped by a select: every index is inside
+    //  the array, and a load UNDER the condition is a scalar load, a wait and a branch of its own -- this kernel was a chain
+    //  of ~190 of those, most of its 13 us at C2)
+    float cj[PMBRL_MAX_TIP];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q)
-      if (q < k) delta[q] = fmaf(ph, rw->C[q * De + j], delta[q]);
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q) cj[q] = rw->C[q * De + j];
+#pragma unroll
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] = q < k ? fmaf(ph, cj[q], delta[q]) : delta[q];
   }
 #pragma unroll
-  for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] -= (q < k) ? rw->tt[q] : 0.f;
+  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+    const float ttq = rw->tt[q];
+    delta[q] -= (q < k) ? ttq : 0.f;
+  }
   float cost = 0.f;
 #pragma unroll
   for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
     float s = 0.f;
+    float qv[PMBRL_MAX_TIP];
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p)
-      if (p < k && q < k) s = fmaf(delta[p], rw->Q[p * k + q], s);
-    if (q < k) cost = fmaf(s, delta[q], cost);
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p) qv[p] = rw->Q[p * k + q];      // (p k + q <= 63 for any k <= 8)
+#pragma unroll
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
+    cost = q < k ? fmaf(s, delta[q], cost) : cost;
   }
-  for (int q = 0; q < U; ++q) {
-    float s = 0.f;
-    for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->R[p * U + q], s);
-    cost = fmaf(s, as[q], cost);
+  if (U <= 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = 0.f;
+      float rv4[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rv4[p] = rw->R[p * U + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s = (p < U && q < U) ? fmaf(a4[p], rv4[p], s) : s;
+      cost = q < U ? fmaf(s, a4[q], cost) : cost;
+    }
+  } else {
+    for (int q = 0; q < U; ++q) {
+      float s = 0.f;
+      for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->R[p * U + q], s);
+      cost = fmaf(s, as[q], cost);
+    }
   }
   cost *= rw->w;
   const float rv = rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
@@ -1011,16 +1076,20 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
 #pragma unroll
   for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
     float s = 0.f;
+    float qv[PMBRL_MAX_TIP];
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p)
-      if (p < k && q < k) s = fmaf(delta[p], rw->QQ[p * k + q], s);
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p) qv[p] = rw->QQ[p * k + q];
+#pragma unroll
+    for (int p = 0; p < PMBRL_MAX_TIP; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
     gdelta[q] = gc * s;
   }
   auto gphi = [&](int j) {
     float s = 0.f;
+    float cj[PMBRL_MAX_TIP];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q)
-      if (q < k) s = fmaf(gdelta[q], rw->C[q * De + j], s);
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q) cj[q] = rw->C[q * De + j];
+#pragma unroll
+    for (int q = 0; q < PMBRL_MAX_TIP; ++q) s = q < k ? fmaf(gdelta[q], cj[q], s) : s;
     return s;
   };
   for (int d = 0; d < D; ++d) {
@@ -1033,10 +1102,23 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
     }
     xs[d] = g;      // (x_d has been read: only dimension d's own sine / cosine terms use it)
   }
-  for (int q = 0; q < U; ++q) {
-    float s = 0.f;
-    for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->RR[p * U + q], s);
-    A.Ja[(size_t)i * U + q] = gc * s;
+  if (U <= 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = 0.f;
+      float rv4[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rv4[p] = rw->RR[p * U + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s = (p < U && q < U) ? fmaf(a4[p], rv4[p], s) : s;
+      if (q < U) A.Ja[(size_t)i * U + q] = gc * s;
+    }
+  } else {
+    for (int q = 0; q < U; ++q) {
+      float s = 0.f;
+      for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->RR[p * U + q], s);
+      A.Ja[(size_t)i * U + q] = gc * s;
+    }
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[i] = rv;
   else A.rewards[i] = rv;
@@ -1049,12 +1131,44 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
 }
 
 // moment matching of the rewards for all (t, group) at once (one wave each), and its adjoint
+// A LARGE group (mm_groups=None: one group of 2 500 rows) first brings its rows -- rewards, noise, in the adjoint the
+// upstream gradient -- into LDS, sixteen loads in flight per lane, and runs the same routine on them there: its sums walk
+// the rows one dependent load at a time, three to five passes of 39 memory round trips on one wave (26 / 34 us per launch
+// at 2 500 rows).  Same arithmetic in the same order: the results are the unstaged form's bit for bit.
+#define PM_MMR_STAGE_MIN 128           // rows from which a group is staged
+#define PM_MMR_STAGE_MAX 4096          // ... and up to which its three arrays fit (48 KB beside the scratch)
+__host__ __device__ inline size_t pm_mmr_lds_bytes(int M, int arrays) {
+  const size_t scr = pm_mm_scratch_doubles(1) * sizeof(double);
+  return (M >= PM_MMR_STAGE_MIN && M <= PM_MMR_STAGE_MAX) ? scr + (size_t)arrays * M * sizeof(float) : scr;
+}
+// rows src[idx(i)] for i < M into dst[i]
+template <class IDX>
+__device__ __forceinline__ void pm_mmr_stage(float* dst, const float* src, int M, int lane, IDX idx) {
+  for (int i0 = lane; i0 < M; i0 += 16 * 64) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = src[idx(min(i0 + 64 * u, M - 1))];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + 64 * u < M) dst[i0 + 64 * u] = v[u];
+  }
+}
 __global__ void pm_mm_rewards_fwd_kernel(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) double mmscr_r[];
   const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
   const int r0 = gi * A.M;
-  const bool ok = pm_mm_fwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-                            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0,
+  const float* s = A.rt + (size_t)t * A.B + r0;
+  const float* z = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
+  int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags), Bg = A.Bg;
+  if (A.M >= PM_MMR_STAGE_MIN && A.M <= PM_MMR_STAGE_MAX) {
+    float* ls = reinterpret_cast<float*>(mmscr_r + pm_mm_scratch_doubles(1));
+    float* lz = ls + A.M;
+    pm_mmr_stage(ls, s, A.M, lane, [](int i) { return i; });
+    pm_mmr_stage(lz, z, A.M, lane, [=](int i) { return (size_t)pm_zidx(zrow0, i, Bg); });
+    pm_wave_sync();
+    s = ls; z = lz; zrow0 = 0; Bg = 0;
+  }
+  const bool ok = pm_mm_fwd(s, 1, A.M, 1, z, 1, zrow0, Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0,
                             A.rewards + (size_t)t * A.B + r0, 1, mmscr_r, lane);
   if (!ok && lane == 0) atomicMin(A.status, t);
 }
@@ -1063,9 +1177,21 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
   const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
   const int r0 = gi * A.M;
   if (A.nvalid && t >= *A.nvalid) return;   // a step the forward sweep did not complete
-  pm_mm_bwd(A.rt + (size_t)t * A.B + r0, 1, A.M, 1, pm_zbase(A.zrr, 1, t, A.Bg, A.flags), 1,
-            pm_zrow0(t, A.row_off + r0, A.flags), A.Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0,
-            A.grad_rewards + (size_t)t * A.B + r0, 1,
+  const float* s = A.rt + (size_t)t * A.B + r0;
+  const float* z = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
+  const float* g = A.grad_rewards + (size_t)t * A.B + r0;
+  int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags), Bg = A.Bg;
+  if (A.M >= PM_MMR_STAGE_MIN && A.M <= PM_MMR_STAGE_MAX) {
+    float* ls = reinterpret_cast<float*>(mmscr_r + pm_mm_scratch_doubles(1));
+    float* lz = ls + A.M;
+    float* lg = lz + A.M;
+    pm_mmr_stage(ls, s, A.M, lane, [](int i) { return i; });
+    pm_mmr_stage(lz, z, A.M, lane, [=](int i) { return (size_t)pm_zidx(zrow0, i, Bg); });
+    pm_mmr_stage(lg, g, A.M, lane, [](int i) { return i; });
+    pm_wave_sync();
+    s = ls; z = lz; g = lg; zrow0 = 0; Bg = 0;
+  }
+  pm_mm_bwd(s, 1, A.M, 1, z, 1, zrow0, Bg, (A.flags & PMBRL_FLAG_INFER_NS) != 0, g, 1,
             gr_tilde + (size_t)t * A.B + r0, 1, mmscr_r, lane);
 }
 
