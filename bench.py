@@ -506,8 +506,8 @@ def self_launch(n):
 # what the weak curve should look like if the one exposed 163 KiB all-reduce per iteration costs what a
 # ring over xGMI is expected to cost (2 (N - 1) hops of 2-3 us) -- kept in the line so that the record can be checked
 # against it
-PREDICTED_WEAK = {2: dict(ms_per_step=0.50, value=10.0e6, efficiency=0.94), 4: dict(ms_per_step=0.51, value=19.5e6, efficiency=0.92),
-                  8: dict(ms_per_step=0.53, value=37.9e6, efficiency=0.89)}
+PREDICTED_WEAK = {2: dict(ms_per_step=0.476, value=10.5e6, efficiency=0.95), 4: dict(ms_per_step=0.486, value=20.6e6, efficiency=0.93),
+                  8: dict(ms_per_step=0.506, value=39.5e6, efficiency=0.89)}
 
 
 def other_configs(a, dev):

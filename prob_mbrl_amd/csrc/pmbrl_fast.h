@@ -938,6 +938,10 @@ struct EpiBwdL {
 // The 256 state rows of a block go through LDS (row stride D | 1): a thread walks ITS row, so straight from HBM
 // every load and every Jacobian store of a wave touched 64 cache lines (1.7 ms at D = 32, 1.6 M row-steps).  The
 // Jacobian row overwrites the state row in place and leaves the same way.
+// NU: compile-time bound on the action width (4: the common shapes, their path unchanged; 8 / 16: the quadratic forms of the
+// action cost unrolled to that width -- an instance of their own: compiled into the one kernel their 30 KB of code sat
+// between the halves of the narrow path and cost ITS launches 3 us of instruction fetch)
+template <int NU>
 __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A) {
   extern __shared__ float rw_rows[];
   // The cache lines of the reward's constants a row-step will read -- the heads of its arrays: the scalar cache met each of
@@ -993,6 +997,13 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
 #pragma unroll
     for (int u = 0; u < 4; ++u) a4[u] = ac[min(u, U - 1)];
   }
+  // (wider action vectors: the NU = 8 / 16 instances)
+  float av[NU];
+  if constexpr (NU > 4) {
+    const float* ac = A.actions + (size_t)min(i, n - 1) * U;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) av[u] = ac[min(u, U - 1)];
+  }
   __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -1009,7 +1020,6 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   const RewardDev* rw = A.rew;
 #endif
   float* xs = rw_rows + threadIdx.x * ld;
-  const float* as = A.actions + (size_t)i * U;
   // No per-thread array is indexed at run time (that would live in scratch): the feature map is
   // walked in gather form, x / a come from their (L1-resident) rows, only the k <= 8 tip
   // residuals sit in registers with static indices.
@@ -1048,7 +1058,39 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
     for (int p = 0; p < PMBRL_MAX_TIP; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
     cost = q < k ? fmaf(s, delta[q], cost) : cost;
   }
-  if (U <= 4) {
+  // U > 4: s[q] = sum_p a_p M[p][q], p ascending, for a compile-time bound NU >= U on both indices: the rows of M loaded
+  // whole (every index inside the 16 x 16 array), entries beyond U dropped by selects -- as run-time loops over U this was
+  // a vector load of a_p, a scalar load of M[p][q] and a wait per term: 2 x 64 of them in a row at U = 8, half of the
+  // launch's 0.5 ms at C5
+  auto quad = [&](auto nu, auto Mx, float* sq) {
+    constexpr int NW = decltype(nu)::value;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sq[q] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      float row[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) row[q] = Mx[p * U + q];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) sq[q] = (p < U && q < U) ? fmaf(av[p], row[q], sq[q]) : sq[q];
+    }
+  };
+  auto cost_part = [&](auto nu) {
+    constexpr int NW = decltype(nu)::value;
+    float sq[NW];
+    quad(nu, &rw->R[0], sq);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) cost = q < U ? fmaf(sq[q], av[q], cost) : cost;
+  };
+  auto ja_part = [&](auto nu, float gcv) {
+    constexpr int NW = decltype(nu)::value;
+    float sq[NW];
+    quad(nu, &rw->RR[0], sq);
+#pragma unroll
+    for (int q = 0; q < NW; ++q)
+      if (q < U) A.Ja[(size_t)i * U + q] = gcv * sq[q];
+  };
+  if constexpr (NU == 4) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float s = 0.f;
@@ -1060,11 +1102,7 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
       cost = q < U ? fmaf(s, a4[q], cost) : cost;
     }
   } else {
-    for (int q = 0; q < U; ++q) {
-      float s = 0.f;
-      for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->R[p * U + q], s);
-      cost = fmaf(s, as[q], cost);
-    }
+    cost_part(std::integral_constant<int, NU>{});
   }
   cost *= rw->w;
   const float rv = rw->kind == PMBRL_REWARD_EXP ? expf(-cost) : -cost;
@@ -1102,7 +1140,7 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
     }
     xs[d] = g;      // (x_d has been read: only dimension d's own sine / cosine terms use it)
   }
-  if (U <= 4) {
+  if constexpr (NU == 4) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float s = 0.f;
@@ -1114,11 +1152,7 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
       if (q < U) A.Ja[(size_t)i * U + q] = gc * s;
     }
   } else {
-    for (int q = 0; q < U; ++q) {
-      float s = 0.f;
-      for (int p = 0; p < U; ++p) s = fmaf(as[p], rw->RR[p * U + q], s);
-      A.Ja[(size_t)i * U + q] = gc * s;
-    }
+    ja_part(std::integral_constant<int, NU>{}, gc);
   }
   if (A.flags & PMBRL_FLAG_MM_REWARDS) A.rt[i] = rv;
   else A.rewards[i] = rv;
