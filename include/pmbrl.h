@@ -369,6 +369,10 @@ typedef struct pmbrl_adam {
   double lr, beta1, beta2, eps, max_norm;   /* max_norm <= 0: no clipping */
   float* norm_out_d;      /* optional: the gradient norm before clipping */
   int32_t expect_steps;   /* the step is taken if the rollout completed at least this many steps (0: H) */
+  float* loss_out_d;      /* optional (round 6): the loss sum_{t < valid steps, b} grad_rewards[t][b] * rewards[t][b] of THIS
+                           * call's arguments, written by the optimiser launch whether or not the step is taken -- the
+                           * launch pmbrl_plan_set_loss queues behind the forward call is then not needed (one launch
+                           * less per iteration); NULL: not wanted */
 } pmbrl_adam;
 int pmbrl_plan_set_loss(pmbrl_plan* plan, const float* loss_weights_d, float* loss_out_d);
 int pmbrl_rollout_bwd_adam(pmbrl_plan* plan, void* stream, void* workspace_d, const pmbrl_inputs* in,

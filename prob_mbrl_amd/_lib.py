@@ -105,7 +105,8 @@ class Adam(C.Structure):
     """pmbrl_adam (include/pmbrl.h): the optimiser state pmbrl_rollout_bwd_adam updates."""
     _fields_ = [('params_d', C.c_void_p), ('exp_avg_d', C.c_void_p), ('exp_avg_sq_d', C.c_void_p),
                 ('step_d', C.c_void_p), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
-                ('eps', C.c_double), ('max_norm', C.c_double), ('norm_out_d', C.c_void_p), ('expect_steps', C.c_int32)]
+                ('eps', C.c_double), ('max_norm', C.c_double), ('norm_out_d', C.c_void_p), ('expect_steps', C.c_int32),
+                ('loss_out_d', C.c_void_p)]
 
 
 _lib = None

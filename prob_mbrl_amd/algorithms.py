@@ -183,7 +183,8 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
     prec = dict(name=None)
     pending = None          # (i, event, pinned status, loss, S, A, R) of the iteration in flight
     pipe = dict(snap=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(2)],
-                ev=[torch.cuda.Event() for _ in range(2)], step_dev=None) if pipelined else None
+                ev=[torch.cuda.Event() for _ in range(2)], step_dev=None,
+                loss=[torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]) if pipelined else None
 
     # a rollout that failed after more than 5 steps is optimised on its truncated horizon
     # (utils/rollout.py:154-157); earlier failures skip the step (algorithms/mc_pilco.py:122-131)
@@ -221,7 +222,7 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 msg = 'Pred. Cumm. rewards: %f' if maximize else 'Pred. Cumm. costs: %f'
                 print((msg % float(torch.stack(rewards).sum(0).mean())) + ' [{0}]'.format(len(rewards)))
             if callable(on_iteration):
-                on_iteration(j, loss_j, states, actions, rewards, disc)
+                on_iteration(j, loss_j.clone(), states, actions, rewards, disc)     # (the buffer is reused two iterations on)
 
     for i in range(opt_iters):
         if pending is not None:
@@ -263,13 +264,15 @@ def mc_pilco(init_states, dynamics, policy, steps, opt=None, exp=None, opt_iters
                 pipe['snap'][k].copy_(eng.status[0:1], non_blocking=True)
                 pipe['ev'][k].record()
                 gw = _loss_weights(eng, gamma_full, sign, Bg, dev)
-                loss = eng.weighted_sum(R, gw)[0]
+                # (the loss: formed by the backward call's gradient reduction, written by its optimiser launch --
+                #  pmbrl_adam::loss_out_d; two buffers: the host reads iteration i's one iteration late)
+                loss = pipe['loss'][k][0]
                 grp = cache['group']
-                # adjoint sweep, dW GEMM, then reduction + global norm + clip + Adam as one launch, taken on the device
-                # only if the rollout completed (pmbrl_rollout_bwd_adam)
+                # adjoint sweep, dW GEMM, then reduction + global norm + clip + Adam, taken on the device only if the
+                # rollout completed (pmbrl_rollout_bwd_adam)
                 eng.backward(gw, adam=dict(params=bundle.pol_flat, exp_avg=cache['m'], exp_avg_sq=cache['v'],
                                            step=pipe['step_dev'], lr=grp['lr'], betas=grp['betas'], eps=grp['eps'],
-                                           max_norm=clip_grad, expect=min_steps))
+                                           max_norm=clip_grad, expect=min_steps, loss_out=pipe['loss'][k]))
                 pending = (i, pipe['ev'][k], pipe['snap'][k], loss, S, A, R)
                 queued = True
             else:

@@ -209,7 +209,8 @@ static inline pm_reward_kernel_t pm_reward_kernel_for(int U) {
 static inline int pm_norm_blocks(long long n) { return (int)std::max<long long>(1, std::min<long long>(PM_NORM_MAXB, (n + 255) / 256)); }
 static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d, float* exp_avg_d, float* exp_avg_sq_d,
                                   int64_t n, int64_t* step_d, double lr, double beta1, double beta2, double eps,
-                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done);
+                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done,
+                                  float* loss_out_d = nullptr, int n_loss_part = 0);
 #define PM_RED_MAXB 128
 __device__ double g_red_part[2][PM_RED_MAXB];
 __device__ unsigned g_red_count;
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
                                                            float bc1, float bc2_sqrt, float max_norm,
                                                            float* __restrict__ norm_out,
                                                            const long long* __restrict__ step, int guarded,
-                                                           double ln_b1, double ln_b2, double lr_d) {
+                                                           double ln_b1, double ln_b2, double lr_d,
+                                                           float* __restrict__ loss_out, int n_loss_part) {
   // The first four elements of this thread and the norm's partial sums are requested before anything is decided: as
   // "go? -> step counter -> partial sums (a loop of dependent loads) -> elements (a loop of four)" this launch was ten
   // memory round trips in a row around a few hundred instructions.
@@ -316,6 +318,15 @@ __global__ __launch_bounds__(256) void pm_clip_adam_kernel(float* __restrict__ p
   for (int u = 0; u < 4; ++u) {
     const double x = g_norm_part[min(lane + 64 * u, PM_NORM_MAXB - 1)];
     part[u] = lane + 64 * u < n_part ? x : 0.0;
+  }
+  // the fused iteration's loss: the sums pm_dw_reduce's workgroups left, added in workgroup order by one wave (taken or
+  // not, the step's loss is reported)
+  if (loss_out && blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {
+    double ls = 0.0;
+    for (int b = lane; b < n_loss_part; b += 64) ls += g_loss_part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o);
+    if (lane == 0) loss_out[0] = (float)ls;
   }
   if (guarded && !g_adam_go) return;   // the rollout failed: leave parameters and moments alone
   double step_size_d = lr_d / (double)bc1;
@@ -2308,6 +2319,9 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   // go / no-go decision on the way -- pm_gradnorm_kernel's launch is not needed (PMBRL_FUSE_NORM=0: the separate launch)
   const bool norm_fused = opt && !piped && (n + 255) / 256 <= PM_NORM_MAXB &&
                           !(getenv("PMBRL_FUSE_NORM") && atoi(getenv("PMBRL_FUSE_NORM")) == 0);
+  // ... and, asked for (pmbrl_adam::loss_out_d), the loss' partial sums: the optimiser launch adds them -- no loss launch
+  // behind the forward call (PMBRL_FUSE_LOSS=0: pm_weighted_sum_kernel, here)
+  const bool loss_fused = norm_fused && opt->loss_out_d && !(getenv("PMBRL_FUSE_LOSS") && atoi(getenv("PMBRL_FUSE_LOSS")) == 0);
   {
     ScopedTimer tm(p, PMBRL_TIMER_DW_REDUCE, s);
     if (piped)   // every partial row was written (pm_dw_range)
@@ -2317,7 +2331,16 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
       hipLaunchKernelGGL(pm_dw_reduce, dim3((n + 255) / 256), dim3(512), 0, s, W.part, p->dw_nsplit, n,
                          W.part_stride, grad_pol_flat_d, (const int*)status_d, W.chunks_per_step, W.chunks_per_split,
                          norm_fused ? 1 : 0, (const int*)status_d, opt ? (opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H) : 0,
-                         opt ? reinterpret_cast<long long*>(opt->step_d) : (long long*)nullptr);
+                         opt ? reinterpret_cast<long long*>(opt->step_d) : (long long*)nullptr,
+                         loss_fused ? rewards_d : (const float*)nullptr, grad_rewards_d, (long long)p->cfg.H * p->cfg.B,
+                         (long long)p->cfg.B);
+  }
+  // the loss asked for with the optimiser step, where the reduction does not form it on the way: a launch of its own
+  if (opt && opt->loss_out_d && !loss_fused) {
+    const long long nn = (long long)p->cfg.H * p->cfg.B;
+    const int nbl = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (nn + 2047) / 2048));
+    hipLaunchKernelGGL(pm_weighted_sum_kernel, dim3(nbl), dim3(256), 0, s, rewards_d, grad_rewards_d, nn, opt->loss_out_d,
+                       (const int*)status_d, (long long)p->cfg.B);
   }
   HIPCHK(hipGetLastError());
   // the optimiser step behind it, decided on the device (a form with the reduction, the norm and the update in ONE launch
@@ -2326,7 +2349,8 @@ static int rollout_bwd(pmbrl_plan* p, void* stream, void* workspace, const pmbrl
   if (opt)
     return clip_adam_guarded_impl(stream, opt->params_d, grad_pol_flat_d, opt->exp_avg_d, opt->exp_avg_sq_d, n, opt->step_d,
                                   opt->lr, opt->beta1, opt->beta2, opt->eps, opt->max_norm, opt->norm_out_d, status_d,
-                                  opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H, norm_fused);
+                                  opt->expect_steps > 0 ? opt->expect_steps : p->cfg.H, norm_fused,
+                                  loss_fused ? opt->loss_out_d : nullptr, loss_fused ? (n + 255) / 256 : 0);
   return 0;
 }
 
@@ -2948,7 +2972,8 @@ extern "C" int pmbrl_clip_adam(void* stream, float* params_d, float* grads_d, fl
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, need_norm ? np : 0, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0, 0.0, 0.0, lr);
+                     (float)bc1, (float)sqrt(bc2), (float)max_norm, norm_out_d, (const long long*)nullptr, 0, 0.0, 0.0, lr,
+                     (float*)nullptr, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2966,7 +2991,8 @@ extern "C" int pmbrl_clip_adam_guarded(void* stream, float* params_d, float* gra
 // gradient reduction formed them: pm_dw_reduce, norm_on)
 static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d, float* exp_avg_d, float* exp_avg_sq_d,
                                   int64_t n, int64_t* step_d, double lr, double beta1, double beta2, double eps,
-                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done) {
+                                  double max_norm, float* norm_out_d, const int32_t* status_d, int32_t expect, bool norm_done,
+                                  float* loss_out_d, int n_loss_part) {
   const int nb = (int)std::max<long long>(1, std::min<long long>(PM_RED_MAXB, (n + 1023) / 1024));
   const int np = pm_norm_blocks(n);
   if (!norm_done)
@@ -2975,7 +3001,8 @@ static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d,
   hipLaunchKernelGGL(pm_clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params_d,
                      grads_d, exp_avg_d, exp_avg_sq_d, (long long)n, np, (float)lr, (float)beta1,
                      (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.f, 1.f,
-                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1, log(beta1), log(beta2), lr);
+                     (float)max_norm, norm_out_d, reinterpret_cast<const long long*>(step_d), 1, log(beta1), log(beta2), lr,
+                     loss_out_d, n_loss_part);
   HIPCHK(hipGetLastError());
   return 0;
 }

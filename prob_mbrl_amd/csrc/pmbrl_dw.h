@@ -1176,6 +1176,7 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_layer_kernel(const DwArgs A
 // block: squares added in element order, then a fixed butterfly over the 64 lanes.
 #define PM_NORM_MAXB 8192      // blocks of 256 elements: gradients of up to 2 M parameters (beyond: pm_gradnorm_kernel strides)
 __device__ double g_norm_part[PM_NORM_MAXB];
+__device__ double g_loss_part[PM_NORM_MAXB];   // the loss' partial sums, one per workgroup of pm_dw_reduce (loss_r != nullptr)
 __device__ int g_adam_go;
 __device__ __forceinline__ double pm_sq4_wave(const f32x4& t, long long i0, long long n) {
   double s = 0.0;
@@ -1205,8 +1206,26 @@ __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ pa
                                                     const int* __restrict__ nvalid = nullptr, int chunks_per_step = 0,
                                                     int chunks_per_split = 1, int norm_on = 0,
                                                     const int* __restrict__ status = nullptr, int expect = 0,
-                                                    long long* __restrict__ step = nullptr) {
+                                                    long long* __restrict__ step = nullptr,
+                                                    const float* __restrict__ loss_r = nullptr,
+                                                    const float* __restrict__ loss_w = nullptr, long long loss_n = 0,
+                                                    long long loss_per_step = 0) {
   __shared__ f32x4 sm[8][64];
+  __shared__ double sl_[8];
+  // loss_r: the fused iteration's loss on the way -- this workgroup's slice of sum_i r_i w_i over the valid steps (requested
+  // here, added below: pm_clip_adam_kernel adds the workgroups' sums in workgroup order).  One launch less per iteration.
+  float lr4[4] = {0.f, 0.f, 0.f, 0.f}, lw4[4] = {0.f, 0.f, 0.f, 0.f};
+  long long l_n = 0;
+  const long long l_i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, l_st = (long long)gridDim.x * blockDim.x;
+  if (loss_r) {
+    l_n = nvalid ? min(loss_n, (long long)max(0, *nvalid) * loss_per_step) : loss_n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long j = min(l_i0 + u * l_st, loss_n - 1);
+      lr4[u] = loss_r[j];
+      lw4[u] = loss_w[j];
+    }
+  }
   if (nvalid) {   // truncated horizon: only the splits that own a chunk of a valid step wrote a partial
     const long long nc = (long long)max(0, *nvalid) * chunks_per_step;
     nsplit = (int)min((long long)nsplit, (nc + chunks_per_split - 1) / chunks_per_split);
@@ -1237,7 +1256,22 @@ __global__ __launch_bounds__(512) void pm_dw_reduce(const float* __restrict__ pa
     }
   }
   sm[sl][col] = s;
+  if (loss_r) {
+    double ls = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ls += l_i0 + u * l_st < l_n ? (double)lr4[u] * (double)lw4[u] : 0.0;
+    for (long long j = l_i0 + 4 * l_st; j < l_n; j += l_st) ls += (double)loss_r[j] * (double)loss_w[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o);
+    if (col == 0) sl_[sl] = ls;
+  }
   __syncthreads();
+  if (loss_r && threadIdx.x == 0) {
+    double t = sl_[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sl_[k];
+    g_loss_part[blockIdx.x] = t;
+  }
   if (sl == 0) {
     f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c4 * 4 < n) {

@@ -610,7 +610,9 @@ class Engine:
         # (truncated horizon, utils/rollout.py:154-157), decided on the device
         if adam is not None:
             # the optimiser step in the same call (pmbrl_rollout_bwd_adam): adam = dict(params, exp_avg, exp_avg_sq,
-            # step (device int64), lr, betas, eps, max_norm, [norm_out], [expect])
+            # step (device int64), lr, betas, eps, max_norm, [norm_out], [expect], [loss_out]); loss_out: a one-element
+            # float32 tensor that receives sum(grad_rewards * rewards) over the valid steps from this call's own
+            # launches (pmbrl_adam::loss_out_d) -- no set_loss / weighted_sum launch needed then
             for k in ('params', 'exp_avg', 'exp_avg_sq'):
                 t = adam[k]
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.n_pol_params
@@ -619,7 +621,11 @@ class Engine:
                           adam['step'].data_ptr(), float(adam['lr']), float(adam['betas'][0]), float(adam['betas'][1]),
                           float(adam['eps']), float(adam.get('max_norm') or 0.0),
                           adam['norm_out'].data_ptr() if adam.get('norm_out') is not None else None,
-                          int(adam.get('expect') or 0))
+                          int(adam.get('expect') or 0),
+                          adam['loss_out'].data_ptr() if adam.get('loss_out') is not None else None)
+            if adam.get('loss_out') is not None:
+                lo = adam['loss_out']
+                assert lo.is_cuda and lo.dtype == torch.float32 and lo.numel() >= 1
             _lib.check(self.lib.pmbrl_rollout_bwd_adam(self.plan, _stream(), self._ws_ptr,
                                                        C.byref(self._inputs), _ptr(S), _ptr(A), _ptr(R), _ptr(gr),
                                                        _ptr(gs), _ptr(ga), _ptr(self.grad_flat), _ptr(gx0),

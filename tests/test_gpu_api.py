@@ -845,6 +845,58 @@ def test_library_graph_entry_points_replay_an_iteration(name, groups, monkeypatc
         assert nodes >= 8
 
 
+@pytest.mark.parametrize('name', ['full200_nomm', 'full200_mmg', 'mmg_h40'])
+def test_backward_call_reports_the_loss_of_its_iteration(name, monkeypatch):
+    """pmbrl_adam::loss_out_d (round 6): the fused backward call forms sum(grad_rewards * rewards) over the valid steps
+    on the way of its gradient reduction and its optimiser launch writes it -- no loss launch behind the forward call.
+    Against pmbrl_weighted_sum of the same rollout (another summation order: rounding only), with the same parameters
+    afterwards as the form that queues the loss with the forward call (bit for bit: the loss feeds nothing); on a
+    truncated horizon (status word lowered by hand: the steps beyond it do not count); and with the reduction's fusion
+    switched off (PMBRL_FUSE_LOSS=0: a launch of its own inside the backward call)."""
+    d = dict(common.load(name))
+    H, B = int(d['H']), d['x0'].shape[0]
+
+    def run(how, cut=None):
+        eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+        gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+        params = args['pol_flat'].clone()
+        args['pol_flat'] = params
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+        loss = torch.full((1,), float('nan'), device=DEV)
+        adam = dict(params=params, exp_avg=m, exp_avg_sq=v, step=step_dev, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                    max_norm=1.0, expect=min(H, 6))
+        if how == 'queued':
+            loss = eng.set_loss(gw)
+        else:
+            adam['loss_out'] = loss
+        losses, refs = [], []
+        for _ in range(3):
+            _, _, R = eng.forward(**args)
+            if cut is not None:
+                eng.status[0:1].fill_(cut)
+            n_valid = eng.valid_steps()
+            refs.append(float((R[:n_valid, :, 0].double() * gw[:n_valid].double()).sum()))
+            eng.backward(gw, adam=adam)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return np.array(losses), np.array(refs), params.cpu().numpy().copy(), int(step_dev.item())
+
+    l_q, r_q, p_q, s_q = run('queued')
+    l_b, r_b, p_b, s_b = run('backward')
+    assert s_q == 3 and s_b == 3
+    assert np.allclose(l_b, r_b, rtol=2e-6) and np.allclose(l_q, l_b, rtol=1e-6), (l_q, l_b, r_b)
+    assert np.array_equal(p_q, p_b)
+    # truncated horizon: only the first 7 steps count (and the step is still taken: expect = 6)
+    if H > 8:
+        l_t, r_t, _, s_t = run('backward', cut=7)
+        assert s_t == 3 and np.allclose(l_t, r_t, rtol=2e-6), (l_t, r_t)
+        assert not np.allclose(l_t, l_b, rtol=1e-3)
+    monkeypatch.setenv('PMBRL_FUSE_LOSS', '0')
+    l_u, r_u, p_u, _ = run('backward')
+    assert np.allclose(l_u, r_u, rtol=2e-6) and np.array_equal(p_u, p_b)
+
+
 @pytest.mark.parametrize('mode', [1, 2])
 def test_repeated_calls_are_replayed_and_match_eager_calls(mode, monkeypatch):
     """pmbrl_plan_set_replay.  mode 1, the default: a per-step-launch form (one moment-matching group
