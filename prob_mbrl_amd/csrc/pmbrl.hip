@@ -485,72 +485,18 @@ __host__ __device__ inline size_t pm_mm_kernel_doubles(int D) {
     case 6: { CALL(6); break; }        \
     default: { ELSE; }                 \
   }
-// Standardisation of a large group's noise rows, mean and 1 / std per column and step (what every part of a split group
-// needs of the WHOLE group); same formula and summation scheme as the sweeps' own prologue (pmbrl_fast.h): lane l adds the
-// rows l, l + 64, ... in that order, a butterfly joins the lanes.
-//   pack = 0: grid (H, groups), wave w takes the columns w, w + 4, ... (large groups: eight rows' loads in flight per lane --
-//             one at a time, a 2 500-row group was 39 memory round trips in a row, 14 us);
-//   pack = 1: groups of <= 64 rows and D <= 8: a WAVE per (step, group), four to a workgroup, the columns' loads issued
-//             together (4 000 workgroups of four waves for 25 rows each were bound by their dispatch: 7 us at C3).
-__global__ __launch_bounds__(256) void pm_mm_ztable_kernel(RolloutArgs A, double* tab, int pack) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int D = A.D, M = A.M;
-  const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
-  if (pack) {
-    const int item = blockIdx.x * 4 + wid;
-    if (item >= A.H * A.G) return;
-    const int t = item / A.G, gi = item - t * A.G;
-    const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
-    const int z0 = pm_zrow0(t, A.row_off + gi * M, A.flags);
-    double* out = tab + (size_t)item * 2 * D;
-    const float* zr = zb + (size_t)pm_zidx(z0, min(lane, M - 1), A.Bg) * D;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = zr[min(j, D - 1)];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < D) {
-        double s1 = 0.0, s2 = 0.0;
-        if (lane < M) {
-          const double zv = (double)v[j];
-          s1 += zv;
-          s2 += zv * zv;
-        }
-        const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
-        const double zm = sm * inv_m;
-        if (lane == 0) {
-          out[j] = zm;
-          out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
-        }
-      }
-    }
-    return;
-  }
-  const int t = blockIdx.x, gi = blockIdx.y;
-  const float* zb = pm_zbase(A.zmm, D, t, A.Bg, A.flags);
-  const int z0 = pm_zrow0(t, A.row_off + gi * M, A.flags);
-  double* out = tab + ((size_t)t * gridDim.y + gi) * 2 * D;
-  for (int j = wid; j < D; j += 4) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int r0 = lane; r0 < M; r0 += 8 * 64) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = zb[(size_t)pm_zidx(z0, min(r0 + 64 * u, M - 1), A.Bg) * D + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (r0 + 64 * u < M) {
-          const double zv = (double)v[u];
-          s1 += zv;
-          s2 += zv * zv;
-        }
-    }
-    const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
-    const double zm = sm * inv_m;
-    if (lane == 0) {
-      out[j] = zm;
-      out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
-    }
-  }
+// the noise table of split groups in a launch of its own (pmbrl_mm.h: pm_ztab_block; the register-resident family's pack
+// launch forms it with extra workgroups instead)
+__global__ __launch_bounds__(256) void pm_mm_ztable_kernel(const ZtabArgs Z) { pm_ztab_block(Z, (int)blockIdx.x, (int)threadIdx.x); }
+static ZtabArgs pm_ztab_args(const pmbrl_plan* p, const RolloutArgs& A) {
+  ZtabArgs Z;
+  Z.zmm = A.zmm; Z.tab = const_cast<double*>(A.mm_ztab);
+  Z.pack = (p->M <= 64 && p->cfg.D <= 8) ? 1 : 0;
+  Z.H = p->cfg.H; Z.G = p->G; Z.M = p->M; Z.D = p->cfg.D; Z.Bg = A.Bg;
+  Z.per_step = (A.flags & PMBRL_FLAG_ZMM_PER_STEP) ? 1 : 0;
+  Z.row_off = A.row_off;
+  Z.n_blocks = pm_ztab_blocks(Z.H, Z.G, Z.pack);
+  return Z;
 }
 
 __global__ __launch_bounds__(PM_MM_NW * 64) void pm_mm_fwd_kernel(RolloutArgs A, int t) {
@@ -1966,6 +1912,7 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
   // the register-resident family serves this call (pmbrl_reg.h): only ITS weights are packed now -- the
   // latency-optimised family's are packed by the adjoint call if it turns out to need them (optional outputs)
   const bool reg_fwd = pm_reg_can_run(p, A, true);
+  bool ztab_done = false;
   {
     ScopedTimer tm(p, PMBRL_TIMER_PACK, s);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1984,7 +1931,16 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
       p->old_pack_stale = 1;
     }
     p->abits_packed = reg_fwd ? 1 : 0;
-    if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s, reg_fwd ? status_d : nullptr);
+    // (the noise table of split moment-matching groups rides in the same launch: extra workgroups, PMBRL_ZTAB_MERGE=0 for
+    //  the launch of its own)
+    ZtabArgs Zt;
+    Zt.n_blocks = 0;
+    if (p->reg && reg_fwd && (p->mm_fan || p->reg_mm) && p->mm_mode == 1 &&
+        !(getenv("PMBRL_ZTAB_MERGE") && atoi(getenv("PMBRL_ZTAB_MERGE")) == 0)) {
+      Zt = pm_ztab_args(p, A);
+      ztab_done = true;
+    }
+    if (p->reg) pm_reg_pack_launch(p, ws, in->pol_params_d, in->dyn_params_d, p->wflag_d, p->wgen, s, reg_fwd ? status_d : nullptr, &Zt);
   }
   A.wflag = p->prec == PMBRL_PREC_SPLIT_F16 ? p->wflag_d : nullptr;
   A.wgen = p->wgen;
@@ -2009,10 +1965,9 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
   } else if (p->mm_mode != 2) {
     RolloutArgs As = A;
     if (!p->fast) { As.ext_reward = 1; As.flags &= ~PMBRL_FLAG_MM_REWARDS; }   // general family: rewards after the sweep
-    if (p->mm_fan || p->reg_mm) {
-      const bool zpack = p->M <= 64 && p->cfg.D <= 8;
-      hipLaunchKernelGGL(pm_mm_ztable_kernel, zpack ? dim3((p->cfg.H * p->G + 3) / 4) : dim3(p->cfg.H, p->G), dim3(256), 0, s, As,
-                         const_cast<double*>(As.mm_ztab), zpack ? 1 : 0);
+    if ((p->mm_fan || p->reg_mm) && !ztab_done) {
+      const ZtabArgs Z = pm_ztab_args(p, As);
+      hipLaunchKernelGGL(pm_mm_ztable_kernel, dim3(Z.n_blocks), dim3(256), 0, s, Z);
     }
     // (the granules' tags: zeroed per launch for the latency-optimised family, whose tags count the steps from 1; the
     //  register-resident family's carry a launch generation instead -- once zeroed, never again: two 5 us fill kernels less;

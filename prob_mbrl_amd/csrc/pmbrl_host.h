@@ -183,8 +183,9 @@ int pm_reg_mm_width(const pmbrl_plan* p);
 size_t pm_reg_pack_bytes();
 int pm_reg_set_attr(const pmbrl_plan* p);
 bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd);
+struct ZtabArgs;   // (pmbrl_mm.h: the noise table of split moment-matching groups, formed by extra workgroups of the pack launch)
 void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
-                        hipStream_t s, int* status_reset);
+                        hipStream_t s, int* status_reset, const ZtabArgs* ztab);
 void pm_reg_unpack_abits(const pmbrl_plan* p, char* ws, hipStream_t s);
 void pm_reg_launch(const pmbrl_plan* p, char* ws, const RolloutArgs& A, const float* pol_params, const float* dyn_params,
                    hipStream_t s, bool fwd);

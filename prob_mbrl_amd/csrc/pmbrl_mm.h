@@ -74,6 +74,81 @@ __device__ __forceinline__ double pm_seg_sum(double v, int P) {
   return v;
 }
 
+// Standardisation of a split group's noise rows, mean and 1 / std per column and step (what every part of a split group
+// needs of the WHOLE group), tabulated per launch: [H][groups][2 D] doubles.  Same formula and summation scheme as the
+// sweeps' own prologue (pmbrl_fast.h): lane l adds the rows l, l + 64, ... in that order, a butterfly joins the lanes.
+// Workgroups of 256 threads; ONE definition for the launch of its own (pm_mm_ztable_kernel) and for the extra workgroups
+// of the register-resident family's pack launch (pm_reg_pack_kernel: one launch less per iteration).
+//   pack = 0: workgroup = (step, group), wave w takes the columns w, w + 4, ... (large groups: eight rows' loads in flight
+//             per lane -- one at a time, a 2 500-row group was 39 memory round trips in a row, 14 us);
+//   pack = 1: groups of <= 64 rows and D <= 8: a WAVE per (step, group), four to a workgroup, the columns' loads issued
+//             together.
+struct ZtabArgs {
+  const float* zmm;
+  double* tab;
+  int n_blocks;        // workgroups the table takes (0: no table)
+  int pack;
+  int H, G, M, D, Bg, per_step, row_off;
+};
+__host__ __device__ inline int pm_ztab_blocks(int H, int G, int pack) { return pack ? (H * G + 3) / 4 : H * G; }
+__device__ __forceinline__ void pm_ztab_block(const ZtabArgs& Z, int blk, int tid) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const int D = Z.D, M = Z.M;
+  const double dM = (double)M, inv_m = 1.0 / dM, inv_m1 = 1.0 / (double)(M - 1);
+  const int item = Z.pack ? blk * 4 + wid : blk;
+  if (item >= Z.H * Z.G) return;
+  const int t = item / Z.G, gi = item - t * Z.G;
+  const float* zb = Z.per_step ? Z.zmm + (size_t)t * Z.Bg * D : Z.zmm;
+  const int row = Z.row_off + gi * M;
+  const int z0 = Z.per_step ? row : t + row;
+  double* out = Z.tab + (size_t)item * 2 * D;
+  if (Z.pack) {
+    const float* zr = zb + (size_t)pm_zidx(z0, min(lane, M - 1), Z.Bg) * D;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = zr[min(j, D - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < D) {
+        double s1 = 0.0, s2 = 0.0;
+        if (lane < M) {
+          const double zv = (double)v[j];
+          s1 += zv;
+          s2 += zv * zv;
+        }
+        const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
+        const double zm = sm * inv_m;
+        if (lane == 0) {
+          out[j] = zm;
+          out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
+        }
+      }
+    }
+    return;
+  }
+  for (int j = wid; j < D; j += 4) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r0 = lane; r0 < M; r0 += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = zb[(size_t)pm_zidx(z0, min(r0 + 64 * u, M - 1), Z.Bg) * D + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + 64 * u < M) {
+          const double zv = (double)v[u];
+          s1 += zv;
+          s2 += zv * zv;
+        }
+    }
+    const double sm = pm_seg_sum(s1, 64), sq = pm_seg_sum(s2, 64);
+    const double zm = sm * inv_m;
+    if (lane == 0) {
+      out[j] = zm;
+      out[D + j] = pm_rsqrt((sq - dM * zm * zm) * inv_m1);
+    }
+  }
+}
+
 // In-place Cholesky factor of the covariance in q.Lm (lower triangle), 1 / diag(L) into q.invd.
 // Returns false (wave-uniform) on a non-positive pivot.
 __device__ __forceinline__ bool pm_mm_chol(int d, const MMScratch& q, int lane) {

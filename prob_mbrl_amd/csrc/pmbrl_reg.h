@@ -205,6 +205,8 @@ struct RegPackArgs {
   int* wflag;
   int gen;
   int* status;                  // the forward sweep's status word: reset here (first launch of an iteration)
+  int n_pack_blocks;            // workgroups of the pack proper; the ones behind them form the noise table (zt.n_blocks)
+  ZtabArgs zt;
 };
 
 __device__ __forceinline__ unsigned short pr_f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
@@ -219,11 +221,20 @@ __device__ __forceinline__ unsigned short pr_piece(float v, int p, bool f16) {
   return p == 0 ? (unsigned short)a : pr_bf16_bits(v - pm_bf_lo(a));
 }
 
+// ZT: the launch has extra workgroups that form the noise table of split moment-matching groups (pmbrl_mm.h) -- an instance
+// of its own, so that the shapes without moment matching launch the code they always did
+template <bool ZT>
 __global__ __launch_bounds__(256) void pm_reg_pack_kernel(const RegPackArgs P) {
+  if constexpr (ZT) {
+    if ((int)blockIdx.x >= P.n_pack_blocks) {
+      pm_ztab_block(P.zt, (int)blockIdx.x - P.n_pack_blocks, (int)threadIdx.x);
+      return;
+    }
+  }
   if (P.status && blockIdx.x == 0 && threadIdx.x == 0) *P.status = 0x7fffffff;
   const int n_frag_net = PR_NET_FLOATS / PR_FRAG;
   const int total = 4 * n_frag_net * 64;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += P.n_pack_blocks * blockDim.x) {
     const int lane = idx & 63, fr_all = idx >> 6;
     const int dn = fr_all / n_frag_net, fr = fr_all - dn * n_frag_net;
     const int dir = dn >> 1, net = dn & 1;

@@ -151,7 +151,7 @@ bool pm_reg_can_run(const pmbrl_plan* p, const RolloutArgs& A, bool fwd) {
 }
 
 void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, const float* dyn_params, int* wflag, int gen,
-                        hipStream_t s, int* status_reset) {
+                        hipStream_t s, int* status_reset, const ZtabArgs* ztab) {
   RegPackArgs P;
   memset(&P, 0, sizeof(P));
   P.par[0] = pol_params; P.par[1] = dyn_params;
@@ -166,7 +166,10 @@ void pm_reg_pack_launch(const pmbrl_plan* p, char* ws, const float* pol_params, 
   P.wflag = wflag; P.gen = gen;
   P.status = status_reset;
   const int total = 4 * (PR_NET_FLOATS / PR_FRAG) * 64;
-  hipLaunchKernelGGL(pm_reg_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P);
+  P.n_pack_blocks = (total + 255) / 256;
+  if (ztab) P.zt = *ztab;      // (memset above: n_blocks = 0 without one)
+  if (P.zt.n_blocks > 0) hipLaunchKernelGGL(pm_reg_pack_kernel<true>, dim3(P.n_pack_blocks + P.zt.n_blocks), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(pm_reg_pack_kernel<false>, dim3(P.n_pack_blocks), dim3(256), 0, s, P);
 }
 
 // the activity bits of the last forward sweep, from the family's words to the per-tile bytes the latency-optimised
