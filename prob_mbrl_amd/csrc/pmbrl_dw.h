@@ -1143,20 +1143,48 @@ __global__ __launch_bounds__(PM_DW_NT, 2) void pm_dw_layer_kernel(const DwArgs A
     if (more) stage(st ^ 1);
     __syncthreads();
   }
-  // lane holds dW[o = 16 (wid + 8 i) + 4 g + r][k = 16 j + c16]
+  // lane holds dW[o = 16 (wid + 8 i) + 4 g + r][k = 16 j + c16].  Through LDS and out in rows (round 6): written from the
+  // accumulators a store instruction covered four 64-byte pieces of four different rows -- 160 KB per workgroup in 2 560
+  // such pieces, all 252 workgroups at the end of the launch at once.  Two halves (tile rows 0..6, 7..12: 7 x 16 rows of
+  // 212 floats fit the stages' LDS), each copied out as whole rows, 16 bytes per lane where the row starts allow it.
+  {
+    constexpr int LDE = PM_DWL_F + 4;            // (row stride 212: the four lane groups' rows on different banks)
+    float* ep = reinterpret_cast<float*>(dww_lds);
+    float* wpart = part + A.w_off[l];
+    const bool vec4 = (K & 3) == 0 && (A.w_off[l] & 3) == 0;
+    __syncthreads();                             // (the last step's operands have been read)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    if (i == 0 || two) {
+    for (int half = 0; half < 2; ++half) {
+      const int tr0 = 7 * half;
 #pragma unroll
-      for (int j = 0; j < PM_DWL_NT; ++j) {
-        const int k = j * 16 + c16;
+      for (int i = 0; i < 2; ++i) {
+        const int tr = wid + 8 * i;
+        if ((i == 0 || two) && (half == 0 ? tr < 7 : tr >= 7)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = (wid + 8 * i) * 16 + 4 * g + r;
-          if (o < O && k < K) pm_dw_put(part + A.w_off[l] + (size_t)o * K + k, acc[i][j][r], R.add);
+          for (int j = 0; j < PM_DWL_NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[((tr - tr0) * 16 + 4 * g + r) * LDE + j * 16 + c16] = acc[i][j][r];
         }
       }
+      __syncthreads();
+      const int o0 = tr0 * 16, nro = min(half == 0 ? 7 * 16 : 6 * 16, max(0, O - o0));   // rows of this half that exist
+      if (vec4) {
+        const int K4 = K >> 2;
+        for (int e = tid; e < nro * K4; e += PM_DW_NT) {
+          const int ro = e / K4, kq = e - ro * K4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ep + ro * LDE + 4 * kq);
+          f32x4* q = reinterpret_cast<f32x4*>(wpart + (size_t)(o0 + ro) * K + 4 * kq);
+          *q = R.add ? *q + v : v;
+        }
+      } else {
+        for (int e = tid; e < nro * K; e += PM_DW_NT) {
+          const int ro = e / K, k = e - ro * K;
+          pm_dw_put(wpart + (size_t)(o0 + ro) * K + k, ep[ro * LDE + k], R.add);
+        }
+      }
+      __syncthreads();
     }
+  }
   // bias gradient: the eight threads that staged one delta feature hold its partial row sums
 #pragma unroll
   for (int j = 0; j < PM_DWL_Q; ++j) {

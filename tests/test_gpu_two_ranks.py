@@ -68,7 +68,7 @@ def test_bench_launches_itself_without_a_launcher():
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['timed_blocks'] == 2
     assert out['value_min'] <= out['value'] <= out['value_max']
     assert 'weak curve' in out['scaling_note'] or '`value` is the weak' in out['scaling_note']
-    assert out['predicted']['weak']['value'] == 10.6e6 and out['strong']['global_rows'] == 2500
+    assert out['predicted']['weak']['value'] == 10.7e6 and out['strong']['global_rows'] == 2500
 
 
 def test_bench_three_ranks_uneven_strong_split():
