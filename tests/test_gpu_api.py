@@ -892,6 +892,32 @@ def test_backward_call_reports_the_loss_of_its_iteration(name, monkeypatch):
         l_t, r_t, _, s_t = run('backward', cut=7)
         assert s_t == 3 and np.allclose(l_t, r_t, rtol=2e-6), (l_t, r_t)
         assert not np.allclose(l_t, l_b, rtol=1e-3)
+    # recorded and replayed (engine.Graph): the same loss and parameters as the eager calls, bit for bit
+    from prob_mbrl_amd import engine as E
+    eng, args, _ = common.engine_from_fixture(d, torch.device(DEV))
+    gw = torch.tensor(common.loss_weights(d, B), device=DEV)
+    params = args['pol_flat'].clone()
+    args['pol_flat'] = params
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    step_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+    loss = torch.full((1,), float('nan'), device=DEV)
+    out = (torch.empty((H + 1, B, eng.D), device=DEV), torch.empty((H, B, eng.U), device=DEV),
+           torch.empty((H, B, 1), device=DEV))
+    adam = dict(params=params, exp_avg=m, exp_avg_sq=v, step=step_dev, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                max_norm=1.0, expect=min(H, 6), loss_out=loss)
+
+    def step():
+        eng.forward(**args, out=out)
+        eng.backward(gw, adam=adam)
+
+    g = E.Graph(step, warmup=1)
+    l_g = [float(loss)]
+    for _ in range(2):
+        g.replay()
+        l_g.append(float(loss))
+    torch.cuda.synchronize()
+    assert int(step_dev.item()) == 3
+    assert np.array_equal(np.array(l_g), l_b) and np.array_equal(params.cpu().numpy(), p_b)
     monkeypatch.setenv('PMBRL_FUSE_LOSS', '0')
     l_u, r_u, p_u, _ = run('backward')
     assert np.allclose(l_u, r_u, rtol=2e-6) and np.array_equal(p_u, p_b)
