@@ -37,6 +37,11 @@ CONFIGS = {
     # enough that the K-split partial tiles live in the output buffer's free columns)
     'wide_small': dict(D=12, U=3, pol_hid=[272, 256], dyn_hid=[256, 288, 256], P=10, S=4, H=6,
                        mm=False, reward='generic', maxU=1.0),
+    # action vectors wider than 8 (the reward launch's 16-wide instance of the action cost) / between 5 and 8
+    'wide_actions': dict(D=10, U=12, pol_hid=[64, 64], dyn_hid=[64, 64], P=6, S=8, H=6,
+                         mm=False, reward='generic', maxU=1.0),
+    'mid_actions': dict(D=10, U=6, pol_hid=[64, 64], dyn_hid=[64, 64], P=6, S=8, H=6,
+                        mm=False, reward='generic', maxU=1.0),
 }
 
 

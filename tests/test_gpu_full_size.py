@@ -301,6 +301,24 @@ def test_wide_network_general_family_matches_oracle():
     assert common.rel(g, g64.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize('config', ['wide_actions', 'mid_actions'])
+def test_wide_action_vectors_match_oracle(config):
+    """U = 12 and U = 6: the reward launch's instances with the action cost's quadratic forms unrolled to 16 / 8
+    (pm_reward_all_kernel<16> / <8>; the cart-pole shapes run <4>, C5 <8>) -- trajectory, rewards, loss and gradient against
+    the fp64 oracle at the plain bars."""
+    from oracle import ref_torch as R
+    d = _problem(config)
+    eng, S, A, Rw, loss, g, _ = _run(d)
+    x0, pol, dyn, spec, meta, z_mm, z_rr, gamma = R.problem_from_npz(d, torch.float64)
+    l64, g64, (S64, A64, R64) = R.iteration(x0, pol, dyn, spec, meta['H'], gamma, True, meta['mm_states'],
+                                            meta['mm_rewards'], meta['mm_groups'], z_mm, z_rr)
+    assert common.rel(S, torch.stack(S64).detach().numpy()) < 2e-5
+    assert common.rel(A, torch.stack(A64).detach().numpy()) < 2e-5
+    assert common.rel(Rw, torch.stack(R64).detach().numpy().reshape(Rw.shape)) < 2e-5
+    assert abs(loss - float(l64)) <= 2e-5 * abs(float(l64))
+    assert common.rel(g, g64.numpy()) < 1e-4
+
+
 def test_c5_shape_matches_oracle():
     """BASELINE.json configs[4] (D=32, U=8, 3 x 512 both nets, H=100, generic reward) on the general
     kernel family, at a row count the fp64 oracle finishes in seconds (8 particles x 64 samples)."""

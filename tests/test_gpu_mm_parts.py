@@ -214,3 +214,27 @@ def test_statistics_exchange_matches_row_exchange(name, n):
     assert e1.info['mm_parts'] == e2.info['mm_parts'] == n and nv1 == nv2 == int(d['H'])
     assert common.rel(S2, S1) < 5e-6 and common.rel(g2, g1) < 2e-5 and common.rel(x2, x1) < 2e-5
     assert common.rel(g1, d['ref64_grad']) < TOL_GRAD and common.rel(g2, d['ref64_grad']) < TOL_GRAD
+
+
+@pytest.mark.parametrize('name', ['full200_mmg', 'dcp200_mmg50'])
+def test_noise_table_in_the_pack_launch_matches_its_own_launch(name, monkeypatch):
+    """Round 6: on the register-resident family the noise table of split groups (mean and 1 / std of every group's noise
+    rows per step) is formed by extra workgroups of the weight-pack launch (pm_reg_pack_kernel<true>, pm_ztab_block);
+    PMBRL_ZTAB_MERGE=0 forms it in the launch of its own it had.  One definition of the arithmetic: identical results."""
+    d = common.load(name)
+    dev = torch.device(DEV)
+
+    def once():
+        eng, args, _ = common.engine_from_fixture(d, dev)
+        S, A, Rw = eng.forward(**args)
+        gw = torch.tensor(common.loss_weights(d, d['x0'].shape[0]), device=dev)
+        g, _, _ = eng.backward(gw)
+        torch.cuda.synchronize()
+        assert eng.info['reg'] and eng.reg_calls() == (1, 1) and eng.info['mm_parts'] > 1, eng.info
+        return S.cpu().numpy(), Rw.cpu().numpy(), g.cpu().numpy().copy()
+
+    S1, R1, g1 = once()
+    monkeypatch.setenv('PMBRL_ZTAB_MERGE', '0')
+    S0, R0, g0 = once()
+    assert np.array_equal(S1, S0) and np.array_equal(R1, R0) and np.array_equal(g1, g0)
+
