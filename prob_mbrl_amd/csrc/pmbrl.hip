@@ -203,8 +203,10 @@ __global__ __launch_bounds__(256) void pm_draw_masks_kernel(const DrawArgs A) {
 // be stream-ordered (one optimisation loop per device), like the rest of a plan's work.
 // the reward launch's instance for an action width (pmbrl_fast.h)
 typedef void (*pm_reward_kernel_t)(const RolloutArgs);
-static inline pm_reward_kernel_t pm_reward_kernel_for(int U) {
-  return U <= 4 ? pm_reward_all_kernel<4> : (U <= 8 ? pm_reward_all_kernel<8> : pm_reward_all_kernel<16>);
+static inline pm_reward_kernel_t pm_reward_kernel_for(int U, int k) {
+  if (k <= 2) return U <= 4 ? pm_reward_all_kernel<4, 2> : (U <= 8 ? pm_reward_all_kernel<8, 2> : pm_reward_all_kernel<16, 2>);
+  return U <= 4 ? pm_reward_all_kernel<4, PMBRL_MAX_TIP>
+                : (U <= 8 ? pm_reward_all_kernel<8, PMBRL_MAX_TIP> : pm_reward_all_kernel<16, PMBRL_MAX_TIP>);
 }
 static inline int pm_norm_blocks(long long n) { return (int)std::max<long long>(1, std::min<long long>(PM_NORM_MAXB, (n + 255) / 256)); }
 static int clip_adam_guarded_impl(void* stream, float* params_d, float* grads_d, float* exp_avg_d, float* exp_avg_sq_d,
@@ -1126,8 +1128,9 @@ extern "C" int pmbrl_plan_create(const pmbrl_config* cfg, int device, pmbrl_plan
       for (int i = 0; i < c.D; ++i) { r.phi_src[i] = i; r.phi_mode[i] = 0; r.d_copy[i] = i; }
     }
     if ((size_t)256 * (c.D | 1) * sizeof(float) > 64 * 1024)      // (rows of a block staged in LDS)
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(pm_reward_kernel_for(c.U)),
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(pm_reward_kernel_for(c.U, r.k)),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (c.D | 1) * (int)sizeof(float)));
+    p->rew_k = r.k;
     HIPCHK(hipMalloc(&p->rew_d, sizeof(RewardDev)));
     HIPCHK(hipMemcpy(p->rew_d, &r, sizeof(RewardDev), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&p->wflag_d, sizeof(int)));
@@ -2015,7 +2018,7 @@ static int rollout_fwd_impl(pmbrl_plan* p, void* stream, void* workspace, const 
     ScopedTimer tm(p, PMBRL_TIMER_REWARD, s);
     A.t0 = 0; A.t1 = p->cfg.H;
     const long long n = (long long)p->cfg.H * p->cfg.B;
-    hipLaunchKernelGGL(pm_reward_kernel_for(p->cfg.U), dim3((unsigned)((n + 255) / 256)), dim3(256),
+    hipLaunchKernelGGL(pm_reward_kernel_for(p->cfg.U, p->rew_k), dim3((unsigned)((n + 255) / 256)), dim3(256),
                        (size_t)256 * (p->cfg.D | 1) * sizeof(float), s, A);
     if (mm_r && p->span) {
       // the rewards of all steps: one exchange for the whole horizon

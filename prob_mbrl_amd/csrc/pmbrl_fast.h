@@ -941,7 +941,11 @@ struct EpiBwdL {
 // NU: compile-time bound on the action width (4: the common shapes, their path unchanged; 8 / 16: the quadratic forms of the
 // action cost unrolled to that width -- an instance of their own: compiled into the one kernel their 30 KB of code sat
 // between the halves of the narrow path and cost ITS launches 3 us of instruction fetch)
-template <int NU>
+// KT: compile-time bound on the tip residuals k (2: the cart-pole class -- a tip position in the plane; KT: any):
+// the loops over them are unrolled to KT with the entries beyond k dropped by selects, so at k = 2 an instance unrolled to
+// eight carried sixteen times the loads and selects of its quadratic forms (4.6 of the launch's 10.5 us at C2 were this
+// arithmetic).
+template <int NU, int KT>
 __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A) {
   extern __shared__ float rw_rows[];
   // The cache lines of the reward's constants a row-step will read -- the heads of its arrays: the scalar cache met each of
@@ -1026,36 +1030,36 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   const int k = rw->k, De = rw->De;
   bool ok = true;
   for (int d = 0; d < D; ++d) ok = ok && isfinite(xs[d]);
-  float delta[PMBRL_MAX_TIP];
+  float delta[KT];
 #pragma unroll
-  for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] = 0.f;
+  for (int q = 0; q < KT; ++q) delta[q] = 0.f;
   for (int j = 0; j < De; ++j) {
     const float xv = xs[rw->phi_src[j]];
     const int md = rw->phi_mode[j];
     const float ph = md == 0 ? xv : (md == 1 ? sinf(xv) : cosf(xv));
-    // (the coefficients of all PMBRL_MAX_TIP rows are loaded, the rows beyond k dropped by a select: every index is inside
+    // (the coefficients of all KT rows are loaded, the rows beyond k dropped by a select: every index is inside
     //  the array, and a load UNDER the condition is a scalar load, a wait and a branch of its own -- this kernel was a chain
     //  of ~190 of those, most of its 13 us at C2)
-    float cj[PMBRL_MAX_TIP];
+    float cj[KT];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q) cj[q] = rw->C[q * De + j];
+    for (int q = 0; q < KT; ++q) cj[q] = rw->C[q * De + j];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q) delta[q] = q < k ? fmaf(ph, cj[q], delta[q]) : delta[q];
+    for (int q = 0; q < KT; ++q) delta[q] = q < k ? fmaf(ph, cj[q], delta[q]) : delta[q];
   }
 #pragma unroll
-  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+  for (int q = 0; q < KT; ++q) {
     const float ttq = rw->tt[q];
     delta[q] -= (q < k) ? ttq : 0.f;
   }
   float cost = 0.f;
 #pragma unroll
-  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+  for (int q = 0; q < KT; ++q) {
     float s = 0.f;
-    float qv[PMBRL_MAX_TIP];
+    float qv[KT];
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p) qv[p] = rw->Q[p * k + q];      // (p k + q <= 63 for any k <= 8)
+    for (int p = 0; p < KT; ++p) qv[p] = rw->Q[p * k + q];      // (p k + q < KT^2 <= 64 for any k <= KT)
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
+    for (int p = 0; p < KT; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
     cost = q < k ? fmaf(s, delta[q], cost) : cost;
   }
   // U > 4: s[q] = sum_p a_p M[p][q], p ascending, for a compile-time bound NU >= U on both indices: the rows of M loaded
@@ -1110,24 +1114,24 @@ __global__ __launch_bounds__(256) void pm_reward_all_kernel(const RolloutArgs A)
   if (!ok) atomicMin(A.status, t);
   // adjoint with unit upstream gradient
   const float gc = (rw->kind == PMBRL_REWARD_EXP ? -rv : -1.f) * rw->w;
-  float gdelta[PMBRL_MAX_TIP];
+  float gdelta[KT];
 #pragma unroll
-  for (int q = 0; q < PMBRL_MAX_TIP; ++q) {
+  for (int q = 0; q < KT; ++q) {
     float s = 0.f;
-    float qv[PMBRL_MAX_TIP];
+    float qv[KT];
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p) qv[p] = rw->QQ[p * k + q];
+    for (int p = 0; p < KT; ++p) qv[p] = rw->QQ[p * k + q];
 #pragma unroll
-    for (int p = 0; p < PMBRL_MAX_TIP; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
+    for (int p = 0; p < KT; ++p) s = (p < k && q < k) ? fmaf(delta[p], qv[p], s) : s;
     gdelta[q] = gc * s;
   }
   auto gphi = [&](int j) {
     float s = 0.f;
-    float cj[PMBRL_MAX_TIP];
+    float cj[KT];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q) cj[q] = rw->C[q * De + j];
+    for (int q = 0; q < KT; ++q) cj[q] = rw->C[q * De + j];
 #pragma unroll
-    for (int q = 0; q < PMBRL_MAX_TIP; ++q) s = q < k ? fmaf(gdelta[q], cj[q], s) : s;
+    for (int q = 0; q < KT; ++q) s = q < k ? fmaf(gdelta[q], cj[q], s) : s;
     return s;
   };
   for (int d = 0; d < D; ++d) {

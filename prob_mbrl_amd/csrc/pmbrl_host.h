@@ -38,6 +38,7 @@ struct pmbrl_plan {
   size_t lds_bytes;
   NetPlan pol, dyn;
   RewardDev* rew_d;
+  int rew_k = PMBRL_MAX_TIP;   // tip residuals of the reward (which instance of the reward launch: pm_reward_kernel_for)
   int* wflag_d;        // weight-range flag of the fp16 packer (see RolloutArgs::wflag)
   int wgen;            // generation of the last forward call
   int dw_split;        // dW GEMM on split bf16 operands (pm_dw_kernel_s)
