@@ -1191,6 +1191,43 @@ __device__ __forceinline__ void pm_mmr_stage(float* dst, const float* src, int M
       if (i0 + 64 * u < M) dst[i0 + 64 * u] = v[u];
   }
 }
+// A SMALL group (<= 64 rows: lane l holds row l) in registers: what pm_mm_fwd / pm_mm_bwd do at d = 1 -- the same sums
+// in the same order (a lane's one row, the butterfly over the wave), the same formulas -- without their passes over
+// memory: at 25 rows every pass of the general routine was a global load and a wait, three to five in a row per group
+// (6 + 8 us per iteration at C3 for 4 000 groups).  Returns false on a non-positive pivot (pm_mm_chol's rule).
+struct Mm1Fac { double mean, zmean, zistd, L, invd; };
+__device__ __forceinline__ bool pm_mm1_reg_factor(float sv, float zv, bool in, int M, Mm1Fac& f) {
+  const double inv_m = 1.0 / (double)M, inv_m1 = 1.0 / (double)(M - 1);
+  double m = 0.0, zm = 0.0, zz = 0.0;
+  if (in) {
+    m += (double)sv;
+    const double zd = (double)zv;
+    zm += zd;
+    zz += zd * zd;
+  }
+  m = pm_seg_sum(m, 64);
+  zm = pm_seg_sum(zm, 64);
+  zz = pm_seg_sum(zz, 64);
+  m *= inv_m;
+  zm *= inv_m;
+  f.mean = m;
+  f.zmean = zm;
+  f.zistd = pm_rsqrt((zz - (double)M * zm * zm) * inv_m1);
+  double acc = 0.0;
+  if (in) acc += ((double)sv - m) * ((double)sv - m);
+  acc = pm_seg_sum(acc, 64);
+  const double c0 = acc * inv_m1 + 1e-12;
+  double piv = c0;
+  bool ok = true;
+  if (!(piv > 6e-8 * c0)) {
+    ok = false;
+    piv = 1.0;
+  }
+  const double rs = pm_rsqrt(piv);
+  f.L = piv * rs;
+  f.invd = rs;
+  return ok;
+}
 __global__ void pm_mm_rewards_fwd_kernel(const RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) double mmscr_r[];
   const int t = blockIdx.x / A.G, gi = blockIdx.x - t * A.G, lane = threadIdx.x;
@@ -1198,6 +1235,20 @@ __global__ void pm_mm_rewards_fwd_kernel(const RolloutArgs A) {
   const float* s = A.rt + (size_t)t * A.B + r0;
   const float* z = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags), Bg = A.Bg;
+  if (A.M <= 64 && !(A.flags & PMBRL_FLAG_INFER_NS)) {
+    const bool in = lane < A.M;
+    const int li = min(lane, A.M - 1);
+    const float sv = s[li], zv = z[(size_t)pm_zidx(zrow0, li, Bg)];
+    Mm1Fac f;
+    const bool ok = pm_mm1_reg_factor(sv, zv, in, A.M, f);
+    if (in) {
+      double acc = f.mean;
+      acc += ((double)zv - f.zmean) * f.zistd * f.L;
+      A.rewards[(size_t)t * A.B + r0 + lane] = (float)acc;
+    }
+    if (!ok && lane == 0) atomicMin(A.status, t);
+    return;
+  }
   if (A.M >= PM_MMR_STAGE_MIN && A.M <= PM_MMR_STAGE_MAX) {
     float* ls = reinterpret_cast<float*>(mmscr_r + pm_mm_scratch_doubles(1));
     float* lz = ls + A.M;
@@ -1219,6 +1270,35 @@ __global__ void pm_mm_rewards_bwd_kernel(const RolloutArgs A, float* gr_tilde) {
   const float* z = pm_zbase(A.zrr, 1, t, A.Bg, A.flags);
   const float* g = A.grad_rewards + (size_t)t * A.B + r0;
   int zrow0 = pm_zrow0(t, A.row_off + r0, A.flags), Bg = A.Bg;
+  if (A.M <= 64 && !(A.flags & PMBRL_FLAG_INFER_NS)) {
+    const bool in = lane < A.M;
+    const int li = min(lane, A.M - 1);
+    const float sv = s[li], zv = z[(size_t)pm_zidx(zrow0, li, Bg)], gv = g[li];
+    Mm1Fac f;
+    (void)pm_mm1_reg_factor(sv, zv, in, A.M, f);
+    const double inv_m = 1.0 / (double)A.M, inv_m1 = 1.0 / (double)(A.M - 1);
+    // mbar = sum_r g ;  Lbar = g^T zhat
+    double a = 0.0, lb = 0.0;
+    if (in) {
+      a += (double)gv;
+      lb += (double)gv * (((double)zv - f.zmean) * f.zistd);
+    }
+    const double mbar = pm_seg_sum(a, 64);
+    lb = pm_seg_sum(lb, 64);
+    // pm_mm_bwd_solve at d = 1: Phi = L Lbar / 2, X = Phi / L, Sbar = X / L, P = 2 Sbar / (M - 1)
+    double phi = 0.0;
+    phi += f.L * lb;
+    phi *= 0.5;
+    const double xs = phi * f.invd;
+    const double sb = xs * f.invd;
+    const double P = (sb + sb) * inv_m1;
+    if (in) {
+      double acc = mbar * inv_m;
+      acc += ((double)sv - f.mean) * P;
+      gr_tilde[(size_t)t * A.B + r0 + lane] = (float)acc;
+    }
+    return;
+  }
   if (A.M >= PM_MMR_STAGE_MIN && A.M <= PM_MMR_STAGE_MAX) {
     float* ls = reinterpret_cast<float*>(mmscr_r + pm_mm_scratch_doubles(1));
     float* lz = ls + A.M;
